@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""Writes tests/golden/reference_tables.json.
+
+The tables below are DATA transcribed by hand from the reference's own test
+files (inputs and expected outputs only); nothing is executed or imported from
+/root/reference.  Each block names the file:line range it was read from.
+The Go reference cannot run here (no Go toolchain), so these literal tables are
+the only reference-held known answers for the path.
+"""
+import json
+import os
+
+T = {}
+
+# xcorr_test.go:20-38  TestNextPowOf2
+T["next_pow2"] = [
+    {"val": 1.0, "expected": 1}, {"val": 1.5, "expected": 2},
+    {"val": 4.5, "expected": 8}, {"val": 15.9, "expected": 16},
+    {"val": -5, "expected": 0}, {"val": 0, "expected": 0},
+]
+
+# xcorr_test.go:40-61  TestZNormalize: sum of squares == len-1 within 1e-8
+T["znormalize"] = {
+    "tol": 1e-8,
+    "cases": [
+        [0, 1, 2, 3, 4, 5],
+        [0, 1, 2, 3, 4, 5, 6],
+        [3, 4, 3, 4, 3],
+        [99, 100, 101, 102, 103],
+    ],
+}
+
+# xcorr_test.go:63-85  TestZeroPad (exact)
+T["zero_pad"] = [
+    {"x": [1, 2, 3, 4], "n": 6, "expected": [0, 0, 1, 2, 3, 4]},
+    {"x": [1, 2, 3, 4], "n": 3, "expected": [1, 2, 3, 4]},
+    {"x": [1, 2, 3, 4], "n": 4, "expected": [1, 2, 3, 4]},
+]
+
+# xcorr_test.go:86-202  TestXCorr: n = len(X) = 5, cc within 1e-8
+# (prettyClose, xcorr.go:26-36), exact index, sign of the max value.
+X = [0, 0, 2, 0, 0]
+T["xcorr"] = {
+    "tol": 1e-8,
+    "cases": [
+        {"x": X, "y": [0, 0, 5, 0, 0], "normalize": False, "cc": [10, 0, 0, 0, 0], "idx": 0, "sign": 1},
+        {"x": X, "y": [0, 0, 0, 0, 5], "normalize": False, "cc": [0, 0, 0, 10, 0], "idx": -2, "sign": 1},
+        {"x": X, "y": [5, 0, 0, 0, 0], "normalize": False, "cc": [0, 0, 10, 0, 0], "idx": 2, "sign": 1},
+        {"x": X, "y": [0, 0, -5, 0, 0], "normalize": False, "cc": [-10, 0, 0, 0, 0], "idx": 0, "sign": -1},
+        {"x": X, "y": [-5, 0, 0, 0, 0], "normalize": False, "cc": [0, 0, -10, 0, 0], "idx": 2, "sign": -1},
+        {"x": X, "y": [0, 0, 5, 0, 0], "normalize": True, "cc": [1.00, -0.25, -0.25, -0.25, -0.25], "idx": 0, "sign": 1},
+        {"x": X, "y": [0, 0, 0, 0, 5], "normalize": True, "cc": [-0.25, -0.25, -0.25, 1.00, -0.25], "idx": -2, "sign": 1},
+        {"x": X, "y": [5, 0, 0, 0, 0], "normalize": True, "cc": [-0.25, -0.25, 1.00, -0.25, -0.25], "idx": 2, "sign": 1},
+        {"x": X, "y": [0, 0, -5, 0, 0], "normalize": True, "cc": [-1.00, 0.25, 0.25, 0.25, 0.25], "idx": 0, "sign": -1},
+        {"x": X, "y": [-5, 0, 0, 0, 0], "normalize": True, "cc": [0.25, 0.25, -1.00, 0.25, 0.25], "idx": 2, "sign": -1},
+        {"x": [0, 0, 2, 2, 0], "y": [3, 3, 3, 3, 3], "normalize": True, "cc": None, "idx": 0, "sign": 0},
+    ],
+}
+
+# xcorr_test.go:204-286  TestXCorrWithX: reference spectrum built exactly as
+# NewBatch does (xcorr_test.go:259-266), n = 5.
+T["xcorr_with_x"] = {
+    "tol": 1e-8,
+    "cases": [
+        {"x": X, "y": [0, 0, 5, 0, 0], "cc": [1.00, -0.25, -0.25, -0.25, -0.25], "idx": 0, "sign": 1},
+        {"x": X, "y": [0, 0, 0, 0, 5], "cc": [-0.25, -0.25, -0.25, 1.00, -0.25], "idx": -2, "sign": 1},
+        {"x": X, "y": [5, 0, 0, 0, 0], "cc": [-0.25, -0.25, 1.00, -0.25, -0.25], "idx": 2, "sign": 1},
+        {"x": X, "y": [0, 0, -5, 0, 0], "cc": [-1.00, 0.25, 0.25, 0.25, 0.25], "idx": 0, "sign": -1},
+        {"x": X, "y": [-5, 0, 0, 0, 0], "cc": [0.25, 0.25, -1.00, 0.25, 0.25], "idx": 2, "sign": -1},
+        {"x": [0, 0, 2, 2, 0], "y": [3, 3, 3, 3, 3], "cc": None, "idx": 0, "sign": 0},
+    ],
+}
+
+# muse_batch_test.go:9-44  TestBatchRunSimple.  NewResults(10, 20, 0, ANY),
+# Run(["graph"]); compareScores (muse_test.go:11-39): order, exact lag,
+# score within 1e-3, labels.
+REF12 = [0, 0, 0, 0, 1, 2, 3, 3, 2, 1, 0, 0]
+T["batch_run_simple"] = {
+    "ref": REF12,
+    "results": {"max_lag": 10, "top_n": 20, "threshold": 0, "sign_filter": 0},
+    "group_by": ["graph"],
+    "score_tol": 1e-3,
+    "comp": [
+        {"y": [0, 0, 0, 0, 2, 4, 6, 6, 4, 2, 0, 0], "labels": {"graph": "perfectMatch"}},
+        {"y": [0, 0, 0, 0, 2, 4, 6, 4, 2, 0, 0, 0], "labels": {"graph": "slightlyLower"}},
+        {"y": [0, 0, 0, 2, 4, 2, 0, 0, 0, 0, 0, 0], "labels": {"graph": "evenLower"}},
+        {"y": [0, 0, 0, 0, 0, 0, 0, 0, 2, 3, 2, 0], "labels": {"graph": "evenLowerShiftedAhead"}},
+        {"y": [3] * 12, "labels": {"graph": "zeros"}},
+    ],
+    "expected": [
+        {"labels": {"graph": "perfectMatch"}, "lag": 0, "score": 1.000},
+        {"labels": {"graph": "slightlyLower"}, "lag": 0, "score": 0.929},
+        {"labels": {"graph": "evenLowerShiftedAhead"}, "lag": -3, "score": 0.754},
+        {"labels": {"graph": "evenLower"}, "lag": 2, "score": 0.733},
+        {"labels": {"graph": "zeros"}, "lag": 0, "score": 0},
+    ],
+}
+
+# muse_batch_test.go:46-82  TestBatchRunMultiDimensional (N = 8 = n: circular)
+T["batch_run_multidim"] = {
+    "ref": [0.0, 0.0, 0.0, 0.0, 0.1, 0.2, 0.3, 0.4],
+    "results": {"max_lag": 10, "top_n": 20, "threshold": 0, "sign_filter": 0},
+    "group_by": ["graph"],
+    "score_tol": 1e-3,
+    "comp": [
+        {"y": [0.0, 0.0, 0.0, 0.0, 0.1, 0.2, 0.3, 0.4], "labels": {"graph": "graph1", "host": "host1"}},
+        {"y": [0.2, 0.1, 0.2, 0.1, 0.2, 0.1, 0.2, 0.1], "labels": {"graph": "graph1", "host": "host2"}},
+        {"y": [0.0, 0.0, 0.0, 0.0, 0.2, 0.4, 0.4, 0.8], "labels": {"graph": "graph2", "host": "host1"}},
+        {"y": [0.2, 0.1, 0.2, 0.1, 0.2, 0.1, 0.22, 0.1], "labels": {"graph": "graph3", "host": "host1"}},
+        {"y": [0.0, 0.0, 0.0, 0.0, -0.2, -0.4, 0.0, -0.8], "labels": {"graph": "graph4", "host": "host1"}},
+        {"y": [0.0, 0.0, 0.0, -0.2, -0.4, -0.6, 1.0, 0.0], "labels": {"graph": "graph5", "host": "host1"}},
+    ],
+    "expected": [
+        {"labels": {"graph": "graph1", "host": "host1"}, "lag": 0, "score": 1.000},
+        {"labels": {"graph": "graph2", "host": "host1"}, "lag": 0, "score": 0.976},
+        {"labels": {"graph": "graph4", "host": "host1"}, "lag": 0, "score": 0.759},
+        {"labels": {"graph": "graph5", "host": "host1"}, "lag": 2, "score": 0.719},
+        {"labels": {"graph": "graph3", "host": "host1"}, "lag": 1, "score": 0.248},
+    ],
+}
+
+# muse_batch_test.go:83-102  TestBatchRunWithLargerGroup: NewBatch must error
+T["batch_run_larger_group"] = {
+    "ref": [0, 1, 2, 3, 3, 2, 1, 0],
+    "comp": [{"y": [0] * 12 + [2, 4, 6, 6, 4, 2, 0, 0], "labels": {"graph": "longer"}}],
+    "expect_error": True,
+}
+
+# muse_test.go:41-73  TestRunSimple (Muse: signed scores, one Run per series)
+MUSE_COMP = [
+    {"y": [0, 0, 0, 0, 2, 4, 6, 6, 4, 2, 0, 0], "labels": {"graph": "perfectMatch"}},
+    {"y": [0, 0, 0, 0, 2, 4, 6, 4, 2, 0, 0, 0], "labels": {"graph": "slightlyLower"}},
+    {"y": [0, 0, 0, 2, 4, 2, 0, 0, 0, 0, 0, 0], "labels": {"graph": "evenLower"}},
+    {"y": [0, 0, 0, 0, 0, 0, 0, 0, -2, -3, -2, 0], "labels": {"graph": "evenLowerShiftedAhead"}},
+    {"y": [3] * 12, "labels": {"graph": "zeros"}},
+]
+T["muse_run_simple"] = {
+    "ref": REF12,
+    "results": {"max_lag": 10, "top_n": 20, "threshold": 0, "sign_filter": 0},
+    "score_tol": 1e-3,
+    "comp": MUSE_COMP,
+    "expected": [
+        {"labels": {"graph": "perfectMatch"}, "lag": 0, "score": 1.000},
+        {"labels": {"graph": "slightlyLower"}, "lag": 0, "score": 0.929},
+        {"labels": {"graph": "evenLowerShiftedAhead"}, "lag": -3, "score": -0.754},
+        {"labels": {"graph": "evenLower"}, "lag": 2, "score": 0.733},
+        {"labels": {"graph": "zeros"}, "lag": 0, "score": 0},
+    ],
+}
+
+# muse_test.go:75-104  TestRunSimpleSignFilter, FIRST pass only (POS filter).
+# The second pass (muse_test.go:106-121, lag -2) is excluded on purpose: in
+# exact arithmetic cc[13] == cc[14] == -65/6, the reference's answer there is
+# decided by FFTPACK rounding noise on inputs its first pass mutated in place
+#  and no independent implementation can match it.
+T["muse_run_sign_filter_pass1"] = {
+    "ref": REF12,
+    "results": {"max_lag": 10, "top_n": 20, "threshold": 0, "sign_filter": 1},
+    "score_tol": 1e-3,
+    "comp": MUSE_COMP,
+    "expected": [
+        {"labels": {"graph": "perfectMatch"}, "lag": 0, "score": 1.000},
+        {"labels": {"graph": "slightlyLower"}, "lag": 0, "score": 0.929},
+        {"labels": {"graph": "evenLower"}, "lag": 2, "score": 0.733},
+    ],
+}
+# same test, NEG filter on FRESH inputs: the score/label are pinned, the lag
+# is the documented exact tie {-3, -2}.
+T["muse_run_sign_filter_neg_fresh"] = {
+    "ref": REF12,
+    "results": {"max_lag": 10, "top_n": 20, "threshold": 0, "sign_filter": -1},
+    "score_tol": 1e-3,
+    "comp": MUSE_COMP,
+    "expected": [
+        {"labels": {"graph": "evenLowerShiftedAhead"}, "lag_in": [-3, -2], "score": -0.754},
+    ],
+}
+
+# muse_test.go:122-142  TestRunNoInput
+T["muse_run_no_input"] = {
+    "ref": REF12,
+    "results": {"max_lag": 10, "top_n": 20, "threshold": 0, "sign_filter": 0},
+    "comp": [],
+    "expected": [],
+}
+
+# example_test.go:82-93 -- qualitative only (inputs come from Go's unseeded
+# math/rand through the un-vendored siggen package; not reproducible here).
+T["example_qualitative"] = {
+    "N": 480, "n": 512, "max_lag": 15, "top_n": 4, "threshold": 0.0,
+    "unique": [
+        {"id": "graph:CallTime99Pct,host:host1", "lag": 0, "score": 1.000},
+        {"id": "graph:ErrorRate,host:host1", "lag": 0, "score": 0.991},
+        {"id": "graph:CallTime99Pct,host:host2", "lag": -3, "score": 0.822},
+        {"id": "graph:ErrorRate,host:host3", "lag": 0, "score": 0.000},
+    ],
+    "by_graph_rows": 2,
+    "by_host_rows": 3,
+}
+
+if __name__ == "__main__":
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_tables.json")
+    with open(out, "w") as f:
+        json.dump(T, f, indent=1)
+    print("wrote", out)
