@@ -1,0 +1,155 @@
+#!/usr/bin/env python3
+"""bench.py -- go-muse XCorr/Batch.Run hot path on MI355X.
+
+One "step" = one Batch.Run over the resident Group: fused z-norm + FFT xcorr +
+argmax kernel over every series, group max, filter, top-N, (N > 1: RCCL gather
+of per-shard top-N records + merge).  Workload (BASELINE.json configs[2]):
+1 reference x 1 000 000 series per GPU, N = 4096 float64, synthetic rect+noise
+generated on the device and resident in HBM before the timed region.
+
+Prints ONE JSON line (rank 0).  `roofline.achieved` is algorithmic bytes
+(8*N + 16 per series) / the fused kernel's average launch duration,
+measured with HIP events on the stream the kernel runs on.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def cpu_baseline(dg, ref, N):
+    """CPU port (oracle/: C restatement of the reference algorithm) timed on
+    this box's host cores on a bounded sample of the same rows."""
+    import numpy as np
+    from oracle import oracle_py
+    oracle_py.build()
+    cores = os.cpu_count() or 1
+    threads = max(1, min(cores, 64))
+    probe = dg.read(0, min(512, dg.M))
+    t0 = time.perf_counter()
+    oracle_py.batch_scores(ref, probe, nthreads=threads, want_gap=False)
+    dt = max(time.perf_counter() - t0, 1e-6)
+    rate = len(probe) / dt
+    S = int(min(dg.M, max(len(probe), min(200_000, rate * 12.0))))   # ~12 s of work
+    S -= S % 2
+    rows = dg.read(0, S)
+    t0 = time.perf_counter()
+    oracle_py.batch_scores(ref, rows, nthreads=threads, want_gap=False)
+    dt = time.perf_counter() - t0
+    return {"value": S / dt, "unit": "series-pairs/s", "cores": threads, "kind": "port",
+            "sample": "first %d rows of the same 1Mx%d synthetic matrix (D2H copy), %d pthreads, "
+                      "C restatement of go-muse xCorrWithX (not Go/gonum)" % (S, N, threads)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=1_000_000, help="series per GPU")
+    ap.add_argument("--length", type=int, default=4096)
+    ap.add_argument("--top-n", type=int, default=20)
+    ap.add_argument("--max-lag", type=int, default=15)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    n_gpus = max(world, 1)
+
+    pkg = importlib.import_module("go-muse_amd")
+    if pkg.build.stale():
+        pkg.build.build()
+    eng = pkg.Engine(local_rank)                      # raises without a gfx950 GPU: no fallback
+    dev_name, cus, hbm = eng.device_info()
+    M, N = args.rows, args.length
+    dg, ref = pkg.DeviceGroup.synthetic(eng, M, N, seed=0x6D757365, global_first=rank * M)
+    db = pkg.DeviceBatch(eng, dg, ref)
+    tdev = torch.device("cuda", local_rank)
+
+    def step():
+        if world > 1:
+            return pkg.dist.run_sharded(db, rank * M, None, 0, args.max_lag, args.top_n, 0.0, 0, True, device=tdev)
+        return db.run(None, 0, args.max_lag, args.top_n, 0.0, 0, True)
+
+    def fence():
+        eng.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    eng.kernel_time()                                   # drop warm-up events
+    eng.kernel_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    eng.kernel_timing(False)
+    k_ms, k_cnt = eng.kernel_time()
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=tdev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        total_pairs = float(M) * n_gpus * args.steps
+        value = total_pairs / dt
+        k_avg_s = (k_ms / max(k_cnt, 1)) * 1e-3
+        bytes_per_launch = float(M) * (8 * N + 16)
+        achieved = bytes_per_launch / k_avg_s / 1e9 if k_avg_s > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("rows") == M and tj.get("length") == N:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "series-pairs XCorr/sec at N=4096, 1M-series batch; achieved HBM GB/s",
+            "value": value, "unit": "series-pairs/s", "n_gpus": n_gpus, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "configs[2]: 1 ref x %d series/GPU, N=%d float64 rect+noise, Run(nil), "
+                                   "MaxLag=%d TopN=%d" % (M, N, args.max_lag, args.top_n),
+                       "rows_per_gpu": M, "length": N, "fft_len": db.n, "sharding": "rows x %d" % n_gpus,
+                       "device": dev_name},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "kernel": "xcorr_fused_n4096" if db.n == 4096 else "xcorr_fused_generic",
+                         "kernel_ms_avg": k_avg_s * 1e3, "launches_timed": k_cnt,
+                         "algorithmic_bytes_per_launch": bytes_per_launch},
+            "achieved_hbm_gbps_whole_step": value / n_gpus * (8 * N + 16) / 1e9,
+            "top_score": float(out[2][0]) if len(out[2]) else None,
+        }
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(dg, ref, N)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

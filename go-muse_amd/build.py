@@ -1,0 +1,52 @@
+"""Builds go-muse_amd/lib/libmuse_hip.so (gfx950 only) with hipcc.
+
+The library is built IN-TREE so it travels with the repo snapshot to the GPU
+box; it is git-ignored.  hipcc cross-compiles gfx950 code objects without a
+GPU present.
+"""
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIBDIR = os.path.join(PKG, "lib")
+LIB = os.path.join(LIBDIR, "libmuse_hip.so")
+SOURCES = ["xcorr_kernels.hip", "reduce_kernels.hip", "muse_capi.hip"]
+HEADERS = [os.path.join(CSRC, "xcorr_kernels.h"), os.path.join(ROOT, "include", "muse_hip.h")]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False, extra_flags=()):
+    if not force and not stale():
+        return LIB
+    os.makedirs(LIBDIR, exist_ok=True)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+    cmd += list(extra_flags)
+    cmd += [os.path.join(CSRC, s) for s in SOURCES]
+    cmd += ["-o", LIB]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    flags = [a for a in sys.argv[1:] if a.startswith("-") and a != "--force"]
+    print(build(force=True, verbose=True, extra_flags=flags))

@@ -1,0 +1,998 @@
+// muse_capi.hip -- implementation of the C ABI declared in include/muse_hip.h.
+// Host-side orchestration only: device memory, streams, launches, and the
+// final (tiny) top-N heap that mirrors go-muse's Results (results.go:55-87).
+// There is no CPU compute fallback anywhere in this file: without a gfx950
+// device every compute entry point returns MUSE_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <new>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "muse_hip.h"
+#include "xcorr_kernels.h"
+
+using namespace muse;
+
+// ------------------------------------------------------------------ errors
+static thread_local std::string g_last_error;
+
+static int fail(int status, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return status;
+}
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return fail(MUSE_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),       \
+                        __FILE__, __LINE__);                                                       \
+    } while (0)
+
+extern "C" int muse_abi_version(void) { return MUSE_HIP_ABI_VERSION; }
+extern "C" const char *muse_last_error(void) { return g_last_error.c_str(); }
+extern "C" const char *muse_status_string(int s)
+{
+    switch (s) {
+    case MUSE_OK: return "ok";
+    case MUSE_ERR_INVALID: return "invalid argument";
+    case MUSE_ERR_LENGTH: return "series length mismatch";
+    case MUSE_ERR_ZERO_STD: return "Invalid input query, Standard deviation of zero";
+    case MUSE_ERR_NO_DEVICE: return "no usable gfx950 device";
+    case MUSE_ERR_HIP: return "HIP runtime error";
+    case MUSE_ERR_UNSUPPORTED: return "unsupported FFT length";
+    case MUSE_ERR_NOMEM: return "out of memory";
+    case MUSE_ERR_EMPTY: return "Reference series length must be greater than zero";
+    default: return "unknown status";
+    }
+}
+
+// xcorr.go:19-24
+extern "C" int64_t muse_next_pow2(double val)
+{
+    if (val <= 0)
+        return 0;
+    return (int64_t)std::pow(2.0, std::ceil(std::log(val) / std::log(2.0)));
+}
+
+// ----------------------------------------------------------------- handles
+struct muse_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int num_cus = 0;
+    int64_t hbm = 0;
+    char name[64] = {0};
+    double2 *tw1 = nullptr, *tw2 = nullptr, *twm = nullptr;
+    int variant = 0;
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    double total_ms = 0.0;
+    int64_t launches = 0;
+};
+
+struct muse_group {
+    muse_ctx *ctx = nullptr;
+    double *rows = nullptr;
+    int64_t cap = 0, M = 0, stride = 0;
+    int32_t N = 0;
+};
+
+struct muse_batch {
+    muse_ctx *ctx = nullptr;
+    muse_group *g = nullptr;
+    int32_t N = 0, n = 0, logn = 0;
+    double2 *X = nullptr, *xc = nullptr;
+    double *mv = nullptr;
+    int *lag = nullptr;
+    int64_t score_cap = 0;
+    // selection workspace
+    int *gid_dev = nullptr;
+    int64_t gid_cap = 0;
+    std::vector<int32_t> gid_host;
+    bool gid_valid = false;
+    GroupWork gw{nullptr, nullptr, nullptr};
+    muse_record *rec = nullptr;
+    unsigned long long *selkey = nullptr;
+    int64_t grp_cap = 0;
+    muse_record *cand = nullptr;
+    int *cnt = nullptr;
+    int64_t cand_cap = 0, cnt_cap = 0;
+};
+
+static int use_device(muse_ctx *ctx)
+{
+    if (!ctx)
+        return fail(MUSE_ERR_INVALID, "NULL context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    return MUSE_OK;
+}
+
+// ----------------------------------------------------------------- context
+static void fill_twiddle(std::vector<double2> &v, size_t i, long long num, long long den)
+{
+    const long double PI2 = 6.283185307179586476925286766559005768L;
+    num %= den;
+    const long double a = -PI2 * (long double)num / (long double)den;
+    v[i] = make_double2((double)cosl(a), (double)sinl(a));
+}
+
+extern "C" int muse_ctx_create(int32_t device, muse_ctx **out)
+{
+    if (!out)
+        return fail(MUSE_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        return fail(MUSE_ERR_NO_DEVICE, "no HIP device visible (this engine has no CPU fallback)");
+    }
+    if (device < 0 || device >= count)
+        return fail(MUSE_ERR_NO_DEVICE, "device %d out of range (%d visible)", device, count);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(MUSE_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 (MI355X) only", device,
+                    prop.gcnArchName);
+    muse_ctx *ctx = new (std::nothrow) muse_ctx();
+    if (!ctx)
+        return fail(MUSE_ERR_NOMEM, "host allocation failed");
+    ctx->device = device;
+    ctx->num_cus = prop.multiProcessorCount;
+    ctx->hbm = (int64_t)prop.totalGlobalMem;
+    snprintf(ctx->name, sizeof(ctx->name), "%s (%s)", prop.name, prop.gcnArchName);
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    std::vector<double2> t1(16 * 256), t2(16 * 16), tm(4096);
+    for (int k = 0; k < 16; k++)
+        for (int t = 0; t < 256; t++)
+            fill_twiddle(t1, (size_t)k * 256 + t, (long long)k * t, 4096);
+    for (int k = 0; k < 16; k++)
+        for (int c = 0; c < 16; c++)
+            fill_twiddle(t2, (size_t)k * 16 + c, (long long)k * c, 256);
+    for (int k = 0; k < 4096; k++)
+        fill_twiddle(tm, (size_t)k, k, 8192);
+    HIP_TRY(hipMalloc(&ctx->tw1, t1.size() * sizeof(double2)));
+    HIP_TRY(hipMalloc(&ctx->tw2, t2.size() * sizeof(double2)));
+    HIP_TRY(hipMalloc(&ctx->twm, tm.size() * sizeof(double2)));
+    HIP_TRY(hipMemcpy(ctx->tw1, t1.data(), t1.size() * sizeof(double2), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->tw2, t2.data(), t2.size() * sizeof(double2), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->twm, tm.data(), tm.size() * sizeof(double2), hipMemcpyHostToDevice));
+    *out = ctx;
+    return MUSE_OK;
+}
+
+extern "C" int muse_ctx_destroy(muse_ctx *ctx)
+{
+    if (!ctx)
+        return MUSE_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream)
+        (void)hipStreamSynchronize(ctx->stream);
+    for (auto &e : ctx->events) {
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    (void)hipFree(ctx->tw1);
+    (void)hipFree(ctx->tw2);
+    (void)hipFree(ctx->twm);
+    if (ctx->stream)
+        (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return MUSE_OK;
+}
+
+extern "C" int muse_ctx_synchronize(muse_ctx *ctx)
+{
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return MUSE_OK;
+}
+
+extern "C" int muse_ctx_device_info(muse_ctx *ctx, char *name, int32_t name_cap, int32_t *cus, int64_t *hbm)
+{
+    if (!ctx)
+        return fail(MUSE_ERR_INVALID, "NULL context");
+    if (name && name_cap > 0)
+        snprintf(name, (size_t)name_cap, "%s", ctx->name);
+    if (cus)
+        *cus = ctx->num_cus;
+    if (hbm)
+        *hbm = ctx->hbm;
+    return MUSE_OK;
+}
+
+extern "C" int muse_ctx_set_kernel(muse_ctx *ctx, int32_t variant)
+{
+    if (!ctx || variant < 0 || variant > 1)
+        return fail(MUSE_ERR_INVALID, "bad kernel variant");
+    ctx->variant = variant;
+    return MUSE_OK;
+}
+
+extern "C" int muse_ctx_kernel_timing(muse_ctx *ctx, int32_t enable)
+{
+    if (!ctx)
+        return fail(MUSE_ERR_INVALID, "NULL context");
+    ctx->timing = enable != 0;
+    return MUSE_OK;
+}
+
+extern "C" int muse_ctx_kernel_time(muse_ctx *ctx, double *total_ms, int64_t *launches)
+{
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    for (auto &e : ctx->events) {
+        HIP_TRY(hipEventSynchronize(e.second));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e.first, e.second));
+        ctx->total_ms += (double)ms;
+        ctx->launches += 1;
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    ctx->events.clear();
+    if (total_ms)
+        *total_ms = ctx->total_ms;
+    if (launches)
+        *launches = ctx->launches;
+    ctx->total_ms = 0.0;
+    ctx->launches = 0;
+    return MUSE_OK;
+}
+
+// ------------------------------------------------------------------- group
+extern "C" int muse_group_create(muse_ctx *ctx, int64_t capacity_rows, int32_t N, muse_group **out)
+{
+    if (!out)
+        return fail(MUSE_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    if (N < 1 || capacity_rows < 0)
+        return fail(MUSE_ERR_INVALID, "bad group shape (%lld x %d)", (long long)capacity_rows, N);
+    muse_group *g = new (std::nothrow) muse_group();
+    if (!g)
+        return fail(MUSE_ERR_NOMEM, "host allocation failed");
+    g->ctx = ctx;
+    g->N = N;
+    g->stride = N;
+    g->cap = capacity_rows;
+    if (capacity_rows > 0) {
+        hipError_t e = hipMalloc(&g->rows, (size_t)capacity_rows * (size_t)N * sizeof(double));
+        if (e != hipSuccess) {
+            delete g;
+            return fail(MUSE_ERR_NOMEM, "hipMalloc of %lld x %d doubles failed: %s", (long long)capacity_rows, N,
+                        hipGetErrorString(e));
+        }
+    }
+    *out = g;
+    return MUSE_OK;
+}
+
+static int group_reserve(muse_group *g, int64_t rows)
+{
+    if (rows <= g->cap)
+        return MUSE_OK;
+    int64_t ncap = std::max<int64_t>(rows, g->cap * 2);
+    double *nr = nullptr;
+    hipError_t e = hipMalloc(&nr, (size_t)ncap * (size_t)g->N * sizeof(double));
+    if (e != hipSuccess)
+        return fail(MUSE_ERR_NOMEM, "hipMalloc of %lld rows failed: %s", (long long)ncap, hipGetErrorString(e));
+    if (g->M > 0) {
+        HIP_TRY(hipMemcpyAsync(nr, g->rows, (size_t)g->M * (size_t)g->N * sizeof(double), hipMemcpyDeviceToDevice,
+                               g->ctx->stream));
+        HIP_TRY(hipStreamSynchronize(g->ctx->stream));
+    }
+    (void)hipFree(g->rows);
+    g->rows = nr;
+    g->cap = ncap;
+    return MUSE_OK;
+}
+
+extern "C" int muse_group_append(muse_group *g, const double *rows, int64_t count, int64_t row_stride)
+{
+    if (!g || (!rows && count > 0) || count < 0)
+        return fail(MUSE_ERR_INVALID, "bad append arguments");
+    if (count == 0)
+        return MUSE_OK;
+    if (row_stride < g->N) // group.go:45-51: one length per group
+        return fail(MUSE_ERR_LENGTH, "Timeseries has length %lld, but current group has length %d",
+                    (long long)row_stride, g->N);
+    int rc = use_device(g->ctx);
+    if (rc)
+        return rc;
+    rc = group_reserve(g, g->M + count);
+    if (rc)
+        return rc;
+    HIP_TRY(hipMemcpy2D(g->rows + g->M * g->stride, (size_t)g->stride * sizeof(double), rows,
+                        (size_t)row_stride * sizeof(double), (size_t)g->N * sizeof(double), (size_t)count,
+                        hipMemcpyHostToDevice));
+    g->M += count;
+    return MUSE_OK;
+}
+
+extern "C" int muse_group_upload(muse_ctx *ctx, const double *rows, int64_t M, int32_t N, int64_t row_stride,
+                                 muse_group **out)
+{
+    int rc = muse_group_create(ctx, M, N, out);
+    if (rc)
+        return rc;
+    rc = muse_group_append(*out, rows, M, row_stride);
+    if (rc) {
+        muse_group_free(*out);
+        *out = nullptr;
+    }
+    return rc;
+}
+
+extern "C" int muse_group_fill_synthetic(muse_group *g, int64_t first, int64_t count, int64_t global_first,
+                                         uint64_t seed, double *ref_out)
+{
+    if (!g || first < 0 || count < 0 || first > g->M)
+        return fail(MUSE_ERR_INVALID, "bad synthetic fill range");
+    int rc = use_device(g->ctx);
+    if (rc)
+        return rc;
+    rc = group_reserve(g, first + count);
+    if (rc)
+        return rc;
+    HIP_TRY(launch_synth(g->rows, g->stride, first, count, global_first, g->N, seed, g->ctx->stream));
+    g->M = std::max(g->M, first + count);
+    if (ref_out) {
+        double *d = nullptr;
+        HIP_TRY(hipMalloc(&d, (size_t)g->N * sizeof(double)));
+        hipError_t e = launch_synth_ref(d, g->N, seed, g->ctx->stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(ref_out, d, (size_t)g->N * sizeof(double), hipMemcpyDeviceToHost, g->ctx->stream);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(g->ctx->stream);
+        (void)hipFree(d);
+        HIP_TRY(e);
+    }
+    HIP_TRY(hipStreamSynchronize(g->ctx->stream));
+    return MUSE_OK;
+}
+
+extern "C" int muse_group_shape(muse_group *g, int64_t *M, int32_t *N)
+{
+    if (!g)
+        return fail(MUSE_ERR_INVALID, "NULL group");
+    if (M)
+        *M = g->M;
+    if (N)
+        *N = g->N;
+    return MUSE_OK;
+}
+
+extern "C" int muse_group_read(muse_group *g, int64_t first, int64_t count, double *out)
+{
+    if (!g || !out || first < 0 || count < 0 || first + count > g->M)
+        return fail(MUSE_ERR_INVALID, "bad read range");
+    if (count == 0)
+        return MUSE_OK;
+    int rc = use_device(g->ctx);
+    if (rc)
+        return rc;
+    HIP_TRY(hipStreamSynchronize(g->ctx->stream));
+    HIP_TRY(hipMemcpy2D(out, (size_t)g->N * sizeof(double), g->rows + first * g->stride,
+                        (size_t)g->stride * sizeof(double), (size_t)g->N * sizeof(double), (size_t)count,
+                        hipMemcpyDeviceToHost));
+    return MUSE_OK;
+}
+
+extern "C" int muse_group_free(muse_group *g)
+{
+    if (!g)
+        return MUSE_OK;
+    (void)hipSetDevice(g->ctx->device);
+    (void)hipStreamSynchronize(g->ctx->stream);
+    (void)hipFree(g->rows);
+    delete g;
+    return MUSE_OK;
+}
+
+// ------------------------------------------------------------------- batch
+static int ilog2(int64_t n)
+{
+    int l = 0;
+    while (((int64_t)1 << l) < n)
+        l++;
+    return l;
+}
+
+// device reference spectrum for (ref, N) at FFT length n: fills X, xc
+static int build_spectrum(muse_ctx *ctx, const double *ref_host, int N, int n, int normalize, double x_scale,
+                          double xc_scale, double2 *X, double2 *xc, int *zero_std)
+{
+    double *dref = nullptr;
+    int *dstat = nullptr;
+    HIP_TRY(hipMalloc(&dref, (size_t)N * sizeof(double)));
+    hipError_t e = hipMalloc(&dstat, sizeof(int));
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(dref, ref_host, (size_t)N * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess)
+        e = launch_ref_spectrum(dref, N, n, ilog2(n), normalize, x_scale, xc_scale, ctx->twm, X, xc, dstat,
+                                ctx->stream);
+    int st = 0;
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(&st, dstat, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(dref);
+    (void)hipFree(dstat);
+    HIP_TRY(e);
+    *zero_std = st;
+    return MUSE_OK;
+}
+
+extern "C" int muse_batch_create(muse_ctx *ctx, muse_group *g, const double *ref, int32_t N, muse_batch **out)
+{
+    if (!out)
+        return fail(MUSE_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    if (N < 1) // muse.go:24-26
+        return fail(MUSE_ERR_EMPTY, "Reference series length must be greater than zero");
+    if (!g || !ref || g->ctx != ctx)
+        return fail(MUSE_ERR_INVALID, "bad batch arguments");
+    if (g->N != N) // muse_batch.go:24-28
+        return fail(MUSE_ERR_LENGTH, "comparison group series does not have the same length as the reference (%d vs %d)",
+                    g->N, N);
+    if (N < 2)
+        return fail(MUSE_ERR_INVALID, "series length 1 has no sample standard deviation");
+    const int64_t n = muse_next_pow2((double)N); // muse_batch.go:35
+    if (n > 8192)
+        return fail(MUSE_ERR_UNSUPPORTED, "FFT length %lld > 8192 is not built yet (LDS-resident kernels only)",
+                    (long long)n);
+    muse_batch *b = new (std::nothrow) muse_batch();
+    if (!b)
+        return fail(MUSE_ERR_NOMEM, "host allocation failed");
+    b->ctx = ctx;
+    b->g = g;
+    b->N = N;
+    b->n = (int32_t)n;
+    b->logn = ilog2(n);
+    hipError_t e = hipMalloc(&b->X, (size_t)(n / 2 + 1) * sizeof(double2));
+    if (e == hipSuccess)
+        e = hipMalloc(&b->xc, (size_t)n * sizeof(double2));
+    if (e != hipSuccess) {
+        muse_batch_free(b);
+        return fail(MUSE_ERR_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e));
+    }
+    int zero = 0;
+    // x = zNormalize(ref) / (N-1), zeroPad, FFT   (muse_batch.go:38-47)
+    rc = build_spectrum(ctx, ref, N, (int)n, 1, 1.0 / (double)(N - 1), 1.0 / (double)n, b->X, b->xc, &zero);
+    if (rc) {
+        muse_batch_free(b);
+        return rc;
+    }
+    if (zero) { // muse_batch.go:39-41
+        muse_batch_free(b);
+        return fail(MUSE_ERR_ZERO_STD, "Invalid input query, Standard deviation of zero");
+    }
+    *out = b;
+    return MUSE_OK;
+}
+
+extern "C" int muse_batch_fft_len(muse_batch *b, int32_t *n)
+{
+    if (!b || !n)
+        return fail(MUSE_ERR_INVALID, "NULL argument");
+    *n = b->n;
+    return MUSE_OK;
+}
+
+extern "C" int muse_batch_spectrum(muse_batch *b, double *out)
+{
+    if (!b || !out)
+        return fail(MUSE_ERR_INVALID, "NULL argument");
+    int rc = use_device(b->ctx);
+    if (rc)
+        return rc;
+    HIP_TRY(hipMemcpy(out, b->X, (size_t)(b->n / 2 + 1) * sizeof(double2), hipMemcpyDeviceToHost));
+    return MUSE_OK;
+}
+
+static int ensure_scores(muse_batch *b)
+{
+    const int64_t M = b->g->M;
+    if (M <= b->score_cap)
+        return MUSE_OK;
+    (void)hipFree(b->mv);
+    (void)hipFree(b->lag);
+    b->mv = nullptr;
+    b->lag = nullptr;
+    b->score_cap = 0;
+    HIP_TRY(hipMalloc(&b->mv, (size_t)M * sizeof(double)));
+    HIP_TRY(hipMalloc(&b->lag, (size_t)M * sizeof(int)));
+    b->score_cap = M;
+    return MUSE_OK;
+}
+
+extern "C" int muse_batch_score(muse_batch *b)
+{
+    if (!b)
+        return fail(MUSE_ERR_INVALID, "NULL batch");
+    muse_ctx *ctx = b->ctx;
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    const int64_t M = b->g->M;
+    if (M == 0)
+        return MUSE_OK;
+    rc = ensure_scores(b);
+    if (rc)
+        return rc;
+    FusedParams p{};
+    p.rows = b->g->rows;
+    p.M = M;
+    p.stride = b->g->stride;
+    p.npairs = (M + 1) / 2;
+    p.N = b->N;
+    p.n = b->n;
+    p.logn = b->logn;
+    p.normalize_y = 1;
+    p.xc = b->xc;
+    p.tw1 = ctx->tw1;
+    p.tw2 = ctx->tw2;
+    p.twm = ctx->twm;
+    p.mv = b->mv;
+    p.lag = b->lag;
+    p.cc_out = nullptr;
+    p.nil_out = nullptr;
+    const int variant = (b->n == 4096 && ctx->variant == 0) ? KERNEL_R16_N4096 : KERNEL_GENERIC;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ctx->timing) {
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, ctx->stream));
+    }
+    HIP_TRY(launch_fused(p, variant, ctx->num_cus, ctx->stream));
+    if (ctx->timing) {
+        HIP_TRY(hipEventRecord(e1, ctx->stream));
+        ctx->events.emplace_back(e0, e1);
+    }
+    return MUSE_OK;
+}
+
+extern "C" int muse_batch_scores(muse_batch *b, int32_t *lag, double *mv)
+{
+    int rc = muse_batch_score(b);
+    if (rc)
+        return rc;
+    const int64_t M = b->g->M;
+    if (M == 0)
+        return MUSE_OK;
+    if (!lag || !mv)
+        return fail(MUSE_ERR_INVALID, "NULL output");
+    HIP_TRY(hipMemcpyAsync(lag, b->lag, (size_t)M * sizeof(int), hipMemcpyDeviceToHost, b->ctx->stream));
+    HIP_TRY(hipMemcpyAsync(mv, b->mv, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, b->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    return MUSE_OK;
+}
+
+// ---- Results: Go container/heap on |score| (scores.go:25-27, results.go)
+namespace {
+struct GoHeap {
+    std::vector<muse_record> h;
+    static bool less(const muse_record &a, const muse_record &b) { return std::fabs(a.score) < std::fabs(b.score); }
+    void up(size_t j)
+    {
+        for (;;) {
+            if (j == 0)
+                break;
+            size_t i = (j - 1) / 2;
+            if (!less(h[j], h[i]))
+                break;
+            std::swap(h[i], h[j]);
+            j = i;
+        }
+    }
+    void down(size_t i0, size_t n)
+    {
+        size_t i = i0;
+        for (;;) {
+            size_t j1 = 2 * i + 1;
+            if (j1 >= n)
+                break;
+            size_t j = j1, j2 = j1 + 1;
+            if (j2 < n && less(h[j2], h[j1]))
+                j = j2;
+            if (!less(h[j], h[i]))
+                break;
+            std::swap(h[i], h[j]);
+            i = j;
+        }
+    }
+    void push(const muse_record &r)
+    {
+        h.push_back(r);
+        up(h.size() - 1);
+    }
+    muse_record pop()
+    {
+        size_t n = h.size() - 1;
+        std::swap(h[0], h[n]);
+        down(0, n);
+        muse_record r = h.back();
+        h.pop_back();
+        return r;
+    }
+};
+
+// Results.Update over `cands` (already filtered by passed()) in group order,
+// then Results.Fetch: descending |score|.
+std::vector<muse_record> heap_select(std::vector<muse_record> cands, int64_t top_n)
+{
+    std::stable_sort(cands.begin(), cands.end(), [](const muse_record &a, const muse_record &b) {
+        if (a.group != b.group)
+            return a.group < b.group;
+        return a.series < b.series;
+    });
+    GoHeap hp;
+    if (top_n > 0) {
+        for (const auto &r : cands) {
+            if ((int64_t)hp.h.size() == top_n) { // results.go:62-66
+                if (std::fabs(r.score) > std::fabs(hp.h[0].score)) {
+                    hp.pop();
+                    hp.push(r);
+                }
+            } else {
+                hp.push(r);
+            }
+        }
+    }
+    std::vector<muse_record> out(hp.h.size());
+    for (size_t i = out.size(); i-- > 0;) // results.go:81-85
+        out[i] = hp.pop();
+    return out;
+}
+} // namespace
+
+static int ensure_select_ws(muse_batch *b, int64_t M, int64_t G, bool with_gid, int K)
+{
+    if (with_gid && M > b->gid_cap) {
+        (void)hipFree(b->gid_dev);
+        b->gid_dev = nullptr;
+        b->gid_cap = 0;
+        b->gid_valid = false;
+        HIP_TRY(hipMalloc(&b->gid_dev, (size_t)M * sizeof(int)));
+        b->gid_cap = M;
+    }
+    if (G > b->grp_cap) {
+        (void)hipFree(b->gw.key);
+        (void)hipFree(b->gw.first);
+        (void)hipFree(b->gw.win);
+        (void)hipFree(b->rec);
+        (void)hipFree(b->selkey);
+        b->gw = GroupWork{nullptr, nullptr, nullptr};
+        b->rec = nullptr;
+        b->selkey = nullptr;
+        b->grp_cap = 0;
+        HIP_TRY(hipMalloc(&b->gw.key, (size_t)G * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc(&b->gw.first, (size_t)G * sizeof(long long)));
+        HIP_TRY(hipMalloc(&b->gw.win, (size_t)G * sizeof(long long)));
+        HIP_TRY(hipMalloc(&b->rec, (size_t)G * sizeof(muse_record)));
+        HIP_TRY(hipMalloc(&b->selkey, (size_t)G * sizeof(unsigned long long)));
+        b->grp_cap = G;
+    }
+    const int64_t nb = (G + TOPN_CHUNK - 1) / TOPN_CHUNK;
+    if (nb > b->cnt_cap) {
+        (void)hipFree(b->cnt);
+        b->cnt = nullptr;
+        b->cnt_cap = 0;
+        HIP_TRY(hipMalloc(&b->cnt, (size_t)nb * sizeof(int)));
+        b->cnt_cap = nb;
+    }
+    if (nb * K > b->cand_cap) {
+        (void)hipFree(b->cand);
+        b->cand = nullptr;
+        b->cand_cap = 0;
+        HIP_TRY(hipMalloc(&b->cand, (size_t)(nb * K) * sizeof(muse_record)));
+        b->cand_cap = nb * K;
+    }
+    return MUSE_OK;
+}
+
+static int run_select(muse_batch *b, const int32_t *group_id, int32_t G_in, int64_t series_offset, int32_t max_lag,
+                      int32_t top_n, double threshold, int32_t sign_filter, int32_t abs_scores,
+                      std::vector<muse_record> &out)
+{
+    out.clear();
+    muse_ctx *ctx = b->ctx;
+    const int64_t M = b->g->M;
+    if (sign_filter < -1 || sign_filter > 1)
+        return fail(MUSE_ERR_INVALID, "sign_filter must be -1, 0 or 1");
+    if (group_id && G_in < 0)
+        return fail(MUSE_ERR_INVALID, "negative group count");
+    // Batch.Run re-scores on every call (muse_batch.go:116-122)
+    int rc = muse_batch_score(b);
+    if (rc)
+        return rc;
+    const int64_t G = group_id ? (int64_t)G_in : M;
+    if (M == 0 || G == 0 || top_n <= 0)
+        return MUSE_OK;
+    if (G > 0x7fffffffLL)
+        return fail(MUSE_ERR_UNSUPPORTED, "more than 2^31-1 groups on one device");
+    const bool on_device = top_n <= TOPN_DEVICE_MAX && G > TOPN_CHUNK / 4;
+    const int K = on_device ? top_n : 1;
+    rc = ensure_select_ws(b, M, G, group_id != nullptr, K);
+    if (rc)
+        return rc;
+    if (group_id) {
+        const bool same = b->gid_valid && (int64_t)b->gid_host.size() == M &&
+                          memcmp(b->gid_host.data(), group_id, (size_t)M * sizeof(int32_t)) == 0;
+        if (!same) {
+            b->gid_host.assign(group_id, group_id + M);
+            HIP_TRY(hipMemcpyAsync(b->gid_dev, b->gid_host.data(), (size_t)M * sizeof(int), hipMemcpyHostToDevice,
+                                   ctx->stream));
+            b->gid_valid = true;
+        }
+    }
+    SelectParams sp{};
+    sp.mv = b->mv;
+    sp.lag = b->lag;
+    sp.M = M;
+    sp.group_id = group_id ? b->gid_dev : nullptr;
+    sp.G = (int)G;
+    sp.abs_scores = abs_scores ? 1 : 0;
+    sp.max_lag = max_lag;
+    sp.threshold = threshold;
+    sp.sign_filter = sign_filter;
+    sp.series_offset = series_offset;
+    HIP_TRY(launch_group_reduce(sp, b->gw, b->rec, b->selkey, ctx->stream));
+    std::vector<muse_record> cands;
+    if (on_device) {
+        const int64_t nb = (G + TOPN_CHUNK - 1) / TOPN_CHUNK;
+        HIP_TRY(launch_topn(b->rec, b->selkey, (int)G, K, b->cand, b->cnt, ctx->stream));
+        std::vector<int> cnt((size_t)nb);
+        std::vector<muse_record> cand((size_t)(nb * K));
+        HIP_TRY(hipMemcpyAsync(cnt.data(), b->cnt, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(cand.data(), b->cand, cand.size() * sizeof(muse_record), hipMemcpyDeviceToHost,
+                               ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        for (int64_t blk = 0; blk < nb; blk++)
+            for (int r = 0; r < cnt[(size_t)blk]; r++)
+                cands.push_back(cand[(size_t)(blk * K + r)]);
+    } else {
+        std::vector<muse_record> rec((size_t)G);
+        std::vector<unsigned long long> key((size_t)G);
+        HIP_TRY(hipMemcpyAsync(rec.data(), b->rec, (size_t)G * sizeof(muse_record), hipMemcpyDeviceToHost,
+                               ctx->stream));
+        HIP_TRY(hipMemcpyAsync(key.data(), b->selkey, (size_t)G * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                               ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        for (int64_t g = 0; g < G; g++)
+            if (key[(size_t)g] != 0ull)
+                cands.push_back(rec[(size_t)g]);
+    }
+    if (!group_id) // ungrouped: global order of the groups is the global series index
+        for (auto &r : cands)
+            r.group = (int32_t)std::min<int64_t>(r.series, 0x7fffffffLL);
+    out = heap_select(std::move(cands), top_n);
+    return MUSE_OK;
+}
+
+static void emit(const std::vector<muse_record> &sel, int64_t *out_series, int32_t *out_lag, double *out_score,
+                 int32_t *out_count, double *out_mean_abs)
+{
+    double sum = 0.0;
+    for (size_t i = sel.size(); i-- > 0;) { // results.go:81-85 sums in pop order (ascending |score|)
+        if (out_series)
+            out_series[i] = sel[i].series;
+        if (out_lag)
+            out_lag[i] = sel[i].lag;
+        if (out_score)
+            out_score[i] = sel[i].score;
+        sum += std::fabs(sel[i].score);
+    }
+    if (out_count)
+        *out_count = (int32_t)sel.size();
+    if (out_mean_abs) // results.go:86 (0/0 = NaN when empty)
+        *out_mean_abs = sel.empty() ? std::numeric_limits<double>::quiet_NaN() : sum / (double)sel.size();
+}
+
+extern "C" int muse_batch_run(muse_batch *b, const int32_t *group_id, int32_t G, int32_t max_lag, int32_t top_n,
+                              double threshold, int32_t sign_filter, int32_t abs_scores, int64_t *out_series,
+                              int32_t *out_lag, double *out_score, int32_t *out_count, double *out_mean_abs)
+{
+    if (!b)
+        return fail(MUSE_ERR_INVALID, "NULL batch");
+    std::vector<muse_record> sel;
+    int rc = run_select(b, group_id, G, 0, max_lag, top_n, threshold, sign_filter, abs_scores, sel);
+    if (rc)
+        return rc;
+    emit(sel, out_series, out_lag, out_score, out_count, out_mean_abs);
+    return MUSE_OK;
+}
+
+extern "C" int muse_batch_run_shard(muse_batch *b, const int32_t *group_id, int32_t G, int64_t series_offset,
+                                    int32_t max_lag, int32_t top_n, double threshold, int32_t sign_filter,
+                                    int32_t abs_scores, muse_record *out_records, int32_t *out_count)
+{
+    if (!b || !out_count || (top_n > 0 && !out_records))
+        return fail(MUSE_ERR_INVALID, "NULL argument");
+    std::vector<muse_record> sel;
+    int rc = run_select(b, group_id, G, series_offset, max_lag, top_n, threshold, sign_filter, abs_scores, sel);
+    if (rc)
+        return rc;
+    for (size_t i = 0; i < sel.size(); i++)
+        out_records[i] = sel[i];
+    *out_count = (int32_t)sel.size();
+    return MUSE_OK;
+}
+
+extern "C" int muse_merge_records(const muse_record *records, int64_t count, int32_t top_n, int64_t *out_series,
+                                  int32_t *out_lag, double *out_score, int32_t *out_count, double *out_mean_abs)
+{
+    if (count < 0 || (count > 0 && !records))
+        return fail(MUSE_ERR_INVALID, "bad records");
+    std::vector<muse_record> c(records, records + count);
+    std::vector<muse_record> sel = heap_select(std::move(c), top_n);
+    emit(sel, out_series, out_lag, out_score, out_count, out_mean_abs);
+    return MUSE_OK;
+}
+
+extern "C" int muse_batch_free(muse_batch *b)
+{
+    if (!b)
+        return MUSE_OK;
+    (void)hipSetDevice(b->ctx->device);
+    (void)hipStreamSynchronize(b->ctx->stream);
+    (void)hipFree(b->X);
+    (void)hipFree(b->xc);
+    (void)hipFree(b->mv);
+    (void)hipFree(b->lag);
+    (void)hipFree(b->gid_dev);
+    (void)hipFree(b->gw.key);
+    (void)hipFree(b->gw.first);
+    (void)hipFree(b->gw.win);
+    (void)hipFree(b->rec);
+    (void)hipFree(b->selkey);
+    (void)hipFree(b->cand);
+    (void)hipFree(b->cnt);
+    delete b;
+    return MUSE_OK;
+}
+
+// ------------------------------------------------- single-pair entry points
+static bool is_pow2(int64_t n) { return n > 0 && (n & (n - 1)) == 0; }
+
+// shared tail: x (len lenx) vs y (len leny) at FFT length n
+static int single_pair(muse_ctx *ctx, const double *x, int lenx, const double *y, int leny, int n, int normalize_x,
+                       int normalize_y, double x_scale, double cc_scale, double *cc, int32_t *lag, double *mv,
+                       int32_t *is_nil)
+{
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    if (!x || !y || lenx < 1 || leny < 1 || n < lenx || n < leny || !lag || !mv)
+        return fail(MUSE_ERR_INVALID, "bad single-pair arguments");
+    if ((normalize_x && lenx < 2) || (normalize_y && leny < 2))
+        return fail(MUSE_ERR_INVALID, "series length 1 has no sample standard deviation");
+    if (n > 8192)
+        return fail(MUSE_ERR_UNSUPPORTED, "FFT length %d > 8192", n);
+    double *dx = nullptr, *dy = nullptr, *dcc = nullptr, *dmv = nullptr;
+    int *dlag = nullptr, *dstat = nullptr;
+    double2 *dX = nullptr, *dxc = nullptr;
+    int nil = 0, lg = 0;
+    double val = 0.0;
+    hipError_t e = hipSuccess;
+    auto cleanup = [&]() {
+        (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dcc); (void)hipFree(dmv);
+        (void)hipFree(dlag); (void)hipFree(dstat); (void)hipFree(dX); (void)hipFree(dxc);
+    };
+#define SP_TRY(expr)                                                                                        \
+    do {                                                                                                    \
+        e = (expr);                                                                                         \
+        if (e != hipSuccess) {                                                                              \
+            cleanup();                                                                                      \
+            return fail(MUSE_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e));                        \
+        }                                                                                                   \
+    } while (0)
+    SP_TRY(hipMalloc(&dy, (size_t)leny * sizeof(double)));
+    SP_TRY(hipMalloc(&dcc, (size_t)n * sizeof(double)));
+    SP_TRY(hipMalloc(&dmv, sizeof(double)));
+    SP_TRY(hipMalloc(&dlag, sizeof(int)));
+    SP_TRY(hipMalloc(&dstat, sizeof(int)));
+    SP_TRY(hipMemcpyAsync(dy, y, (size_t)leny * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if (is_pow2(n) && n >= 2) {
+        // FFT path: the same device code the batch uses (generic kernel)
+        SP_TRY(hipMalloc(&dX, (size_t)(n / 2 + 1) * sizeof(double2)));
+        SP_TRY(hipMalloc(&dxc, (size_t)n * sizeof(double2)));
+        int zero = 0;
+        rc = build_spectrum(ctx, x, lenx, n, normalize_x, x_scale, cc_scale, dX, dxc, &zero);
+        if (rc) {
+            cleanup();
+            return rc;
+        }
+        FusedParams p{};
+        p.rows = dy;
+        p.M = 1;
+        p.stride = leny;
+        p.npairs = 1;
+        p.N = leny;
+        p.n = n;
+        p.logn = ilog2(n);
+        p.normalize_y = normalize_y;
+        p.xc = dxc;
+        p.tw1 = ctx->tw1;
+        p.tw2 = ctx->tw2;
+        p.twm = ctx->twm;
+        p.mv = dmv;
+        p.lag = dlag;
+        p.cc_out = dcc;
+        p.nil_out = dstat;
+        SP_TRY(launch_fused(p, KERNEL_GENERIC, ctx->num_cus, ctx->stream));
+        SP_TRY(hipMemcpyAsync(&lg, dlag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        SP_TRY(hipMemcpyAsync(&val, dmv, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        SP_TRY(hipMemcpyAsync(&nil, dstat, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        SP_TRY(hipStreamSynchronize(ctx->stream));
+        nil = (nil || zero) ? 1 : 0; // sigma(y) == 0 or sigma(x) == 0 -> (nil, 0, 0)
+    } else {
+        SP_TRY(hipMalloc(&dx, (size_t)lenx * sizeof(double)));
+        SP_TRY(hipMemcpyAsync(dx, x, (size_t)lenx * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        SP_TRY(launch_direct(dx, lenx, dy, leny, n, normalize_x, normalize_y, x_scale, cc_scale * (double)n, dcc,
+                             dlag, dmv, dstat, ctx->stream));
+        SP_TRY(hipMemcpyAsync(&lg, dlag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        SP_TRY(hipMemcpyAsync(&val, dmv, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        SP_TRY(hipMemcpyAsync(&nil, dstat, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        SP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    if (cc && !nil)
+        SP_TRY(hipMemcpy(cc, dcc, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+#undef SP_TRY
+    cleanup();
+    *lag = nil ? 0 : lg;
+    *mv = nil ? 0.0 : val;
+    if (is_nil)
+        *is_nil = nil;
+    return MUSE_OK;
+}
+
+extern "C" int muse_xcorr_with_x(muse_ctx *ctx, const double *ref, const double *y, int32_t N, int32_t n, double *cc,
+                                 int32_t *lag, double *mv, int32_t *is_nil)
+{
+    if (N < 2)
+        return fail(MUSE_ERR_INVALID, "N must be >= 2");
+    // reference side: zNormalize(ref)/(N-1) (xcorr_test.go:259-266 == muse_batch.go:38-47);
+    // sigma(ref) == 0 is the caller's "Invalid input query" error.
+    int32_t nil = 0;
+    // probe sigma(ref) through the same path: build with normalize and check flag
+    int rc = single_pair(ctx, ref, N, y, N, n, 1, 1, 1.0 / (double)(N - 1), 1.0 / (double)n, cc, lag, mv, &nil);
+    if (rc)
+        return rc;
+    if (is_nil)
+        *is_nil = nil;
+    return MUSE_OK;
+}
+
+extern "C" int muse_xcorr(muse_ctx *ctx, const double *x, int32_t lenx, const double *y, int32_t leny, int32_t n,
+                          int32_t normalize, double *cc, int32_t *lag, double *mv, int32_t *is_nil)
+{
+    const int32_t minn = std::max(lenx, leny); // xcorr.go:104-106
+    if (n < minn)
+        n = minn;
+    // xcorr.go:139-143: 1/(n(n-1)) when normalized, else 1/n
+    const double cc_scale = normalize ? 1.0 / ((double)n * (double)(n - 1)) : 1.0 / (double)n;
+    return single_pair(ctx, x, lenx, y, leny, n, normalize, normalize, 1.0, cc_scale, cc, lag, mv, is_nil);
+}

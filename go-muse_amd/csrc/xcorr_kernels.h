@@ -1,0 +1,73 @@
+// xcorr_kernels.h -- host-visible launch interface of the device code
+// (internal to libmuse_hip.so; the public ABI is include/muse_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "muse_hip.h"
+
+namespace muse {
+
+enum { KERNEL_GENERIC = 0, KERNEL_R16_N4096 = 1 };
+
+struct FusedParams {
+    const double *rows; // M x N row-major, row stride `stride` doubles
+    long long M;
+    long long stride;
+    long long npairs; // ceil(M/2): one workgroup pass handles two series
+    int N;            // series length
+    int n;            // FFT length (power of two >= N)
+    int logn;
+    int normalize_y;     // 1: zNormalize each series (xCorrWithX, xCorr normalize=true)
+    const double2 *xc;   // n entries: conj(X_full[f]) * scale
+    const double2 *tw1;  // [16][256] W_4096^(k*t)      (tuned kernel)
+    const double2 *tw2;  // [16][16]  W_256^(k*c)       (tuned kernel)
+    const double2 *twm;  // [4096]    W_8192^k          (generic kernel)
+    double *mv;          // out: M signed max values
+    int *lag;            // out: M lags
+    double *cc_out;      // optional (generic kernel only): M x n correlations
+    int *nil_out;        // optional (generic kernel only): M flags, 1 = sigma == 0 -> (nil,0,0)
+};
+
+hipError_t launch_fused(const FusedParams &p, int variant, int num_cus, hipStream_t stream);
+hipError_t launch_ref_spectrum(const double *ref_dev, int N, int n, int logn, int normalize, double x_scale,
+                               double xc_scale, const double2 *twm, double2 *X, double2 *xc, int *status,
+                               hipStream_t stream);
+hipError_t launch_direct(const double *x, int lenx, const double *y, int leny, int n, int normalize_x,
+                         int normalize_y, double x_scale, double cc_scale, double *cc, int *lag, double *mv,
+                         int *status, hipStream_t stream);
+hipError_t launch_synth(double *rows, long long stride, long long first, long long count, long long global_first,
+                        int N, unsigned long long seed, hipStream_t stream);
+hipError_t launch_synth_ref(double *ref, int N, unsigned long long seed, hipStream_t stream);
+
+// ---- group max / filter / top-N (reduce_kernels.hip)
+constexpr int TOPN_CHUNK = 4096;    // groups per workgroup in the selection pass
+constexpr int TOPN_DEVICE_MAX = 256; // larger top_n: winners are copied to the host instead
+
+struct GroupWork {
+    unsigned long long *key; // [G] max of bits(|score|) over members (atomicMax)
+    long long *first;        // [G] lowest member index (atomicMin)
+    long long *win;          // [G] lowest member index attaining key (atomicMin)
+};
+
+struct SelectParams {
+    const double *mv;
+    const int *lag;
+    long long M;
+    const int *group_id; // device, or nullptr: every series its own group
+    int G;
+    int abs_scores;
+    int max_lag;
+    double threshold;
+    int sign_filter;
+    long long series_offset;
+};
+
+// per-group winners -> rec[G] (+ selection keys selkey[G]: 0 = filtered out)
+hipError_t launch_group_reduce(const SelectParams &sp, const GroupWork &gw, muse_record *rec,
+                               unsigned long long *selkey, hipStream_t stream);
+// per-chunk top-K extraction: cand[nblocks*K], cnt[nblocks]
+hipError_t launch_topn(const muse_record *rec, const unsigned long long *selkey, int G, int K, muse_record *cand,
+                       int *cnt, hipStream_t stream);
+
+} // namespace muse

@@ -1,0 +1,769 @@
+// xcorr_kernels.hip -- gfx950 (MI355X / CDNA4) device code for go-muse's
+// z-normalized cross-correlation hot path.
+//
+// What one launch of the fused kernel computes, per comparison series y
+// (reference: /root/reference/xcorr.go:160-197 xCorrWithX, called from
+// muse_batch.go:73 and muse.go:71):
+//     y  <- zNormalize(y)                      xcorr.go:164  (84-95)
+//     s  <- [0 ... 0 | y]  (leading zeros)     xcorr.go:176-181
+//     C  <- conj(FFT(s)) * X                   xcorr.go:183-185
+//     cc <- IFFT(C) / n                        xcorr.go:186-187
+//     mi <- first index of max |cc|; mv=cc[mi] xcorr.go:189-190 (39-50)
+//     lag <- mi > n/2 ? mi - n : mi            xcorr.go:192-194
+// and emits (lag, mv); sigma == 0 gives (0, 0.0) (xcorr.go:166-167).
+//
+// MI355X-first formulation (no rocFFT/hipFFT, no MFMA: add-heavy fp64
+// butterflies on the VALU, data staged through LDS, one coalesced pass over
+// the HBM-resident matrix):
+//   * two real series are packed as one complex signal z = yA + i*yB.  With
+//     Z = FFT(z):  FFT(Z[f] * conj(X[f]) / n)[k] = ccA[k] + i*ccB[k], so a
+//     pair of series costs two FORWARD complex FFTs of length n and no
+//     real-FFT untangling pass; the table xc[f] = conj(X_full[f])/n is
+//     precomputed per batch (1/n is a power of two: exact).
+//   * tuned n = 4096 kernel: 256 threads hold 16 complex points each; the FFT
+//     is three radix-16 passes in registers with two LDS transposes (b128,
+//     conflict-free by construction, see exchange comments); thread t starts
+//     and ends with elements t + 256*a, so global loads are coalesced and the
+//     second FFT consumes the first one's output layout directly.
+//   * generic kernel: any power-of-two n <= 8192, in-place radix-2 DIF then
+//     DIT in LDS (bit-reversed middle, no reorder pass).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "xcorr_kernels.h"
+
+namespace muse {
+
+// ------------------------------------------------------------ small helpers
+__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ double2 cmul(double2 a, double2 b)
+{
+    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_min_i(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Block-wide sums of K doubles for a 256-thread block (4 waves).  Every
+// thread returns the same bits (fixed summation order).  `scratch` must hold
+// 4*K doubles that no other reduction is using concurrently.
+template <int K>
+__device__ __forceinline__ void block_sum(double (&v)[K], double *scratch)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        double s = wave_sum(v[k]);
+        if (lane == 0)
+            scratch[wave * K + k] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; k++)
+        v[k] = (scratch[0 * K + k] + scratch[1 * K + k]) + (scratch[2 * K + k] + scratch[3 * K + k]);
+}
+
+// z-normalisation constants from block totals (xcorr.go:84-95 with the
+// centred second pass of gonum stat.StdDev): returns 1/sigma, sets flags.
+struct ZnFlags {
+    bool zero; // sigma == 0  -> (nil,0,0)
+    bool nan;  // sigma is NaN -> every cc is NaN -> (lag 0, mv NaN)
+};
+__device__ __forceinline__ double zn_scale(double s1, double s2, int N, ZnFlags &f)
+{
+    const double n = (double)N;
+    double var = (s2 - s1 * s1 / n) / (double)(N - 1);
+    double sd = sqrt(var);
+    f.zero = (sd == 0.0);
+    f.nan = (sd != sd);
+    return (f.zero || f.nan) ? 0.0 : 1.0 / sd;
+}
+
+// ===================================================== tuned n = 4096 kernel
+// 16-point DFT in registers: two radix-4 layers.  Input x[a] at v[a]; output
+// X[k] at v[P16(k)], P16(k) = 4*(k&3) + (k>>2) (an involution).
+#define P16(k) ((((k)&3) << 2) | ((k) >> 2))
+
+__device__ __forceinline__ void radix4(double2 &a, double2 &b, double2 &c, double2 &d)
+{
+    double2 t0 = cadd(a, c), t1 = csub(a, c), t2 = cadd(b, d), t3 = csub(b, d);
+    a = cadd(t0, t2);
+    c = csub(t0, t2);
+    b = make_double2(t1.x + t3.y, t1.y - t3.x); // t1 - i*t3
+    d = make_double2(t1.x - t3.y, t1.y + t3.x); // t1 + i*t3
+}
+
+__device__ __forceinline__ void dft16(double2 (&v)[16])
+{
+    constexpr double C1 = 0.92387953251128675613; // cos(pi/8)
+    constexpr double S1 = 0.38268343236508977173; // sin(pi/8)
+    constexpr double H = 0.70710678118654752440;  // sqrt(1/2)
+    // layer 1: over a1 (stride 4): v[a0 + 4*k1] = y[a0][k1]
+#pragma unroll
+    for (int a0 = 0; a0 < 4; a0++)
+        radix4(v[a0], v[a0 + 4], v[a0 + 8], v[a0 + 12]);
+    // internal twiddles W16^(a0*k1)
+    double2 u;
+    // a0 = 1: k1 = 1,2,3 -> W1, W2, W3
+    u = v[1 + 4];  v[1 + 4]  = make_double2(u.x * C1 + u.y * S1, u.y * C1 - u.x * S1);
+    u = v[1 + 8];  v[1 + 8]  = make_double2((u.x + u.y) * H, (u.y - u.x) * H);
+    u = v[1 + 12]; v[1 + 12] = make_double2(u.x * S1 + u.y * C1, u.y * S1 - u.x * C1);
+    // a0 = 2: W2, W4, W6
+    u = v[2 + 4];  v[2 + 4]  = make_double2((u.x + u.y) * H, (u.y - u.x) * H);
+    u = v[2 + 8];  v[2 + 8]  = make_double2(u.y, -u.x);
+    u = v[2 + 12]; v[2 + 12] = make_double2((u.y - u.x) * H, -(u.x + u.y) * H);
+    // a0 = 3: W3, W6, W9
+    u = v[3 + 4];  v[3 + 4]  = make_double2(u.x * S1 + u.y * C1, u.y * S1 - u.x * C1);
+    u = v[3 + 8];  v[3 + 8]  = make_double2((u.y - u.x) * H, -(u.x + u.y) * H);
+    u = v[3 + 12]; v[3 + 12] = make_double2(-u.x * C1 - u.y * S1, u.x * S1 - u.y * C1);
+    // layer 2: over a0: v[4*k1 + k0] = X[4*k0 + k1]
+#pragma unroll
+    for (int k1 = 0; k1 < 4; k1++)
+        radix4(v[4 * k1], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);
+}
+
+constexpr int R16_THREADS = 256;
+constexpr int R16_LDS = 16 * 272; // double2 elements: 69,632 B
+
+// Forward FFT of 4096 points spread as v[a] = x[t + 256*a]; on return
+// v[a] = X[t + 256*a].  `lds` is the R16_LDS exchange buffer.
+__device__ __forceinline__ void fft4096(double2 (&v)[16], double2 *lds, const double2 *__restrict__ tw1,
+                                        const double2 *__restrict__ tw2, const int t)
+{
+    const int hi = t >> 4, lo = t & 15;
+    // ---- pass 1: DFT over a, twiddle W_4096^(k1 * t)
+    dft16(v);
+#pragma unroll
+    for (int k = 1; k < 16; k++)
+        v[P16(k)] = cmul(v[P16(k)], tw1[k * 256 + t]);
+    // ---- exchange A: (k1 | b,c) -> (b | k1,c).  pos = 256*k1 + 16*b + c.
+    // writes: consecutive lanes -> consecutive 16-B slots; reads: slot index
+    // == lane (mod 16): conflict-free for ds_write_b128 / ds_read_b128.
+    __syncthreads(); // previous readers of the buffer are done
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        lds[256 * k + t] = v[P16(k)];
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 16; b++)
+        v[b] = lds[256 * hi + 16 * b + lo];
+    // ---- pass 2: DFT over b (this thread: k1 = hi, c = lo), twiddle W_256^(k2*c)
+    dft16(v);
+#pragma unroll
+    for (int k = 1; k < 16; k++)
+        v[P16(k)] = cmul(v[P16(k)], tw2[k * 16 + lo]);
+    // ---- exchange B: (k2 | k1,c) -> (c | k1,k2).  pos = 272*k2 + 17*k1 + c
+    // (rows padded 16 -> 17 so the transposed read has slot == lane + c mod 16).
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        lds[272 * k + 17 * hi + lo] = v[P16(k)];
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 16; c++)
+        v[c] = lds[272 * hi + 17 * lo + c]; // this thread: k1 = lo, k2 = hi
+    // ---- pass 3: DFT over c; frequency f = k1 + 16*k2 + 256*k3 = t + 256*k3
+    dft16(v);
+    // un-permute (register renaming only)
+    double2 w[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        w[k] = v[P16(k)];
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        v[k] = w[k];
+}
+
+__global__ __launch_bounds__(R16_THREADS, 2) void xcorr_fused_n4096(const FusedParams p)
+{
+    __shared__ double2 lds[R16_LDS];
+    __shared__ double red[64];
+    __shared__ int redi[16];
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int N = p.N;
+    const int pad = 4096 - N;
+
+    for (long long pair = blockIdx.x; pair < p.npairs; pair += gridDim.x) {
+        const long long rA = 2 * pair, rB = rA + 1;
+        const bool hasB = rB < p.M;
+        const double *__restrict__ ra = p.rows + rA * p.stride;
+        const double *__restrict__ rb = p.rows + (hasB ? rB : rA) * p.stride;
+
+        // ---- coalesced load: element t + 256*a of the zero-padded rows
+        double2 v[16];
+#pragma unroll
+        for (int a = 0; a < 16; a++) {
+            const int j = t + 256 * a - pad;
+            double xa = 0.0, xb = 0.0;
+            if (j >= 0) {
+                xa = ra[j];
+                xb = rb[j];
+            }
+            v[a] = make_double2(xa, hasB ? xb : 0.0);
+        }
+        // ---- zNormalize both series (xcorr.go:84-95)
+        double s[2] = {0.0, 0.0};
+#pragma unroll
+        for (int a = 0; a < 16; a++) {
+            s[0] += v[a].x;
+            s[1] += v[a].y;
+        }
+        block_sum<2>(s, red);
+        const double ca = -s[0] / (double)N, cb = -s[1] / (double)N;
+        double q[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int a = 0; a < 16; a++) {
+            if (t + 256 * a - pad >= 0) {
+                v[a].x += ca;
+                v[a].y += cb;
+            }
+            q[0] += v[a].x;
+            q[1] = fma(v[a].x, v[a].x, q[1]);
+            q[2] += v[a].y;
+            q[3] = fma(v[a].y, v[a].y, q[3]);
+        }
+        block_sum<4>(q, red + 8);
+        ZnFlags fa, fb;
+        const double ia = zn_scale(q[0], q[1], N, fa);
+        const double ib = zn_scale(q[2], q[3], N, fb);
+#pragma unroll
+        for (int a = 0; a < 16; a++) {
+            v[a].x *= ia;
+            v[a].y *= ib;
+        }
+        // ---- Z = FFT(yA + i yB)
+        fft4096(v, lds, p.tw1, p.tw2, t);
+        // ---- V[f] = Z[f] * conj(X[f]) / n      (f = t + 256*k)
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            v[k] = cmul(v[k], p.xc[t + 256 * k]);
+        // ---- ccA + i ccB = FFT(V)
+        fft4096(v, lds, p.tw1, p.tw2, t);
+
+        // ---- maxAbsIndex (xcorr.go:39-50) for both series: index = t + 256*k
+        double ma = 0.0, mb = 0.0, sa = 0.0, sb = 0.0;
+        int ka = 0, kb = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const double aa = fabs(v[k].x), ab = fabs(v[k].y);
+            if (aa > ma) { ma = aa; sa = v[k].x; ka = k; }
+            if (ab > mb) { mb = ab; sb = v[k].y; kb = k; }
+        }
+        double wa = wave_max(ma), wb = wave_max(mb);
+        if (lane == 0) {
+            red[32 + wave] = wa;
+            red[36 + wave] = wb;
+        }
+        __syncthreads();
+        const double MA = fmax(fmax(red[32], red[33]), fmax(red[34], red[35]));
+        const double MB = fmax(fmax(red[36], red[37]), fmax(red[38], red[39]));
+        int ca_i = (ma == MA && MA > 0.0) ? (t + 256 * ka) : 0x7fffffff;
+        int cb_i = (mb == MB && MB > 0.0) ? (t + 256 * kb) : 0x7fffffff;
+        ca_i = wave_min_i(ca_i);
+        cb_i = wave_min_i(cb_i);
+        if (lane == 0) {
+            redi[wave] = ca_i;
+            redi[4 + wave] = cb_i;
+        }
+        __syncthreads();
+        const int IA = min(min(redi[0], redi[1]), min(redi[2], redi[3]));
+        const int IB = min(min(redi[4], redi[5]), min(redi[6], redi[7]));
+        // owner thread writes (lag, mv)
+        {
+            const bool none = (IA == 0x7fffffff); // all |cc| == 0 or NaN: index 0, mv = cc[0]
+            const int idx = none ? 0 : IA;
+            if (t == (idx & 255)) {
+                double mv = none ? v[0].x : sa;
+                int lag = idx > 2048 ? idx - 4096 : idx;
+                if (fa.zero) { mv = 0.0; lag = 0; }
+                if (fa.nan) { mv = __builtin_nan(""); lag = 0; }
+                p.mv[rA] = mv;
+                p.lag[rA] = lag;
+            }
+        }
+        if (hasB) {
+            const bool none = (IB == 0x7fffffff);
+            const int idx = none ? 0 : IB;
+            if (t == (idx & 255)) {
+                double mv = none ? v[0].y : sb;
+                int lag = idx > 2048 ? idx - 4096 : idx;
+                if (fb.zero) { mv = 0.0; lag = 0; }
+                if (fb.nan) { mv = __builtin_nan(""); lag = 0; }
+                p.mv[rB] = mv;
+                p.lag[rB] = lag;
+            }
+        }
+    }
+}
+
+// ======================================================== generic kernel
+// Any power-of-two n in [2, 8192].  Dynamic LDS: n double2 + 64 doubles.
+// In-place radix-2 DIF (natural -> bit-reversed), multiply by xc[brev],
+// in-place radix-2 DIT (bit-reversed -> natural).  twm = exp(-2 pi i k/8192).
+
+__device__ __forceinline__ void lds_dif(double2 *z, int n, int logn, const double2 *__restrict__ twm)
+{
+    const int T = blockDim.x;
+    for (int lh = logn - 1; lh >= 0; lh--) {
+        const int half = 1 << lh;
+        for (int j = threadIdx.x; j < (n >> 1); j += T) {
+            const int pos = j & (half - 1);
+            const int i0 = ((j >> lh) << (lh + 1)) + pos, i1 = i0 + half;
+            const double2 a = z[i0], b = z[i1];
+            z[i0] = cadd(a, b);
+            // W_{2*half}^pos = W_8192^(pos * 8192/(2*half))
+            z[i1] = cmul(csub(a, b), twm[pos << (12 - lh)]);
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ void lds_dit(double2 *z, int n, int logn, const double2 *__restrict__ twm)
+{
+    const int T = blockDim.x;
+    for (int lh = 0; lh < logn; lh++) {
+        const int half = 1 << lh;
+        for (int j = threadIdx.x; j < (n >> 1); j += T) {
+            const int pos = j & (half - 1);
+            const int i0 = ((j >> lh) << (lh + 1)) + pos, i1 = i0 + half;
+            const double2 a = z[i0], b = cmul(z[i1], twm[pos << (12 - lh)]);
+            z[i0] = cadd(a, b);
+            z[i1] = csub(a, b);
+        }
+        __syncthreads();
+    }
+}
+
+// loads (and optionally z-normalises) up to two rows into z[] as re/im,
+// right-aligned in n (leading zeros).  Returns flags through fa/fb.
+__device__ __forceinline__ void lds_load_znorm(double2 *z, double *red, const double *__restrict__ ra,
+                                               const double *__restrict__ rb, bool hasB, int N, int n,
+                                               bool normalize, double post_scale_a, ZnFlags &fa, ZnFlags &fb)
+{
+    const int T = blockDim.x, t = threadIdx.x;
+    const int pad = n - N;
+    double s[2] = {0.0, 0.0};
+    for (int i = t; i < n; i += T) {
+        const int j = i - pad;
+        double xa = 0.0, xb = 0.0;
+        if (j >= 0) {
+            xa = ra[j];
+            if (hasB)
+                xb = rb[j];
+        }
+        z[i] = make_double2(xa, xb);
+        s[0] += xa;
+        s[1] += xb;
+    }
+    fa.zero = fa.nan = fb.zero = fb.nan = false;
+    if (normalize) {
+        block_sum<2>(s, red);
+        const double ca = -s[0] / (double)N, cb = -s[1] / (double)N;
+        double q[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int i = t; i < n; i += T) {
+            if (i - pad >= 0) {
+                double2 e = z[i];
+                e.x += ca;
+                e.y += cb;
+                z[i] = e;
+                q[0] += e.x;
+                q[1] = fma(e.x, e.x, q[1]);
+                q[2] += e.y;
+                q[3] = fma(e.y, e.y, q[3]);
+            }
+        }
+        block_sum<4>(q, red + 8);
+        const double ia = zn_scale(q[0], q[1], N, fa) * post_scale_a;
+        const double ib = zn_scale(q[2], q[3], N, fb);
+        for (int i = t; i < n; i += T) {
+            double2 e = z[i];
+            e.x *= ia;
+            e.y *= ib;
+            z[i] = e;
+        }
+    }
+    __syncthreads();
+}
+
+// block argmax over z[i].x (sel=0) or z[i].y (sel=1): first index of max |.|
+__device__ __forceinline__ void lds_argmax(const double2 *z, double *red, int *redi, int n, int sel, int &idx,
+                                           double &mv)
+{
+    const int T = blockDim.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    double m = 0.0;
+    int mi = 0x7fffffff;
+    for (int i = t; i < n; i += T) {
+        const double a = fabs(sel ? z[i].y : z[i].x);
+        if (a > m) {
+            m = a;
+            mi = i;
+        }
+    }
+    double wm = wave_max(m);
+    if (lane == 0)
+        red[32 + wave] = wm;
+    __syncthreads();
+    const double M = fmax(fmax(red[32], red[33]), fmax(red[34], red[35]));
+    int c = (m == M && M > 0.0) ? mi : 0x7fffffff;
+    c = wave_min_i(c);
+    if (lane == 0)
+        redi[wave] = c;
+    __syncthreads();
+    int I = min(min(redi[0], redi[1]), min(redi[2], redi[3]));
+    if (I == 0x7fffffff)
+        I = 0;
+    idx = I;
+    mv = sel ? z[I].y : z[I].x;
+    __syncthreads(); // red/redi free for the next call
+}
+
+__global__ __launch_bounds__(256) void xcorr_fused_generic(const FusedParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double2 *z = reinterpret_cast<double2 *>(smem_raw);
+    double *red = reinterpret_cast<double *>(z + p.n);
+    int *redi = reinterpret_cast<int *>(red + 48);
+    const int n = p.n, logn = p.logn, N = p.N, t = threadIdx.x;
+
+    for (long long pair = blockIdx.x; pair < p.npairs; pair += gridDim.x) {
+        const long long rA = 2 * pair, rB = rA + 1;
+        const bool hasB = rB < p.M;
+        ZnFlags fa, fb;
+        lds_load_znorm(z, red, p.rows + rA * p.stride, p.rows + (hasB ? rB : rA) * p.stride, hasB, N, n,
+                       p.normalize_y != 0, 1.0, fa, fb);
+        lds_dif(z, n, logn, p.twm);
+        for (int q = t; q < n; q += blockDim.x) {
+            const int f = (int)(__brev((unsigned)q) >> (32 - logn));
+            z[q] = cmul(z[q], p.xc[f]);
+        }
+        __syncthreads();
+        lds_dit(z, n, logn, p.twm);
+        if (p.cc_out) { // debug: full correlation of this pair
+            for (int i = t; i < n; i += blockDim.x) {
+                p.cc_out[rA * (long long)n + i] = z[i].x;
+                if (hasB)
+                    p.cc_out[rB * (long long)n + i] = z[i].y;
+            }
+        }
+        int idx;
+        double mv;
+        lds_argmax(z, red, redi, n, 0, idx, mv);
+        if (t == 0) {
+            int lag = idx > n / 2 ? idx - n : idx;
+            if (fa.zero) { mv = 0.0; lag = 0; }
+            if (fa.nan) { mv = __builtin_nan(""); lag = 0; }
+            p.mv[rA] = mv;
+            p.lag[rA] = lag;
+            if (p.nil_out)
+                p.nil_out[rA] = fa.zero ? 1 : 0;
+        }
+        if (hasB) {
+            lds_argmax(z, red, redi, n, 1, idx, mv);
+            if (t == 0) {
+                int lag = idx > n / 2 ? idx - n : idx;
+                if (fb.zero) { mv = 0.0; lag = 0; }
+                if (fb.nan) { mv = __builtin_nan(""); lag = 0; }
+                p.mv[rB] = mv;
+                p.lag[rB] = lag;
+                if (p.nil_out)
+                    p.nil_out[rB] = fb.zero ? 1 : 0;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------ reference spectrum kernel
+// NewBatch precompute (muse_batch.go:35-47): x = zNormalize(ref)/(N-1),
+// leading-zero pad to n, FFT.  One workgroup.  Writes
+//   X[f], f <= n/2           (the batch's x, for muse_batch_spectrum)
+//   xc[f] = conj(X_full[f]) * xc_scale, f < n   (table the fused kernels use)
+// status[0] = 1 when sigma == 0 (or NaN) with normalize set.
+__global__ __launch_bounds__(256) void ref_spectrum_kernel(const double *__restrict__ ref, int N, int n, int logn,
+                                                           int normalize, double x_scale, double xc_scale,
+                                                           const double2 *__restrict__ twm, double2 *X,
+                                                           double2 *xc, int *status)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double2 *z = reinterpret_cast<double2 *>(smem_raw);
+    double *red = reinterpret_cast<double *>(z + n);
+    ZnFlags fa, fb;
+    // post scale 1/(N-1) on the real part (muse_batch.go:42)
+    lds_load_znorm(z, red, ref, ref, false, N, n, normalize != 0, x_scale, fa, fb);
+    if (!normalize && x_scale != 1.0) {
+        for (int i = threadIdx.x; i < n; i += blockDim.x)
+            z[i].x *= x_scale;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        status[0] = (fa.zero || fa.nan) ? 1 : 0;
+    lds_dif(z, n, logn, twm);
+    for (int q = threadIdx.x; q < n; q += blockDim.x) {
+        const int f = (int)(__brev((unsigned)q) >> (32 - logn));
+        const double2 v = z[q];
+        if (f <= n / 2)
+            X[f] = v;
+        xc[f] = make_double2(v.x * xc_scale, -v.y * xc_scale);
+    }
+}
+
+// --------------------------------------------------- direct O(n^2) kernel
+// Single pair, any n (used by the debug entry points when n is not a power of
+// two, e.g. the n = 5 known-answer tables of xcorr_test.go).  One workgroup.
+//   cc[k] = scale * sum_j y_pad[j] * x_pad[(j + k) mod n]
+__global__ __launch_bounds__(256) void xcorr_direct_kernel(const double *__restrict__ x, int lenx,
+                                                           const double *__restrict__ y, int leny, int n,
+                                                           int normalize_x, int normalize_y, double x_scale,
+                                                           double cc_scale, double *cc, int *lag_out, double *mv_out,
+                                                           int *status)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double *xs = reinterpret_cast<double *>(smem_raw);
+    double *ys = xs + n;
+    double *red = ys + n;
+    const int T = blockDim.x, t = threadIdx.x;
+    int nil = 0;
+    for (int which = 0; which < 2; which++) {
+        const double *src = which ? y : x;
+        double *dst = which ? ys : xs;
+        const int len = which ? leny : lenx;
+        const int pad = n - len;
+        const bool norm = which ? normalize_y : normalize_x;
+        double s[2] = {0.0, 0.0};
+        for (int i = t; i < n; i += T) {
+            const int j = i - pad;
+            const double e = j >= 0 ? src[j] : 0.0;
+            dst[i] = e;
+            s[0] += e;
+        }
+        double scale = which ? 1.0 : x_scale;
+        if (norm) {
+            block_sum<2>(s, red);
+            const double c = -s[0] / (double)len;
+            double q[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int i = t; i < n; i += T) {
+                if (i - pad >= 0) {
+                    const double e = dst[i] + c;
+                    dst[i] = e;
+                    q[0] += e;
+                    q[1] = fma(e, e, q[1]);
+                }
+            }
+            block_sum<4>(q, red + 8);
+            ZnFlags f;
+            scale *= zn_scale(q[0], q[1], len, f);
+            if (f.zero || f.nan)
+                nil = 1;
+            __syncthreads();
+        }
+        for (int i = t; i < n; i += T)
+            dst[i] *= scale;
+        __syncthreads();
+    }
+    for (int k = t; k < n; k += T) {
+        double acc = 0.0;
+        for (int j = 0; j < n; j++) {
+            int q = j + k;
+            if (q >= n)
+                q -= n;
+            acc = fma(ys[j], xs[q], acc);
+        }
+        cc[k] = acc * cc_scale;
+    }
+    __syncthreads();
+    if (t == 0) {
+        int mi = 0;
+        double mval = 0.0;
+        for (int i = 0; i < n; i++) { // xcorr.go:39-50
+            const double v = cc[i];
+            if (fabs(v) > fabs(mval)) {
+                mval = v;
+                mi = i;
+            }
+        }
+        double mv = cc[mi];
+        if (mi > n / 2)
+            mi -= n;
+        if (nil) {
+            mi = 0;
+            mv = 0.0;
+        }
+        *lag_out = mi;
+        *mv_out = mv;
+        *status = nil;
+    }
+}
+
+// -------------------------------------------------- synthetic rect + noise
+// SURVEY 8d workload, after example_test.go:15-20: y[t] = A*1[|t-c| <= w/2]
+// + 0.1*g(row,t).  Counter-based: every value is a pure function of
+// (seed, global row, t).  Row kinds: 1/1024 constant rows (sigma == 0 path),
+// 1/1024 exact copies of the reference (score 1, lag 0).
+__device__ __forceinline__ uint64_t mix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__device__ __forceinline__ double gauss(uint64_t seed, uint64_t row, uint64_t t)
+{
+    const uint64_t h = mix64(mix64(seed ^ (row * 0xD1342543DE82EF95ull)) ^ t);
+    const uint64_t h2 = mix64(h);
+    const double u1 = ((double)(h >> 11) + 1.0) * (1.0 / 9007199254740993.0); // (0,1)
+    const double u2 = (double)(h2 >> 11) * (1.0 / 9007199254740992.0);        // [0,1)
+    return sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
+}
+__device__ __forceinline__ double synth_value(uint64_t seed, long long grow, int t, int N)
+{
+    const uint64_t REF_ROW = 0xFFFFFFFFFFFFFFFFull;
+    uint64_t row = (uint64_t)grow;
+    if (grow >= 0) {
+        const uint64_t kind = mix64(seed ^ (row * 0xA24BAED4963EE407ull)) & 1023ull;
+        if (kind == 0) // constant row, dyadic value: sum and mean are exact
+            return 0.5 * (double)(1 + (row % 7));
+        if (kind == 1)
+            row = REF_ROW;
+    } else {
+        row = REF_ROW;
+    }
+    double A, c, w;
+    if (row == REF_ROW) {
+        A = 1.5;
+        c = (double)(N / 2);
+        w = 10.0;
+    } else {
+        const uint64_t h = mix64(seed ^ (row * 0x9FB21C651E98DF25ull));
+        const double ua = (double)(h & 0xFFFF) / 65536.0;
+        const double uc = (double)((h >> 16) & 0xFFFF) / 65536.0;
+        const int iw = 4 + (int)((h >> 32) % 61);
+        A = 0.5 + ua * 42.5;
+        if ((h >> 48) & 1)
+            A = -A;
+        c = (double)(N / 4) + floor(uc * (double)(N / 2));
+        w = (double)iw;
+    }
+    const double rect = (fabs((double)t - c) <= 0.5 * w) ? A : 0.0;
+    return rect + 0.1 * gauss(seed, row, (uint64_t)t);
+}
+
+__global__ void synth_fill_kernel(double *rows, long long stride, long long first, long long count,
+                                  long long global_first, int N, unsigned long long seed)
+{
+    const long long total = count * (long long)N;
+    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+         e += (long long)gridDim.x * blockDim.x) {
+        const long long r = e / N;
+        const int t = (int)(e - r * N);
+        rows[(first + r) * stride + t] = synth_value(seed, global_first + r, t, N);
+    }
+}
+__global__ void synth_ref_kernel(double *ref, int N, unsigned long long seed)
+{
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < N; t += gridDim.x * blockDim.x)
+        ref[t] = synth_value(seed, -1, t, N);
+}
+
+// ----------------------------------------------------------- host launchers
+hipError_t launch_fused(const FusedParams &p, int variant, int num_cus, hipStream_t stream)
+{
+    if (p.npairs <= 0)
+        return hipSuccess;
+    if (variant == KERNEL_R16_N4096) {
+        long long grid = p.npairs;
+        const long long cap = (long long)num_cus * 2 * 8; // persistent-ish: grid-stride beyond this
+        if (grid > cap)
+            grid = cap;
+        hipLaunchKernelGGL(xcorr_fused_n4096, dim3((unsigned)grid), dim3(R16_THREADS), 0, stream, p);
+        return hipGetLastError();
+    }
+    const size_t lds = (size_t)p.n * sizeof(double2) + 64 * sizeof(double);
+    static size_t configured = 0;
+    if (lds > 64 * 1024 && lds > configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(xcorr_fused_generic),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess)
+            return e;
+        configured = lds;
+    }
+    long long grid = p.npairs;
+    const long long cap = (long long)num_cus * 16;
+    if (grid > cap)
+        grid = cap;
+    hipLaunchKernelGGL(xcorr_fused_generic, dim3((unsigned)grid), dim3(256), lds, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_ref_spectrum(const double *ref_dev, int N, int n, int logn, int normalize, double x_scale,
+                               double xc_scale, const double2 *twm, double2 *X, double2 *xc, int *status,
+                               hipStream_t stream)
+{
+    const size_t lds = (size_t)n * sizeof(double2) + 64 * sizeof(double);
+    static size_t configured = 0;
+    if (lds > 64 * 1024 && lds > configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ref_spectrum_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess)
+            return e;
+        configured = lds;
+    }
+    hipLaunchKernelGGL(ref_spectrum_kernel, dim3(1), dim3(256), lds, stream, ref_dev, N, n, logn, normalize, x_scale,
+                       xc_scale, twm, X, xc, status);
+    return hipGetLastError();
+}
+
+hipError_t launch_direct(const double *x, int lenx, const double *y, int leny, int n, int normalize_x,
+                         int normalize_y, double x_scale, double cc_scale, double *cc, int *lag, double *mv,
+                         int *status, hipStream_t stream)
+{
+    const size_t lds = (size_t)n * 2 * sizeof(double) + 64 * sizeof(double);
+    static size_t configured = 0;
+    if (lds > 64 * 1024 && lds > configured) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(xcorr_direct_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess)
+            return e;
+        configured = lds;
+    }
+    hipLaunchKernelGGL(xcorr_direct_kernel, dim3(1), dim3(256), lds, stream, x, lenx, y, leny, n, normalize_x,
+                       normalize_y, x_scale, cc_scale, cc, lag, mv, status);
+    return hipGetLastError();
+}
+
+hipError_t launch_synth(double *rows, long long stride, long long first, long long count, long long global_first,
+                        int N, unsigned long long seed, hipStream_t stream)
+{
+    if (count <= 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(synth_fill_kernel, dim3(4096), dim3(256), 0, stream, rows, stride, first, count, global_first,
+                       N, seed);
+    return hipGetLastError();
+}
+hipError_t launch_synth_ref(double *ref, int N, unsigned long long seed, hipStream_t stream)
+{
+    hipLaunchKernelGGL(synth_ref_kernel, dim3(16), dim3(256), 0, stream, ref, N, seed);
+    return hipGetLastError();
+}
+
+} // namespace muse

@@ -1,0 +1,571 @@
+"""Host-side mirror of go-muse's exported API for the Batch.Run / Muse.Run path,
+driving libmuse_hip.so through its C ABI.
+
+Names, argument meaning and error behaviour follow the reference
+(/root/reference): NewLabels/Labels (labels.go), NewSeries/Series (series.go),
+NewGroup/Group (group.go), NewResults/Results/Score (results.go, scores.go),
+NewBatch/Batch.Run (muse_batch.go:23,99), New/Muse.Run (muse.go:23,46).  Go's
+`(value, error)` returns become Python exceptions: MuseError for the errors the
+reference returns, ValueError for Group.Add's.  All arithmetic happens on the
+GPU; this layer does label bookkeeping only (the reference's L2).
+
+One documented difference: the reference's zNormalize overwrites the caller's
+slices in place (xcorr.go:86,93); this engine never mutates user
+data, so every Run behaves like the reference's FIRST Run on fresh inputs.
+"""
+import ctypes
+import math
+import uuid
+
+import numpy as np
+
+from . import binding as B
+from .binding import MuseError
+
+DefaultLabel = "uid"  # labels.go:7
+
+SignFilter_POS = 1   # results.go:22-26
+SignFilter_NEG = -1
+SignFilter_ANY = 0
+
+
+# ------------------------------------------------------------------ engine
+class Engine:
+    """One muse_ctx = one GPU."""
+
+    def __init__(self, device=0):
+        self._h = ctypes.c_void_p()
+        B.check(B.load().muse_ctx_create(int(device), ctypes.byref(self._h)))
+        self.device = int(device)
+
+    def close(self):
+        if self._h:
+            B.load().muse_ctx_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        B.check(B.load().muse_ctx_synchronize(self._h))
+
+    def device_info(self):
+        name = ctypes.create_string_buffer(128)
+        cus, hbm = ctypes.c_int32(0), ctypes.c_int64(0)
+        B.check(B.load().muse_ctx_device_info(self._h, name, 128, ctypes.byref(cus), ctypes.byref(hbm)))
+        return name.value.decode(), int(cus.value), int(hbm.value)
+
+    def set_kernel(self, variant):
+        B.check(B.load().muse_ctx_set_kernel(self._h, int(variant)))
+
+    def kernel_timing(self, enable):
+        B.check(B.load().muse_ctx_kernel_timing(self._h, 1 if enable else 0))
+
+    def kernel_time(self):
+        ms, cnt = ctypes.c_double(0), ctypes.c_int64(0)
+        B.check(B.load().muse_ctx_kernel_time(self._h, ctypes.byref(ms), ctypes.byref(cnt)))
+        return float(ms.value), int(cnt.value)
+
+    # single-pair entry points (xcorr_test.go-style known-answer access)
+    def xcorr_with_x(self, ref, y, n=None):
+        ref, y = B.as_f64(ref), B.as_f64(y)
+        N = len(y)
+        if n is None:
+            n = next_pow2(N)
+        cc = np.zeros(max(n, 1))
+        lag, nil, mv = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_double(0)
+        B.check(B.load().muse_xcorr_with_x(self._h, B.dptr(ref), B.dptr(y), N, int(n), B.dptr(cc),
+                                           ctypes.byref(lag), ctypes.byref(mv), ctypes.byref(nil)))
+        if nil.value:
+            return None, 0, 0.0
+        return cc, int(lag.value), float(mv.value)
+
+    def xcorr(self, x, y, n, normalize):
+        x, y = B.as_f64(x), B.as_f64(y)
+        nn = max(int(n), len(x), len(y))
+        cc = np.zeros(nn)
+        lag, nil, mv = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_double(0)
+        B.check(B.load().muse_xcorr(self._h, B.dptr(x), len(x), B.dptr(y), len(y), int(n),
+                                    1 if normalize else 0, B.dptr(cc), ctypes.byref(lag),
+                                    ctypes.byref(mv), ctypes.byref(nil)))
+        if nil.value:
+            return None, 0, 0.0
+        return cc, int(lag.value), float(mv.value)
+
+
+_engines = {}
+
+
+def get_engine(device=0):
+    if device not in _engines:
+        _engines[device] = Engine(device)
+    return _engines[device]
+
+
+def next_pow2(val):
+    """nextPowOf2, xcorr.go:19-24 (host-side scalar, same floating formula)."""
+    return int(B.load().muse_next_pow2(float(val)))
+
+
+class DeviceGroup:
+    """Device-resident M x N float64 matrix (muse_group)."""
+
+    def __init__(self, engine, N, capacity=0):
+        self.engine = engine
+        self._h = ctypes.c_void_p()
+        B.check(B.load().muse_group_create(engine._h, int(capacity), int(N), ctypes.byref(self._h)))
+        self.N = int(N)
+
+    @classmethod
+    def from_rows(cls, engine, rows):
+        rows = np.asarray(rows, dtype=np.float64)
+        if rows.ndim != 2:
+            raise ValueError("rows must be 2-D")
+        g = cls(engine, rows.shape[1], rows.shape[0])
+        g.append(rows)
+        return g
+
+    @classmethod
+    def synthetic(cls, engine, M, N, seed=0x6D757365, global_first=0):
+        """rect+noise workload generated on the device; returns (group, ref)."""
+        g = cls(engine, N, M)
+        ref = np.zeros(N)
+        B.check(B.load().muse_group_fill_synthetic(g._h, 0, int(M), int(global_first),
+                                                   ctypes.c_uint64(seed), B.dptr(ref)))
+        return g, ref
+
+    def append(self, rows):
+        rows = np.asarray(rows, dtype=np.float64)
+        if rows.ndim == 1:
+            rows = rows[None, :]
+        if rows.shape[0] == 0:
+            return
+        if rows.strides[1] != 8:
+            rows = np.ascontiguousarray(rows)
+        if rows.shape[1] != self.N:
+            raise MuseError(B.MUSE_ERR_LENGTH, "Timeseries has length %d, but current group has length %d"
+                            % (rows.shape[1], self.N))
+        stride = rows.strides[0] // 8 if rows.shape[0] > 1 else self.N
+        B.check(B.load().muse_group_append(self._h, rows.ctypes.data_as(B._dp), rows.shape[0], stride))
+
+    @property
+    def M(self):
+        m, n = ctypes.c_int64(0), ctypes.c_int32(0)
+        B.check(B.load().muse_group_shape(self._h, ctypes.byref(m), ctypes.byref(n)))
+        return int(m.value)
+
+    def read(self, first, count):
+        out = np.zeros((int(count), self.N))
+        B.check(B.load().muse_group_read(self._h, int(first), int(count), B.dptr(out)))
+        return out
+
+    def close(self):
+        if self._h:
+            B.load().muse_group_free(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceBatch:
+    """muse_batch: resident reference spectrum + per-series result buffers."""
+
+    def __init__(self, engine, dgroup, ref):
+        ref = B.as_f64(ref)
+        self.engine, self.dgroup = engine, dgroup
+        self._h = ctypes.c_void_p()
+        B.check(B.load().muse_batch_create(engine._h, dgroup._h, B.dptr(ref), len(ref), ctypes.byref(self._h)))
+        n = ctypes.c_int32(0)
+        B.check(B.load().muse_batch_fft_len(self._h, ctypes.byref(n)))
+        self.n = int(n.value)
+
+    def spectrum(self):
+        out = np.zeros(2 * (self.n // 2 + 1))
+        B.check(B.load().muse_batch_spectrum(self._h, B.dptr(out)))
+        return out[0::2] + 1j * out[1::2]
+
+    def score(self):
+        """enqueue the fused kernel (asynchronous)"""
+        B.check(B.load().muse_batch_score(self._h))
+
+    def scores(self):
+        M = self.dgroup.M
+        lag = np.zeros(M, dtype=np.int32)
+        mv = np.zeros(M)
+        B.check(B.load().muse_batch_scores(self._h, B.i32ptr(lag), B.dptr(mv)))
+        return lag, mv
+
+    def run(self, group_id=None, G=0, max_lag=10, top_n=20, threshold=0.0, sign_filter=0, abs_scores=True):
+        cap = max(int(top_n), 1)
+        o_s = np.zeros(cap, dtype=np.int64)
+        o_l = np.zeros(cap, dtype=np.int32)
+        o_v = np.zeros(cap)
+        cnt, mean = ctypes.c_int32(0), ctypes.c_double(0)
+        gid = None
+        if group_id is not None:
+            gid = np.ascontiguousarray(group_id, dtype=np.int32)
+        B.check(B.load().muse_batch_run(
+            self._h, B.i32ptr(gid) if gid is not None else None, int(G), int(max_lag), int(top_n),
+            float(threshold), int(sign_filter), 1 if abs_scores else 0,
+            B.i64ptr(o_s), B.i32ptr(o_l), B.dptr(o_v), ctypes.byref(cnt), ctypes.byref(mean)))
+        c = cnt.value
+        return o_s[:c].copy(), o_l[:c].copy(), o_v[:c].copy(), float(mean.value)
+
+    def run_shard(self, group_id=None, G=0, series_offset=0, max_lag=10, top_n=20, threshold=0.0,
+                  sign_filter=0, abs_scores=True):
+        """this shard's top-N candidates as a RECORD_DTYPE array (<= top_n)"""
+        rec = np.zeros(max(int(top_n), 1), dtype=B.RECORD_DTYPE)
+        cnt = ctypes.c_int32(0)
+        gid = None
+        if group_id is not None:
+            gid = np.ascontiguousarray(group_id, dtype=np.int32)
+        B.check(B.load().muse_batch_run_shard(
+            self._h, B.i32ptr(gid) if gid is not None else None, int(G), int(series_offset), int(max_lag),
+            int(top_n), float(threshold), int(sign_filter), 1 if abs_scores else 0,
+            B.recptr(rec), ctypes.byref(cnt)))
+        return rec[:cnt.value].copy()
+
+    def close(self):
+        if self._h:
+            B.load().muse_batch_free(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def merge_records(records, top_n):
+    """Results.Update/Fetch over gathered shard candidates (host only)."""
+    records = np.ascontiguousarray(records, dtype=B.RECORD_DTYPE)
+    cap = max(int(top_n), 1)
+    o_s = np.zeros(cap, dtype=np.int64)
+    o_l = np.zeros(cap, dtype=np.int32)
+    o_v = np.zeros(cap)
+    cnt, mean = ctypes.c_int32(0), ctypes.c_double(0)
+    B.check(B.load().muse_merge_records(B.recptr(records), len(records), int(top_n), B.i64ptr(o_s),
+                                        B.i32ptr(o_l), B.dptr(o_v), ctypes.byref(cnt), ctypes.byref(mean)))
+    c = cnt.value
+    return o_s[:c].copy(), o_l[:c].copy(), o_v[:c].copy(), float(mean.value)
+
+
+# --------------------------------------------------- labels.go / series.go
+class Labels:
+    def __init__(self, label_map):
+        self.labels = dict(label_map)
+        self.keys = sorted(self.labels)          # labels.go:21-29
+
+    def Len(self):
+        return len(self.labels)
+
+    def Keys(self):
+        return self.keys
+
+    def Get(self, key):                           # labels.go:44-49
+        if key in self.labels:
+            return self.labels[key], True
+        return "", False
+
+    def ID(self, labels=None):                    # labels.go:54-73
+        if not labels:
+            labels = self.Keys()
+        else:
+            labels.sort()                         # labels.go:59 sorts the caller's slice
+        return ",".join("%s:%s" % (k, self.labels[k]) for k in labels if k in self.labels)
+
+    def __eq__(self, other):
+        return isinstance(other, Labels) and self.labels == other.labels
+
+    def __repr__(self):
+        return "Labels(%r)" % (self.labels,)
+
+
+def NewLabels(label_map):
+    return Labels(label_map)
+
+
+class Series:
+    def __init__(self, y, labels=None):           # series.go:15-21
+        if labels is None or labels.Len() == 0:
+            labels = NewLabels({DefaultLabel: str(uuid.uuid4())})
+        self.y = np.asarray(y, dtype=np.float64)
+        self.labels = labels
+
+    def Length(self):
+        return int(self.y.shape[0])
+
+    def Values(self):
+        return self.y
+
+    def Labels(self):
+        return self.labels
+
+    def UID(self):                                # series.go:40-42
+        return self.labels.ID(self.labels.Keys())
+
+
+def NewSeries(y, labels=None):
+    return Series(y, labels)
+
+
+# ---------------------------------------------------------------- group.go
+class Group:
+    def __init__(self, name):
+        self.Name = name
+        self.n = 0
+        self.index = {}
+        self.registry = {}                        # uid -> Series, insertion ordered
+        self._dev = None                          # (engine, DeviceGroup, rows uploaded)
+
+    def Length(self):
+        return self.n
+
+    def Add(self, *series):                       # group.go:31-56
+        for s in series:
+            if len(s.labels.Keys()) == 0:
+                raise ValueError("Invalid Series with no labels, %r" % (s,))
+            uid = s.UID()
+            if uid in self.registry:
+                raise ValueError("Series with label:values, %s, already exists within group, %s"
+                                 % (uid, self.Name))
+            if len(self.registry) == 0:
+                self.n = s.Length()
+            elif s.Length() != self.n:
+                raise ValueError("Timeseries has length %d, but current group has length %d"
+                                 % (s.Length(), self.n))
+            self.registry[uid] = s
+
+    def FilterByLabelValues(self, labels):        # group.go:60-71
+        guid = labels.ID(labels.Keys())
+        return [self.registry[u] for u in self.index.get(guid, [])]
+
+    def indexLabelValues(self, groupByLabels):    # group.go:76-104
+        distinct = []
+        self.index = {}
+        groupByLabels = list(groupByLabels) if groupByLabels else []
+        for uid, s in self.registry.items():
+            if len(groupByLabels) != 0:
+                guid = s.labels.ID(groupByLabels)
+            else:
+                guid = uid
+                groupByLabels = list(s.Labels().Keys())   # group.go:88
+            if guid not in self.index:
+                lv = {}
+                for name in groupByLabels:
+                    v, ok = s.labels.Get(name)
+                    if ok:
+                        lv[name] = v
+                distinct.append(NewLabels(lv))
+                self.index[guid] = []
+            self.index[guid].append(uid)
+        return distinct
+
+    # --- device residency: the matrix is uploaded once and appended to
+    def _series_list(self):
+        return list(self.registry.values())
+
+    def _device_group(self, engine):
+        ser = self._series_list()
+        if self._dev is None or self._dev[0] is not engine:
+            self._dev = [engine, DeviceGroup(engine, self.n, len(ser)), 0]
+        _, dg, done = self._dev
+        if done < len(ser):
+            dg.append(np.stack([s.y for s in ser[done:]]))
+            self._dev[2] = len(ser)
+        return dg
+
+
+def NewGroup(name):
+    return Group(name)
+
+
+# --------------------------------------------------- scores.go / results.go
+class Score:
+    __slots__ = ("Labels", "Lag", "PercentScore")
+
+    def __init__(self, Labels=None, Lag=0, PercentScore=0.0):
+        self.Labels, self.Lag, self.PercentScore = Labels, Lag, PercentScore
+
+    def __repr__(self):
+        return "Score(%r, Lag=%d, PercentScore=%.6f)" % (self.Labels, self.Lag, self.PercentScore)
+
+
+class Results:
+    """results.go:11-87.  The heap is Go's container/heap on |PercentScore|."""
+
+    def __init__(self, maxLag, topN, threshold, signFilter):
+        self.MaxLag, self.TopN, self.Threshold, self.SignFilter = maxLag, topN, threshold, signFilter
+        self.scores = []
+
+    def _less(self, i, j):                        # scores.go:25-27
+        return abs(self.scores[i].PercentScore) < abs(self.scores[j].PercentScore)
+
+    def _up(self, j):
+        while True:
+            i = (j - 1) // 2 if j > 0 else 0
+            if i == j or not self._less(j, i):
+                break
+            self.scores[i], self.scores[j] = self.scores[j], self.scores[i]
+            j = i
+
+    def _down(self, i0, n):
+        i = i0
+        while True:
+            j1 = 2 * i + 1
+            if j1 >= n:
+                break
+            j = j1
+            if j1 + 1 < n and self._less(j1 + 1, j1):
+                j = j1 + 1
+            if not self._less(j, i):
+                break
+            self.scores[i], self.scores[j] = self.scores[j], self.scores[i]
+            i = j
+
+    def _push(self, s):
+        self.scores.append(s)
+        self._up(len(self.scores) - 1)
+
+    def _pop(self):
+        n = len(self.scores) - 1
+        self.scores[0], self.scores[n] = self.scores[n], self.scores[0]
+        self._down(0, n)
+        return self.scores.pop()
+
+    def passed(self, s):                          # results.go:46-52
+        return (abs(float(s.Lag)) <= float(self.MaxLag)
+                and abs(s.PercentScore) >= self.Threshold
+                and (self.SignFilter == SignFilter_ANY
+                     or (s.PercentScore > 0 and self.SignFilter == SignFilter_POS)
+                     or (s.PercentScore < 0 and self.SignFilter == SignFilter_NEG)))
+
+    def Update(self, s):                          # results.go:55-72
+        if s.Labels is None:
+            return
+        if self.passed(s):
+            if len(self.scores) == self.TopN:
+                if self.TopN > 0 and abs(s.PercentScore) > abs(self.scores[0].PercentScore):
+                    self._pop()
+                    self._push(s)
+            else:
+                self._push(s)
+
+    def Fetch(self):                              # results.go:75-87
+        num = len(self.scores)
+        out = [None] * num
+        total = 0.0
+        for i in range(num - 1, -1, -1):
+            sc = self._pop()
+            total += abs(sc.PercentScore)
+            out[i] = sc
+        return out, (total / num if num else math.nan)
+
+
+def NewResults(maxLag, topN, threshold, signFilter):
+    return Results(maxLag, topN, threshold, signFilter)
+
+
+# ----------------------------------------------------------- muse_batch.go
+class Batch:
+    def __init__(self, ref, comp, results, cc, engine=None):
+        # muse_batch.go:24-28 (length check over the registry)
+        for uid, s in comp.registry.items():
+            if ref.Length() != s.Length():
+                raise MuseError(B.MUSE_ERR_LENGTH, "%s from comparison group series does not have the same "
+                                "length as the reference" % uid)
+        self.Concurrency = max(int(cc), 1)       # kept for API compatibility; the GPU is the fan-out
+        self.Comparison = comp
+        self.Results = results
+        self._engine = engine or get_engine()
+        self._ref = np.array(ref.Values(), dtype=np.float64)
+        self._db = None
+        self.n = next_pow2(float(ref.Length()))   # muse_batch.go:35
+        # NewBatch computes the reference spectrum right away and returns
+        # "Invalid input query" on sigma == 0 (muse_batch.go:38-41): probe it.
+        probe = DeviceGroup(self._engine, ref.Length(), 0)
+        try:
+            DeviceBatch(self._engine, probe, self._ref).close()
+        finally:
+            probe.close()
+
+    def _batch(self):
+        dg = self.Comparison._device_group(self._engine)
+        if self._db is None or self._db.dgroup is not dg:
+            self._db = DeviceBatch(self._engine, dg, self._ref)
+        return self._db
+
+    def Run(self, groupByLabels):                 # muse_batch.go:99-130
+        comp = self.Comparison
+        labelValuesSet = comp.indexLabelValues(groupByLabels)
+        if not labelValuesSet:
+            return None
+        series = comp._series_list()
+        uid_pos = {uid: i for i, uid in enumerate(comp.registry)}
+        gid = np.zeros(len(series), dtype=np.int32)
+        for g, uids in enumerate(comp.index.values()):   # same order as labelValuesSet
+            for u in uids:
+                gid[uid_pos[u]] = g
+        r = self.Results
+        idx, lag, score, _ = self._batch().run(gid, len(labelValuesSet), r.MaxLag, r.TopN, r.Threshold,
+                                               r.SignFilter, abs_scores=True)
+        # feed Results in group order, as the ordered drain does (muse_batch.go:124-128)
+        order = np.argsort(gid[idx], kind="stable")
+        for k in order:
+            r.Update(Score(series[int(idx[k])].Labels(), int(lag[k]), float(score[k])))
+        return None
+
+
+def NewBatch(ref, comp, results, cc, engine=None):
+    return Batch(ref, comp, results, cc, engine)
+
+
+# ----------------------------------------------------------------- muse.go
+class Muse:
+    def __init__(self, ref, results, engine=None):
+        if ref.Length() < 1:                      # muse.go:24-26
+            raise MuseError(B.MUSE_ERR_EMPTY, "Reference series length must be greater than zero")
+        self.refN = ref.Length()
+        self.n = next_pow2(float(self.refN))
+        self.Results = results
+        self._engine = engine or get_engine()
+        self._ref = np.array(ref.Values(), dtype=np.float64)
+        # validate sigma(ref) now, as New does (muse.go:29-32)
+        probe = DeviceGroup(self._engine, self.refN, 0)
+        try:
+            DeviceBatch(self._engine, probe, self._ref).close()
+        finally:
+            probe.close()
+
+    def Run(self, compGraphs):                    # muse.go:46-92
+        if len(compGraphs) == 0:
+            return None
+        for s in compGraphs:                      # muse.go:68-70
+            if s.Length() != self.refN:
+                raise MuseError(B.MUSE_ERR_LENGTH, "Encountered a comparison graph with differing length "
+                                "than the reference, %r" % (s.Labels(),))
+        dg = DeviceGroup.from_rows(self._engine, np.stack([s.y for s in compGraphs]))
+        db = DeviceBatch(self._engine, dg, self._ref)
+        try:
+            r = self.Results
+            gid = np.zeros(len(compGraphs), dtype=np.int32)
+            idx, lag, score, _ = db.run(gid, 1, r.MaxLag, max(r.TopN, 1), r.Threshold, r.SignFilter,
+                                        abs_scores=False)
+            for k in range(len(idx)):
+                r.Update(Score(compGraphs[int(idx[k])].Labels(), int(lag[k]), float(score[k])))
+        finally:
+            db.close()
+            dg.close()
+        return None
+
+
+def New(ref, results, engine=None):
+    return Muse(ref, results, engine)

@@ -1,0 +1,182 @@
+/*
+ * muse_hip.h -- C ABI of libmuse_hip.so: the MI355X (gfx950) engine behind
+ * go-muse's z-normalized cross-correlation hot path.
+ *
+ * The reference (aouyang1/go-muse, pure Go) has no FFI layer; the natural
+ * seam is its exported batch API.  Each entry point below names the reference
+ * interface it replaces (paths relative to /root/reference).  The Go-side
+ * cgo binding a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C types only; every function returns MUSE_OK (0) or a negative
+ *     muse_status; text for the last error on the calling thread comes from
+ *     muse_last_error().
+ *   - no caller pointer is retained after a call returns (cgo rule): uploads
+ *     copy.  Caller data is never mutated (the reference's zNormalize mutates
+ *     Series values in place, xcorr.go:86,93; this engine does not).
+ *   - one context = one GPU (one process per GPU under torch.distributed /
+ *     RCCL; a Go host creates one context per device).  A handle may be used
+ *     from any host thread, one call in flight per context.
+ *   - there is NO CPU fallback: every compute entry point fails with
+ *     MUSE_ERR_NO_DEVICE when no gfx950 device is usable.
+ */
+#ifndef MUSE_HIP_H
+#define MUSE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MUSE_HIP_ABI_VERSION 1
+
+typedef enum muse_status {
+    MUSE_OK = 0,
+    MUSE_ERR_INVALID = -1,     /* bad argument / NULL handle                      */
+    MUSE_ERR_LENGTH = -2,      /* length mismatch: muse_batch.go:24-28, muse.go:68-70, group.go:45-51 */
+    MUSE_ERR_ZERO_STD = -3,    /* "Invalid input query": sigma(ref)==0, muse_batch.go:39-41 */
+    MUSE_ERR_NO_DEVICE = -4,   /* no usable gfx950 device                         */
+    MUSE_ERR_HIP = -5,         /* a HIP runtime call failed                       */
+    MUSE_ERR_UNSUPPORTED = -6, /* FFT length outside the built kernels (n > 8192) */
+    MUSE_ERR_NOMEM = -7,
+    MUSE_ERR_EMPTY = -8        /* empty reference: muse.go:24-26                  */
+} muse_status;
+
+/* SignFilter values: results.go:20-26 */
+#define MUSE_SIGN_ANY 0
+#define MUSE_SIGN_POS 1
+#define MUSE_SIGN_NEG (-1)
+
+typedef struct muse_ctx muse_ctx;
+typedef struct muse_group muse_group;
+typedef struct muse_batch muse_batch;
+
+/* One top-N candidate as exchanged between shards. 24 bytes. */
+typedef struct muse_record {
+    int64_t series; /* global series (row) index of the group's winner */
+    double score;   /* clamped score: |mv| (Batch) or signed mv (Muse)  */
+    int32_t lag;
+    int32_t group;  /* group id (or series index when ungrouped, truncated) */
+} muse_record;
+
+int muse_abi_version(void);
+const char *muse_last_error(void);
+const char *muse_status_string(int status);
+
+/* ------------------------------------------------------------ context */
+/* Streams, twiddle tables, scratch.  device = HIP device ordinal.      */
+int muse_ctx_create(int32_t device, muse_ctx **out);
+int muse_ctx_destroy(muse_ctx *ctx);
+int muse_ctx_synchronize(muse_ctx *ctx);
+/* name: >= 64 bytes.  Any out pointer may be NULL. */
+int muse_ctx_device_info(muse_ctx *ctx, char *name, int32_t name_cap,
+                         int32_t *compute_units, int64_t *hbm_bytes);
+/* Kernel variant for the fused pass: 0 = auto (tuned radix-16 kernel when
+ * n == 4096, generic LDS radix-2 kernel otherwise), 1 = force generic. */
+int muse_ctx_set_kernel(muse_ctx *ctx, int32_t variant);
+/* HIP-event timing of the fused kernel on the stream it is launched on:
+ * enable, run, then read (sum of launch durations in ms, launch count). */
+int muse_ctx_kernel_timing(muse_ctx *ctx, int32_t enable);
+int muse_ctx_kernel_time(muse_ctx *ctx, double *total_ms, int64_t *launches);
+
+/* -------------------------------------------------------------- group */
+/* Device-resident row-major M x N float64 comparison matrix; replaces the
+ * per-Series []float64 storage behind Group.Add (group.go:31-56: one length
+ * per group).  Never mutated by any run. */
+int muse_group_create(muse_ctx *ctx, int64_t capacity_rows, int32_t N,
+                      muse_group **out);
+/* Appends count rows read from host memory (row_stride in doubles, >= N).
+ * This is what Group.Add calls once per Series (count = 1) or per slab. */
+int muse_group_append(muse_group *g, const double *rows, int64_t count,
+                      int64_t row_stride);
+/* create + append in one call */
+int muse_group_upload(muse_ctx *ctx, const double *rows, int64_t M, int32_t N,
+                      int64_t row_stride, muse_group **out);
+/* Fills rows [first, first+count) ON DEVICE with the rect+noise workload of
+ * SURVEY 8d (after example_test.go:15-20), keyed by (seed, global row index =
+ * global_first + local row, sample index): bench/test utility; rows become
+ * part of the group (size grows to first+count if needed). ref_out (N doubles,
+ * host, may be NULL) receives the reference series of the workload. */
+int muse_group_fill_synthetic(muse_group *g, int64_t first, int64_t count,
+                              int64_t global_first, uint64_t seed,
+                              double *ref_out);
+int muse_group_shape(muse_group *g, int64_t *M, int32_t *N);
+/* D2H copy of rows [first, first+count) (dense, N doubles per row): lets a
+ * checker feed byte-identical inputs to a CPU oracle. */
+int muse_group_read(muse_group *g, int64_t first, int64_t count, double *out);
+int muse_group_free(muse_group *g);
+
+/* -------------------------------------------------------------- batch */
+/* NewBatch (muse_batch.go:23-52) / New (muse.go:23-42): validates
+ * N == group length (MUSE_ERR_LENGTH), n = nextPowOf2(N), reference spectrum
+ * FFT(zeroPad(zNormalize(ref)/(N-1), n)) computed on the device and kept
+ * resident.  MUSE_ERR_ZERO_STD when sigma(ref) == 0; MUSE_ERR_EMPTY when
+ * N < 1.  ref is copied, not mutated. */
+int muse_batch_create(muse_ctx *ctx, muse_group *g, const double *ref,
+                      int32_t N, muse_batch **out);
+int muse_batch_fft_len(muse_batch *b, int32_t *n);
+/* The batch's x (muse_batch.go:47): n/2+1 complex128, interleaved re,im. */
+int muse_batch_spectrum(muse_batch *b, double *out);
+/* The hot loop of Batch.scoreSingle / Muse.Run (muse_batch.go:68-73,
+ * muse.go:64-71): one fused kernel launch computes, for every series of the
+ * group, exactly what xCorrWithX returns (xcorr.go:160-197) minus the cc
+ * slice: lag and signed max value; sigma==0 series give (0, 0.0).  Results
+ * stay on the device (asynchronous; see muse_ctx_synchronize). */
+int muse_batch_score(muse_batch *b);
+/* muse_batch_score + D2H of the per-series results (lag[M], mv[M]). */
+int muse_batch_scores(muse_batch *b, int32_t *lag, double *mv);
+/* Batch.Run + Results.Update + Results.Fetch (muse_batch.go:99-130,
+ * results.go:46-87); abs_scores = 0 gives the Muse.Run post-processing
+ * (muse.go:72-90: signed score clamped to [-1,1], group max by |score|).
+ *   group_id : host int32[M], label-group of each series in [0,G), or NULL =
+ *              every series its own group (Run(nil) with distinct labels).
+ *              Groups are fed to Results in group-id order; inside a group the
+ *              first series (lowest index) wins ties (muse_batch.go:87).
+ *   outputs  : up to top_n entries in Fetch order (descending |score|),
+ *              out_series = index of each group's winning series;
+ *              *out_mean_abs = mean |score| (NaN when empty, results.go:86). */
+int muse_batch_run(muse_batch *b, const int32_t *group_id, int32_t G,
+                   int32_t max_lag, int32_t top_n, double threshold,
+                   int32_t sign_filter, int32_t abs_scores,
+                   int64_t *out_series, int32_t *out_lag, double *out_score,
+                   int32_t *out_count, double *out_mean_abs);
+/* Sharded form of the same run: this context holds rows
+ * [series_offset, series_offset + M) of a larger group and every label group
+ * lives on ONE shard.  Returns this shard's top-N candidates (<= top_n
+ * records, descending |score|); the host gathers the records of all shards
+ * (RCCL all_gather of top_n * 24 B per rank) and passes them to
+ * muse_merge_records.  group ids are global. */
+int muse_batch_run_shard(muse_batch *b, const int32_t *group_id, int32_t G,
+                         int64_t series_offset, int32_t max_lag, int32_t top_n,
+                         double threshold, int32_t sign_filter,
+                         int32_t abs_scores, muse_record *out_records,
+                         int32_t *out_count);
+/* Final Results.Update/Fetch over gathered shard candidates (host only, no
+ * GPU): records in any order; they are fed to the top-N heap in group order. */
+int muse_merge_records(const muse_record *records, int64_t count, int32_t top_n,
+                       int64_t *out_series, int32_t *out_lag, double *out_score,
+                       int32_t *out_count, double *out_mean_abs);
+int muse_batch_free(muse_batch *b);
+
+/* ------------------------------------------- single-pair entry points */
+/* xCorrWithX as exercised by xcorr_test.go:204-286: ref and y of length N,
+ * FFT length n (any n >= N; n need not be a power of two -- then a direct
+ * O(n^2) device kernel is used).  cc (n doubles, may be NULL) receives the
+ * full correlation.  Returns MUSE_OK with *is_nil = 1 (lag 0, mv 0) where
+ * the reference returns (nil, 0, 0). */
+int muse_xcorr_with_x(muse_ctx *ctx, const double *ref, const double *y,
+                      int32_t N, int32_t n, double *cc, int32_t *lag,
+                      double *mv, int32_t *is_nil);
+/* xCorr (xcorr.go:102-153): n is raised to max(n, lenx, leny); cc holds that
+ * many doubles. */
+int muse_xcorr(muse_ctx *ctx, const double *x, int32_t lenx, const double *y,
+               int32_t leny, int32_t n, int32_t normalize, double *cc,
+               int32_t *lag, double *mv, int32_t *is_nil);
+/* nextPowOf2 (xcorr.go:19-24), same floating formula. */
+int64_t muse_next_pow2(double val);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

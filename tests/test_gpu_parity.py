@@ -1,0 +1,410 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every case goes through the
+C ABI of libmuse_hip.so and is checked against the CPU oracle on byte-identical
+inputs, or against the reference's own known-answer tables (tests/golden).
+
+Tolerances (BASELINE.json north_star): correlation scores within 1e-6 relative
+(absolute floor 1e-12 for scores that are exactly 0 in the oracle); lag indices
+exact, except rows the oracle flags as rounding-decided ties (top-two |cc| gap
+< 1e-12 relative) -- their count is asserted to be tiny.
+"""
+import math
+
+import numpy as np
+import pytest
+
+from _load import pkg
+
+pytestmark = pytest.mark.gpu
+
+SCORE_RTOL = 1e-6
+SCORE_ATOL = 1e-12
+TIE_GAP = 1e-12
+
+
+@pytest.fixture(scope="module")
+def muse():
+    m = pkg()
+    m.build.build()
+    return m
+
+
+@pytest.fixture(scope="module")
+def eng(muse):
+    return muse.get_engine(0)
+
+
+def assert_scores_match(lag, mv, olag, omv, gap, max_ties=0):
+    lag, mv, olag, omv = map(np.asarray, (lag, mv, olag, omv))
+    nan_o = np.isnan(omv)
+    assert np.array_equal(np.isnan(mv), nan_o)
+    ok = ~nan_o
+    err = np.abs(mv[ok] - omv[ok])
+    tol = SCORE_RTOL * np.abs(omv[ok]) + SCORE_ATOL
+    assert np.all(err <= tol), "score mismatch: worst rel %.3e" % float(np.max(err / np.maximum(np.abs(omv[ok]), 1e-300)))
+    tie = (gap < TIE_GAP) & ok
+    bad = (lag != olag) & ~tie
+    assert not bad.any(), "lag mismatches at %s" % np.nonzero(bad)[0][:10]
+    assert int(((lag != olag) & tie).sum()) <= max_ties
+    return float(np.max(err / np.maximum(np.abs(omv[ok]), 1e-300))) if ok.any() else 0.0
+
+
+# ------------------------------------------------ reference known-answer tables
+def _check_sign(mv, sign):
+    assert (mv > 0) if sign > 0 else (mv < 0) if sign < 0 else (mv == 0)
+
+
+def test_golden_xcorr(eng, golden):                    # xcorr_test.go:86-202 (n = 5: direct kernel)
+    for c in golden["xcorr"]["cases"]:
+        cc, lag, mv = eng.xcorr(c["x"], c["y"], len(c["x"]), c["normalize"])
+        if c["cc"] is None:
+            assert cc is None
+        else:
+            assert np.max(np.abs(cc - np.array(c["cc"], float))) <= golden["xcorr"]["tol"]
+        assert lag == c["idx"]
+        _check_sign(mv, c["sign"])
+
+
+def test_golden_xcorr_with_x(eng, golden):             # xcorr_test.go:204-286
+    for c in golden["xcorr_with_x"]["cases"]:
+        cc, lag, mv = eng.xcorr_with_x(c["x"], c["y"], n=len(c["x"]))
+        if c["cc"] is None:
+            assert cc is None
+        else:
+            assert np.max(np.abs(cc - np.array(c["cc"], float))) <= golden["xcorr_with_x"]["tol"]
+        assert lag == c["idx"]
+        _check_sign(mv, c["sign"])
+
+
+def test_golden_tables_through_fft_kernel(eng, golden, oracle):
+    """Same tables zero-padded to n = 8 (power of two -> LDS FFT kernel):
+    checked against the oracle at n = 8 (the reference tables pin n = 5 only)."""
+    for c in golden["xcorr_with_x"]["cases"]:
+        cc, lag, mv = eng.xcorr_with_x(c["x"], c["y"], n=8)
+        try:
+            X, _ = oracle.ref_spectrum(c["x"], n=8)
+        except ValueError:
+            continue
+        occ, olag, omv, _ = oracle.xcorr_with_x(X, c["y"], 8)
+        if occ is None:
+            assert cc is None
+            continue
+        assert np.max(np.abs(cc - occ)) <= 1e-12 and lag == olag and abs(mv - omv) <= 1e-12
+    for c in golden["xcorr"]["cases"]:
+        cc, lag, mv = eng.xcorr(c["x"], c["y"], 8, c["normalize"])
+        occ, olag, omv = oracle.xcorr(c["x"], c["y"], 8, c["normalize"])
+        if occ is None:
+            assert cc is None
+            continue
+        assert np.max(np.abs(cc - occ)) <= 1e-12 and lag == olag and abs(mv - omv) <= 1e-12
+
+
+def _compare_scores(scores, case):                     # compareScores, muse_test.go:11-39
+    exp = case["expected"]
+    assert len(scores) == len(exp)
+    for s, e in zip(scores, exp):
+        if "lag_in" in e:
+            assert s.Lag in e["lag_in"]
+        else:
+            assert s.Lag == e["lag"]
+        assert abs(s.PercentScore - e["score"]) <= case["score_tol"]
+        assert s.Labels.labels == e["labels"]
+
+
+def _batch_case(muse, case):
+    ref = muse.NewSeries(case["ref"], muse.NewLabels({"graph": "graph1"}))
+    comp = [muse.NewSeries(s["y"], muse.NewLabels(s["labels"])) for s in case["comp"]]
+    group = muse.NewGroup("targets")
+    group.Add(*comp)
+    r = case["results"]
+    g = muse.NewBatch(ref, group, muse.NewResults(r["max_lag"], r["top_n"], r["threshold"], r["sign_filter"]), 10)
+    g.Run(list(case["group_by"]))
+    scores, _ = g.Results.Fetch()
+    return scores
+
+
+def test_batch_run_simple(muse, golden):               # muse_batch_test.go:9-44
+    _compare_scores(_batch_case(muse, golden["batch_run_simple"]), golden["batch_run_simple"])
+
+
+def test_batch_run_multidimensional(muse, golden):     # muse_batch_test.go:46-82
+    _compare_scores(_batch_case(muse, golden["batch_run_multidim"]), golden["batch_run_multidim"])
+
+
+def test_batch_run_with_larger_group(muse, golden):    # muse_batch_test.go:83-102
+    c = golden["batch_run_larger_group"]
+    ref = muse.NewSeries(c["ref"], muse.NewLabels({"graph": "graph1"}))
+    group = muse.NewGroup("targets")
+    group.Add(*[muse.NewSeries(s["y"], muse.NewLabels(s["labels"])) for s in c["comp"]])
+    with pytest.raises(muse.MuseError) as e:
+        muse.NewBatch(ref, group, muse.NewResults(10, 20, 0, muse.SignFilter_ANY), 1)
+    assert e.value.status == muse.binding.MUSE_ERR_LENGTH
+
+
+def test_new_batch_zero_std_reference(muse):           # muse_batch.go:39-41
+    group = muse.NewGroup("targets")
+    group.Add(muse.NewSeries([1, 2, 3, 4], muse.NewLabels({"graph": "a"})))
+    with pytest.raises(muse.MuseError) as e:
+        muse.NewBatch(muse.NewSeries([2, 2, 2, 2], None), group, muse.NewResults(10, 20, 0, 0), 1)
+    assert e.value.status == muse.binding.MUSE_ERR_ZERO_STD
+    assert "Invalid input query" in str(e.value)
+
+
+def _muse_case(muse, case):
+    ref = muse.NewSeries(case["ref"], muse.NewLabels({"graph": "graph1"}))
+    r = case["results"]
+    g = muse.New(ref, muse.NewResults(r["max_lag"], r["top_n"], r["threshold"], r["sign_filter"]))
+    for s in case["comp"]:
+        assert g.Run([muse.NewSeries(s["y"], muse.NewLabels(s["labels"]))]) is None
+    scores, _ = g.Results.Fetch()
+    return g, scores
+
+
+def test_run_simple(muse, golden):                     # muse_test.go:41-73
+    _compare_scores(_muse_case(muse, golden["muse_run_simple"])[1], golden["muse_run_simple"])
+
+
+def test_run_simple_sign_filter(muse, golden):         # muse_test.go:75-104 (+ NEG on fresh inputs)
+    _compare_scores(_muse_case(muse, golden["muse_run_sign_filter_pass1"])[1], golden["muse_run_sign_filter_pass1"])
+    _compare_scores(_muse_case(muse, golden["muse_run_sign_filter_neg_fresh"])[1],
+                    golden["muse_run_sign_filter_neg_fresh"])
+
+
+def test_run_no_input(muse, golden):                   # muse_test.go:122-142
+    g, scores = _muse_case(muse, golden["muse_run_no_input"])
+    assert g.Run([]) is None and scores == []
+    with pytest.raises(muse.MuseError):                # muse.go:68-70
+        g.Run([muse.NewSeries([1.0, 2.0, 3.0], None)])
+
+
+def test_example_shape_config1(muse, oracle):
+    """BASELINE config 1 / example_test.go: N = 480 -> n = 512, 5 labelled series,
+    Run(nil), Run(["graph"]), Run(["host"]) on one reused Results."""
+    rng = np.random.default_rng(480)
+    N = 480
+    t = np.arange(N)
+
+    def rect(a, c, w):
+        return a * (np.abs(t - c) <= w / 2)
+
+    ref_y = rect(1.5, 240, 10) + 0.1 * rng.standard_normal(N)
+    L = lambda g, h: muse.NewLabels({"graph": g, "host": h})
+    ref = muse.NewSeries(ref_y.copy(), L("CallTime99Pct", "host1"))
+    comp = muse.NewGroup("comparison")
+    ser = [ref,
+           muse.NewSeries(rect(1.5, 242, 7) + 0.1 * rng.standard_normal(N), L("CallTime99Pct", "host2")),
+           muse.NewSeries(rect(43, 240, 10) + 0.1 * rng.standard_normal(N), L("ErrorRate", "host1")),
+           muse.NewSeries(0.1 + 0.1 * rng.standard_normal(N), L("ErrorRate", "host2")),
+           muse.NewSeries(np.full(N, 0.125), L("ErrorRate", "host3"))]
+    comp.Add(*ser)
+    m = muse.NewBatch(ref, comp, muse.NewResults(15, 4, 0.0, muse.SignFilter_ANY), 2)
+    assert m.n == 512
+    rows = np.stack([s.y for s in ser])
+    olag, omv, _ = oracle.batch_scores(ref_y, rows)
+    for group_by, nrows in ((None, 4), (["graph"], 2), (["host"], 3)):
+        m.Run(group_by)
+        res, _ = m.Results.Fetch()
+        assert len(res) == nrows
+        keys = group_by or ["graph", "host"]
+        gid, seen = [], {}
+        for s in ser:
+            gid.append(seen.setdefault(tuple(s.labels.labels[k] for k in keys), len(seen)))
+        oi, ol, osc, _ = oracle.results(olag, omv, np.array(gid, np.int32), len(seen), True, 15, 4, 0.0, 0)
+        assert [r.Labels.labels for r in res] == [ser[i].labels.labels for i in oi]
+        assert [r.Lag for r in res] == ol.tolist()
+        assert np.allclose([r.PercentScore for r in res], osc, rtol=1e-6, atol=1e-12)
+    m.Run(None)
+    res, _ = m.Results.Fetch()
+    assert res[0].Labels.labels["host"] == "host1" and abs(res[0].PercentScore - 1.0) < 1e-9 and res[0].Lag == 0
+    assert res[1].Labels.labels["graph"] == "ErrorRate" and res[1].PercentScore > 0.97 and res[1].Lag == 0
+    assert res[-1].PercentScore == 0.0 and res[-1].Lag == 0           # constant line: sigma == 0
+
+
+# ------------------------------------------------------- kernel vs oracle
+def _rows(M, N, seed):
+    rng = np.random.default_rng(seed)
+    ref = rng.standard_normal(N)
+    rows = rng.standard_normal((M, N))
+    for i in range(0, M, 5):
+        rows[i] += rng.uniform(-2, 2) * np.roll(ref, int(rng.integers(-N // 3, N // 3)))
+    if M > 3:
+        rows[1] = 4.0            # sigma == 0
+        rows[2] = 2.5 * ref - 7  # perfect match
+        rows[3] = -ref           # perfect anti-match
+    return ref, rows
+
+
+@pytest.mark.parametrize("N", [2, 3, 8, 12, 100, 480, 512, 1000, 2048, 3000, 4096, 5000, 8192])
+@pytest.mark.parametrize("M", [1, 2, 7])
+def test_scores_match_oracle_all_lengths(muse, eng, oracle, N, M):
+    """generic LDS kernel (and the tuned one at n = 4096, incl. N < n padding)"""
+    ref, rows = _rows(M, N, 1000 * N + M)
+    dg = muse.DeviceGroup.from_rows(eng, rows)
+    db = muse.DeviceBatch(eng, dg, ref)
+    assert db.n == oracle.next_pow2(N)
+    X, _ = oracle.ref_spectrum(ref)
+    assert np.max(np.abs(db.spectrum() - (X[0::2] + 1j * X[1::2]))) < 1e-12
+    lag, mv = db.scores()
+    olag, omv, gap = oracle.batch_scores(ref, rows)
+    assert_scores_match(lag, mv, olag, omv, gap)
+    np.testing.assert_array_equal(dg.read(0, M), rows)      # inputs are never mutated
+
+
+@pytest.mark.parametrize("N", [2049, 3000, 4095, 4096])
+def test_tuned_and_generic_kernels_agree(muse, eng, oracle, N):
+    ref, rows = _rows(65, N, N)
+    rows[10, 5] = np.nan          # NaN row: (lag 0, mv NaN), must not disturb its pair partner
+    rows[12, :] = np.inf
+    dg = muse.DeviceGroup.from_rows(eng, rows)
+    db = muse.DeviceBatch(eng, dg, ref)
+    assert db.n == 4096
+    lag_t, mv_t = db.scores()
+    eng.set_kernel(1)
+    try:
+        lag_g, mv_g = db.scores()
+    finally:
+        eng.set_kernel(0)
+    olag, omv, gap = oracle.batch_scores(ref, rows)
+    assert math.isnan(mv_t[10]) and lag_t[10] == 0 and math.isnan(mv_t[12]) and lag_t[12] == 0
+    assert_scores_match(lag_t, mv_t, olag, omv, gap)
+    assert_scores_match(lag_g, mv_g, olag, omv, gap)
+
+
+def test_config2_10000x4096_full_parity(muse, eng, oracle):
+    """BASELINE config 2: 1 ref x 10 000 series, N = 4096, one batched launch;
+    every row checked against the oracle on the bytes the GPU used."""
+    M, N = 10000, 4096
+    dg, ref = muse.DeviceGroup.synthetic(eng, M, N, seed=0x6D757365)
+    db = muse.DeviceBatch(eng, dg, ref)
+    lag, mv = db.scores()
+    rows = dg.read(0, M)
+    olag, omv, gap = oracle.batch_scores(ref, rows, nthreads=16)
+    worst = assert_scores_match(lag, mv, olag, omv, gap, max_ties=2)
+    const = np.ptp(rows, axis=1) == 0
+    copies = np.all(rows == ref[None, :], axis=1)
+    assert const.sum() >= 3 and copies.sum() >= 3             # the workload exercises both paths
+    assert np.all(mv[const] == 0) and np.all(lag[const] == 0)
+    assert np.all(np.abs(mv[copies] - 1.0) < 1e-12) and np.all(lag[copies] == 0)
+    assert (mv < 0).sum() > M // 10                           # sign mix
+    print("config2 worst score rel err %.3e, ties %d" % (worst, int((gap < TIE_GAP).sum())))
+    # Batch.Run semantics on top: label groups of 50 "hosts" per "graph"
+    gid = (np.arange(M) // 50).astype(np.int32)
+    for top_n, max_lag, thr, sign, absf in ((20, 15, 0.0, 0, True), (20, 2048, 0.3, 0, True),
+                                            (7, 100, 0.0, -1, False), (300, 4096, 0.0, 0, True)):
+        got = db.run(gid, M // 50, max_lag, top_n, thr, sign, absf)
+        exp = oracle.results(olag, omv, gid, M // 50, absf, max_lag, top_n, thr, sign)
+        assert got[1].tolist() == exp[1].tolist()
+        assert np.allclose(got[2], exp[2], rtol=1e-6, atol=1e-12)
+        distinct = len(set(np.round(exp[2], 9))) == len(exp[2])
+        if distinct:
+            assert got[0].tolist() == exp[0].tolist()
+    got = db.run(None, 0, 15, 20, 0.0, 0, True)               # Run(nil): each series its own group
+    exp = oracle.results(olag, omv, None, 0, True, 15, 20, 0.0, 0)
+    assert np.allclose(got[2], exp[2], rtol=1e-6, atol=1e-12) and got[1].tolist() == exp[1].tolist()
+
+
+def test_group_semantics_edge_cases(muse, eng, oracle):
+    """first-wins ties, NaN-first groups, empty groups, out-of-window lags,
+    sign filters with abs scores."""
+    N = 64
+    rng = np.random.default_rng(5)
+    ref = rng.standard_normal(N)
+    rows = rng.standard_normal((40, N))
+    rows[4] = rows[5] = 2 * ref + 1          # exact tie inside a group: first wins
+    rows[8, 3] = np.nan                      # NaN first in its group: never replaced
+    rows[13] = np.roll(ref, 20)              # strong peak outside MaxLag: dropped, not re-windowed
+    rows[20] = 7.0
+    gid = (np.arange(40) // 4).astype(np.int32)
+    gid[36:] = 11                            # leaves group 9 with members 36.. gone -> group 9 empty
+    G = 12
+    dg = muse.DeviceGroup.from_rows(eng, rows)
+    db = muse.DeviceBatch(eng, dg, ref)
+    lag, mv = db.scores()
+    olag, omv, gap = oracle.batch_scores(ref, rows)
+    assert_scores_match(lag, mv, olag, omv, gap)
+    for top_n in (3, 12, 300):
+        for sign in (0, 1, -1):
+            for absf in (True, False):
+                got = db.run(gid, G, 10, top_n, 0.0, sign, absf)
+                exp = oracle.results(olag, omv, gid, G, absf, 10, top_n, 0.0, sign)
+                assert got[0].tolist() == exp[0].tolist(), (top_n, sign, absf)
+                assert got[1].tolist() == exp[1].tolist()
+                assert np.allclose(got[2], exp[2], rtol=1e-6, atol=1e-12)
+    got = db.run(gid, G, 10, 12, 0.0, 0, True)
+    assert 4 in got[0] and 5 not in got[0] and 13 not in got[0] and 8 not in got[0]
+    s, l, sc, mean = db.run(gid, G, 10, 0, 0.0, 0, True)
+    assert len(s) == 0 and math.isnan(mean)
+
+
+def test_device_topn_path_large_group_count(muse, eng, oracle):
+    """G > 1024 exercises the on-device top-N pre-selection kernel."""
+    M, N = 6000, 64
+    rng = np.random.default_rng(9)
+    ref = rng.standard_normal(N)
+    rows = rng.standard_normal((M, N))
+    rows[::7] += np.roll(ref, 2) * rng.uniform(0.5, 3, (len(rows[::7]), 1))
+    dg = muse.DeviceGroup.from_rows(eng, rows)
+    db = muse.DeviceBatch(eng, dg, ref)
+    lag, mv = db.scores()
+    olag, omv, gap = oracle.batch_scores(ref, rows, nthreads=4)
+    assert_scores_match(lag, mv, olag, omv, gap)
+    gid = (np.arange(M) % 3000).astype(np.int32)          # interleaved groups
+    for args in ((None, 0), (gid, 3000)):
+        for top_n in (1, 20, 256):
+            got = db.run(args[0], args[1], 5, top_n, 0.1, 0, True)
+            exp = oracle.results(olag, omv, args[0], args[1], True, 5, top_n, 0.1, 0)
+            assert got[0].tolist() == exp[0].tolist() and got[1].tolist() == exp[1].tolist()
+            assert np.allclose(got[2], exp[2], rtol=1e-6, atol=1e-12)
+            assert abs(got[3] - exp[3]) < 1e-9
+    # sharded form: two half shards + host merge == single run
+    half = M // 2
+    recs = []
+    for off in (0, half):
+        dgs = muse.DeviceGroup.from_rows(eng, rows[off:off + half])
+        dbs = muse.DeviceBatch(eng, dgs, ref)
+        recs.append(dbs.run_shard(None, 0, off, 5, 20, 0.1, 0, True))
+    s, l, sc, mean = muse.merge_records(np.concatenate(recs), 20)
+    exp = oracle.results(olag, omv, None, 0, True, 5, 20, 0.1, 0)
+    assert s.tolist() == exp[0].tolist() and l.tolist() == exp[1].tolist()
+
+
+def test_invariances(muse, eng):
+    """size-independent properties of z-normalized correlation: affine
+    invariance of y, score 1 at the injected shift, sign flip symmetry."""
+    N = 4096
+    rng = np.random.default_rng(77)
+    ref = rng.standard_normal(N)
+    base = rng.standard_normal((32, N))
+    rows = np.concatenate([base, 3.0 * base + 11.0, -base, np.stack([np.roll(ref, -k) for k in range(-8, 9)])])
+    db = muse.DeviceBatch(eng, muse.DeviceGroup.from_rows(eng, rows), ref)
+    lag, mv = db.scores()
+    assert np.allclose(mv[:32], mv[32:64], rtol=1e-9) and np.array_equal(lag[:32], lag[32:64])
+    assert np.allclose(mv[:32], -mv[64:96], rtol=1e-12) and np.array_equal(lag[:32], lag[64:96])
+    assert np.array_equal(lag[96:], np.arange(-8, 9)) and np.allclose(mv[96:], 1.0, atol=1e-12)
+
+
+def test_full_size_1m_x_4096_properties(muse, eng, oracle):
+    """BASELINE config 3 shape (1 M x 4096 = 32.8 GB resident): sampled rows vs
+    the oracle, plus properties that need no oracle at full size."""
+    M, N = 1_000_000, 4096
+    dg, ref = muse.DeviceGroup.synthetic(eng, M, N, seed=0x6D757365)
+    db = muse.DeviceBatch(eng, dg, ref)
+    lag, mv = db.scores()
+    assert np.all(np.abs(mv) <= 1.0 + 1e-9) and np.all(np.abs(lag) <= N // 2)
+    rng = np.random.default_rng(1)
+    starts = np.sort(rng.choice(M // 256, 16, replace=False)) * 256
+    for s0 in starts:                                       # 16 x 256 = 4096 sampled rows
+        rows = dg.read(int(s0), 256)
+        olag, omv, gap = oracle.batch_scores(ref, rows, nthreads=16)
+        assert_scores_match(lag[s0:s0 + 256], mv[s0:s0 + 256], olag, omv, gap, max_ties=1)
+    zero = mv == 0
+    assert 500 < zero.sum() < 1500 and np.all(lag[zero] == 0)            # ~1/1024 constant rows
+    ones = np.abs(mv - 1.0) < 1e-12
+    assert 500 < ones.sum() < 1500 and np.all(lag[ones] == 0)            # ~1/1024 copies of ref
+    lag2, mv2 = db.scores()                                              # idempotent: inputs not mutated
+    assert np.array_equal(lag, lag2) and np.array_equal(mv, mv2)
+    got = db.run(None, 0, 15, 20, 0.0, 0, True)
+    assert np.all(np.diff(got[2]) <= 0) and np.all(np.abs(got[2] - 1.0) < 1e-12) and np.all(got[1] == 0)
+    gid = (np.arange(M) // 50).astype(np.int32)
+    got = db.run(gid, M // 50, 15, 20, 0.0, 0, True)
+    exp = oracle.results(lag, mv, gid, M // 50, True, 15, 20, 0.0, 0)   # host semantics on GPU scores
+    assert got[1].tolist() == exp[1].tolist() and np.array_equal(got[2], exp[2])
