@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -81,9 +82,13 @@ struct muse_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     double total_ms = 0.0;
     int64_t launches = 0;
+    // Handles may be released in any order (Go finalizers, Python GC): the
+    // context lives until it is destroyed AND its last group/batch is freed.
+    std::atomic<int> refs{1};
 };
 
 struct muse_group {
+    std::atomic<int> refs{1}; // the handle itself + one per batch built on it
     muse_ctx *ctx = nullptr;
     double *rows = nullptr;
     int64_t cap = 0, M = 0, stride = 0;
@@ -174,10 +179,10 @@ extern "C" int muse_ctx_create(int32_t device, muse_ctx **out)
     return MUSE_OK;
 }
 
-extern "C" int muse_ctx_destroy(muse_ctx *ctx)
+static void ctx_release(muse_ctx *ctx)
 {
-    if (!ctx)
-        return MUSE_OK;
+    if (!ctx || ctx->refs.fetch_sub(1) != 1)
+        return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream)
         (void)hipStreamSynchronize(ctx->stream);
@@ -191,6 +196,11 @@ extern "C" int muse_ctx_destroy(muse_ctx *ctx)
     if (ctx->stream)
         (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+}
+
+extern "C" int muse_ctx_destroy(muse_ctx *ctx)
+{
+    ctx_release(ctx);
     return MUSE_OK;
 }
 
@@ -282,6 +292,7 @@ extern "C" int muse_group_create(muse_ctx *ctx, int64_t capacity_rows, int32_t N
                         hipGetErrorString(e));
         }
     }
+    ctx->refs.fetch_add(1);
     *out = g;
     return MUSE_OK;
 }
@@ -397,14 +408,21 @@ extern "C" int muse_group_read(muse_group *g, int64_t first, int64_t count, doub
     return MUSE_OK;
 }
 
-extern "C" int muse_group_free(muse_group *g)
+static void group_release(muse_group *g)
 {
-    if (!g)
-        return MUSE_OK;
+    if (!g || g->refs.fetch_sub(1) != 1)
+        return;
     (void)hipSetDevice(g->ctx->device);
     (void)hipStreamSynchronize(g->ctx->stream);
     (void)hipFree(g->rows);
+    muse_ctx *ctx = g->ctx;
     delete g;
+    ctx_release(ctx);
+}
+
+extern "C" int muse_group_free(muse_group *g)
+{
+    group_release(g);
     return MUSE_OK;
 }
 
@@ -468,6 +486,8 @@ extern "C" int muse_batch_create(muse_ctx *ctx, muse_group *g, const double *ref
         return fail(MUSE_ERR_NOMEM, "host allocation failed");
     b->ctx = ctx;
     b->g = g;
+    g->refs.fetch_add(1);
+    ctx->refs.fetch_add(1);
     b->N = N;
     b->n = (int32_t)n;
     b->logn = ilog2(n);
@@ -870,7 +890,11 @@ extern "C" int muse_batch_free(muse_batch *b)
     (void)hipFree(b->selkey);
     (void)hipFree(b->cand);
     (void)hipFree(b->cnt);
+    muse_group *g = b->g;
+    muse_ctx *ctx = b->ctx;
     delete b;
+    group_release(g);
+    ctx_release(ctx);
     return MUSE_OK;
 }
 

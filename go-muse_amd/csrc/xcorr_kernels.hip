@@ -247,10 +247,13 @@ __global__ __launch_bounds__(R16_THREADS, 2) void xcorr_fused_n4096(const FusedP
         ZnFlags fa, fb;
         const double ia = zn_scale(q[0], q[1], N, fa);
         const double ib = zn_scale(q[2], q[3], N, fb);
+        // a sigma == 0 / NaN series contributes zeros, so it cannot leak into
+        // the series it shares the complex transform with
+        const bool deadA = fa.zero || fa.nan, deadB = fb.zero || fb.nan;
 #pragma unroll
         for (int a = 0; a < 16; a++) {
-            v[a].x *= ia;
-            v[a].y *= ib;
+            v[a].x = deadA ? 0.0 : v[a].x * ia;
+            v[a].y = deadB ? 0.0 : v[a].y * ib;
         }
         // ---- Z = FFT(yA + i yB)
         fft4096(v, lds, p.tw1, p.tw2, t);
@@ -396,10 +399,11 @@ __device__ __forceinline__ void lds_load_znorm(double2 *z, double *red, const do
         block_sum<4>(q, red + 8);
         const double ia = zn_scale(q[0], q[1], N, fa) * post_scale_a;
         const double ib = zn_scale(q[2], q[3], N, fb);
+        const bool deadA = fa.zero || fa.nan, deadB = fb.zero || fb.nan;
         for (int i = t; i < n; i += T) {
             double2 e = z[i];
-            e.x *= ia;
-            e.y *= ib;
+            e.x = deadA ? 0.0 : e.x * ia;
+            e.y = deadB ? 0.0 : e.y * ib;
             z[i] = e;
         }
     }

@@ -15,6 +15,7 @@ data, so every Run behaves like the reference's FIRST Run on fresh inputs.
 """
 import ctypes
 import math
+import sys
 import uuid
 
 import numpy as np
@@ -45,7 +46,8 @@ class Engine:
 
     def __del__(self):
         try:
-            self.close()
+            if not sys.is_finalizing():   # at exit the HIP runtime tears itself down
+                self.close()
         except Exception:
             pass
 
@@ -169,7 +171,8 @@ class DeviceGroup:
 
     def __del__(self):
         try:
-            self.close()
+            if not sys.is_finalizing():   # at exit the HIP runtime tears itself down
+                self.close()
         except Exception:
             pass
 
@@ -239,7 +242,8 @@ class DeviceBatch:
 
     def __del__(self):
         try:
-            self.close()
+            if not sys.is_finalizing():   # at exit the HIP runtime tears itself down
+                self.close()
         except Exception:
             pass
 

@@ -90,7 +90,10 @@ T["batch_run_simple"] = {
     "expected": [
         {"labels": {"graph": "perfectMatch"}, "lag": 0, "score": 1.000},
         {"labels": {"graph": "slightlyLower"}, "lag": 0, "score": 0.929},
-        {"labels": {"graph": "evenLowerShiftedAhead"}, "lag": -3, "score": 0.754},
+        # exact tie: cc[13] == cc[14] in exact arithmetic; the
+        # reference's -3 is a rounding outcome, so checkers other than the CPU
+        # oracle accept either lag ("tie_lags").
+        {"labels": {"graph": "evenLowerShiftedAhead"}, "lag": -3, "tie_lags": [-3, -2], "score": 0.754},
         {"labels": {"graph": "evenLower"}, "lag": 2, "score": 0.733},
         {"labels": {"graph": "zeros"}, "lag": 0, "score": 0},
     ],
@@ -142,7 +145,7 @@ T["muse_run_simple"] = {
     "expected": [
         {"labels": {"graph": "perfectMatch"}, "lag": 0, "score": 1.000},
         {"labels": {"graph": "slightlyLower"}, "lag": 0, "score": 0.929},
-        {"labels": {"graph": "evenLowerShiftedAhead"}, "lag": -3, "score": -0.754},
+        {"labels": {"graph": "evenLowerShiftedAhead"}, "lag": -3, "tie_lags": [-3, -2], "score": -0.754},
         {"labels": {"graph": "evenLower"}, "lag": 2, "score": 0.733},
         {"labels": {"graph": "zeros"}, "lag": 0, "score": 0},
     ],
