@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Condenses rocprofv3 CSV output (kernel trace stats + PMC passes) into a small text summary."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+out = sys.argv[1]
+
+
+def find(sub, pat):
+    return sorted(glob.glob(os.path.join(out, sub, "**", pat), recursive=True))
+
+
+print("# rocprofv3 summary for", out)
+for f in find("trace", "*kernel_stats.csv"):
+    print("\n## kernel stats (%s)" % os.path.relpath(f, out))
+    rows = list(csv.DictReader(open(f)))
+    for r in rows[:12]:
+        print("  %-60s calls=%s total_ns=%s avg_ns=%s pct=%s" % (
+            r.get("Name", "")[:60], r.get("Calls"), r.get("TotalDurationNs"), r.get("AverageNs"), r.get("Percentage")))
+for sub in ("pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2"):
+    for f in find(sub, "*counter_collection.csv"):
+        acc = defaultdict(lambda: defaultdict(list))
+        for r in csv.DictReader(open(f)):
+            acc[r.get("Kernel_Name", "")][r.get("Counter_Name", "")].append(float(r.get("Counter_Value", 0)))
+        print("\n## %s (%s)" % (sub, os.path.relpath(f, out)))
+        for k, cs in acc.items():
+            if "xcorr_fused" not in k:
+                continue
+            for c, vals in sorted(cs.items()):
+                print("  %-40s %-28s n=%d mean=%.6g" % (k[:40], c, len(vals), sum(vals) / len(vals)))
