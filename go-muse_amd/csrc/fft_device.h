@@ -1,0 +1,163 @@
+// fft_device.h -- device-side building blocks shared by the fused xcorr kernels
+// (complex helpers, wave/block reductions, z-normalisation constants, the
+// in-register 16-point DFT).  gfx950 only; wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace muse {
+
+// ------------------------------------------------------------ small helpers
+__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ double2 cmul(double2 a, double2 b)
+{
+    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_min_i(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// Block-wide sums of K doubles for a 256-thread block (4 waves).  Every
+// thread returns the same bits (fixed summation order).  `scratch` must hold
+// 4*K doubles that no other reduction is using concurrently.
+template <int K>
+__device__ __forceinline__ void block_sum(double (&v)[K], double *scratch)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        double s = wave_sum(v[k]);
+        if (lane == 0)
+            scratch[wave * K + k] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; k++)
+        v[k] = (scratch[0 * K + k] + scratch[1 * K + k]) + (scratch[2 * K + k] + scratch[3 * K + k]);
+}
+
+// z-normalisation constants from block totals (xcorr.go:84-95 with the
+// centred second pass of gonum stat.StdDev): returns 1/sigma, sets flags.
+struct ZnFlags {
+    bool zero; // sigma == 0  -> (nil,0,0)
+    bool nan;  // sigma is NaN -> every cc is NaN -> (lag 0, mv NaN)
+};
+__device__ __forceinline__ double zn_scale(double s1, double s2, int N, ZnFlags &f)
+{
+    const double n = (double)N;
+    double var = (s2 - s1 * s1 / n) / (double)(N - 1);
+    double sd = sqrt(var);
+    f.zero = (sd == 0.0);
+    f.nan = (sd != sd);
+    return (f.zero || f.nan) ? 0.0 : 1.0 / sd;
+}
+
+// ===================================================== tuned n = 4096 kernel
+// 16-point DFT in registers: two radix-4 layers.  Input x[a] at v[a]; output
+// X[k] at v[P16(k)], P16(k) = 4*(k&3) + (k>>2) (an involution).
+#define P16(k) ((((k)&3) << 2) | ((k) >> 2))
+
+__device__ __forceinline__ void radix4(double2 &a, double2 &b, double2 &c, double2 &d)
+{
+    double2 t0 = cadd(a, c), t1 = csub(a, c), t2 = cadd(b, d), t3 = csub(b, d);
+    a = cadd(t0, t2);
+    c = csub(t0, t2);
+    b = make_double2(t1.x + t3.y, t1.y - t3.x); // t1 - i*t3
+    d = make_double2(t1.x - t3.y, t1.y + t3.x); // t1 + i*t3
+}
+
+__device__ __forceinline__ void dft16(double2 (&v)[16])
+{
+    constexpr double C1 = 0.92387953251128675613; // cos(pi/8)
+    constexpr double S1 = 0.38268343236508977173; // sin(pi/8)
+    constexpr double H = 0.70710678118654752440;  // sqrt(1/2)
+    // layer 1: over a1 (stride 4): v[a0 + 4*k1] = y[a0][k1]
+#pragma unroll
+    for (int a0 = 0; a0 < 4; a0++)
+        radix4(v[a0], v[a0 + 4], v[a0 + 8], v[a0 + 12]);
+    // internal twiddles W16^(a0*k1)
+    double2 u;
+    // a0 = 1: k1 = 1,2,3 -> W1, W2, W3
+    u = v[1 + 4];  v[1 + 4]  = make_double2(u.x * C1 + u.y * S1, u.y * C1 - u.x * S1);
+    u = v[1 + 8];  v[1 + 8]  = make_double2((u.x + u.y) * H, (u.y - u.x) * H);
+    u = v[1 + 12]; v[1 + 12] = make_double2(u.x * S1 + u.y * C1, u.y * S1 - u.x * C1);
+    // a0 = 2: W2, W4, W6
+    u = v[2 + 4];  v[2 + 4]  = make_double2((u.x + u.y) * H, (u.y - u.x) * H);
+    u = v[2 + 8];  v[2 + 8]  = make_double2(u.y, -u.x);
+    u = v[2 + 12]; v[2 + 12] = make_double2((u.y - u.x) * H, -(u.x + u.y) * H);
+    // a0 = 3: W3, W6, W9
+    u = v[3 + 4];  v[3 + 4]  = make_double2(u.x * S1 + u.y * C1, u.y * S1 - u.x * C1);
+    u = v[3 + 8];  v[3 + 8]  = make_double2((u.y - u.x) * H, -(u.x + u.y) * H);
+    u = v[3 + 12]; v[3 + 12] = make_double2(-u.x * C1 - u.y * S1, u.x * S1 - u.y * C1);
+    // layer 2: over a0: v[4*k1 + k0] = X[4*k0 + k1]
+#pragma unroll
+    for (int k1 = 0; k1 < 4; k1++)
+        radix4(v[4 * k1], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);
+}
+
+
+// ------------------------------------------------------- DPP wave reductions
+// All-lanes reductions without LDS traffic: xor-1, xor-2 (quad_perm), then
+// row_half_mirror and row_mirror complete each 16-lane row; the four row
+// results are combined through v_readlane.  Every lane returns the same bits.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_dpp(double v)
+{
+    v += dpp_f64<0xB1>(v);  // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);  // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141>(v); // row_half_mirror
+    v += dpp_f64<0x140>(v); // row_mirror
+    return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
+__device__ __forceinline__ double wave_max_dpp(double v)
+{
+    v = fmax(v, dpp_f64<0xB1>(v));
+    v = fmax(v, dpp_f64<0x4E>(v));
+    v = fmax(v, dpp_f64<0x141>(v));
+    v = fmax(v, dpp_f64<0x140>(v));
+    return fmax(fmax(readlane_f64(v, 0), readlane_f64(v, 16)), fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
+}
+__device__ __forceinline__ int wave_min_i_dpp(int v)
+{
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+
+} // namespace muse

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -155,6 +156,8 @@ extern "C" int muse_ctx_create(int32_t device, muse_ctx **out)
     if (!ctx)
         return fail(MUSE_ERR_NOMEM, "host allocation failed");
     ctx->device = device;
+    if (const char *kv = getenv("MUSE_HIP_KERNEL")) // profiling aid: same meaning as muse_ctx_set_kernel
+        ctx->variant = atoi(kv);
     ctx->num_cus = prop.multiProcessorCount;
     ctx->hbm = (int64_t)prop.totalGlobalMem;
     snprintf(ctx->name, sizeof(ctx->name), "%s (%s)", prop.name, prop.gcnArchName);
@@ -228,7 +231,7 @@ extern "C" int muse_ctx_device_info(muse_ctx *ctx, char *name, int32_t name_cap,
 
 extern "C" int muse_ctx_set_kernel(muse_ctx *ctx, int32_t variant)
 {
-    if (!ctx || variant < 0 || variant > 1)
+    if (!ctx || variant < 0 || variant > 7)
         return fail(MUSE_ERR_INVALID, "bad kernel variant");
     ctx->variant = variant;
     return MUSE_OK;
@@ -579,7 +582,21 @@ extern "C" int muse_batch_score(muse_batch *b)
     p.lag = b->lag;
     p.cc_out = nullptr;
     p.nil_out = nullptr;
-    const int variant = (b->n == 4096 && ctx->variant == 0) ? KERNEL_R16_N4096 : KERNEL_GENERIC;
+    // kernel selection: ctx->variant 0 = auto; 1 = generic LDS radix-2; 2..7 force one
+    // of the n = 4096 kernels (parity tests run every one of them on the same inputs)
+    int variant = KERNEL_GENERIC;
+    if (b->n == 4096) {
+        switch (ctx->variant) {
+        case 0: variant = KERNEL_R16_OCC3; break; // fastest measured (profiles/)
+        case 2: variant = KERNEL_R16_N4096; break;
+        case 3: variant = KERNEL_R16_SPLIT; break;
+        case 4: variant = KERNEL_R16_SPLIT3; break;
+        case 5: variant = KERNEL_R16_PIPE; break;
+        case 6: variant = KERNEL_R16_OCC4; break;
+        case 7: variant = KERNEL_R16_OCC3; break;
+        default: variant = KERNEL_GENERIC; break;
+        }
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->timing) {
         HIP_TRY(hipEventCreate(&e0));

@@ -8,7 +8,7 @@
 
 namespace muse {
 
-enum { KERNEL_GENERIC = 0, KERNEL_R16_N4096 = 1 };
+enum { KERNEL_GENERIC = 0, KERNEL_R16_N4096 = 1, KERNEL_R16_SPLIT = 2, KERNEL_R16_SPLIT3 = 3, KERNEL_R16_PIPE = 4, KERNEL_R16_OCC4 = 5, KERNEL_R16_OCC3 = 6 };
 
 struct FusedParams {
     const double *rows; // M x N row-major, row stride `stride` doubles
@@ -27,9 +27,13 @@ struct FusedParams {
     int *lag;            // out: M lags
     double *cc_out;      // optional (generic kernel only): M x n correlations
     int *nil_out;        // optional (generic kernel only): M flags, 1 = sigma == 0 -> (nil,0,0)
+    unsigned long long *dbg; // diagnostic builds only (tools/ablate): per-workgroup phase cycle sums
 };
 
 hipError_t launch_fused(const FusedParams &p, int variant, int num_cus, hipStream_t stream);
+hipError_t launch_fused_split(const FusedParams &p, int num_cus, int waves_per_simd, hipStream_t stream); // xcorr_r16_split.hip
+hipError_t launch_fused_pipe(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_r16_pipe.hip
+hipError_t launch_fused_occ4(const FusedParams &p, int num_cus, int waves_per_simd, hipStream_t stream); // xcorr_r16_occ4.hip
 hipError_t launch_ref_spectrum(const double *ref_dev, int N, int n, int logn, int normalize, double x_scale,
                                double xc_scale, const double2 *twm, double2 *X, double2 *xc, int *status,
                                hipStream_t stream);

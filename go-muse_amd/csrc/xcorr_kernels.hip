@@ -30,117 +30,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "fft_device.h"
 #include "xcorr_kernels.h"
 
 namespace muse {
-
-// ------------------------------------------------------------ small helpers
-__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ double2 cmul(double2 a, double2 b)
-{
-    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
-}
-
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-        v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ double wave_max(double v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-        v = fmax(v, __shfl_xor(v, o, 64));
-    return v;
-}
-__device__ __forceinline__ int wave_min_i(int v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-        v = min(v, __shfl_xor(v, o, 64));
-    return v;
-}
-
-// Block-wide sums of K doubles for a 256-thread block (4 waves).  Every
-// thread returns the same bits (fixed summation order).  `scratch` must hold
-// 4*K doubles that no other reduction is using concurrently.
-template <int K>
-__device__ __forceinline__ void block_sum(double (&v)[K], double *scratch)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-        double s = wave_sum(v[k]);
-        if (lane == 0)
-            scratch[wave * K + k] = s;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < K; k++)
-        v[k] = (scratch[0 * K + k] + scratch[1 * K + k]) + (scratch[2 * K + k] + scratch[3 * K + k]);
-}
-
-// z-normalisation constants from block totals (xcorr.go:84-95 with the
-// centred second pass of gonum stat.StdDev): returns 1/sigma, sets flags.
-struct ZnFlags {
-    bool zero; // sigma == 0  -> (nil,0,0)
-    bool nan;  // sigma is NaN -> every cc is NaN -> (lag 0, mv NaN)
-};
-__device__ __forceinline__ double zn_scale(double s1, double s2, int N, ZnFlags &f)
-{
-    const double n = (double)N;
-    double var = (s2 - s1 * s1 / n) / (double)(N - 1);
-    double sd = sqrt(var);
-    f.zero = (sd == 0.0);
-    f.nan = (sd != sd);
-    return (f.zero || f.nan) ? 0.0 : 1.0 / sd;
-}
-
-// ===================================================== tuned n = 4096 kernel
-// 16-point DFT in registers: two radix-4 layers.  Input x[a] at v[a]; output
-// X[k] at v[P16(k)], P16(k) = 4*(k&3) + (k>>2) (an involution).
-#define P16(k) ((((k)&3) << 2) | ((k) >> 2))
-
-__device__ __forceinline__ void radix4(double2 &a, double2 &b, double2 &c, double2 &d)
-{
-    double2 t0 = cadd(a, c), t1 = csub(a, c), t2 = cadd(b, d), t3 = csub(b, d);
-    a = cadd(t0, t2);
-    c = csub(t0, t2);
-    b = make_double2(t1.x + t3.y, t1.y - t3.x); // t1 - i*t3
-    d = make_double2(t1.x - t3.y, t1.y + t3.x); // t1 + i*t3
-}
-
-__device__ __forceinline__ void dft16(double2 (&v)[16])
-{
-    constexpr double C1 = 0.92387953251128675613; // cos(pi/8)
-    constexpr double S1 = 0.38268343236508977173; // sin(pi/8)
-    constexpr double H = 0.70710678118654752440;  // sqrt(1/2)
-    // layer 1: over a1 (stride 4): v[a0 + 4*k1] = y[a0][k1]
-#pragma unroll
-    for (int a0 = 0; a0 < 4; a0++)
-        radix4(v[a0], v[a0 + 4], v[a0 + 8], v[a0 + 12]);
-    // internal twiddles W16^(a0*k1)
-    double2 u;
-    // a0 = 1: k1 = 1,2,3 -> W1, W2, W3
-    u = v[1 + 4];  v[1 + 4]  = make_double2(u.x * C1 + u.y * S1, u.y * C1 - u.x * S1);
-    u = v[1 + 8];  v[1 + 8]  = make_double2((u.x + u.y) * H, (u.y - u.x) * H);
-    u = v[1 + 12]; v[1 + 12] = make_double2(u.x * S1 + u.y * C1, u.y * S1 - u.x * C1);
-    // a0 = 2: W2, W4, W6
-    u = v[2 + 4];  v[2 + 4]  = make_double2((u.x + u.y) * H, (u.y - u.x) * H);
-    u = v[2 + 8];  v[2 + 8]  = make_double2(u.y, -u.x);
-    u = v[2 + 12]; v[2 + 12] = make_double2((u.y - u.x) * H, -(u.x + u.y) * H);
-    // a0 = 3: W3, W6, W9
-    u = v[3 + 4];  v[3 + 4]  = make_double2(u.x * S1 + u.y * C1, u.y * S1 - u.x * C1);
-    u = v[3 + 8];  v[3 + 8]  = make_double2((u.y - u.x) * H, -(u.x + u.y) * H);
-    u = v[3 + 12]; v[3 + 12] = make_double2(-u.x * C1 - u.y * S1, u.x * S1 - u.y * C1);
-    // layer 2: over a0: v[4*k1 + k0] = X[4*k0 + k1]
-#pragma unroll
-    for (int k1 = 0; k1 < 4; k1++)
-        radix4(v[4 * k1], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);
-}
 
 constexpr int R16_THREADS = 256;
 constexpr int R16_LDS = 16 * 272; // double2 elements: 69,632 B
@@ -215,12 +108,9 @@ __global__ __launch_bounds__(R16_THREADS, 2) void xcorr_fused_n4096(const FusedP
 #pragma unroll
         for (int a = 0; a < 16; a++) {
             const int j = t + 256 * a - pad;
-            double xa = 0.0, xb = 0.0;
-            if (j >= 0) {
-                xa = ra[j];
-                xb = rb[j];
-            }
-            v[a] = make_double2(xa, hasB ? xb : 0.0);
+            const int jc = j < 0 ? 0 : j; // always load (a conditional load serialises behind vmcnt(0))
+            const double xa = ra[jc], xb = rb[jc];
+            v[a] = make_double2(j >= 0 ? xa : 0.0, (j >= 0 && hasB) ? xb : 0.0);
         }
         // ---- zNormalize both series (xcorr.go:84-95)
         double s[2] = {0.0, 0.0};
@@ -694,6 +584,16 @@ hipError_t launch_fused(const FusedParams &p, int variant, int num_cus, hipStrea
 {
     if (p.npairs <= 0)
         return hipSuccess;
+    if (variant == KERNEL_R16_OCC4)
+        return launch_fused_occ4(p, num_cus, 4, stream);
+    if (variant == KERNEL_R16_OCC3)
+        return launch_fused_occ4(p, num_cus, 3, stream);
+    if (variant == KERNEL_R16_PIPE)
+        return launch_fused_pipe(p, num_cus, stream);
+    if (variant == KERNEL_R16_SPLIT)
+        return launch_fused_split(p, num_cus, 4, stream);
+    if (variant == KERNEL_R16_SPLIT3)
+        return launch_fused_split(p, num_cus, 3, stream);
     if (variant == KERNEL_R16_N4096) {
         long long grid = p.npairs;
         const long long cap = (long long)num_cus * 2 * 8; // persistent-ish: grid-stride beyond this

@@ -1,0 +1,541 @@
+// xcorr_r16_occ4.hip -- high-occupancy tuned kernel for n = 4096.
+//
+// Mathematics: identical to xcorr_fused_n4096 (xcorr_kernels.hip header; the
+// reference path is xCorrWithX, /root/reference/xcorr.go:160-197).
+//
+// Why this shape (round-1 ablations and phase stamps, tools/ablate +
+// profiles/): with the full-size complex exchange buffer (69.6 KB) only two
+// workgroups fit a CU; a workgroup's timeline per pair is ~28k cycles of which
+// ~8k are VALU work, the rest dependent stalls (HBM, L2, LDS, barriers, and
+// fp64 div/sqrt chains), and two waves per SIMD cannot cover that.  Here:
+//   * each LDS transpose runs as TWO half rounds through a 34.8 KB buffer
+//     (outputs 0..7, then 8..15; waves 0-1 read after the first round, waves
+//     2-3 after the second), so 3-4 workgroups share a CU;
+//   * the dependent chains are shortened: twiddle / spectrum loads are issued
+//     one phase ahead of their use; the z-normalisation needs no division on
+//     the critical path (1/N, 1/(N-1) are per-launch constants; sqrt and 1/sigma
+//     are evaluated only by the thread that writes the result); the argmax is
+//     resolved with wave ballots on the scalar unit and its cross-wave combine
+//     is deferred behind the next pair's first barrier (no barrier of its own);
+//   * all global pointers are re-materialised as scalars (saddr + shared VGPR
+//     offset): no hoisted 64-bit VGPR addresses; loads are unconditional
+//     (clamped index + select);
+//   * DPP wave reductions; 1/sigma multiplies only the winning value; for
+//     N == n the mean is removed from the DC bin after the first FFT instead of
+//     from every sample.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fft_device.h"
+#include "xcorr_kernels.h"
+
+namespace muse {
+
+constexpr int OCC_THREADS = 256;
+constexpr int OCC_XBUF = 8 * 272; // double2 elements: 34,816 B
+
+namespace occ4 {
+
+// In-kernel phase stamps (diagnostic builds only: TIMING = false in every
+// shipped instantiation, where all of this compiles to nothing).
+constexpr int NPHASE = 16;
+template <bool TIMING>
+struct PhaseClock {
+    unsigned long long acc[NPHASE];
+    unsigned long long last;
+    __device__ __forceinline__ void start()
+    {
+        if (TIMING) {
+#pragma unroll
+            for (int i = 0; i < NPHASE; i++)
+                acc[i] = 0;
+            last = __builtin_amdgcn_s_memtime();
+        }
+    }
+    template <int I>
+    __device__ __forceinline__ void stamp()
+    {
+        if (TIMING) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            acc[I] += now - last;
+            last = now;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+};
+
+__device__ __forceinline__ void fence() { __builtin_amdgcn_sched_barrier(0); }
+// LDS-only barrier (does not drain outstanding global loads)
+__device__ __forceinline__ void lds_barrier()
+{
+    fence();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    fence();
+}
+// a wave-uniform double moved to SGPRs (frees two VGPRs per value)
+__device__ __forceinline__ double uniform(double v)
+{
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+// The result is an address_space(1) (global) pointer on purpose: laundering a
+// generic pointer through the asm loses the address space and every load through
+// it becomes flat_load, which counts on lgkmcnt as well -- the LDS-only barrier
+// (s_waitcnt lgkmcnt(0)) would then drain the prefetch.
+#if defined(__HIP_DEVICE_COMPILE__)
+template <typename T>
+using gptr = const T __attribute__((address_space(1))) *;
+#else
+template <typename T>
+using gptr = const T *; // host pass only parses this file
+#endif
+typedef double d2v __attribute__((ext_vector_type(2)));
+template <typename T>
+__device__ __forceinline__ gptr<T> scalar_ptr(const T *p)
+{
+    unsigned long long u = (unsigned long long)p;
+    asm volatile("" : "+s"(u));
+    return (gptr<T>)u;
+}
+// 16-byte global load of one complex value (native vector type: HIP's double2
+// struct cannot be copied out of an address_space(1) reference)
+__device__ __forceinline__ double2 ldg2(gptr<double2> p, int i)
+{
+    const d2v x = ((gptr<d2v>)p)[i];
+    return make_double2(x.x, x.y);
+}
+
+// One LDS transpose in two half rounds through the 8 x 272 buffer (positions in
+// double2 units).  Layouts (same bank analysis as xcorr_kernels.hip):
+//   A: writer (b = hi, c = lo) output k1 -> 272*(k1&7) + t
+//      reader (k1 = hi, c = lo) input b  <- 272*(hi&7) + 16*b + lo
+//   B: writer (k1 = hi, c = lo) output k2 -> 272*(k2&7) + 17*hi + lo
+//      reader (k1 = lo, k2 = hi) input c <- 272*(hi&7) + 17*lo + c
+// Round 0 moves outputs 0..7 (read by waves 0-1, whose hi is 0..7), round 1
+// outputs 8..15 (waves 2-3).  `wave` is an SGPR, so the two paths are scalar
+// branches with disjoint live ranges; both execute the same four barriers.
+template <bool B>
+__device__ __forceinline__ void exchange(double2 (&v)[16], double2 *xbuf, const int wave, const int t)
+{
+    const int hi = t >> 4, lo = t & 15;
+    const int wbase = B ? 17 * hi + lo : t;
+    const int rbase = 272 * (hi & 7) + (B ? 17 * lo : lo);
+    lds_barrier(); // buffer free: the previous transpose's last readers are done
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        xbuf[272 * k + wbase] = v[P16(k)];
+    lds_barrier();
+    if (wave < 2) {
+        double2 w[16];
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+            w[e] = xbuf[rbase + (B ? e : 16 * e)];
+        lds_barrier();
+#pragma unroll
+        for (int k = 8; k < 16; k++)
+            xbuf[272 * (k - 8) + wbase] = v[P16(k)];
+        lds_barrier();
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+            v[e] = w[e];
+    } else {
+        lds_barrier();
+#pragma unroll
+        for (int k = 8; k < 16; k++)
+            xbuf[272 * (k - 8) + wbase] = v[P16(k)];
+        lds_barrier();
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+            v[e] = xbuf[rbase + (B ? e : 16 * e)];
+    }
+}
+
+// 16-point DFT followed by 15 twiddle multiplies whose factors are fetched by
+// `fetch(k)` (k = 1..15) in two batches; the first batch is issued BEFORE the
+// butterflies and the second before the first is consumed, so the fetch latency
+// (L2 or LDS) overlaps arithmetic instead of adding to the dependent chain.
+template <typename F>
+__device__ __forceinline__ void dft16_twiddle(double2 (&v)[16], F fetch)
+{
+    double2 ta[8], tb[7];
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+        ta[j] = fetch(1 + j);
+    fence();
+    dft16(v);
+    fence();
+#pragma unroll
+    for (int j = 0; j < 7; j++)
+        tb[j] = fetch(9 + j);
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+        v[P16(1 + j)] = cmul(v[P16(1 + j)], ta[j]);
+    fence();
+#pragma unroll
+    for (int j = 0; j < 7; j++)
+        v[P16(9 + j)] = cmul(v[P16(9 + j)], tb[j]);
+}
+
+struct Tw1Fetch {
+    gptr<double2> p;
+    int t;
+    __device__ __forceinline__ double2 operator()(int k) const { return ldg2(p, k * 256 + t); }
+};
+struct Tw2Fetch {
+    const double2 *p;
+    int lo;
+    __device__ __forceinline__ double2 operator()(int k) const { return p[k * 16 + lo]; }
+};
+
+// The next pair's rows, prefetched into registers: element t + 256*i of the two
+// (zero-padded) rows plus each row's first sample.
+struct RawPair {
+    double a[16], b[16];
+    double ka, kb;
+};
+// Unconditional coalesced nontemporal loads (a conditional prefetch parks `raw`
+// in scratch; a per-element `if` serialises the loads): the caller clamps `pair`.
+template <bool PADDED>
+__device__ __forceinline__ void issue_row_loads(RawPair &r, const FusedParams &p, long long pair, int t, int pad)
+{
+    const long long rA = 2 * pair;
+    const long long rB = (rA + 1 < p.M) ? rA + 1 : rA;
+    const gptr<double> ra = scalar_ptr(p.rows + rA * p.stride);
+    const gptr<double> rb = scalar_ptr(p.rows + rB * p.stride);
+    r.ka = ra[0];
+    r.kb = rb[0];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        if (PADDED) {
+            int j = t + 256 * i - pad;
+            j = j < 0 ? 0 : j; // clamped: always load, the value is masked later
+            r.a[i] = __builtin_nontemporal_load(ra + j);
+            r.b[i] = __builtin_nontemporal_load(rb + j);
+        } else {
+            r.a[i] = __builtin_nontemporal_load(ra + 256 * i + t);
+            r.b[i] = __builtin_nontemporal_load(rb + 256 * i + t);
+        }
+    }
+}
+
+// forward FFT: v[a] = x[t + 256 a] -> v[a] = X[t + 256 a].  With MULXC the
+// result is multiplied by xc[t + 256 a] (the batch's conj(X)/n table); those 16
+// L2 loads are issued around the last butterflies.  For N == n the DC bin is
+// corrected by dc (see caller) before the multiply.
+// Without MULXC (the second FFT) the next pair's row loads are issued just before
+// the last butterflies: they stay in flight during pass 3 and the argmax, the only
+// stretch with no other global access and the registers to spare.
+template <int P0, bool MULXC, bool PADDED, bool TIMING>
+__device__ __forceinline__ void fft4096(double2 (&v)[16], double2 *xbuf, const double2 *tw2s,
+                                        const double2 *__restrict__ tw1g, const double2 *__restrict__ xcg,
+                                        const double2 dc, const int t, const int wave, PhaseClock<TIMING> &clk,
+                                        RawPair &raw, const FusedParams &p, long long next_pair, int pad)
+{
+    // pass 1: DFT over a, twiddle W_4096^(k1 t) (L2-resident table)
+    dft16_twiddle(v, Tw1Fetch{scalar_ptr(tw1g), t});
+    clk.template stamp<P0>();
+    exchange<false>(v, xbuf, wave, t);
+    clk.template stamp<P0 + 1>();
+    // pass 2: DFT over b (k1 = hi, c = lo), twiddle W_256^(k2 c) from the LDS table
+    dft16_twiddle(v, Tw2Fetch{tw2s, t & 15});
+    clk.template stamp<P0 + 2>();
+    exchange<true>(v, xbuf, wave, t);
+    clk.template stamp<P0 + 3>();
+    // pass 3: DFT over c (k1 = lo, k2 = hi): f = t + 256 k3
+    if (MULXC) {
+        const gptr<double2> xcp = scalar_ptr(xcg);
+        double2 xa[8], xb[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            xa[j] = ldg2(xcp, 256 * j + t);
+        fence();
+        dft16(v);
+        fence();
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            xb[j] = ldg2(xcp, 256 * (8 + j) + t);
+        double2 w[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            w[k] = v[P16(k)];
+        if (t == 0) { // N == n: FFT(d - m)[0] = FFT(d)[0] - n m  (dc = 0 otherwise)
+            w[0].x -= dc.x;
+            w[0].y -= dc.y;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            v[j] = cmul(w[j], xa[j]);
+        fence();
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            v[8 + j] = cmul(w[8 + j], xb[j]);
+    } else {
+        fence();
+        issue_row_loads<PADDED>(raw, p, next_pair, t, pad);
+        fence();
+        dft16(v);
+        double2 w[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            w[k] = v[P16(k)];
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            v[k] = w[k];
+    }
+    clk.template stamp<P0 + 4>();
+}
+
+// shifted sums of one series: sum d, sum d^2  (d = x - x[0])
+struct Stat {
+    double s1, s2;
+};
+
+// zNormalize constants (xcorr.go:84-95 via the centred sample variance):
+// variance from the shifted sums; flags for the (nil,0,0) and NaN outcomes.
+__device__ __forceinline__ double variance(const Stat &s, double invN, double invNm1, bool &zero, bool &nan)
+{
+    const double var = (s.s2 - s.s1 * s.s1 * invN) * invNm1;
+    // NaN or +-Inf statistics: every cc is NaN in the reference.  (Not `var - var != 0`:
+    // under fp-contract the compiler fuses var's multiply into the subtraction and
+    // the rounding residual makes it true for finite values.)
+    nan = !__builtin_isfinite(var);
+    zero = !nan && !(var > 0.0);  // sigma == 0 (rounding may leave -0 / a tiny negative)
+    return var;
+}
+
+// cross-wave combine of one series' argmax + result store (threads 0 / 1 only):
+// r[6*w + {0,1,2}] = wave w's {max |cc|, signed value, first index}
+__device__ __forceinline__ void finalize(const double *r, const Stat &st, double invN, double invNm1,
+                                         double *mv_out, int *lag_out)
+{
+    double m[4], s[4], ix[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        m[w] = r[6 * w];
+        s[w] = r[6 * w + 1];
+        ix[w] = r[6 * w + 2];
+    }
+    double best = m[0], bsv = s[0], bidx = ix[0];
+#pragma unroll
+    for (int w = 1; w < 4; w++) {
+        if (m[w] > best || (m[w] == best && ix[w] < bidx)) {
+            best = m[w];
+            bsv = s[w];
+            bidx = ix[w];
+        }
+    }
+    bool zero, nan;
+    const double var = variance(st, invN, invNm1, zero, nan);
+    const int idx = (best > 0.0) ? (int)bidx : 0;           // nothing above 0: index 0, mv = cc[0]
+    double mv = ((best > 0.0) ? bsv : s[0]) * (1.0 / sqrt(var)); // 1/sigma applied to the winner only
+    int lag = idx > 2048 ? idx - 4096 : idx;
+    if (zero) { mv = 0.0; lag = 0; }                        // xcorr.go:166-167
+    if (nan) { mv = __builtin_nan(""); lag = 0; }           // NaN sigma: every cc is NaN
+    *mv_out = mv;
+    *lag_out = lag;
+}
+
+} // namespace occ4
+
+template <bool PADDED, int WPS, bool TIMING = false>
+__global__ __launch_bounds__(OCC_THREADS, WPS) void xcorr_fused_n4096_occ4(const FusedParams p)
+{
+    using namespace occ4;
+    __shared__ double2 xbuf[OCC_XBUF];
+    __shared__ double2 tw2s[256];
+    __shared__ double red[16 + 2 * 24]; // [0,16): z-norm partials; then 2 parities x 4 waves x 2 series x 3
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6); // wave-uniform by construction
+    const int N = p.N;
+    const int pad = 4096 - N;
+    const double invN = 1.0 / (double)N, invNm1 = 1.0 / (double)(N - 1);
+
+    tw2s[t] = p.tw2[t];
+    __syncthreads();
+    PhaseClock<TIMING> clk;
+    clk.start();
+
+    // state of the previous pair, kept by threads 0 (series A) and 1 (series B)
+    // until its cross-wave argmax combine runs behind this pair's first barrier
+    long long prev_row = -1;
+    Stat prev_stat{0.0, 0.0};
+    int parity = 0;
+
+    RawPair raw;
+    {
+        const long long first = blockIdx.x < p.npairs ? (long long)blockIdx.x : 0;
+        issue_row_loads<PADDED>(raw, p, first, t, pad);
+    }
+
+    for (long long pair = blockIdx.x; pair < p.npairs; pair += gridDim.x) {
+        const long long rA = 2 * pair, rB = rA + 1;
+        const bool hasB = rB < p.M;
+        // ---- consume the prefetched rows (element t + 256 i of the zero-padded rows)
+        double2 v[16];
+        const double KA = raw.ka, KB = raw.kb;
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            v[i] = make_double2(raw.a[i], raw.b[i]);
+        if (TIMING) // charge the load wait to phase 0
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        clk.template stamp<0>();
+        // ---- d = x - K, K = first sample (pads -> 0); shifted one-pass statistics:
+        // mean = K + S1/N, (N-1) var = S2 - S1^2/N.  K is a sample of the series, so
+        // (mean-K)^2 <= (N-1) var and the cancellation is bounded by ~N ulp.
+        double q[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            double da = v[i].x - KA, db = v[i].y - KB;
+            if (PADDED) {
+                const bool valid = t + 256 * i - pad >= 0;
+                da = valid ? da : 0.0;
+                db = valid ? db : 0.0;
+            }
+            v[i] = make_double2(da, db);
+            q[0] += da;
+            q[1] = fma(da, da, q[1]);
+            q[2] += db;
+            q[3] = fma(db, db, q[3]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            q[k] = wave_sum_dpp(q[k]);
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                red[wave * 4 + k] = q[k];
+        }
+        lds_barrier();
+#pragma unroll
+        for (int k = 0; k < 4; k++) // block totals: identical in every lane -> SGPRs
+            q[k] = uniform((red[k] + red[4 + k]) + (red[8 + k] + red[12 + k]));
+        // the previous pair's argmax triples are visible now: finish that pair
+        if (t < 2 && prev_row >= 0)
+            finalize(red + 16 + 24 * (parity ^ 1) + 3 * t, prev_stat, invN, invNm1, p.mv + prev_row,
+                     p.lag + prev_row);
+        const Stat stA{q[0], q[1]}, stB{q[2], q[3]};
+        bool zeroA, nanA, zeroB, nanB;
+        variance(stA, invN, invNm1, zeroA, nanA);
+        variance(stB, invN, invNm1, zeroB, nanB);
+        const double mA = uniform(q[0] * invN), mB = uniform(q[2] * invN); // mean of d
+        if (PADDED) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const bool valid = t + 256 * i - pad >= 0;
+                v[i].x = valid ? v[i].x - mA : 0.0;
+                v[i].y = valid ? v[i].y - mB : 0.0;
+            }
+        }
+        // a sigma == 0 / NaN series (or the missing partner of an odd last row) must
+        // contribute exact zeros to the shared complex transform
+        const bool deadA = zeroA || nanA, deadB = zeroB || nanB || !hasB;
+        if (deadA || deadB) { // block-uniform, rare
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                v[i].x = deadA ? 0.0 : v[i].x;
+                v[i].y = deadB ? 0.0 : v[i].y;
+            }
+        }
+        const double2 dc = PADDED ? make_double2(0.0, 0.0)
+                                  : make_double2(uniform(deadA ? 0.0 : 4096.0 * mA), uniform(deadB ? 0.0 : 4096.0 * mB));
+        clk.template stamp<1>();
+        // ---- Z = FFT(yA + i yB);  V[f] = Z[f] * conj(X[f]) / n
+        long long nxt = pair + gridDim.x; // last iteration: harmless re-read of this pair
+        nxt = nxt < p.npairs ? nxt : pair;
+        fft4096<2, true, PADDED>(v, xbuf, tw2s, p.tw1, p.xc, dc, t, wave, clk, raw, p, nxt, pad);
+        clk.template stamp<7>();
+        // ---- ccA + i ccB = FFT(V)   (unscaled by 1/sigma)
+        fft4096<8, false, PADDED>(v, xbuf, tw2s, p.tw1, p.xc, dc, t, wave, clk, raw, p, nxt, pad);
+
+        // ---- maxAbsIndex (xcorr.go:39-50), index = t + 256 k.  Per thread only
+        // max |cc| is tracked; the wave's first index attaining the wave maximum and
+        // its sign come from ballots (scalar unit).  Lowest k first, then lowest lane
+        // == lowest index, because t < 256.
+        double ma = 0.0, mb = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            ma = fmax(ma, fabs(v[k].x));
+            mb = fmax(mb, fabs(v[k].y));
+        }
+        const double wa = wave_max_dpp(ma), wb = wave_max_dpp(mb);
+        int widxA = 0x7fffffff, widxB = 0x7fffffff;
+        double svA = 0.0, svB = 0.0;
+        if (wa > 0.0) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const unsigned long long m = __ballot(fabs(v[k].x) == wa);
+                if (m != 0ull && widxA == 0x7fffffff) {
+                    const int l = __ffsll((long long)m) - 1;
+                    widxA = wave * 64 + l + 256 * k;
+                    const unsigned long long ng = __ballot(v[k].x < 0.0);
+                    svA = ((ng >> l) & 1ull) ? -wa : wa;
+                }
+            }
+        }
+        if (wb > 0.0) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const unsigned long long m = __ballot(fabs(v[k].y) == wb);
+                if (m != 0ull && widxB == 0x7fffffff) {
+                    const int l = __ffsll((long long)m) - 1;
+                    widxB = wave * 64 + l + 256 * k;
+                    const unsigned long long ng = __ballot(v[k].y < 0.0);
+                    svB = ((ng >> l) & 1ull) ? -wb : wb;
+                }
+            }
+        }
+        if (lane == 0) { // {max |cc|, signed value (cc[0] when nothing is above 0), index}
+            double *ra_ = red + 16 + 24 * parity + 6 * wave;
+            ra_[0] = widxA == 0x7fffffff ? 0.0 : wa;
+            ra_[1] = widxA == 0x7fffffff ? v[0].x : svA; // wave 0 lane 0 holds cc[0]
+            ra_[2] = (double)widxA;
+            ra_[3] = widxB == 0x7fffffff ? 0.0 : wb;
+            ra_[4] = widxB == 0x7fffffff ? v[0].y : svB;
+            ra_[5] = (double)widxB;
+        }
+        // no barrier here: the triples are combined behind the next pair's first one
+        if (t == 0) {
+            prev_row = rA;
+            prev_stat = stA;
+        } else if (t == 1) {
+            prev_row = hasB ? rB : -1;
+            prev_stat = stB;
+        }
+        parity ^= 1;
+        clk.template stamp<13>();
+    }
+    lds_barrier();
+    if (t < 2 && prev_row >= 0)
+        finalize(red + 16 + 24 * (parity ^ 1) + 3 * t, prev_stat, invN, invNm1, p.mv + prev_row, p.lag + prev_row);
+    if (TIMING && p.dbg && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < occ4::NPHASE; i++)
+            p.dbg[((long long)blockIdx.x * 4 + wave) * occ4::NPHASE + i] = clk.acc[i];
+    }
+}
+
+hipError_t launch_fused_occ4(const FusedParams &p, int num_cus, int waves_per_simd, hipStream_t stream)
+{
+    long long grid = p.npairs;
+    const long long cap = (long long)num_cus * waves_per_simd; // persistent: the resident workgroups
+    if (grid > cap)
+        grid = cap;
+    const dim3 g((unsigned)grid), b(OCC_THREADS);
+    if (waves_per_simd == 3) {
+        if (p.N < 4096)
+            hipLaunchKernelGGL((xcorr_fused_n4096_occ4<true, 3>), g, b, 0, stream, p);
+        else
+            hipLaunchKernelGGL((xcorr_fused_n4096_occ4<false, 3>), g, b, 0, stream, p);
+    } else {
+        if (p.N < 4096)
+            hipLaunchKernelGGL((xcorr_fused_n4096_occ4<true, 4>), g, b, 0, stream, p);
+        else
+            hipLaunchKernelGGL((xcorr_fused_n4096_occ4<false, 4>), g, b, 0, stream, p);
+    }
+    return hipGetLastError();
+}
+
+} // namespace muse

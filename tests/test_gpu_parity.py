@@ -252,23 +252,25 @@ def test_scores_match_oracle_all_lengths(muse, eng, oracle, N, M):
 
 
 @pytest.mark.parametrize("N", [2049, 3000, 4095, 4096])
-def test_tuned_and_generic_kernels_agree(muse, eng, oracle, N):
+def test_every_kernel_variant_matches_oracle(muse, eng, oracle, N):
+    """auto (0), generic (1) and each n = 4096 kernel generation (2..7) on the same
+    inputs, incl. N < n padding, sigma == 0, NaN / Inf rows and an odd row count."""
     ref, rows = _rows(65, N, N)
     rows[10, 5] = np.nan          # NaN row: (lag 0, mv NaN), must not disturb its pair partner
     rows[12, :] = np.inf
+    rows[20, :] = 2.0 ** 600      # huge but exactly summable constant: sigma == 0 without overflow
     dg = muse.DeviceGroup.from_rows(eng, rows)
     db = muse.DeviceBatch(eng, dg, ref)
     assert db.n == 4096
-    lag_t, mv_t = db.scores()
-    eng.set_kernel(1)
+    olag, omv, gap = oracle.batch_scores(ref, rows)
     try:
-        lag_g, mv_g = db.scores()
+        for variant in range(8):
+            eng.set_kernel(variant)
+            lag, mv = db.scores()
+            assert math.isnan(mv[10]) and lag[10] == 0 and math.isnan(mv[12]) and lag[12] == 0, variant
+            assert_scores_match(lag, mv, olag, omv, gap)
     finally:
         eng.set_kernel(0)
-    olag, omv, gap = oracle.batch_scores(ref, rows)
-    assert math.isnan(mv_t[10]) and lag_t[10] == 0 and math.isnan(mv_t[12]) and lag_t[12] == 0
-    assert_scores_match(lag_t, mv_t, olag, omv, gap)
-    assert_scores_match(lag_g, mv_g, olag, omv, gap)
 
 
 def test_config2_10000x4096_full_parity(muse, eng, oracle):
