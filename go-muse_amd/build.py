@@ -50,3 +50,20 @@ def build(force=False, verbose=False, extra_flags=()):
 if __name__ == "__main__":
     flags = [a for a in sys.argv[1:] if a.startswith("-") and a != "--force"]
     print(build(force=True, verbose=True, extra_flags=flags))
+
+
+HOST_TEST = os.path.join(LIBDIR, "muse_host_test")
+
+
+def build_host_test(force=False):
+    """g++ build of the C++ host mirror's test program (links libmuse_hip.so)."""
+    src = os.path.join(PKG, "host", "muse_host_test.cpp")
+    hdr = os.path.join(PKG, "host", "muse.hpp")
+    build()
+    if (not force and os.path.exists(HOST_TEST)
+            and os.path.getmtime(HOST_TEST) >= max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(LIB))):
+        return HOST_TEST
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I" + os.path.join(ROOT, "include"),
+                           "-I" + os.path.join(PKG, "host"), src, "-o", HOST_TEST,
+                           "-L" + LIBDIR, "-lmuse_hip", "-Wl,-rpath," + LIBDIR])
+    return HOST_TEST

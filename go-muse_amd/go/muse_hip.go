@@ -1,0 +1,199 @@
+// Package muse -- cgo binding of libmuse_hip.so for aouyang1/go-muse.
+//
+// WRITTEN BLIND: the build image has no Go toolchain, so this file has never
+// been compiled.  It is the reference-side binding a maintainer would add next
+// to the existing sources (series.go, group.go, labels.go, results.go,
+// scores.go stay as they are); it replaces the bodies of NewBatch / Batch.Run
+// (muse_batch.go:23-130) and New / Muse.Run (muse.go:23-92) and deletes
+// xcorr.go's hot loop.  Every cgo call copies its inputs (no Go pointer is
+// retained by C after the call returns), as the cgo pointer rules require.
+//
+// Build: CGO_CFLAGS="-I${REPO}/include" CGO_LDFLAGS="-L${REPO}/go-muse_amd/lib -lmuse_hip"
+package muse
+
+/*
+#cgo LDFLAGS: -lmuse_hip
+#include <stdlib.h>
+#include "muse_hip.h"
+*/
+import "C"
+
+import (
+	"errors"
+	"fmt"
+	"runtime"
+	"sort"
+	"unsafe"
+)
+
+// hipError turns a muse_status into a Go error carrying muse_last_error().
+func hipError(status C.int) error {
+	if status == C.MUSE_OK {
+		return nil
+	}
+	return errors.New(C.GoString(C.muse_last_error()))
+}
+
+// engine is one muse_ctx (one GPU).  A process-wide default is created lazily.
+type engine struct{ ctx *C.muse_ctx }
+
+var defaultEngine *engine
+
+func getEngine() (*engine, error) {
+	if defaultEngine == nil {
+		e := &engine{}
+		// cgo calls that use muse_last_error must stay on one OS thread
+		runtime.LockOSThread()
+		defer runtime.UnlockOSThread()
+		if err := hipError(C.muse_ctx_create(0, &e.ctx)); err != nil {
+			return nil, err
+		}
+		defaultEngine = e
+	}
+	return defaultEngine, nil
+}
+
+// deviceGroup mirrors Group's rows on the GPU; rows are appended once.
+type deviceGroup struct {
+	g        *C.muse_group
+	uploaded int
+}
+
+// residentRows uploads the series added since the last call (Group.Add order).
+// Group gains two fields: order []*Series (insertion order) and dev *deviceGroup.
+func (g *Group) residentRows(e *engine) (*C.muse_group, error) {
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	if g.dev == nil {
+		d := &deviceGroup{}
+		n := g.n
+		if n < 1 {
+			n = 1
+		}
+		if err := hipError(C.muse_group_create(e.ctx, C.int64_t(len(g.order)), C.int32_t(n), &d.g)); err != nil {
+			return nil, err
+		}
+		runtime.SetFinalizer(d, func(d *deviceGroup) { C.muse_group_free(d.g) })
+		g.dev = d
+	}
+	for ; g.dev.uploaded < len(g.order); g.dev.uploaded++ {
+		y := g.order[g.dev.uploaded].y
+		st := C.muse_group_append(g.dev.g, (*C.double)(unsafe.Pointer(&y[0])), 1, C.int64_t(len(y)))
+		if err := hipError(st); err != nil {
+			return nil, err
+		}
+	}
+	return g.dev.g, nil
+}
+
+// Batch keeps the exported fields of muse_batch.go:13-19; x and n are gone
+// (the reference spectrum lives on the device).
+type Batch struct {
+	ref         []float64
+	Comparison  *Group
+	Results     *Results
+	Concurrency int
+	batch       *C.muse_batch
+	batchGroup  *C.muse_group
+}
+
+// NewBatch replaces muse_batch.go:23-52: same length check, same
+// "Invalid input query" error on a constant reference.
+func NewBatch(ref *Series, comp *Group, results *Results, cc int) (*Batch, error) {
+	for uid, s := range comp.registry {
+		if ref.Length() != s.Length() {
+			return nil, fmt.Errorf("%s from comparison group series does not have the same length as the reference", uid)
+		}
+	}
+	if cc < 1 {
+		cc = 1
+	}
+	e, err := getEngine()
+	if err != nil {
+		return nil, err
+	}
+	b := &Batch{ref: append([]float64(nil), ref.Values()...), Comparison: comp, Results: results, Concurrency: cc}
+	// validate the reference now (sigma == 0 -> error), as the reference does
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	var probe *C.muse_group
+	if err := hipError(C.muse_group_create(e.ctx, 0, C.int32_t(len(b.ref)), &probe)); err != nil {
+		return nil, err
+	}
+	defer C.muse_group_free(probe)
+	var mb *C.muse_batch
+	st := C.muse_batch_create(e.ctx, probe, (*C.double)(unsafe.Pointer(&b.ref[0])), C.int32_t(len(b.ref)), &mb)
+	if err := hipError(st); err != nil {
+		return nil, fmt.Errorf("Invalid input query, %v", err)
+	}
+	C.muse_batch_free(mb)
+	return b, nil
+}
+
+// Run replaces muse_batch.go:99-130.  groupByLabels semantics are unchanged
+// (indexLabelValues, group.go:76-104); the goroutine fan-out becomes one fused
+// kernel launch over the resident matrix plus a device-side group-max / top-N.
+func (b *Batch) Run(groupByLabels []string) error {
+	labelValuesSet := b.Comparison.indexLabelValues(groupByLabels)
+	if len(labelValuesSet) == 0 {
+		return nil
+	}
+	e, err := getEngine()
+	if err != nil {
+		return err
+	}
+	dg, err := b.Comparison.residentRows(e)
+	if err != nil {
+		return err
+	}
+	// group id of every series, in upload order
+	pos := make(map[string]int, len(b.Comparison.order))
+	for i, s := range b.Comparison.order {
+		pos[s.UID()] = i
+	}
+	gid := make([]C.int32_t, len(b.Comparison.order))
+	gi := 0
+	for _, lv := range labelValuesSet {
+		for _, uid := range b.Comparison.index[lv.ID(lv.Keys())] {
+			gid[pos[uid]] = C.int32_t(gi)
+		}
+		gi++
+	}
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	if b.batch == nil || b.batchGroup != dg {
+		if b.batch != nil {
+			C.muse_batch_free(b.batch)
+		}
+		st := C.muse_batch_create(e.ctx, dg, (*C.double)(unsafe.Pointer(&b.ref[0])), C.int32_t(len(b.ref)), &b.batch)
+		if err := hipError(st); err != nil {
+			return err
+		}
+		b.batchGroup = dg
+	}
+	r := b.Results
+	top := r.TopN
+	if top < 1 {
+		top = 1
+	}
+	idx := make([]C.int64_t, top)
+	lag := make([]C.int32_t, top)
+	score := make([]C.double, top)
+	var cnt C.int32_t
+	var mean C.double
+	st := C.muse_batch_run(b.batch, &gid[0], C.int32_t(len(labelValuesSet)), C.int32_t(r.MaxLag), C.int32_t(r.TopN),
+		C.double(r.Threshold), C.int32_t(r.SignFilter), 1, &idx[0], &lag[0], &score[0], &cnt, &mean)
+	if err := hipError(st); err != nil {
+		return err
+	}
+	// ordered drain (muse_batch.go:124-128): feed Results in group order
+	order := make([]int, int(cnt))
+	for i := range order {
+		order[i] = i
+	}
+	sort.SliceStable(order, func(a, c int) bool { return gid[idx[order[a]]] < gid[idx[order[c]]] })
+	for _, k := range order {
+		b.Results.Update(Score{Labels: b.Comparison.order[idx[k]].Labels(), Lag: int(lag[k]), PercentScore: float64(score[k])})
+	}
+	return nil
+}

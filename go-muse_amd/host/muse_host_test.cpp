@@ -1,0 +1,181 @@
+// muse_host_test.cpp -- the reference's driver tests, restated against the C++
+// host mirror (muse.hpp) over libmuse_hip.so.  Tables are the reference's own
+// (muse_batch_test.go:9-102, muse_test.go:41-142); compareScores follows
+// muse_test.go:11-39 (order, exact lag, score within 1e-3, labels).
+// Exit code 0 = all passed.  Needs a gfx950 GPU (there is no CPU fallback).
+#include <cstdio>
+#include <cmath>
+#include <string>
+#include <vector>
+
+#include "muse.hpp"
+
+using namespace muse;
+static int failures = 0;
+#define EXPECT(cond, ...)                                                                       \
+    do {                                                                                        \
+        if (!(cond)) {                                                                          \
+            failures++;                                                                         \
+            printf("FAIL %s:%d: ", __FILE__, __LINE__);                                         \
+            printf(__VA_ARGS__);                                                                \
+            printf("\n");                                                                       \
+        }                                                                                       \
+    } while (0)
+
+struct Expect {
+    LabelMap labels;
+    std::vector<int> lags; // more than one: exact tie in exact arithmetic
+    double score;
+};
+
+static void compareScores(const Scores &got, const std::vector<Expect> &exp, const char *name)
+{
+    EXPECT(got.size() == exp.size(), "%s: got %zu scores, expected %zu", name, got.size(), exp.size());
+    for (size_t i = 0; i < got.size() && i < exp.size(); i++) {
+        bool lag_ok = false;
+        for (int l : exp[i].lags)
+            lag_ok |= (l == got[i].Lag);
+        EXPECT(lag_ok, "%s[%zu]: lag %d", name, i, got[i].Lag);
+        EXPECT(std::fabs(got[i].PercentScore - exp[i].score) <= 1e-3, "%s[%zu]: score %.4f vs %.3f", name, i,
+               got[i].PercentScore, exp[i].score);
+        EXPECT(got[i].Labels->Map() == exp[i].labels, "%s[%zu]: labels %s", name, i, got[i].Labels->ID().c_str());
+    }
+}
+
+static const std::vector<double> REF12 = {0, 0, 0, 0, 1, 2, 3, 3, 2, 1, 0, 0};
+
+static void TestBatchRunSimple() // muse_batch_test.go:9-44
+{
+    auto ref = NewSeries(REF12, NewLabels({{"graph", "graph1"}}));
+    auto g = NewGroup("targets");
+    g->Add({NewSeries({0, 0, 0, 0, 2, 4, 6, 6, 4, 2, 0, 0}, NewLabels({{"graph", "perfectMatch"}})),
+            NewSeries({0, 0, 0, 0, 2, 4, 6, 4, 2, 0, 0, 0}, NewLabels({{"graph", "slightlyLower"}})),
+            NewSeries({0, 0, 0, 2, 4, 2, 0, 0, 0, 0, 0, 0}, NewLabels({{"graph", "evenLower"}})),
+            NewSeries({0, 0, 0, 0, 0, 0, 0, 0, 2, 3, 2, 0}, NewLabels({{"graph", "evenLowerShiftedAhead"}})),
+            NewSeries(std::vector<double>(12, 3.0), NewLabels({{"graph", "zeros"}}))});
+    auto b = NewBatch(ref, g, NewResults(10, 20, 0, SignFilter_ANY), 10);
+    b->Run({"graph"});
+    compareScores(b->Results_->Fetch().first,
+                  {{{{"graph", "perfectMatch"}}, {0}, 1.000},
+                   {{{"graph", "slightlyLower"}}, {0}, 0.929},
+                   {{{"graph", "evenLowerShiftedAhead"}}, {-3, -2}, 0.754},
+                   {{{"graph", "evenLower"}}, {2}, 0.733},
+                   {{{"graph", "zeros"}}, {0}, 0.0}},
+                  "TestBatchRunSimple");
+}
+
+static void TestBatchRunMultiDimensional() // muse_batch_test.go:46-82
+{
+    auto ref = NewSeries({0.0, 0.0, 0.0, 0.0, 0.1, 0.2, 0.3, 0.4}, NewLabels({{"graph", "graph1"}}));
+    auto L = [](const char *g, const char *h) { return NewLabels({{"graph", g}, {"host", h}}); };
+    auto grp = NewGroup("targets");
+    grp->Add({NewSeries({0.0, 0.0, 0.0, 0.0, 0.1, 0.2, 0.3, 0.4}, L("graph1", "host1")),
+              NewSeries({0.2, 0.1, 0.2, 0.1, 0.2, 0.1, 0.2, 0.1}, L("graph1", "host2")),
+              NewSeries({0.0, 0.0, 0.0, 0.0, 0.2, 0.4, 0.4, 0.8}, L("graph2", "host1")),
+              NewSeries({0.2, 0.1, 0.2, 0.1, 0.2, 0.1, 0.22, 0.1}, L("graph3", "host1")),
+              NewSeries({0.0, 0.0, 0.0, 0.0, -0.2, -0.4, 0.0, -0.8}, L("graph4", "host1")),
+              NewSeries({0.0, 0.0, 0.0, -0.2, -0.4, -0.6, 1.0, 0.0}, L("graph5", "host1"))});
+    auto m = NewBatch(ref, grp, NewResults(10, 20, 0, SignFilter_ANY), 10);
+    m->Run({"graph"});
+    compareScores(m->Results_->Fetch().first,
+                  {{{{"graph", "graph1"}, {"host", "host1"}}, {0}, 1.000},
+                   {{{"graph", "graph2"}, {"host", "host1"}}, {0}, 0.976},
+                   {{{"graph", "graph4"}, {"host", "host1"}}, {0}, 0.759},
+                   {{{"graph", "graph5"}, {"host", "host1"}}, {2}, 0.719},
+                   {{{"graph", "graph3"}, {"host", "host1"}}, {1}, 0.248}},
+                  "TestBatchRunMultiDimensional");
+}
+
+static void TestBatchRunWithLargerGroup() // muse_batch_test.go:83-102
+{
+    auto ref = NewSeries({0, 1, 2, 3, 3, 2, 1, 0}, NewLabels({{"graph", "graph1"}}));
+    auto g = NewGroup("targets");
+    std::vector<double> longer(20, 0.0);
+    g->Add({NewSeries(longer, NewLabels({{"graph", "longer"}}))});
+    bool threw = false;
+    try {
+        NewBatch(ref, g, NewResults(10, 20, 0, SignFilter_ANY), 1);
+    } catch (const Error &e) {
+        threw = e.status == MUSE_ERR_LENGTH;
+    }
+    EXPECT(threw, "TestBatchRunWithLargerGroup: expected a length-mismatch error");
+    threw = false;
+    try { // muse_batch.go:39-41
+        NewBatch(NewSeries({2, 2, 2, 2}), NewGroup("e"), NewResults(10, 20, 0, SignFilter_ANY), 1);
+    } catch (const Error &e) {
+        threw = e.status == MUSE_ERR_ZERO_STD;
+    }
+    EXPECT(threw, "NewBatch: expected Invalid input query on sigma == 0");
+}
+
+static std::vector<std::pair<std::vector<double>, const char *>> museComp()
+{
+    return {{{0, 0, 0, 0, 2, 4, 6, 6, 4, 2, 0, 0}, "perfectMatch"},
+            {{0, 0, 0, 0, 2, 4, 6, 4, 2, 0, 0, 0}, "slightlyLower"},
+            {{0, 0, 0, 2, 4, 2, 0, 0, 0, 0, 0, 0}, "evenLower"},
+            {{0, 0, 0, 0, 0, 0, 0, 0, -2, -3, -2, 0}, "evenLowerShiftedAhead"},
+            {std::vector<double>(12, 3.0), "zeros"}};
+}
+
+static void TestRunSimple() // muse_test.go:41-73
+{
+    auto g = New(NewSeries(REF12, NewLabels({{"graph", "graph1"}})), NewResults(10, 20, 0, SignFilter_ANY));
+    for (auto &c : museComp())
+        g->Run({NewSeries(c.first, NewLabels({{"graph", c.second}}))});
+    compareScores(g->Results_->Fetch().first,
+                  {{{{"graph", "perfectMatch"}}, {0}, 1.000},
+                   {{{"graph", "slightlyLower"}}, {0}, 0.929},
+                   {{{"graph", "evenLowerShiftedAhead"}}, {-3, -2}, -0.754},
+                   {{{"graph", "evenLower"}}, {2}, 0.733},
+                   {{{"graph", "zeros"}}, {0}, 0.0}},
+                  "TestRunSimple");
+}
+
+static void TestRunSimpleSignFilter() // muse_test.go:75-104 (first pass) + NEG on fresh inputs
+{
+    auto g = New(NewSeries(REF12, NewLabels({{"graph", "graph1"}})), NewResults(10, 20, 0, SignFilter_POS));
+    for (auto &c : museComp())
+        g->Run({NewSeries(c.first, NewLabels({{"graph", c.second}}))});
+    compareScores(g->Results_->Fetch().first,
+                  {{{{"graph", "perfectMatch"}}, {0}, 1.000},
+                   {{{"graph", "slightlyLower"}}, {0}, 0.929},
+                   {{{"graph", "evenLower"}}, {2}, 0.733}},
+                  "TestRunSimpleSignFilter/POS");
+    g = New(NewSeries(REF12, NewLabels({{"graph", "graph1"}})), NewResults(10, 20, 0, SignFilter_NEG));
+    for (auto &c : museComp())
+        g->Run({NewSeries(c.first, NewLabels({{"graph", c.second}}))});
+    compareScores(g->Results_->Fetch().first, {{{{"graph", "evenLowerShiftedAhead"}}, {-3, -2}, -0.754}},
+                  "TestRunSimpleSignFilter/NEG");
+}
+
+static void TestRunNoInput() // muse_test.go:122-142
+{
+    auto g = New(NewSeries(REF12, NewLabels({{"graph", "graph1"}})), NewResults(10, 20, 0, SignFilter_ANY));
+    g->Run({});
+    auto r = g->Results_->Fetch();
+    EXPECT(r.first.empty() && std::isnan(r.second), "TestRunNoInput");
+    bool threw = false;
+    try { // muse.go:68-70
+        g->Run({NewSeries({1, 2, 3})});
+    } catch (const Error &e) {
+        threw = e.status == MUSE_ERR_LENGTH;
+    }
+    EXPECT(threw, "Muse.Run: expected a length error");
+}
+
+int main()
+{
+    try {
+        TestBatchRunSimple();
+        TestBatchRunMultiDimensional();
+        TestBatchRunWithLargerGroup();
+        TestRunSimple();
+        TestRunSimpleSignFilter();
+        TestRunNoInput();
+    } catch (const Error &e) {
+        printf("muse::Error %d: %s\n", e.status, e.what());
+        return 2;
+    }
+    printf(failures ? "%d FAILURES\n" : "all host tests passed\n", failures);
+    return failures ? 1 : 0;
+}

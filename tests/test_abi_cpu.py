@@ -125,3 +125,17 @@ def test_results_heap_matches_oracle(muse, oracle):
     assert [int(s.Labels.Get("i")[0]) for s in got] == oi.tolist()
     assert [s.PercentScore for s in got] == osc.tolist() and mean == omean
     assert r.Fetch()[0] == [] and math.isnan(r.Fetch()[1])   # Fetch drains (results.go:75-87)
+
+
+def test_cpp_host_mirror_builds_and_fails_loudly_without_gpu(muse):
+    """go-muse_amd/host/muse.hpp (the compiled-language host layer over the C ABI)
+    compiles with g++, links libmuse_hip.so, and its test program refuses to run
+    without a GPU instead of falling back to anything."""
+    import subprocess
+    import torch
+    exe = muse.build.build_host_test()
+    assert os.path.exists(exe)
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: covered by the gpu-marked test")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "no HIP device" in r.stdout

@@ -412,3 +412,12 @@ def test_full_size_1m_x_4096_properties(muse, eng, oracle):
     got = db.run(gid, M // 50, 15, 20, 0.0, 0, True)
     exp = oracle.results(lag, mv, gid, M // 50, True, 15, 20, 0.0, 0)   # host semantics on GPU scores
     assert got[1].tolist() == exp[1].tolist() and np.array_equal(got[2], exp[2])
+
+
+def test_cpp_host_mirror_reference_tests(muse):
+    """the reference's driver tests restated in C++ over the C ABI (host/muse_host_test.cpp)"""
+    import subprocess
+    exe = muse.build.build_host_test()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all host tests passed" in r.stdout
