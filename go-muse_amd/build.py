@@ -13,7 +13,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libmuse_hip.so")
-SOURCES = ["xcorr_kernels.hip", "xcorr_r16_split.hip", "xcorr_r16_pipe.hip", "xcorr_r16_occ4.hip", "reduce_kernels.hip", "muse_capi.hip"]
+SOURCES = ["xcorr_kernels.hip", "xcorr_r16_split.hip", "xcorr_r16_pipe.hip", "xcorr_r16_occ4.hip", "xcorr_r16_screen.hip", "reduce_kernels.hip", "muse_capi.hip"]
 HEADERS = [os.path.join(CSRC, "xcorr_kernels.h"), os.path.join(CSRC, "fft_device.h"), os.path.join(ROOT, "include", "muse_hip.h")]
 
 
@@ -32,15 +32,28 @@ def stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+# per-source extra flags: the fp32 screening kernel must keep scalar fp32 ops (2-cycle
+# issue); SLP packing into v_pk_*_f32 costs v_mov shuffles and issues no faster
+PER_FILE_FLAGS = {"xcorr_r16_screen.hip": ["-fno-slp-vectorize"]}
+
+
 def build(force=False, verbose=False, extra_flags=()):
     if not force and not stale():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
-    cmd += list(extra_flags)
-    cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += ["-o", LIB]
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    base = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
+            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + list(extra_flags)
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(objdir, src + ".o")
+        cmd = base + PER_FILE_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

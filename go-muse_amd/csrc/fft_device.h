@@ -160,4 +160,105 @@ __device__ __forceinline__ int wave_min_i_dpp(int v)
                min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
+
+// ------------------------------------------------------------- fp32 complex
+// A plain struct of two floats on purpose: every operation is a scalar fp32 VALU
+// op (2-cycle issue).  With a native 2-vector type (or SLP vectorisation) the
+// compiler emits v_pk_*_f32, which issue no faster per flop and cost v_mov
+// shuffles to pair registers (measured: 400 v_mov per pair of series).
+struct alignas(8) f2 {
+    float x, y;
+};
+__device__ __forceinline__ f2 mk2(float x, float y)
+{
+    f2 r;
+    r.x = x;
+    r.y = y;
+    return r;
+}
+__device__ __forceinline__ f2 caddf(f2 a, f2 b) { return mk2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ f2 csubf(f2 a, f2 b) { return mk2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ f2 cmulf(f2 a, f2 w) // a * w
+{
+    return mk2(a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x);
+}
+
+__device__ __forceinline__ void radix4f(f2 &a, f2 &b, f2 &c, f2 &d)
+{
+    const f2 t0 = caddf(a, c), t1 = csubf(a, c), t2 = caddf(b, d), t3 = csubf(b, d);
+    a = caddf(t0, t2);
+    c = csubf(t0, t2);
+    b = mk2(t1.x + t3.y, t1.y - t3.x); // t1 - i*t3
+    d = mk2(t1.x - t3.y, t1.y + t3.x); // t1 + i*t3
+}
+
+// 16-point DFT in registers, fp32: same dataflow as dft16 (output X[k] at v[P16(k)])
+__device__ __forceinline__ void dft16f(f2 (&v)[16])
+{
+    constexpr float C1 = 0.92387953251128675613f; // cos(pi/8)
+    constexpr float S1 = 0.38268343236508977173f; // sin(pi/8)
+    constexpr float H = 0.70710678118654752440f;  // sqrt(1/2)
+#pragma unroll
+    for (int a0 = 0; a0 < 4; a0++)
+        radix4f(v[a0], v[a0 + 4], v[a0 + 8], v[a0 + 12]);
+    f2 u;
+    u = v[1 + 4];  v[1 + 4]  = mk2(u.x * C1 + u.y * S1, u.y * C1 - u.x * S1);
+    u = v[1 + 8];  v[1 + 8]  = mk2((u.x + u.y) * H, (u.y - u.x) * H);
+    u = v[1 + 12]; v[1 + 12] = mk2(u.x * S1 + u.y * C1, u.y * S1 - u.x * C1);
+    u = v[2 + 4];  v[2 + 4]  = mk2((u.x + u.y) * H, (u.y - u.x) * H);
+    u = v[2 + 8];  v[2 + 8]  = mk2(u.y, -u.x);
+    u = v[2 + 12]; v[2 + 12] = mk2((u.y - u.x) * H, -(u.x + u.y) * H);
+    u = v[3 + 4];  v[3 + 4]  = mk2(u.x * S1 + u.y * C1, u.y * S1 - u.x * C1);
+    u = v[3 + 8];  v[3 + 8]  = mk2((u.y - u.x) * H, -(u.x + u.y) * H);
+    u = v[3 + 12]; v[3 + 12] = mk2(-u.x * C1 - u.y * S1, u.x * S1 - u.y * C1);
+#pragma unroll
+    for (int k1 = 0; k1 < 4; k1++)
+        radix4f(v[4 * k1], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);
+}
+
+// fp32 DPP all-lanes max of non-negative values
+__device__ __forceinline__ float wave_max_f32_dpp(float v)
+{
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, false)));
+    const float a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float c = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float d = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return fmaxf(fmaxf(a, b), fmaxf(c, d));
+}
+
+
+// In-kernel phase stamps (diagnostic builds only: TIMING = false in every
+// shipped instantiation, where all of this compiles to nothing).
+constexpr int NPHASE = 16;
+template <bool TIMING>
+struct PhaseClock {
+    unsigned long long acc[NPHASE];
+    unsigned long long last;
+    __device__ __forceinline__ void start()
+    {
+        if (TIMING) {
+#pragma unroll
+            for (int i = 0; i < NPHASE; i++)
+                acc[i] = 0;
+            last = __builtin_amdgcn_s_memtime();
+        }
+    }
+    template <int I>
+    __device__ __forceinline__ void stamp()
+    {
+        if (TIMING) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            acc[I] += now - last;
+            last = now;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+};
+
+
 } // namespace muse

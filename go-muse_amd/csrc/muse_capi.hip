@@ -78,6 +78,8 @@ struct muse_ctx {
     int64_t hbm = 0;
     char name[64] = {0};
     double2 *tw1 = nullptr, *tw2 = nullptr, *twm = nullptr;
+    float2 *tw1f = nullptr, *tw2f = nullptr; // fp32 copies for the screening kernel
+    double screen_delta = 1e-4;
     int variant = 0;
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -101,6 +103,11 @@ struct muse_batch {
     muse_group *g = nullptr;
     int32_t N = 0, n = 0, logn = 0;
     double2 *X = nullptr, *xc = nullptr;
+    float2 *xcf = nullptr; // fp32 conj(X)/n (screening kernel)
+    double *xs = nullptr;  // padded time-domain reference (exact re-evaluation)
+    int *ovf_count = nullptr;
+    long long *ovf_list = nullptr;
+    int64_t ovf_cap = 0;
     double *mv = nullptr;
     int *lag = nullptr;
     int64_t score_cap = 0;
@@ -178,6 +185,17 @@ extern "C" int muse_ctx_create(int32_t device, muse_ctx **out)
     HIP_TRY(hipMemcpy(ctx->tw1, t1.data(), t1.size() * sizeof(double2), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ctx->tw2, t2.data(), t2.size() * sizeof(double2), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ctx->twm, tm.data(), tm.size() * sizeof(double2), hipMemcpyHostToDevice));
+    std::vector<float2> t1f(t1.size()), t2f(t2.size());
+    for (size_t i = 0; i < t1.size(); i++)
+        t1f[i] = make_float2((float)t1[i].x, (float)t1[i].y);
+    for (size_t i = 0; i < t2.size(); i++)
+        t2f[i] = make_float2((float)t2[i].x, (float)t2[i].y);
+    HIP_TRY(hipMalloc(&ctx->tw1f, t1f.size() * sizeof(float2)));
+    HIP_TRY(hipMalloc(&ctx->tw2f, t2f.size() * sizeof(float2)));
+    HIP_TRY(hipMemcpy(ctx->tw1f, t1f.data(), t1f.size() * sizeof(float2), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->tw2f, t2f.data(), t2f.size() * sizeof(float2), hipMemcpyHostToDevice));
+    if (const char *dv = getenv("MUSE_HIP_SCREEN_DELTA"))
+        ctx->screen_delta = atof(dv);
     *out = ctx;
     return MUSE_OK;
 }
@@ -196,6 +214,8 @@ static void ctx_release(muse_ctx *ctx)
     (void)hipFree(ctx->tw1);
     (void)hipFree(ctx->tw2);
     (void)hipFree(ctx->twm);
+    (void)hipFree(ctx->tw1f);
+    (void)hipFree(ctx->tw2f);
     if (ctx->stream)
         (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -231,7 +251,7 @@ extern "C" int muse_ctx_device_info(muse_ctx *ctx, char *name, int32_t name_cap,
 
 extern "C" int muse_ctx_set_kernel(muse_ctx *ctx, int32_t variant)
 {
-    if (!ctx || variant < 0 || variant > 7)
+    if (!ctx || variant < 0 || variant > 8)
         return fail(MUSE_ERR_INVALID, "bad kernel variant");
     ctx->variant = variant;
     return MUSE_OK;
@@ -440,7 +460,7 @@ static int ilog2(int64_t n)
 
 // device reference spectrum for (ref, N) at FFT length n: fills X, xc
 static int build_spectrum(muse_ctx *ctx, const double *ref_host, int N, int n, int normalize, double x_scale,
-                          double xc_scale, double2 *X, double2 *xc, int *zero_std)
+                          double xc_scale, double2 *X, double2 *xc, float2 *xcf, double *xs, int *zero_std)
 {
     double *dref = nullptr;
     int *dstat = nullptr;
@@ -449,7 +469,7 @@ static int build_spectrum(muse_ctx *ctx, const double *ref_host, int N, int n, i
     if (e == hipSuccess)
         e = hipMemcpyAsync(dref, ref_host, (size_t)N * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess)
-        e = launch_ref_spectrum(dref, N, n, ilog2(n), normalize, x_scale, xc_scale, ctx->twm, X, xc, dstat,
+        e = launch_ref_spectrum(dref, N, n, ilog2(n), normalize, x_scale, xc_scale, ctx->twm, X, xc, xcf, xs, dstat,
                                 ctx->stream);
     int st = 0;
     if (e == hipSuccess)
@@ -497,13 +517,20 @@ extern "C" int muse_batch_create(muse_ctx *ctx, muse_group *g, const double *ref
     hipError_t e = hipMalloc(&b->X, (size_t)(n / 2 + 1) * sizeof(double2));
     if (e == hipSuccess)
         e = hipMalloc(&b->xc, (size_t)n * sizeof(double2));
+    if (e == hipSuccess)
+        e = hipMalloc(&b->xcf, (size_t)n * sizeof(float2));
+    if (e == hipSuccess)
+        e = hipMalloc(&b->xs, (size_t)n * sizeof(double));
+    if (e == hipSuccess)
+        e = hipMalloc(&b->ovf_count, sizeof(int));
     if (e != hipSuccess) {
         muse_batch_free(b);
         return fail(MUSE_ERR_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e));
     }
     int zero = 0;
     // x = zNormalize(ref) / (N-1), zeroPad, FFT   (muse_batch.go:38-47)
-    rc = build_spectrum(ctx, ref, N, (int)n, 1, 1.0 / (double)(N - 1), 1.0 / (double)n, b->X, b->xc, &zero);
+    rc = build_spectrum(ctx, ref, N, (int)n, 1, 1.0 / (double)(N - 1), 1.0 / (double)n, b->X, b->xc, b->xcf, b->xs,
+                        &zero);
     if (rc) {
         muse_batch_free(b);
         return rc;
@@ -582,6 +609,11 @@ extern "C" int muse_batch_score(muse_batch *b)
     p.lag = b->lag;
     p.cc_out = nullptr;
     p.nil_out = nullptr;
+    p.tw1f = ctx->tw1f;
+    p.tw2f = ctx->tw2f;
+    p.xcf = b->xcf;
+    p.xs = b->xs;
+    p.screen_delta = ctx->screen_delta;
     // kernel selection: ctx->variant 0 = auto; 1 = generic LDS radix-2; 2..7 force one
     // of the n = 4096 kernels (parity tests run every one of them on the same inputs)
     int variant = KERNEL_GENERIC;
@@ -594,6 +626,7 @@ extern "C" int muse_batch_score(muse_batch *b)
         case 5: variant = KERNEL_R16_PIPE; break;
         case 6: variant = KERNEL_R16_OCC4; break;
         case 7: variant = KERNEL_R16_OCC3; break;
+        case 8: variant = KERNEL_R16_SCREEN; break;
         default: variant = KERNEL_GENERIC; break;
         }
     }
@@ -603,7 +636,29 @@ extern "C" int muse_batch_score(muse_batch *b)
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, ctx->stream));
     }
-    HIP_TRY(launch_fused(p, variant, ctx->num_cus, ctx->stream));
+    if (variant == KERNEL_R16_SCREEN) {
+        // pairs with too many near-tie candidates are listed by the screening kernel and
+        // redone by the fp64 kernel right behind it (no host round trip: the count stays on
+        // the device and bounds the second launch's loop)
+        if (p.npairs > b->ovf_cap) {
+            (void)hipFree(b->ovf_list);
+            b->ovf_list = nullptr;
+            b->ovf_cap = 0;
+            HIP_TRY(hipMalloc(&b->ovf_list, (size_t)p.npairs * sizeof(long long)));
+            b->ovf_cap = p.npairs;
+        }
+        p.ovf_count = b->ovf_count;
+        p.ovf_list = b->ovf_list;
+        HIP_TRY(hipMemsetAsync(b->ovf_count, 0, sizeof(int), ctx->stream));
+        HIP_TRY(launch_fused(p, KERNEL_R16_SCREEN, ctx->num_cus, ctx->stream));
+        FusedParams q = p;
+        q.pair_list = b->ovf_list;
+        q.pair_count = b->ovf_count;
+        q.npairs = std::min<long long>(p.npairs, 64); // grid size only; the loop bound is *pair_count
+        HIP_TRY(launch_fused(q, KERNEL_R16_OCC3, ctx->num_cus, ctx->stream));
+    } else {
+        HIP_TRY(launch_fused(p, variant, ctx->num_cus, ctx->stream));
+    }
     if (ctx->timing) {
         HIP_TRY(hipEventRecord(e1, ctx->stream));
         ctx->events.emplace_back(e0, e1);
@@ -897,6 +952,10 @@ extern "C" int muse_batch_free(muse_batch *b)
     (void)hipStreamSynchronize(b->ctx->stream);
     (void)hipFree(b->X);
     (void)hipFree(b->xc);
+    (void)hipFree(b->xcf);
+    (void)hipFree(b->xs);
+    (void)hipFree(b->ovf_count);
+    (void)hipFree(b->ovf_list);
     (void)hipFree(b->mv);
     (void)hipFree(b->lag);
     (void)hipFree(b->gid_dev);
@@ -961,7 +1020,7 @@ static int single_pair(muse_ctx *ctx, const double *x, int lenx, const double *y
         SP_TRY(hipMalloc(&dX, (size_t)(n / 2 + 1) * sizeof(double2)));
         SP_TRY(hipMalloc(&dxc, (size_t)n * sizeof(double2)));
         int zero = 0;
-        rc = build_spectrum(ctx, x, lenx, n, normalize_x, x_scale, cc_scale, dX, dxc, &zero);
+        rc = build_spectrum(ctx, x, lenx, n, normalize_x, x_scale, cc_scale, dX, dxc, nullptr, nullptr, &zero);
         if (rc) {
             cleanup();
             return rc;

@@ -8,7 +8,7 @@
 
 namespace muse {
 
-enum { KERNEL_GENERIC = 0, KERNEL_R16_N4096 = 1, KERNEL_R16_SPLIT = 2, KERNEL_R16_SPLIT3 = 3, KERNEL_R16_PIPE = 4, KERNEL_R16_OCC4 = 5, KERNEL_R16_OCC3 = 6 };
+enum { KERNEL_GENERIC = 0, KERNEL_R16_N4096 = 1, KERNEL_R16_SPLIT = 2, KERNEL_R16_SPLIT3 = 3, KERNEL_R16_PIPE = 4, KERNEL_R16_OCC4 = 5, KERNEL_R16_OCC3 = 6, KERNEL_R16_SCREEN = 7 };
 
 struct FusedParams {
     const double *rows; // M x N row-major, row stride `stride` doubles
@@ -28,15 +28,27 @@ struct FusedParams {
     double *cc_out;      // optional (generic kernel only): M x n correlations
     int *nil_out;        // optional (generic kernel only): M flags, 1 = sigma == 0 -> (nil,0,0)
     unsigned long long *dbg; // diagnostic builds only (tools/ablate): per-workgroup phase cycle sums
+    // fp32 screening kernel (xcorr_r16_screen.hip)
+    const float2 *tw1f;  // [16][256] W_4096^(k*t), fp32
+    const float2 *tw2f;  // [16][16]  W_256^(k*c), fp32
+    const float2 *xcf;   // n entries: conj(X_full[f]) / n, fp32
+    const double *xs;    // n entries: zeroPad(zNormalize(ref)/(N-1), n), time domain, fp64
+    double screen_delta; // candidate window below the fp32 maximum (scaled units, max |cc| <= 1)
+    int *ovf_count;      // pairs with too many candidates: redone by the fp64 kernel
+    long long *ovf_list;
+    // optional indirection for the fp64 kernels: process pair_list[0 .. *pair_count)
+    const long long *pair_list;
+    const int *pair_count;
 };
 
 hipError_t launch_fused(const FusedParams &p, int variant, int num_cus, hipStream_t stream);
 hipError_t launch_fused_split(const FusedParams &p, int num_cus, int waves_per_simd, hipStream_t stream); // xcorr_r16_split.hip
 hipError_t launch_fused_pipe(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_r16_pipe.hip
 hipError_t launch_fused_occ4(const FusedParams &p, int num_cus, int waves_per_simd, hipStream_t stream); // xcorr_r16_occ4.hip
+hipError_t launch_fused_screen(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_r16_screen.hip
 hipError_t launch_ref_spectrum(const double *ref_dev, int N, int n, int logn, int normalize, double x_scale,
-                               double xc_scale, const double2 *twm, double2 *X, double2 *xc, int *status,
-                               hipStream_t stream);
+                               double xc_scale, const double2 *twm, double2 *X, double2 *xc, float2 *xcf, double *xs,
+                               int *status, hipStream_t stream);
 hipError_t launch_direct(const double *x, int lenx, const double *y, int leny, int n, int normalize_x,
                          int normalize_y, double x_scale, double cc_scale, double *cc, int *lag, double *mv,
                          int *status, hipStream_t stream);

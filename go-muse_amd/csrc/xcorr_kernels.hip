@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256) void xcorr_fused_generic(const FusedParams p)
 __global__ __launch_bounds__(256) void ref_spectrum_kernel(const double *__restrict__ ref, int N, int n, int logn,
                                                            int normalize, double x_scale, double xc_scale,
                                                            const double2 *__restrict__ twm, double2 *X,
-                                                           double2 *xc, int *status)
+                                                           double2 *xc, float2 *xcf, double *xs, int *status)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double2 *z = reinterpret_cast<double2 *>(smem_raw);
@@ -412,6 +412,10 @@ __global__ __launch_bounds__(256) void ref_spectrum_kernel(const double *__restr
     }
     if (threadIdx.x == 0)
         status[0] = (fa.zero || fa.nan) ? 1 : 0;
+    if (xs) { // time-domain x (normalised, scaled, leading-zero padded): exact re-evaluation table
+        for (int i = threadIdx.x; i < n; i += blockDim.x)
+            xs[i] = z[i].x;
+    }
     lds_dif(z, n, logn, twm);
     for (int q = threadIdx.x; q < n; q += blockDim.x) {
         const int f = (int)(__brev((unsigned)q) >> (32 - logn));
@@ -419,6 +423,8 @@ __global__ __launch_bounds__(256) void ref_spectrum_kernel(const double *__restr
         if (f <= n / 2)
             X[f] = v;
         xc[f] = make_double2(v.x * xc_scale, -v.y * xc_scale);
+        if (xcf)
+            xcf[f] = make_float2((float)(v.x * xc_scale), (float)(-v.y * xc_scale));
     }
 }
 
@@ -584,6 +590,8 @@ hipError_t launch_fused(const FusedParams &p, int variant, int num_cus, hipStrea
 {
     if (p.npairs <= 0)
         return hipSuccess;
+    if (variant == KERNEL_R16_SCREEN)
+        return launch_fused_screen(p, num_cus, stream);
     if (variant == KERNEL_R16_OCC4)
         return launch_fused_occ4(p, num_cus, 4, stream);
     if (variant == KERNEL_R16_OCC3)
@@ -620,8 +628,8 @@ hipError_t launch_fused(const FusedParams &p, int variant, int num_cus, hipStrea
 }
 
 hipError_t launch_ref_spectrum(const double *ref_dev, int N, int n, int logn, int normalize, double x_scale,
-                               double xc_scale, const double2 *twm, double2 *X, double2 *xc, int *status,
-                               hipStream_t stream)
+                               double xc_scale, const double2 *twm, double2 *X, double2 *xc, float2 *xcf, double *xs,
+                               int *status, hipStream_t stream)
 {
     const size_t lds = (size_t)n * sizeof(double2) + 64 * sizeof(double);
     static size_t configured = 0;
@@ -633,7 +641,7 @@ hipError_t launch_ref_spectrum(const double *ref_dev, int N, int n, int logn, in
         configured = lds;
     }
     hipLaunchKernelGGL(ref_spectrum_kernel, dim3(1), dim3(256), lds, stream, ref_dev, N, n, logn, normalize, x_scale,
-                       xc_scale, twm, X, xc, status);
+                       xc_scale, twm, X, xc, xcf, xs, status);
     return hipGetLastError();
 }
 

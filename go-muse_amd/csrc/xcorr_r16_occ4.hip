@@ -36,35 +36,6 @@ constexpr int OCC_XBUF = 8 * 272; // double2 elements: 34,816 B
 
 namespace occ4 {
 
-// In-kernel phase stamps (diagnostic builds only: TIMING = false in every
-// shipped instantiation, where all of this compiles to nothing).
-constexpr int NPHASE = 16;
-template <bool TIMING>
-struct PhaseClock {
-    unsigned long long acc[NPHASE];
-    unsigned long long last;
-    __device__ __forceinline__ void start()
-    {
-        if (TIMING) {
-#pragma unroll
-            for (int i = 0; i < NPHASE; i++)
-                acc[i] = 0;
-            last = __builtin_amdgcn_s_memtime();
-        }
-    }
-    template <int I>
-    __device__ __forceinline__ void stamp()
-    {
-        if (TIMING) {
-            __builtin_amdgcn_sched_barrier(0);
-            const unsigned long long now = __builtin_amdgcn_s_memtime();
-            acc[I] += now - last;
-            last = now;
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-};
-
 __device__ __forceinline__ void fence() { __builtin_amdgcn_sched_barrier(0); }
 // LDS-only barrier (does not drain outstanding global loads)
 __device__ __forceinline__ void lds_barrier()
@@ -364,13 +335,19 @@ __global__ __launch_bounds__(OCC_THREADS, WPS) void xcorr_fused_n4096_occ4(const
     Stat prev_stat{0.0, 0.0};
     int parity = 0;
 
+    // optional indirection: process pair_list[0 .. *pair_count) (overflow pairs of the
+    // fp32 screening kernel); otherwise pairs 0 .. npairs
+    const long long total = p.pair_count ? (long long)*p.pair_count : p.npairs;
     RawPair raw;
     {
-        const long long first = blockIdx.x < p.npairs ? (long long)blockIdx.x : 0;
+        long long first = 0;
+        if (blockIdx.x < total)
+            first = p.pair_list ? p.pair_list[blockIdx.x] : (long long)blockIdx.x;
         issue_row_loads<PADDED>(raw, p, first, t, pad);
     }
 
-    for (long long pair = blockIdx.x; pair < p.npairs; pair += gridDim.x) {
+    for (long long it = blockIdx.x; it < total; it += gridDim.x) {
+        const long long pair = p.pair_list ? p.pair_list[it] : it;
         const long long rA = 2 * pair, rB = rA + 1;
         const bool hasB = rB < p.M;
         // ---- consume the prefetched rows (element t + 256 i of the zero-padded rows)
@@ -443,8 +420,9 @@ __global__ __launch_bounds__(OCC_THREADS, WPS) void xcorr_fused_n4096_occ4(const
                                   : make_double2(uniform(deadA ? 0.0 : 4096.0 * mA), uniform(deadB ? 0.0 : 4096.0 * mB));
         clk.template stamp<1>();
         // ---- Z = FFT(yA + i yB);  V[f] = Z[f] * conj(X[f]) / n
-        long long nxt = pair + gridDim.x; // last iteration: harmless re-read of this pair
-        nxt = nxt < p.npairs ? nxt : pair;
+        long long nxt = pair; // last iteration: harmless re-read of this pair
+        if (it + gridDim.x < total)
+            nxt = p.pair_list ? p.pair_list[it + gridDim.x] : it + gridDim.x;
         fft4096<2, true, PADDED>(v, xbuf, tw2s, p.tw1, p.xc, dc, t, wave, clk, raw, p, nxt, pad);
         clk.template stamp<7>();
         // ---- ccA + i ccB = FFT(V)   (unscaled by 1/sigma)
@@ -512,8 +490,8 @@ __global__ __launch_bounds__(OCC_THREADS, WPS) void xcorr_fused_n4096_occ4(const
         finalize(red + 16 + 24 * (parity ^ 1) + 3 * t, prev_stat, invN, invNm1, p.mv + prev_row, p.lag + prev_row);
     if (TIMING && p.dbg && lane == 0) {
 #pragma unroll
-        for (int i = 0; i < occ4::NPHASE; i++)
-            p.dbg[((long long)blockIdx.x * 4 + wave) * occ4::NPHASE + i] = clk.acc[i];
+        for (int i = 0; i < NPHASE; i++)
+            p.dbg[((long long)blockIdx.x * 4 + wave) * NPHASE + i] = clk.acc[i];
     }
 }
 

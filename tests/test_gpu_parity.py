@@ -253,8 +253,9 @@ def test_scores_match_oracle_all_lengths(muse, eng, oracle, N, M):
 
 @pytest.mark.parametrize("N", [2049, 3000, 4095, 4096])
 def test_every_kernel_variant_matches_oracle(muse, eng, oracle, N):
-    """auto (0), generic (1) and each n = 4096 kernel generation (2..7) on the same
-    inputs, incl. N < n padding, sigma == 0, NaN / Inf rows and an odd row count."""
+    """auto (0), generic (1), each fp64 n = 4096 kernel generation (2..7) and the fp32-screen
+    + fp64-re-evaluation kernel (8) on the same inputs, incl. N < n padding, sigma == 0,
+    NaN / Inf rows and an odd row count."""
     ref, rows = _rows(65, N, N)
     rows[10, 5] = np.nan          # NaN row: (lag 0, mv NaN), must not disturb its pair partner
     rows[12, :] = np.inf
@@ -264,7 +265,7 @@ def test_every_kernel_variant_matches_oracle(muse, eng, oracle, N):
     assert db.n == 4096
     olag, omv, gap = oracle.batch_scores(ref, rows)
     try:
-        for variant in range(8):
+        for variant in range(9):
             eng.set_kernel(variant)
             lag, mv = db.scores()
             assert math.isnan(mv[10]) and lag[10] == 0 and math.isnan(mv[12]) and lag[12] == 0, variant
@@ -421,3 +422,22 @@ def test_cpp_host_mirror_reference_tests(muse):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all host tests passed" in r.stdout
+
+
+def test_screen_kernel_many_near_ties_overflow_path(muse, eng, oracle):
+    """periodic series have many lags within the fp32 window of the maximum: the screening
+    kernel must hand those pairs to the fp64 kernel (overflow list) and still match."""
+    N = 4096
+    t = np.arange(N)
+    rng = np.random.default_rng(12)
+    ref = np.sin(2 * np.pi * t / 64.0) + 0.01 * rng.standard_normal(N)
+    rows = np.stack([np.sin(2 * np.pi * (t + s) / 64.0) + 0.01 * rng.standard_normal(N) for s in range(12)]
+                    + [rng.standard_normal(N) for _ in range(5)])
+    db = muse.DeviceBatch(eng, muse.DeviceGroup.from_rows(eng, rows), ref)
+    olag, omv, gap = oracle.batch_scores(ref, rows)
+    try:
+        eng.set_kernel(8)
+        lag, mv = db.scores()
+    finally:
+        eng.set_kernel(0)
+    assert_scores_match(lag, mv, olag, omv, gap)

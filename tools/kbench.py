@@ -37,6 +37,11 @@ for r in range(rounds + 1):
                 same_lag = int((lag != base[0]).sum())
                 rel = np.nanmax(np.abs(mv - base[1]) / np.maximum(np.abs(base[1]), 1e-300))
                 print("variant %d vs %d: lag diffs %d, max rel score diff %.3e" % (v, variants[0], same_lag, rel))
+                with np.errstate(all="ignore"):
+                    bad = np.nonzero((lag != base[0]) | (np.abs(mv - base[1]) > 1e-9 * np.maximum(np.abs(base[1]), 1e-300))
+                                     | (np.isnan(mv) != np.isnan(base[1])))[0]
+                for i in bad[:8]:
+                    print("   row %d: lag %d vs %d, mv %.17g vs %.17g" % (i, lag[i], base[0][i], mv[i], base[1][i]))
 for v in variants:
     t = np.array(times[v])
     print("variant %d: median %.3f ms  min %.3f ms  -> %.3e series/s, %.1f%% of 8 TB/s" % (
