@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--top-n", type=int, default=20)
     ap.add_argument("--max-lag", type=int, default=15)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the RCCL gather path even with one rank (rehearsal on a 1-GPU box)")
     args = ap.parse_args()
 
     import numpy as np
@@ -67,9 +69,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(backend="nccl", rank=rank, world_size=max(world, 1),
+                                device_id=torch.device("cuda", local_rank))
     n_gpus = max(world, 1)
 
     pkg = importlib.import_module("go-muse_amd")
@@ -83,14 +89,14 @@ def main():
     tdev = torch.device("cuda", local_rank)
 
     def step():
-        if world > 1:
+        if use_dist:
             return pkg.dist.run_sharded(db, rank * M, None, 0, args.max_lag, args.top_n, 0.0, 0, True, device=tdev)
         return db.run(None, 0, args.max_lag, args.top_n, 0.0, 0, True)
 
     def fence():
         eng.synchronize()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -106,7 +112,7 @@ def main():
     dt = time.perf_counter() - t0
     eng.kernel_timing(False)
     k_ms, k_cnt = eng.kernel_time()
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=tdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -146,7 +152,7 @@ def main():
         if n_gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(dg, ref, N)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -77,7 +77,7 @@ struct muse_ctx {
     int num_cus = 0;
     int64_t hbm = 0;
     char name[64] = {0};
-    double2 *tw1 = nullptr, *tw2 = nullptr, *twm = nullptr;
+    double2 *tw1 = nullptr, *tw2 = nullptr, *twm = nullptr, *tw1w8 = nullptr;
     float2 *tw1f = nullptr, *tw2f = nullptr; // fp32 copies for the screening kernel
     double screen_delta = 1e-4;
     int variant = 0;
@@ -185,6 +185,12 @@ extern "C" int muse_ctx_create(int32_t device, muse_ctx **out)
     HIP_TRY(hipMemcpy(ctx->tw1, t1.data(), t1.size() * sizeof(double2), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ctx->tw2, t2.data(), t2.size() * sizeof(double2), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ctx->twm, tm.data(), tm.size() * sizeof(double2), hipMemcpyHostToDevice));
+    std::vector<double2> t8(8 * 512);
+    for (int k = 0; k < 8; k++)
+        for (int t = 0; t < 512; t++)
+            fill_twiddle(t8, (size_t)k * 512 + t, (long long)k * t, 4096);
+    HIP_TRY(hipMalloc(&ctx->tw1w8, t8.size() * sizeof(double2)));
+    HIP_TRY(hipMemcpy(ctx->tw1w8, t8.data(), t8.size() * sizeof(double2), hipMemcpyHostToDevice));
     std::vector<float2> t1f(t1.size()), t2f(t2.size());
     for (size_t i = 0; i < t1.size(); i++)
         t1f[i] = make_float2((float)t1[i].x, (float)t1[i].y);
@@ -215,6 +221,7 @@ static void ctx_release(muse_ctx *ctx)
     (void)hipFree(ctx->tw2);
     (void)hipFree(ctx->twm);
     (void)hipFree(ctx->tw1f);
+    (void)hipFree(ctx->tw1w8);
     (void)hipFree(ctx->tw2f);
     if (ctx->stream)
         (void)hipStreamDestroy(ctx->stream);
@@ -251,7 +258,7 @@ extern "C" int muse_ctx_device_info(muse_ctx *ctx, char *name, int32_t name_cap,
 
 extern "C" int muse_ctx_set_kernel(muse_ctx *ctx, int32_t variant)
 {
-    if (!ctx || variant < 0 || variant > 8)
+    if (!ctx || variant < 0 || variant > 9 || variant == 3 || variant == 4) // 3, 4: retired
         return fail(MUSE_ERR_INVALID, "bad kernel variant");
     ctx->variant = variant;
     return MUSE_OK;
@@ -609,24 +616,24 @@ extern "C" int muse_batch_score(muse_batch *b)
     p.lag = b->lag;
     p.cc_out = nullptr;
     p.nil_out = nullptr;
+    p.tw1w8 = ctx->tw1w8;
     p.tw1f = ctx->tw1f;
     p.tw2f = ctx->tw2f;
     p.xcf = b->xcf;
     p.xs = b->xs;
     p.screen_delta = ctx->screen_delta;
-    // kernel selection: ctx->variant 0 = auto; 1 = generic LDS radix-2; 2..7 force one
+    // kernel selection: ctx->variant 0 = auto; 1 = generic LDS radix-2; 2, 5..9 force one
     // of the n = 4096 kernels (parity tests run every one of them on the same inputs)
     int variant = KERNEL_GENERIC;
     if (b->n == 4096) {
         switch (ctx->variant) {
         case 0: variant = KERNEL_R16_OCC3; break; // fastest measured (profiles/)
         case 2: variant = KERNEL_R16_N4096; break;
-        case 3: variant = KERNEL_R16_SPLIT; break;
-        case 4: variant = KERNEL_R16_SPLIT3; break;
         case 5: variant = KERNEL_R16_PIPE; break;
         case 6: variant = KERNEL_R16_OCC4; break;
         case 7: variant = KERNEL_R16_OCC3; break;
         case 8: variant = KERNEL_R16_SCREEN; break;
+        case 9: variant = KERNEL_R8_W8; break;
         default: variant = KERNEL_GENERIC; break;
         }
     }

@@ -8,7 +8,7 @@
 
 namespace muse {
 
-enum { KERNEL_GENERIC = 0, KERNEL_R16_N4096 = 1, KERNEL_R16_SPLIT = 2, KERNEL_R16_SPLIT3 = 3, KERNEL_R16_PIPE = 4, KERNEL_R16_OCC4 = 5, KERNEL_R16_OCC3 = 6, KERNEL_R16_SCREEN = 7 };
+enum { KERNEL_GENERIC = 0, KERNEL_R16_N4096 = 1, KERNEL_R16_PIPE = 4, KERNEL_R16_OCC4 = 5, KERNEL_R16_OCC3 = 6, KERNEL_R16_SCREEN = 7, KERNEL_R8_W8 = 8 };
 
 struct FusedParams {
     const double *rows; // M x N row-major, row stride `stride` doubles
@@ -22,6 +22,7 @@ struct FusedParams {
     const double2 *xc;   // n entries: conj(X_full[f]) * scale
     const double2 *tw1;  // [16][256] W_4096^(k*t)      (tuned kernel)
     const double2 *tw2;  // [16][16]  W_256^(k*c)       (tuned kernel)
+    const double2 *tw1w8; // [8][512]  W_4096^(k*t)      (radix-8 kernel)
     const double2 *twm;  // [4096]    W_8192^k          (generic kernel)
     double *mv;          // out: M signed max values
     int *lag;            // out: M lags
@@ -42,10 +43,10 @@ struct FusedParams {
 };
 
 hipError_t launch_fused(const FusedParams &p, int variant, int num_cus, hipStream_t stream);
-hipError_t launch_fused_split(const FusedParams &p, int num_cus, int waves_per_simd, hipStream_t stream); // xcorr_r16_split.hip
 hipError_t launch_fused_pipe(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_r16_pipe.hip
 hipError_t launch_fused_occ4(const FusedParams &p, int num_cus, int waves_per_simd, hipStream_t stream); // xcorr_r16_occ4.hip
 hipError_t launch_fused_screen(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_r16_screen.hip
+hipError_t launch_fused_w8(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_r8_w8.hip
 hipError_t launch_ref_spectrum(const double *ref_dev, int N, int n, int logn, int normalize, double x_scale,
                                double xc_scale, const double2 *twm, double2 *X, double2 *xc, float2 *xcf, double *xs,
                                int *status, hipStream_t stream);

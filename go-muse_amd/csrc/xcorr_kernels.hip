@@ -590,6 +590,8 @@ hipError_t launch_fused(const FusedParams &p, int variant, int num_cus, hipStrea
 {
     if (p.npairs <= 0)
         return hipSuccess;
+    if (variant == KERNEL_R8_W8)
+        return launch_fused_w8(p, num_cus, stream);
     if (variant == KERNEL_R16_SCREEN)
         return launch_fused_screen(p, num_cus, stream);
     if (variant == KERNEL_R16_OCC4)
@@ -598,10 +600,6 @@ hipError_t launch_fused(const FusedParams &p, int variant, int num_cus, hipStrea
         return launch_fused_occ4(p, num_cus, 3, stream);
     if (variant == KERNEL_R16_PIPE)
         return launch_fused_pipe(p, num_cus, stream);
-    if (variant == KERNEL_R16_SPLIT)
-        return launch_fused_split(p, num_cus, 4, stream);
-    if (variant == KERNEL_R16_SPLIT3)
-        return launch_fused_split(p, num_cus, 3, stream);
     if (variant == KERNEL_R16_N4096) {
         long long grid = p.npairs;
         const long long cap = (long long)num_cus * 2 * 8; // persistent-ish: grid-stride beyond this

@@ -300,7 +300,12 @@ __device__ __forceinline__ void finalize(const double *r, const Stat &st, double
     bool zero, nan;
     const double var = variance(st, invN, invNm1, zero, nan);
     const int idx = (best > 0.0) ? (int)bidx : 0;           // nothing above 0: index 0, mv = cc[0]
-    double mv = ((best > 0.0) ? bsv : s[0]) * (1.0 / sqrt(var)); // 1/sigma applied to the winner only
+    // 1/sigma for the winner only: v_rsq_f64 seed + two Newton steps (full double accuracy)
+    // instead of the sqrt + division chains, which sat on wave 0's way to the next barrier
+    double y = __builtin_amdgcn_rsq(var);
+    y = y * fma(-0.5 * var * y, y, 1.5);
+    y = y * fma(-0.5 * var * y, y, 1.5);
+    double mv = ((best > 0.0) ? bsv : s[0]) * y;
     int lag = idx > 2048 ? idx - 4096 : idx;
     if (zero) { mv = 0.0; lag = 0; }                        // xcorr.go:166-167
     if (nan) { mv = __builtin_nan(""); lag = 0; }           // NaN sigma: every cc is NaN
@@ -439,30 +444,36 @@ __global__ __launch_bounds__(OCC_THREADS, WPS) void xcorr_fused_n4096_occ4(const
             mb = fmax(mb, fabs(v[k].y));
         }
         const double wa = wave_max_dpp(ma), wb = wave_max_dpp(mb);
+        // first index attaining the wave maximum: all 16 ballots are issued back to back
+        // (VALU -> SGPR), then a branch-free scalar select chain picks the lowest k with a
+        // hit; lowest k first, then lowest lane == lowest index because t < 256.  The sign
+        // comes from the selected value's high word at that lane.
         int widxA = 0x7fffffff, widxB = 0x7fffffff;
         double svA = 0.0, svB = 0.0;
-        if (wa > 0.0) {
+        {
+            unsigned long long selA = 0ull, selB = 0ull;
+            int kA = 0, kB = 0, hiA = 0, hiB = 0;
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const unsigned long long m = __ballot(fabs(v[k].x) == wa);
-                if (m != 0ull && widxA == 0x7fffffff) {
-                    const int l = __ffsll((long long)m) - 1;
-                    widxA = wave * 64 + l + 256 * k;
-                    const unsigned long long ng = __ballot(v[k].x < 0.0);
-                    svA = ((ng >> l) & 1ull) ? -wa : wa;
-                }
+            for (int k = 15; k >= 0; k--) { // descending: the lowest k is selected last
+                const unsigned long long mA_ = __ballot(fabs(v[k].x) == wa);
+                const unsigned long long mB_ = __ballot(fabs(v[k].y) == wb);
+                const bool hA = mA_ != 0ull, hB = mB_ != 0ull; // wave-uniform
+                selA = hA ? mA_ : selA;
+                kA = hA ? k : kA;
+                hiA = hA ? __double2hiint(v[k].x) : hiA;
+                selB = hB ? mB_ : selB;
+                kB = hB ? k : kB;
+                hiB = hB ? __double2hiint(v[k].y) : hiB;
             }
-        }
-        if (wb > 0.0) {
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const unsigned long long m = __ballot(fabs(v[k].y) == wb);
-                if (m != 0ull && widxB == 0x7fffffff) {
-                    const int l = __ffsll((long long)m) - 1;
-                    widxB = wave * 64 + l + 256 * k;
-                    const unsigned long long ng = __ballot(v[k].y < 0.0);
-                    svB = ((ng >> l) & 1ull) ? -wb : wb;
-                }
+            if (wa > 0.0 && selA != 0ull) {
+                const int l = __ffsll((long long)selA) - 1;
+                widxA = wave * 64 + l + 256 * kA;
+                svA = (__builtin_amdgcn_readlane(hiA, l) < 0) ? -wa : wa;
+            }
+            if (wb > 0.0 && selB != 0ull) {
+                const int l = __ffsll((long long)selB) - 1;
+                widxB = wave * 64 + l + 256 * kB;
+                svB = (__builtin_amdgcn_readlane(hiB, l) < 0) ? -wb : wb;
             }
         }
         if (lane == 0) { // {max |cc|, signed value (cc[0] when nothing is above 0), index}

@@ -34,7 +34,7 @@ def gather_records(local_records, top_n, group=None, device=None):
     buf = np.zeros(cap + 1, dtype=B.RECORD_DTYPE)          # slot 0 carries the count
     buf[0]["series"] = len(local_records)
     buf[1:1 + len(local_records)] = local_records
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return local_records.copy()
     world = dist.get_world_size(group)
     t = torch.from_numpy(buf.view(np.uint8).copy())

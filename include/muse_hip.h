@@ -72,13 +72,14 @@ int muse_ctx_synchronize(muse_ctx *ctx);
 /* name: >= 64 bytes.  Any out pointer may be NULL. */
 int muse_ctx_device_info(muse_ctx *ctx, char *name, int32_t name_cap,
                          int32_t *compute_units, int64_t *hbm_bytes);
-/* Kernel variant for the fused pass: 0 = auto (fastest tuned radix-16 kernel
- * when n == 4096, generic LDS radix-2 kernel otherwise), 1 = force the generic
- * kernel, 2..7 = force one of the fp64 n = 4096 kernel generations (first,
- * split-3, split-4, pipelined, occupancy-4, occupancy-3), 8 = fp32 screening
- * transform + exact fp64 re-evaluation (experimental).  The parity tests run every
- * variant on the same inputs; the environment variable MUSE_HIP_KERNEL sets
- * the initial value (profiling aid). */
+/* Kernel variant for the fused pass: 0 = auto (fastest tuned kernel when
+ * n == 4096, generic LDS radix-2 kernel otherwise), 1 = force the generic
+ * kernel; forcing one n = 4096 kernel: 2 = first (simple) fp64 kernel,
+ * 5 = register-prefetch pipeline, 6 / 7 = half-round transposes at 4 / 3
+ * waves per SIMD (7 is what auto picks), 8 = fp32 screening + exact fp64
+ * re-evaluation (experimental), 9 = 512-thread radix-8 (experimental).
+ * The parity tests run every variant on the same inputs; the environment
+ * variable MUSE_HIP_KERNEL sets the initial value (profiling aid). */
 int muse_ctx_set_kernel(muse_ctx *ctx, int32_t variant);
 /* HIP-event timing of the fused kernel on the stream it is launched on:
  * enable, run, then read (sum of launch durations in ms, launch count). */

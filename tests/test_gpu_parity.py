@@ -253,8 +253,8 @@ def test_scores_match_oracle_all_lengths(muse, eng, oracle, N, M):
 
 @pytest.mark.parametrize("N", [2049, 3000, 4095, 4096])
 def test_every_kernel_variant_matches_oracle(muse, eng, oracle, N):
-    """auto (0), generic (1), each fp64 n = 4096 kernel generation (2..7) and the fp32-screen
-    + fp64-re-evaluation kernel (8) on the same inputs, incl. N < n padding, sigma == 0,
+    """auto (0), generic (1), each fp64 n = 4096 kernel generation (2, 5, 6, 7, 9) and the
+    fp32-screen + fp64-re-evaluation kernel (8) on the same inputs, incl. N < n padding, sigma == 0,
     NaN / Inf rows and an odd row count."""
     ref, rows = _rows(65, N, N)
     rows[10, 5] = np.nan          # NaN row: (lag 0, mv NaN), must not disturb its pair partner
@@ -265,7 +265,7 @@ def test_every_kernel_variant_matches_oracle(muse, eng, oracle, N):
     assert db.n == 4096
     olag, omv, gap = oracle.batch_scores(ref, rows)
     try:
-        for variant in range(9):
+        for variant in (0, 1, 2, 5, 6, 7, 8, 9):
             eng.set_kernel(variant)
             lag, mv = db.scores()
             assert math.isnan(mv[10]) and lag[10] == 0 and math.isnan(mv[12]) and lag[12] == 0, variant
@@ -441,3 +441,43 @@ def test_screen_kernel_many_near_ties_overflow_path(muse, eng, oracle):
     finally:
         eng.set_kernel(0)
     assert_scores_match(lag, mv, olag, omv, gap)
+
+
+@pytest.mark.parametrize("N", [512, 1000, 4096, 5000])
+def test_config5_mixed_lengths_label_grouped(muse, eng, oracle, N):
+    """BASELINE config 5 (the <= 8192 part): one (ref, Group) pair per series length
+    (the reference has no mixed-length Group: group.go:45-51, muse_batch.go:24-28), label
+    groups of 10 hosts per graph, Batch.Run(["graph"]) through the host mirror, checked
+    against the oracle's Batch.Run/Results semantics.  N = 1000 / 5000 are zero-padded to
+    1024 / 8192 (xcorr.go:176-181); N = 512 / 4096 are circular (no padding)."""
+    rng = np.random.default_rng(N)
+    graphs, hosts = 40, 10
+    t = np.arange(N)
+    ref_y = 1.5 * (np.abs(t - N // 2) <= 5) + 0.1 * rng.standard_normal(N)
+    ref = muse.NewSeries(ref_y, muse.NewLabels({"graph": "ref", "host": "h0"}))
+    comp = muse.NewGroup("comparison")
+    series, rows, gid = [], [], []
+    for g in range(graphs):
+        for h in range(hosts):
+            amp = rng.uniform(-3, 3)
+            y = amp * (np.abs(t - N // 2 - rng.integers(-20, 21)) <= rng.integers(2, 12)) + 0.1 * rng.standard_normal(N)
+            if g == 7 and h == 3:
+                y = 2.0 * ref_y + 1.0                     # perfect match inside a group
+            if g == 9:
+                y = np.full(N, 0.25)                      # a whole graph of constant lines
+            series.append(muse.NewSeries(y, muse.NewLabels({"graph": "g%02d" % g, "host": "h%d" % h})))
+            rows.append(y)
+            gid.append(g)
+    comp.Add(*series)
+    res = muse.NewResults(15, 12, 0.0, muse.SignFilter_ANY)
+    b = muse.NewBatch(ref, comp, res, 8)
+    assert b.n == oracle.next_pow2(N)
+    b.Run(["graph"])
+    got, mean = res.Fetch()
+    olag, omv, gap = oracle.batch_scores(ref_y, np.stack(rows))
+    oi, ol, osc, omean = oracle.results(olag, omv, np.array(gid, np.int32), graphs, True, 15, 12, 0.0, 0)
+    assert [s.Lag for s in got] == ol.tolist()
+    assert np.allclose([s.PercentScore for s in got], osc, rtol=1e-6, atol=1e-12)
+    assert [s.Labels.labels for s in got] == [series[i].labels.labels for i in oi]
+    assert abs(mean - omean) < 1e-9
+    assert got[0].Labels.labels == {"graph": "g07", "host": "h3"} and abs(got[0].PercentScore - 1.0) < 1e-9
