@@ -25,6 +25,7 @@
 //     from every sample.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "fft_device.h"
 #include "xcorr_kernels.h"
@@ -425,7 +426,8 @@ __global__ __launch_bounds__(OCC_THREADS, WPS) void xcorr_fused_n4096_occ4(const
                                   : make_double2(uniform(deadA ? 0.0 : 4096.0 * mA), uniform(deadB ? 0.0 : 4096.0 * mB));
         clk.template stamp<1>();
         // ---- Z = FFT(yA + i yB);  V[f] = Z[f] * conj(X[f]) / n
-        long long nxt = pair; // last iteration: harmless re-read of this pair
+        long long nxt = 0; // last iteration: an unconditional dummy prefetch of pair 0, whose 64 KB every
+                           // workgroup re-reads (L2-resident) -- re-reading the own pair cost 2.4 % HBM traffic
         if (it + gridDim.x < total)
             nxt = p.pair_list ? p.pair_list[it + gridDim.x] : it + gridDim.x;
         fft4096<2, true, PADDED>(v, xbuf, tw2s, p.tw1, p.xc, dc, t, wave, clk, raw, p, nxt, pad);
@@ -509,7 +511,13 @@ __global__ __launch_bounds__(OCC_THREADS, WPS) void xcorr_fused_n4096_occ4(const
 hipError_t launch_fused_occ4(const FusedParams &p, int num_cus, int waves_per_simd, hipStream_t stream)
 {
     long long grid = p.npairs;
-    const long long cap = (long long)num_cus * waves_per_simd; // persistent: the resident workgroups
+    // 16x the resident set (each workgroup still loops over ~40 pairs): workgroups that
+    // start as others retire keep the CUs' phases decorrelated and balance CU speed
+    // differences; measured 12.6 ms (1x) -> 11.5 ms (16x) per 1 M series, flat beyond.
+    int mult = 16;
+    if (const char *m = getenv("MUSE_HIP_GRID_MULT")) // tuning aid
+        mult = atoi(m) > 0 ? atoi(m) : mult;
+    const long long cap = (long long)num_cus * waves_per_simd * mult;
     if (grid > cap)
         grid = cap;
     const dim3 g((unsigned)grid), b(OCC_THREADS);
