@@ -104,6 +104,7 @@ struct muse_batch {
     int32_t N = 0, n = 0, logn = 0;
     double2 *X = nullptr, *xc = nullptr;
     float2 *xcf = nullptr; // fp32 conj(X)/n (screening kernel)
+    double2 *gscratch = nullptr; // n > 8192: per-workgroup work buffers of the generic kernel
     double *xs = nullptr;  // padded time-domain reference (exact re-evaluation)
     int *ovf_count = nullptr;
     long long *ovf_list = nullptr;
@@ -170,15 +171,15 @@ extern "C" int muse_ctx_create(int32_t device, muse_ctx **out)
     snprintf(ctx->name, sizeof(ctx->name), "%s (%s)", prop.name, prop.gcnArchName);
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    std::vector<double2> t1(16 * 256), t2(16 * 16), tm(4096);
+    std::vector<double2> t1(16 * 256), t2(16 * 16), tm(GENERIC_MAX_N / 2);
     for (int k = 0; k < 16; k++)
         for (int t = 0; t < 256; t++)
             fill_twiddle(t1, (size_t)k * 256 + t, (long long)k * t, 4096);
     for (int k = 0; k < 16; k++)
         for (int c = 0; c < 16; c++)
             fill_twiddle(t2, (size_t)k * 16 + c, (long long)k * c, 256);
-    for (int k = 0; k < 4096; k++)
-        fill_twiddle(tm, (size_t)k, k, 8192);
+    for (int k = 0; k < GENERIC_MAX_N / 2; k++)
+        fill_twiddle(tm, (size_t)k, k, GENERIC_MAX_N);
     HIP_TRY(hipMalloc(&ctx->tw1, t1.size() * sizeof(double2)));
     HIP_TRY(hipMalloc(&ctx->tw2, t2.size() * sizeof(double2)));
     HIP_TRY(hipMalloc(&ctx->twm, tm.size() * sizeof(double2)));
@@ -471,13 +472,16 @@ static int build_spectrum(muse_ctx *ctx, const double *ref_host, int N, int n, i
 {
     double *dref = nullptr;
     int *dstat = nullptr;
+    double2 *dscr = nullptr; // n > 8192: global work buffer for the radix-2 passes
     HIP_TRY(hipMalloc(&dref, (size_t)N * sizeof(double)));
     hipError_t e = hipMalloc(&dstat, sizeof(int));
+    if (e == hipSuccess && n > GENERIC_LDS_MAX_N)
+        e = hipMalloc(&dscr, (size_t)n * sizeof(double2));
     if (e == hipSuccess)
         e = hipMemcpyAsync(dref, ref_host, (size_t)N * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess)
-        e = launch_ref_spectrum(dref, N, n, ilog2(n), normalize, x_scale, xc_scale, ctx->twm, X, xc, xcf, xs, dstat,
-                                ctx->stream);
+        e = launch_ref_spectrum(dref, N, n, ilog2(n), normalize, x_scale, xc_scale, ctx->twm, X, xc, xcf, xs, dscr,
+                                dstat, ctx->stream);
     int st = 0;
     if (e == hipSuccess)
         e = hipMemcpyAsync(&st, dstat, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
@@ -485,6 +489,7 @@ static int build_spectrum(muse_ctx *ctx, const double *ref_host, int N, int n, i
         e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(dref);
     (void)hipFree(dstat);
+    (void)hipFree(dscr);
     HIP_TRY(e);
     *zero_std = st;
     return MUSE_OK;
@@ -508,9 +513,8 @@ extern "C" int muse_batch_create(muse_ctx *ctx, muse_group *g, const double *ref
     if (N < 2)
         return fail(MUSE_ERR_INVALID, "series length 1 has no sample standard deviation");
     const int64_t n = muse_next_pow2((double)N); // muse_batch.go:35
-    if (n > 8192)
-        return fail(MUSE_ERR_UNSUPPORTED, "FFT length %lld > 8192 is not built yet (LDS-resident kernels only)",
-                    (long long)n);
+    if (n > GENERIC_MAX_N)
+        return fail(MUSE_ERR_UNSUPPORTED, "FFT length %lld > %d is not built", (long long)n, GENERIC_MAX_N);
     muse_batch *b = new (std::nothrow) muse_batch();
     if (!b)
         return fail(MUSE_ERR_NOMEM, "host allocation failed");
@@ -530,6 +534,8 @@ extern "C" int muse_batch_create(muse_ctx *ctx, muse_group *g, const double *ref
         e = hipMalloc(&b->xs, (size_t)n * sizeof(double));
     if (e == hipSuccess)
         e = hipMalloc(&b->ovf_count, sizeof(int));
+    if (e == hipSuccess && n > GENERIC_LDS_MAX_N)
+        e = hipMalloc(&b->gscratch, (size_t)ctx->num_cus * GENERIC_GLOBAL_WGS_PER_CU * (size_t)n * sizeof(double2));
     if (e != hipSuccess) {
         muse_batch_free(b);
         return fail(MUSE_ERR_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e));
@@ -612,6 +618,7 @@ extern "C" int muse_batch_score(muse_batch *b)
     p.tw1 = ctx->tw1;
     p.tw2 = ctx->tw2;
     p.twm = ctx->twm;
+    p.gscratch = b->gscratch;
     p.mv = b->mv;
     p.lag = b->lag;
     p.cc_out = nullptr;
@@ -960,6 +967,7 @@ extern "C" int muse_batch_free(muse_batch *b)
     (void)hipFree(b->X);
     (void)hipFree(b->xc);
     (void)hipFree(b->xcf);
+    (void)hipFree(b->gscratch);
     (void)hipFree(b->xs);
     (void)hipFree(b->ovf_count);
     (void)hipFree(b->ovf_list);
@@ -996,17 +1004,18 @@ static int single_pair(muse_ctx *ctx, const double *x, int lenx, const double *y
         return fail(MUSE_ERR_INVALID, "bad single-pair arguments");
     if ((normalize_x && lenx < 2) || (normalize_y && leny < 2))
         return fail(MUSE_ERR_INVALID, "series length 1 has no sample standard deviation");
-    if (n > 8192)
-        return fail(MUSE_ERR_UNSUPPORTED, "FFT length %d > 8192", n);
+    if (n > GENERIC_MAX_N || (!is_pow2(n) && n > 8192))
+        return fail(MUSE_ERR_UNSUPPORTED, "FFT length %d is not built (powers of two up to %d, any n up to 8192)", n,
+                    GENERIC_MAX_N);
     double *dx = nullptr, *dy = nullptr, *dcc = nullptr, *dmv = nullptr;
     int *dlag = nullptr, *dstat = nullptr;
-    double2 *dX = nullptr, *dxc = nullptr;
+    double2 *dX = nullptr, *dxc = nullptr, *dscr = nullptr;
     int nil = 0, lg = 0;
     double val = 0.0;
     hipError_t e = hipSuccess;
     auto cleanup = [&]() {
         (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dcc); (void)hipFree(dmv);
-        (void)hipFree(dlag); (void)hipFree(dstat); (void)hipFree(dX); (void)hipFree(dxc);
+        (void)hipFree(dlag); (void)hipFree(dstat); (void)hipFree(dX); (void)hipFree(dxc); (void)hipFree(dscr);
     };
 #define SP_TRY(expr)                                                                                        \
     do {                                                                                                    \
@@ -1049,6 +1058,10 @@ static int single_pair(muse_ctx *ctx, const double *x, int lenx, const double *y
         p.lag = dlag;
         p.cc_out = dcc;
         p.nil_out = dstat;
+        if (n > GENERIC_LDS_MAX_N) {
+            SP_TRY(hipMalloc(&dscr, (size_t)n * sizeof(double2)));
+            p.gscratch = dscr;
+        }
         SP_TRY(launch_fused(p, KERNEL_GENERIC, ctx->num_cus, ctx->stream));
         SP_TRY(hipMemcpyAsync(&lg, dlag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         SP_TRY(hipMemcpyAsync(&val, dmv, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));

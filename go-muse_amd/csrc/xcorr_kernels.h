@@ -23,7 +23,8 @@ struct FusedParams {
     const double2 *tw1;  // [16][256] W_4096^(k*t)      (tuned kernel)
     const double2 *tw2;  // [16][16]  W_256^(k*c)       (tuned kernel)
     const double2 *tw1w8; // [8][512]  W_4096^(k*t)      (radix-8 kernel)
-    const double2 *twm;  // [4096]    W_8192^k          (generic kernel)
+    const double2 *twm;  // [32768]   W_65536^k         (generic kernel; half period)
+    double2 *gscratch;   // n > 8192: one n-element complex work buffer per workgroup (global, L2-resident)
     double *mv;          // out: M signed max values
     int *lag;            // out: M lags
     double *cc_out;      // optional (generic kernel only): M x n correlations
@@ -49,7 +50,10 @@ hipError_t launch_fused_screen(const FusedParams &p, int num_cus, hipStream_t st
 hipError_t launch_fused_w8(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_r8_w8.hip
 hipError_t launch_ref_spectrum(const double *ref_dev, int N, int n, int logn, int normalize, double x_scale,
                                double xc_scale, const double2 *twm, double2 *X, double2 *xc, float2 *xcf, double *xs,
-                               int *status, hipStream_t stream);
+                               double2 *gscratch, int *status, hipStream_t stream);
+constexpr int GENERIC_LDS_MAX_N = 8192;  // larger n: the radix-2 passes run in gscratch
+constexpr int GENERIC_MAX_N = 65536;
+constexpr int GENERIC_GLOBAL_WGS_PER_CU = 2;
 hipError_t launch_direct(const double *x, int lenx, const double *y, int leny, int n, int normalize_x,
                          int normalize_y, double x_scale, double cc_scale, double *cc, int *lag, double *mv,
                          int *status, hipStream_t stream);

@@ -25,7 +25,7 @@
 //     conflict-free by construction, see exchange comments); thread t starts
 //     and ends with elements t + 256*a, so global loads are coalesced and the
 //     second FFT consumes the first one's output layout directly.
-//   * generic kernel: any power-of-two n <= 8192, in-place radix-2 DIF then
+//   * generic kernel: any power-of-two n <= 65536, in-place radix-2 DIF then
 //     DIT in LDS (bit-reversed middle, no reorder pass).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -211,9 +211,11 @@ __global__ __launch_bounds__(R16_THREADS, 2) void xcorr_fused_n4096(const FusedP
 }
 
 // ======================================================== generic kernel
-// Any power-of-two n in [2, 8192].  Dynamic LDS: n double2 + 64 doubles.
+// Any power-of-two n in [2, 65536].  The n-element complex work buffer lives in LDS
+// (dynamic: n double2 + 64 doubles) for n <= 8192 and in a per-workgroup global
+// scratch buffer (L2-resident; __syncthreads orders the passes) above that.
 // In-place radix-2 DIF (natural -> bit-reversed), multiply by xc[brev],
-// in-place radix-2 DIT (bit-reversed -> natural).  twm = exp(-2 pi i k/8192).
+// in-place radix-2 DIT (bit-reversed -> natural).  twm = exp(-2 pi i k/65536), k < 32768.
 
 __device__ __forceinline__ void lds_dif(double2 *z, int n, int logn, const double2 *__restrict__ twm)
 {
@@ -225,8 +227,8 @@ __device__ __forceinline__ void lds_dif(double2 *z, int n, int logn, const doubl
             const int i0 = ((j >> lh) << (lh + 1)) + pos, i1 = i0 + half;
             const double2 a = z[i0], b = z[i1];
             z[i0] = cadd(a, b);
-            // W_{2*half}^pos = W_8192^(pos * 8192/(2*half))
-            z[i1] = cmul(csub(a, b), twm[pos << (12 - lh)]);
+            // W_{2*half}^pos = W_65536^(pos * 65536/(2*half))
+            z[i1] = cmul(csub(a, b), twm[pos << (15 - lh)]);
         }
         __syncthreads();
     }
@@ -240,7 +242,7 @@ __device__ __forceinline__ void lds_dit(double2 *z, int n, int logn, const doubl
         for (int j = threadIdx.x; j < (n >> 1); j += T) {
             const int pos = j & (half - 1);
             const int i0 = ((j >> lh) << (lh + 1)) + pos, i1 = i0 + half;
-            const double2 a = z[i0], b = cmul(z[i1], twm[pos << (12 - lh)]);
+            const double2 a = z[i0], b = cmul(z[i1], twm[pos << (15 - lh)]);
             z[i0] = cadd(a, b);
             z[i1] = csub(a, b);
         }
@@ -335,10 +337,12 @@ __device__ __forceinline__ void lds_argmax(const double2 *z, double *red, int *r
 __global__ __launch_bounds__(256) void xcorr_fused_generic(const FusedParams p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    double2 *z = reinterpret_cast<double2 *>(smem_raw);
-    double *red = reinterpret_cast<double *>(z + p.n);
-    int *redi = reinterpret_cast<int *>(red + 48);
     const int n = p.n, logn = p.logn, N = p.N, t = threadIdx.x;
+    double2 *z = reinterpret_cast<double2 *>(smem_raw);
+    double *red = reinterpret_cast<double *>(z + (p.gscratch ? 0 : n));
+    if (p.gscratch) // n > 8192: work buffer in global memory, one slice per workgroup
+        z = p.gscratch + (size_t)blockIdx.x * (size_t)n;
+    int *redi = reinterpret_cast<int *>(red + 48);
 
     for (long long pair = blockIdx.x; pair < p.npairs; pair += gridDim.x) {
         const long long rA = 2 * pair, rB = rA + 1;
@@ -397,11 +401,14 @@ __global__ __launch_bounds__(256) void xcorr_fused_generic(const FusedParams p)
 __global__ __launch_bounds__(256) void ref_spectrum_kernel(const double *__restrict__ ref, int N, int n, int logn,
                                                            int normalize, double x_scale, double xc_scale,
                                                            const double2 *__restrict__ twm, double2 *X,
-                                                           double2 *xc, float2 *xcf, double *xs, int *status)
+                                                           double2 *xc, float2 *xcf, double *xs, double2 *gscratch,
+                                                           int *status)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double2 *z = reinterpret_cast<double2 *>(smem_raw);
-    double *red = reinterpret_cast<double *>(z + n);
+    double *red = reinterpret_cast<double *>(z + (gscratch ? 0 : n));
+    if (gscratch)
+        z = gscratch;
     ZnFlags fa, fb;
     // post scale 1/(N-1) on the real part (muse_batch.go:42)
     lds_load_znorm(z, red, ref, ref, false, N, n, normalize != 0, x_scale, fa, fb);
@@ -608,7 +615,10 @@ hipError_t launch_fused(const FusedParams &p, int variant, int num_cus, hipStrea
         hipLaunchKernelGGL(xcorr_fused_n4096, dim3((unsigned)grid), dim3(R16_THREADS), 0, stream, p);
         return hipGetLastError();
     }
-    const size_t lds = (size_t)p.n * sizeof(double2) + 64 * sizeof(double);
+    const bool global_mode = p.n > GENERIC_LDS_MAX_N;
+    if (global_mode && !p.gscratch)
+        return hipErrorInvalidValue;
+    const size_t lds = (global_mode ? 0 : (size_t)p.n * sizeof(double2)) + 64 * sizeof(double);
     static size_t configured = 0;
     if (lds > 64 * 1024 && lds > configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(xcorr_fused_generic),
@@ -618,7 +628,7 @@ hipError_t launch_fused(const FusedParams &p, int variant, int num_cus, hipStrea
         configured = lds;
     }
     long long grid = p.npairs;
-    const long long cap = (long long)num_cus * 16;
+    const long long cap = (long long)num_cus * (global_mode ? GENERIC_GLOBAL_WGS_PER_CU : 16); // global mode: one scratch slice each
     if (grid > cap)
         grid = cap;
     hipLaunchKernelGGL(xcorr_fused_generic, dim3((unsigned)grid), dim3(256), lds, stream, p);
@@ -627,9 +637,11 @@ hipError_t launch_fused(const FusedParams &p, int variant, int num_cus, hipStrea
 
 hipError_t launch_ref_spectrum(const double *ref_dev, int N, int n, int logn, int normalize, double x_scale,
                                double xc_scale, const double2 *twm, double2 *X, double2 *xc, float2 *xcf, double *xs,
-                               int *status, hipStream_t stream)
+                               double2 *gscratch, int *status, hipStream_t stream)
 {
-    const size_t lds = (size_t)n * sizeof(double2) + 64 * sizeof(double);
+    if (n > GENERIC_LDS_MAX_N && !gscratch)
+        return hipErrorInvalidValue;
+    const size_t lds = (n > GENERIC_LDS_MAX_N ? 0 : (size_t)n * sizeof(double2)) + 64 * sizeof(double);
     static size_t configured = 0;
     if (lds > 64 * 1024 && lds > configured) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ref_spectrum_kernel),
@@ -639,7 +651,7 @@ hipError_t launch_ref_spectrum(const double *ref_dev, int N, int n, int logn, in
         configured = lds;
     }
     hipLaunchKernelGGL(ref_spectrum_kernel, dim3(1), dim3(256), lds, stream, ref_dev, N, n, logn, normalize, x_scale,
-                       xc_scale, twm, X, xc, xcf, xs, status);
+                       xc_scale, twm, X, xc, xcf, xs, n > GENERIC_LDS_MAX_N ? gscratch : nullptr, status);
     return hipGetLastError();
 }
 

@@ -23,6 +23,7 @@
 //     value instead of to every sample (the argmax is scale invariant).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "fft_device.h"
 #include "xcorr_kernels.h"
@@ -408,7 +409,10 @@ __global__ __launch_bounds__(PIPE_THREADS, 2) void xcorr_fused_n4096_pipe(const 
 hipError_t launch_fused_pipe(const FusedParams &p, int num_cus, hipStream_t stream)
 {
     long long grid = p.npairs;
-    const long long cap = (long long)num_cus * 2; // persistent: 2 resident workgroups per CU
+    int mult = 1; // resident workgroups per CU x mult (MUSE_HIP_GRID_MULT: tuning aid)
+    if (const char *m = getenv("MUSE_HIP_GRID_MULT"))
+        mult = atoi(m) > 0 ? atoi(m) : mult;
+    const long long cap = (long long)num_cus * 2 * mult;
     if (grid > cap)
         grid = cap;
     if (p.N < 4096)

@@ -24,6 +24,7 @@
 //      near ties) is appended to an overflow list and redone by the fp64 kernel.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "fft_device.h"
 #include "xcorr_kernels.h"
@@ -437,7 +438,10 @@ __global__ __launch_bounds__(SCR_THREADS, 3) void xcorr_fused_n4096_screen(const
 hipError_t launch_fused_screen(const FusedParams &p, int num_cus, hipStream_t stream)
 {
     long long grid = p.npairs;
-    const long long cap = (long long)num_cus * 3 * 2;
+    int mult = 1; // resident workgroups per CU x mult (MUSE_HIP_GRID_MULT: tuning aid)
+    if (const char *m = getenv("MUSE_HIP_GRID_MULT"))
+        mult = atoi(m) > 0 ? atoi(m) : mult;
+    const long long cap = (long long)num_cus * 3 * mult;
     if (grid > cap)
         grid = cap;
     if (p.N < 4096)

@@ -28,6 +28,7 @@
 // on any aligned 16 lanes and on the hardware's {0-3,12-15,20-27}-style groups.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "fft_device.h"
 #include "xcorr_kernels.h"
@@ -284,19 +285,20 @@ __global__ __launch_bounds__(W8_THREADS, 4) void xcorr_fused_n4096_w8(const Fuse
     const int pad = 4096 - N;
     const double invN = 1.0 / (double)N, invNm1 = 1.0 / (double)(N - 1);
 
-    // workgroup-lifetime twiddle tables from the W_8192 master table: W_512^m = W_8192^(16 m), W_64^m = W_8192^(128 m)
+    // workgroup-lifetime twiddle tables from the W_65536 master table (half period stored):
+    // W_512^m = W_65536^(128 m), W_64^m = W_65536^(1024 m)
     {
         const int k = t >> 6, l = t & 63;
-        const int m = (k * l) & 511;
-        double2 w = p.twm[(m * 16) & 4095];
-        if (m * 16 >= 4096) // W^(x + 4096) = -W^x for the 8192-th root table (half period stored)
+        const int i2 = ((k * l) & 511) * 128;
+        double2 w = p.twm[i2 & 32767];
+        if (i2 >= 32768) // W^(x + 32768) = -W^x
             w = make_double2(-w.x, -w.y);
         tw2s[t] = w;
         if (t < 64) {
             const int kk = t >> 3, dd = t & 7;
-            const int mm = (kk * dd) & 63;
-            double2 w3 = p.twm[(mm * 128) & 4095];
-            if (mm * 128 >= 4096)
+            const int i3 = ((kk * dd) & 63) * 1024;
+            double2 w3 = p.twm[i3 & 32767];
+            if (i3 >= 32768)
                 w3 = make_double2(-w3.x, -w3.y);
             tw3s[t] = w3;
         }
@@ -438,7 +440,10 @@ __global__ __launch_bounds__(W8_THREADS, 4) void xcorr_fused_n4096_w8(const Fuse
 hipError_t launch_fused_w8(const FusedParams &p, int num_cus, hipStream_t stream)
 {
     long long grid = p.npairs;
-    const long long cap = (long long)num_cus * 2; // persistent: 2 resident 512-thread workgroups per CU
+    int mult = 1; // resident workgroups per CU x mult (MUSE_HIP_GRID_MULT: tuning aid)
+    if (const char *m = getenv("MUSE_HIP_GRID_MULT"))
+        mult = atoi(m) > 0 ? atoi(m) : mult;
+    const long long cap = (long long)num_cus * 2 * mult;
     if (grid > cap)
         grid = cap;
     if (p.N < 4096)

@@ -38,7 +38,7 @@ typedef enum muse_status {
     MUSE_ERR_ZERO_STD = -3,    /* "Invalid input query": sigma(ref)==0, muse_batch.go:39-41 */
     MUSE_ERR_NO_DEVICE = -4,   /* no usable gfx950 device                         */
     MUSE_ERR_HIP = -5,         /* a HIP runtime call failed                       */
-    MUSE_ERR_UNSUPPORTED = -6, /* FFT length outside the built kernels (n > 8192) */
+    MUSE_ERR_UNSUPPORTED = -6, /* FFT length outside the built kernels (n > 65536) */
     MUSE_ERR_NOMEM = -7,
     MUSE_ERR_EMPTY = -8        /* empty reference: muse.go:24-26                  */
 } muse_status;

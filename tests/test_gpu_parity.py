@@ -235,10 +235,11 @@ def _rows(M, N, seed):
     return ref, rows
 
 
-@pytest.mark.parametrize("N", [2, 3, 8, 12, 100, 480, 512, 1000, 2048, 3000, 4096, 5000, 8192])
+@pytest.mark.parametrize("N", [2, 3, 8, 12, 100, 480, 512, 1000, 2048, 3000, 4096, 5000, 8192, 10000, 16384, 40000, 65536])
 @pytest.mark.parametrize("M", [1, 2, 7])
 def test_scores_match_oracle_all_lengths(muse, eng, oracle, N, M):
-    """generic LDS kernel (and the tuned one at n = 4096, incl. N < n padding)"""
+    """generic kernel (LDS work buffer up to n = 8192, global scratch up to n = 65536: the long
+    series of BASELINE config 5) and the tuned one at n = 4096, incl. N < n padding"""
     ref, rows = _rows(M, N, 1000 * N + M)
     dg = muse.DeviceGroup.from_rows(eng, rows)
     db = muse.DeviceBatch(eng, dg, ref)
