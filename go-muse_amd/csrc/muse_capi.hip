@@ -94,8 +94,16 @@ struct muse_group {
     std::atomic<int> refs{1}; // the handle itself + one per batch built on it
     muse_ctx *ctx = nullptr;
     double *rows = nullptr;
-    int64_t cap = 0, M = 0, stride = 0;
+    int64_t cap = 0, M = 0, stride = 0; // M counts staged rows too
     int32_t N = 0;
+    // Small appends (Group.Add calls muse_group_append once per Series) are packed into
+    // two pinned staging buffers and uploaded asynchronously on the context's stream, one
+    // buffer in flight while the other fills; kernels on that stream are ordered behind.
+    double *stage[2] = {nullptr, nullptr};
+    hipEvent_t stage_done[2] = {nullptr, nullptr};
+    int cur = 0;
+    int64_t staged = 0;     // rows waiting in stage[cur]
+    int64_t stage_rows = 0; // capacity of one staging buffer, in rows
 };
 
 struct muse_batch {
@@ -348,6 +356,21 @@ static int group_reserve(muse_group *g, int64_t rows)
     return MUSE_OK;
 }
 
+// enqueue the staged rows' upload (asynchronous); the buffer is reusable after stage_done
+static int group_flush(muse_group *g)
+{
+    if (!g->staged)
+        return MUSE_OK;
+    const int64_t first = g->M - g->staged;
+    HIP_TRY(hipMemcpyAsync(g->rows + first * g->stride, g->stage[g->cur],
+                           (size_t)g->staged * (size_t)g->N * sizeof(double), hipMemcpyHostToDevice, g->ctx->stream));
+    HIP_TRY(hipEventRecord(g->stage_done[g->cur], g->ctx->stream));
+    g->staged = 0;
+    g->cur ^= 1;
+    HIP_TRY(hipEventSynchronize(g->stage_done[g->cur])); // the other buffer's last upload has landed
+    return MUSE_OK;
+}
+
 extern "C" int muse_group_append(muse_group *g, const double *rows, int64_t count, int64_t row_stride)
 {
     if (!g || (!rows && count > 0) || count < 0)
@@ -360,13 +383,49 @@ extern "C" int muse_group_append(muse_group *g, const double *rows, int64_t coun
     int rc = use_device(g->ctx);
     if (rc)
         return rc;
-    rc = group_reserve(g, g->M + count);
-    if (rc)
-        return rc;
-    HIP_TRY(hipMemcpy2D(g->rows + g->M * g->stride, (size_t)g->stride * sizeof(double), rows,
-                        (size_t)row_stride * sizeof(double), (size_t)g->N * sizeof(double), (size_t)count,
-                        hipMemcpyHostToDevice));
-    g->M += count;
+    const size_t row_bytes = (size_t)g->N * sizeof(double);
+    constexpr size_t STAGE_BYTES = 32u << 20;
+    const bool small = (size_t)count * row_bytes < STAGE_BYTES / 4;
+    if (small && !g->stage[0]) { // first small append: set the staging pair up
+        g->stage_rows = std::max<int64_t>(1, (int64_t)(STAGE_BYTES / row_bytes));
+        for (int i = 0; i < 2; i++) {
+            HIP_TRY(hipHostMalloc((void **)&g->stage[i], (size_t)g->stage_rows * row_bytes, hipHostMallocDefault));
+            HIP_TRY(hipEventCreateWithFlags(&g->stage_done[i], hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(g->stage_done[i], g->ctx->stream));
+        }
+    }
+    if (!small) { // a slab: upload it directly (synchronously: the caller's memory is not retained)
+        rc = group_flush(g);
+        if (rc)
+            return rc;
+        rc = group_reserve(g, g->M + count);
+        if (rc)
+            return rc;
+        HIP_TRY(hipMemcpy2DAsync(g->rows + g->M * g->stride, (size_t)g->stride * sizeof(double), rows,
+                                 (size_t)row_stride * sizeof(double), row_bytes, (size_t)count, hipMemcpyHostToDevice,
+                                 g->ctx->stream));
+        HIP_TRY(hipStreamSynchronize(g->ctx->stream));
+        g->M += count;
+        return MUSE_OK;
+    }
+    for (int64_t r = 0; r < count; r++) {
+        if (g->staged == g->stage_rows) {
+            rc = group_flush(g);
+            if (rc)
+                return rc;
+        }
+        if (g->M + 1 > g->cap) {
+            // growing re-allocates and copies on the stream; staged rows are uploaded first
+            rc = group_flush(g);
+            if (!rc)
+                rc = group_reserve(g, g->M + 1);
+            if (rc)
+                return rc;
+        }
+        memcpy(g->stage[g->cur] + g->staged * g->N, rows + r * row_stride, row_bytes);
+        g->staged++;
+        g->M++;
+    }
     return MUSE_OK;
 }
 
@@ -390,6 +449,9 @@ extern "C" int muse_group_fill_synthetic(muse_group *g, int64_t first, int64_t c
     if (!g || first < 0 || count < 0 || first > g->M)
         return fail(MUSE_ERR_INVALID, "bad synthetic fill range");
     int rc = use_device(g->ctx);
+    if (rc)
+        return rc;
+    rc = group_flush(g);
     if (rc)
         return rc;
     rc = group_reserve(g, first + count);
@@ -432,6 +494,9 @@ extern "C" int muse_group_read(muse_group *g, int64_t first, int64_t count, doub
     int rc = use_device(g->ctx);
     if (rc)
         return rc;
+    rc = group_flush(g);
+    if (rc)
+        return rc;
     HIP_TRY(hipStreamSynchronize(g->ctx->stream));
     HIP_TRY(hipMemcpy2D(out, (size_t)g->N * sizeof(double), g->rows + first * g->stride,
                         (size_t)g->stride * sizeof(double), (size_t)g->N * sizeof(double), (size_t)count,
@@ -446,6 +511,12 @@ static void group_release(muse_group *g)
     (void)hipSetDevice(g->ctx->device);
     (void)hipStreamSynchronize(g->ctx->stream);
     (void)hipFree(g->rows);
+    for (int i = 0; i < 2; i++) {
+        if (g->stage[i])
+            (void)hipHostFree(g->stage[i]);
+        if (g->stage_done[i])
+            (void)hipEventDestroy(g->stage_done[i]);
+    }
     muse_ctx *ctx = g->ctx;
     delete g;
     ctx_release(ctx);
@@ -597,6 +668,9 @@ extern "C" int muse_batch_score(muse_batch *b)
         return fail(MUSE_ERR_INVALID, "NULL batch");
     muse_ctx *ctx = b->ctx;
     int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    rc = group_flush(b->g); // rows still in the staging buffer are uploaded ahead of the kernel
     if (rc)
         return rc;
     const int64_t M = b->g->M;

@@ -482,3 +482,35 @@ def test_config5_mixed_lengths_label_grouped(muse, eng, oracle, N):
     assert [s.Labels.labels for s in got] == [series[i].labels.labels for i in oi]
     assert abs(mean - omean) < 1e-9
     assert got[0].Labels.labels == {"graph": "g07", "host": "h3"} and abs(got[0].PercentScore - 1.0) < 1e-9
+
+
+def test_group_append_staging_paths(muse, eng, oracle):
+    """Group.Add-style ingestion: one muse_group_append per Series (pinned double-buffered
+    staging, asynchronous upload), mixed with slab appends and growth re-allocations; the
+    resident matrix must read back bit-identical and score like a bulk upload."""
+    rng = np.random.default_rng(99)
+    M, N = 5000, 1500                      # 12 KB rows: ~2800 rows per 32 MB staging buffer
+    rows = rng.standard_normal((M, N))
+    ref = rng.standard_normal(N)
+    dg = muse.DeviceGroup(eng, N, capacity=16)          # forces several growth steps
+    i = 0
+    while i < M:
+        if i % 1000 == 0 and i + 300 <= M:               # a slab of 300 rows (direct path when large enough)
+            dg.append(rows[i:i + 300])
+            i += 300
+        else:
+            dg.append(rows[i])                           # per-Series append
+            i += 1
+    assert dg.M == M
+    np.testing.assert_array_equal(dg.read(0, M), rows)
+    db = muse.DeviceBatch(eng, dg, ref)
+    lag, mv = db.scores()
+    big = muse.DeviceGroup.from_rows(eng, rows)
+    lag2, mv2 = muse.DeviceBatch(eng, big, ref).scores()
+    assert np.array_equal(lag, lag2) and np.array_equal(mv, mv2)
+    dg.append(rows[:7])                                  # append after a run: next run sees the new rows
+    lag3, mv3 = db.scores()
+    # two series share one complex FFT, so a row's last bits depend on its pair partner
+    assert len(lag3) == M + 7 and np.array_equal(lag3[M:], lag[:7])
+    np.testing.assert_allclose(mv3[M:], mv[:7], rtol=1e-12, atol=0)
+    assert np.array_equal(lag3[:M], lag) and np.array_equal(mv3[:M], mv)
