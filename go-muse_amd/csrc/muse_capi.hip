@@ -77,7 +77,7 @@ struct muse_ctx {
     int num_cus = 0;
     int64_t hbm = 0;
     char name[64] = {0};
-    double2 *tw1 = nullptr, *tw2 = nullptr, *twm = nullptr, *tw1w8 = nullptr;
+    double2 *tw1 = nullptr, *tw2 = nullptr, *twm = nullptr, *tw1w8 = nullptr, *tw1p = nullptr;
     float2 *tw1f = nullptr, *tw2f = nullptr; // fp32 copies for the screening kernel
     double screen_delta = 1e-4;
     int variant = 0;
@@ -111,6 +111,7 @@ struct muse_batch {
     muse_group *g = nullptr;
     int32_t N = 0, n = 0, logn = 0;
     double2 *X = nullptr, *xc = nullptr;
+    double2 *xcp = nullptr; // n == 4096: xc in the lane order of xcorr_r16_fast.hip
     float2 *xcf = nullptr; // fp32 conj(X)/n (screening kernel)
     double2 *gscratch = nullptr; // n > 8192: per-workgroup work buffers of the generic kernel
     double *xs = nullptr;  // padded time-domain reference (exact re-evaluation)
@@ -194,6 +195,12 @@ extern "C" int muse_ctx_create(int32_t device, muse_ctx **out)
     HIP_TRY(hipMemcpy(ctx->tw1, t1.data(), t1.size() * sizeof(double2), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ctx->tw2, t2.data(), t2.size() * sizeof(double2), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ctx->twm, tm.data(), tm.size() * sizeof(double2), hipMemcpyHostToDevice));
+    std::vector<double2> t1p(16 * 256); // tw1 in the lane order of xcorr_r16_fast.hip's second transform
+    for (int k = 0; k < 16; k++)
+        for (int t = 0; t < 256; t++)
+            fill_twiddle(t1p, (size_t)k * 256 + t, (long long)k * (16 * (t & 15) + (t >> 4)), 4096);
+    HIP_TRY(hipMalloc(&ctx->tw1p, t1p.size() * sizeof(double2)));
+    HIP_TRY(hipMemcpy(ctx->tw1p, t1p.data(), t1p.size() * sizeof(double2), hipMemcpyHostToDevice));
     std::vector<double2> t8(8 * 512);
     for (int k = 0; k < 8; k++)
         for (int t = 0; t < 512; t++)
@@ -231,6 +238,7 @@ static void ctx_release(muse_ctx *ctx)
     (void)hipFree(ctx->twm);
     (void)hipFree(ctx->tw1f);
     (void)hipFree(ctx->tw1w8);
+    (void)hipFree(ctx->tw1p);
     (void)hipFree(ctx->tw2f);
     if (ctx->stream)
         (void)hipStreamDestroy(ctx->stream);
@@ -267,7 +275,7 @@ extern "C" int muse_ctx_device_info(muse_ctx *ctx, char *name, int32_t name_cap,
 
 extern "C" int muse_ctx_set_kernel(muse_ctx *ctx, int32_t variant)
 {
-    if (!ctx || variant < 0 || variant > 9 || variant == 3 || variant == 4) // 3, 4: retired
+    if (!ctx || variant < 0 || variant > 10 || variant == 3 || variant == 4) // 3, 4: retired
         return fail(MUSE_ERR_INVALID, "bad kernel variant");
     ctx->variant = variant;
     return MUSE_OK;
@@ -619,6 +627,17 @@ extern "C" int muse_batch_create(muse_ctx *ctx, muse_group *g, const double *ref
         muse_batch_free(b);
         return rc;
     }
+    if (n == 4096) {
+        e = hipMalloc(&b->xcp, (size_t)n * sizeof(double2));
+        if (e == hipSuccess)
+            e = launch_lane_order(b->xc, b->xcp, ctx->stream);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            muse_batch_free(b);
+            return fail(MUSE_ERR_HIP, "lane-order table: %s", hipGetErrorString(e));
+        }
+    }
     if (zero) { // muse_batch.go:39-41
         muse_batch_free(b);
         return fail(MUSE_ERR_ZERO_STD, "Invalid input query, Standard deviation of zero");
@@ -698,25 +717,30 @@ extern "C" int muse_batch_score(muse_batch *b)
     p.cc_out = nullptr;
     p.nil_out = nullptr;
     p.tw1w8 = ctx->tw1w8;
+    p.tw1p = ctx->tw1p;
+    p.xcp = b->xcp;
     p.tw1f = ctx->tw1f;
     p.tw2f = ctx->tw2f;
     p.xcf = b->xcf;
     p.xs = b->xs;
     p.screen_delta = ctx->screen_delta;
-    // kernel selection: ctx->variant 0 = auto; 1 = generic LDS radix-2; 2, 5..9 force one
+    // kernel selection: ctx->variant 0 = auto; 1 = generic LDS radix-2; 2, 5..10 force one
     // of the n = 4096 kernels (parity tests run every one of them on the same inputs)
     int variant = KERNEL_GENERIC;
     if (b->n == 4096) {
         switch (ctx->variant) {
-        case 0: variant = KERNEL_R16_OCC3; break; // fastest measured (profiles/)
+        case 0: variant = KERNEL_R16_FAST; break; // fastest measured (profiles/); N < 4096: occ3, below
         case 2: variant = KERNEL_R16_N4096; break;
         case 5: variant = KERNEL_R16_PIPE; break;
         case 6: variant = KERNEL_R16_OCC4; break;
         case 7: variant = KERNEL_R16_OCC3; break;
         case 8: variant = KERNEL_R16_SCREEN; break;
         case 9: variant = KERNEL_R8_W8; break;
+        case 10: variant = KERNEL_R16_FAST; break;
         default: variant = KERNEL_GENERIC; break;
         }
+        if (variant == KERNEL_R16_FAST && b->N != 4096) // the deferred-statistics kernel is built for N == n only
+            variant = KERNEL_R16_OCC3;
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->timing) {
@@ -724,21 +748,22 @@ extern "C" int muse_batch_score(muse_batch *b)
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, ctx->stream));
     }
-    if (variant == KERNEL_R16_SCREEN) {
+    if (variant == KERNEL_R16_SCREEN || variant == KERNEL_R16_FAST) {
         // pairs with too many near-tie candidates are listed by the screening kernel and
         // redone by the fp64 kernel right behind it (no host round trip: the count stays on
         // the device and bounds the second launch's loop)
-        if (p.npairs > b->ovf_cap) {
+        // (the fast kernel lists pairs with a NaN/Inf series, once per such series: 2 entries per pair)
+        if (2 * p.npairs > b->ovf_cap) {
             (void)hipFree(b->ovf_list);
             b->ovf_list = nullptr;
             b->ovf_cap = 0;
-            HIP_TRY(hipMalloc(&b->ovf_list, (size_t)p.npairs * sizeof(long long)));
-            b->ovf_cap = p.npairs;
+            HIP_TRY(hipMalloc(&b->ovf_list, (size_t)(2 * p.npairs) * sizeof(long long)));
+            b->ovf_cap = 2 * p.npairs;
         }
         p.ovf_count = b->ovf_count;
         p.ovf_list = b->ovf_list;
         HIP_TRY(hipMemsetAsync(b->ovf_count, 0, sizeof(int), ctx->stream));
-        HIP_TRY(launch_fused(p, KERNEL_R16_SCREEN, ctx->num_cus, ctx->stream));
+        HIP_TRY(launch_fused(p, variant, ctx->num_cus, ctx->stream));
         FusedParams q = p;
         q.pair_list = b->ovf_list;
         q.pair_count = b->ovf_count;
@@ -1040,6 +1065,7 @@ extern "C" int muse_batch_free(muse_batch *b)
     (void)hipStreamSynchronize(b->ctx->stream);
     (void)hipFree(b->X);
     (void)hipFree(b->xc);
+    (void)hipFree(b->xcp);
     (void)hipFree(b->xcf);
     (void)hipFree(b->gscratch);
     (void)hipFree(b->xs);

@@ -1,0 +1,251 @@
+// r16_device.h -- device helpers shared by the tuned n = 4096 kernels
+// (xcorr_r16_occ4.hip, xcorr_r16_fast.hip): LDS-only barrier, scalar global
+// pointers, the half-round LDS transposes, twiddle fetchers and the register
+// prefetch of the next pair's rows.  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fft_device.h"
+#include "xcorr_kernels.h"
+
+namespace muse {
+
+constexpr int OCC_THREADS = 256;
+constexpr int OCC_XBUF = 8 * 272; // double2 elements: 34,816 B
+
+namespace occ4 {
+
+__device__ __forceinline__ void fence() { __builtin_amdgcn_sched_barrier(0); }
+// LDS-only barrier (does not drain outstanding global loads)
+__device__ __forceinline__ void lds_barrier()
+{
+    fence();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    fence();
+}
+// a wave-uniform double moved to SGPRs (frees two VGPRs per value)
+__device__ __forceinline__ double uniform(double v)
+{
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+// The result is an address_space(1) (global) pointer on purpose: laundering a
+// generic pointer through the asm loses the address space and every load through
+// it becomes flat_load, which counts on lgkmcnt as well -- the LDS-only barrier
+// (s_waitcnt lgkmcnt(0)) would then drain the prefetch.
+#if defined(__HIP_DEVICE_COMPILE__)
+template <typename T>
+using gptr = const T __attribute__((address_space(1))) *;
+#else
+template <typename T>
+using gptr = const T *; // host pass only parses this file
+#endif
+typedef double d2v __attribute__((ext_vector_type(2)));
+template <typename T>
+__device__ __forceinline__ gptr<T> scalar_ptr(const T *p)
+{
+    unsigned long long u = (unsigned long long)p;
+    asm volatile("" : "+s"(u));
+    return (gptr<T>)u;
+}
+// p + off as a scalar computed where it is used: the base is made opaque first, so
+// the s_add cannot be hoisted out of the pair loop (hoisted bases get spilled to VGPR
+// lanes and cost a v_readlane per use)
+template <typename T>
+__device__ __forceinline__ gptr<T> scalar_ptr_at(const T *p, long long off)
+{
+    unsigned long long u = (unsigned long long)p;
+    asm volatile("" : "+s"(u));
+    u += (unsigned long long)(off * (long long)sizeof(T));
+    asm volatile("" : "+s"(u));
+    return (gptr<T>)u;
+}
+// 16-byte global load of one complex value (native vector type: HIP's double2
+// struct cannot be copied out of an address_space(1) reference)
+__device__ __forceinline__ double2 ldg2(gptr<double2> p, int i)
+{
+    const d2v x = ((gptr<d2v>)p)[i];
+    return make_double2(x.x, x.y);
+}
+
+// One LDS transpose in two half rounds through the 8 x 272 buffer (positions in
+// double2 units).  Layouts (same bank analysis as xcorr_kernels.hip):
+//   A: writer (b = hi, c = lo) output k1 -> 272*(k1&7) + t
+//      reader (k1 = hi, c = lo) input b  <- 272*(hi&7) + 16*b + lo
+//   B: writer (k1 = hi, c = lo) output k2 -> 272*(k2&7) + 17*hi + lo
+//      reader (k1 = lo, k2 = hi) input c <- 272*(hi&7) + 17*lo + c
+// Round 0 moves outputs 0..7 (read by waves 0-1, whose hi is 0..7), round 1
+// outputs 8..15 (waves 2-3).  `wave` is an SGPR, so the two paths are scalar
+// branches with disjoint live ranges; both execute the same four barriers.
+template <bool B>
+__device__ __forceinline__ void exchange(double2 (&v)[16], double2 *xbuf, const int wave, const int t)
+{
+    const int hi = t >> 4, lo = t & 15;
+    const int wbase = B ? 17 * hi + lo : t;
+    const int rbase = 272 * (hi & 7) + (B ? 17 * lo : lo);
+    lds_barrier(); // buffer free: the previous transpose's last readers are done
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        xbuf[272 * k + wbase] = v[P16(k)];
+    lds_barrier();
+    if (wave < 2) {
+        double2 w[16];
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+            w[e] = xbuf[rbase + (B ? e : 16 * e)];
+        lds_barrier();
+#pragma unroll
+        for (int k = 8; k < 16; k++)
+            xbuf[272 * (k - 8) + wbase] = v[P16(k)];
+        lds_barrier();
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+            v[e] = w[e];
+    } else {
+        lds_barrier();
+#pragma unroll
+        for (int k = 8; k < 16; k++)
+            xbuf[272 * (k - 8) + wbase] = v[P16(k)];
+        lds_barrier();
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+            v[e] = xbuf[rbase + (B ? e : 16 * e)];
+    }
+}
+
+// 16-point DFT followed by 15 twiddle multiplies whose factors are fetched by
+// `fetch(k)` (k = 1..15) in two batches; the first batch is issued BEFORE the
+// butterflies and the second before the first is consumed, so the fetch latency
+// (L2 or LDS) overlaps arithmetic instead of adding to the dependent chain.
+template <typename F>
+__device__ __forceinline__ void dft16_twiddle(double2 (&v)[16], F fetch)
+{
+    double2 ta[8], tb[7];
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+        ta[j] = fetch(1 + j);
+    fence();
+    dft16(v);
+    fence();
+#pragma unroll
+    for (int j = 0; j < 7; j++)
+        tb[j] = fetch(9 + j);
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+        v[P16(1 + j)] = cmul(v[P16(1 + j)], ta[j]);
+    fence();
+#pragma unroll
+    for (int j = 0; j < 7; j++)
+        v[P16(9 + j)] = cmul(v[P16(9 + j)], tb[j]);
+}
+
+// The same with four batches of four factors (two in flight: 32 VGPRs instead of 60), for the
+// 128-register builds.
+template <typename F>
+__device__ __forceinline__ void dft16_twiddle_small(double2 (&v)[16], F fetch)
+{
+    double2 ta[4], tb[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        ta[j] = fetch(1 + j);
+    fence();
+    dft16(v);
+    fence();
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        tb[j] = fetch(5 + j);
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        v[P16(1 + j)] = cmul(v[P16(1 + j)], ta[j]);
+    fence();
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        ta[j] = fetch(9 + j);
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        v[P16(5 + j)] = cmul(v[P16(5 + j)], tb[j]);
+    fence();
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+        tb[j] = fetch(13 + j);
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+        v[P16(9 + j)] = cmul(v[P16(9 + j)], ta[j]);
+    fence();
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+        v[P16(13 + j)] = cmul(v[P16(13 + j)], tb[j]);
+}
+
+// each factor's row base is a scalar (s_add on the table pointer): the load is
+// saddr + the shared VGPR offset 16 t, no 64-bit VALU address arithmetic
+struct Tw1Fetch {
+    const double2 *p;
+    int t;
+    __device__ __forceinline__ double2 operator()(int k) const
+    {   // one scalar base per two rows: the odd row sits at immediate offset -4096 B
+        return ldg2(scalar_ptr_at(p, ((k + 1) & ~1) * 256), t - 256 * (k & 1));
+    }
+};
+struct Tw2Fetch {
+    const double2 *p;
+    int lo;
+    __device__ __forceinline__ double2 operator()(int k) const { return p[k * 16 + lo]; }
+};
+
+// The next pair's rows, prefetched into registers: element t + 256*i of the two
+// (zero-padded) rows plus each row's first sample.
+struct RawPair {
+    double a[16], b[16];
+    double ka, kb;
+};
+// Unconditional coalesced nontemporal loads (a conditional prefetch parks `raw`
+// in scratch; a per-element `if` serialises the loads): the caller clamps `pair`.
+template <bool PADDED>
+__device__ __forceinline__ void issue_row_loads(RawPair &r, const FusedParams &p, long long pair, int t, int pad)
+{
+    const long long rA = 2 * pair;
+    const long long rB = (rA + 1 < p.M) ? rA + 1 : rA;
+    const gptr<double> ra = scalar_ptr(p.rows + rA * p.stride);
+    const gptr<double> rb = scalar_ptr(p.rows + rB * p.stride);
+    r.ka = ra[0];
+    r.kb = rb[0];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        if (PADDED) {
+            int j = t + 256 * i - pad;
+            j = j < 0 ? 0 : j; // clamped: always load, the value is masked later
+            r.a[i] = __builtin_nontemporal_load(ra + j);
+            r.b[i] = __builtin_nontemporal_load(rb + j);
+        } else { // one scalar base per four 2 KB slices (immediate offsets -4096 .. +2048 B)
+                 // + the shared VGPR offset 8 t: no 64-bit VALU address arithmetic
+            const int c = (i & ~3) * 256 + 512;
+            r.a[i] = __builtin_nontemporal_load(scalar_ptr_at(p.rows + rA * p.stride, c) + (256 * i - c) + t);
+            r.b[i] = __builtin_nontemporal_load(scalar_ptr_at(p.rows + rB * p.stride, c) + (256 * i - c) + t);
+        }
+    }
+}
+
+// shifted sums of one series: sum d, sum d^2  (d = x - x[0])
+struct Stat {
+    double s1, s2;
+};
+
+// zNormalize constants (xcorr.go:84-95 via the centred sample variance):
+// variance from the shifted sums; flags for the (nil,0,0) and NaN outcomes.
+__device__ __forceinline__ double variance(const Stat &s, double invN, double invNm1, bool &zero, bool &nan)
+{
+    const double var = (s.s2 - s.s1 * s.s1 * invN) * invNm1;
+    // NaN or +-Inf statistics: every cc is NaN in the reference.  (Not `var - var != 0`:
+    // under fp-contract the compiler fuses var's multiply into the subtraction and
+    // the rounding residual makes it true for finite values.)
+    nan = !__builtin_isfinite(var);
+    zero = !nan && !(var > 0.0);  // sigma == 0 (rounding may leave -0 / a tiny negative)
+    return var;
+}
+
+} // namespace occ4
+
+} // namespace muse

@@ -8,7 +8,7 @@
 
 namespace muse {
 
-enum { KERNEL_GENERIC = 0, KERNEL_R16_N4096 = 1, KERNEL_R16_PIPE = 4, KERNEL_R16_OCC4 = 5, KERNEL_R16_OCC3 = 6, KERNEL_R16_SCREEN = 7, KERNEL_R8_W8 = 8 };
+enum { KERNEL_GENERIC = 0, KERNEL_R16_N4096 = 1, KERNEL_R16_PIPE = 4, KERNEL_R16_OCC4 = 5, KERNEL_R16_OCC3 = 6, KERNEL_R16_SCREEN = 7, KERNEL_R8_W8 = 8, KERNEL_R16_FAST = 9 };
 
 struct FusedParams {
     const double *rows; // M x N row-major, row stride `stride` doubles
@@ -23,6 +23,8 @@ struct FusedParams {
     const double2 *tw1;  // [16][256] W_4096^(k*t)      (tuned kernel)
     const double2 *tw2;  // [16][16]  W_256^(k*c)       (tuned kernel)
     const double2 *tw1w8; // [8][512]  W_4096^(k*t)      (radix-8 kernel)
+    const double2 *tw1p; // [16][256] W_4096^(k*(16*(t&15) + (t>>4)))   (xcorr_r16_fast.hip, second transform)
+    const double2 *xcp;  // [16][256] xc[256*k + (t>>4) + 16*(t&15)]     (xcorr_r16_fast.hip: xc in lane order)
     const double2 *twm;  // [32768]   W_65536^k         (generic kernel; half period)
     double2 *gscratch;   // n > 8192: one n-element complex work buffer per workgroup (global, L2-resident)
     double *mv;          // out: M signed max values
@@ -48,6 +50,9 @@ hipError_t launch_fused_pipe(const FusedParams &p, int num_cus, hipStream_t stre
 hipError_t launch_fused_occ4(const FusedParams &p, int num_cus, int waves_per_simd, hipStream_t stream); // xcorr_r16_occ4.hip
 hipError_t launch_fused_screen(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_r16_screen.hip
 hipError_t launch_fused_w8(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_r8_w8.hip
+hipError_t launch_fused_fast(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_r16_fast.hip (N == n == 4096)
+// out[256 k + t] = in[256 k + (t >> 4) + 16 (t & 15)], k < 16: a 4096-entry table in the lane order of xcorr_r16_fast.hip
+hipError_t launch_lane_order(const double2 *in, double2 *out, hipStream_t stream);
 hipError_t launch_ref_spectrum(const double *ref_dev, int N, int n, int logn, int normalize, double x_scale,
                                double xc_scale, const double2 *twm, double2 *X, double2 *xc, float2 *xcf, double *xs,
                                double2 *gscratch, int *status, hipStream_t stream);

@@ -593,10 +593,24 @@ __global__ void synth_ref_kernel(double *ref, int N, unsigned long long seed)
 }
 
 // ----------------------------------------------------------- host launchers
+__global__ __launch_bounds__(256) void lane_order_kernel(const double2 *__restrict__ in, double2 *__restrict__ out)
+{
+    const int t = threadIdx.x, k = blockIdx.x;
+    out[256 * k + t] = in[256 * k + (t >> 4) + 16 * (t & 15)];
+}
+
+hipError_t launch_lane_order(const double2 *in, double2 *out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(lane_order_kernel, dim3(16), dim3(256), 0, stream, in, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_fused(const FusedParams &p, int variant, int num_cus, hipStream_t stream)
 {
     if (p.npairs <= 0)
         return hipSuccess;
+    if (variant == KERNEL_R16_FAST)
+        return launch_fused_fast(p, num_cus, stream);
     if (variant == KERNEL_R8_W8)
         return launch_fused_w8(p, num_cus, stream);
     if (variant == KERNEL_R16_SCREEN)

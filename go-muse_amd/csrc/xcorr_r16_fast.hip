@@ -1,0 +1,572 @@
+// xcorr_r16_fast.hip -- n = 4096, N == 4096 kernel with nine workgroup barriers
+// per pair of series (xcorr_r16_occ4.hip: nineteen).
+//
+// Mathematics: identical to xcorr_fused_n4096 (xcorr_kernels.hip header; the
+// reference path is xCorrWithX, /root/reference/xcorr.go:160-197).
+//
+// What changed against xcorr_r16_occ4.hip and why (phase stamps in profiles/:
+// the LDS transposes with their barriers and the two reductions were 56 % of a
+// workgroup's timeline, the butterflies 31 %):
+//   * Thread numbering.  The first transform keeps (b, c) -> (k1, c) for its first
+//     transpose (workgroup-wide, dictated by the coalesced row loads), but its second
+//     transpose hands (k1, c) -> (k1, k2): the sixteen lanes that share k1 sit in one
+//     wave, so it runs inside each wave's private quarter of the buffer with no
+//     workgroup barrier.  The second transform starts from that numbering
+//     (c' = k1 in the high half of the lane id, b' = k2 in the low half): its FIRST
+//     transpose is wave-local for the same reason and only its second is
+//     workgroup-wide.  The twiddle and spectrum tables are stored in lane order
+//     (FusedParams::tw1p, xcp), so every table load stays coalesced.
+//   * No statistics barrier.  For N == n the mean is never needed before the
+//     transform: the DC bin of the centred series is exactly 0, so bin 0 is zeroed
+//     after the first transform and sum(d) is read off it; sum(d^2) partials go to
+//     LDS and are only read by the two lanes that write the results, behind the next
+//     pair's first barrier, together with the argmax partials.
+//   * A series with NaN/Inf samples cannot be isolated from its pair partner once
+//     the statistics are deferred: such pairs are appended to FusedParams::ovf_list
+//     and redone by the occ4 kernel (which zeroes the dead series before the
+//     transform) in a second launch bounded by the on-device count.
+//   * The state of the previous pair lives in LDS, not in registers that only two
+//     lanes use.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "r16_device.h"
+
+namespace muse {
+
+namespace fast {
+
+using namespace occ4;
+
+#ifndef MUSE_FAST_PRIO
+#define MUSE_FAST_PRIO 0
+#endif
+__device__ __forceinline__ void prio_hi() { if (MUSE_FAST_PRIO) __builtin_amdgcn_s_setprio(3); }
+__device__ __forceinline__ void prio_lo() { if (MUSE_FAST_PRIO) __builtin_amdgcn_s_setprio(0); }
+
+constexpr int XW = 544; // double2 per wave-private quarter of the 8 x 272 buffer (8 rows x 68)
+
+// compiler-level ordering of a wave's own LDS traffic (the hardware executes one
+// wave's DS instructions in order; no s_waitcnt or s_barrier is needed)
+__device__ __forceinline__ void wave_order()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Workgroup-wide transpose in two half rounds (as occ4::exchange; layouts in
+// double2 units, bank analysis there):
+//   MODE 0 (first transform, transpose 1):
+//      writer (b = hi, c = lo) output k1 -> 272*(k1&7) + t
+//      reader (k1 = hi, c = lo) input b  <- 272*(hi&7) + 16*b + lo
+//   MODE 1 (second transform, transpose 2):
+//      writer (c' = hi, m1 = lo) output m2 -> 272*(m2&7) + 17*lo + hi
+//      reader (m1 = lo, m2 = hi) input c'  <- 272*(hi&7) + 17*lo + c'
+// Round 0 moves outputs 0..7 (read by waves 0-1), round 1 outputs 8..15 (waves 2-3).
+template <int MODE>
+__device__ __forceinline__ void exchange_cross(double2 (&v)[16], double2 *xbuf, const int wave, const int t)
+{
+    const int hi = t >> 4, lo = t & 15;
+    const int wbase = MODE ? 17 * lo + hi : t;
+    const int rbase = 272 * (hi & 7) + (MODE ? 17 * lo : lo);
+    prio_hi();
+    lds_barrier(); // buffer free: every wave is done with its previous (wave-local or shared) use
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        xbuf[272 * k + wbase] = v[P16(k)];
+    lds_barrier();
+    if (wave < 2) {
+        double2 w[16];
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+            w[e] = xbuf[rbase + (MODE ? e : 16 * e)];
+        lds_barrier();
+#pragma unroll
+        for (int k = 8; k < 16; k++)
+            xbuf[272 * (k - 8) + wbase] = v[P16(k)];
+        lds_barrier();
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+            v[e] = w[e];
+    } else {
+        lds_barrier();
+#pragma unroll
+        for (int k = 8; k < 16; k++)
+            xbuf[272 * (k - 8) + wbase] = v[P16(k)];
+        lds_barrier();
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+            v[e] = xbuf[rbase + (MODE ? e : 16 * e)];
+    }
+    prio_lo();
+}
+
+// Wave-local transpose among the sixteen lanes that share hi: lane (hi, lo) holds
+// outputs k = 0..15 (at v[P16(k)]) and receives input e = 0..15 of the lane-row's
+// output lo, i.e. value lo of lane (hi, e).  Two half rounds through the wave's
+// private quarter xw[0..544):
+//   writer: output k (round k>>3) -> 68*(k&7) + 17*hl + lo        (hl = hi & 3)
+//   reader: lane (hl, lo), lo>>3 == round, input e <- 68*(lo&7) + 17*hl + e
+// ds_write_b128 groups are 8 contiguous lanes (fixed hl, consecutive lo): 8 consecutive
+// 16-B slots.  ds_read_b128 groups hold, per round, 4 active lanes of one lane-row and 4
+// of the next: slots 4*(lo&7) + hl + e (mod 16) are distinct across them.
+// The half-lane reads are EXEC-masked inside one asm block: written as divergent C++
+// branches the receiving registers become a scratch array (548 B/lane).  The block ends
+// with s_waitcnt lgkmcnt(0), so its outputs are valid when it returns.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(3))) char *lds_ptr;
+#define MUSE_LDS_ADDR(p) ((unsigned)(unsigned long long)(lds_ptr)(p))
+#else
+#define MUSE_LDS_ADDR(p) 0u
+#endif
+__device__ __forceinline__ void exchange_local(double2 (&v)[16], double2 *xw, const int hl, const int lo)
+{
+    const int wbase = 17 * hl + lo;
+    const int rbase = 68 * (lo & 7) + 17 * hl;
+    prio_hi();
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        xw[68 * k + wbase] = v[P16(k)];
+    const unsigned waddr = MUSE_LDS_ADDR(xw + wbase), raddr = MUSE_LDS_ADDR(xw + rbase);
+    const unsigned long long first = __ballot(lo < 8); // lanes that read in round 0
+    d2v w[16], d[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        d[k].x = v[P16(8 + k)].x;
+        d[k].y = v[P16(8 + k)].y;
+    }
+    unsigned long long sv;
+    asm volatile("s_mov_b64 %[sv], exec\n\t"
+                 "s_and_b64 exec, %[sv], %[m]\n\t"
+                 "ds_read_b128 %[w0], %[ra]\n\t"
+                 "ds_read_b128 %[w1], %[ra] offset:16\n\t"
+                 "ds_read_b128 %[w2], %[ra] offset:32\n\t"
+                 "ds_read_b128 %[w3], %[ra] offset:48\n\t"
+                 "ds_read_b128 %[w4], %[ra] offset:64\n\t"
+                 "ds_read_b128 %[w5], %[ra] offset:80\n\t"
+                 "ds_read_b128 %[w6], %[ra] offset:96\n\t"
+                 "ds_read_b128 %[w7], %[ra] offset:112\n\t"
+                 "ds_read_b128 %[w8], %[ra] offset:128\n\t"
+                 "ds_read_b128 %[w9], %[ra] offset:144\n\t"
+                 "ds_read_b128 %[w10], %[ra] offset:160\n\t"
+                 "ds_read_b128 %[w11], %[ra] offset:176\n\t"
+                 "ds_read_b128 %[w12], %[ra] offset:192\n\t"
+                 "ds_read_b128 %[w13], %[ra] offset:208\n\t"
+                 "ds_read_b128 %[w14], %[ra] offset:224\n\t"
+                 "ds_read_b128 %[w15], %[ra] offset:240\n\t"
+                 "s_mov_b64 exec, %[sv]\n\t"
+                 "ds_write_b128 %[wa], %[d0]\n\t"
+                 "ds_write_b128 %[wa], %[d1] offset:1088\n\t"
+                 "ds_write_b128 %[wa], %[d2] offset:2176\n\t"
+                 "ds_write_b128 %[wa], %[d3] offset:3264\n\t"
+                 "ds_write_b128 %[wa], %[d4] offset:4352\n\t"
+                 "ds_write_b128 %[wa], %[d5] offset:5440\n\t"
+                 "ds_write_b128 %[wa], %[d6] offset:6528\n\t"
+                 "ds_write_b128 %[wa], %[d7] offset:7616\n\t"
+                 "s_andn2_b64 exec, %[sv], %[m]\n\t"
+                 "ds_read_b128 %[w0], %[ra]\n\t"
+                 "ds_read_b128 %[w1], %[ra] offset:16\n\t"
+                 "ds_read_b128 %[w2], %[ra] offset:32\n\t"
+                 "ds_read_b128 %[w3], %[ra] offset:48\n\t"
+                 "ds_read_b128 %[w4], %[ra] offset:64\n\t"
+                 "ds_read_b128 %[w5], %[ra] offset:80\n\t"
+                 "ds_read_b128 %[w6], %[ra] offset:96\n\t"
+                 "ds_read_b128 %[w7], %[ra] offset:112\n\t"
+                 "ds_read_b128 %[w8], %[ra] offset:128\n\t"
+                 "ds_read_b128 %[w9], %[ra] offset:144\n\t"
+                 "ds_read_b128 %[w10], %[ra] offset:160\n\t"
+                 "ds_read_b128 %[w11], %[ra] offset:176\n\t"
+                 "ds_read_b128 %[w12], %[ra] offset:192\n\t"
+                 "ds_read_b128 %[w13], %[ra] offset:208\n\t"
+                 "ds_read_b128 %[w14], %[ra] offset:224\n\t"
+                 "ds_read_b128 %[w15], %[ra] offset:240\n\t"
+                 "s_mov_b64 exec, %[sv]\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : [w0] "=&v"(w[0]), [w1] "=&v"(w[1]), [w2] "=&v"(w[2]), [w3] "=&v"(w[3]), [w4] "=&v"(w[4]),
+                   [w5] "=&v"(w[5]), [w6] "=&v"(w[6]), [w7] "=&v"(w[7]), [w8] "=&v"(w[8]), [w9] "=&v"(w[9]),
+                   [w10] "=&v"(w[10]), [w11] "=&v"(w[11]), [w12] "=&v"(w[12]), [w13] "=&v"(w[13]),
+                   [w14] "=&v"(w[14]), [w15] "=&v"(w[15]), [sv] "=&s"(sv)
+                 : [ra] "v"(raddr), [wa] "v"(waddr), [m] "s"(first), [d0] "v"(d[0]), [d1] "v"(d[1]), [d2] "v"(d[2]),
+                   [d3] "v"(d[3]), [d4] "v"(d[4]), [d5] "v"(d[5]), [d6] "v"(d[6]), [d7] "v"(d[7])
+                 : "memory", "scc");
+#pragma unroll
+    for (int e = 0; e < 16; e++)
+        v[e] = make_double2(w[e].x, w[e].y);
+    prio_lo();
+}
+
+// Twiddle passes.  With 168 registers (WPS 3) the first eight factors of a pass are requested
+// one phase EARLY -- before the transpose (or the row consumption) that precedes the pass -- and
+// the other seven right before the butterflies, so neither the L2 nor the LDS latency sits on
+// the wave's dependent chain (phase stamps: a twiddled pass cost 1.8-2.5k ticks against 0.95k
+// for the bare butterflies).  With 128 registers (WPS 4) there is no room to carry factors
+// across a transpose: four batches of four, two in flight.
+template <int WPS, typename F>
+__device__ __forceinline__ void tw_early(double2 (&ta)[8], F fetch)
+{
+    if (WPS < 4) {
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            ta[j] = fetch(1 + j);
+        fence();
+    }
+}
+template <int WPS, typename F>
+__device__ __forceinline__ void twiddle_pass(double2 (&v)[16], const double2 (&ta)[8], F fetch)
+{
+    if (WPS >= 4) {
+        dft16_twiddle_small(v, fetch);
+    } else {
+        double2 tb[7];
+#pragma unroll
+        for (int j = 0; j < 7; j++)
+            tb[j] = fetch(9 + j);
+        fence();
+        dft16(v);
+        fence();
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            v[P16(1 + j)] = cmul(v[P16(1 + j)], ta[j]);
+        fence();
+#pragma unroll
+        for (int j = 0; j < 7; j++)
+            v[P16(9 + j)] = cmul(v[P16(9 + j)], tb[j]);
+    }
+}
+
+// LDS record of one pair (one per parity): what the two result-writing lanes need
+// after the pair's transforms are over.
+//   [0, 24)  argmax partials: 6*wave + 3*series + {max |cc|, signed value, index}
+//   [24, 32) sum d^2 partials: 24 + 2*wave + series
+//   [32, 34) sum d per series (from the DC bin)
+//   [34]     first row of the pair as a double (exact below 2^53); < 0: nothing to write
+//   [35]     1.0 when the pair has a second row
+constexpr int REC = 36;
+
+// cross-wave argmax combine + variance + store (lanes 0 / 1, one series each);
+// returns true when the series' statistics are NaN/Inf (the pair must be redone)
+__device__ __forceinline__ bool finalize(const double *r, const int series, const double invN, const double invNm1,
+                                         double *mv_out, int *lag_out)
+{
+    double m[4], s[4], ix[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        m[w] = r[6 * w + 3 * series];
+        s[w] = r[6 * w + 3 * series + 1];
+        ix[w] = r[6 * w + 3 * series + 2];
+    }
+    const double s2 = (r[24 + series] + r[26 + series]) + (r[28 + series] + r[30 + series]);
+    const Stat st{r[32 + series], s2};
+    double best = m[0], bsv = s[0], bidx = ix[0];
+#pragma unroll
+    for (int w = 1; w < 4; w++) {
+        if (m[w] > best || (m[w] == best && ix[w] < bidx)) {
+            best = m[w];
+            bsv = s[w];
+            bidx = ix[w];
+        }
+    }
+    bool zero, nan;
+    const double var = variance(st, invN, invNm1, zero, nan);
+    const int idx = (best > 0.0) ? (int)bidx : 0; // nothing above 0: index 0, mv = cc[0]
+    double y = __builtin_amdgcn_rsq(var);
+    y = y * fma(-0.5 * var * y, y, 1.5);
+    y = y * fma(-0.5 * var * y, y, 1.5);
+    double mv = ((best > 0.0) ? bsv : s[0]) * y;
+    int lag = idx > 2048 ? idx - 4096 : idx;
+    if (zero) { mv = 0.0; lag = 0; }              // xcorr.go:166-167
+    if (nan) { mv = __builtin_nan(""); lag = 0; } // placeholder: the pair is redone
+    *mv_out = mv;
+    *lag_out = lag;
+    return nan;
+}
+
+} // namespace fast
+
+// WPS = waves per SIMD the register budget is set for: 3 (168 VGPRs: the next pair's rows are
+// requested before the last butterflies) or 4 (128 VGPRs: no room for the 64 prefetch registers
+// next to the butterflies, the rows are requested after the argmax and their latency is covered
+// by the other three workgroups on the CU only).
+template <int WPS, bool TIMING = false>
+__global__ __launch_bounds__(OCC_THREADS, WPS) void xcorr_fused_n4096_fast(const FusedParams p)
+{
+    using namespace occ4;
+    using namespace fast;
+    __shared__ double2 xbuf[OCC_XBUF];
+    __shared__ double2 tw2s[256];
+    __shared__ double red[2 * REC];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6); // wave-uniform by construction
+    const int hi = t >> 4, lo = t & 15;
+    double2 *const xw = xbuf + XW * wave;
+    const double invN = 1.0 / 4096.0, invNm1 = 1.0 / 4095.0;
+
+    tw2s[t] = p.tw2[t];
+    if (t < 2)
+        red[REC * (t) + 34] = -1.0; // no previous pair yet (either parity)
+    __syncthreads();
+    PhaseClock<TIMING> clk;
+    clk.start();
+
+    int parity = 0;
+    const long long total = p.npairs;
+    RawPair raw;
+    issue_row_loads<false>(raw, p, blockIdx.x < total ? (long long)blockIdx.x : 0ll, t, 0);
+
+    for (long long pair = blockIdx.x; pair < total; pair += gridDim.x) {
+        const long long rA = 2 * pair;
+        const bool hasB = rA + 1 < p.M;
+        double *const rec = red + REC * parity;
+        const double *const prec = red + REC * (parity ^ 1);
+        // ---- consume the prefetched rows: d = x - K (K = the row's first sample) bounds
+        // the cancellation in sum d^2 - (sum d)^2 / N and keeps a large level out of the
+        // transform's rounding; sum d itself is read off the DC bin below
+        double2 v[16], ta[8];
+        tw_early<WPS>(ta, Tw1Fetch{p.tw1, t}); // pass 1's first factors (L2) while the rows are consumed
+        {
+            const double KA = raw.ka, KB = raw.kb;
+            double qa = 0.0, qb = 0.0;
+            if (TIMING)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            clk.template stamp<0>();
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const double da = raw.a[i] - KA, db = raw.b[i] - KB;
+                v[i] = make_double2(da, db);
+                qa = fma(da, da, qa);
+                qb = fma(db, db, qb);
+            }
+            qa = wave_sum_dpp(qa);
+            qb = wave_sum_dpp(qb);
+            if (lane == 0) {
+                rec[24 + 2 * wave] = qa;
+                rec[24 + 2 * wave + 1] = qb;
+            }
+            if (t == 0) {
+                rec[34] = (double)rA;
+                rec[35] = hasB ? 1.0 : 0.0;
+            }
+        }
+        clk.template stamp<1>();
+        // ================= Z = FFT(dA + i dB) =================
+        // pass 1: DFT over a, twiddle W_4096^(k1 t)
+        twiddle_pass<WPS>(v, ta, Tw1Fetch{p.tw1, t});
+        clk.template stamp<2>();
+        tw_early<WPS>(ta, Tw2Fetch{tw2s, lo});
+        exchange_cross<0>(v, xbuf, wave, t);
+        // the previous pair's record is complete and visible: write its results
+        if (t < 2 && prec[34] >= 0.0 && (t == 0 || prec[35] != 0.0)) {
+            const long long row = (long long)prec[34] + t;
+            if (finalize(prec, t, invN, invNm1, p.mv + row, p.lag + row)) {
+                const int slot = atomicAdd(p.ovf_count, 1);
+                p.ovf_list[slot] = row >> 1;
+            }
+        }
+        clk.template stamp<3>();
+        // pass 2: DFT over b (k1 = hi, c = lo), twiddle W_256^(k2 c)
+        twiddle_pass<WPS>(v, ta, Tw2Fetch{tw2s, lo});
+        clk.template stamp<4>();
+        const auto xcl = [&](int j) { return ldg2(scalar_ptr_at(p.xcp, 256 * ((j + 1) & ~1)), t - 256 * (j & 1)); };
+        constexpr int XB = WPS >= 4 ? 4 : 8; // spectrum factors per batch (two batches in flight)
+        double2 xa[XB], xb[XB];
+        if (WPS < 4) { // the first spectrum factors (L2) travel during the transpose
+#pragma unroll
+            for (int j = 0; j < XB; j++)
+                xa[j] = xcl(j);
+            fence();
+        }
+        lds_barrier(); // waves 2-3 may still be reading this wave's quarter (round 1 above)
+        exchange_local(v, xw, hi & 3, lo);
+        clk.template stamp<5>();
+        // pass 3: DFT over c (k1 = hi, k2 = lo): f = hi + 16 lo + 256 k3; V = Z * conj(X)/n
+        double s1a, s1b;
+        {
+            if (WPS >= 4) {
+#pragma unroll
+                for (int j = 0; j < XB; j++)
+                    xa[j] = xcl(j);
+            } else {
+#pragma unroll
+                for (int j = 0; j < XB; j++)
+                    xb[j] = xcl(XB + j);
+            }
+            fence();
+            dft16(v);
+            fence();
+            if (WPS >= 4) {
+#pragma unroll
+                for (int j = 0; j < XB; j++)
+                    xb[j] = xcl(XB + j);
+            }
+            double2 w[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                w[k] = v[P16(k)];
+            // bin 0 (lane 0 of wave 0) = (sum dA, sum dB): kept in SGPRs until the record is
+            // written; the centred series' DC bin is exactly 0.  Branch-free on purpose: a
+            // divergent block here splits the schedule and the table loads get spilled.
+            s1a = readlane_f64(w[0].x, 0);
+            s1b = readlane_f64(w[0].y, 0);
+            w[0].x = (t == 0) ? 0.0 : w[0].x;
+            w[0].y = (t == 0) ? 0.0 : w[0].y;
+#pragma unroll
+            for (int b = 0; b < 16 / XB; b += 2) {
+#pragma unroll
+                for (int j = 0; j < XB; j++)
+                    v[b * XB + j] = cmul(w[b * XB + j], xa[j]);
+                fence();
+                if (b == 0)
+                    tw_early<WPS>(ta, Tw1Fetch{p.tw1p, t}); // second transform, pass 1 (L2)
+                if ((b + 2) * XB < 16) {
+#pragma unroll
+                    for (int j = 0; j < XB; j++)
+                        xa[j] = xcl((b + 2) * XB + j);
+                }
+#pragma unroll
+                for (int j = 0; j < XB; j++)
+                    v[(b + 1) * XB + j] = cmul(w[(b + 1) * XB + j], xb[j]);
+                fence();
+                if ((b + 3) * XB < 16) {
+#pragma unroll
+                    for (int j = 0; j < XB; j++)
+                        xb[j] = xcl((b + 3) * XB + j);
+                }
+            }
+        }
+        clk.template stamp<6>();
+        // ================= ccA + i ccB = FFT(V) (unscaled by 1/sigma) =================
+        // element f = 256 a' + 16 b' + c' with a' = k3 (register), b' = lo, c' = hi
+        // pass 1: DFT over a', twiddle W_4096^(m1 (16 lo + hi)) (lane-ordered table)
+        twiddle_pass<WPS>(v, ta, Tw1Fetch{p.tw1p, t});
+        clk.template stamp<7>();
+        tw_early<WPS>(ta, Tw2Fetch{tw2s, hi});
+        exchange_local(v, xw, hi & 3, lo); // (c' = hi, b' = lo) -> (c' = hi, m1 = lo): same wave
+        clk.template stamp<8>();
+        // pass 2: DFT over b', twiddle W_256^(m2 c'), c' = hi
+        twiddle_pass<WPS>(v, ta, Tw2Fetch{tw2s, hi});
+        clk.template stamp<9>();
+        exchange_cross<1>(v, xbuf, wave, t);
+        clk.template stamp<10>();
+        // pass 3: DFT over c' (m1 = lo, m2 = hi): index t + 256 m3.  The next pair's rows
+        // are requested first: they stay in flight during the butterflies and the argmax.
+        {
+            long long nxt = pair + gridDim.x; // last iteration: pair 0 (L2-resident dummy)
+            nxt = nxt < total ? nxt : 0;
+            fence();
+            if (WPS < 4)
+                issue_row_loads<false>(raw, p, nxt, t, 0);
+            fence();
+            dft16(v);
+            double2 w[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                w[k] = v[P16(k)];
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                v[k] = w[k];
+        }
+        clk.template stamp<11>();
+        // ---- maxAbsIndex (xcorr.go:39-50), as in xcorr_r16_occ4.hip
+        double ma = 0.0, mb = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            ma = fmax(ma, fabs(v[k].x));
+            mb = fmax(mb, fabs(v[k].y));
+        }
+        const double wa = wave_max_dpp(ma), wb = wave_max_dpp(mb);
+        int widxA = 0x7fffffff, widxB = 0x7fffffff;
+        double svA = 0.0, svB = 0.0;
+        {
+            unsigned long long selA = 0ull, selB = 0ull;
+            int kA = 0, kB = 0, hiA = 0, hiB = 0;
+#pragma unroll
+            for (int k = 15; k >= 0; k--) { // descending: the lowest k is selected last
+                const unsigned long long mA_ = __ballot(fabs(v[k].x) == wa);
+                const unsigned long long mB_ = __ballot(fabs(v[k].y) == wb);
+                const bool hA = mA_ != 0ull, hB = mB_ != 0ull; // wave-uniform
+                selA = hA ? mA_ : selA;
+                kA = hA ? k : kA;
+                hiA = hA ? __double2hiint(v[k].x) : hiA;
+                selB = hB ? mB_ : selB;
+                kB = hB ? k : kB;
+                hiB = hB ? __double2hiint(v[k].y) : hiB;
+            }
+            if (wa > 0.0 && selA != 0ull) {
+                const int l = __ffsll((long long)selA) - 1;
+                widxA = wave * 64 + l + 256 * kA;
+                svA = (__builtin_amdgcn_readlane(hiA, l) < 0) ? -wa : wa;
+            }
+            if (wb > 0.0 && selB != 0ull) {
+                const int l = __ffsll((long long)selB) - 1;
+                widxB = wave * 64 + l + 256 * kB;
+                svB = (__builtin_amdgcn_readlane(hiB, l) < 0) ? -wb : wb;
+            }
+        }
+        const double cc0a = v[0].x, cc0b = v[0].y;
+        if (WPS >= 4) {
+            long long nxt = pair + gridDim.x;
+            nxt = nxt < total ? nxt : 0;
+            fence();
+            issue_row_loads<false>(raw, p, nxt, t, 0);
+            fence();
+        }
+        if (lane == 0) { // {max |cc|, signed value (cc[0] when nothing is above 0), index}
+            double *ra_ = rec + 6 * wave;
+            ra_[0] = widxA == 0x7fffffff ? 0.0 : wa;
+            ra_[1] = widxA == 0x7fffffff ? cc0a : svA; // wave 0 lane 0 holds cc[0]
+            ra_[2] = (double)widxA;
+            ra_[3] = widxB == 0x7fffffff ? 0.0 : wb;
+            ra_[4] = widxB == 0x7fffffff ? cc0b : svB;
+            ra_[5] = (double)widxB;
+            if (wave == 0) {
+                rec[32] = s1a;
+                rec[33] = s1b;
+            }
+        }
+        parity ^= 1;
+        clk.template stamp<12>();
+    }
+    lds_barrier();
+    {
+        const double *const prec = red + REC * (parity ^ 1);
+        if (t < 2 && prec[34] >= 0.0 && (t == 0 || prec[35] != 0.0)) {
+            const long long row = (long long)prec[34] + t;
+            if (finalize(prec, t, invN, invNm1, p.mv + row, p.lag + row)) {
+                const int slot = atomicAdd(p.ovf_count, 1);
+                p.ovf_list[slot] = row >> 1;
+            }
+        }
+    }
+    if (TIMING && p.dbg && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NPHASE; i++)
+            p.dbg[((long long)blockIdx.x * 4 + wave) * NPHASE + i] = clk.acc[i];
+    }
+}
+
+// N == n == 4096 only; p.ovf_count must be zeroed and p.ovf_list hold 2*npairs entries
+hipError_t launch_fused_fast(const FusedParams &p, int num_cus, hipStream_t stream)
+{
+    long long grid = p.npairs;
+    int mult = 16; // see launch_fused_occ4
+    if (const char *m = getenv("MUSE_HIP_GRID_MULT"))
+        mult = atoi(m) > 0 ? atoi(m) : mult;
+    // 4 waves/SIMD (128 VGPRs, late row request) measured 10.7-10.9 ms per 1 M series against
+    // 11.0-11.1 ms for the 3-wave build with the early row request (same box, interleaved)
+    int wps = 4;
+    if (const char *w = getenv("MUSE_HIP_FAST_WPS")) // tuning aid
+        wps = atoi(w) == 3 ? 3 : 4;
+    const long long cap = (long long)num_cus * wps * mult;
+    if (grid > cap)
+        grid = cap;
+    if (wps == 4)
+        hipLaunchKernelGGL((xcorr_fused_n4096_fast<4, false>), dim3((unsigned)grid), dim3(OCC_THREADS), 0, stream, p);
+    else
+        hipLaunchKernelGGL((xcorr_fused_n4096_fast<3, false>), dim3((unsigned)grid), dim3(OCC_THREADS), 0, stream, p);
+    return hipGetLastError();
+}
+
+} // namespace muse

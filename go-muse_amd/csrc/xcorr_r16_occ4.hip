@@ -27,170 +27,11 @@
 #include <stdint.h>
 #include <stdlib.h>
 
-#include "fft_device.h"
-#include "xcorr_kernels.h"
+#include "r16_device.h"
 
 namespace muse {
 
-constexpr int OCC_THREADS = 256;
-constexpr int OCC_XBUF = 8 * 272; // double2 elements: 34,816 B
-
 namespace occ4 {
-
-__device__ __forceinline__ void fence() { __builtin_amdgcn_sched_barrier(0); }
-// LDS-only barrier (does not drain outstanding global loads)
-__device__ __forceinline__ void lds_barrier()
-{
-    fence();
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    fence();
-}
-// a wave-uniform double moved to SGPRs (frees two VGPRs per value)
-__device__ __forceinline__ double uniform(double v)
-{
-    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
-    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
-    return __hiloint2double(hi, lo);
-}
-// The result is an address_space(1) (global) pointer on purpose: laundering a
-// generic pointer through the asm loses the address space and every load through
-// it becomes flat_load, which counts on lgkmcnt as well -- the LDS-only barrier
-// (s_waitcnt lgkmcnt(0)) would then drain the prefetch.
-#if defined(__HIP_DEVICE_COMPILE__)
-template <typename T>
-using gptr = const T __attribute__((address_space(1))) *;
-#else
-template <typename T>
-using gptr = const T *; // host pass only parses this file
-#endif
-typedef double d2v __attribute__((ext_vector_type(2)));
-template <typename T>
-__device__ __forceinline__ gptr<T> scalar_ptr(const T *p)
-{
-    unsigned long long u = (unsigned long long)p;
-    asm volatile("" : "+s"(u));
-    return (gptr<T>)u;
-}
-// 16-byte global load of one complex value (native vector type: HIP's double2
-// struct cannot be copied out of an address_space(1) reference)
-__device__ __forceinline__ double2 ldg2(gptr<double2> p, int i)
-{
-    const d2v x = ((gptr<d2v>)p)[i];
-    return make_double2(x.x, x.y);
-}
-
-// One LDS transpose in two half rounds through the 8 x 272 buffer (positions in
-// double2 units).  Layouts (same bank analysis as xcorr_kernels.hip):
-//   A: writer (b = hi, c = lo) output k1 -> 272*(k1&7) + t
-//      reader (k1 = hi, c = lo) input b  <- 272*(hi&7) + 16*b + lo
-//   B: writer (k1 = hi, c = lo) output k2 -> 272*(k2&7) + 17*hi + lo
-//      reader (k1 = lo, k2 = hi) input c <- 272*(hi&7) + 17*lo + c
-// Round 0 moves outputs 0..7 (read by waves 0-1, whose hi is 0..7), round 1
-// outputs 8..15 (waves 2-3).  `wave` is an SGPR, so the two paths are scalar
-// branches with disjoint live ranges; both execute the same four barriers.
-template <bool B>
-__device__ __forceinline__ void exchange(double2 (&v)[16], double2 *xbuf, const int wave, const int t)
-{
-    const int hi = t >> 4, lo = t & 15;
-    const int wbase = B ? 17 * hi + lo : t;
-    const int rbase = 272 * (hi & 7) + (B ? 17 * lo : lo);
-    lds_barrier(); // buffer free: the previous transpose's last readers are done
-#pragma unroll
-    for (int k = 0; k < 8; k++)
-        xbuf[272 * k + wbase] = v[P16(k)];
-    lds_barrier();
-    if (wave < 2) {
-        double2 w[16];
-#pragma unroll
-        for (int e = 0; e < 16; e++)
-            w[e] = xbuf[rbase + (B ? e : 16 * e)];
-        lds_barrier();
-#pragma unroll
-        for (int k = 8; k < 16; k++)
-            xbuf[272 * (k - 8) + wbase] = v[P16(k)];
-        lds_barrier();
-#pragma unroll
-        for (int e = 0; e < 16; e++)
-            v[e] = w[e];
-    } else {
-        lds_barrier();
-#pragma unroll
-        for (int k = 8; k < 16; k++)
-            xbuf[272 * (k - 8) + wbase] = v[P16(k)];
-        lds_barrier();
-#pragma unroll
-        for (int e = 0; e < 16; e++)
-            v[e] = xbuf[rbase + (B ? e : 16 * e)];
-    }
-}
-
-// 16-point DFT followed by 15 twiddle multiplies whose factors are fetched by
-// `fetch(k)` (k = 1..15) in two batches; the first batch is issued BEFORE the
-// butterflies and the second before the first is consumed, so the fetch latency
-// (L2 or LDS) overlaps arithmetic instead of adding to the dependent chain.
-template <typename F>
-__device__ __forceinline__ void dft16_twiddle(double2 (&v)[16], F fetch)
-{
-    double2 ta[8], tb[7];
-#pragma unroll
-    for (int j = 0; j < 8; j++)
-        ta[j] = fetch(1 + j);
-    fence();
-    dft16(v);
-    fence();
-#pragma unroll
-    for (int j = 0; j < 7; j++)
-        tb[j] = fetch(9 + j);
-#pragma unroll
-    for (int j = 0; j < 8; j++)
-        v[P16(1 + j)] = cmul(v[P16(1 + j)], ta[j]);
-    fence();
-#pragma unroll
-    for (int j = 0; j < 7; j++)
-        v[P16(9 + j)] = cmul(v[P16(9 + j)], tb[j]);
-}
-
-struct Tw1Fetch {
-    gptr<double2> p;
-    int t;
-    __device__ __forceinline__ double2 operator()(int k) const { return ldg2(p, k * 256 + t); }
-};
-struct Tw2Fetch {
-    const double2 *p;
-    int lo;
-    __device__ __forceinline__ double2 operator()(int k) const { return p[k * 16 + lo]; }
-};
-
-// The next pair's rows, prefetched into registers: element t + 256*i of the two
-// (zero-padded) rows plus each row's first sample.
-struct RawPair {
-    double a[16], b[16];
-    double ka, kb;
-};
-// Unconditional coalesced nontemporal loads (a conditional prefetch parks `raw`
-// in scratch; a per-element `if` serialises the loads): the caller clamps `pair`.
-template <bool PADDED>
-__device__ __forceinline__ void issue_row_loads(RawPair &r, const FusedParams &p, long long pair, int t, int pad)
-{
-    const long long rA = 2 * pair;
-    const long long rB = (rA + 1 < p.M) ? rA + 1 : rA;
-    const gptr<double> ra = scalar_ptr(p.rows + rA * p.stride);
-    const gptr<double> rb = scalar_ptr(p.rows + rB * p.stride);
-    r.ka = ra[0];
-    r.kb = rb[0];
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-        if (PADDED) {
-            int j = t + 256 * i - pad;
-            j = j < 0 ? 0 : j; // clamped: always load, the value is masked later
-            r.a[i] = __builtin_nontemporal_load(ra + j);
-            r.b[i] = __builtin_nontemporal_load(rb + j);
-        } else {
-            r.a[i] = __builtin_nontemporal_load(ra + 256 * i + t);
-            r.b[i] = __builtin_nontemporal_load(rb + 256 * i + t);
-        }
-    }
-}
 
 // forward FFT: v[a] = x[t + 256 a] -> v[a] = X[t + 256 a].  With MULXC the
 // result is multiplied by xc[t + 256 a] (the batch's conj(X)/n table); those 16
@@ -206,7 +47,7 @@ __device__ __forceinline__ void fft4096(double2 (&v)[16], double2 *xbuf, const d
                                         RawPair &raw, const FusedParams &p, long long next_pair, int pad)
 {
     // pass 1: DFT over a, twiddle W_4096^(k1 t) (L2-resident table)
-    dft16_twiddle(v, Tw1Fetch{scalar_ptr(tw1g), t});
+    dft16_twiddle(v, Tw1Fetch{tw1g, t});
     clk.template stamp<P0>();
     exchange<false>(v, xbuf, wave, t);
     clk.template stamp<P0 + 1>();
@@ -217,17 +58,16 @@ __device__ __forceinline__ void fft4096(double2 (&v)[16], double2 *xbuf, const d
     clk.template stamp<P0 + 3>();
     // pass 3: DFT over c (k1 = lo, k2 = hi): f = t + 256 k3
     if (MULXC) {
-        const gptr<double2> xcp = scalar_ptr(xcg);
         double2 xa[8], xb[8];
 #pragma unroll
         for (int j = 0; j < 8; j++)
-            xa[j] = ldg2(xcp, 256 * j + t);
+            xa[j] = ldg2(scalar_ptr_at(xcg, 256 * ((j + 1) & ~1)), t - 256 * (j & 1));
         fence();
         dft16(v);
         fence();
 #pragma unroll
         for (int j = 0; j < 8; j++)
-            xb[j] = ldg2(xcp, 256 * (8 + j) + t);
+            xb[j] = ldg2(scalar_ptr_at(xcg, 256 * ((9 + j) & ~1)), t - 256 * (j & 1));
         double2 w[16];
 #pragma unroll
         for (int k = 0; k < 16; k++)
@@ -257,24 +97,6 @@ __device__ __forceinline__ void fft4096(double2 (&v)[16], double2 *xbuf, const d
             v[k] = w[k];
     }
     clk.template stamp<P0 + 4>();
-}
-
-// shifted sums of one series: sum d, sum d^2  (d = x - x[0])
-struct Stat {
-    double s1, s2;
-};
-
-// zNormalize constants (xcorr.go:84-95 via the centred sample variance):
-// variance from the shifted sums; flags for the (nil,0,0) and NaN outcomes.
-__device__ __forceinline__ double variance(const Stat &s, double invN, double invNm1, bool &zero, bool &nan)
-{
-    const double var = (s.s2 - s.s1 * s.s1 * invN) * invNm1;
-    // NaN or +-Inf statistics: every cc is NaN in the reference.  (Not `var - var != 0`:
-    // under fp-contract the compiler fuses var's multiply into the subtraction and
-    // the rounding residual makes it true for finite values.)
-    nan = !__builtin_isfinite(var);
-    zero = !nan && !(var > 0.0);  // sigma == 0 (rounding may leave -0 / a tiny negative)
-    return var;
 }
 
 // cross-wave combine of one series' argmax + result store (threads 0 / 1 only):

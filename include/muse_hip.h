@@ -76,8 +76,10 @@ int muse_ctx_device_info(muse_ctx *ctx, char *name, int32_t name_cap,
  * n == 4096, generic LDS radix-2 kernel otherwise), 1 = force the generic
  * kernel; forcing one n = 4096 kernel: 2 = first (simple) fp64 kernel,
  * 5 = register-prefetch pipeline, 6 / 7 = half-round transposes at 4 / 3
- * waves per SIMD (7 is what auto picks), 8 = fp32 screening + exact fp64
- * re-evaluation (experimental), 9 = 512-thread radix-8 (experimental).
+ * waves per SIMD (7 is what auto picks when N < n = 4096), 8 = fp32 screening
+ * + exact fp64 re-evaluation (experimental), 9 = 512-thread radix-8
+ * (experimental), 10 = wave-local transposes + deferred statistics (what auto
+ * picks when N == 4096; other N fall back to 7).
  * The parity tests run every variant on the same inputs; the environment
  * variable MUSE_HIP_KERNEL sets the initial value (profiling aid). */
 int muse_ctx_set_kernel(muse_ctx *ctx, int32_t variant);

@@ -266,7 +266,7 @@ def test_every_kernel_variant_matches_oracle(muse, eng, oracle, N):
     assert db.n == 4096
     olag, omv, gap = oracle.batch_scores(ref, rows)
     try:
-        for variant in (0, 1, 2, 5, 6, 7, 8, 9):
+        for variant in (0, 1, 2, 5, 6, 7, 8, 9, 10):
             eng.set_kernel(variant)
             lag, mv = db.scores()
             assert math.isnan(mv[10]) and lag[10] == 0 and math.isnan(mv[12]) and lag[12] == 0, variant
