@@ -58,6 +58,9 @@ def main():
     ap.add_argument("--top-n", type=int, default=20)
     ap.add_argument("--max-lag", type=int, default=15)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--many-refs", type=int, default=8,
+                    help="also time muse_batch_run_many with this many references (N=1 only; 0 = skip); "
+                         "reported as an extra object, never as `value`")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the RCCL gather path even with one rank (rehearsal on a 1-GPU box)")
     args = ap.parse_args()
@@ -149,6 +152,23 @@ def main():
             "achieved_hbm_gbps_whole_step": value / n_gpus * (8 * N + 16) / 1e9,
             "top_score": float(out[2][0]) if len(out[2]) else None,
         }
+        if n_gpus == 1 and args.many_refs > 1 and db.n == 4096 and N == 4096:
+            # R references against the same resident group in one pass over the rows
+            R = args.many_refs
+            refs = [ref] + [dg.read(997 * r + 1, 1)[0] for r in range(1, R)]
+            bs = [db] + [pkg.DeviceBatch(eng, dg, x) for x in refs[1:]]
+            pkg.run_many(bs, None, 0, args.max_lag, args.top_n, 0.0, 0, True)
+            eng.synchronize()
+            t1 = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                pkg.run_many(bs, None, 0, args.max_lag, args.top_n, 0.0, 0, True)
+            eng.synchronize()
+            dtm = (time.perf_counter() - t1) / reps
+            line["many_references"] = {"references": R, "value": R * float(M) / dtm, "unit": "series-pairs/s",
+                                       "ms_per_run": dtm * 1e3,
+                                       "note": "muse_batch_run_many: one pass over the rows for all references"}
+            del bs
         if n_gpus == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(dg, ref, N)
         print(json.dumps(line), flush=True)

@@ -66,6 +66,10 @@ SIGNATURES = {
     "muse_batch_run_shard": (ctypes.c_int, [_vp, _i32p, _i32, _i64, _i32, _i32, _f64, _i32, _i32,
                                             _recp, _i32p]),
     "muse_merge_records": (ctypes.c_int, [_recp, _i64, _i32, _i64p, _i32p, _dp, _i32p, _dp]),
+    "muse_batch_score_many": (ctypes.c_int, [ctypes.POINTER(_vp), _i32]),
+    "muse_batch_read_scores": (ctypes.c_int, [_vp, _i32p, _dp]),
+    "muse_batch_run_many": (ctypes.c_int, [ctypes.POINTER(_vp), _i32, _i32p, _i32, _i32, _i32, _f64, _i32, _i32,
+                                           _i64p, _i32p, _dp, _i32p, _dp]),
     "muse_batch_free": (ctypes.c_int, [_vp]),
     "muse_xcorr_with_x": (ctypes.c_int, [_vp, _dp, _dp, _i32, _i32, _dp, _i32p, _dp, _i32p]),
     "muse_xcorr": (ctypes.c_int, [_vp, _dp, _i32, _dp, _i32, _i32, _i32, _dp, _i32p, _dp, _i32p]),

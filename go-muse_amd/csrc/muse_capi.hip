@@ -79,6 +79,13 @@ struct muse_ctx {
     char name[64] = {0};
     double2 *tw1 = nullptr, *tw2 = nullptr, *twm = nullptr, *tw1w8 = nullptr, *tw1p = nullptr;
     float2 *tw1f = nullptr, *tw2f = nullptr; // fp32 copies for the screening kernel
+    // many-reference pass (muse_batch_score_many): parked spectra + device pointer tables
+    double2 *zscratch = nullptr;
+    int *zbusy = nullptr;
+    int zslots = 0;
+    void *many_tab = nullptr; // R x {xcp, mv, lag} pointers
+    std::vector<void *> many_host; // host image of many_tab (outlives the asynchronous copy)
+    int many_cap = 0;
     double screen_delta = 1e-4;
     int variant = 0;
     bool timing = false;
@@ -239,6 +246,9 @@ static void ctx_release(muse_ctx *ctx)
     (void)hipFree(ctx->tw1f);
     (void)hipFree(ctx->tw1w8);
     (void)hipFree(ctx->tw1p);
+    (void)hipFree(ctx->zscratch);
+    (void)hipFree(ctx->zbusy);
+    (void)hipFree(ctx->many_tab);
     (void)hipFree(ctx->tw2f);
     if (ctx->stream)
         (void)hipStreamDestroy(ctx->stream);
@@ -681,23 +691,11 @@ static int ensure_scores(muse_batch *b)
     return MUSE_OK;
 }
 
-extern "C" int muse_batch_score(muse_batch *b)
+// the launch parameters every fused kernel shares for batch b (group flushed, M > 0, scores allocated)
+static FusedParams base_params(muse_batch *b)
 {
-    if (!b)
-        return fail(MUSE_ERR_INVALID, "NULL batch");
     muse_ctx *ctx = b->ctx;
-    int rc = use_device(ctx);
-    if (rc)
-        return rc;
-    rc = group_flush(b->g); // rows still in the staging buffer are uploaded ahead of the kernel
-    if (rc)
-        return rc;
     const int64_t M = b->g->M;
-    if (M == 0)
-        return MUSE_OK;
-    rc = ensure_scores(b);
-    if (rc)
-        return rc;
     FusedParams p{};
     p.rows = b->g->rows;
     p.M = M;
@@ -724,6 +722,27 @@ extern "C" int muse_batch_score(muse_batch *b)
     p.xcf = b->xcf;
     p.xs = b->xs;
     p.screen_delta = ctx->screen_delta;
+    return p;
+}
+
+extern "C" int muse_batch_score(muse_batch *b)
+{
+    if (!b)
+        return fail(MUSE_ERR_INVALID, "NULL batch");
+    muse_ctx *ctx = b->ctx;
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    rc = group_flush(b->g); // rows still in the staging buffer are uploaded ahead of the kernel
+    if (rc)
+        return rc;
+    const int64_t M = b->g->M;
+    if (M == 0)
+        return MUSE_OK;
+    rc = ensure_scores(b);
+    if (rc)
+        return rc;
+    FusedParams p = base_params(b);
     // kernel selection: ctx->variant 0 = auto; 1 = generic LDS radix-2; 2, 5..10 force one
     // of the n = 4096 kernels (parity tests run every one of them on the same inputs)
     int variant = KERNEL_GENERIC;
@@ -920,7 +939,7 @@ static int ensure_select_ws(muse_batch *b, int64_t M, int64_t G, bool with_gid, 
 
 static int run_select(muse_batch *b, const int32_t *group_id, int32_t G_in, int64_t series_offset, int32_t max_lag,
                       int32_t top_n, double threshold, int32_t sign_filter, int32_t abs_scores,
-                      std::vector<muse_record> &out)
+                      std::vector<muse_record> &out, bool already_scored = false)
 {
     out.clear();
     muse_ctx *ctx = b->ctx;
@@ -930,7 +949,7 @@ static int run_select(muse_batch *b, const int32_t *group_id, int32_t G_in, int6
     if (group_id && G_in < 0)
         return fail(MUSE_ERR_INVALID, "negative group count");
     // Batch.Run re-scores on every call (muse_batch.go:116-122)
-    int rc = muse_batch_score(b);
+    int rc = already_scored ? MUSE_OK : muse_batch_score(b);
     if (rc)
         return rc;
     const int64_t G = group_id ? (int64_t)G_in : M;
@@ -1043,6 +1062,151 @@ extern "C" int muse_batch_run_shard(muse_batch *b, const int32_t *group_id, int3
     for (size_t i = 0; i < sel.size(); i++)
         out_records[i] = sel[i];
     *out_count = (int32_t)sel.size();
+    return MUSE_OK;
+}
+
+// -------------------------------------------------------- many references
+extern "C" int muse_batch_read_scores(muse_batch *b, int32_t *lag, double *mv)
+{
+    if (!b)
+        return fail(MUSE_ERR_INVALID, "NULL batch");
+    int rc = use_device(b->ctx);
+    if (rc)
+        return rc;
+    const int64_t M = b->g->M;
+    if (M == 0)
+        return MUSE_OK;
+    if (!lag || !mv)
+        return fail(MUSE_ERR_INVALID, "NULL output");
+    if (M > b->score_cap)
+        return fail(MUSE_ERR_INVALID, "the batch has not been scored since the group grew");
+    HIP_TRY(hipMemcpyAsync(lag, b->lag, (size_t)M * sizeof(int), hipMemcpyDeviceToHost, b->ctx->stream));
+    HIP_TRY(hipMemcpyAsync(mv, b->mv, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, b->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    return MUSE_OK;
+}
+
+extern "C" int muse_batch_score_many(muse_batch *const *bs, int32_t R)
+{
+    if (!bs || R < 1)
+        return fail(MUSE_ERR_INVALID, "bad batch list");
+    for (int r = 0; r < R; r++) {
+        if (!bs[r])
+            return fail(MUSE_ERR_INVALID, "NULL batch in list");
+        if (bs[r]->ctx != bs[0]->ctx || bs[r]->g != bs[0]->g)
+            return fail(MUSE_ERR_INVALID, "batches of one pass must share the context and the comparison group");
+        for (int q = 0; q < r; q++)
+            if (bs[q] == bs[r])
+                return fail(MUSE_ERR_INVALID, "the same batch appears twice in the list");
+    }
+    muse_batch *b0 = bs[0];
+    muse_ctx *ctx = b0->ctx;
+    // the one-pass kernel is built for N == n == 4096 (and is only taken under automatic kernel
+    // selection); everything else scores the batches one after the other
+    if (R == 1 || b0->n != 4096 || b0->N != 4096 || (ctx->variant != 0 && ctx->variant != 10)) {
+        for (int r = 0; r < R; r++) {
+            int rc = muse_batch_score(bs[r]);
+            if (rc)
+                return rc;
+        }
+        return MUSE_OK;
+    }
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    rc = group_flush(b0->g);
+    if (rc)
+        return rc;
+    const int64_t M = b0->g->M;
+    if (M == 0)
+        return MUSE_OK;
+    for (int r = 0; r < R; r++) {
+        rc = ensure_scores(bs[r]);
+        if (rc)
+            return rc;
+    }
+    if (!ctx->zscratch) {
+        const int slots = ctx->num_cus * 4 * 2; // twice the resident workgroups: short probe sequences
+        HIP_TRY(hipMalloc(&ctx->zscratch, (size_t)slots * 4096 * sizeof(double2)));
+        HIP_TRY(hipMalloc(&ctx->zbusy, (size_t)slots * sizeof(int)));
+        ctx->zslots = slots;
+    }
+    if (R > ctx->many_cap) {
+        (void)hipFree(ctx->many_tab);
+        ctx->many_tab = nullptr;
+        ctx->many_cap = 0;
+        HIP_TRY(hipMalloc(&ctx->many_tab, (size_t)R * 3 * sizeof(void *)));
+        ctx->many_cap = R;
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream)); // the previous pass may still be reading the host image
+    std::vector<void *> &tab = ctx->many_host;
+    tab.assign((size_t)R * 3, nullptr);
+    for (int r = 0; r < R; r++) {
+        tab[(size_t)r] = bs[r]->xcp;
+        tab[(size_t)R + r] = bs[r]->mv;
+        tab[(size_t)2 * R + r] = bs[r]->lag;
+    }
+    HIP_TRY(hipMemcpyAsync(ctx->many_tab, tab.data(), tab.size() * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
+    FusedParams p = base_params(b0);
+    p.R = R;
+    p.xcp_many = (const double2 *const *)ctx->many_tab;
+    p.mv_many = (double *const *)((void **)ctx->many_tab + R);
+    p.lag_many = (int *const *)((void **)ctx->many_tab + 2 * R);
+    p.zscratch = ctx->zscratch;
+    p.zbusy = ctx->zbusy;
+    p.zslots = ctx->zslots;
+    if (2 * p.npairs > b0->ovf_cap) {
+        (void)hipFree(b0->ovf_list);
+        b0->ovf_list = nullptr;
+        b0->ovf_cap = 0;
+        HIP_TRY(hipMalloc(&b0->ovf_list, (size_t)(2 * p.npairs) * sizeof(long long)));
+        b0->ovf_cap = 2 * p.npairs;
+    }
+    p.ovf_count = b0->ovf_count;
+    p.ovf_list = b0->ovf_list;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ctx->timing) {
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, ctx->stream));
+    }
+    HIP_TRY(hipMemsetAsync(b0->ovf_count, 0, sizeof(int), ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->zbusy, 0, (size_t)ctx->zslots * sizeof(int), ctx->stream));
+    HIP_TRY(launch_fused_multi(p, ctx->num_cus, ctx->stream));
+    // pairs holding a NaN/Inf series (listed once, by reference 0): redone per reference by the
+    // kernel that isolates the dead series before the shared transform
+    for (int r = 0; r < R; r++) {
+        FusedParams q = base_params(bs[r]);
+        q.pair_list = b0->ovf_list;
+        q.pair_count = b0->ovf_count;
+        q.npairs = std::min<long long>(q.npairs, 64);
+        HIP_TRY(launch_fused(q, KERNEL_R16_OCC3, ctx->num_cus, ctx->stream));
+    }
+    if (ctx->timing) {
+        HIP_TRY(hipEventRecord(e1, ctx->stream));
+        ctx->events.emplace_back(e0, e1);
+    }
+    return MUSE_OK;
+}
+
+extern "C" int muse_batch_run_many(muse_batch *const *bs, int32_t R, const int32_t *group_id, int32_t G,
+                                   int32_t max_lag, int32_t top_n, double threshold, int32_t sign_filter,
+                                   int32_t abs_scores, int64_t *out_series, int32_t *out_lag, double *out_score,
+                                   int32_t *out_count, double *out_mean_abs)
+{
+    int rc = muse_batch_score_many(bs, R);
+    if (rc)
+        return rc;
+    const size_t cap = (size_t)std::max(top_n, 0);
+    for (int r = 0; r < R; r++) {
+        std::vector<muse_record> sel;
+        rc = run_select(bs[r], group_id, G, 0, max_lag, top_n, threshold, sign_filter, abs_scores, sel, true);
+        if (rc)
+            return rc;
+        emit(sel, out_series ? out_series + cap * r : nullptr, out_lag ? out_lag + cap * r : nullptr,
+             out_score ? out_score + cap * r : nullptr, out_count ? out_count + r : nullptr,
+             out_mean_abs ? out_mean_abs + r : nullptr);
+    }
     return MUSE_OK;
 }
 

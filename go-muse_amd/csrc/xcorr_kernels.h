@@ -25,6 +25,14 @@ struct FusedParams {
     const double2 *tw1w8; // [8][512]  W_4096^(k*t)      (radix-8 kernel)
     const double2 *tw1p; // [16][256] W_4096^(k*(16*(t&15) + (t>>4)))   (xcorr_r16_fast.hip, second transform)
     const double2 *xcp;  // [16][256] xc[256*k + (t>>4) + 16*(t&15)]     (xcorr_r16_fast.hip: xc in lane order)
+    // many references in one pass (xcorr_fused_n4096_multi): device arrays of R pointers
+    int R;
+    const double2 *const *xcp_many; // R lane-ordered spectrum tables
+    double *const *mv_many;         // R result vectors (M doubles each)
+    int *const *lag_many;           // R lag vectors (M ints each)
+    double2 *zscratch;              // zslots x 4096 complex: one parked spectrum per running workgroup
+    int *zbusy;                     // zslots flags, zeroed before the launch
+    int zslots;
     const double2 *twm;  // [32768]   W_65536^k         (generic kernel; half period)
     double2 *gscratch;   // n > 8192: one n-element complex work buffer per workgroup (global, L2-resident)
     double *mv;          // out: M signed max values
@@ -51,6 +59,7 @@ hipError_t launch_fused_occ4(const FusedParams &p, int num_cus, int waves_per_si
 hipError_t launch_fused_screen(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_r16_screen.hip
 hipError_t launch_fused_w8(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_r8_w8.hip
 hipError_t launch_fused_fast(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_r16_fast.hip (N == n == 4096)
+hipError_t launch_fused_multi(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_r16_fast.hip (R references)
 // out[256 k + t] = in[256 k + (t >> 4) + 16 (t & 15)], k < 16: a 4096-entry table in the lane order of xcorr_r16_fast.hip
 hipError_t launch_lane_order(const double2 *in, double2 *out, hipStream_t stream);
 hipError_t launch_ref_spectrum(const double *ref_dev, int N, int n, int logn, int normalize, double x_scale,

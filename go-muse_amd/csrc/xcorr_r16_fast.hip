@@ -547,6 +547,365 @@ __global__ __launch_bounds__(OCC_THREADS, WPS) void xcorr_fused_n4096_fast(const
     }
 }
 
+// ============================================================================
+// Many references against one resident group in ONE pass over the rows
+// (the README use case iterates references over a fixed set of
+// series).  Each pair of series is read from HBM and forward-transformed once; its
+// spectrum Z (DC bin zeroed) is parked in a 64 KB per-workgroup slice of a global
+// scratch buffer (L2 / Infinity-Cache resident: every lane re-reads exactly the
+// addresses it wrote) and re-loaded for references 1..R-1, each of which costs one
+// spectrum multiply, one transform and one argmax.  Per (series, reference) that is
+// (1 + R) / (2 R) of the single-reference transform work and 1/R of the HBM bytes.
+//
+// One prefetch buffer serves both kinds of iteration: 16 x (re, im) of Z, or
+// 16 x (row A sample, row B sample) -- the same packing the transform starts from --
+// so every path through the loop defines all of it (no stale live ranges).
+namespace fast {
+
+constexpr int MSTAT = 12; // per pair: [0,8) sum d^2 partials (2*wave + series), [8,10) sum d, [10] first row, [11] has second row
+constexpr int MTRIP = 26; // per iteration: [0,24) argmax partials, [24] reference index (< 0: nothing to write), [25] pair parity
+
+__device__ __forceinline__ bool finalize_multi(const double *tr, const double *st, const int series, const double invN,
+                                               const double invNm1, double *mv_out, int *lag_out)
+{
+    double m[4], s[4], ix[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        m[w] = tr[6 * w + 3 * series];
+        s[w] = tr[6 * w + 3 * series + 1];
+        ix[w] = tr[6 * w + 3 * series + 2];
+    }
+    const double s2 = (st[series] + st[2 + series]) + (st[4 + series] + st[6 + series]);
+    const Stat stt{st[8 + series], s2};
+    double best = m[0], bsv = s[0], bidx = ix[0];
+#pragma unroll
+    for (int w = 1; w < 4; w++) {
+        if (m[w] > best || (m[w] == best && ix[w] < bidx)) {
+            best = m[w];
+            bsv = s[w];
+            bidx = ix[w];
+        }
+    }
+    bool zero, nan;
+    const double var = variance(stt, invN, invNm1, zero, nan);
+    const int idx = (best > 0.0) ? (int)bidx : 0;
+    double y = __builtin_amdgcn_rsq(var);
+    y = y * fma(-0.5 * var * y, y, 1.5);
+    y = y * fma(-0.5 * var * y, y, 1.5);
+    double mv = ((best > 0.0) ? bsv : s[0]) * y;
+    int lag = idx > 2048 ? idx - 4096 : idx;
+    if (zero) { mv = 0.0; lag = 0; }
+    if (nan) { mv = __builtin_nan(""); lag = 0; }
+    *mv_out = mv;
+    *lag_out = lag;
+    return nan;
+}
+
+// 16-byte global store through a scalar base (+ element offset `off`) and a lane index
+__device__ __forceinline__ void zstore(double2 *base, long long off, int idx, d2v val)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned long long u = (unsigned long long)base;
+    asm volatile("" : "+s"(u));
+    u += (unsigned long long)(off * 16);
+    asm volatile("" : "+s"(u));
+    ((d2v __attribute__((address_space(1))) *)u)[idx] = val;
+#endif
+}
+
+// the previous iteration's results, written behind the first barrier of the current one
+// (a free function on purpose: a by-reference lambda with two call sites is not inlined and
+// drags the kernel argument struct into private memory)
+__device__ __forceinline__ void finalize_prev_multi(const double *trip, const double *stats, const int cur_ip,
+                                                    const int t, const double invN, const double invNm1,
+                                                    double *const *mv_many, int *const *lag_many, int *ovf_count,
+                                                    long long *ovf_list)
+{
+    const double *const tr = trip + MTRIP * (cur_ip ^ 1);
+    if (t < 2 && tr[24] >= 0.0) {
+        const double *const st = stats + MSTAT * (int)tr[25];
+        if (t == 0 || st[11] != 0.0) {
+            const int r = (int)tr[24];
+            const long long row = (long long)st[10] + t;
+            if (finalize_multi(tr, st, t, invN, invNm1, mv_many[r] + row, lag_many[r] + row) && r == 0) {
+                const int slot = atomicAdd(ovf_count, 1);
+                ovf_list[slot] = row >> 1;
+            }
+        }
+    }
+}
+
+} // namespace fast
+
+template <bool TIMING = false>
+__global__ __launch_bounds__(OCC_THREADS, 4) void xcorr_fused_n4096_multi(const FusedParams p)
+{
+    using namespace occ4;
+    using namespace fast;
+    constexpr int WPS = 4;
+    __shared__ double2 xbuf[OCC_XBUF];
+    __shared__ double2 tw2s[256];
+    __shared__ double stats[2 * MSTAT];
+    __shared__ double trip[2 * MTRIP];
+    __shared__ int slot_s;
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int hi = t >> 4, lo = t & 15;
+    double2 *const xw = xbuf + XW * wave;
+    const double invN = 1.0 / 4096.0, invNm1 = 1.0 / 4095.0;
+    const int R = p.R;
+
+    tw2s[t] = p.tw2[t];
+    if (t < 2)
+        trip[MTRIP * t + 24] = -1.0;
+    if (wave == 0) { // a scratch slice no running workgroup holds (zslots >= the resident workgroups).
+                     // The probe loop is wave-uniform (readfirstlane): a lane-divergent loop here makes
+                     // the compiler treat every later scalar base as divergent.
+        int s = (int)(blockIdx.x % (unsigned)p.zslots);
+        for (;;) {
+            int got = 0;
+            if (lane == 0)
+                got = atomicCAS(p.zbusy + s, 0, 1) == 0 ? 1 : 0;
+            if (__builtin_amdgcn_readfirstlane(got))
+                break;
+            s = s + 1 == p.zslots ? 0 : s + 1;
+        }
+        if (lane == 0)
+            slot_s = s;
+    }
+    __syncthreads();
+    double2 *const zs = p.zscratch + (size_t)__builtin_amdgcn_readfirstlane(slot_s) * 4096;
+
+    int ip = 0, pp = 0;
+    const long long total = p.npairs;
+    // prefetch buffer: rows (pre[i] = (A[t + 256 i], B[t + 256 i]), ka/kb = first samples) or Z
+    double2 pre[16];
+    double ka, kb;
+    {
+        RawPair raw;
+        issue_row_loads<false>(raw, p, blockIdx.x < total ? (long long)blockIdx.x : 0ll, t, 0);
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            pre[i] = make_double2(raw.a[i], raw.b[i]);
+        ka = raw.ka;
+        kb = raw.kb;
+    }
+    // one flat loop over (pair, reference) iterations: the prefetch buffer is live across
+    // exactly one back-edge
+    double s1a = 0.0, s1b = 0.0;
+    int r = 0;
+#pragma clang loop unroll(disable)
+    for (long long pair = blockIdx.x; pair < total;) {
+        {
+            const long long rA = 2 * pair;
+            const bool hasB = rA + 1 < p.M;
+            double *const st = stats + MSTAT * pp;
+            double *const tr = trip + MTRIP * ip;
+            double2 v[16], ta[8];
+            double2 w[16];
+            if (r == 0) {
+                // ---------- rows -> Z = FFT(dA + i dB), as in xcorr_fused_n4096_fast
+                {
+                    double qa = 0.0, qb = 0.0;
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const double da = pre[i].x - ka, db = pre[i].y - kb;
+                        v[i] = make_double2(da, db);
+                        qa = fma(da, da, qa);
+                        qb = fma(db, db, qb);
+                    }
+                    qa = wave_sum_dpp(qa);
+                    qb = wave_sum_dpp(qb);
+                    if (lane == 0) {
+                        st[2 * wave] = qa;
+                        st[2 * wave + 1] = qb;
+                    }
+                    if (t == 0) {
+                        st[10] = (double)rA;
+                        st[11] = hasB ? 1.0 : 0.0;
+                    }
+                }
+                twiddle_pass<WPS>(v, ta, Tw1Fetch{p.tw1, t});
+                exchange_cross<0>(v, xbuf, wave, t);
+                finalize_prev_multi(trip, stats, ip, t, invN, invNm1, p.mv_many, p.lag_many, p.ovf_count, p.ovf_list);
+                twiddle_pass<WPS>(v, ta, Tw2Fetch{tw2s, lo});
+                lds_barrier();
+                exchange_local(v, xw, hi & 3, lo);
+                dft16(v);
+#pragma unroll
+                for (int k = 0; k < 16; k++)
+                    w[k] = v[P16(k)];
+                s1a = readlane_f64(w[0].x, 0);
+                s1b = readlane_f64(w[0].y, 0);
+                w[0].x = (t == 0) ? 0.0 : w[0].x;
+                w[0].y = (t == 0) ? 0.0 : w[0].y;
+                if (R > 1) { // park Z: lane t owns zs[256 k + t] (scalar bases: no hoisted VGPR addresses)
+#pragma unroll
+                    for (int k = 0; k < 16; k++) {
+                        d2v z;
+                        z.x = w[k].x;
+                        z.y = w[k].y;
+                        zstore(zs, 256 * ((k + 1) & ~1), t - 256 * (k & 1), z);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; k++)
+                    w[k] = pre[k];
+            }
+            // ---------- V = Z * conj(X_r)/n ; cc = FFT(V) ; argmax
+            {
+                const double2 *xr;
+                { // the table pointer is wave-uniform: keep it in SGPRs
+                    const unsigned long long u = (unsigned long long)p.xcp_many[r];
+                    const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)u);
+                    const unsigned hi32 = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+                    xr = (const double2 *)(((unsigned long long)hi32 << 32) | lo32);
+                }
+                const auto xcl = [&](int j) { return ldg2(scalar_ptr_at(xr, 256 * ((j + 1) & ~1)), t - 256 * (j & 1)); };
+                double2 xa[4], xb[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    xa[j] = xcl(j);
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    xb[j] = xcl(4 + j);
+#pragma unroll
+                for (int b = 0; b < 4; b += 2) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        v[b * 4 + j] = cmul(w[b * 4 + j], xa[j]);
+                    fence();
+                    if ((b + 2) * 4 < 16) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            xa[j] = xcl((b + 2) * 4 + j);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        v[(b + 1) * 4 + j] = cmul(w[(b + 1) * 4 + j], xb[j]);
+                    fence();
+                    if ((b + 3) * 4 < 16) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            xb[j] = xcl((b + 3) * 4 + j);
+                    }
+                }
+            }
+            twiddle_pass<WPS>(v, ta, Tw1Fetch{p.tw1p, t});
+            exchange_local(v, xw, hi & 3, lo);
+            twiddle_pass<WPS>(v, ta, Tw2Fetch{tw2s, hi});
+            exchange_cross<1>(v, xbuf, wave, t);
+            if (r > 0) // this iteration's first workgroup barriers were the four above
+                finalize_prev_multi(trip, stats, ip, t, invN, invNm1, p.mv_many, p.lag_many, p.ovf_count, p.ovf_list);
+            dft16(v);
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                w[k] = v[P16(k)];
+            double ma = 0.0, mb = 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                ma = fmax(ma, fabs(w[k].x));
+                mb = fmax(mb, fabs(w[k].y));
+            }
+            const double wa = wave_max_dpp(ma), wb = wave_max_dpp(mb);
+            int widxA = 0x7fffffff, widxB = 0x7fffffff;
+            double svA = 0.0, svB = 0.0;
+            {
+                unsigned long long selA = 0ull, selB = 0ull;
+                int kA = 0, kB = 0, hiA = 0, hiB = 0;
+#pragma unroll
+                for (int k = 15; k >= 0; k--) {
+                    const unsigned long long mA_ = __ballot(fabs(w[k].x) == wa);
+                    const unsigned long long mB_ = __ballot(fabs(w[k].y) == wb);
+                    const bool hA = mA_ != 0ull, hB = mB_ != 0ull;
+                    selA = hA ? mA_ : selA;
+                    kA = hA ? k : kA;
+                    hiA = hA ? __double2hiint(w[k].x) : hiA;
+                    selB = hB ? mB_ : selB;
+                    kB = hB ? k : kB;
+                    hiB = hB ? __double2hiint(w[k].y) : hiB;
+                }
+                if (wa > 0.0 && selA != 0ull) {
+                    const int l = __ffsll((long long)selA) - 1;
+                    widxA = wave * 64 + l + 256 * kA;
+                    svA = (__builtin_amdgcn_readlane(hiA, l) < 0) ? -wa : wa;
+                }
+                if (wb > 0.0 && selB != 0ull) {
+                    const int l = __ffsll((long long)selB) - 1;
+                    widxB = wave * 64 + l + 256 * kB;
+                    svB = (__builtin_amdgcn_readlane(hiB, l) < 0) ? -wb : wb;
+                }
+            }
+            const double cc0a = w[0].x, cc0b = w[0].y;
+            // ---------- request the next iteration's input: Z again, or the next pair's rows
+            fence();
+            if (r + 1 < R) {
+#pragma unroll
+                for (int k = 0; k < 16; k++)
+                    pre[k] = ldg2(scalar_ptr_at((const double2 *)zs, 256 * ((k + 1) & ~1)), t - 256 * (k & 1));
+                ka = 0.0;
+                kb = 0.0;
+            } else {
+                long long nxt = pair + gridDim.x; // last pair: pair 0 (L2-resident dummy)
+                nxt = nxt < total ? nxt : 0;
+                RawPair raw;
+                issue_row_loads<false>(raw, p, nxt, t, 0);
+#pragma unroll
+                for (int i = 0; i < 16; i++)
+                    pre[i] = make_double2(raw.a[i], raw.b[i]);
+                ka = raw.ka;
+                kb = raw.kb;
+            }
+            fence();
+            if (lane == 0) {
+                double *ra_ = tr + 6 * wave;
+                ra_[0] = widxA == 0x7fffffff ? 0.0 : wa;
+                ra_[1] = widxA == 0x7fffffff ? cc0a : svA;
+                ra_[2] = (double)widxA;
+                ra_[3] = widxB == 0x7fffffff ? 0.0 : wb;
+                ra_[4] = widxB == 0x7fffffff ? cc0b : svB;
+                ra_[5] = (double)widxB;
+                if (wave == 0) {
+                    tr[24] = (double)r;
+                    tr[25] = (double)pp;
+                    if (r == 0) {
+                        st[8] = s1a;
+                        st[9] = s1b;
+                    }
+                }
+            }
+            ip ^= 1;
+        }
+        if (++r == R) {
+            r = 0;
+            pair += gridDim.x;
+            pp ^= 1;
+        }
+    }
+    lds_barrier();
+    finalize_prev_multi(trip, stats, ip, t, invN, invNm1, p.mv_many, p.lag_many, p.ovf_count, p.ovf_list);
+    if (t == 0)
+        atomicExch(p.zbusy + slot_s, 0);
+}
+
+// R >= 2 references, N == n == 4096; p.ovf_count zeroed, p.zbusy zeroed (zslots ints)
+hipError_t launch_fused_multi(const FusedParams &p, int num_cus, hipStream_t stream)
+{
+    long long grid = p.npairs;
+    int mult = 8; // measured 1 / 4 / 8 / 16: 58.0 / 55.7 / 54.8 / 54.5 ms for 8 references x 1 M series
+    if (const char *m = getenv("MUSE_HIP_GRID_MULT"))
+        mult = atoi(m) > 0 ? atoi(m) : mult;
+    const long long cap = (long long)num_cus * 4 * mult;
+    if (grid > cap)
+        grid = cap;
+    if (p.zslots < num_cus * 4 || !p.zscratch || !p.zbusy || p.R < 1)
+        return hipErrorInvalidValue;
+    hipLaunchKernelGGL((xcorr_fused_n4096_multi<false>), dim3((unsigned)grid), dim3(OCC_THREADS), 0, stream, p);
+    return hipGetLastError();
+}
+
 // N == n == 4096 only; p.ovf_count must be zeroed and p.ovf_list hold 2*npairs entries
 hipError_t launch_fused_fast(const FusedParams &p, int num_cus, hipStream_t stream)
 {

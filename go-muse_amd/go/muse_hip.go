@@ -197,3 +197,100 @@ func (b *Batch) Run(groupByLabels []string) error {
 	}
 	return nil
 }
+
+// RunMany is Run for several batches that share one Comparison group and the
+// same Results settings (README.md:10-13: many references against one set of
+// series): the resident rows are read and forward-transformed once for all
+// references (muse_batch_run_many).  Not part of the reference's API; batches
+// that do not qualify are simply run one after the other.
+func RunMany(batches []*Batch, groupByLabels []string) error {
+	if len(batches) == 0 {
+		return nil
+	}
+	b0 := batches[0]
+	same := true
+	for _, b := range batches {
+		r, r0 := b.Results, b0.Results
+		same = same && b.Comparison == b0.Comparison && r.MaxLag == r0.MaxLag && r.TopN == r0.TopN &&
+			r.Threshold == r0.Threshold && r.SignFilter == r0.SignFilter
+	}
+	if !same {
+		for _, b := range batches {
+			if err := b.Run(groupByLabels); err != nil {
+				return err
+			}
+		}
+		return nil
+	}
+	labelValuesSet := b0.Comparison.indexLabelValues(groupByLabels)
+	if len(labelValuesSet) == 0 {
+		return nil
+	}
+	e, err := getEngine()
+	if err != nil {
+		return err
+	}
+	dg, err := b0.Comparison.residentRows(e)
+	if err != nil {
+		return err
+	}
+	pos := make(map[string]int, len(b0.Comparison.order))
+	for i, s := range b0.Comparison.order {
+		pos[s.UID()] = i
+	}
+	gid := make([]C.int32_t, len(b0.Comparison.order))
+	gi := 0
+	for _, lv := range labelValuesSet {
+		for _, uid := range b0.Comparison.index[lv.ID(lv.Keys())] {
+			gid[pos[uid]] = C.int32_t(gi)
+		}
+		gi++
+	}
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	// the handle array lives in C memory: cgo forbids passing Go memory that holds pointers
+	R := len(batches)
+	hs := (**C.muse_batch)(C.malloc(C.size_t(R) * C.size_t(unsafe.Sizeof((*C.muse_batch)(nil)))))
+	defer C.free(unsafe.Pointer(hs))
+	hv := unsafe.Slice(hs, R)
+	for i, b := range batches {
+		if b.batch == nil || b.batchGroup != dg {
+			if b.batch != nil {
+				C.muse_batch_free(b.batch)
+			}
+			st := C.muse_batch_create(e.ctx, dg, (*C.double)(unsafe.Pointer(&b.ref[0])), C.int32_t(len(b.ref)), &b.batch)
+			if err := hipError(st); err != nil {
+				return err
+			}
+			b.batchGroup = dg
+		}
+		hv[i] = b.batch
+	}
+	r := b0.Results
+	top := r.TopN
+	if top < 1 {
+		top = 1
+	}
+	idx := make([]C.int64_t, R*top)
+	lag := make([]C.int32_t, R*top)
+	score := make([]C.double, R*top)
+	cnt := make([]C.int32_t, R)
+	mean := make([]C.double, R)
+	st := C.muse_batch_run_many(hs, C.int32_t(R), &gid[0], C.int32_t(len(labelValuesSet)), C.int32_t(r.MaxLag),
+		C.int32_t(r.TopN), C.double(r.Threshold), C.int32_t(r.SignFilter), 1, &idx[0], &lag[0], &score[0], &cnt[0], &mean[0])
+	if err := hipError(st); err != nil {
+		return err
+	}
+	for i, b := range batches {
+		o := i * r.TopN
+		order := make([]int, int(cnt[i]))
+		for k := range order {
+			order[k] = k
+		}
+		sort.SliceStable(order, func(a, c int) bool { return gid[idx[o+order[a]]] < gid[idx[o+order[c]]] })
+		for _, k := range order {
+			b.Results.Update(Score{Labels: b.Comparison.order[idx[o+k]].Labels(), Lag: int(lag[o+k]), PercentScore: float64(score[o+k])})
+		}
+	}
+	return nil
+}

@@ -382,12 +382,7 @@ public:
         if (lvs.empty())
             return;
         muse_group *dg = Comparison->device(eng_);
-        if (!batch_ || batch_group_ != dg) {
-            muse_batch_free(batch_);
-            batch_ = nullptr;
-            check(muse_batch_create(eng_->handle(), dg, ref_.data(), (int32_t)ref_.size(), &batch_));
-            batch_group_ = dg;
-        }
+        ensure(dg);
         const int cap = std::max(Results_->TopN, 1);
         std::vector<int64_t> idx(cap);
         std::vector<int32_t> lag(cap);
@@ -406,7 +401,65 @@ public:
             Results_->Update(Score{Comparison->series()[idx[k]]->Labels(), lag[k], score[k]});
     }
 
+    // The README use case (README.md:10-13) runs many references against one Group: the same as
+    // calling Run on every batch, but the resident rows are read and transformed once for all of
+    // them (muse_batch_run_many).  The batches must share the Comparison group and the Results settings
+    // that select (MaxLag, TopN, Threshold, Filter are taken from each batch's own Results only if
+    // they all agree; otherwise the batches are run one by one).
+    static void RunMany(const std::vector<std::shared_ptr<Batch>> &batches, const std::vector<std::string> &groupByLabels)
+    {
+        if (batches.empty())
+            return;
+        bool same = true;
+        for (auto &b : batches) {
+            same &= b->Comparison == batches[0]->Comparison && b->eng_ == batches[0]->eng_;
+            same &= b->Results_->MaxLag == batches[0]->Results_->MaxLag && b->Results_->TopN == batches[0]->Results_->TopN;
+            same &= b->Results_->Threshold == batches[0]->Results_->Threshold && b->Results_->Filter == batches[0]->Results_->Filter;
+        }
+        if (!same) {
+            for (auto &b : batches)
+                b->Run(groupByLabels);
+            return;
+        }
+        Batch &b0 = *batches[0];
+        std::vector<int32_t> gid;
+        auto lvs = b0.Comparison->indexLabelValues(groupByLabels, &gid);
+        if (lvs.empty())
+            return;
+        muse_group *dg = b0.Comparison->device(b0.eng_);
+        std::vector<muse_batch *> hs;
+        for (auto &b : batches) {
+            b->ensure(dg);
+            hs.push_back(b->batch_);
+        }
+        const int R = (int)hs.size(), top = b0.Results_->TopN, cap = std::max(top, 1);
+        std::vector<int64_t> idx((size_t)R * cap);
+        std::vector<int32_t> lag((size_t)R * cap), cnt((size_t)R);
+        std::vector<double> score((size_t)R * cap), mean((size_t)R);
+        check(muse_batch_run_many(hs.data(), R, gid.data(), (int32_t)lvs.size(), b0.Results_->MaxLag, top,
+                                  b0.Results_->Threshold, (int32_t)b0.Results_->Filter, 1, idx.data(), lag.data(),
+                                  score.data(), cnt.data(), mean.data()));
+        for (int r = 0; r < R; r++) {
+            const size_t o = (size_t)r * std::max(top, 0);
+            std::vector<int> order(cnt[r]);
+            for (int i = 0; i < cnt[r]; i++)
+                order[i] = i;
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return gid[idx[o + a]] < gid[idx[o + b]]; });
+            for (int k : order)
+                batches[r]->Results_->Update(Score{b0.Comparison->series()[idx[o + k]]->Labels(), lag[o + k], score[o + k]});
+        }
+    }
+
 private:
+    void ensure(muse_group *dg)
+    {
+        if (!batch_ || batch_group_ != dg) {
+            muse_batch_free(batch_);
+            batch_ = nullptr;
+            check(muse_batch_create(eng_->handle(), dg, ref_.data(), (int32_t)ref_.size(), &batch_));
+            batch_group_ = dg;
+        }
+    }
     std::shared_ptr<Engine> eng_;
     std::vector<double> ref_;
     muse_batch *batch_ = nullptr;

@@ -163,6 +163,41 @@ static void TestRunNoInput() // muse_test.go:122-142
     EXPECT(threw, "Muse.Run: expected a length error");
 }
 
+// many references against one group in one pass (muse_batch_run_many) == one Run per reference
+static void TestRunManyEqualsRuns()
+{
+    const int N = 4096, M = 37, R = 3;
+    auto mk = [&](int seed, int shift) {
+        std::vector<double> v(N);
+        unsigned long long h = 0x9E3779B97F4A7C15ull * (unsigned long long)(seed + 1);
+        for (int i = 0; i < N; i++) {
+            h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+            v[i] = (double)(h >> 11) * (1.0 / 9007199254740992.0) - 0.5 + ((i + shift) % N >= 2000 && (i + shift) % N < 2040 ? 3.0 : 0.0);
+        }
+        return v;
+    };
+    auto g = NewGroup("targets");
+    for (int i = 0; i < M; i++)
+        g->Add({NewSeries(mk(100 + i, 7 * i), NewLabels({{"graph", "g" + std::to_string(i / 3)}, {"host", "h" + std::to_string(i)}}))});
+    std::vector<std::shared_ptr<Batch>> many, single;
+    for (int r = 0; r < R; r++) {
+        auto ref = NewSeries(mk(r, 11 * r), NewLabels({{"graph", "ref"}}));
+        many.push_back(NewBatch(ref, g, NewResults(4096, 8, 0, SignFilter_ANY), 4));
+        single.push_back(NewBatch(ref, g, NewResults(4096, 8, 0, SignFilter_ANY), 4));
+    }
+    Batch::RunMany(many, {"graph"});
+    for (int r = 0; r < R; r++) {
+        single[r]->Run({"graph"});
+        auto a = many[r]->Results_->Fetch(), b = single[r]->Results_->Fetch();
+        EXPECT(a.first.size() == b.first.size() && a.first.size() == 8, "RunMany[%d]: %zu vs %zu scores", r, a.first.size(), b.first.size());
+        for (size_t i = 0; i < a.first.size() && i < b.first.size(); i++) {
+            EXPECT(a.first[i].Lag == b.first[i].Lag && a.first[i].Labels->ID() == b.first[i].Labels->ID(), "RunMany[%d][%zu]: lag/labels", r, i);
+            EXPECT(std::fabs(a.first[i].PercentScore - b.first[i].PercentScore) <= 1e-12, "RunMany[%d][%zu]: score", r, i);
+        }
+        EXPECT(std::fabs(a.second - b.second) <= 1e-12, "RunMany[%d]: mean", r);
+    }
+}
+
 int main()
 {
     try {
@@ -172,6 +207,7 @@ int main()
         TestRunSimple();
         TestRunSimpleSignFilter();
         TestRunNoInput();
+        TestRunManyEqualsRuns();
     } catch (const Error &e) {
         printf("muse::Error %d: %s\n", e.status, e.what());
         return 2;

@@ -248,6 +248,64 @@ class DeviceBatch:
             pass
 
 
+def _batch_handles(batches):
+    batches = list(batches)
+    if not batches:
+        raise ValueError("empty batch list")
+    arr = (ctypes.c_void_p * len(batches))(*[b._h for b in batches])
+    return batches, arr
+
+
+def score_many(batches):
+    """muse_batch_score_many: R references against one resident group in ONE pass over the rows
+    (asynchronous; results land in each DeviceBatch's own buffers)."""
+    batches, arr = _batch_handles(batches)
+    B.check(B.load().muse_batch_score_many(arr, len(batches)))
+
+
+def scores_many(batches):
+    """score_many + copy back: list of (lag, mv), one per batch"""
+    batches, arr = _batch_handles(batches)
+    B.check(B.load().muse_batch_score_many(arr, len(batches)))
+    out = []
+    lib = B.load()
+    for b in batches:
+        M = b.dgroup.M
+        lag = np.zeros(M, dtype=np.int32)
+        mv = np.zeros(M)
+        if M:
+            B.check(lib.muse_batch_read_scores(b._h, B.i32ptr(lag), B.dptr(mv)))
+        out.append((lag, mv))
+    return out
+
+
+def run_many(batches, group_id=None, G=0, max_lag=10, top_n=20, threshold=0.0, sign_filter=0, abs_scores=True):
+    """muse_batch_run_many: Batch.Run for every reference with one pass over the rows;
+    returns a list of (series, lag, score, mean_abs), one per batch"""
+    batches, arr = _batch_handles(batches)
+    R = len(batches)
+    cap = max(int(top_n), 1)
+    o_s = np.zeros(R * cap, dtype=np.int64)
+    o_l = np.zeros(R * cap, dtype=np.int32)
+    o_v = np.zeros(R * cap)
+    cnt = np.zeros(R, dtype=np.int32)
+    mean = np.zeros(R)
+    gid = None
+    if group_id is not None:
+        gid = np.ascontiguousarray(group_id, dtype=np.int32)
+    B.check(B.load().muse_batch_run_many(
+        arr, R, B.i32ptr(gid) if gid is not None else None, int(G), int(max_lag), int(top_n),
+        float(threshold), int(sign_filter), 1 if abs_scores else 0,
+        B.i64ptr(o_s), B.i32ptr(o_l), B.dptr(o_v), B.i32ptr(cnt), B.dptr(mean)))
+    tn = max(int(top_n), 0)
+    res = []
+    for r in range(R):
+        c = int(cnt[r])
+        res.append((o_s[r * tn:r * tn + c].copy(), o_l[r * tn:r * tn + c].copy(), o_v[r * tn:r * tn + c].copy(),
+                    float(mean[r])))
+    return res
+
+
 def merge_records(records, top_n):
     """Results.Update/Fetch over gathered shard candidates (host only)."""
     records = np.ascontiguousarray(records, dtype=B.RECORD_DTYPE)

@@ -165,6 +165,29 @@ int muse_batch_run_shard(muse_batch *b, const int32_t *group_id, int32_t G,
 int muse_merge_records(const muse_record *records, int64_t count, int32_t top_n,
                        int64_t *out_series, int32_t *out_lag, double *out_score,
                        int32_t *out_count, double *out_mean_abs);
+/* Many references against one resident group (the
+ * README.md:10-13 use case iterates references and groupings over a fixed
+ * set of series, i.e. one NewBatch + Run per reference against the same
+ * Group).  The R batches must share the context and the group; each is
+ * scored exactly as muse_batch_score would, but in ONE pass over the rows:
+ * every pair of series is read and forward-transformed once and correlated
+ * against all R reference spectra (N == 4096; other lengths and forced kernel
+ * variants score the batches one after the other).  Results land in each
+ * batch's own buffers (muse_batch_scores / _run on a batch re-score it). */
+int muse_batch_score_many(muse_batch *const *batches, int32_t R);
+/* Copies back the (lag, signed mv) of the last scoring pass WITHOUT re-scoring
+ * (muse_batch_scores = muse_batch_score + this). */
+int muse_batch_read_scores(muse_batch *b, int32_t *lag, double *mv);
+/* muse_batch_score_many followed by Batch.Run's selection for every batch
+ * with the same grouping and Results settings: outputs are R consecutive
+ * blocks of top_n entries (out_series[r*top_n + i], ...), out_count[r] and
+ * out_mean_abs[r] per reference.  Any output may be NULL. */
+int muse_batch_run_many(muse_batch *const *batches, int32_t R,
+                        const int32_t *group_id, int32_t G, int32_t max_lag,
+                        int32_t top_n, double threshold, int32_t sign_filter,
+                        int32_t abs_scores, int64_t *out_series,
+                        int32_t *out_lag, double *out_score,
+                        int32_t *out_count, double *out_mean_abs);
 int muse_batch_free(muse_batch *b);
 
 /* ------------------------------------------- single-pair entry points */

@@ -514,3 +514,55 @@ def test_group_append_staging_paths(muse, eng, oracle):
     assert len(lag3) == M + 7 and np.array_equal(lag3[M:], lag[:7])
     np.testing.assert_allclose(mv3[M:], mv[:7], rtol=1e-12, atol=0)
     assert np.array_equal(lag3[:M], lag) and np.array_equal(mv3[:M], mv)
+
+
+@pytest.mark.parametrize("R,M", [(2, 65), (5, 300), (1, 40)])
+def test_many_references_one_pass_matches_single_batches(muse, eng, oracle, R, M):
+    """muse_batch_score_many: R references against one resident group in one pass over the rows
+    (each pair transformed once, its spectrum parked in the per-workgroup scratch slice) must give
+    what R separate batches give -- and what the oracle gives -- incl. NaN/Inf/constant rows and an
+    odd row count."""
+    N = 4096
+    rng = np.random.default_rng(1000 + R)
+    rows = rng.standard_normal((M, N))
+    rows[3, 100] = np.nan
+    rows[8, :] = np.inf
+    rows[11, :] = -7.25
+    refs = [rng.standard_normal(N) + (np.arange(N) == 100 * r) * 30.0 for r in range(R)]
+    rows[20:20 + R] = np.stack([np.roll(refs[r], 5 * r + 1) for r in range(R)])   # known lags per reference
+    dg = muse.DeviceGroup.from_rows(eng, rows)
+    batches = [muse.DeviceBatch(eng, dg, ref) for ref in refs]
+    got = muse.scores_many(batches)
+    for r in range(R):
+        lag, mv = got[r]
+        olag, omv, gap = oracle.batch_scores(refs[r], rows)
+        assert math.isnan(mv[3]) and lag[3] == 0 and math.isnan(mv[8]) and lag[8] == 0
+        assert mv[11] == 0.0 and lag[11] == 0
+        assert_scores_match(lag, mv, olag, omv, gap)
+        slag, smv = batches[r].scores()                 # the single-reference kernel on the same batch
+        assert np.array_equal(lag, slag)
+        np.testing.assert_allclose(mv, smv, rtol=1e-12, atol=0, equal_nan=True)
+    # Run semantics for every reference in one call
+    gid = (np.arange(M) // 7).astype(np.int32)
+    G = int(gid.max()) + 1
+    many = muse.run_many(batches, gid, G, max_lag=2048, top_n=6, threshold=0.0, sign_filter=0, abs_scores=True)
+    for r in range(R):
+        s1, l1, v1, m1 = batches[r].run(gid, G, 2048, 6, 0.0, 0, True)
+        s2, l2, v2, m2 = many[r]
+        assert np.array_equal(s1, s2) and np.array_equal(l1, l2)
+        np.testing.assert_allclose(v1, v2, rtol=1e-12)
+        assert abs(m1 - m2) <= 1e-12 * abs(m1)
+
+
+def test_many_references_large(muse, eng):
+    """200 000 x 4096 synthetic rows, 4 references: every row of every reference equals the
+    single-reference result (lags exact, scores to rounding)."""
+    M, N, R = 200_000, 4096, 4
+    dg, ref0 = muse.DeviceGroup.synthetic(eng, M, N, seed=77)
+    refs = [ref0] + [dg.read(1000 * r + 1, 1)[0] for r in range(1, R)]
+    batches = [muse.DeviceBatch(eng, dg, ref) for ref in refs]
+    got = muse.scores_many(batches)
+    for r in range(R):
+        slag, smv = batches[r].scores()
+        assert np.array_equal(got[r][0], slag), r
+        np.testing.assert_allclose(got[r][1], smv, rtol=1e-11, atol=0, equal_nan=True)
