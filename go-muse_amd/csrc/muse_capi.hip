@@ -81,7 +81,6 @@ struct muse_ctx {
     float2 *tw1f = nullptr, *tw2f = nullptr; // fp32 copies for the screening kernel
     // many-reference pass (muse_batch_score_many): parked spectra + device pointer tables
     double2 *zscratch = nullptr;
-    int *zbusy = nullptr;
     int zslots = 0;
     void *many_tab = nullptr; // R x {xcp, mv, lag} pointers
     std::vector<void *> many_host; // host image of many_tab (outlives the asynchronous copy)
@@ -247,7 +246,6 @@ static void ctx_release(muse_ctx *ctx)
     (void)hipFree(ctx->tw1w8);
     (void)hipFree(ctx->tw1p);
     (void)hipFree(ctx->zscratch);
-    (void)hipFree(ctx->zbusy);
     (void)hipFree(ctx->many_tab);
     (void)hipFree(ctx->tw2f);
     if (ctx->stream)
@@ -622,7 +620,7 @@ extern "C" int muse_batch_create(muse_ctx *ctx, muse_group *g, const double *ref
     if (e == hipSuccess)
         e = hipMalloc(&b->xs, (size_t)n * sizeof(double));
     if (e == hipSuccess)
-        e = hipMalloc(&b->ovf_count, sizeof(int));
+        e = hipMalloc(&b->ovf_count, 2 * sizeof(int)); // [0] overflow-pair count, [1] dynamic work counter
     if (e == hipSuccess && n > GENERIC_LDS_MAX_N)
         e = hipMalloc(&b->gscratch, (size_t)ctx->num_cus * GENERIC_GLOBAL_WGS_PER_CU * (size_t)n * sizeof(double2));
     if (e != hipSuccess) {
@@ -780,8 +778,9 @@ extern "C" int muse_batch_score(muse_batch *b)
             b->ovf_cap = 2 * p.npairs;
         }
         p.ovf_count = b->ovf_count;
+        p.work_counter = b->ovf_count + 1;
         p.ovf_list = b->ovf_list;
-        HIP_TRY(hipMemsetAsync(b->ovf_count, 0, sizeof(int), ctx->stream));
+        HIP_TRY(hipMemsetAsync(b->ovf_count, 0, 2 * sizeof(int), ctx->stream));
         HIP_TRY(launch_fused(p, variant, ctx->num_cus, ctx->stream));
         FusedParams q = p;
         q.pair_list = b->ovf_list;
@@ -1126,9 +1125,8 @@ extern "C" int muse_batch_score_many(muse_batch *const *bs, int32_t R)
             return rc;
     }
     if (!ctx->zscratch) {
-        const int slots = ctx->num_cus * 4 * 2; // twice the resident workgroups: short probe sequences
+        const int slots = ctx->num_cus * 4; // one 64 KB slice per resident workgroup
         HIP_TRY(hipMalloc(&ctx->zscratch, (size_t)slots * 4096 * sizeof(double2)));
-        HIP_TRY(hipMalloc(&ctx->zbusy, (size_t)slots * sizeof(int)));
         ctx->zslots = slots;
     }
     if (R > ctx->many_cap) {
@@ -1153,7 +1151,6 @@ extern "C" int muse_batch_score_many(muse_batch *const *bs, int32_t R)
     p.mv_many = (double *const *)((void **)ctx->many_tab + R);
     p.lag_many = (int *const *)((void **)ctx->many_tab + 2 * R);
     p.zscratch = ctx->zscratch;
-    p.zbusy = ctx->zbusy;
     p.zslots = ctx->zslots;
     if (2 * p.npairs > b0->ovf_cap) {
         (void)hipFree(b0->ovf_list);
@@ -1163,6 +1160,7 @@ extern "C" int muse_batch_score_many(muse_batch *const *bs, int32_t R)
         b0->ovf_cap = 2 * p.npairs;
     }
     p.ovf_count = b0->ovf_count;
+    p.work_counter = b0->ovf_count + 1;
     p.ovf_list = b0->ovf_list;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->timing) {
@@ -1170,8 +1168,7 @@ extern "C" int muse_batch_score_many(muse_batch *const *bs, int32_t R)
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, ctx->stream));
     }
-    HIP_TRY(hipMemsetAsync(b0->ovf_count, 0, sizeof(int), ctx->stream));
-    HIP_TRY(hipMemsetAsync(ctx->zbusy, 0, (size_t)ctx->zslots * sizeof(int), ctx->stream));
+    HIP_TRY(hipMemsetAsync(b0->ovf_count, 0, 2 * sizeof(int), ctx->stream));
     HIP_TRY(launch_fused_multi(p, ctx->num_cus, ctx->stream));
     // pairs holding a NaN/Inf series (listed once, by reference 0): redone per reference by the
     // kernel that isolates the dead series before the shared transform

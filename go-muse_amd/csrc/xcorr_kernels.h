@@ -30,8 +30,7 @@ struct FusedParams {
     const double2 *const *xcp_many; // R lane-ordered spectrum tables
     double *const *mv_many;         // R result vectors (M doubles each)
     int *const *lag_many;           // R lag vectors (M ints each)
-    double2 *zscratch;              // zslots x 4096 complex: one parked spectrum per running workgroup
-    int *zbusy;                     // zslots flags, zeroed before the launch
+    double2 *zscratch;              // zslots x 4096 complex: one parked spectrum per (resident) workgroup
     int zslots;
     const double2 *twm;  // [32768]   W_65536^k         (generic kernel; half period)
     double2 *gscratch;   // n > 8192: one n-element complex work buffer per workgroup (global, L2-resident)
@@ -47,6 +46,7 @@ struct FusedParams {
     const double *xs;    // n entries: zeroPad(zNormalize(ref)/(N-1), n), time domain, fp64
     double screen_delta; // candidate window below the fp32 maximum (scaled units, max |cc| <= 1)
     int *ovf_count;      // pairs with too many candidates: redone by the fp64 kernel
+    int *work_counter;   // dynamic pair hand-out (xcorr_r16_fast.hip, DYN): zeroed before the launch
     long long *ovf_list;
     // optional indirection for the fp64 kernels: process pair_list[0 .. *pair_count)
     const long long *pair_list;

@@ -30,6 +30,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <algorithm>
 
 #include "r16_device.h"
 
@@ -289,7 +290,10 @@ __device__ __forceinline__ bool finalize(const double *r, const int series, cons
 // requested before the last butterflies) or 4 (128 VGPRs: no room for the 64 prefetch registers
 // next to the butterflies, the rows are requested after the argmax and their latency is covered
 // by the other three workgroups on the CU only).
-template <int WPS, bool TIMING = false>
+// DYN: pairs are handed out by an atomic counter (FusedParams::work_counter, zeroed before the
+// launch) to a grid of resident workgroups only, instead of a static stride over an oversubscribed
+// grid: no tail while the slowest CUs finish their fixed share.
+template <int WPS, bool TIMING = false, bool DYN = false>
 __global__ __launch_bounds__(OCC_THREADS, WPS) void xcorr_fused_n4096_fast(const FusedParams p)
 {
     using namespace occ4;
@@ -297,6 +301,7 @@ __global__ __launch_bounds__(OCC_THREADS, WPS) void xcorr_fused_n4096_fast(const
     __shared__ double2 xbuf[OCC_XBUF];
     __shared__ double2 tw2s[256];
     __shared__ double red[2 * REC];
+    __shared__ int next_s[2];
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6); // wave-uniform by construction
@@ -316,11 +321,18 @@ __global__ __launch_bounds__(OCC_THREADS, WPS) void xcorr_fused_n4096_fast(const
     RawPair raw;
     issue_row_loads<false>(raw, p, blockIdx.x < total ? (long long)blockIdx.x : 0ll, t, 0);
 
-    for (long long pair = blockIdx.x; pair < total; pair += gridDim.x) {
+    long long nextpair = 0;
+    for (long long pair = blockIdx.x; pair < total; pair = nextpair) {
         const long long rA = 2 * pair;
         const bool hasB = rA + 1 < p.M;
         double *const rec = red + REC * parity;
         const double *const prec = red + REC * (parity ^ 1);
+        if (DYN) { // the pair after this one: claimed now, read behind this pair's barriers
+            if (t == 0)
+                next_s[parity] = (int)gridDim.x + atomicAdd(p.work_counter, 1);
+        } else {
+            nextpair = pair + gridDim.x;
+        }
         // ---- consume the prefetched rows: d = x - K (K = the row's first sample) bounds
         // the cancellation in sum d^2 - (sum d)^2 / N and keeps a large level out of the
         // transform's rounding; sum d itself is read off the DC bin below
@@ -453,7 +465,9 @@ __global__ __launch_bounds__(OCC_THREADS, WPS) void xcorr_fused_n4096_fast(const
         // pass 3: DFT over c' (m1 = lo, m2 = hi): index t + 256 m3.  The next pair's rows
         // are requested first: they stay in flight during the butterflies and the argmax.
         {
-            long long nxt = pair + gridDim.x; // last iteration: pair 0 (L2-resident dummy)
+            if (DYN)
+                nextpair = __builtin_amdgcn_readfirstlane(next_s[parity]);
+            long long nxt = nextpair; // last iteration: pair 0 (L2-resident dummy)
             nxt = nxt < total ? nxt : 0;
             fence();
             if (WPS < 4)
@@ -507,7 +521,7 @@ __global__ __launch_bounds__(OCC_THREADS, WPS) void xcorr_fused_n4096_fast(const
         }
         const double cc0a = v[0].x, cc0b = v[0].y;
         if (WPS >= 4) {
-            long long nxt = pair + gridDim.x;
+            long long nxt = nextpair;
             nxt = nxt < total ? nxt : 0;
             fence();
             issue_row_loads<false>(raw, p, nxt, t, 0);
@@ -647,7 +661,7 @@ __global__ __launch_bounds__(OCC_THREADS, 4) void xcorr_fused_n4096_multi(const 
     __shared__ double2 tw2s[256];
     __shared__ double stats[2 * MSTAT];
     __shared__ double trip[2 * MTRIP];
-    __shared__ int slot_s;
+    __shared__ int next_s[2];
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -659,23 +673,8 @@ __global__ __launch_bounds__(OCC_THREADS, 4) void xcorr_fused_n4096_multi(const 
     tw2s[t] = p.tw2[t];
     if (t < 2)
         trip[MTRIP * t + 24] = -1.0;
-    if (wave == 0) { // a scratch slice no running workgroup holds (zslots >= the resident workgroups).
-                     // The probe loop is wave-uniform (readfirstlane): a lane-divergent loop here makes
-                     // the compiler treat every later scalar base as divergent.
-        int s = (int)(blockIdx.x % (unsigned)p.zslots);
-        for (;;) {
-            int got = 0;
-            if (lane == 0)
-                got = atomicCAS(p.zbusy + s, 0, 1) == 0 ? 1 : 0;
-            if (__builtin_amdgcn_readfirstlane(got))
-                break;
-            s = s + 1 == p.zslots ? 0 : s + 1;
-        }
-        if (lane == 0)
-            slot_s = s;
-    }
     __syncthreads();
-    double2 *const zs = p.zscratch + (size_t)__builtin_amdgcn_readfirstlane(slot_s) * 4096;
+    double2 *const zs = p.zscratch + (size_t)blockIdx.x * 4096; // resident grid: one slice per workgroup
 
     int ip = 0, pp = 0;
     const long long total = p.npairs;
@@ -694,6 +693,7 @@ __global__ __launch_bounds__(OCC_THREADS, 4) void xcorr_fused_n4096_multi(const 
     // one flat loop over (pair, reference) iterations: the prefetch buffer is live across
     // exactly one back-edge
     double s1a = 0.0, s1b = 0.0;
+    long long nextpair = 0;
     int r = 0;
 #pragma clang loop unroll(disable)
     for (long long pair = blockIdx.x; pair < total;) {
@@ -706,6 +706,8 @@ __global__ __launch_bounds__(OCC_THREADS, 4) void xcorr_fused_n4096_multi(const 
             double2 w[16];
             if (r == 0) {
                 // ---------- rows -> Z = FFT(dA + i dB), as in xcorr_fused_n4096_fast
+                if (t == 0) // claim the pair after this one (read at the last reference, many barriers later)
+                    next_s[pp] = (int)gridDim.x + atomicAdd(p.work_counter, 1);
                 {
                     double qa = 0.0, qb = 0.0;
 #pragma unroll
@@ -848,8 +850,8 @@ __global__ __launch_bounds__(OCC_THREADS, 4) void xcorr_fused_n4096_multi(const 
                 ka = 0.0;
                 kb = 0.0;
             } else {
-                long long nxt = pair + gridDim.x; // last pair: pair 0 (L2-resident dummy)
-                nxt = nxt < total ? nxt : 0;
+                nextpair = __builtin_amdgcn_readfirstlane(next_s[pp]);
+                long long nxt = nextpair < total ? nextpair : 0; // nothing left: pair 0 (L2-resident dummy)
                 RawPair raw;
                 issue_row_loads<false>(raw, p, nxt, t, 0);
 #pragma unroll
@@ -880,27 +882,20 @@ __global__ __launch_bounds__(OCC_THREADS, 4) void xcorr_fused_n4096_multi(const 
         }
         if (++r == R) {
             r = 0;
-            pair += gridDim.x;
+            pair = nextpair;
             pp ^= 1;
         }
     }
     lds_barrier();
     finalize_prev_multi(trip, stats, ip, t, invN, invNm1, p.mv_many, p.lag_many, p.ovf_count, p.ovf_list);
-    if (t == 0)
-        atomicExch(p.zbusy + slot_s, 0);
 }
 
-// R >= 2 references, N == n == 4096; p.ovf_count zeroed, p.zbusy zeroed (zslots ints)
+// R >= 2 references, N == n == 4096; p.ovf_count and p.work_counter zeroed; a resident grid
+// (pairs are handed out dynamically), one scratch slice per workgroup
 hipError_t launch_fused_multi(const FusedParams &p, int num_cus, hipStream_t stream)
 {
-    long long grid = p.npairs;
-    int mult = 8; // measured 1 / 4 / 8 / 16: 58.0 / 55.7 / 54.8 / 54.5 ms for 8 references x 1 M series
-    if (const char *m = getenv("MUSE_HIP_GRID_MULT"))
-        mult = atoi(m) > 0 ? atoi(m) : mult;
-    const long long cap = (long long)num_cus * 4 * mult;
-    if (grid > cap)
-        grid = cap;
-    if (p.zslots < num_cus * 4 || !p.zscratch || !p.zbusy || p.R < 1)
+    const long long grid = std::min<long long>(p.npairs, (long long)num_cus * 4);
+    if (p.zslots < grid || !p.zscratch || !p.work_counter || p.R < 1)
         return hipErrorInvalidValue;
     hipLaunchKernelGGL((xcorr_fused_n4096_multi<false>), dim3((unsigned)grid), dim3(OCC_THREADS), 0, stream, p);
     return hipGetLastError();
@@ -921,7 +916,18 @@ hipError_t launch_fused_fast(const FusedParams &p, int num_cus, hipStream_t stre
     const long long cap = (long long)num_cus * wps * mult;
     if (grid > cap)
         grid = cap;
-    if (wps == 4)
+    // dynamic hand-out on a resident grid measured 10.58 ms against 10.74 ms for the static stride
+    // over 16x the resident set (same box, interleaved)
+    int dyn = 1;
+    if (const char *d = getenv("MUSE_HIP_FAST_DYN")) // tuning aid
+        dyn = atoi(d) != 0;
+    if (dyn && p.work_counter) {
+        grid = std::min<long long>(p.npairs, (long long)num_cus * wps); // resident workgroups only
+        if (wps == 4)
+            hipLaunchKernelGGL((xcorr_fused_n4096_fast<4, false, true>), dim3((unsigned)grid), dim3(OCC_THREADS), 0, stream, p);
+        else
+            hipLaunchKernelGGL((xcorr_fused_n4096_fast<3, false, true>), dim3((unsigned)grid), dim3(OCC_THREADS), 0, stream, p);
+    } else if (wps == 4)
         hipLaunchKernelGGL((xcorr_fused_n4096_fast<4, false>), dim3((unsigned)grid), dim3(OCC_THREADS), 0, stream, p);
     else
         hipLaunchKernelGGL((xcorr_fused_n4096_fast<3, false>), dim3((unsigned)grid), dim3(OCC_THREADS), 0, stream, p);
