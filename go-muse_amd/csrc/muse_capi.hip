@@ -283,7 +283,7 @@ extern "C" int muse_ctx_device_info(muse_ctx *ctx, char *name, int32_t name_cap,
 
 extern "C" int muse_ctx_set_kernel(muse_ctx *ctx, int32_t variant)
 {
-    if (!ctx || variant < 0 || variant > 10 || variant == 3 || variant == 4) // 3, 4: retired
+    if (!ctx || variant < 0 || variant > 11 || variant == 3 || variant == 4) // 3, 4: retired
         return fail(MUSE_ERR_INVALID, "bad kernel variant");
     ctx->variant = variant;
     return MUSE_OK;
@@ -758,6 +758,8 @@ extern "C" int muse_batch_score(muse_batch *b)
         }
         if (variant == KERNEL_R16_FAST && b->N != 4096) // the deferred-statistics kernel is built for N == n only
             variant = KERNEL_R16_OCC3;
+    } else if (b->n >= 512 && b->n <= 2048 && (ctx->variant == 0 || ctx->variant == 11)) {
+        variant = KERNEL_STOCKHAM; // radix-16 Stockham through LDS (xcorr_stockham.hip)
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->timing) {

@@ -8,7 +8,7 @@
 
 namespace muse {
 
-enum { KERNEL_GENERIC = 0, KERNEL_R16_N4096 = 1, KERNEL_R16_PIPE = 4, KERNEL_R16_OCC4 = 5, KERNEL_R16_OCC3 = 6, KERNEL_R16_SCREEN = 7, KERNEL_R8_W8 = 8, KERNEL_R16_FAST = 9 };
+enum { KERNEL_GENERIC = 0, KERNEL_R16_N4096 = 1, KERNEL_R16_PIPE = 4, KERNEL_R16_OCC4 = 5, KERNEL_R16_OCC3 = 6, KERNEL_R16_SCREEN = 7, KERNEL_R8_W8 = 8, KERNEL_R16_FAST = 9, KERNEL_STOCKHAM = 10 };
 
 struct FusedParams {
     const double *rows; // M x N row-major, row stride `stride` doubles
@@ -47,6 +47,7 @@ struct FusedParams {
     double screen_delta; // candidate window below the fp32 maximum (scaled units, max |cc| <= 1)
     int *ovf_count;      // pairs with too many candidates: redone by the fp64 kernel
     int *work_counter;   // dynamic pair hand-out (xcorr_r16_fast.hip, DYN): zeroed before the launch
+    int tune;            // experiment bits (MUSE_HIP_FAST_TUNE); 0 in production
     long long *ovf_list;
     // optional indirection for the fp64 kernels: process pair_list[0 .. *pair_count)
     const long long *pair_list;
@@ -60,6 +61,7 @@ hipError_t launch_fused_screen(const FusedParams &p, int num_cus, hipStream_t st
 hipError_t launch_fused_w8(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_r8_w8.hip
 hipError_t launch_fused_fast(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_r16_fast.hip (N == n == 4096)
 hipError_t launch_fused_multi(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_r16_fast.hip (R references)
+hipError_t launch_fused_stockham(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_stockham.hip (n = 512 .. 2048)
 // out[256 k + t] = in[256 k + (t >> 4) + 16 (t & 15)], k < 16: a 4096-entry table in the lane order of xcorr_r16_fast.hip
 hipError_t launch_lane_order(const double2 *in, double2 *out, hipStream_t stream);
 hipError_t launch_ref_spectrum(const double *ref_dev, int N, int n, int logn, int normalize, double x_scale,

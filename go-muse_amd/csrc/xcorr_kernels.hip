@@ -611,6 +611,8 @@ hipError_t launch_fused(const FusedParams &p, int variant, int num_cus, hipStrea
         return hipSuccess;
     if (variant == KERNEL_R16_FAST)
         return launch_fused_fast(p, num_cus, stream);
+    if (variant == KERNEL_STOCKHAM)
+        return launch_fused_stockham(p, num_cus, stream);
     if (variant == KERNEL_R8_W8)
         return launch_fused_w8(p, num_cus, stream);
     if (variant == KERNEL_R16_SCREEN)

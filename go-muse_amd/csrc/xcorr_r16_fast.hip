@@ -921,16 +921,19 @@ hipError_t launch_fused_fast(const FusedParams &p, int num_cus, hipStream_t stre
     int dyn = 1;
     if (const char *d = getenv("MUSE_HIP_FAST_DYN")) // tuning aid
         dyn = atoi(d) != 0;
+    FusedParams q = p;
+    if (const char *d = getenv("MUSE_HIP_FAST_TUNE")) // tuning aid: experiment bits
+        q.tune = atoi(d);
     if (dyn && p.work_counter) {
         grid = std::min<long long>(p.npairs, (long long)num_cus * wps); // resident workgroups only
         if (wps == 4)
-            hipLaunchKernelGGL((xcorr_fused_n4096_fast<4, false, true>), dim3((unsigned)grid), dim3(OCC_THREADS), 0, stream, p);
+            hipLaunchKernelGGL((xcorr_fused_n4096_fast<4, false, true>), dim3((unsigned)grid), dim3(OCC_THREADS), 0, stream, q);
         else
-            hipLaunchKernelGGL((xcorr_fused_n4096_fast<3, false, true>), dim3((unsigned)grid), dim3(OCC_THREADS), 0, stream, p);
+            hipLaunchKernelGGL((xcorr_fused_n4096_fast<3, false, true>), dim3((unsigned)grid), dim3(OCC_THREADS), 0, stream, q);
     } else if (wps == 4)
-        hipLaunchKernelGGL((xcorr_fused_n4096_fast<4, false>), dim3((unsigned)grid), dim3(OCC_THREADS), 0, stream, p);
+        hipLaunchKernelGGL((xcorr_fused_n4096_fast<4, false>), dim3((unsigned)grid), dim3(OCC_THREADS), 0, stream, q);
     else
-        hipLaunchKernelGGL((xcorr_fused_n4096_fast<3, false>), dim3((unsigned)grid), dim3(OCC_THREADS), 0, stream, p);
+        hipLaunchKernelGGL((xcorr_fused_n4096_fast<3, false>), dim3((unsigned)grid), dim3(OCC_THREADS), 0, stream, q);
     return hipGetLastError();
 }
 

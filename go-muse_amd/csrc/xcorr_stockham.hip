@@ -1,0 +1,391 @@
+// xcorr_stockham.hip -- radix-16 Stockham kernels for the FFT lengths the tuned
+// n = 4096 kernels do not cover (BASELINE config 5: N in {512 ... 65536}).
+//
+// Mathematics: as xcorr_fused_n4096 (xcorr_kernels.hip header); reference path
+// xCorrWithX, /root/reference/xcorr.go:160-197.  Two real series per complex
+// transform, two FORWARD transforms per pair.
+//
+// Transform structure.  n = R1 * 16^(NP-1), R1 = 2, 4, 8 or 16.  Every thread owns 16
+// points x[j + i*S], S = n/16.  Forward transform = NP Stockham (autosort, decimation in
+// time) passes; pass p has radix R (R1 for the first, 16 after), Ns = product of the
+// earlier radices, and for butterfly q computes
+//     y[(q / Ns) * Ns * R + (q % Ns) + r * Ns] = sum_s W_R^(r s) W_(Ns R)^(s (q % Ns)) x[q + s * n / R]
+// (Ns = 1: no twiddles; R < 16: a thread runs 16/R butterflies q = j + m*S on the registers
+// m + s*(16/R)).  The last pass leaves X[j + r*S] in the thread that owns j: the natural
+// layout again, so the spectrum multiply needs no exchange.
+// The second transform runs the TRANSPOSED passes in reverse order (the DFT matrix is
+// symmetric: F = M_NP ... M_1 = M_1^T ... M_NP^T): pass p^T reads the positions pass p
+// wrote, applies the same radix-R DFT, multiplies by the twiddle AFTER the butterfly and
+// writes the positions pass p read.  It therefore starts from the layout the first
+// transform ended in and ends with cc[j + i*S] in register i of thread j.
+// Twiddles W^(s m), s = 1..15: W^m, W^2m, W^4m, W^8m come from the context's W_65536 table
+// (8 m * 65536/(16 Ns) < 32768: always inside the half-period table), the other eleven are
+// products of two of them (2 ulp; the parity bar is 1e-6).
+//
+// xcorr_fused_stk_lds<LOGN> (n = 512, 1024, 2048): n/16 threads per pair, 4096/n pairs per
+// 256-thread workgroup, one padded LDS work buffer per pair (pos + pos/16: the Ns = 1 pass
+// writes with a lane stride of R1 slots), three passes per transform, 11 barriers per
+// workgroup iteration.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <algorithm>
+
+#include "r16_device.h"
+
+namespace muse {
+
+namespace stk {
+
+using namespace occ4;
+
+// ------------------------------------------------------------ small DFTs (in place, natural order)
+__device__ __forceinline__ void dft2(double2 &a, double2 &b)
+{
+    const double2 t = a;
+    a = cadd(t, b);
+    b = csub(t, b);
+}
+__device__ __forceinline__ void dft4(double2 &a, double2 &b, double2 &c, double2 &d)
+{
+    // X0 = a+b+c+d, X1 = a - i b - c + i d, X2 = a-b+c-d, X3 = a + i b - c - i d
+    const double2 t0 = cadd(a, c), t1 = csub(a, c), t2 = cadd(b, d), t3 = csub(b, d);
+    a = cadd(t0, t2);
+    c = csub(t0, t2);
+    b = make_double2(t1.x + t3.y, t1.y - t3.x);
+    d = make_double2(t1.x - t3.y, t1.y + t3.x);
+}
+__device__ __forceinline__ void dft8(double2 &x0, double2 &x1, double2 &x2, double2 &x3, double2 &x4, double2 &x5,
+                                     double2 &x6, double2 &x7)
+{
+    constexpr double H = 0.70710678118654752440;
+    // radix-2 over the high input bit, twiddle W8^k on the odd half, two radix-4s
+    double2 e0 = cadd(x0, x4), e1 = cadd(x1, x5), e2 = cadd(x2, x6), e3 = cadd(x3, x7);
+    double2 o0 = csub(x0, x4), o1 = csub(x1, x5), o2 = csub(x2, x6), o3 = csub(x3, x7);
+    o1 = make_double2((o1.x + o1.y) * H, (o1.y - o1.x) * H); // * W8^1
+    o2 = make_double2(o2.y, -o2.x);                          // * W8^2 = -i
+    o3 = make_double2((o3.y - o3.x) * H, -(o3.x + o3.y) * H); // * W8^3
+    dft4(e0, e1, e2, e3); // X[0], X[2], X[4], X[6]
+    dft4(o0, o1, o2, o3); // X[1], X[3], X[5], X[7]
+    x0 = e0; x2 = e1; x4 = e2; x6 = e3;
+    x1 = o0; x3 = o1; x5 = o2; x7 = o3;
+}
+
+// 16/R independent radix-R DFTs on the registers m + s*(16/R) (in place, natural order)
+template <int R>
+__device__ __forceinline__ void dft_small(double2 (&v)[16])
+{
+    constexpr int Q = 16 / R;
+#pragma unroll
+    for (int m = 0; m < Q; m++) {
+        if (R == 2)
+            dft2(v[m], v[m + Q]);
+        else if (R == 4)
+            dft4(v[m], v[m + Q], v[m + 2 * Q], v[m + 3 * Q]);
+        else if (R == 8)
+            dft8(v[m], v[m + Q], v[m + 2 * Q], v[m + 3 * Q], v[m + 4 * Q], v[m + 5 * Q], v[m + 6 * Q], v[m + 7 * Q]);
+    }
+}
+
+// w[s] = W_(16 Ns)^(s m), s = 1..15, from the W_65536 half-period table
+__device__ __forceinline__ void tw_powers(double2 (&w)[16], const double2 *__restrict__ twm, int m, int ns16)
+{
+    const int i1 = m * (65536 / ns16);
+    w[1] = twm[i1];
+    w[2] = twm[2 * i1];
+    w[4] = twm[4 * i1];
+    w[8] = twm[8 * i1];
+    w[3] = cmul(w[1], w[2]);
+    w[5] = cmul(w[1], w[4]);
+    w[6] = cmul(w[2], w[4]);
+    w[7] = cmul(w[3], w[4]);
+    w[9] = cmul(w[1], w[8]);
+    w[10] = cmul(w[2], w[8]);
+    w[11] = cmul(w[3], w[8]);
+    w[12] = cmul(w[4], w[8]);
+    w[13] = cmul(w[5], w[8]);
+    w[14] = cmul(w[6], w[8]);
+    w[15] = cmul(w[7], w[8]);
+}
+
+// forward radix-16 pass on natural-order registers: pre-twiddle, DFT; output r at v[P16(r)]
+__device__ __forceinline__ void fwd16(double2 (&v)[16], const double2 *__restrict__ twm, int m, int ns16)
+{
+    if (ns16 > 16) { // Ns > 1
+        double2 w[16];
+        tw_powers(w, twm, m, ns16);
+#pragma unroll
+        for (int s = 1; s < 16; s++)
+            v[s] = cmul(v[s], w[s]);
+    }
+    dft16(v);
+}
+// transposed radix-16 pass on natural-order registers: DFT, post-twiddle; output s at v[P16(s)]
+__device__ __forceinline__ void trn16(double2 (&v)[16], const double2 *__restrict__ twm, int m, int ns16)
+{
+    dft16(v);
+    if (ns16 > 16) {
+        double2 w[16];
+        tw_powers(w, twm, m, ns16);
+#pragma unroll
+        for (int s = 1; s < 16; s++)
+            v[P16(s)] = cmul(v[P16(s)], w[s]);
+    }
+}
+
+// sums / max / min over each 16-lane row (every lane of the row gets the result)
+__device__ __forceinline__ double row_sum_dpp(double v)
+{
+    v += dpp_f64<0xB1>(v);
+    v += dpp_f64<0x4E>(v);
+    v += dpp_f64<0x141>(v);
+    v += dpp_f64<0x140>(v);
+    return v;
+}
+__device__ __forceinline__ double row_max_dpp(double v)
+{
+    v = fmax(v, dpp_f64<0xB1>(v));
+    v = fmax(v, dpp_f64<0x4E>(v));
+    v = fmax(v, dpp_f64<0x141>(v));
+    v = fmax(v, dpp_f64<0x140>(v));
+    return v;
+}
+__device__ __forceinline__ int row_min_i_dpp(int v)
+{
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));
+    return v;
+}
+
+__device__ __forceinline__ int padpos(int pos) { return pos + (pos >> 4); }
+
+} // namespace stk
+
+template <int LOGN>
+__global__ __launch_bounds__(256, 2) void xcorr_fused_stk_lds(const FusedParams p)
+{
+    using namespace occ4;
+    using namespace stk;
+    constexpr int n = 1 << LOGN;
+    constexpr int S = n / 16;      // threads per pair = stride between a thread's points
+    constexpr int G = 256 / S;     // pairs per workgroup iteration
+    constexpr int R1 = n / 256;    // first radix (2, 4, 8); passes 2 and 3 are radix 16
+    constexpr int Q1 = 16 / R1;    // butterflies per thread in the radix-R1 pass
+    constexpr int ROWS = S / 16;   // 16-lane rows per pair
+    constexpr int BUF = n + n / 16;
+    static_assert(LOGN >= 9 && LOGN <= 11, "LDS Stockham kernel: n = 512, 1024, 2048");
+    __shared__ double2 buf[G * BUF];
+    __shared__ double red[16 * 4];      // per 16-lane row: {sum dA, sum dA^2, sum dB, sum dB^2}
+    __shared__ double arg[16 * 2 * 3];  // per row and series: {max |cc|, signed value, index}
+    const int t = threadIdx.x;
+    const int g = t / S, j = t % S;
+    const int row = t >> 4;             // global 16-lane row id; pair g owns rows g*ROWS .. +ROWS
+    double2 *const b = buf + g * BUF;
+    const int N = p.N, pad = n - N;
+    const double invN = 1.0 / (double)N, invNm1 = 1.0 / (double)(N - 1);
+    const double2 *__restrict__ twm = p.twm;
+    const long long ngroups = (p.npairs + G - 1) / G;
+
+    for (long long it = blockIdx.x; it < ngroups; it += gridDim.x) {
+        const long long pair_raw = it * G + g;
+        const bool live = pair_raw < p.npairs;
+        const long long pair = live ? pair_raw : p.npairs - 1; // idle sub-groups shadow the last pair
+        const long long rA = 2 * pair;
+        const bool hasB = rA + 1 < p.M;
+        const double *__restrict__ ra = p.rows + rA * p.stride;
+        const double *__restrict__ rb = p.rows + (hasB ? rA + 1 : rA) * p.stride;
+        // ---- rows (leading zero pad), d = x - K with K the first sample, shifted statistics
+        double2 v[16];
+        const double KA = ra[0], KB = rb[0];
+        double q[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int e = j + i * S - pad;
+            const int ec = e < 0 ? 0 : e;
+            double da = __builtin_nontemporal_load(ra + ec) - KA, db = __builtin_nontemporal_load(rb + ec) - KB;
+            da = e >= 0 ? da : 0.0;
+            db = e >= 0 ? db : 0.0;
+            v[i] = make_double2(da, db);
+            q[0] += da;
+            q[1] = fma(da, da, q[1]);
+            q[2] += db;
+            q[3] = fma(db, db, q[3]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            q[k] = row_sum_dpp(q[k]);
+        if ((t & 15) == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                red[row * 4 + k] = q[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            double s = 0.0;
+#pragma unroll
+            for (int r = 0; r < ROWS; r++)
+                s += red[(g * ROWS + r) * 4 + k];
+            q[k] = s;
+        }
+        const Stat stA{q[0], q[1]}, stB{q[2], q[3]};
+        bool zeroA, nanA, zeroB, nanB;
+        const double varA = variance(stA, invN, invNm1, zeroA, nanA);
+        const double varB = variance(stB, invN, invNm1, zeroB, nanB);
+        const double mA = q[0] * invN, mB = q[2] * invN;
+        const bool deadA = zeroA || nanA, deadB = zeroB || nanB || !hasB;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const bool valid = j + i * S - pad >= 0;
+            v[i].x = (valid && !deadA) ? v[i].x - mA : 0.0;
+            v[i].y = (valid && !deadB) ? v[i].y - mB : 0.0;
+        }
+        // ================= forward transform =================
+        dft_small<R1>(v); // pass 1: Ns = 1, butterflies q = j + m S on registers m + s Q1
+#pragma unroll
+        for (int m = 0; m < Q1; m++)
+#pragma unroll
+            for (int r = 0; r < R1; r++)
+                b[padpos((j + m * S) * R1 + r)] = v[m + r * Q1];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            v[i] = b[padpos(j + i * S)];
+        fwd16(v, twm, j % R1, 16 * R1); // pass 2: Ns = R1
+        __syncthreads();
+        {
+            const int base = (j / R1) * (16 * R1) + (j % R1);
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                b[padpos(base + r * R1)] = v[P16(r)];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            v[i] = b[padpos(j + i * S)];
+        fwd16(v, twm, j, n); // pass 3: Ns = S, q % Ns = j; output X[j + r S] at v[P16(r)]
+        // ================= V = Z conj(X)/n, second transform (transposed passes) =================
+        {
+            double2 w[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                w[r] = cmul(v[P16(r)], p.xc[j + r * S]);
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                v[r] = w[r];
+        }
+        trn16(v, twm, j, n); // pass 3^T: output s at v[P16(s)] -> position j + s S
+        __syncthreads();     // every thread is past its last read of the buffer
+#pragma unroll
+        for (int s = 0; s < 16; s++)
+            b[padpos(j + s * S)] = v[P16(s)];
+        __syncthreads();
+        {
+            const int base = (j / R1) * (16 * R1) + (j % R1);
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                v[r] = b[padpos(base + r * R1)];
+        }
+        trn16(v, twm, j % R1, 16 * R1); // pass 2^T
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < 16; s++)
+            b[padpos(j + s * S)] = v[P16(s)];
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < Q1; m++)
+#pragma unroll
+            for (int r = 0; r < R1; r++)
+                v[m + r * Q1] = b[padpos((j + m * S) * R1 + r)];
+        dft_small<R1>(v); // pass 1^T: register i holds cc[j + i S] (re: series A, im: series B)
+        // ================= maxAbsIndex (xcorr.go:39-50) per series =================
+        double ma = 0.0, mb = 0.0, sa = 0.0, sb = 0.0;
+        int ia = 0x7fffffff, ib = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < 16; i++) { // ascending i = ascending index for this thread
+            const double aa = fabs(v[i].x), ab = fabs(v[i].y);
+            if (aa > ma) { ma = aa; sa = v[i].x; ia = j + i * S; }
+            if (ab > mb) { mb = ab; sb = v[i].y; ib = j + i * S; }
+        }
+        {
+            const double rma = row_max_dpp(ma), rmb = row_max_dpp(mb);
+            const int ca = row_min_i_dpp((ma == rma && rma > 0.0) ? ia : 0x7fffffff);
+            const int cb = row_min_i_dpp((mb == rmb && rmb > 0.0) ? ib : 0x7fffffff);
+            if (ca == 0x7fffffff) {
+                if ((t & 15) == 0) {
+                    arg[row * 6 + 0] = 0.0;
+                    arg[row * 6 + 1] = 0.0;
+                    arg[row * 6 + 2] = (double)0x7fffffff;
+                }
+            } else if (ia == ca && ma == rma) {
+                arg[row * 6 + 0] = rma;
+                arg[row * 6 + 1] = sa;
+                arg[row * 6 + 2] = (double)ca;
+            }
+            if (cb == 0x7fffffff) {
+                if ((t & 15) == 0) {
+                    arg[row * 6 + 3] = 0.0;
+                    arg[row * 6 + 4] = 0.0;
+                    arg[row * 6 + 5] = (double)0x7fffffff;
+                }
+            } else if (ib == cb && mb == rmb) {
+                arg[row * 6 + 3] = rmb;
+                arg[row * 6 + 4] = sb;
+                arg[row * 6 + 5] = (double)cb;
+            }
+        }
+        if (j == 0) // cc[0] of both series, for the "nothing above zero" case (index 0, mv = cc[0])
+            red[g * ROWS * 4] = v[0].x, red[g * ROWS * 4 + 1] = v[0].y;
+        __syncthreads();
+        if (j < 2 && live && (j == 0 || hasB)) {
+            double best = 0.0, bsv = 0.0, bidx = (double)0x7fffffff;
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) {
+                const double *a = arg + (g * ROWS + r) * 6 + 3 * j;
+                if (a[0] > best || (a[0] == best && a[2] < bidx)) {
+                    best = a[0];
+                    bsv = a[1];
+                    bidx = a[2];
+                }
+            }
+            const double var = j == 0 ? varA : varB;
+            const bool zero = j == 0 ? zeroA : zeroB, nan = j == 0 ? nanA : nanB;
+            const int idx = (best > 0.0) ? (int)bidx : 0;
+            double y = __builtin_amdgcn_rsq(var);
+            y = y * fma(-0.5 * var * y, y, 1.5);
+            y = y * fma(-0.5 * var * y, y, 1.5);
+            double mv = ((best > 0.0) ? bsv : red[g * ROWS * 4 + j]) * y;
+            int lag = idx > n / 2 ? idx - n : idx;
+            if (zero) { mv = 0.0; lag = 0; }
+            if (nan) { mv = __builtin_nan(""); lag = 0; }
+            p.mv[rA + j] = mv;
+            p.lag[rA + j] = lag;
+        }
+        __syncthreads(); // red / arg / buf free for the next iteration
+    }
+}
+
+template <int LOGN>
+static hipError_t launch_stk_lds(const FusedParams &p, int num_cus, hipStream_t stream)
+{
+    constexpr int G = 256 / ((1 << LOGN) / 16);
+    const long long ngroups = (p.npairs + G - 1) / G;
+    const long long grid = std::min<long long>(ngroups, (long long)num_cus * 2 * 8);
+    hipLaunchKernelGGL((xcorr_fused_stk_lds<LOGN>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+// n = 512, 1024, 2048 (any N in (n/2, n])
+hipError_t launch_fused_stockham(const FusedParams &p, int num_cus, hipStream_t stream)
+{
+    switch (p.logn) {
+    case 9: return launch_stk_lds<9>(p, num_cus, stream);
+    case 10: return launch_stk_lds<10>(p, num_cus, stream);
+    case 11: return launch_stk_lds<11>(p, num_cus, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+} // namespace muse

@@ -566,3 +566,29 @@ def test_many_references_large(muse, eng):
         slag, smv = batches[r].scores()
         assert np.array_equal(got[r][0], slag), r
         np.testing.assert_allclose(got[r][1], smv, rtol=1e-11, atol=0, equal_nan=True)
+
+
+@pytest.mark.parametrize("N", [257, 480, 512, 700, 1000, 1024, 1025, 1500, 2048])
+def test_stockham_kernels_match_oracle_and_generic(muse, eng, oracle, N):
+    """n = 512, 1024, 2048: the radix-16 Stockham kernel (auto / variant 11) against the oracle and
+    the radix-2 generic kernel (variant 1) on the same rows, incl. N < n padding, sigma == 0,
+    NaN / Inf rows, an odd row count and more pairs than one workgroup iteration holds."""
+    M = 83
+    ref, rows = _rows(M, N, 31 * N)
+    rows[10, 5 % N] = np.nan
+    rows[12, :] = np.inf
+    rows[20, :] = 2.0 ** 600
+    dg = muse.DeviceGroup.from_rows(eng, rows)
+    db = muse.DeviceBatch(eng, dg, ref)
+    olag, omv, gap = oracle.batch_scores(ref, rows)
+    try:
+        got = {}
+        for variant in (0, 11, 1):
+            eng.set_kernel(variant)
+            lag, mv = db.scores()
+            assert math.isnan(mv[10]) and lag[10] == 0 and math.isnan(mv[12]) and lag[12] == 0, variant
+            assert_scores_match(lag, mv, olag, omv, gap)
+            got[variant] = (lag, mv)
+        assert np.array_equal(got[0][0], got[11][0]) and np.array_equal(got[0][1], got[11][1], equal_nan=True)
+    finally:
+        eng.set_kernel(0)
