@@ -621,8 +621,8 @@ extern "C" int muse_batch_create(muse_ctx *ctx, muse_group *g, const double *ref
         e = hipMalloc(&b->xs, (size_t)n * sizeof(double));
     if (e == hipSuccess)
         e = hipMalloc(&b->ovf_count, 2 * sizeof(int)); // [0] overflow-pair count, [1] dynamic work counter
-    if (e == hipSuccess && n > GENERIC_LDS_MAX_N)
-        e = hipMalloc(&b->gscratch, (size_t)ctx->num_cus * GENERIC_GLOBAL_WGS_PER_CU * (size_t)n * sizeof(double2));
+    if (e == hipSuccess && n >= GENERIC_LDS_MAX_N) // generic kernel above 8192: one slice per workgroup; Stockham from 8192: two
+        e = hipMalloc(&b->gscratch, (size_t)ctx->num_cus * std::max(GENERIC_GLOBAL_WGS_PER_CU, 2 * STOCKHAM_GLOBAL_WGS_PER_CU) * (size_t)n * sizeof(double2));
     if (e != hipSuccess) {
         muse_batch_free(b);
         return fail(MUSE_ERR_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e));
@@ -758,9 +758,11 @@ extern "C" int muse_batch_score(muse_batch *b)
         }
         if (variant == KERNEL_R16_FAST && b->N != 4096) // the deferred-statistics kernel is built for N == n only
             variant = KERNEL_R16_OCC3;
-    } else if (b->n >= 512 && b->n <= 2048 && (ctx->variant == 0 || ctx->variant == 11)) {
-        variant = KERNEL_STOCKHAM; // radix-16 Stockham through LDS (xcorr_stockham.hip)
+    } else if (((b->n >= 512 && b->n <= 2048) || b->n >= 8192) && (ctx->variant == 0 || ctx->variant == 11)) {
+        variant = KERNEL_STOCKHAM; // radix-16 Stockham through LDS / global scratch (xcorr_stockham.hip)
     }
+    if (variant == KERNEL_GENERIC && b->n <= GENERIC_LDS_MAX_N)
+        p.gscratch = nullptr; // the generic kernel takes a non-NULL scratch pointer as "work in global memory"
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->timing) {
         HIP_TRY(hipEventCreate(&e0));

@@ -61,7 +61,7 @@ hipError_t launch_fused_screen(const FusedParams &p, int num_cus, hipStream_t st
 hipError_t launch_fused_w8(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_r8_w8.hip
 hipError_t launch_fused_fast(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_r16_fast.hip (N == n == 4096)
 hipError_t launch_fused_multi(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_r16_fast.hip (R references)
-hipError_t launch_fused_stockham(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_stockham.hip (n = 512 .. 2048)
+hipError_t launch_fused_stockham(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_stockham.hip (n = 512 .. 2048, 8192 .. 65536)
 // out[256 k + t] = in[256 k + (t >> 4) + 16 (t & 15)], k < 16: a 4096-entry table in the lane order of xcorr_r16_fast.hip
 hipError_t launch_lane_order(const double2 *in, double2 *out, hipStream_t stream);
 hipError_t launch_ref_spectrum(const double *ref_dev, int N, int n, int logn, int normalize, double x_scale,
@@ -70,6 +70,7 @@ hipError_t launch_ref_spectrum(const double *ref_dev, int N, int n, int logn, in
 constexpr int GENERIC_LDS_MAX_N = 8192;  // larger n: the radix-2 passes run in gscratch
 constexpr int GENERIC_MAX_N = 65536;
 constexpr int GENERIC_GLOBAL_WGS_PER_CU = 2;
+constexpr int STOCKHAM_GLOBAL_WGS_PER_CU = 2; // each holds two n-element complex scratch slices
 hipError_t launch_direct(const double *x, int lenx, const double *y, int leny, int n, int normalize_x,
                          int normalize_y, double x_scale, double cc_scale, double *cc, int *lag, double *mv,
                          int *status, hipStream_t stream);

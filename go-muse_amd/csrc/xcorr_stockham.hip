@@ -75,6 +75,17 @@ __device__ __forceinline__ void dft8(double2 &x0, double2 &x1, double2 &x2, doub
 template <int R>
 __device__ __forceinline__ void dft_small(double2 (&v)[16])
 {
+    if (R == 16) { // one radix-16 DFT, un-permuted to natural order (register renaming only)
+        dft16(v);
+        double2 w[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            w[r] = v[P16(r)];
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            v[r] = w[r];
+        return;
+    }
     constexpr int Q = 16 / R;
 #pragma unroll
     for (int m = 0; m < Q; m++) {
@@ -164,21 +175,24 @@ __device__ __forceinline__ int padpos(int pos) { return pos + (pos >> 4); }
 } // namespace stk
 
 template <int LOGN>
-__global__ __launch_bounds__(256, 2) void xcorr_fused_stk_lds(const FusedParams p)
+__global__ __launch_bounds__(((1 << LOGN) / 16 > 256 ? (1 << LOGN) / 16 : 256), ((1 << LOGN) / 16 > 256 ? 1 : 2))
+void xcorr_fused_stk_lds(const FusedParams p)
 {
     using namespace occ4;
     using namespace stk;
     constexpr int n = 1 << LOGN;
-    constexpr int S = n / 16;      // threads per pair = stride between a thread's points
-    constexpr int G = 256 / S;     // pairs per workgroup iteration
-    constexpr int R1 = n / 256;    // first radix (2, 4, 8); passes 2 and 3 are radix 16
-    constexpr int Q1 = 16 / R1;    // butterflies per thread in the radix-R1 pass
-    constexpr int ROWS = S / 16;   // 16-lane rows per pair
+    constexpr int S = n / 16;                 // threads per pair = stride between a thread's points
+    constexpr int G = S >= 256 ? 1 : 256 / S; // pairs per workgroup iteration
+    constexpr int TPB = S * G;                // 256 (n <= 4096) or 512 (n = 8192)
+    constexpr int NP = (LOGN + 3) / 4;        // passes per transform: radix R1, then radix 16
+    constexpr int R1 = n >> (4 * (NP - 1));   // first radix (2, 4, 8 or 16)
+    constexpr int Q1 = 16 / R1;               // butterflies per thread in the radix-R1 pass
+    constexpr int ROWS = S / 16;              // 16-lane rows per pair
     constexpr int BUF = n + n / 16;
-    static_assert(LOGN >= 9 && LOGN <= 11, "LDS Stockham kernel: n = 512, 1024, 2048");
+    static_assert((LOGN >= 9 && LOGN <= 11) || LOGN == 13, "LDS Stockham kernel: n = 512, 1024, 2048, 8192");
     __shared__ double2 buf[G * BUF];
-    __shared__ double red[16 * 4];      // per 16-lane row: {sum dA, sum dA^2, sum dB, sum dB^2}
-    __shared__ double arg[16 * 2 * 3];  // per row and series: {max |cc|, signed value, index}
+    __shared__ double red[(TPB / 16) * 4];      // per 16-lane row: {sum dA, sum dA^2, sum dB, sum dB^2}
+    __shared__ double arg[(TPB / 16) * 2 * 3];  // per row and series: {max |cc|, signed value, index}
     const int t = threadIdx.x;
     const int g = t / S, j = t % S;
     const int row = t >> 4;             // global 16-lane row id; pair g owns rows g*ROWS .. +ROWS
@@ -225,7 +239,6 @@ __global__ __launch_bounds__(256, 2) void xcorr_fused_stk_lds(const FusedParams 
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             double s = 0.0;
-#pragma unroll
             for (int r = 0; r < ROWS; r++)
                 s += red[(g * ROWS + r) * 4 + k];
             q[k] = s;
@@ -251,21 +264,24 @@ __global__ __launch_bounds__(256, 2) void xcorr_fused_stk_lds(const FusedParams 
                 b[padpos((j + m * S) * R1 + r)] = v[m + r * Q1];
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 16; i++)
-            v[i] = b[padpos(j + i * S)];
-        fwd16(v, twm, j % R1, 16 * R1); // pass 2: Ns = R1
-        __syncthreads();
-        {
-            const int base = (j / R1) * (16 * R1) + (j % R1);
+        for (int pp = 2; pp <= NP; pp++) { // radix-16 passes, Ns = R1 16^(pp-2); the last has Ns = S
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int Ns = R1 << (4 * (pp - 2));
 #pragma unroll
-            for (int r = 0; r < 16; r++)
-                b[padpos(base + r * R1)] = v[P16(r)];
+            for (int i = 0; i < 16; i++)
+                v[i] = b[padpos(j + i * S)];
+            fwd16(v, twm, j % Ns, 16 * Ns);
+            if (pp < NP) {
+                __syncthreads(); // every thread has read its inputs
+                const int base = (j / Ns) * (16 * Ns) + (j % Ns);
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    b[padpos(base + r * Ns)] = v[P16(r)];
+                __syncthreads();
+            }
         }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 16; i++)
-            v[i] = b[padpos(j + i * S)];
-        fwd16(v, twm, j, n); // pass 3: Ns = S, q % Ns = j; output X[j + r S] at v[P16(r)]
+        // output X[j + r S] at v[P16(r)]
         // ================= V = Z conj(X)/n, second transform (transposed passes) =================
         {
             double2 w[16];
@@ -276,24 +292,23 @@ __global__ __launch_bounds__(256, 2) void xcorr_fused_stk_lds(const FusedParams 
             for (int r = 0; r < 16; r++)
                 v[r] = w[r];
         }
-        trn16(v, twm, j, n); // pass 3^T: output s at v[P16(s)] -> position j + s S
-        __syncthreads();     // every thread is past its last read of the buffer
 #pragma unroll
-        for (int s = 0; s < 16; s++)
-            b[padpos(j + s * S)] = v[P16(s)];
-        __syncthreads();
-        {
-            const int base = (j / R1) * (16 * R1) + (j % R1);
+        for (int pp = NP; pp >= 2; pp--) {
+            const int Ns = R1 << (4 * (pp - 2));
+            trn16(v, twm, j % Ns, 16 * Ns); // pass pp^T: output s at v[P16(s)] -> position j + s S
+            __syncthreads();                // every thread is past its last read of the buffer
 #pragma unroll
-            for (int r = 0; r < 16; r++)
-                v[r] = b[padpos(base + r * R1)];
+            for (int s = 0; s < 16; s++)
+                b[padpos(j + s * S)] = v[P16(s)];
+            __syncthreads();
+            if (pp > 2) { // read the positions pass pp-1 wrote
+                const int Np = R1 << (4 * (pp - 3));
+                const int base = (j / Np) * (16 * Np) + (j % Np);
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    v[r] = b[padpos(base + r * Np)];
+            }
         }
-        trn16(v, twm, j % R1, 16 * R1); // pass 2^T
-        __syncthreads();
-#pragma unroll
-        for (int s = 0; s < 16; s++)
-            b[padpos(j + s * S)] = v[P16(s)];
-        __syncthreads();
 #pragma unroll
         for (int m = 0; m < Q1; m++)
 #pragma unroll
@@ -367,23 +382,275 @@ __global__ __launch_bounds__(256, 2) void xcorr_fused_stk_lds(const FusedParams 
     }
 }
 
+// ---------------------------------------------------------------------------
+// xcorr_fused_stk_glb<LOGN> (n = 8192 ... 65536): one pair per 256-thread workgroup at a
+// time, four passes per transform, the work buffers are two n-element complex slices of a
+// global scratch buffer per workgroup (ping-pong; L2 / Infinity-Cache traffic, ordered by
+// __syncthreads as in the radix-2 generic kernel).  Every thread walks n/4096 chunks of 16
+// points per pass.  The last forward pass, the spectrum multiply and the first transposed
+// pass are fused in registers; the last transposed pass feeds the argmax without a store:
+// 13 buffer sweeps per pair (radix 2: 2 log2 n + 3 = 29 ... 35).
 template <int LOGN>
-static hipError_t launch_stk_lds(const FusedParams &p, int num_cus, hipStream_t stream)
+__global__ __launch_bounds__(256, 2) void xcorr_fused_stk_glb(const FusedParams p)
 {
-    constexpr int G = 256 / ((1 << LOGN) / 16);
-    const long long ngroups = (p.npairs + G - 1) / G;
-    const long long grid = std::min<long long>(ngroups, (long long)num_cus * 2 * 8);
-    hipLaunchKernelGGL((xcorr_fused_stk_lds<LOGN>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    using namespace occ4;
+    using namespace stk;
+    constexpr int n = 1 << LOGN;
+    constexpr int S = n / 16;
+    constexpr int CH = S / 256;      // chunks per thread and pass
+    constexpr int R1 = n / 4096;     // first radix (2, 4, 8, 16); passes 2-4 are radix 16
+    constexpr int Q1 = 16 / R1;
+    constexpr int NS2 = R1, NS3 = 16 * R1; // Ns of passes 2 and 3 (pass 4: Ns = 256 R1 = S)
+    static_assert(LOGN >= 14 && LOGN <= 16, "global Stockham kernel: n = 16384 ... 65536");
+    __shared__ double red[64];
+    __shared__ int redi[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    double2 *const X0 = p.gscratch + (size_t)blockIdx.x * (size_t)(2 * n);
+    double2 *const X1 = X0 + n;
+    const int N = p.N, pad = n - N;
+    const double invN = 1.0 / (double)N, invNm1 = 1.0 / (double)(N - 1);
+    const double2 *__restrict__ twm = p.twm;
+
+    for (long long pair = blockIdx.x; pair < p.npairs; pair += gridDim.x) {
+        const long long rA = 2 * pair;
+        const bool hasB = rA + 1 < p.M;
+        const double *__restrict__ ra = p.rows + rA * p.stride;
+        const double *__restrict__ rb = p.rows + (hasB ? rA + 1 : rA) * p.stride;
+        const double KA = ra[0], KB = rb[0];
+        // ---- sweep 0: rows -> d = x - K (leading zero pad) into X0, shifted statistics
+        double q[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma clang loop unroll(disable)
+        for (int ch = 0; ch < CH; ch++) {
+            const int j = t + 256 * ch;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int e = j + i * S - pad;
+                const int ec = e < 0 ? 0 : e;
+                double da = __builtin_nontemporal_load(ra + ec) - KA, db = __builtin_nontemporal_load(rb + ec) - KB;
+                da = e >= 0 ? da : 0.0;
+                db = e >= 0 ? db : 0.0;
+                X0[j + i * S] = make_double2(da, db);
+                q[0] += da;
+                q[1] = fma(da, da, q[1]);
+                q[2] += db;
+                q[3] = fma(db, db, q[3]);
+            }
+        }
+        block_sum<4>(q, red); // includes the barrier that orders sweep 0 before pass 1
+        const Stat stA{q[0], q[1]}, stB{q[2], q[3]};
+        bool zeroA, nanA, zeroB, nanB;
+        const double varA = variance(stA, invN, invNm1, zeroA, nanA);
+        const double varB = variance(stB, invN, invNm1, zeroB, nanB);
+        const double mA = q[0] * invN, mB = q[2] * invN;
+        const bool deadA = zeroA || nanA, deadB = zeroB || nanB || !hasB;
+        // ---- pass 1 (radix R1, Ns = 1): X0 -> X1, mean removed on the way in
+#pragma clang loop unroll(disable)
+        for (int ch = 0; ch < CH; ch++) {
+            const int j = t + 256 * ch;
+            double2 v[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const bool valid = j + i * S - pad >= 0;
+                const double2 d = X0[j + i * S];
+                v[i].x = (valid && !deadA) ? d.x - mA : 0.0;
+                v[i].y = (valid && !deadB) ? d.y - mB : 0.0;
+            }
+            dft_small<R1>(v);
+#pragma unroll
+            for (int m = 0; m < Q1; m++)
+#pragma unroll
+                for (int r = 0; r < R1; r++)
+                    X1[(j + m * S) * R1 + r] = v[m + r * Q1];
+        }
+        __syncthreads();
+        // ---- pass 2 (Ns = R1): X1 -> X0
+#pragma clang loop unroll(disable)
+        for (int ch = 0; ch < CH; ch++) {
+            const int j = t + 256 * ch;
+            double2 v[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                v[i] = X1[j + i * S];
+            fwd16(v, twm, j % NS2, 16 * NS2);
+            const int base = (j / NS2) * (16 * NS2) + (j % NS2);
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                X0[base + r * NS2] = v[P16(r)];
+        }
+        __syncthreads();
+        // ---- pass 3 (Ns = 16 R1): X0 -> X1
+#pragma clang loop unroll(disable)
+        for (int ch = 0; ch < CH; ch++) {
+            const int j = t + 256 * ch;
+            double2 v[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                v[i] = X0[j + i * S];
+            fwd16(v, twm, j % NS3, 16 * NS3);
+            const int base = (j / NS3) * (16 * NS3) + (j % NS3);
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                X1[base + r * NS3] = v[P16(r)];
+        }
+        __syncthreads();
+        // ---- pass 4 (Ns = S) + spectrum multiply + pass 4^T, in registers: X1 -> X0
+#pragma clang loop unroll(disable)
+        for (int ch = 0; ch < CH; ch++) {
+            const int j = t + 256 * ch;
+            double2 v[16], w[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                v[i] = X1[j + i * S];
+            fwd16(v, twm, j, n); // X[j + r S] at v[P16(r)]
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                w[r] = cmul(v[P16(r)], p.xc[j + r * S]);
+            trn16(w, twm, j, n);
+#pragma unroll
+            for (int s = 0; s < 16; s++)
+                X0[j + s * S] = w[P16(s)];
+        }
+        __syncthreads();
+        // ---- pass 3^T: X0 -> X1
+#pragma clang loop unroll(disable)
+        for (int ch = 0; ch < CH; ch++) {
+            const int j = t + 256 * ch;
+            double2 v[16];
+            const int base = (j / NS3) * (16 * NS3) + (j % NS3);
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                v[r] = X0[base + r * NS3];
+            trn16(v, twm, j % NS3, 16 * NS3);
+#pragma unroll
+            for (int s = 0; s < 16; s++)
+                X1[j + s * S] = v[P16(s)];
+        }
+        __syncthreads();
+        // ---- pass 2^T: X1 -> X0
+#pragma clang loop unroll(disable)
+        for (int ch = 0; ch < CH; ch++) {
+            const int j = t + 256 * ch;
+            double2 v[16];
+            const int base = (j / NS2) * (16 * NS2) + (j % NS2);
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                v[r] = X1[base + r * NS2];
+            trn16(v, twm, j % NS2, 16 * NS2);
+#pragma unroll
+            for (int s = 0; s < 16; s++)
+                X0[j + s * S] = v[P16(s)];
+        }
+        __syncthreads();
+        // ---- pass 1^T + per-thread argmax (register i of chunk ch holds cc[j + i S])
+        double ma = 0.0, mb = 0.0, sa = 0.0, sb = 0.0, cc0a = 0.0, cc0b = 0.0;
+        int ia = 0x7fffffff, ib = 0x7fffffff;
+#pragma clang loop unroll(disable)
+        for (int ch = 0; ch < CH; ch++) {
+            const int j = t + 256 * ch;
+            double2 v[16];
+#pragma unroll
+            for (int m = 0; m < Q1; m++)
+#pragma unroll
+                for (int r = 0; r < R1; r++)
+                    v[m + r * Q1] = X0[(j + m * S) * R1 + r];
+            dft_small<R1>(v);
+            if (ch == 0) {
+                cc0a = v[0].x; // thread 0: cc[0]
+                cc0b = v[0].y;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const double aa = fabs(v[i].x), ab = fabs(v[i].y);
+                const int idx = j + i * S;
+                if (aa > ma || (aa == ma && aa > 0.0 && idx < ia)) { ma = aa; sa = v[i].x; ia = idx; }
+                if (ab > mb || (ab == mb && ab > 0.0 && idx < ib)) { mb = ab; sb = v[i].y; ib = idx; }
+            }
+        }
+        // ---- block argmax (first index of the maximum), owner thread stores
+        {
+            const double wa = wave_max(ma), wb = wave_max(mb);
+            if (lane == 0) {
+                red[32 + wave] = wa;
+                red[36 + wave] = wb;
+            }
+            if (t == 0) {
+                red[40] = cc0a;
+                red[41] = cc0b;
+            }
+            __syncthreads();
+            const double MA = fmax(fmax(red[32], red[33]), fmax(red[34], red[35]));
+            const double MB = fmax(fmax(red[36], red[37]), fmax(red[38], red[39]));
+            int ca = (ma == MA && MA > 0.0) ? ia : 0x7fffffff;
+            int cb = (mb == MB && MB > 0.0) ? ib : 0x7fffffff;
+            ca = wave_min_i(ca);
+            cb = wave_min_i(cb);
+            if (lane == 0) {
+                redi[wave] = ca;
+                redi[4 + wave] = cb;
+            }
+            __syncthreads();
+            const int IA = min(min(redi[0], redi[1]), min(redi[2], redi[3]));
+            const int IB = min(min(redi[4], redi[5]), min(redi[6], redi[7]));
+            for (int sidx = 0; sidx < 2; sidx++) {
+                if (sidx == 1 && !hasB)
+                    break;
+                const int I = sidx ? IB : IA;
+                const bool none = I == 0x7fffffff;
+                const bool owner = none ? (t == 0) : ((sidx ? ib : ia) == I && (sidx ? mb : ma) == (sidx ? MB : MA));
+                if (owner) {
+                    const double var = sidx ? varB : varA;
+                    const bool zero = sidx ? zeroB : zeroA, nan = sidx ? nanB : nanA;
+                    double y = __builtin_amdgcn_rsq(var);
+                    y = y * fma(-0.5 * var * y, y, 1.5);
+                    y = y * fma(-0.5 * var * y, y, 1.5);
+                    const int idx = none ? 0 : I;
+                    double mv = (none ? red[40 + sidx] : (sidx ? sb : sa)) * y;
+                    int lag = idx > n / 2 ? idx - n : idx;
+                    if (zero) { mv = 0.0; lag = 0; }
+                    if (nan) { mv = __builtin_nan(""); lag = 0; }
+                    p.mv[rA + sidx] = mv;
+                    p.lag[rA + sidx] = lag;
+                }
+            }
+            __syncthreads(); // red / redi / the scratch slices are free for the next pair
+        }
+    }
+}
+
+template <int LOGN>
+static hipError_t launch_stk_glb(const FusedParams &p, int num_cus, hipStream_t stream)
+{
+    if (!p.gscratch)
+        return hipErrorInvalidValue;
+    const long long grid = std::min<long long>(p.npairs, (long long)num_cus * STOCKHAM_GLOBAL_WGS_PER_CU);
+    hipLaunchKernelGGL((xcorr_fused_stk_glb<LOGN>), dim3((unsigned)grid), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 
-// n = 512, 1024, 2048 (any N in (n/2, n])
+template <int LOGN>
+static hipError_t launch_stk_lds(const FusedParams &p, int num_cus, hipStream_t stream)
+{
+    constexpr int S = (1 << LOGN) / 16;
+    constexpr int G = S >= 256 ? 1 : 256 / S;
+    constexpr int TPB = S * G;
+    constexpr int WPC = TPB > 256 ? 1 : 2; // workgroups per CU the LDS buffer allows
+    const long long ngroups = (p.npairs + G - 1) / G;
+    const long long grid = std::min<long long>(ngroups, (long long)num_cus * WPC * 8);
+    hipLaunchKernelGGL((xcorr_fused_stk_lds<LOGN>), dim3((unsigned)grid), dim3(TPB), 0, stream, p);
+    return hipGetLastError();
+}
+
+// n = 512, 1024, 2048 (LDS) and 8192 ... 65536 (global scratch: 2 n complex per workgroup); any N in (n/2, n]
 hipError_t launch_fused_stockham(const FusedParams &p, int num_cus, hipStream_t stream)
 {
     switch (p.logn) {
     case 9: return launch_stk_lds<9>(p, num_cus, stream);
     case 10: return launch_stk_lds<10>(p, num_cus, stream);
     case 11: return launch_stk_lds<11>(p, num_cus, stream);
+    case 13: return launch_stk_lds<13>(p, num_cus, stream);
+    case 14: return launch_stk_glb<14>(p, num_cus, stream);
+    case 15: return launch_stk_glb<15>(p, num_cus, stream);
+    case 16: return launch_stk_glb<16>(p, num_cus, stream);
     default: return hipErrorInvalidValue;
     }
 }

@@ -568,12 +568,14 @@ def test_many_references_large(muse, eng):
         np.testing.assert_allclose(got[r][1], smv, rtol=1e-11, atol=0, equal_nan=True)
 
 
-@pytest.mark.parametrize("N", [257, 480, 512, 700, 1000, 1024, 1025, 1500, 2048])
+@pytest.mark.parametrize("N", [257, 480, 512, 700, 1000, 1024, 1025, 1500, 2048,
+                               4097, 5000, 8192, 10000, 16384, 20000, 32768, 40000, 65536])
 def test_stockham_kernels_match_oracle_and_generic(muse, eng, oracle, N):
-    """n = 512, 1024, 2048: the radix-16 Stockham kernel (auto / variant 11) against the oracle and
-    the radix-2 generic kernel (variant 1) on the same rows, incl. N < n padding, sigma == 0,
-    NaN / Inf rows, an odd row count and more pairs than one workgroup iteration holds."""
-    M = 83
+    """n = 512 ... 2048 (LDS) and 8192 ... 65536 (global scratch): the radix-16 Stockham kernels
+    (auto / variant 11) against the oracle and the radix-2 generic kernel (variant 1) on the same
+    rows, incl. N < n padding, sigma == 0, NaN / Inf rows, an odd row count and more pairs than one
+    workgroup iteration holds."""
+    M = 83 if N <= 4096 else 23
     ref, rows = _rows(M, N, 31 * N)
     rows[10, 5 % N] = np.nan
     rows[12, :] = np.inf
