@@ -72,14 +72,15 @@ int muse_ctx_synchronize(muse_ctx *ctx);
 /* name: >= 64 bytes.  Any out pointer may be NULL. */
 int muse_ctx_device_info(muse_ctx *ctx, char *name, int32_t name_cap,
                          int32_t *compute_units, int64_t *hbm_bytes);
-/* Kernel variant for the fused pass: 0 = auto (fastest tuned kernel when
- * n == 4096, generic LDS radix-2 kernel otherwise), 1 = force the generic
- * kernel; forcing one n = 4096 kernel: 2 = first (simple) fp64 kernel,
+/* Kernel variant for the fused pass: 0 = auto (fastest kernel built for the
+ * FFT length), 1 = force the generic radix-2 kernel; forcing one n = 4096 kernel: 2 = first (simple) fp64 kernel,
  * 5 = register-prefetch pipeline, 6 / 7 = half-round transposes at 4 / 3
  * waves per SIMD (7 is what auto picks when N < n = 4096), 8 = fp32 screening
  * + exact fp64 re-evaluation (experimental), 9 = 512-thread radix-8
  * (experimental), 10 = wave-local transposes + deferred statistics (what auto
- * picks when N == 4096; other N fall back to 7).
+ * picks when N == 4096; other N fall back to 7).  For n != 4096: 11 = radix-16
+ * Stockham kernels (n = 512 ... 2048 and 8192 through LDS, 16384 ... 65536
+ * through a global scratch buffer; what auto picks for n >= 512), 1 = radix-2.
  * The parity tests run every variant on the same inputs; the environment
  * variable MUSE_HIP_KERNEL sets the initial value (profiling aid). */
 int muse_ctx_set_kernel(muse_ctx *ctx, int32_t variant);
