@@ -82,7 +82,12 @@ def main():
     n_gpus = max(world, 1)
 
     pkg = importlib.import_module("go-muse_amd")
-    if pkg.build.stale():
+    # the library ships prebuilt in the tree; rebuild only if a source is newer, and then by ONE rank
+    if use_dist:
+        if local_rank == 0 and pkg.build.stale():
+            pkg.build.build()
+        dist.barrier()
+    elif pkg.build.stale():
         pkg.build.build()
     eng = pkg.Engine(local_rank)                      # raises without a gfx950 GPU: no fallback
     dev_name, cus, hbm = eng.device_info()
