@@ -590,6 +590,42 @@ def NewBatch(ref, comp, results, cc, engine=None):
     return Batch(ref, comp, results, cc, engine)
 
 
+def RunMany(batches, groupByLabels):
+    """Batch.Run for several batches that share one Comparison group and the same Results settings
+    (README.md:10-13: many references against one set of series): the resident rows are read and
+    transformed once for all references (muse_batch_run_many).  Not part of the reference's API;
+    batches that do not qualify are run one after the other."""
+    batches = list(batches)
+    if not batches:
+        return None
+    b0 = batches[0]
+    r0 = b0.Results
+    same = all(b.Comparison is b0.Comparison and b._engine is b0._engine and
+               (b.Results.MaxLag, b.Results.TopN, b.Results.Threshold, b.Results.SignFilter) ==
+               (r0.MaxLag, r0.TopN, r0.Threshold, r0.SignFilter) for b in batches)
+    if not same:
+        for b in batches:
+            b.Run(groupByLabels)
+        return None
+    comp = b0.Comparison
+    labelValuesSet = comp.indexLabelValues(groupByLabels)
+    if not labelValuesSet:
+        return None
+    series = comp._series_list()
+    uid_pos = {uid: i for i, uid in enumerate(comp.registry)}
+    gid = np.zeros(len(series), dtype=np.int32)
+    for g, uids in enumerate(comp.index.values()):
+        for u in uids:
+            gid[uid_pos[u]] = g
+    res = run_many([b._batch() for b in batches], gid, len(labelValuesSet), r0.MaxLag, r0.TopN, r0.Threshold,
+                   r0.SignFilter, abs_scores=True)
+    for b, (idx, lag, score, _) in zip(batches, res):
+        order = np.argsort(gid[idx], kind="stable")
+        for k in order:
+            b.Results.Update(Score(series[int(idx[k])].Labels(), int(lag[k]), float(score[k])))
+    return None
+
+
 # ----------------------------------------------------------------- muse.go
 class Muse:
     def __init__(self, ref, results, engine=None):

@@ -594,3 +594,32 @@ def test_stockham_kernels_match_oracle_and_generic(muse, eng, oracle, N):
         assert np.array_equal(got[0][0], got[11][0]) and np.array_equal(got[0][1], got[11][1], equal_nan=True)
     finally:
         eng.set_kernel(0)
+
+
+def test_mirror_run_many_equals_runs(muse):
+    """RunMany over the reference-style API (Series / Group / Batch / Results): three references
+    against one Group with Run(["graph"]) semantics == three separate Batch.Run calls."""
+    rng = np.random.default_rng(5)
+    N, M, R = 4096, 41, 3
+    comp = muse.NewGroup("targets")
+    for i in range(M):
+        y = rng.standard_normal(N)
+        y[1000 + 13 * i:1040 + 13 * i] += 4.0
+        comp.Add(muse.NewSeries(y, muse.NewLabels({"graph": "g%d" % (i // 4), "host": "h%d" % i})))
+    refs = []
+    for r in range(R):
+        y = rng.standard_normal(N)
+        y[1500 + 100 * r:1540 + 100 * r] += 4.0
+        refs.append(muse.NewSeries(y, muse.NewLabels({"graph": "ref%d" % r})))
+    many = [muse.NewBatch(ref, comp, muse.NewResults(4096, 5, 0.0, muse.SignFilter_ANY), 4) for ref in refs]
+    single = [muse.NewBatch(ref, comp, muse.NewResults(4096, 5, 0.0, muse.SignFilter_ANY), 4) for ref in refs]
+    muse.RunMany(many, ["graph"])
+    for r in range(R):
+        single[r].Run(["graph"])
+        a, am = many[r].Results.Fetch()
+        b, bm = single[r].Results.Fetch()
+        assert len(a) == len(b) == 5
+        for x, y in zip(a, b):
+            assert x.Lag == y.Lag and x.Labels.ID(x.Labels.Keys()) == y.Labels.ID(y.Labels.Keys())
+            assert abs(x.PercentScore - y.PercentScore) <= 1e-12
+        assert abs(am - bm) <= 1e-12
