@@ -66,27 +66,31 @@ __device__ __forceinline__ void wave_order()
 //      writer (c' = hi, m1 = lo) output m2 -> 272*(m2&7) + 17*lo + hi
 //      reader (m1 = lo, m2 = hi) input c'  <- 272*(hi&7) + 17*lo + c'
 // Round 0 moves outputs 0..7 (read by waves 0-1), round 1 outputs 8..15 (waves 2-3).
-template <int MODE>
+template <int MODE, bool SWAP = false>
 __device__ __forceinline__ void exchange_cross(double2 (&v)[16], double2 *xbuf, const int wave, const int t)
 {
+    // SWAP: outputs 8..15 travel first and waves 2-3 are the early readers (used for the second
+    // workgroup-wide transpose of a pair so that the late-reader role alternates between the wave pairs)
+    constexpr int K0 = SWAP ? 8 : 0, K1 = SWAP ? 0 : 8;
     const int hi = t >> 4, lo = t & 15;
     const int wbase = MODE ? 17 * lo + hi : t;
     const int rbase = 272 * (hi & 7) + (MODE ? 17 * lo : lo);
+    const bool early = SWAP ? wave >= 2 : wave < 2;
     prio_hi();
     lds_barrier(); // buffer free: every wave is done with its previous (wave-local or shared) use
 #pragma unroll
     for (int k = 0; k < 8; k++)
-        xbuf[272 * k + wbase] = v[P16(k)];
+        xbuf[272 * k + wbase] = v[P16(K0 + k)];
     lds_barrier();
-    if (wave < 2) {
+    if (early) {
         double2 w[16];
 #pragma unroll
         for (int e = 0; e < 16; e++)
             w[e] = xbuf[rbase + (MODE ? e : 16 * e)];
         lds_barrier();
 #pragma unroll
-        for (int k = 8; k < 16; k++)
-            xbuf[272 * (k - 8) + wbase] = v[P16(k)];
+        for (int k = 0; k < 8; k++)
+            xbuf[272 * k + wbase] = v[P16(K1 + k)];
         lds_barrier();
 #pragma unroll
         for (int e = 0; e < 16; e++)
@@ -94,8 +98,8 @@ __device__ __forceinline__ void exchange_cross(double2 (&v)[16], double2 *xbuf, 
     } else {
         lds_barrier();
 #pragma unroll
-        for (int k = 8; k < 16; k++)
-            xbuf[272 * (k - 8) + wbase] = v[P16(k)];
+        for (int k = 0; k < 8; k++)
+            xbuf[272 * k + wbase] = v[P16(K1 + k)];
         lds_barrier();
 #pragma unroll
         for (int e = 0; e < 16; e++)
@@ -293,7 +297,7 @@ __device__ __forceinline__ bool finalize(const double *r, const int series, cons
 // DYN: pairs are handed out by an atomic counter (FusedParams::work_counter, zeroed before the
 // launch) to a grid of resident workgroups only, instead of a static stride over an oversubscribed
 // grid: no tail while the slowest CUs finish their fixed share.
-template <int WPS, bool TIMING = false, bool DYN = false>
+template <int WPS, bool TIMING = false, bool DYN = false, bool SWAPB = false>
 __global__ __launch_bounds__(OCC_THREADS, WPS) void xcorr_fused_n4096_fast(const FusedParams p)
 {
     using namespace occ4;
@@ -460,7 +464,7 @@ __global__ __launch_bounds__(OCC_THREADS, WPS) void xcorr_fused_n4096_fast(const
         // pass 2: DFT over b', twiddle W_256^(m2 c'), c' = hi
         twiddle_pass<WPS>(v, ta, Tw2Fetch{tw2s, hi});
         clk.template stamp<9>();
-        exchange_cross<1>(v, xbuf, wave, t);
+        exchange_cross<1, SWAPB>(v, xbuf, wave, t);
         clk.template stamp<10>();
         // pass 3: DFT over c' (m1 = lo, m2 = hi): index t + 256 m3.  The next pair's rows
         // are requested first: they stay in flight during the butterflies and the argmax.

@@ -172,6 +172,76 @@ __device__ __forceinline__ int row_min_i_dpp(int v)
 
 __device__ __forceinline__ int padpos(int pos) { return pos + (pos >> 4); }
 
+// The on-chip part shared by the LDS kernels and the four-step kernel's row stage: forward
+// transform of the n points held as v[i] = x[j + i S] by the S = n/16 threads of a pair
+// (work buffer b, padded), multiply output X[j + r S] by xcf(r), transposed transform; on
+// return v[i] = result[j + i S].  Must be called by every thread of the workgroup (barriers).
+template <int LOGN, typename XcF>
+__device__ __forceinline__ void lds_transforms(double2 (&v)[16], double2 *b, const double2 *__restrict__ twm, const int j,
+                                               XcF xcf)
+{
+    constexpr int n = 1 << LOGN;
+    constexpr int S = n / 16;
+    constexpr int NP = (LOGN + 3) / 4;
+    constexpr int R1 = n >> (4 * (NP - 1));
+    constexpr int Q1 = 16 / R1;
+    dft_small<R1>(v); // pass 1: Ns = 1, butterflies q = j + m S on registers m + s Q1
+#pragma unroll
+    for (int m = 0; m < Q1; m++)
+#pragma unroll
+        for (int r = 0; r < R1; r++)
+            b[padpos((j + m * S) * R1 + r)] = v[m + r * Q1];
+    __syncthreads();
+#pragma unroll
+    for (int pp = 2; pp <= NP; pp++) { // radix-16 passes, Ns = R1 16^(pp-2); the last has Ns = S
+        const int Ns = R1 << (4 * (pp - 2));
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            v[i] = b[padpos(j + i * S)];
+        fwd16(v, twm, j % Ns, 16 * Ns);
+        if (pp < NP) {
+            __syncthreads(); // every thread has read its inputs
+            const int base = (j / Ns) * (16 * Ns) + (j % Ns);
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                b[padpos(base + r * Ns)] = v[P16(r)];
+            __syncthreads();
+        }
+    }
+    { // output X[j + r S] at v[P16(r)]: spectrum multiply
+        double2 w[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            w[r] = cmul(v[P16(r)], xcf(r));
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            v[r] = w[r];
+    }
+#pragma unroll
+    for (int pp = NP; pp >= 2; pp--) {
+        const int Ns = R1 << (4 * (pp - 2));
+        trn16(v, twm, j % Ns, 16 * Ns); // pass pp^T: output s at v[P16(s)] -> position j + s S
+        __syncthreads();                // every thread is past its last read of the buffer
+#pragma unroll
+        for (int s = 0; s < 16; s++)
+            b[padpos(j + s * S)] = v[P16(s)];
+        __syncthreads();
+        if (pp > 2) { // read the positions pass pp-1 wrote
+            const int Np = R1 << (4 * (pp - 3));
+            const int base = (j / Np) * (16 * Np) + (j % Np);
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                v[r] = b[padpos(base + r * Np)];
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < Q1; m++)
+#pragma unroll
+        for (int r = 0; r < R1; r++)
+            v[m + r * Q1] = b[padpos((j + m * S) * R1 + r)];
+    dft_small<R1>(v); // pass 1^T
+}
+
 } // namespace stk
 
 template <int LOGN>
@@ -255,66 +325,8 @@ void xcorr_fused_stk_lds(const FusedParams p)
             v[i].x = (valid && !deadA) ? v[i].x - mA : 0.0;
             v[i].y = (valid && !deadB) ? v[i].y - mB : 0.0;
         }
-        // ================= forward transform =================
-        dft_small<R1>(v); // pass 1: Ns = 1, butterflies q = j + m S on registers m + s Q1
-#pragma unroll
-        for (int m = 0; m < Q1; m++)
-#pragma unroll
-            for (int r = 0; r < R1; r++)
-                b[padpos((j + m * S) * R1 + r)] = v[m + r * Q1];
-        __syncthreads();
-#pragma unroll
-        for (int pp = 2; pp <= NP; pp++) { // radix-16 passes, Ns = R1 16^(pp-2); the last has Ns = S
-            constexpr int dummy = 0;
-            (void)dummy;
-            const int Ns = R1 << (4 * (pp - 2));
-#pragma unroll
-            for (int i = 0; i < 16; i++)
-                v[i] = b[padpos(j + i * S)];
-            fwd16(v, twm, j % Ns, 16 * Ns);
-            if (pp < NP) {
-                __syncthreads(); // every thread has read its inputs
-                const int base = (j / Ns) * (16 * Ns) + (j % Ns);
-#pragma unroll
-                for (int r = 0; r < 16; r++)
-                    b[padpos(base + r * Ns)] = v[P16(r)];
-                __syncthreads();
-            }
-        }
-        // output X[j + r S] at v[P16(r)]
-        // ================= V = Z conj(X)/n, second transform (transposed passes) =================
-        {
-            double2 w[16];
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-                w[r] = cmul(v[P16(r)], p.xc[j + r * S]);
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-                v[r] = w[r];
-        }
-#pragma unroll
-        for (int pp = NP; pp >= 2; pp--) {
-            const int Ns = R1 << (4 * (pp - 2));
-            trn16(v, twm, j % Ns, 16 * Ns); // pass pp^T: output s at v[P16(s)] -> position j + s S
-            __syncthreads();                // every thread is past its last read of the buffer
-#pragma unroll
-            for (int s = 0; s < 16; s++)
-                b[padpos(j + s * S)] = v[P16(s)];
-            __syncthreads();
-            if (pp > 2) { // read the positions pass pp-1 wrote
-                const int Np = R1 << (4 * (pp - 3));
-                const int base = (j / Np) * (16 * Np) + (j % Np);
-#pragma unroll
-                for (int r = 0; r < 16; r++)
-                    v[r] = b[padpos(base + r * Np)];
-            }
-        }
-#pragma unroll
-        for (int m = 0; m < Q1; m++)
-#pragma unroll
-            for (int r = 0; r < R1; r++)
-                v[m + r * Q1] = b[padpos((j + m * S) * R1 + r)];
-        dft_small<R1>(v); // pass 1^T: register i holds cc[j + i S] (re: series A, im: series B)
+        // forward transform, V = Z conj(X)/n, transposed transform: register i ends with cc[j + i S]
+        lds_transforms<LOGN>(v, b, twm, j, [&](int r) __attribute__((always_inline)) { return p.xc[j + r * S]; });
         // ================= maxAbsIndex (xcorr.go:39-50) per series =================
         double ma = 0.0, mb = 0.0, sa = 0.0, sb = 0.0;
         int ia = 0x7fffffff, ib = 0x7fffffff;
@@ -617,6 +629,210 @@ __global__ __launch_bounds__(256, 2) void xcorr_fused_stk_glb(const FusedParams 
     }
 }
 
+// ---------------------------------------------------------------------------
+// xcorr_fused_stk_4step<LOGN> (n = R1 * 4096, R1 = 4, 8, 16): the long-series path as a
+// four-step transform, n1 = R1 (in-thread), n2 = 4096 (on chip through LDS):
+//   X[k1 + R1 k2] = sum_m2 W_4096^(m2 k2) [ W_n^(m2 k1) sum_m1 W_R1^(m1 k1) x[m1 4096 + m2] ]
+// sweep 0: rows -> d = x - K into the workgroup's scratch slice, statistics;
+// sweep 1: radix-R1 over m1 + twiddle, IN PLACE (a thread reads and writes the same
+//          positions q + s 4096);
+// rows:    for each k1: the 4096 points of row k1 -> lds_transforms<12> (forward, multiply by
+//          xc[k1 + R1 k2], transposed forward) -> back to the row, in place;
+// sweep 2: twiddle + radix-R1 over k1 -> cc[m1 4096 + m2], argmax on the fly.
+// Scratch traffic: 3 writes + 3 reads of the pair (the four-pass kernel above: 14), one
+// n-element slice per workgroup, and the butterflies of the 4096-point rows run on chip.
+template <int LOGN>
+__global__ __launch_bounds__(256, 2) void xcorr_fused_stk_4step(const FusedParams p)
+{
+    using namespace occ4;
+    using namespace stk;
+    constexpr int n = 1 << LOGN;
+    constexpr int S = n / 16;
+    constexpr int CH = S / 256;
+    constexpr int R1 = n / 4096;
+    constexpr int Q1 = 16 / R1;
+    static_assert(LOGN >= 13 && LOGN <= 16, "four-step kernel: n = 8192 ... 65536");
+    __shared__ double2 buf[4096 + 256];
+    __shared__ double red[64];
+    __shared__ int redi[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    double2 *const Y = p.gscratch + (size_t)blockIdx.x * (size_t)(2 * n);
+    const int N = p.N, pad = n - N;
+    const double invN = 1.0 / (double)N, invNm1 = 1.0 / (double)(N - 1);
+    const double2 *__restrict__ twm = p.twm;
+
+    for (long long pair = blockIdx.x; pair < p.npairs; pair += gridDim.x) {
+        const long long rA = 2 * pair;
+        const bool hasB = rA + 1 < p.M;
+        const double *__restrict__ ra = p.rows + rA * p.stride;
+        const double *__restrict__ rb = p.rows + (hasB ? rA + 1 : rA) * p.stride;
+        const double KA = ra[0], KB = rb[0];
+        // ---- sweep 0
+        double q[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma clang loop unroll(disable)
+        for (int ch = 0; ch < CH; ch++) {
+            const int j = t + 256 * ch;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int e = j + i * S - pad;
+                const int ec = e < 0 ? 0 : e;
+                double da = __builtin_nontemporal_load(ra + ec) - KA, db = __builtin_nontemporal_load(rb + ec) - KB;
+                da = e >= 0 ? da : 0.0;
+                db = e >= 0 ? db : 0.0;
+                Y[j + i * S] = make_double2(da, db);
+                q[0] += da;
+                q[1] = fma(da, da, q[1]);
+                q[2] += db;
+                q[3] = fma(db, db, q[3]);
+            }
+        }
+        block_sum<4>(q, red);
+        const Stat stA{q[0], q[1]}, stB{q[2], q[3]};
+        bool zeroA, nanA, zeroB, nanB;
+        const double varA = variance(stA, invN, invNm1, zeroA, nanA);
+        const double varB = variance(stB, invN, invNm1, zeroB, nanB);
+        const double mA = q[0] * invN, mB = q[2] * invN;
+        const bool deadA = zeroA || nanA, deadB = zeroB || nanB || !hasB;
+        // ---- sweep 1: radix R1 over m1 (butterflies m2 = j + m S on registers m + s Q1), twiddle
+        // W_n^(m2 k1), in place (positions m2 + s 4096 = j + (m + s Q1) S)
+#pragma clang loop unroll(disable)
+        for (int ch = 0; ch < CH; ch++) {
+            const int j = t + 256 * ch;
+            double2 v[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const bool valid = j + i * S - pad >= 0;
+                const double2 d = Y[j + i * S];
+                v[i].x = (valid && !deadA) ? d.x - mA : 0.0;
+                v[i].y = (valid && !deadB) ? d.y - mB : 0.0;
+            }
+            dft_small<R1>(v);
+#pragma unroll
+            for (int m = 0; m < Q1; m++) {
+                const int m2 = j + m * S;
+#pragma unroll
+                for (int r = 1; r < R1; r++) {
+                    const int e = (m2 * r * (65536 / n)) & 65535;
+                    const double2 w = twm[e & 32767];
+                    const double2 ws = e >= 32768 ? make_double2(-w.x, -w.y) : w;
+                    v[m + r * Q1] = cmul(v[m + r * Q1], ws);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                Y[j + i * S] = v[i]; // register m + r Q1 <-> row k1 = r, column m2: position r 4096 + m2
+        }
+        __syncthreads();
+        // ---- rows: k1 = 0 .. R1-1, 4096 points each, on chip
+#pragma clang loop unroll(disable)
+        for (int k1 = 0; k1 < R1; k1++) {
+            double2 *const row = Y + k1 * 4096;
+            double2 v[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                v[i] = row[t + 256 * i];
+            lds_transforms<12>(v, buf, twm, t,
+                               [&](int r) __attribute__((always_inline)) { return p.xc[k1 + R1 * (t + 256 * r)]; });
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                row[t + 256 * i] = v[i];
+        }
+        __syncthreads();
+        // ---- sweep 2: twiddle, radix R1 over k1 -> cc[m1 4096 + m2] at register m + m1 Q1; argmax
+        double ma = 0.0, mb = 0.0, sa = 0.0, sb = 0.0, cc0a = 0.0, cc0b = 0.0;
+        int ia = 0x7fffffff, ib = 0x7fffffff;
+#pragma clang loop unroll(disable)
+        for (int ch = 0; ch < CH; ch++) {
+            const int j = t + 256 * ch;
+            double2 v[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                v[i] = Y[j + i * S];
+#pragma unroll
+            for (int m = 0; m < Q1; m++) {
+                const int m2 = j + m * S;
+#pragma unroll
+                for (int r = 1; r < R1; r++) {
+                    const int e = (m2 * r * (65536 / n)) & 65535;
+                    const double2 w = twm[e & 32767];
+                    const double2 ws = e >= 32768 ? make_double2(-w.x, -w.y) : w;
+                    v[m + r * Q1] = cmul(v[m + r * Q1], ws);
+                }
+            }
+            dft_small<R1>(v);
+            if (ch == 0) {
+                cc0a = v[0].x;
+                cc0b = v[0].y;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const double aa = fabs(v[i].x), ab = fabs(v[i].y);
+                const int idx = j + i * S;
+                if (aa > ma || (aa == ma && aa > 0.0 && idx < ia)) { ma = aa; sa = v[i].x; ia = idx; }
+                if (ab > mb || (ab == mb && ab > 0.0 && idx < ib)) { mb = ab; sb = v[i].y; ib = idx; }
+            }
+        }
+        // ---- block argmax (first index of the maximum), owner thread stores
+        {
+            const double wa = wave_max(ma), wb = wave_max(mb);
+            if (lane == 0) {
+                red[32 + wave] = wa;
+                red[36 + wave] = wb;
+            }
+            if (t == 0) {
+                red[40] = cc0a;
+                red[41] = cc0b;
+            }
+            __syncthreads();
+            const double MA = fmax(fmax(red[32], red[33]), fmax(red[34], red[35]));
+            const double MB = fmax(fmax(red[36], red[37]), fmax(red[38], red[39]));
+            int ca = (ma == MA && MA > 0.0) ? ia : 0x7fffffff;
+            int cb = (mb == MB && MB > 0.0) ? ib : 0x7fffffff;
+            ca = wave_min_i(ca);
+            cb = wave_min_i(cb);
+            if (lane == 0) {
+                redi[wave] = ca;
+                redi[4 + wave] = cb;
+            }
+            __syncthreads();
+            const int IA = min(min(redi[0], redi[1]), min(redi[2], redi[3]));
+            const int IB = min(min(redi[4], redi[5]), min(redi[6], redi[7]));
+            for (int sidx = 0; sidx < 2; sidx++) {
+                if (sidx == 1 && !hasB)
+                    break;
+                const int I = sidx ? IB : IA;
+                const bool none = I == 0x7fffffff;
+                const bool owner = none ? (t == 0) : ((sidx ? ib : ia) == I && (sidx ? mb : ma) == (sidx ? MB : MA));
+                if (owner) {
+                    const double var = sidx ? varB : varA;
+                    const bool zero = sidx ? zeroB : zeroA, nan = sidx ? nanB : nanA;
+                    double y = __builtin_amdgcn_rsq(var);
+                    y = y * fma(-0.5 * var * y, y, 1.5);
+                    y = y * fma(-0.5 * var * y, y, 1.5);
+                    const int idx = none ? 0 : I;
+                    double mv = (none ? red[40 + sidx] : (sidx ? sb : sa)) * y;
+                    int lag = idx > n / 2 ? idx - n : idx;
+                    if (zero) { mv = 0.0; lag = 0; }
+                    if (nan) { mv = __builtin_nan(""); lag = 0; }
+                    p.mv[rA + sidx] = mv;
+                    p.lag[rA + sidx] = lag;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int LOGN>
+static hipError_t launch_stk_4step(const FusedParams &p, int num_cus, hipStream_t stream)
+{
+    if (!p.gscratch)
+        return hipErrorInvalidValue;
+    const long long grid = std::min<long long>(p.npairs, (long long)num_cus * STOCKHAM_GLOBAL_WGS_PER_CU);
+    hipLaunchKernelGGL((xcorr_fused_stk_4step<LOGN>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
 template <int LOGN>
 static hipError_t launch_stk_glb(const FusedParams &p, int num_cus, hipStream_t stream)
 {
@@ -641,16 +857,19 @@ static hipError_t launch_stk_lds(const FusedParams &p, int num_cus, hipStream_t 
 }
 
 // n = 512, 1024, 2048 (LDS) and 8192 ... 65536 (global scratch: 2 n complex per workgroup); any N in (n/2, n]
-hipError_t launch_fused_stockham(const FusedParams &p, int num_cus, hipStream_t stream)
+hipError_t launch_fused_stockham(const FusedParams &p0, int num_cus, hipStream_t stream)
 {
+    FusedParams p = p0;
+    if (const char *d = getenv("MUSE_HIP_FAST_TUNE")) // tuning aid: bit 1 = four-pass global kernel instead of four-step
+        p.tune = atoi(d);
     switch (p.logn) {
     case 9: return launch_stk_lds<9>(p, num_cus, stream);
     case 10: return launch_stk_lds<10>(p, num_cus, stream);
     case 11: return launch_stk_lds<11>(p, num_cus, stream);
     case 13: return launch_stk_lds<13>(p, num_cus, stream);
-    case 14: return launch_stk_glb<14>(p, num_cus, stream);
-    case 15: return launch_stk_glb<15>(p, num_cus, stream);
-    case 16: return launch_stk_glb<16>(p, num_cus, stream);
+    case 14: return p.tune & 2 ? launch_stk_glb<14>(p, num_cus, stream) : launch_stk_4step<14>(p, num_cus, stream);
+    case 15: return p.tune & 2 ? launch_stk_glb<15>(p, num_cus, stream) : launch_stk_4step<15>(p, num_cus, stream);
+    case 16: return p.tune & 2 ? launch_stk_glb<16>(p, num_cus, stream) : launch_stk_4step<16>(p, num_cus, stream);
     default: return hipErrorInvalidValue;
     }
 }
