@@ -667,46 +667,8 @@ __global__ __launch_bounds__(256, 2) void xcorr_fused_stk_4step(const FusedParam
         const double *__restrict__ ra = p.rows + rA * p.stride;
         const double *__restrict__ rb = p.rows + (hasB ? rA + 1 : rA) * p.stride;
         const double KA = ra[0], KB = rb[0];
-        // ---- sweep 0
-        double q[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma clang loop unroll(disable)
-        for (int ch = 0; ch < CH; ch++) {
-            const int j = t + 256 * ch;
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const int e = j + i * S - pad;
-                const int ec = e < 0 ? 0 : e;
-                double da = __builtin_nontemporal_load(ra + ec) - KA, db = __builtin_nontemporal_load(rb + ec) - KB;
-                da = e >= 0 ? da : 0.0;
-                db = e >= 0 ? db : 0.0;
-                Y[j + i * S] = make_double2(da, db);
-                q[0] += da;
-                q[1] = fma(da, da, q[1]);
-                q[2] += db;
-                q[3] = fma(db, db, q[3]);
-            }
-        }
-        block_sum<4>(q, red);
-        const Stat stA{q[0], q[1]}, stB{q[2], q[3]};
-        bool zeroA, nanA, zeroB, nanB;
-        const double varA = variance(stA, invN, invNm1, zeroA, nanA);
-        const double varB = variance(stB, invN, invNm1, zeroB, nanB);
-        const double mA = q[0] * invN, mB = q[2] * invN;
-        const bool deadA = zeroA || nanA, deadB = zeroB || nanB || !hasB;
-        // ---- sweep 1: radix R1 over m1 (butterflies m2 = j + m S on registers m + s Q1), twiddle
-        // W_n^(m2 k1), in place (positions m2 + s 4096 = j + (m + s Q1) S)
-#pragma clang loop unroll(disable)
-        for (int ch = 0; ch < CH; ch++) {
-            const int j = t + 256 * ch;
-            double2 v[16];
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const bool valid = j + i * S - pad >= 0;
-                const double2 d = Y[j + i * S];
-                v[i].x = (valid && !deadA) ? d.x - mA : 0.0;
-                v[i].y = (valid && !deadB) ? d.y - mB : 0.0;
-            }
-            dft_small<R1>(v);
+        // twiddle of sweeps 1 and 2: v[m + r Q1] *= W_n^(m2 r), m2 = j + m S
+        const auto twiddle_rows = [&](double2 (&v)[16], const int j) __attribute__((always_inline)) {
 #pragma unroll
             for (int m = 0; m < Q1; m++) {
                 const int m2 = j + m * S;
@@ -718,9 +680,88 @@ __global__ __launch_bounds__(256, 2) void xcorr_fused_stk_4step(const FusedParam
                     v[m + r * Q1] = cmul(v[m + r * Q1], ws);
                 }
             }
+        };
+        double q[4] = {0.0, 0.0, 0.0, 0.0};
+        bool zeroA = false, nanA = false, zeroB = false, nanB = false;
+        double varA = 0.0, varB = 0.0;
+        bool zero_dc = false;
+        if (pad == 0) {
+            // N == n: the mean is never needed before the transform (the centred series' DC bin is
+            // exactly 0: bin 0 is zeroed through the spectrum multiplier), so sweep 1 reads the rows
+            // directly and the statistics ride along -- no sweep 0.  A NaN / Inf series cannot be
+            // isolated from its partner this way: such pairs take the general path below.
+#pragma clang loop unroll(disable)
+            for (int ch = 0; ch < CH; ch++) {
+                const int j = t + 256 * ch;
+                double2 v[16];
 #pragma unroll
-            for (int i = 0; i < 16; i++)
-                Y[j + i * S] = v[i]; // register m + r Q1 <-> row k1 = r, column m2: position r 4096 + m2
+                for (int i = 0; i < 16; i++) {
+                    const double da = __builtin_nontemporal_load(ra + j + i * S) - KA;
+                    const double db = __builtin_nontemporal_load(rb + j + i * S) - KB;
+                    v[i] = make_double2(da, db);
+                    q[0] += da;
+                    q[1] = fma(da, da, q[1]);
+                    q[2] += db;
+                    q[3] = fma(db, db, q[3]);
+                }
+                dft_small<R1>(v);
+                twiddle_rows(v, j);
+#pragma unroll
+                for (int i = 0; i < 16; i++)
+                    Y[j + i * S] = v[i];
+            }
+            block_sum<4>(q, red);
+            const Stat stA{q[0], q[1]}, stB{q[2], q[3]};
+            varA = variance(stA, invN, invNm1, zeroA, nanA);
+            varB = variance(stB, invN, invNm1, zeroB, nanB);
+            zero_dc = !(nanA || nanB); // block-uniform
+        }
+        if (!zero_dc) {
+            // ---- sweep 0: rows -> d = x - K (leading zero pad) into the slice, shifted statistics
+            q[0] = q[1] = q[2] = q[3] = 0.0;
+            __syncthreads(); // (N == n fallback: every thread is done with its sweep-1 stores)
+#pragma clang loop unroll(disable)
+            for (int ch = 0; ch < CH; ch++) {
+                const int j = t + 256 * ch;
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const int e = j + i * S - pad;
+                    const int ec = e < 0 ? 0 : e;
+                    double da = __builtin_nontemporal_load(ra + ec) - KA, db = __builtin_nontemporal_load(rb + ec) - KB;
+                    da = e >= 0 ? da : 0.0;
+                    db = e >= 0 ? db : 0.0;
+                    Y[j + i * S] = make_double2(da, db);
+                    q[0] += da;
+                    q[1] = fma(da, da, q[1]);
+                    q[2] += db;
+                    q[3] = fma(db, db, q[3]);
+                }
+            }
+            block_sum<4>(q, red);
+            const Stat stA{q[0], q[1]}, stB{q[2], q[3]};
+            varA = variance(stA, invN, invNm1, zeroA, nanA);
+            varB = variance(stB, invN, invNm1, zeroB, nanB);
+            const double mA = q[0] * invN, mB = q[2] * invN;
+            const bool deadA = zeroA || nanA, deadB = zeroB || nanB || !hasB;
+            // ---- sweep 1: radix R1 over m1 (butterflies m2 = j + m S on registers m + s Q1), twiddle
+            // W_n^(m2 k1), in place (positions m2 + s 4096 = j + (m + s Q1) S)
+#pragma clang loop unroll(disable)
+            for (int ch = 0; ch < CH; ch++) {
+                const int j = t + 256 * ch;
+                double2 v[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const bool valid = j + i * S - pad >= 0;
+                    const double2 d = Y[j + i * S];
+                    v[i].x = (valid && !deadA) ? d.x - mA : 0.0;
+                    v[i].y = (valid && !deadB) ? d.y - mB : 0.0;
+                }
+                dft_small<R1>(v);
+                twiddle_rows(v, j);
+#pragma unroll
+                for (int i = 0; i < 16; i++)
+                    Y[j + i * S] = v[i]; // register m + r Q1 <-> row k1 = r, column m2: position r 4096 + m2
+            }
         }
         __syncthreads();
         // ---- rows: k1 = 0 .. R1-1, 4096 points each, on chip
@@ -731,8 +772,11 @@ __global__ __launch_bounds__(256, 2) void xcorr_fused_stk_4step(const FusedParam
 #pragma unroll
             for (int i = 0; i < 16; i++)
                 v[i] = row[t + 256 * i];
-            lds_transforms<12>(v, buf, twm, t,
-                               [&](int r) __attribute__((always_inline)) { return p.xc[k1 + R1 * (t + 256 * r)]; });
+            const bool dc = zero_dc && k1 == 0 && t == 0; // this thread's output r = 0 is bin 0 of the pair
+            lds_transforms<12>(v, buf, twm, t, [&](int r) __attribute__((always_inline)) {
+                const double2 x = p.xc[k1 + R1 * (t + 256 * r)];
+                return (dc && r == 0) ? make_double2(0.0, 0.0) : x;
+            });
 #pragma unroll
             for (int i = 0; i < 16; i++)
                 row[t + 256 * i] = v[i];
@@ -748,17 +792,7 @@ __global__ __launch_bounds__(256, 2) void xcorr_fused_stk_4step(const FusedParam
 #pragma unroll
             for (int i = 0; i < 16; i++)
                 v[i] = Y[j + i * S];
-#pragma unroll
-            for (int m = 0; m < Q1; m++) {
-                const int m2 = j + m * S;
-#pragma unroll
-                for (int r = 1; r < R1; r++) {
-                    const int e = (m2 * r * (65536 / n)) & 65535;
-                    const double2 w = twm[e & 32767];
-                    const double2 ws = e >= 32768 ? make_double2(-w.x, -w.y) : w;
-                    v[m + r * Q1] = cmul(v[m + r * Q1], ws);
-                }
-            }
+            twiddle_rows(v, j);
             dft_small<R1>(v);
             if (ch == 0) {
                 cc0a = v[0].x;
