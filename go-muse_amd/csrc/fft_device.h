@@ -72,6 +72,24 @@ __device__ __forceinline__ double zn_scale(double s1, double s2, int N, ZnFlags 
     return (f.zero || f.nan) ? 0.0 : 1.0 / sd;
 }
 
+// Two series share one complex transform (z = yA + i yB) and 1/sigma is applied to the winning
+// value only, so the transform's rounding noise is relative to the LARGER series: a pair whose
+// sigmas differ by 2^k loses k bits on the smaller one.  Kernels that know the statistics before
+// the transform bring both series to O(1) with an EXACT power of two close to 1/sigma; kernels that
+// defer the statistics list pairs beyond SIGMA_EXP_SPREAD for the kernel that rescales.
+__device__ __forceinline__ int var_exp(double var) { return (int)((__double_as_longlong(var) >> 52) & 0x7ff) - 1023; }
+__device__ __forceinline__ double pow2_inv_sigma(double var) // 2^-(floor(log2 var) / 2), var finite and > 0
+{
+    return __longlong_as_double((long long)(1023 - (var_exp(var) >> 1)) << 52);
+}
+constexpr int SIGMA_EXP_SPREAD = 32; // exponent spread of the VARIANCES tolerated without rescaling: sigma ratio
+                                     // 2^16, i.e. at most 16 of the 53 bits lost on the smaller series (1e-11 relative)
+__device__ __forceinline__ bool sigma_spread_too_wide(double varA, double varB)
+{
+    const int d = var_exp(varA) - var_exp(varB);
+    return varA > 0.0 && varB > 0.0 && (d > SIGMA_EXP_SPREAD || d < -SIGMA_EXP_SPREAD);
+}
+
 // ===================================================== tuned n = 4096 kernel
 // 16-point DFT in registers: two radix-4 layers.  Input x[a] at v[a]; output
 // X[k] at v[P16(k)], P16(k) = 4*(k&3) + (k>>2) (an involution).

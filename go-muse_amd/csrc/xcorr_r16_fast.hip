@@ -285,7 +285,15 @@ __device__ __forceinline__ bool finalize(const double *r, const int series, cons
     if (nan) { mv = __builtin_nan(""); lag = 0; } // placeholder: the pair is redone
     *mv_out = mv;
     *lag_out = lag;
-    return nan;
+    bool redo = nan;
+    if (series == 0 && r[35] != 0.0) { // the pair's other series: sigmas too far apart for one shared transform?
+        const double s2b = (r[25] + r[27]) + (r[29] + r[31]);
+        const Stat sb{r[33], s2b};
+        bool zb, nb;
+        const double varb = variance(sb, invN, invNm1, zb, nb);
+        redo = redo || (!nb && sigma_spread_too_wide(var, varb));
+    }
+    return redo;
 }
 
 } // namespace fast
@@ -616,7 +624,14 @@ __device__ __forceinline__ bool finalize_multi(const double *tr, const double *s
     if (nan) { mv = __builtin_nan(""); lag = 0; }
     *mv_out = mv;
     *lag_out = lag;
-    return nan;
+    bool redo = nan;
+    if (series == 0 && st[11] != 0.0) { // sigmas too far apart for one shared transform?
+        const Stat sb{st[9], (st[1] + st[3]) + (st[5] + st[7])};
+        bool zb, nb;
+        const double varb = variance(sb, invN, invNm1, zb, nb);
+        redo = redo || (!nb && sigma_spread_too_wide(var, varb));
+    }
+    return redo;
 }
 
 // 16-byte global store through a scalar base (+ element offset `off`) and a lane index
@@ -898,7 +913,10 @@ __global__ __launch_bounds__(OCC_THREADS, 4) void xcorr_fused_n4096_multi(const 
 // (pairs are handed out dynamically), one scratch slice per workgroup
 hipError_t launch_fused_multi(const FusedParams &p, int num_cus, hipStream_t stream)
 {
-    const long long grid = std::min<long long>(p.npairs, (long long)num_cus * 4);
+    int wpc = 4;
+    if (const char *d = getenv("MUSE_HIP_MULTI_WPC")) // tuning aid: resident workgroups per CU (1..4)
+        wpc = std::max(1, std::min(4, atoi(d)));
+    const long long grid = std::min<long long>(p.npairs, (long long)num_cus * wpc);
     if (p.zslots < grid || !p.zscratch || !p.work_counter || p.R < 1)
         return hipErrorInvalidValue;
     hipLaunchKernelGGL((xcorr_fused_n4096_multi<false>), dim3((unsigned)grid), dim3(OCC_THREADS), 0, stream, p);

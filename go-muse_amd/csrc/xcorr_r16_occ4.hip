@@ -221,11 +221,11 @@ __global__ __launch_bounds__(OCC_THREADS, WPS) void xcorr_fused_n4096_occ4(const
         if (t < 2 && prev_row >= 0)
             finalize(red + 16 + 24 * (parity ^ 1) + 3 * t, prev_stat, invN, invNm1, p.mv + prev_row,
                      p.lag + prev_row);
-        const Stat stA{q[0], q[1]}, stB{q[2], q[3]};
+        Stat stA{q[0], q[1]}, stB{q[2], q[3]};
         bool zeroA, nanA, zeroB, nanB;
-        variance(stA, invN, invNm1, zeroA, nanA);
-        variance(stB, invN, invNm1, zeroB, nanB);
-        const double mA = uniform(q[0] * invN), mB = uniform(q[2] * invN); // mean of d
+        const double varA0 = variance(stA, invN, invNm1, zeroA, nanA);
+        const double varB0 = variance(stB, invN, invNm1, zeroB, nanB);
+        double mA = uniform(q[0] * invN), mB = uniform(q[2] * invN); // mean of d
         if (PADDED) {
 #pragma unroll
             for (int i = 0; i < 16; i++) {
@@ -243,6 +243,22 @@ __global__ __launch_bounds__(OCC_THREADS, WPS) void xcorr_fused_n4096_occ4(const
                 v[i].x = deadA ? 0.0 : v[i].x;
                 v[i].y = deadB ? 0.0 : v[i].y;
             }
+        }
+        if (hasB && !nanA && !nanB && sigma_spread_too_wide(varA0, varB0)) { // block-uniform, rare
+            // sigmas more than 2^16 apart: bring both series to O(1) with exact powers of two, or the
+            // shared transform's rounding drowns the smaller one; the statistics scale along exactly
+            const double sA = pow2_inv_sigma(varA0), sB = pow2_inv_sigma(varB0);
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                v[i].x *= sA;
+                v[i].y *= sB;
+            }
+            stA.s1 *= sA;
+            stA.s2 *= sA * sA;
+            stB.s1 *= sB;
+            stB.s2 *= sB * sB;
+            mA *= sA;
+            mB *= sB;
         }
         const double2 dc = PADDED ? make_double2(0.0, 0.0)
                                   : make_double2(uniform(deadA ? 0.0 : 4096.0 * mA), uniform(deadB ? 0.0 : 4096.0 * mB));

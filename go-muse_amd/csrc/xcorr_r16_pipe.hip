@@ -279,8 +279,8 @@ __global__ __launch_bounds__(PIPE_THREADS, 2) void xcorr_fused_n4096_pipe(const 
                 q[k] = (red[k] + red[4 + k]) + (red[8 + k] + red[12 + k]);
         }
         ZnFlags fa, fb;
-        const double isa = zn_scale(q[0], q[1], N, fa); // 1/sigma, applied to the winner only
-        const double isb = zn_scale(q[2], q[3], N, fb);
+        double isa = zn_scale(q[0], q[1], N, fa); // 1/sigma, applied to the winner only
+        double isb = zn_scale(q[2], q[3], N, fb);
         const double mA = q[0] / dN, mB = q[2] / dN;
 #pragma unroll
         for (int i = 0; i < 16; i++) {
@@ -296,6 +296,19 @@ __global__ __launch_bounds__(PIPE_THREADS, 2) void xcorr_fused_n4096_pipe(const 
         // a sigma == 0 / NaN series (or the missing partner of an odd last row)
         // must contribute exact zeros to the shared complex transform
         const bool deadA = fa.zero || fa.nan, deadB = fb.zero || fb.nan || !hasB;
+        if (!deadA && !deadB) { // sigmas more than 2^16 apart (block-uniform, rare): see r16_device.h, pow2_inv_sigma
+            const long long ea = (__double_as_longlong(isa) >> 52) & 0x7ff, eb = (__double_as_longlong(isb) >> 52) & 0x7ff;
+            if (ea - eb > 16 || eb - ea > 16) {
+                const double sA = __longlong_as_double(ea << 52), sB = __longlong_as_double(eb << 52); // exact powers of two <= 1/sigma
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    v[i].x *= sA;
+                    v[i].y *= sB;
+                }
+                isa /= sA;
+                isb /= sB;
+            }
+        }
         if (deadA || deadB) { // block-uniform, rare
 #pragma unroll
             for (int i = 0; i < 16; i++) {

@@ -350,11 +350,11 @@ __global__ __launch_bounds__(W8_THREADS, 4) void xcorr_fused_n4096_w8(const Fuse
                            ((red[16 + k] + red[20 + k]) + (red[24 + k] + red[28 + k])));
         if (t < 2 && prev_row >= 0) // previous pair's argmax triples are visible now
             finalize(red + 32 + 48 * (parity ^ 1) + 3 * t, prev_stat, invN, invNm1, p.mv + prev_row, p.lag + prev_row);
-        const Stat stA{q[0], q[1]}, stB{q[2], q[3]};
+        Stat stA{q[0], q[1]}, stB{q[2], q[3]};
         bool zeroA, nanA, zeroB, nanB;
-        variance(stA, invN, invNm1, zeroA, nanA);
-        variance(stB, invN, invNm1, zeroB, nanB);
-        const double mA = uniform(q[0] * invN), mB = uniform(q[2] * invN);
+        const double varA0 = variance(stA, invN, invNm1, zeroA, nanA);
+        const double varB0 = variance(stB, invN, invNm1, zeroB, nanB);
+        double mA = uniform(q[0] * invN), mB = uniform(q[2] * invN);
         if (PADDED) {
 #pragma unroll
             for (int j = 0; j < 8; j++) {
@@ -370,6 +370,20 @@ __global__ __launch_bounds__(W8_THREADS, 4) void xcorr_fused_n4096_w8(const Fuse
                 v[j].x = deadA ? 0.0 : v[j].x;
                 v[j].y = deadB ? 0.0 : v[j].y;
             }
+        }
+        if (hasB && !nanA && !nanB && sigma_spread_too_wide(varA0, varB0)) { // block-uniform, rare: see xcorr_r16_occ4.hip
+            const double sA = pow2_inv_sigma(varA0), sB = pow2_inv_sigma(varB0);
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                v[j].x *= sA;
+                v[j].y *= sB;
+            }
+            stA.s1 *= sA;
+            stA.s2 *= sA * sA;
+            stB.s1 *= sB;
+            stB.s2 *= sB * sB;
+            mA *= sA;
+            mB *= sB;
         }
         const double2 dc = PADDED ? make_double2(0.0, 0.0)
                                   : make_double2(uniform(deadA ? 0.0 : 4096.0 * mA), uniform(deadB ? 0.0 : 4096.0 * mB));

@@ -315,15 +315,19 @@ void xcorr_fused_stk_lds(const FusedParams p)
         }
         const Stat stA{q[0], q[1]}, stB{q[2], q[3]};
         bool zeroA, nanA, zeroB, nanB;
-        const double varA = variance(stA, invN, invNm1, zeroA, nanA);
-        const double varB = variance(stB, invN, invNm1, zeroB, nanB);
-        const double mA = q[0] * invN, mB = q[2] * invN;
+        const double varA0 = variance(stA, invN, invNm1, zeroA, nanA);
+        const double varB0 = variance(stB, invN, invNm1, zeroB, nanB);
         const bool deadA = zeroA || nanA, deadB = zeroB || nanB || !hasB;
+        // both series go into the shared transform at O(1): exact power-of-two scales close to 1/sigma
+        // (r16_device.h, pow2_inv_sigma), folded into the mean removal; the variances scale along exactly
+        const double sA = deadA ? 1.0 : pow2_inv_sigma(varA0), sB = deadB ? 1.0 : pow2_inv_sigma(varB0);
+        const double varA = varA0 * sA * sA, varB = varB0 * sB * sB;
+        const double mA = q[0] * invN * sA, mB = q[2] * invN * sB;
 #pragma unroll
         for (int i = 0; i < 16; i++) {
             const bool valid = j + i * S - pad >= 0;
-            v[i].x = (valid && !deadA) ? v[i].x - mA : 0.0;
-            v[i].y = (valid && !deadB) ? v[i].y - mB : 0.0;
+            v[i].x = (valid && !deadA) ? fma(v[i].x, sA, -mA) : 0.0;
+            v[i].y = (valid && !deadB) ? fma(v[i].y, sB, -mB) : 0.0;
         }
         // forward transform, V = Z conj(X)/n, transposed transform: register i ends with cc[j + i S]
         lds_transforms<LOGN>(v, b, twm, j, [&](int r) __attribute__((always_inline)) { return p.xc[j + r * S]; });
@@ -451,10 +455,12 @@ __global__ __launch_bounds__(256, 2) void xcorr_fused_stk_glb(const FusedParams 
         block_sum<4>(q, red); // includes the barrier that orders sweep 0 before pass 1
         const Stat stA{q[0], q[1]}, stB{q[2], q[3]};
         bool zeroA, nanA, zeroB, nanB;
-        const double varA = variance(stA, invN, invNm1, zeroA, nanA);
-        const double varB = variance(stB, invN, invNm1, zeroB, nanB);
-        const double mA = q[0] * invN, mB = q[2] * invN;
+        const double varA0 = variance(stA, invN, invNm1, zeroA, nanA);
+        const double varB0 = variance(stB, invN, invNm1, zeroB, nanB);
         const bool deadA = zeroA || nanA, deadB = zeroB || nanB || !hasB;
+        const double sA = deadA ? 1.0 : pow2_inv_sigma(varA0), sB = deadB ? 1.0 : pow2_inv_sigma(varB0); // see the LDS kernel
+        const double varA = varA0 * sA * sA, varB = varB0 * sB * sB;
+        const double mA = q[0] * invN * sA, mB = q[2] * invN * sB;
         // ---- pass 1 (radix R1, Ns = 1): X0 -> X1, mean removed on the way in
 #pragma clang loop unroll(disable)
         for (int ch = 0; ch < CH; ch++) {
@@ -464,8 +470,8 @@ __global__ __launch_bounds__(256, 2) void xcorr_fused_stk_glb(const FusedParams 
             for (int i = 0; i < 16; i++) {
                 const bool valid = j + i * S - pad >= 0;
                 const double2 d = X0[j + i * S];
-                v[i].x = (valid && !deadA) ? d.x - mA : 0.0;
-                v[i].y = (valid && !deadB) ? d.y - mB : 0.0;
+                v[i].x = (valid && !deadA) ? fma(d.x, sA, -mA) : 0.0;
+                v[i].y = (valid && !deadB) ? fma(d.y, sB, -mB) : 0.0;
             }
             dft_small<R1>(v);
 #pragma unroll
@@ -714,7 +720,8 @@ __global__ __launch_bounds__(256, 2) void xcorr_fused_stk_4step(const FusedParam
             const Stat stA{q[0], q[1]}, stB{q[2], q[3]};
             varA = variance(stA, invN, invNm1, zeroA, nanA);
             varB = variance(stB, invN, invNm1, zeroB, nanB);
-            zero_dc = !(nanA || nanB); // block-uniform
+            // block-uniform; sigmas too far apart for the unscaled shared transform also take the general path
+            zero_dc = !(nanA || nanB) && !(hasB && sigma_spread_too_wide(varA, varB));
         }
         if (!zero_dc) {
             // ---- sweep 0: rows -> d = x - K (leading zero pad) into the slice, shifted statistics
@@ -739,10 +746,13 @@ __global__ __launch_bounds__(256, 2) void xcorr_fused_stk_4step(const FusedParam
             }
             block_sum<4>(q, red);
             const Stat stA{q[0], q[1]}, stB{q[2], q[3]};
-            varA = variance(stA, invN, invNm1, zeroA, nanA);
-            varB = variance(stB, invN, invNm1, zeroB, nanB);
-            const double mA = q[0] * invN, mB = q[2] * invN;
+            const double varA0 = variance(stA, invN, invNm1, zeroA, nanA);
+            const double varB0 = variance(stB, invN, invNm1, zeroB, nanB);
             const bool deadA = zeroA || nanA, deadB = zeroB || nanB || !hasB;
+            const double sA = deadA ? 1.0 : pow2_inv_sigma(varA0), sB = deadB ? 1.0 : pow2_inv_sigma(varB0); // see the LDS kernel
+            varA = varA0 * sA * sA;
+            varB = varB0 * sB * sB;
+            const double mA = q[0] * invN * sA, mB = q[2] * invN * sB;
             // ---- sweep 1: radix R1 over m1 (butterflies m2 = j + m S on registers m + s Q1), twiddle
             // W_n^(m2 k1), in place (positions m2 + s 4096 = j + (m + s Q1) S)
 #pragma clang loop unroll(disable)
@@ -753,8 +763,8 @@ __global__ __launch_bounds__(256, 2) void xcorr_fused_stk_4step(const FusedParam
                 for (int i = 0; i < 16; i++) {
                     const bool valid = j + i * S - pad >= 0;
                     const double2 d = Y[j + i * S];
-                    v[i].x = (valid && !deadA) ? d.x - mA : 0.0;
-                    v[i].y = (valid && !deadB) ? d.y - mB : 0.0;
+                    v[i].x = (valid && !deadA) ? fma(d.x, sA, -mA) : 0.0;
+                    v[i].y = (valid && !deadB) ? fma(d.y, sB, -mB) : 0.0;
                 }
                 dft_small<R1>(v);
                 twiddle_rows(v, j);

@@ -261,6 +261,13 @@ def test_every_kernel_variant_matches_oracle(muse, eng, oracle, N):
     rows[10, 5] = np.nan          # NaN row: (lag 0, mv NaN), must not disturb its pair partner
     rows[12, :] = np.inf
     rows[20, :] = 2.0 ** 600      # huge but exactly summable constant: sigma == 0 without overflow
+    # pair partners whose sigmas are 1e50 / 1e13 / 1e-30 apart: two series share one complex transform,
+    # so every kernel must rescale (or hand the pair to one that does) to keep the small one exact
+    rows[30] *= 1e50
+    rows[33] *= 1e13
+    rows[36] *= 1e-30
+    rows[39] *= 1e120
+    rows[38] *= 1e-120
     dg = muse.DeviceGroup.from_rows(eng, rows)
     db = muse.DeviceBatch(eng, dg, ref)
     assert db.n == 4096
@@ -528,6 +535,8 @@ def test_many_references_one_pass_matches_single_batches(muse, eng, oracle, R, M
     rows[3, 100] = np.nan
     rows[8, :] = np.inf
     rows[11, :] = -7.25
+    rows[14] *= 1e30              # sigmas far apart inside a pair: listed and redone per reference
+    rows[17] *= 1e-20
     refs = [rng.standard_normal(N) + (np.arange(N) == 100 * r) * 30.0 for r in range(R)]
     rows[20:20 + R] = np.stack([np.roll(refs[r], 5 * r + 1) for r in range(R)])   # known lags per reference
     dg = muse.DeviceGroup.from_rows(eng, rows)
@@ -580,6 +589,8 @@ def test_stockham_kernels_match_oracle_and_generic(muse, eng, oracle, N):
     rows[10, 5 % N] = np.nan
     rows[12, :] = np.inf
     rows[20, :] = 2.0 ** 600
+    rows[14] *= 1e40              # sigmas far apart inside a pair (shared complex transform)
+    rows[17] *= 1e-25
     dg = muse.DeviceGroup.from_rows(eng, rows)
     db = muse.DeviceBatch(eng, dg, ref)
     olag, omv, gap = oracle.batch_scores(ref, rows)
@@ -623,3 +634,41 @@ def test_mirror_run_many_equals_runs(muse):
             assert x.Lag == y.Lag and x.Labels.ID(x.Labels.Keys()) == y.Labels.ID(y.Labels.Keys())
             assert abs(x.PercentScore - y.PercentScore) <= 1e-12
         assert abs(am - bm) <= 1e-12
+
+
+def test_fuzz_random_shapes_against_oracle(muse, eng, oracle):
+    """Seeded sweep over random (N, M) and data regimes -- large offsets, tiny and huge scales, sparse
+    spikes, constant / NaN / Inf rows -- through automatic kernel selection (every kernel family:
+    generic n < 512, Stockham LDS, tuned 4096, four-step) against the oracle."""
+    rng = np.random.default_rng(20261003)
+    lengths = [2, 3, 5, 17, 64, 255, 256, 300, 511, 513, 777, 1023, 1100, 2000, 2047, 2049, 3333, 4095, 4096,
+               4097, 6000, 8191, 8193, 12000, 16383, 16384, 16385, 30000, 32768, 50000, 65535, 65536]
+    worst = 0.0
+    for trial, N in enumerate(lengths):
+        M = int(rng.integers(1, 12)) if N > 8192 else int(rng.integers(1, 40))
+        regime = trial % 5
+        ref = rng.standard_normal(N)
+        rows = rng.standard_normal((M, N))
+        if regime == 1:
+            rows += 1e6 * rng.standard_normal((M, 1))                    # large level, unit noise
+        elif regime == 2:
+            rows *= 10.0 ** rng.uniform(-150, 150, size=(M, 1))          # extreme scales
+        elif regime == 3:
+            rows[:] = 0.0                                                # sparse spikes
+            for i in range(M):
+                rows[i, rng.integers(0, N, size=max(1, min(N, 3)))] = rng.standard_normal(max(1, min(N, 3)))
+        elif regime == 4 and N > 4:
+            rows += np.roll(ref, int(rng.integers(-N // 2, N // 2)))[None, :] * rng.uniform(-3, 3, size=(M, 1))
+        if M > 2:
+            rows[int(rng.integers(0, M))] = 3.25                          # sigma == 0
+        if M > 4:
+            rows[int(rng.integers(0, M)), int(rng.integers(0, N))] = np.nan
+            rows[int(rng.integers(0, M)), int(rng.integers(0, N))] = np.inf
+        dg = muse.DeviceGroup.from_rows(eng, rows)
+        db = muse.DeviceBatch(eng, dg, ref)
+        lag, mv = db.scores()
+        olag, omv, gap = oracle.batch_scores(ref, rows)
+        worst = max(worst, assert_scores_match(lag, mv, olag, omv, gap, max_ties=2))
+        db.close()
+        dg.close()
+    print("fuzz worst relative score error %.3e" % worst)
