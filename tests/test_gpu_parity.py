@@ -672,3 +672,47 @@ def test_fuzz_random_shapes_against_oracle(muse, eng, oracle):
         db.close()
         dg.close()
     print("fuzz worst relative score error %.3e" % worst)
+
+
+def test_fuzz_run_semantics_against_oracle(muse, eng, oracle):
+    """Seeded sweep over Batch.Run / Muse.Run post-processing: random group maps (incl. empty groups and
+    G both below and above the device top-N threshold), MaxLag, TopN, Threshold, sign filter and abs
+    flag; scores are continuous random values, so no exact ties straddle the top-N boundary."""
+    rng = np.random.default_rng(77)
+    for trial in range(24):
+        N = int(rng.choice([96, 700, 4096]))
+        M = int(rng.integers(1, 6000 if N < 1000 else 1500))
+        ref = rng.standard_normal(N)
+        rows = rng.standard_normal((M, N))
+        k = max(1, M // 7)
+        for i in rng.integers(0, M, size=k):                       # planted matches at random lags / signs
+            rows[i] += rng.uniform(-4, 4) * np.roll(ref, int(rng.integers(-N // 2, N // 2)))
+        if M > 10:
+            rows[int(rng.integers(0, M))] = 1.0                    # sigma == 0
+            rows[int(rng.integers(0, M)), 0] = np.nan
+        dg = muse.DeviceGroup.from_rows(eng, rows)
+        db = muse.DeviceBatch(eng, dg, ref)
+        lag, mv = db.scores()
+        olag, omv, gap = oracle.batch_scores(ref, rows)
+        assert_scores_match(lag, mv, olag, omv, gap, max_ties=2)
+        for _ in range(4):
+            if rng.random() < 0.25:
+                gid, G = None, 0
+            else:
+                G = int(rng.integers(1, max(2, 2 * M)))
+                gid = rng.integers(0, G, size=M).astype(np.int32)
+            max_lag = int(rng.choice([0, 3, 15, N // 4, N]))
+            top_n = int(rng.choice([1, 5, 20, 257, 1000]))
+            thr = float(rng.choice([0.0, 0.05, 0.3]))
+            sign = int(rng.choice([0, 1, -1]))
+            absf = bool(rng.random() < 0.6)
+            got = db.run(gid, G, max_lag, top_n, thr, sign, absf)
+            # the oracle post-processes the GPU's own (lag, mv): this test is about the selection logic
+            exp = oracle.results(lag, mv, gid, G, absf, max_lag, top_n, thr, sign)
+            key = (trial, N, M, G, max_lag, top_n, thr, sign, absf)
+            assert got[0].tolist() == exp[0].tolist(), key
+            assert got[1].tolist() == exp[1].tolist(), key
+            assert np.array_equal(got[2], exp[2], equal_nan=True), key
+            assert (math.isnan(got[3]) and math.isnan(exp[3])) or abs(got[3] - exp[3]) <= 1e-15 * max(1.0, abs(exp[3])), key
+        db.close()
+        dg.close()
