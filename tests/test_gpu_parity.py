@@ -716,3 +716,22 @@ def test_fuzz_run_semantics_against_oracle(muse, eng, oracle):
             assert (math.isnan(got[3]) and math.isnan(exp[3])) or abs(got[3] - exp[3]) <= 1e-15 * max(1.0, abs(exp[3])), key
         db.close()
         dg.close()
+
+
+@pytest.mark.parametrize("N", [1000, 4096, 5000, 16384])
+def test_samples_whose_squares_overflow(muse, eng, oracle, N):
+    """|x| ~ 1e250: sum (x - mean)^2 overflows.  In the reference gonum's compensation term
+    (sum (x - mean))^2 / n overflows as well, the variance is Inf - Inf = NaN and every cc is NaN
+    -> (0, NaN); the tuned kernels' shifted sums overflow the same way.  (Between ~1e154 and ~1e170 the
+    reference's outcome depends on the rounding residue of its own summation order -- NaN or (0, 0.0) --
+    and is not reproducible by any other implementation; not tested.)  The pair partner stays exact."""
+    rng = np.random.default_rng(N)
+    ref = rng.standard_normal(N)
+    rows = rng.standard_normal((9, N))
+    rows[2] *= 1e250
+    rows[5] *= -1e250
+    dg = muse.DeviceGroup.from_rows(eng, rows)
+    lag, mv = muse.DeviceBatch(eng, dg, ref).scores()
+    olag, omv, gap = oracle.batch_scores(ref, rows)
+    assert math.isnan(omv[2]) and math.isnan(omv[5])
+    assert_scores_match(lag, mv, olag, omv, gap)
