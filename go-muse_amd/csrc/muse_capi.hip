@@ -789,7 +789,9 @@ extern "C" int muse_batch_score(muse_batch *b)
         FusedParams q = p;
         q.pair_list = b->ovf_list;
         q.pair_count = b->ovf_count;
-        q.npairs = std::min<long long>(p.npairs, 64); // grid size only; the loop bound is *pair_count
+        // grid size only (the loop bound is *pair_count): one resident set, so a group with MANY listed pairs
+        // (mixed-unit metrics: sigmas far apart) is redone at full width; an empty list costs a few microseconds
+        q.npairs = std::min<long long>(p.npairs, (long long)ctx->num_cus * 3);
         HIP_TRY(launch_fused(q, KERNEL_R16_OCC3, ctx->num_cus, ctx->stream));
     } else {
         HIP_TRY(launch_fused(p, variant, ctx->num_cus, ctx->stream));
@@ -1180,7 +1182,7 @@ extern "C" int muse_batch_score_many(muse_batch *const *bs, int32_t R)
         FusedParams q = base_params(bs[r]);
         q.pair_list = b0->ovf_list;
         q.pair_count = b0->ovf_count;
-        q.npairs = std::min<long long>(q.npairs, 64);
+        q.npairs = std::min<long long>(q.npairs, (long long)ctx->num_cus * 3);
         HIP_TRY(launch_fused(q, KERNEL_R16_OCC3, ctx->num_cus, ctx->stream));
     }
     if (ctx->timing) {

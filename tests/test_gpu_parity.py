@@ -735,3 +735,18 @@ def test_samples_whose_squares_overflow(muse, eng, oracle, N):
     olag, omv, gap = oracle.batch_scores(ref, rows)
     assert math.isnan(omv[2]) and math.isnan(omv[5])
     assert_scores_match(lag, mv, olag, omv, gap)
+
+
+def test_mixed_unit_group_every_pair_handed_off(muse, eng, oracle):
+    """a Group that alternates O(1) and O(1e30) series (mixed-unit metrics): EVERY pair of the default
+    N = 4096 kernel is listed for the rescaling kernel; results still match the oracle row by row"""
+    rng = np.random.default_rng(9)
+    M, N = 3001, 4096
+    ref = rng.standard_normal(N)
+    rows = rng.standard_normal((M, N))
+    rows[::5] += 2.0 * np.roll(ref, 7)[None, :]
+    rows[1::2] *= 1e30
+    dg = muse.DeviceGroup.from_rows(eng, rows)
+    lag, mv = muse.DeviceBatch(eng, dg, ref).scores()
+    olag, omv, gap = oracle.batch_scores(ref, rows, nthreads=16)
+    assert_scores_match(lag, mv, olag, omv, gap, max_ties=1)
