@@ -122,6 +122,10 @@ struct muse_batch {
     double2 *gscratch = nullptr; // n > 8192: per-workgroup work buffers of the generic kernel
     double *xs = nullptr;  // padded time-domain reference (exact re-evaluation)
     int *ovf_count = nullptr;
+    // automatic kernel selection learns from the previous pass over the same (immutable) rows: the number of
+    // pairs the default N = 4096 kernel handed to the rescaling kernel lands here (pinned, asynchronous copy)
+    int *handoff_host = nullptr;
+    int64_t handoff_M = -1;
     long long *ovf_list = nullptr;
     int64_t ovf_cap = 0;
     double *mv = nullptr;
@@ -758,6 +762,11 @@ extern "C" int muse_batch_score(muse_batch *b)
         }
         if (variant == KERNEL_R16_FAST && b->N != 4096) // the deferred-statistics kernel is built for N == n only
             variant = KERNEL_R16_OCC3;
+        // a group of mixed-unit series (sigmas far apart inside most pairs) makes the default kernel hand most
+        // pairs to kernel 7 anyway: once a pass over these rows has shown that, go there directly
+        if (variant == KERNEL_R16_FAST && ctx->variant == 0 && b->handoff_host && b->handoff_M == M &&
+            (long long)*(volatile int *)b->handoff_host * 8 > p.npairs)
+            variant = KERNEL_R16_OCC3;
     } else if (((b->n >= 512 && b->n <= 2048) || b->n >= 8192) && (ctx->variant == 0 || ctx->variant == 11)) {
         variant = KERNEL_STOCKHAM; // radix-16 Stockham through LDS / global scratch (xcorr_stockham.hip)
     }
@@ -793,6 +802,13 @@ extern "C" int muse_batch_score(muse_batch *b)
         // (mixed-unit metrics: sigmas far apart) is redone at full width; an empty list costs a few microseconds
         q.npairs = std::min<long long>(p.npairs, (long long)ctx->num_cus * 3);
         HIP_TRY(launch_fused(q, KERNEL_R16_OCC3, ctx->num_cus, ctx->stream));
+        if (variant == KERNEL_R16_FAST) {
+            if (!b->handoff_host)
+                HIP_TRY(hipHostMalloc((void **)&b->handoff_host, sizeof(int), hipHostMallocDefault));
+            *b->handoff_host = 0;
+            b->handoff_M = M;
+            HIP_TRY(hipMemcpyAsync(b->handoff_host, b->ovf_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        }
     } else {
         HIP_TRY(launch_fused(p, variant, ctx->num_cus, ctx->stream));
     }
@@ -1237,6 +1253,7 @@ extern "C" int muse_batch_free(muse_batch *b)
     (void)hipFree(b->gscratch);
     (void)hipFree(b->xs);
     (void)hipFree(b->ovf_count);
+    (void)hipHostFree(b->handoff_host);
     (void)hipFree(b->ovf_list);
     (void)hipFree(b->mv);
     (void)hipFree(b->lag);

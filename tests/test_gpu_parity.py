@@ -747,6 +747,11 @@ def test_mixed_unit_group_every_pair_handed_off(muse, eng, oracle):
     rows[::5] += 2.0 * np.roll(ref, 7)[None, :]
     rows[1::2] *= 1e30
     dg = muse.DeviceGroup.from_rows(eng, rows)
-    lag, mv = muse.DeviceBatch(eng, dg, ref).scores()
+    db = muse.DeviceBatch(eng, dg, ref)
+    lag, mv = db.scores()
     olag, omv, gap = oracle.batch_scores(ref, rows, nthreads=16)
     assert_scores_match(lag, mv, olag, omv, gap, max_ties=1)
+    # the second pass over the same rows goes to the rescaling kernel directly (automatic selection learnt the
+    # hand-off count of the first): same results
+    lag2, mv2 = db.scores()
+    assert np.array_equal(lag, lag2) and np.array_equal(mv, mv2)
