@@ -78,5 +78,5 @@ def build_host_test(force=False):
         return HOST_TEST
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I" + os.path.join(ROOT, "include"),
                            "-I" + os.path.join(PKG, "host"), src, "-o", HOST_TEST,
-                           "-L" + LIBDIR, "-lmuse_hip", "-Wl,-rpath," + LIBDIR])
+                           "-L" + LIBDIR, "-lmuse_hip", "-pthread", "-Wl,-rpath," + LIBDIR])
     return HOST_TEST

@@ -22,6 +22,7 @@
 #include <limits>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <random>
 #include <stdexcept>
 #include <string>
@@ -271,6 +272,7 @@ public:
     {
         if (!s.Labels)
             return;
+        std::lock_guard<std::mutex> lock(mu_); // results.go:12,60: Muse.Run is called from many goroutines
         if (!passed(s))
             return;
         if ((int)h_.size() == TopN) {
@@ -285,6 +287,7 @@ public:
     // results.go:75-87: descending |score| + mean |score| (NaN when empty); drains the heap
     std::pair<Scores, double> Fetch()
     {
+        std::lock_guard<std::mutex> lock(mu_);
         const size_t num = h_.size();
         Scores out(num);
         double sum = 0.0;
@@ -296,6 +299,7 @@ public:
     }
 
 private:
+    std::mutex mu_;
     std::vector<Score> h_;
     bool less(size_t i, size_t j) const { return std::fabs(h_[i].PercentScore) < std::fabs(h_[j].PercentScore); }
     void up(size_t j)

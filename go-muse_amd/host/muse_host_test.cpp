@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cmath>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "muse.hpp"
@@ -198,6 +199,44 @@ static void TestRunManyEqualsRuns()
     }
 }
 
+// muse_test.go:203-214: one *Muse driven from many goroutines (here: std::thread)
+static void TestRunConcurrentCallers()
+{
+    const int N = 512, G = 16;
+    auto mk = [&](int seed, int shift) {
+        std::vector<double> v(N);
+        unsigned long long h = 0x9E3779B97F4A7C15ull * (unsigned long long)(seed + 1);
+        for (int i = 0; i < N; i++) {
+            h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+            v[i] = (double)(h >> 11) * (1.0 / 9007199254740992.0) - 0.5 + ((i + shift) % N >= 200 && (i + shift) % N < 230 ? 2.0 : 0.0);
+        }
+        return v;
+    };
+    auto ref = NewSeries(mk(0, 0), NewLabels({{"graph", "ref"}}));
+    std::vector<std::vector<SeriesPtr>> groups(G);
+    for (int g = 0; g < G; g++)
+        for (int k = 0; k < 4; k++)
+            groups[g].push_back(NewSeries(mk(100 * g + k + 1, 5 * g + k), NewLabels({{"graph", "g" + std::to_string(g)}, {"host", "h" + std::to_string(k)}})));
+    auto seq = New(ref, NewResults(N, 8, 0, SignFilter_ANY));
+    for (auto &gr : groups)
+        seq->Run(gr);
+    auto par = New(ref, NewResults(N, 8, 0, SignFilter_ANY));
+    std::vector<std::thread> th;
+    for (int w = 0; w < 4; w++)
+        th.emplace_back([&, w] {
+            for (int g = w; g < G; g += 4)
+                par->Run(groups[g]);
+        });
+    for (auto &t : th)
+        t.join();
+    auto a = seq->Results_->Fetch(), b = par->Results_->Fetch();
+    EXPECT(a.first.size() == b.first.size(), "concurrent Run: %zu vs %zu scores", a.first.size(), b.first.size());
+    for (size_t i = 0; i < a.first.size() && i < b.first.size(); i++) {
+        EXPECT(a.first[i].Lag == b.first[i].Lag && a.first[i].Labels->ID() == b.first[i].Labels->ID(), "concurrent Run[%zu]: lag/labels", i);
+        EXPECT(std::fabs(a.first[i].PercentScore - b.first[i].PercentScore) <= 1e-12, "concurrent Run[%zu]: score", i);
+    }
+}
+
 int main()
 {
     try {
@@ -208,6 +247,7 @@ int main()
         TestRunSimpleSignFilter();
         TestRunNoInput();
         TestRunManyEqualsRuns();
+        TestRunConcurrentCallers();
     } catch (const Error &e) {
         printf("muse::Error %d: %s\n", e.status, e.what());
         return 2;

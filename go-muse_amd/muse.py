@@ -16,6 +16,7 @@ data, so every Run behaves like the reference's FIRST Run on fresh inputs.
 import ctypes
 import math
 import sys
+import threading
 import uuid
 
 import numpy as np
@@ -467,6 +468,7 @@ class Results:
     def __init__(self, maxLag, topN, threshold, signFilter):
         self.MaxLag, self.TopN, self.Threshold, self.SignFilter = maxLag, topN, threshold, signFilter
         self.scores = []
+        self._mu = threading.Lock()               # results.go:12: Muse.Run is called from many goroutines
 
     def _less(self, i, j):                        # scores.go:25-27
         return abs(self.scores[i].PercentScore) < abs(self.scores[j].PercentScore)
@@ -513,23 +515,25 @@ class Results:
     def Update(self, s):                          # results.go:55-72
         if s.Labels is None:
             return
-        if self.passed(s):
-            if len(self.scores) == self.TopN:
-                if self.TopN > 0 and abs(s.PercentScore) > abs(self.scores[0].PercentScore):
-                    self._pop()
+        with self._mu:
+            if self.passed(s):
+                if len(self.scores) == self.TopN:
+                    if self.TopN > 0 and abs(s.PercentScore) > abs(self.scores[0].PercentScore):
+                        self._pop()
+                        self._push(s)
+                else:
                     self._push(s)
-            else:
-                self._push(s)
 
     def Fetch(self):                              # results.go:75-87
-        num = len(self.scores)
-        out = [None] * num
-        total = 0.0
-        for i in range(num - 1, -1, -1):
-            sc = self._pop()
-            total += abs(sc.PercentScore)
-            out[i] = sc
-        return out, (total / num if num else math.nan)
+        with self._mu:
+            num = len(self.scores)
+            out = [None] * num
+            total = 0.0
+            for i in range(num - 1, -1, -1):
+                sc = self._pop()
+                total += abs(sc.PercentScore)
+                out[i] = sc
+            return out, (total / num if num else math.nan)
 
 
 def NewResults(maxLag, topN, threshold, signFilter):

@@ -755,3 +755,46 @@ def test_mixed_unit_group_every_pair_handed_off(muse, eng, oracle):
     # hand-off count of the first): same results
     lag2, mv2 = db.scores()
     assert np.array_equal(lag, lag2) and np.array_equal(mv, mv2)
+
+
+def test_muse_run_concurrent_callers(muse):
+    """muse_test.go:203-214 drives one *Muse from many goroutines (Results is mutex-protected,
+    results.go:12,60,71): the same from Python threads -- every call crosses the C ABI on the shared
+    context with the GIL released -- must give what sequential calls give."""
+    import threading
+    rng = np.random.default_rng(3)
+    N = 1024
+    ref_y = rng.standard_normal(N)
+    ref_y[400:440] += 5.0
+    ref = muse.NewSeries(ref_y, muse.NewLabels({"graph": "ref"}))
+    groups = []
+    for g in range(24):
+        ss = []
+        for k in range(5):
+            y = rng.standard_normal(N)
+            y[(400 + 9 * g + k) % N:(440 + 9 * g + k) % N or None] += 3.0 + k
+            ss.append(muse.NewSeries(y, muse.NewLabels({"graph": "g%d" % g, "host": "h%d" % k})))
+        groups.append(ss)
+    seq = muse.New(ref, muse.NewResults(N, 10, 0.0, muse.SignFilter_ANY))
+    for ss in groups:
+        seq.Run(ss)
+    par = muse.New(ref, muse.NewResults(N, 10, 0.0, muse.SignFilter_ANY))
+    errors = []
+
+    def work(chunk):
+        try:
+            for ss in chunk:
+                par.Run(ss)
+        except Exception as e:          # pragma: no cover
+            errors.append(e)
+    threads = [threading.Thread(target=work, args=(groups[i::6],)) for i in range(6)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    a, am = seq.Results.Fetch()
+    b, bm = par.Results.Fetch()
+    key = lambda s: (round(abs(s.PercentScore), 12), s.Lag, s.Labels.ID(s.Labels.Keys()))
+    assert sorted(map(key, a)) == sorted(map(key, b))
+    assert abs(am - bm) <= 1e-12
