@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -80,6 +81,14 @@ struct muse_ctx {
     double2 *tw1 = nullptr, *tw2 = nullptr, *twm = nullptr, *tw1w8 = nullptr, *tw1p = nullptr;
     float2 *tw1f = nullptr, *tw2f = nullptr; // fp32 copies for the screening kernel
     // many-reference pass (muse_batch_score_many): parked spectra + device pointer tables
+    // pinned staging buffers (32 MB each) lent to groups that receive many small appends; allocated once
+    // (hipHostMalloc of 32 MB costs milliseconds) and returned when the group is released
+    // work buffers of the generic / Stockham kernels for n >= 8192: one allocation per context, grown on demand
+    // (every kernel that uses it runs on the context's single stream)
+    double2 *gscratch = nullptr;
+    size_t gscratch_elems = 0;
+    std::vector<double *> stage_pool;
+    std::mutex stage_mu;
     double2 *zscratch = nullptr;
     int zslots = 0;
     void *many_tab = nullptr; // R x {xcp, mv, lag} pointers
@@ -110,16 +119,26 @@ struct muse_group {
     int cur = 0;
     int64_t staged = 0;     // rows waiting in stage[cur]
     int64_t stage_rows = 0; // capacity of one staging buffer, in rows
+    int small_appends = 0;  // the first small append goes straight to the device (Muse.Run: one upload per group)
+};
+
+// The reference spectrum and the tables derived from it: shared (reference-counted) by the batches
+// created with muse_batch_create_like -- Muse.Run builds one small group per call against ONE reference.
+struct muse_spectrum {
+    std::atomic<int> refs{1};
+    double2 *X = nullptr, *xc = nullptr, *xcp = nullptr;
+    float2 *xcf = nullptr;
+    double *xs = nullptr;
 };
 
 struct muse_batch {
     muse_ctx *ctx = nullptr;
     muse_group *g = nullptr;
     int32_t N = 0, n = 0, logn = 0;
+    muse_spectrum *sp = nullptr; // owner of the five tables below (the pointers are copies)
     double2 *X = nullptr, *xc = nullptr;
     double2 *xcp = nullptr; // n == 4096: xc in the lane order of xcorr_r16_fast.hip
     float2 *xcf = nullptr; // fp32 conj(X)/n (screening kernel)
-    double2 *gscratch = nullptr; // n > 8192: per-workgroup work buffers of the generic kernel
     double *xs = nullptr;  // padded time-domain reference (exact re-evaluation)
     int *ovf_count = nullptr;
     // automatic kernel selection learns from the previous pass over the same (immutable) rows: the number of
@@ -250,6 +269,9 @@ static void ctx_release(muse_ctx *ctx)
     (void)hipFree(ctx->tw1w8);
     (void)hipFree(ctx->tw1p);
     (void)hipFree(ctx->zscratch);
+    (void)hipFree(ctx->gscratch);
+    for (double *b : ctx->stage_pool)
+        (void)hipHostFree(b);
     (void)hipFree(ctx->many_tab);
     (void)hipFree(ctx->tw2f);
     if (ctx->stream)
@@ -405,11 +427,25 @@ extern "C" int muse_group_append(muse_group *g, const double *rows, int64_t coun
         return rc;
     const size_t row_bytes = (size_t)g->N * sizeof(double);
     constexpr size_t STAGE_BYTES = 32u << 20;
-    const bool small = (size_t)count * row_bytes < STAGE_BYTES / 4;
-    if (small && !g->stage[0]) { // first small append: set the staging pair up
+    // small appends are staged from the SECOND one on: a group that is uploaded in one call (Muse.Run builds one
+    // per call) never needs the staging pair
+    bool small = (size_t)count * row_bytes < STAGE_BYTES / 4 && row_bytes <= STAGE_BYTES;
+    if (small && !g->stage[0] && g->small_appends++ == 0)
+        small = false;
+    if (small && !g->stage[0]) { // borrow the staging pair from the context's pool
         g->stage_rows = std::max<int64_t>(1, (int64_t)(STAGE_BYTES / row_bytes));
         for (int i = 0; i < 2; i++) {
-            HIP_TRY(hipHostMalloc((void **)&g->stage[i], (size_t)g->stage_rows * row_bytes, hipHostMallocDefault));
+            double *buf = nullptr;
+            {
+                std::lock_guard<std::mutex> lock(g->ctx->stage_mu);
+                if (!g->ctx->stage_pool.empty()) {
+                    buf = g->ctx->stage_pool.back();
+                    g->ctx->stage_pool.pop_back();
+                }
+            }
+            if (!buf)
+                HIP_TRY(hipHostMalloc((void **)&buf, STAGE_BYTES, hipHostMallocDefault));
+            g->stage[i] = buf;
             HIP_TRY(hipEventCreateWithFlags(&g->stage_done[i], hipEventDisableTiming));
             HIP_TRY(hipEventRecord(g->stage_done[i], g->ctx->stream));
         }
@@ -532,8 +568,10 @@ static void group_release(muse_group *g)
     (void)hipStreamSynchronize(g->ctx->stream);
     (void)hipFree(g->rows);
     for (int i = 0; i < 2; i++) {
-        if (g->stage[i])
-            (void)hipHostFree(g->stage[i]);
+        if (g->stage[i]) { // back to the context's pool (the stream is idle: no upload reads it any more)
+            std::lock_guard<std::mutex> lock(g->ctx->stage_mu);
+            g->ctx->stage_pool.push_back(g->stage[i]);
+        }
         if (g->stage_done[i])
             (void)hipEventDestroy(g->stage_done[i]);
     }
@@ -586,6 +624,35 @@ static int build_spectrum(muse_ctx *ctx, const double *ref_host, int N, int n, i
     return MUSE_OK;
 }
 
+static hipError_t ensure_gscratch(muse_ctx *ctx, int64_t n)
+{
+    if (n < GENERIC_LDS_MAX_N) // generic kernel above 8192: one slice per workgroup; Stockham from 8192: up to two
+        return hipSuccess;
+    const size_t need = (size_t)ctx->num_cus * std::max(GENERIC_GLOBAL_WGS_PER_CU, 2 * STOCKHAM_GLOBAL_WGS_PER_CU) * (size_t)n;
+    std::lock_guard<std::mutex> lock(ctx->stage_mu); // launches that use the buffer hold the same lock (muse_batch_score)
+    if (need <= ctx->gscratch_elems)
+        return hipSuccess;
+    hipError_t e = hipStreamSynchronize(ctx->stream); // nothing may still be using the old buffer
+    if (e != hipSuccess)
+        return e;
+    (void)hipFree(ctx->gscratch);
+    ctx->gscratch = nullptr;
+    ctx->gscratch_elems = 0;
+    e = hipMalloc(&ctx->gscratch, need * sizeof(double2));
+    if (e == hipSuccess)
+        ctx->gscratch_elems = need;
+    return e;
+}
+
+static void adopt_spectrum(muse_batch *b)
+{
+    b->X = b->sp->X;
+    b->xc = b->sp->xc;
+    b->xcp = b->sp->xcp;
+    b->xcf = b->sp->xcf;
+    b->xs = b->sp->xs;
+}
+
 extern "C" int muse_batch_create(muse_ctx *ctx, muse_group *g, const double *ref, int32_t N, muse_batch **out)
 {
     if (!out)
@@ -616,21 +683,28 @@ extern "C" int muse_batch_create(muse_ctx *ctx, muse_group *g, const double *ref
     b->N = N;
     b->n = (int32_t)n;
     b->logn = ilog2(n);
-    hipError_t e = hipMalloc(&b->X, (size_t)(n / 2 + 1) * sizeof(double2));
+    hipError_t e = hipMalloc(&b->ovf_count, 2 * sizeof(int)); // [0] overflow-pair count, [1] dynamic work counter
     if (e == hipSuccess)
-        e = hipMalloc(&b->xc, (size_t)n * sizeof(double2));
+        e = ensure_gscratch(ctx, n);
+    muse_spectrum *sp = new (std::nothrow) muse_spectrum();
+    if (!sp)
+        e = hipErrorOutOfMemory;
+    b->sp = sp;
     if (e == hipSuccess)
-        e = hipMalloc(&b->xcf, (size_t)n * sizeof(float2));
+        e = hipMalloc(&sp->X, (size_t)(n / 2 + 1) * sizeof(double2));
     if (e == hipSuccess)
-        e = hipMalloc(&b->xs, (size_t)n * sizeof(double));
+        e = hipMalloc(&sp->xc, (size_t)n * sizeof(double2));
     if (e == hipSuccess)
-        e = hipMalloc(&b->ovf_count, 2 * sizeof(int)); // [0] overflow-pair count, [1] dynamic work counter
-    if (e == hipSuccess && n >= GENERIC_LDS_MAX_N) // generic kernel above 8192: one slice per workgroup; Stockham from 8192: two
-        e = hipMalloc(&b->gscratch, (size_t)ctx->num_cus * std::max(GENERIC_GLOBAL_WGS_PER_CU, 2 * STOCKHAM_GLOBAL_WGS_PER_CU) * (size_t)n * sizeof(double2));
+        e = hipMalloc(&sp->xcf, (size_t)n * sizeof(float2));
+    if (e == hipSuccess)
+        e = hipMalloc(&sp->xs, (size_t)n * sizeof(double));
+    if (e == hipSuccess && n == 4096)
+        e = hipMalloc(&sp->xcp, (size_t)n * sizeof(double2));
     if (e != hipSuccess) {
         muse_batch_free(b);
         return fail(MUSE_ERR_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e));
     }
+    adopt_spectrum(b);
     int zero = 0;
     // x = zNormalize(ref) / (N-1), zeroPad, FFT   (muse_batch.go:38-47)
     rc = build_spectrum(ctx, ref, N, (int)n, 1, 1.0 / (double)(N - 1), 1.0 / (double)n, b->X, b->xc, b->xcf, b->xs,
@@ -640,9 +714,7 @@ extern "C" int muse_batch_create(muse_ctx *ctx, muse_group *g, const double *ref
         return rc;
     }
     if (n == 4096) {
-        e = hipMalloc(&b->xcp, (size_t)n * sizeof(double2));
-        if (e == hipSuccess)
-            e = launch_lane_order(b->xc, b->xcp, ctx->stream);
+        e = launch_lane_order(b->xc, b->xcp, ctx->stream);
         if (e == hipSuccess)
             e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) {
@@ -653,6 +725,42 @@ extern "C" int muse_batch_create(muse_ctx *ctx, muse_group *g, const double *ref
     if (zero) { // muse_batch.go:39-41
         muse_batch_free(b);
         return fail(MUSE_ERR_ZERO_STD, "Invalid input query, Standard deviation of zero");
+    }
+    *out = b;
+    return MUSE_OK;
+}
+
+extern "C" int muse_batch_create_like(muse_batch *src, muse_group *g, muse_batch **out)
+{
+    if (!out)
+        return fail(MUSE_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!src || !g || g->ctx != src->ctx)
+        return fail(MUSE_ERR_INVALID, "bad batch arguments");
+    if (g->N != src->N) // muse_batch.go:24-28 / muse.go:68-70
+        return fail(MUSE_ERR_LENGTH, "comparison group series does not have the same length as the reference (%d vs %d)",
+                    g->N, src->N);
+    muse_ctx *ctx = src->ctx;
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    muse_batch *b = new (std::nothrow) muse_batch();
+    if (!b)
+        return fail(MUSE_ERR_NOMEM, "host allocation failed");
+    b->ctx = ctx;
+    b->g = g;
+    g->refs.fetch_add(1);
+    ctx->refs.fetch_add(1);
+    b->N = src->N;
+    b->n = src->n;
+    b->logn = src->logn;
+    b->sp = src->sp;
+    b->sp->refs.fetch_add(1);
+    adopt_spectrum(b);
+    hipError_t e = hipMalloc(&b->ovf_count, 2 * sizeof(int));
+    if (e != hipSuccess) {
+        muse_batch_free(b);
+        return fail(MUSE_ERR_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e));
     }
     *out = b;
     return MUSE_OK;
@@ -711,7 +819,7 @@ static FusedParams base_params(muse_batch *b)
     p.tw1 = ctx->tw1;
     p.tw2 = ctx->tw2;
     p.twm = ctx->twm;
-    p.gscratch = b->gscratch;
+    p.gscratch = ctx->gscratch;
     p.mv = b->mv;
     p.lag = b->lag;
     p.cc_out = nullptr;
@@ -744,6 +852,11 @@ extern "C" int muse_batch_score(muse_batch *b)
     rc = ensure_scores(b);
     if (rc)
         return rc;
+    // long series work in the context's scratch buffer: its pointer must not be swapped (a concurrent
+    // muse_batch_create growing it) between reading it and enqueueing the launch
+    std::unique_lock<std::mutex> scratch_lock(ctx->stage_mu, std::defer_lock);
+    if (b->n >= GENERIC_LDS_MAX_N)
+        scratch_lock.lock();
     FusedParams p = base_params(b);
     // kernel selection: ctx->variant 0 = auto; 1 = generic LDS radix-2; 2, 5..10 force one
     // of the n = 4096 kernels (parity tests run every one of them on the same inputs)
@@ -802,7 +915,7 @@ extern "C" int muse_batch_score(muse_batch *b)
         // (mixed-unit metrics: sigmas far apart) is redone at full width; an empty list costs a few microseconds
         q.npairs = std::min<long long>(p.npairs, (long long)ctx->num_cus * 3);
         HIP_TRY(launch_fused(q, KERNEL_R16_OCC3, ctx->num_cus, ctx->stream));
-        if (variant == KERNEL_R16_FAST) {
+        if (variant == KERNEL_R16_FAST && p.npairs >= 1024) { // (small groups: a pinned allocation costs more than it can save)
             if (!b->handoff_host)
                 HIP_TRY(hipHostMalloc((void **)&b->handoff_host, sizeof(int), hipHostMallocDefault));
             *b->handoff_host = 0;
@@ -1246,12 +1359,14 @@ extern "C" int muse_batch_free(muse_batch *b)
         return MUSE_OK;
     (void)hipSetDevice(b->ctx->device);
     (void)hipStreamSynchronize(b->ctx->stream);
-    (void)hipFree(b->X);
-    (void)hipFree(b->xc);
-    (void)hipFree(b->xcp);
-    (void)hipFree(b->xcf);
-    (void)hipFree(b->gscratch);
-    (void)hipFree(b->xs);
+    if (b->sp && b->sp->refs.fetch_sub(1) == 1) {
+        (void)hipFree(b->sp->X);
+        (void)hipFree(b->sp->xc);
+        (void)hipFree(b->sp->xcp);
+        (void)hipFree(b->sp->xcf);
+        (void)hipFree(b->sp->xs);
+        delete b->sp;
+    }
     (void)hipFree(b->ovf_count);
     (void)hipHostFree(b->handoff_host);
     (void)hipFree(b->ovf_list);

@@ -294,3 +294,89 @@ func RunMany(batches []*Batch, groupByLabels []string) error {
 	}
 	return nil
 }
+
+// Muse keeps the exported fields of muse.go:13-17; x and n are gone (the
+// reference spectrum lives on the device, owned by the template batch).
+type Muse struct {
+	Results  *Results
+	ref      []float64
+	probe    *C.muse_group // empty group the template batch is bound to
+	template *C.muse_batch // owns the reference spectrum, shared by every Run
+}
+
+// New replaces muse.go:23-42: empty reference -> error, sigma(ref) == 0 ->
+// "Invalid input query" error; the spectrum is computed once, here.
+func New(ref *Series, results *Results) (*Muse, error) {
+	if ref.Length() < 1 {
+		return nil, errors.New("Reference series length must be greater than zero")
+	}
+	e, err := getEngine()
+	if err != nil {
+		return nil, err
+	}
+	m := &Muse{Results: results, ref: append([]float64(nil), ref.Values()...)}
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	if err := hipError(C.muse_group_create(e.ctx, 0, C.int32_t(len(m.ref)), &m.probe)); err != nil {
+		return nil, err
+	}
+	st := C.muse_batch_create(e.ctx, m.probe, (*C.double)(unsafe.Pointer(&m.ref[0])), C.int32_t(len(m.ref)), &m.template)
+	if err := hipError(st); err != nil {
+		C.muse_group_free(m.probe)
+		return nil, fmt.Errorf("Invalid input query, %v", err)
+	}
+	runtime.SetFinalizer(m, func(m *Muse) {
+		C.muse_batch_free(m.template)
+		C.muse_group_free(m.probe)
+	})
+	return m, nil
+}
+
+// Run replaces muse.go:46-92: one label group per call, signed score clamped
+// to [-1, 1], the group's best |score| goes to Results.  Safe to call from many
+// goroutines (muse_test.go:203-214): every call owns its group and batch, the
+// spectrum is shared read-only, Results has its mutex.
+func (m *Muse) Run(compGraphs []*Series) error {
+	if len(compGraphs) == 0 {
+		return nil
+	}
+	N := len(m.ref)
+	rows := make([]float64, 0, len(compGraphs)*N)
+	for _, s := range compGraphs {
+		if s.Length() != N { // muse.go:68-70
+			return fmt.Errorf("Encountered a comparison graph with differing length than the reference, %v", s.Labels())
+		}
+		rows = append(rows, s.Values()...)
+	}
+	e, err := getEngine()
+	if err != nil {
+		return err
+	}
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	var g *C.muse_group
+	st := C.muse_group_upload(e.ctx, (*C.double)(unsafe.Pointer(&rows[0])), C.int64_t(len(compGraphs)), C.int32_t(N), C.int64_t(N), &g)
+	if err := hipError(st); err != nil {
+		return err
+	}
+	defer C.muse_group_free(g)
+	var b *C.muse_batch
+	if err := hipError(C.muse_batch_create_like(m.template, g, &b)); err != nil {
+		return err
+	}
+	defer C.muse_batch_free(b)
+	gid := make([]C.int32_t, len(compGraphs)) // all zero: one group
+	var idx C.int64_t
+	var lag, cnt C.int32_t
+	var score, mean C.double
+	r := m.Results
+	st = C.muse_batch_run(b, &gid[0], 1, C.int32_t(r.MaxLag), 1, C.double(r.Threshold), C.int32_t(r.SignFilter),
+		0 /* signed scores: muse.go:72-76 */, &idx, &lag, &score, &cnt, &mean)
+	if err := hipError(st); err != nil {
+		return err
+	}
+	if cnt == 1 {
+		r.Update(Score{Labels: compGraphs[idx].Labels(), Lag: int(lag), PercentScore: float64(score)})
+	}
+	return nil
+}

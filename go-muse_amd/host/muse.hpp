@@ -483,16 +483,23 @@ public:
         if (ref->Length() < 1) // muse.go:24-26
             throw Error(MUSE_ERR_EMPTY, "Reference series length must be greater than zero");
         refN_ = ref->Length();
-        muse_group *probe = nullptr;
-        check(muse_group_create(eng_->handle(), 0, refN_, &probe));
-        muse_batch *b = nullptr;
-        int rc = muse_batch_create(eng_->handle(), probe, ref_.data(), refN_, &b);
-        std::string msg = rc ? muse_last_error() : "";
-        muse_batch_free(b);
-        muse_group_free(probe);
-        if (rc)
+        // the reference spectrum is computed once (muse.go:29-39); every Run shares it (muse_batch_create_like)
+        check(muse_group_create(eng_->handle(), 0, refN_, &probe_));
+        int rc = muse_batch_create(eng_->handle(), probe_, ref_.data(), refN_, &template_);
+        if (rc) {
+            std::string msg = muse_last_error();
+            muse_group_free(probe_);
+            probe_ = nullptr;
             throw Error(rc, msg);
+        }
     }
+    ~Muse()
+    {
+        muse_batch_free(template_);
+        muse_group_free(probe_);
+    }
+    Muse(const Muse &) = delete;
+    Muse &operator=(const Muse &) = delete;
     ResultsPtr Results_;
     void Run(const std::vector<SeriesPtr> &compGraphs) // muse.go:46-92
     {
@@ -507,7 +514,7 @@ public:
         muse_group *g = nullptr;
         check(muse_group_upload(eng_->handle(), rows.data(), (int64_t)compGraphs.size(), refN_, refN_, &g));
         muse_batch *b = nullptr;
-        int rc = muse_batch_create(eng_->handle(), g, ref_.data(), refN_, &b);
+        int rc = muse_batch_create_like(template_, g, &b);
         std::vector<int32_t> gid(compGraphs.size(), 0);
         int64_t idx = 0;
         int32_t lag = 0, cnt = 0;
@@ -528,6 +535,8 @@ private:
     std::shared_ptr<Engine> eng_;
     std::vector<double> ref_;
     int refN_ = 0;
+    muse_group *probe_ = nullptr;    // empty group the template batch is bound to
+    muse_batch *template_ = nullptr; // owns the reference spectrum
 };
 inline std::shared_ptr<Muse> New(SeriesPtr ref, ResultsPtr results)
 {

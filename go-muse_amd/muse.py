@@ -181,14 +181,22 @@ class DeviceGroup:
 class DeviceBatch:
     """muse_batch: resident reference spectrum + per-series result buffers."""
 
-    def __init__(self, engine, dgroup, ref):
-        ref = B.as_f64(ref)
+    def __init__(self, engine, dgroup, ref, like=None):
         self.engine, self.dgroup = engine, dgroup
         self._h = ctypes.c_void_p()
-        B.check(B.load().muse_batch_create(engine._h, dgroup._h, B.dptr(ref), len(ref), ctypes.byref(self._h)))
+        if like is not None:    # same reference, another group: shares the spectrum tables (muse_batch_create_like)
+            B.check(B.load().muse_batch_create_like(like._h, dgroup._h, ctypes.byref(self._h)))
+        else:
+            ref = B.as_f64(ref)
+            B.check(B.load().muse_batch_create(engine._h, dgroup._h, B.dptr(ref), len(ref), ctypes.byref(self._h)))
         n = ctypes.c_int32(0)
         B.check(B.load().muse_batch_fft_len(self._h, ctypes.byref(n)))
         self.n = int(n.value)
+
+    @classmethod
+    def like(cls, template, dgroup):
+        """a batch for `dgroup` against the template's reference (no transform, two small allocations)"""
+        return cls(template.engine, dgroup, None, like=template)
 
     def spectrum(self):
         out = np.zeros(2 * (self.n // 2 + 1))
@@ -640,12 +648,14 @@ class Muse:
         self.Results = results
         self._engine = engine or get_engine()
         self._ref = np.array(ref.Values(), dtype=np.float64)
-        # validate sigma(ref) now, as New does (muse.go:29-32)
-        probe = DeviceGroup(self._engine, self.refN, 0)
+        # the reference spectrum is computed once, as New does (muse.go:29-39: sigma(ref) == 0 is an error here);
+        # every Run shares it through muse_batch_create_like
+        self._probe = DeviceGroup(self._engine, self.refN, 0)
         try:
-            DeviceBatch(self._engine, probe, self._ref).close()
-        finally:
-            probe.close()
+            self._template = DeviceBatch(self._engine, self._probe, self._ref)
+        except Exception:
+            self._probe.close()
+            raise
 
     def Run(self, compGraphs):                    # muse.go:46-92
         if len(compGraphs) == 0:
@@ -655,7 +665,7 @@ class Muse:
                 raise MuseError(B.MUSE_ERR_LENGTH, "Encountered a comparison graph with differing length "
                                 "than the reference, %r" % (s.Labels(),))
         dg = DeviceGroup.from_rows(self._engine, np.stack([s.y for s in compGraphs]))
-        db = DeviceBatch(self._engine, dg, self._ref)
+        db = DeviceBatch.like(self._template, dg)
         try:
             r = self.Results
             gid = np.zeros(len(compGraphs), dtype=np.int32)

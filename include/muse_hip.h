@@ -124,6 +124,13 @@ int muse_group_free(muse_group *g);
  * N < 1.  ref is copied, not mutated. */
 int muse_batch_create(muse_ctx *ctx, muse_group *g, const double *ref,
                       int32_t N, muse_batch **out);
+/* A batch for another group against the SAME reference: shares src's
+ * spectrum tables (reference-counted), so it costs no transform and two
+ * small allocations.  Muse.Run (muse.go:46-92) scores one small group per
+ * call against the Muse's one reference: create the template once in New,
+ * then one _create_like + _run + _free per call.  MUSE_ERR_LENGTH when the
+ * group's length differs from the reference's (muse.go:68-70). */
+int muse_batch_create_like(muse_batch *src, muse_group *g, muse_batch **out);
 int muse_batch_fft_len(muse_batch *b, int32_t *n);
 /* The batch's x (muse_batch.go:47): n/2+1 complex128, interleaved re,im. */
 int muse_batch_spectrum(muse_batch *b, double *out);
