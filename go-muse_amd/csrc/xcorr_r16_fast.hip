@@ -40,22 +40,7 @@ namespace fast {
 
 using namespace occ4;
 
-#ifndef MUSE_FAST_PRIO
-#define MUSE_FAST_PRIO 0
-#endif
-__device__ __forceinline__ void prio_hi() { if (MUSE_FAST_PRIO) __builtin_amdgcn_s_setprio(3); }
-__device__ __forceinline__ void prio_lo() { if (MUSE_FAST_PRIO) __builtin_amdgcn_s_setprio(0); }
-
 constexpr int XW = 544; // double2 per wave-private quarter of the 8 x 272 buffer (8 rows x 68)
-
-// compiler-level ordering of a wave's own LDS traffic (the hardware executes one
-// wave's DS instructions in order; no s_waitcnt or s_barrier is needed)
-__device__ __forceinline__ void wave_order()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 // Workgroup-wide transpose in two half rounds (as occ4::exchange; layouts in
 // double2 units, bank analysis there):
@@ -66,17 +51,16 @@ __device__ __forceinline__ void wave_order()
 //      writer (c' = hi, m1 = lo) output m2 -> 272*(m2&7) + 17*lo + hi
 //      reader (m1 = lo, m2 = hi) input c'  <- 272*(hi&7) + 17*lo + c'
 // Round 0 moves outputs 0..7 (read by waves 0-1), round 1 outputs 8..15 (waves 2-3).
-template <int MODE, bool SWAP = false>
+// (Letting waves 2-3 read first in the second transpose of a pair, so that the late-reader role alternates,
+// was measured: no difference.  So was s_setprio around the transposes.)
+template <int MODE>
 __device__ __forceinline__ void exchange_cross(double2 (&v)[16], double2 *xbuf, const int wave, const int t)
 {
-    // SWAP: outputs 8..15 travel first and waves 2-3 are the early readers (used for the second
-    // workgroup-wide transpose of a pair so that the late-reader role alternates between the wave pairs)
-    constexpr int K0 = SWAP ? 8 : 0, K1 = SWAP ? 0 : 8;
+    constexpr int K0 = 0, K1 = 8;
     const int hi = t >> 4, lo = t & 15;
     const int wbase = MODE ? 17 * lo + hi : t;
     const int rbase = 272 * (hi & 7) + (MODE ? 17 * lo : lo);
-    const bool early = SWAP ? wave >= 2 : wave < 2;
-    prio_hi();
+    const bool early = wave < 2;
     lds_barrier(); // buffer free: every wave is done with its previous (wave-local or shared) use
 #pragma unroll
     for (int k = 0; k < 8; k++)
@@ -105,7 +89,6 @@ __device__ __forceinline__ void exchange_cross(double2 (&v)[16], double2 *xbuf, 
         for (int e = 0; e < 16; e++)
             v[e] = xbuf[rbase + (MODE ? e : 16 * e)];
     }
-    prio_lo();
 }
 
 // Wave-local transpose among the sixteen lanes that share hi: lane (hi, lo) holds
@@ -130,7 +113,6 @@ __device__ __forceinline__ void exchange_local(double2 (&v)[16], double2 *xw, co
 {
     const int wbase = 17 * hl + lo;
     const int rbase = 68 * (lo & 7) + 17 * hl;
-    prio_hi();
 #pragma unroll
     for (int k = 0; k < 8; k++)
         xw[68 * k + wbase] = v[P16(k)];
@@ -199,7 +181,6 @@ __device__ __forceinline__ void exchange_local(double2 (&v)[16], double2 *xw, co
 #pragma unroll
     for (int e = 0; e < 16; e++)
         v[e] = make_double2(w[e].x, w[e].y);
-    prio_lo();
 }
 
 // Twiddle passes.  With 168 registers (WPS 3) the first eight factors of a pass are requested
@@ -305,7 +286,7 @@ __device__ __forceinline__ bool finalize(const double *r, const int series, cons
 // DYN: pairs are handed out by an atomic counter (FusedParams::work_counter, zeroed before the
 // launch) to a grid of resident workgroups only, instead of a static stride over an oversubscribed
 // grid: no tail while the slowest CUs finish their fixed share.
-template <int WPS, bool TIMING = false, bool DYN = false, bool SWAPB = false>
+template <int WPS, bool TIMING = false, bool DYN = false>
 __global__ __launch_bounds__(OCC_THREADS, WPS) void xcorr_fused_n4096_fast(const FusedParams p)
 {
     using namespace occ4;
@@ -472,7 +453,7 @@ __global__ __launch_bounds__(OCC_THREADS, WPS) void xcorr_fused_n4096_fast(const
         // pass 2: DFT over b', twiddle W_256^(m2 c'), c' = hi
         twiddle_pass<WPS>(v, ta, Tw2Fetch{tw2s, hi});
         clk.template stamp<9>();
-        exchange_cross<1, SWAPB>(v, xbuf, wave, t);
+        exchange_cross<1>(v, xbuf, wave, t);
         clk.template stamp<10>();
         // pass 3: DFT over c' (m1 = lo, m2 = hi): index t + 256 m3.  The next pair's rows
         // are requested first: they stay in flight during the butterflies and the argmax.
