@@ -162,6 +162,11 @@ struct muse_batch {
     muse_record *cand = nullptr;
     int *cnt = nullptr;
     int64_t cand_cap = 0, cnt_cap = 0;
+    // pinned host images of cand / cnt: the device top-N pre-selection comes back in two truly asynchronous
+    // copies and one synchronisation
+    muse_record *cand_host = nullptr;
+    int *cnt_host = nullptr;
+    int64_t cand_host_cap = 0, cnt_host_cap = 0;
 };
 
 static int use_device(muse_ctx *ctx)
@@ -1026,7 +1031,7 @@ std::vector<muse_record> heap_select(std::vector<muse_record> cands, int64_t top
 }
 } // namespace
 
-static int ensure_select_ws(muse_batch *b, int64_t M, int64_t G, bool with_gid, int K)
+static int ensure_select_ws(muse_batch *b, int64_t M, int64_t G, bool with_gid, int K, bool on_device)
 {
     if (with_gid && M > b->gid_cap) {
         (void)hipFree(b->gid_dev);
@@ -1068,6 +1073,22 @@ static int ensure_select_ws(muse_batch *b, int64_t M, int64_t G, bool with_gid, 
         HIP_TRY(hipMalloc(&b->cand, (size_t)(nb * K) * sizeof(muse_record)));
         b->cand_cap = nb * K;
     }
+    if (on_device && nb > b->cnt_host_cap) { // (small selections copy the group records instead: no pinned memory)
+        if (b->cnt_host)
+            (void)hipHostFree(b->cnt_host); // (hipHostFree(NULL) leaves a sticky error behind)
+        b->cnt_host = nullptr;
+        b->cnt_host_cap = 0;
+        HIP_TRY(hipHostMalloc((void **)&b->cnt_host, (size_t)nb * sizeof(int), hipHostMallocDefault));
+        b->cnt_host_cap = nb;
+    }
+    if (on_device && nb * K > b->cand_host_cap) {
+        if (b->cand_host)
+            (void)hipHostFree(b->cand_host);
+        b->cand_host = nullptr;
+        b->cand_host_cap = 0;
+        HIP_TRY(hipHostMalloc((void **)&b->cand_host, (size_t)(nb * K) * sizeof(muse_record), hipHostMallocDefault));
+        b->cand_host_cap = nb * K;
+    }
     return MUSE_OK;
 }
 
@@ -1093,7 +1114,7 @@ static int run_select(muse_batch *b, const int32_t *group_id, int32_t G_in, int6
         return fail(MUSE_ERR_UNSUPPORTED, "more than 2^31-1 groups on one device");
     const bool on_device = top_n <= TOPN_DEVICE_MAX && G > TOPN_CHUNK / 4;
     const int K = on_device ? top_n : 1;
-    rc = ensure_select_ws(b, M, G, group_id != nullptr, K);
+    rc = ensure_select_ws(b, M, G, group_id != nullptr, K, on_device);
     if (rc)
         return rc;
     if (group_id) {
@@ -1122,10 +1143,10 @@ static int run_select(muse_batch *b, const int32_t *group_id, int32_t G_in, int6
     if (on_device) {
         const int64_t nb = (G + TOPN_CHUNK - 1) / TOPN_CHUNK;
         HIP_TRY(launch_topn(b->rec, b->selkey, (int)G, K, b->cand, b->cnt, ctx->stream));
-        std::vector<int> cnt((size_t)nb);
-        std::vector<muse_record> cand((size_t)(nb * K));
-        HIP_TRY(hipMemcpyAsync(cnt.data(), b->cnt, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(cand.data(), b->cand, cand.size() * sizeof(muse_record), hipMemcpyDeviceToHost,
+        const int *cnt = b->cnt_host;
+        const muse_record *cand = b->cand_host;
+        HIP_TRY(hipMemcpyAsync(b->cnt_host, b->cnt, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(b->cand_host, b->cand, (size_t)(nb * K) * sizeof(muse_record), hipMemcpyDeviceToHost,
                                ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         for (int64_t blk = 0; blk < nb; blk++)
@@ -1368,7 +1389,8 @@ extern "C" int muse_batch_free(muse_batch *b)
         delete b->sp;
     }
     (void)hipFree(b->ovf_count);
-    (void)hipHostFree(b->handoff_host);
+    if (b->handoff_host)
+        (void)hipHostFree(b->handoff_host);
     (void)hipFree(b->ovf_list);
     (void)hipFree(b->mv);
     (void)hipFree(b->lag);
@@ -1379,6 +1401,10 @@ extern "C" int muse_batch_free(muse_batch *b)
     (void)hipFree(b->rec);
     (void)hipFree(b->selkey);
     (void)hipFree(b->cand);
+    if (b->cand_host)
+        (void)hipHostFree(b->cand_host);
+    if (b->cnt_host)
+        (void)hipHostFree(b->cnt_host);
     (void)hipFree(b->cnt);
     muse_group *g = b->g;
     muse_ctx *ctx = b->ctx;
