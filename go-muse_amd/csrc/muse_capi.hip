@@ -129,6 +129,7 @@ struct muse_spectrum {
     double2 *X = nullptr, *xc = nullptr, *xcp = nullptr;
     float2 *xcf = nullptr;
     double *xs = nullptr;
+    double *c1 = nullptr; // n == 4096, N < 4096: indicator correlation (xcorr_r16_fast.hip, PADDED)
 };
 
 struct muse_batch {
@@ -136,6 +137,7 @@ struct muse_batch {
     muse_group *g = nullptr;
     int32_t N = 0, n = 0, logn = 0;
     muse_spectrum *sp = nullptr; // owner of the five tables below (the pointers are copies)
+    double *c1 = nullptr;
     double2 *X = nullptr, *xc = nullptr;
     double2 *xcp = nullptr; // n == 4096: xc in the lane order of xcorr_r16_fast.hip
     float2 *xcf = nullptr; // fp32 conj(X)/n (screening kernel)
@@ -656,6 +658,7 @@ static void adopt_spectrum(muse_batch *b)
     b->xcp = b->sp->xcp;
     b->xcf = b->sp->xcf;
     b->xs = b->sp->xs;
+    b->c1 = b->sp->c1;
 }
 
 extern "C" int muse_batch_create(muse_ctx *ctx, muse_group *g, const double *ref, int32_t N, muse_batch **out)
@@ -705,6 +708,8 @@ extern "C" int muse_batch_create(muse_ctx *ctx, muse_group *g, const double *ref
         e = hipMalloc(&sp->xs, (size_t)n * sizeof(double));
     if (e == hipSuccess && n == 4096)
         e = hipMalloc(&sp->xcp, (size_t)n * sizeof(double2));
+    if (e == hipSuccess && n == 4096 && N < 4096)
+        e = hipMalloc(&sp->c1, (size_t)n * sizeof(double));
     if (e != hipSuccess) {
         muse_batch_free(b);
         return fail(MUSE_ERR_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e));
@@ -720,6 +725,8 @@ extern "C" int muse_batch_create(muse_ctx *ctx, muse_group *g, const double *ref
     }
     if (n == 4096) {
         e = launch_lane_order(b->xc, b->xcp, ctx->stream);
+        if (e == hipSuccess && b->c1)
+            e = launch_indicator_corr(b->xs, 4096, 4096 - N, b->c1, ctx->stream);
         if (e == hipSuccess)
             e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) {
@@ -832,6 +839,7 @@ static FusedParams base_params(muse_batch *b)
     p.tw1w8 = ctx->tw1w8;
     p.tw1p = ctx->tw1p;
     p.xcp = b->xcp;
+    p.c1 = b->c1;
     p.tw1f = ctx->tw1f;
     p.tw2f = ctx->tw2f;
     p.xcf = b->xcf;
@@ -878,7 +886,7 @@ extern "C" int muse_batch_score(muse_batch *b)
         case 10: variant = KERNEL_R16_FAST; break;
         default: variant = KERNEL_GENERIC; break;
         }
-        if (variant == KERNEL_R16_FAST && b->N != 4096) // the deferred-statistics kernel is built for N == n only
+        if (variant == KERNEL_R16_FAST && b->N != 4096 && !b->c1) // (N < n needs the batch's correction table)
             variant = KERNEL_R16_OCC3;
         // a group of mixed-unit series (sigmas far apart inside most pairs) makes the default kernel hand most
         // pairs to kernel 7 anyway: once a pass over these rows has shown that, go there directly
@@ -1386,6 +1394,7 @@ extern "C" int muse_batch_free(muse_batch *b)
         (void)hipFree(b->sp->xcp);
         (void)hipFree(b->sp->xcf);
         (void)hipFree(b->sp->xs);
+        (void)hipFree(b->sp->c1);
         delete b->sp;
     }
     (void)hipFree(b->ovf_count);

@@ -216,9 +216,12 @@ __device__ __forceinline__ void issue_row_loads(RawPair &r, const FusedParams &p
     for (int i = 0; i < 16; i++) {
         if (PADDED) {
             int j = t + 256 * i - pad;
-            j = j < 0 ? 0 : j; // clamped: always load, the value is masked later
-            r.a[i] = __builtin_nontemporal_load(ra + j);
-            r.b[i] = __builtin_nontemporal_load(rb + j);
+            if (i < 8)             // pad < 2048 (n = nextPowOf2(N)): elements 2048.. are always valid
+                j = j < 0 ? 0 : j; // clamped: always load, the value is masked later
+            // an UNSIGNED 12-bit index: saddr + 32-bit voffset addressing, no 64-bit sign extension per load
+            const unsigned ju = (unsigned)j & 4095u;
+            r.a[i] = __builtin_nontemporal_load(ra + ju);
+            r.b[i] = __builtin_nontemporal_load(rb + ju);
         } else { // one scalar base per four 2 KB slices (immediate offsets -4096 .. +2048 B)
                  // + the shared VGPR offset 8 t: no 64-bit VALU address arithmetic
             const int c = (i & ~3) * 256 + 512;

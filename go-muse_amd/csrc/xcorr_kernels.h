@@ -25,6 +25,7 @@ struct FusedParams {
     const double2 *tw1w8; // [8][512]  W_4096^(k*t)      (radix-8 kernel)
     const double2 *tw1p; // [16][256] W_4096^(k*(16*(t&15) + (t>>4)))   (xcorr_r16_fast.hip, second transform)
     const double2 *xcp;  // [16][256] xc[256*k + (t>>4) + 16*(t&15)]     (xcorr_r16_fast.hip: xc in lane order)
+    const double *c1;    // [4096] N < n = 4096: correlation of the valid-sample indicator with the reference (xcorr_r16_fast.hip)
     // many references in one pass (xcorr_fused_n4096_multi): device arrays of R pointers
     int R;
     const double2 *const *xcp_many; // R lane-ordered spectrum tables
@@ -64,6 +65,8 @@ hipError_t launch_fused_multi(const FusedParams &p, int num_cus, hipStream_t str
 hipError_t launch_fused_stockham(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_stockham.hip (n = 512 .. 2048, 8192 .. 65536)
 // out[256 k + t] = in[256 k + (t >> 4) + 16 (t & 15)], k < 16: a 4096-entry table in the lane order of xcorr_r16_fast.hip
 hipError_t launch_lane_order(const double2 *in, double2 *out, hipStream_t stream);
+// c1[k] = sum_{j >= pad} xs[(j + k) mod n]: what a series of ones at the valid (non-pad) positions correlates to
+hipError_t launch_indicator_corr(const double *xs, int n, int pad, double *c1, hipStream_t stream);
 hipError_t launch_ref_spectrum(const double *ref_dev, int N, int n, int logn, int normalize, double x_scale,
                                double xc_scale, const double2 *twm, double2 *X, double2 *xc, float2 *xcf, double *xs,
                                double2 *gscratch, int *status, hipStream_t stream);

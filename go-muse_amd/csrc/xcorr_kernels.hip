@@ -599,6 +599,28 @@ __global__ __launch_bounds__(256) void lane_order_kernel(const double2 *__restri
     out[256 * k + t] = in[256 * k + (t >> 4) + 16 * (t & 15)];
 }
 
+// one workgroup per 256 lags; a running window sum would do, but n^2 = 1.7e7 additions once per batch are free
+__global__ __launch_bounds__(256) void indicator_corr_kernel(const double *__restrict__ xs, int n, int pad, double *__restrict__ c1)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n)
+        return;
+    double s = 0.0, c = 0.0; // compensated: the table corrects values of the same magnitude it is built from
+    for (int j = pad; j < n; j++) {
+        const double y = xs[(j + k) & (n - 1)] - c;
+        const double tt = s + y;
+        c = (tt - s) - y;
+        s = tt;
+    }
+    c1[k] = s;
+}
+
+hipError_t launch_indicator_corr(const double *xs, int n, int pad, double *c1, hipStream_t stream)
+{
+    hipLaunchKernelGGL(indicator_corr_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, xs, n, pad, c1);
+    return hipGetLastError();
+}
+
 hipError_t launch_lane_order(const double2 *in, double2 *out, hipStream_t stream)
 {
     hipLaunchKernelGGL(lane_order_kernel, dim3(16), dim3(256), 0, stream, in, out);

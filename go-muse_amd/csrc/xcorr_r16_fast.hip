@@ -286,7 +286,12 @@ __device__ __forceinline__ bool finalize(const double *r, const int series, cons
 // DYN: pairs are handed out by an atomic counter (FusedParams::work_counter, zeroed before the
 // launch) to a grid of resident workgroups only, instead of a static stride over an oversubscribed
 // grid: no tail while the slowest CUs finish their fixed share.
-template <int WPS, bool TIMING = false, bool DYN = false>
+// PADDED (2048 < N < 4096, leading zero pad): the mean cannot be dropped with the DC bin -- the pad stays
+// 0, only the valid samples are centred.  By linearity cc(d - m 1_valid) = cc(d) - m c1 with
+// c1 = the batch's correlation of the valid-sample indicator with the reference (FusedParams::c1,
+// built once per batch): the transforms run on d, sum d is read off the DC bin as before and the 16
+// values a lane ends with are corrected by -m c1[index] before the argmax.
+template <int WPS, bool TIMING = false, bool DYN = false, bool PADDED = false>
 __global__ __launch_bounds__(OCC_THREADS, WPS) void xcorr_fused_n4096_fast(const FusedParams p)
 {
     using namespace occ4;
@@ -300,7 +305,8 @@ __global__ __launch_bounds__(OCC_THREADS, WPS) void xcorr_fused_n4096_fast(const
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6); // wave-uniform by construction
     const int hi = t >> 4, lo = t & 15;
     double2 *const xw = xbuf + XW * wave;
-    const double invN = 1.0 / 4096.0, invNm1 = 1.0 / 4095.0;
+    const int pad = PADDED ? 4096 - p.N : 0;
+    const double invN = PADDED ? 1.0 / (double)p.N : 1.0 / 4096.0, invNm1 = PADDED ? 1.0 / (double)(p.N - 1) : 1.0 / 4095.0;
 
     tw2s[t] = p.tw2[t];
     if (t < 2)
@@ -312,7 +318,7 @@ __global__ __launch_bounds__(OCC_THREADS, WPS) void xcorr_fused_n4096_fast(const
     int parity = 0;
     const long long total = p.npairs;
     RawPair raw;
-    issue_row_loads<false>(raw, p, blockIdx.x < total ? (long long)blockIdx.x : 0ll, t, 0);
+    issue_row_loads<PADDED>(raw, p, blockIdx.x < total ? (long long)blockIdx.x : 0ll, t, pad);
 
     long long nextpair = 0;
     for (long long pair = blockIdx.x; pair < total; pair = nextpair) {
@@ -339,6 +345,8 @@ __global__ __launch_bounds__(OCC_THREADS, WPS) void xcorr_fused_n4096_fast(const
             clk.template stamp<0>();
 #pragma unroll
             for (int i = 0; i < 16; i++) {
+                // (PADDED: a pad position was loaded from the clamped index 0, i.e. it holds the row's first
+                // sample K itself, so d = K - K = 0 without any masking)
                 const double da = raw.a[i] - KA, db = raw.b[i] - KB;
                 v[i] = make_double2(da, db);
                 qa = fma(da, da, qa);
@@ -415,8 +423,10 @@ __global__ __launch_bounds__(OCC_THREADS, WPS) void xcorr_fused_n4096_fast(const
             // divergent block here splits the schedule and the table loads get spilled.
             s1a = readlane_f64(w[0].x, 0);
             s1b = readlane_f64(w[0].y, 0);
-            w[0].x = (t == 0) ? 0.0 : w[0].x;
-            w[0].y = (t == 0) ? 0.0 : w[0].y;
+            if (!PADDED) {
+                w[0].x = (t == 0) ? 0.0 : w[0].x;
+                w[0].y = (t == 0) ? 0.0 : w[0].y;
+            }
 #pragma unroll
             for (int b = 0; b < 16 / XB; b += 2) {
 #pragma unroll
@@ -449,6 +459,10 @@ __global__ __launch_bounds__(OCC_THREADS, WPS) void xcorr_fused_n4096_fast(const
         clk.template stamp<7>();
         tw_early<WPS>(ta, Tw2Fetch{tw2s, hi});
         exchange_local(v, xw, hi & 3, lo); // (c' = hi, b' = lo) -> (c' = hi, m1 = lo): same wave
+        if (PADDED && wave == 0 && lane == 0) { // every lane needs the means before its argmax: visible behind
+            rec[32] = s1a;                      // the four barriers of the transpose below
+            rec[33] = s1b;
+        }
         clk.template stamp<8>();
         // pass 2: DFT over b', twiddle W_256^(m2 c'), c' = hi
         twiddle_pass<WPS>(v, ta, Tw2Fetch{tw2s, hi});
@@ -464,16 +478,40 @@ __global__ __launch_bounds__(OCC_THREADS, WPS) void xcorr_fused_n4096_fast(const
             nxt = nxt < total ? nxt : 0;
             fence();
             if (WPS < 4)
-                issue_row_loads<false>(raw, p, nxt, t, 0);
+                issue_row_loads<PADDED>(raw, p, nxt, t, pad);
+            const auto c1l = [&](int k) __attribute__((always_inline)) {
+                return scalar_ptr_at(p.c1, 256 * ((k + 1) & ~1))[t - 256 * (k & 1)];
+            };
+            double ca[8], cb[8];
+            if (PADDED) { // first half of the correction table (L2): in flight during the butterflies
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    ca[k] = c1l(k);
+            }
             fence();
             dft16(v);
+            fence();
             double2 w[16];
 #pragma unroll
             for (int k = 0; k < 16; k++)
                 w[k] = v[P16(k)];
+            if (PADDED) { // cc(d - m 1_valid) = cc(d) - m c1, m = sum d / N
 #pragma unroll
-            for (int k = 0; k < 16; k++)
-                v[k] = w[k];
+                for (int k = 0; k < 8; k++)
+                    cb[k] = c1l(8 + k);
+                const double mA = rec[32] * invN, mB = rec[33] * invN;
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    v[k] = make_double2(fma(-mA, ca[k], w[k].x), fma(-mB, ca[k], w[k].y));
+                fence();
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    v[8 + k] = make_double2(fma(-mA, cb[k], w[8 + k].x), fma(-mB, cb[k], w[8 + k].y));
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; k++)
+                    v[k] = w[k];
+            }
         }
         clk.template stamp<11>();
         // ---- maxAbsIndex (xcorr.go:39-50), as in xcorr_r16_occ4.hip
@@ -517,7 +555,7 @@ __global__ __launch_bounds__(OCC_THREADS, WPS) void xcorr_fused_n4096_fast(const
             long long nxt = nextpair;
             nxt = nxt < total ? nxt : 0;
             fence();
-            issue_row_loads<false>(raw, p, nxt, t, 0);
+            issue_row_loads<PADDED>(raw, p, nxt, t, pad);
             fence();
         }
         if (lane == 0) { // {max |cc|, signed value (cc[0] when nothing is above 0), index}
@@ -904,7 +942,7 @@ hipError_t launch_fused_multi(const FusedParams &p, int num_cus, hipStream_t str
     return hipGetLastError();
 }
 
-// N == n == 4096 only; p.ovf_count must be zeroed and p.ovf_list hold 2*npairs entries
+// n == 4096 (N < 4096: p.c1 required); p.ovf_count / work_counter must be zeroed and p.ovf_list hold 2*npairs entries
 hipError_t launch_fused_fast(const FusedParams &p, int num_cus, hipStream_t stream)
 {
     long long grid = p.npairs;
@@ -927,6 +965,13 @@ hipError_t launch_fused_fast(const FusedParams &p, int num_cus, hipStream_t stre
     FusedParams q = p;
     if (const char *d = getenv("MUSE_HIP_FAST_TUNE")) // tuning aid: experiment bits
         q.tune = atoi(d);
+    if (p.N < 4096) { // leading zero pad: needs the batch's correction table
+        if (!p.c1 || !p.work_counter)
+            return hipErrorInvalidValue;
+        grid = std::min<long long>(p.npairs, (long long)num_cus * 4);
+        hipLaunchKernelGGL((xcorr_fused_n4096_fast<4, false, true, true>), dim3((unsigned)grid), dim3(OCC_THREADS), 0, stream, q);
+        return hipGetLastError();
+    }
     if (dyn && p.work_counter) {
         grid = std::min<long long>(p.npairs, (long long)num_cus * wps); // resident workgroups only
         if (wps == 4)

@@ -193,12 +193,8 @@ __global__ __launch_bounds__(OCC_THREADS, WPS) void xcorr_fused_n4096_occ4(const
         double q[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-            double da = v[i].x - KA, db = v[i].y - KB;
-            if (PADDED) {
-                const bool valid = t + 256 * i - pad >= 0;
-                da = valid ? da : 0.0;
-                db = valid ? db : 0.0;
-            }
+            // (PADDED: a pad position was loaded from the clamped index 0 = the first sample K: d = 0 already)
+            const double da = v[i].x - KA, db = v[i].y - KB;
             v[i] = make_double2(da, db);
             q[0] += da;
             q[1] = fma(da, da, q[1]);
@@ -229,7 +225,7 @@ __global__ __launch_bounds__(OCC_THREADS, WPS) void xcorr_fused_n4096_occ4(const
         if (PADDED) {
 #pragma unroll
             for (int i = 0; i < 16; i++) {
-                const bool valid = t + 256 * i - pad >= 0;
+                const bool valid = i >= 8 || t + 256 * i - pad >= 0;
                 v[i].x = valid ? v[i].x - mA : 0.0;
                 v[i].y = valid ? v[i].y - mB : 0.0;
             }

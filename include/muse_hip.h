@@ -75,10 +75,10 @@ int muse_ctx_device_info(muse_ctx *ctx, char *name, int32_t name_cap,
 /* Kernel variant for the fused pass: 0 = auto (fastest kernel built for the
  * FFT length), 1 = force the generic radix-2 kernel; forcing one n = 4096 kernel: 2 = first (simple) fp64 kernel,
  * 5 = register-prefetch pipeline, 6 / 7 = half-round transposes at 4 / 3
- * waves per SIMD (7 is what auto picks when N < n = 4096), 8 = fp32 screening
+ * waves per SIMD (7 also serves as the rescaling hand-off kernel), 8 = fp32 screening
  * + exact fp64 re-evaluation (experimental), 9 = 512-thread radix-8
  * (experimental), 10 = wave-local transposes + deferred statistics (what auto
- * picks when N == 4096; other N fall back to 7).  For n != 4096: 11 = radix-16
+ * picks for n == 4096).  For n != 4096: 11 = radix-16
  * Stockham kernels (n = 512 ... 2048 and 8192 through LDS, 16384 ... 65536
  * through a global scratch buffer; what auto picks for n >= 512), 1 = radix-2.
  * The parity tests run every variant on the same inputs; the environment
