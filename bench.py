@@ -151,7 +151,7 @@ def main():
                        "device": dev_name},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": ("xcorr_fused_n4096_fast<4>" if args.length == 4096 else "xcorr_fused_n4096_occ4<true,3>") if db.n == 4096 else "xcorr_fused_generic",
+                         "kernel": "xcorr_fused_n4096_fast<4>" if db.n == 4096 else ("xcorr_fused_stk_*" if db.n >= 512 else "xcorr_fused_generic"),
                          "kernel_ms_avg": k_avg_s * 1e3, "launches_timed": k_cnt,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
             "achieved_hbm_gbps_whole_step": value / n_gpus * (8 * N + 16) / 1e9,
