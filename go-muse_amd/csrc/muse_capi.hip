@@ -1266,7 +1266,10 @@ extern "C" int muse_batch_score_many(muse_batch *const *bs, int32_t R)
     muse_ctx *ctx = b0->ctx;
     // the one-pass kernel is built for N == n == 4096 (and is only taken under automatic kernel
     // selection); everything else scores the batches one after the other
-    if (R == 1 || b0->n != 4096 || b0->N != 4096 || (ctx->variant != 0 && ctx->variant != 10)) {
+    bool one_pass = R > 1 && b0->n == 4096 && (ctx->variant == 0 || ctx->variant == 10);
+    for (int r = 0; r < R && one_pass; r++)
+        one_pass = bs[r]->N == b0->N && (b0->N == 4096 || bs[r]->c1 != nullptr);
+    if (!one_pass) {
         for (int r = 0; r < R; r++) {
             int rc = muse_batch_score(bs[r]);
             if (rc)
@@ -1297,16 +1300,17 @@ extern "C" int muse_batch_score_many(muse_batch *const *bs, int32_t R)
         (void)hipFree(ctx->many_tab);
         ctx->many_tab = nullptr;
         ctx->many_cap = 0;
-        HIP_TRY(hipMalloc(&ctx->many_tab, (size_t)R * 3 * sizeof(void *)));
+        HIP_TRY(hipMalloc(&ctx->many_tab, (size_t)R * 4 * sizeof(void *)));
         ctx->many_cap = R;
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream)); // the previous pass may still be reading the host image
     std::vector<void *> &tab = ctx->many_host;
-    tab.assign((size_t)R * 3, nullptr);
+    tab.assign((size_t)R * 4, nullptr);
     for (int r = 0; r < R; r++) {
         tab[(size_t)r] = bs[r]->xcp;
         tab[(size_t)R + r] = bs[r]->mv;
         tab[(size_t)2 * R + r] = bs[r]->lag;
+        tab[(size_t)3 * R + r] = bs[r]->c1;
     }
     HIP_TRY(hipMemcpyAsync(ctx->many_tab, tab.data(), tab.size() * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
     FusedParams p = base_params(b0);
@@ -1314,6 +1318,7 @@ extern "C" int muse_batch_score_many(muse_batch *const *bs, int32_t R)
     p.xcp_many = (const double2 *const *)ctx->many_tab;
     p.mv_many = (double *const *)((void **)ctx->many_tab + R);
     p.lag_many = (int *const *)((void **)ctx->many_tab + 2 * R);
+    p.c1_many = (const double *const *)((void **)ctx->many_tab + 3 * R);
     p.zscratch = ctx->zscratch;
     p.zslots = ctx->zslots;
     if (2 * p.npairs > b0->ovf_cap) {

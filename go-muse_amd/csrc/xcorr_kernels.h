@@ -31,6 +31,7 @@ struct FusedParams {
     const double2 *const *xcp_many; // R lane-ordered spectrum tables
     double *const *mv_many;         // R result vectors (M doubles each)
     int *const *lag_many;           // R lag vectors (M ints each)
+    const double *const *c1_many;   // N < 4096: R indicator-correlation tables
     double2 *zscratch;              // zslots x 4096 complex: one parked spectrum per (resident) workgroup
     int zslots;
     const double2 *twm;  // [32768]   W_65536^k         (generic kernel; half period)

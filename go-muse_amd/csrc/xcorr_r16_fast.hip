@@ -689,7 +689,9 @@ __device__ __forceinline__ void finalize_prev_multi(const double *trip, const do
 
 } // namespace fast
 
-template <bool TIMING = false>
+// PADDED (2048 < N < 4096): as in xcorr_fused_n4096_fast -- the parked spectrum keeps its DC bin and every
+// reference's results are corrected by -m c1_r[index] (FusedParams::c1_many) before the argmax.
+template <bool TIMING = false, bool PADDED = false>
 __global__ __launch_bounds__(OCC_THREADS, 4) void xcorr_fused_n4096_multi(const FusedParams p)
 {
     using namespace occ4;
@@ -705,7 +707,8 @@ __global__ __launch_bounds__(OCC_THREADS, 4) void xcorr_fused_n4096_multi(const 
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int hi = t >> 4, lo = t & 15;
     double2 *const xw = xbuf + XW * wave;
-    const double invN = 1.0 / 4096.0, invNm1 = 1.0 / 4095.0;
+    const int pad = PADDED ? 4096 - p.N : 0;
+    const double invN = PADDED ? 1.0 / (double)p.N : 1.0 / 4096.0, invNm1 = PADDED ? 1.0 / (double)(p.N - 1) : 1.0 / 4095.0;
     const int R = p.R;
 
     tw2s[t] = p.tw2[t];
@@ -721,7 +724,7 @@ __global__ __launch_bounds__(OCC_THREADS, 4) void xcorr_fused_n4096_multi(const 
     double ka, kb;
     {
         RawPair raw;
-        issue_row_loads<false>(raw, p, blockIdx.x < total ? (long long)blockIdx.x : 0ll, t, 0);
+        issue_row_loads<PADDED>(raw, p, blockIdx.x < total ? (long long)blockIdx.x : 0ll, t, pad);
 #pragma unroll
         for (int i = 0; i < 16; i++)
             pre[i] = make_double2(raw.a[i], raw.b[i]);
@@ -778,8 +781,13 @@ __global__ __launch_bounds__(OCC_THREADS, 4) void xcorr_fused_n4096_multi(const 
                     w[k] = v[P16(k)];
                 s1a = readlane_f64(w[0].x, 0);
                 s1b = readlane_f64(w[0].y, 0);
-                w[0].x = (t == 0) ? 0.0 : w[0].x;
-                w[0].y = (t == 0) ? 0.0 : w[0].y;
+                if (!PADDED) {
+                    w[0].x = (t == 0) ? 0.0 : w[0].x;
+                    w[0].y = (t == 0) ? 0.0 : w[0].y;
+                } else if (wave == 0 && lane == 0) { // every lane needs the means before each argmax of this pair
+                    st[8] = s1a;
+                    st[9] = s1b;
+                }
                 if (R > 1) { // park Z: lane t owns zs[256 k + t] (scalar bases: no hoisted VGPR addresses)
 #pragma unroll
                     for (int k = 0; k < 16; k++) {
@@ -843,6 +851,21 @@ __global__ __launch_bounds__(OCC_THREADS, 4) void xcorr_fused_n4096_multi(const 
 #pragma unroll
             for (int k = 0; k < 16; k++)
                 w[k] = v[P16(k)];
+            if (PADDED) { // cc(d - m 1_valid) = cc(d) - m c1_r
+                const double *c1r;
+                {
+                    const unsigned long long u = (unsigned long long)p.c1_many[r];
+                    const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)u);
+                    const unsigned hi32 = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+                    c1r = (const double *)(((unsigned long long)hi32 << 32) | lo32);
+                }
+                const double mA = st[8] * invN, mB = st[9] * invN;
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const double c = scalar_ptr_at(c1r, 256 * ((k + 1) & ~1))[t - 256 * (k & 1)];
+                    w[k] = make_double2(fma(-mA, c, w[k].x), fma(-mB, c, w[k].y));
+                }
+            }
             double ma = 0.0, mb = 0.0;
 #pragma unroll
             for (int k = 0; k < 16; k++) {
@@ -891,7 +914,7 @@ __global__ __launch_bounds__(OCC_THREADS, 4) void xcorr_fused_n4096_multi(const 
                 nextpair = __builtin_amdgcn_readfirstlane(next_s[pp]);
                 long long nxt = nextpair < total ? nextpair : 0; // nothing left: pair 0 (L2-resident dummy)
                 RawPair raw;
-                issue_row_loads<false>(raw, p, nxt, t, 0);
+                issue_row_loads<PADDED>(raw, p, nxt, t, pad);
 #pragma unroll
                 for (int i = 0; i < 16; i++)
                     pre[i] = make_double2(raw.a[i], raw.b[i]);
@@ -938,7 +961,13 @@ hipError_t launch_fused_multi(const FusedParams &p, int num_cus, hipStream_t str
     const long long grid = std::min<long long>(p.npairs, (long long)num_cus * wpc);
     if (p.zslots < grid || !p.zscratch || !p.work_counter || p.R < 1)
         return hipErrorInvalidValue;
-    hipLaunchKernelGGL((xcorr_fused_n4096_multi<false>), dim3((unsigned)grid), dim3(OCC_THREADS), 0, stream, p);
+    if (p.N < 4096) {
+        if (!p.c1_many)
+            return hipErrorInvalidValue;
+        hipLaunchKernelGGL((xcorr_fused_n4096_multi<false, true>), dim3((unsigned)grid), dim3(OCC_THREADS), 0, stream, p);
+    } else {
+        hipLaunchKernelGGL((xcorr_fused_n4096_multi<false, false>), dim3((unsigned)grid), dim3(OCC_THREADS), 0, stream, p);
+    }
     return hipGetLastError();
 }
 
