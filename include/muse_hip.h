@@ -16,7 +16,12 @@
  *     Series values in place, xcorr.go:86,93; this engine does not).
  *   - one context = one GPU (one process per GPU under torch.distributed /
  *     RCCL; a Go host creates one context per device).  A handle may be used
- *     from any host thread, one call in flight per context.
+ *     from any host thread.  Calls on DIFFERENT group / batch handles of one
+ *     context may be in flight at the same time (muse_test.go:203-214 drives
+ *     one Muse from many goroutines: every Muse.Run owns its group and batch);
+ *     at most one call per handle, at most one muse_batch_score_many /
+ *     _run_many per context, and kernel timing (muse_ctx_kernel_timing) only
+ *     with a single caller.  All work of a context runs on its one stream.
  *   - there is NO CPU fallback: every compute entry point fails with
  *     MUSE_ERR_NO_DEVICE when no gfx950 device is usable.
  */
