@@ -798,3 +798,36 @@ def test_muse_run_concurrent_callers(muse):
     key = lambda s: (round(abs(s.PercentScore), 12), s.Lag, s.Labels.ID(s.Labels.Keys()))
     assert sorted(map(key, a)) == sorted(map(key, b))
     assert abs(am - bm) <= 1e-12
+
+
+def test_fuzz_padded_and_many_references(muse, eng, oracle):
+    """Seeded sweep over N in (2048, 4096] (the default kernel's leading-zero-pad build and its correction
+    table), data regimes incl. an outlying first sample (the shift K), and R references in one pass."""
+    rng = np.random.default_rng(4242)
+    for trial in range(14):
+        N = int(rng.choice([2049, 2500, 3000, 3333, 4000, 4095, 4096]))
+        M = int(rng.integers(2, 90))
+        R = int(rng.integers(1, 5))
+        rows = rng.standard_normal((M, N))
+        regime = trial % 4
+        if regime == 1:
+            rows += 1e5 * rng.standard_normal((M, 1))
+        elif regime == 2:
+            rows[:, 0] += 1e4 * rng.standard_normal(M)            # the first sample (the kernel's shift) is an outlier
+        elif regime == 3:
+            rows *= 10.0 ** rng.uniform(-8, 8, size=(M, 1))
+        if M > 6:
+            rows[int(rng.integers(0, M))] = -2.0
+            rows[int(rng.integers(0, M)), int(rng.integers(0, N))] = np.nan
+        refs = [rng.standard_normal(N) * (1.0 + 10.0 * r) + 3.0 * r for r in range(R)]
+        for r in range(R):
+            rows[r % M] += 0.5 * np.roll(refs[r], 3 + r) * np.std(rows[r % M][np.isfinite(rows[r % M])])
+        dg = muse.DeviceGroup.from_rows(eng, rows)
+        batches = [muse.DeviceBatch(eng, dg, ref) for ref in refs]
+        got = muse.scores_many(batches)
+        for r in range(R):
+            olag, omv, gap = oracle.batch_scores(refs[r], rows)
+            assert_scores_match(got[r][0], got[r][1], olag, omv, gap, max_ties=1)
+        for b in batches:
+            b.close()
+        dg.close()
