@@ -1,5 +1,6 @@
-// xcorr_r16_fast.hip -- n = 4096, N == 4096 kernel with nine workgroup barriers
-// per pair of series (xcorr_r16_occ4.hip: nineteen).
+// xcorr_r16_fast.hip -- the default n = 4096 kernels (2048 < N <= 4096): nine workgroup
+// barriers per pair of series (xcorr_r16_occ4.hip: nineteen), and the many-references
+// variant that transforms each pair once for R references (second half of the file).
 //
 // Mathematics: identical to xcorr_fused_n4096 (xcorr_kernels.hip header; the
 // reference path is xCorrWithX, /root/reference/xcorr.go:160-197).
@@ -25,8 +26,12 @@
 //     the statistics are deferred: such pairs are appended to FusedParams::ovf_list
 //     and redone by the occ4 kernel (which zeroes the dead series before the
 //     transform) in a second launch bounded by the on-device count.
+//     The same list takes pairs whose sigmas are more than 2^16 apart (fft_device.h,
+//     sigma_spread_too_wide): kernel 7 rescales both series before the shared transform.
 //   * The state of the previous pair lives in LDS, not in registers that only two
 //     lanes use.
+//   * Pairs are handed out by an atomic counter to a grid of resident workgroups (DYN).
+//   * N < 4096 (PADDED): see the comment at the kernel.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
