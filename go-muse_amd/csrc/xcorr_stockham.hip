@@ -25,7 +25,13 @@
 // xcorr_fused_stk_lds<LOGN> (n = 512, 1024, 2048): n/16 threads per pair, 4096/n pairs per
 // 256-thread workgroup, one padded LDS work buffer per pair (pos + pos/16: the Ns = 1 pass
 // writes with a lane stride of R1 slots), three passes per transform, 11 barriers per
-// workgroup iteration.
+// workgroup iteration; <13> (n = 8192): one pair per 512-thread workgroup, four passes.
+// xcorr_fused_stk_4step<LOGN> (n = 16384 ... 65536): the long series as a four-step transform
+// (radix-R1 sweeps in place in a global scratch slice, 4096-point rows on chip) -- what
+// automatic selection uses; xcorr_fused_stk_glb<LOGN>: the plain four-pass version through two
+// scratch slices, kept for A/B (MUSE_HIP_FAST_TUNE=2).
+// All of them bring both series of a pair to O(1) with exact powers of two before the shared
+// transform (fft_device.h, pow2_inv_sigma) and apply 1/sigma to the winning value only.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
