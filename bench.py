@@ -43,7 +43,14 @@ def cpu_baseline(dg, ref, N):
     t0 = time.perf_counter()
     oracle_py.batch_scores(ref, rows, nthreads=threads, want_gap=False)
     dt = time.perf_counter() - t0
+    # SURVEY 8d also asks for the 1-thread figure: a short sample is enough (linear in rows)
+    S1 = int(min(S, max(256, min(4000, rate / threads * 2.0))))
+    S1 -= S1 % 2
+    t0 = time.perf_counter()
+    oracle_py.batch_scores(ref, rows[:S1], nthreads=1, want_gap=False)
+    dt1 = time.perf_counter() - t0
     return {"value": S / dt, "unit": "series-pairs/s", "cores": threads, "kind": "port",
+            "single_thread": {"value": S1 / dt1, "unit": "series-pairs/s", "cores": 1, "sample": "first %d rows" % S1},
             "sample": "first %d rows of the same 1Mx%d synthetic matrix (D2H copy), %d pthreads, "
                       "C restatement of go-muse xCorrWithX (not Go/gonum)" % (S, N, threads)}
 
