@@ -18,8 +18,16 @@ namespace occ4 {
 
 __device__ __forceinline__ void fence() { __builtin_amdgcn_sched_barrier(0); }
 // LDS-only barrier (does not drain outstanding global loads)
+// MUSE_ABLATE (tools/ablate only; never defined in the library build): bit 0 = no LDS transposes and no workgroup
+// barriers (register permutations keep the data flow), bit 1 = every workgroup re-reads the same eight pairs of
+// rows (L2-resident: no HBM traffic, the load instructions stay).  Same arithmetic, garbage results.
+#ifndef MUSE_ABLATE
+#define MUSE_ABLATE 0
+#endif
 __device__ __forceinline__ void lds_barrier()
 {
+    if (MUSE_ABLATE & 1)
+        return;
     fence();
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     fence();
@@ -192,7 +200,10 @@ struct Tw1Fetch {
 struct Tw2Fetch {
     const double2 *p;
     int lo;
-    __device__ __forceinline__ double2 operator()(int k) const { return p[k * 16 + lo]; }
+    __device__ __forceinline__ double2 operator()(int k) const
+    {
+        return p[k * 16 + lo];
+    }
 };
 
 // The next pair's rows, prefetched into registers: element t + 256*i of the two
@@ -206,6 +217,8 @@ struct RawPair {
 template <bool PADDED>
 __device__ __forceinline__ void issue_row_loads(RawPair &r, const FusedParams &p, long long pair, int t, int pad)
 {
+    if (MUSE_ABLATE & 2)
+        pair &= 7;
     const long long rA = 2 * pair;
     const long long rB = (rA + 1 < p.M) ? rA + 1 : rA;
     const gptr<double> ra = scalar_ptr(p.rows + rA * p.stride);

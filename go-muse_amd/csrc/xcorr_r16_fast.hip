@@ -66,6 +66,16 @@ __device__ __forceinline__ void exchange_cross(double2 (&v)[16], double2 *xbuf, 
     const int wbase = MODE ? 17 * lo + hi : t;
     const int rbase = 272 * (hi & 7) + (MODE ? 17 * lo : lo);
     const bool early = wave < 2;
+    if (MUSE_ABLATE & 1) { // no LDS: keep a register permutation so the data flow stays
+        double2 w[16];
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+            w[e] = v[P16(e)];
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+            v[e] = w[e];
+        return;
+    }
     lds_barrier(); // buffer free: every wave is done with its previous (wave-local or shared) use
 #pragma unroll
     for (int k = 0; k < 8; k++)
@@ -116,6 +126,16 @@ typedef __attribute__((address_space(3))) char *lds_ptr;
 #endif
 __device__ __forceinline__ void exchange_local(double2 (&v)[16], double2 *xw, const int hl, const int lo)
 {
+    if (MUSE_ABLATE & 1) {
+        double2 w[16];
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+            w[e] = v[P16(e)];
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+            v[e] = w[e];
+        return;
+    }
     const int wbase = 17 * hl + lo;
     const int rbase = 68 * (lo & 7) + 17 * hl;
 #pragma unroll
