@@ -18,6 +18,12 @@ template <int WPS> void go(FusedParams p, int grid)
     CK(hipDeviceSynchronize());
     CK(hipMemset(dbg, 0, (size_t)grid * 4 * 16 * 8));
     CK(hipMemset(p.ovf_count, 0, 4));
+    const int loops = getenv("LOOPS") ? atoi(getenv("LOOPS")) : 1; // LOOPS=N: run long enough to sample clocks / power
+    for (int l = 1; l < loops; l++) {
+        CK(hipMemsetAsync(p.ovf_count, 0, 4));
+        hipLaunchKernelGGL((xcorr_fused_n4096_fast<WPS, true>), dim3(grid), dim3(256), 0, 0, p);
+    }
+    if (loops > 1) { CK(hipDeviceSynchronize()); CK(hipMemset(dbg, 0, (size_t)grid * 4 * 16 * 8)); CK(hipMemset(p.ovf_count, 0, 4)); }
     CK(hipEventRecord(e0));
     hipLaunchKernelGGL((xcorr_fused_n4096_fast<WPS, true>), dim3(grid), dim3(256), 0, 0, p);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
