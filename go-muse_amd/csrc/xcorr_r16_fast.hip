@@ -1027,7 +1027,10 @@ hipError_t launch_fused_fast(const FusedParams &p, int num_cus, hipStream_t stre
         return hipGetLastError();
     }
     if (dyn && p.work_counter) {
-        grid = std::min<long long>(p.npairs, (long long)num_cus * wps); // resident workgroups only
+        int wpc = wps;
+        if (const char *d = getenv("MUSE_HIP_FAST_WPC")) // tuning aid: resident workgroups per CU
+            wpc = std::max(1, std::min(wps, atoi(d)));
+        grid = std::min<long long>(p.npairs, (long long)num_cus * wpc); // resident workgroups only
         if (wps == 4)
             hipLaunchKernelGGL((xcorr_fused_n4096_fast<4, false, true>), dim3((unsigned)grid), dim3(OCC_THREADS), 0, stream, q);
         else
