@@ -23,6 +23,28 @@ def shard_bounds(total_rows, world_size, rank, align=2):
     return lo, hi
 
 
+def shard_bounds_grouped(group_id, world_size, rank):
+    """Row range [lo, hi) of `rank` for a GROUPED run (config 5: Batch.Run(["graph"]) over 8 GPUs): rows must be
+    ordered so that every label group is contiguous (group_id non-decreasing or at least run-length contiguous);
+    cuts fall on group boundaries nearest to the even split, so no group straddles two shards and the per-shard
+    group maxima are exact.  Returns (lo, hi); a rank may get an empty range when there are fewer groups than ranks."""
+    gid = np.asarray(group_id)
+    M = len(gid)
+    if M == 0:
+        return 0, 0
+    starts = np.flatnonzero(np.concatenate(([True], gid[1:] != gid[:-1])))   # first row of every run
+    if len(np.unique(gid[starts])) != len(starts):
+        raise ValueError("rows of one label group are not contiguous: reorder the Group before sharding")
+    bounds = np.concatenate((starts, [M]))
+    cuts = [0]
+    for r in range(1, world_size):
+        target = r * M / world_size
+        c = int(bounds[np.argmin(np.abs(bounds - target))])
+        cuts.append(max(c, cuts[-1]))
+    cuts.append(M)
+    return cuts[rank], cuts[rank + 1]
+
+
 def gather_records(local_records, top_n, group=None, device=None):
     """all_gather of fixed-size (top_n records + count) buffers.  Returns the
     concatenated valid records of all ranks (on every rank)."""

@@ -101,3 +101,28 @@ def test_shard_bounds_cover_and_align():
             assert spans[0][0] == 0 and spans[-1][1] == total
             for (a, b), (c, d) in zip(spans, spans[1:]):
                 assert b == c and (a % 2 == 0 or a == total)
+
+
+def test_shard_bounds_grouped_cuts_on_group_boundaries():
+    import importlib
+    dist_mod = importlib.import_module("go-muse_amd").dist
+    rng = np.random.default_rng(0)
+    sizes = rng.integers(1, 40, size=57)
+    gid = np.repeat(np.arange(len(sizes)), sizes)
+    M = len(gid)
+    for world in (1, 2, 3, 8, 100):
+        prev = 0
+        owners = {}
+        for rank in range(world):
+            lo, hi = dist_mod.shard_bounds_grouped(gid, world, rank)
+            assert lo == prev and lo <= hi <= M
+            prev = hi
+            for g in np.unique(gid[lo:hi]):
+                assert g not in owners, "group straddles two shards"
+                owners[g] = rank
+        assert prev == M and len(owners) == len(sizes)
+        if world <= 8:
+            per = [dist_mod.shard_bounds_grouped(gid, world, r) for r in range(world)]
+            assert max(h - l for l, h in per) <= M / world + 40      # near-even split
+    with pytest.raises(ValueError):
+        dist_mod.shard_bounds_grouped(np.array([0, 1, 0]), 2, 0)
