@@ -831,3 +831,29 @@ def test_fuzz_padded_and_many_references(muse, eng, oracle):
         for b in batches:
             b.close()
         dg.close()
+
+
+def test_grouped_run_sharded_on_group_boundaries(muse, eng, oracle):
+    """config 4/5 shape on one GPU: a grouped Batch.Run over three shards cut by dist.shard_bounds_grouped
+    (no label group straddles a shard), per-shard top-N records merged on the host == the unsharded run."""
+    rng = np.random.default_rng(8)
+    N = 1024
+    sizes = rng.integers(1, 30, size=400)
+    gid = np.repeat(np.arange(len(sizes)), sizes).astype(np.int32)
+    M, G = len(gid), len(sizes)
+    ref = rng.standard_normal(N)
+    rows = rng.standard_normal((M, N))
+    rows[::11] += np.roll(ref, 4) * rng.uniform(0.5, 2.0, (len(rows[::11]), 1))
+    dg = muse.DeviceGroup.from_rows(eng, rows)
+    whole = muse.DeviceBatch(eng, dg, ref).run(gid, G, 8, 25, 0.05, 0, True)
+    recs = []
+    for rank in range(3):
+        lo, hi = muse.dist.shard_bounds_grouped(gid, 3, rank)
+        if hi == lo:
+            continue
+        dgs = muse.DeviceGroup.from_rows(eng, rows[lo:hi])
+        recs.append(muse.DeviceBatch(eng, dgs, ref).run_shard(gid[lo:hi], G, lo, 8, 25, 0.05, 0, True))
+    s, l, sc, mean = muse.merge_records(np.concatenate(recs), 25)
+    assert s.tolist() == whole[0].tolist() and l.tolist() == whole[1].tolist()
+    np.testing.assert_allclose(sc, whole[2], rtol=1e-12)
+    assert abs(mean - whole[3]) <= 1e-12
