@@ -47,6 +47,7 @@ SIGNATURES = {
     "muse_ctx_synchronize": (ctypes.c_int, [_vp]),
     "muse_ctx_device_info": (ctypes.c_int, [_vp, ctypes.c_char_p, _i32, _i32p, _i64p]),
     "muse_ctx_set_kernel": (ctypes.c_int, [_vp, _i32]),
+    "muse_ctx_set_screening": (ctypes.c_int, [_vp, _i32]),
     "muse_ctx_kernel_timing": (ctypes.c_int, [_vp, _i32]),
     "muse_ctx_kernel_time": (ctypes.c_int, [_vp, _dp, _i64p]),
     "muse_group_create": (ctypes.c_int, [_vp, _i64, _i32, ctypes.POINTER(_vp)]),
@@ -69,6 +70,7 @@ SIGNATURES = {
     "muse_merge_records": (ctypes.c_int, [_recp, _i64, _i32, _i64p, _i32p, _dp, _i32p, _dp]),
     "muse_batch_score_many": (ctypes.c_int, [ctypes.POINTER(_vp), _i32]),
     "muse_batch_read_scores": (ctypes.c_int, [_vp, _i32p, _dp]),
+    "muse_batch_screen_estimates": (ctypes.c_int, [_vp, _i32, _dp, ctypes.POINTER(ctypes.c_uint32), _dp]),
     "muse_batch_run_many": (ctypes.c_int, [ctypes.POINTER(_vp), _i32, _i32p, _i32, _i32, _i32, _f64, _i32, _i32,
                                            _i64p, _i32p, _dp, _i32p, _dp]),
     "muse_batch_free": (ctypes.c_int, [_vp]),

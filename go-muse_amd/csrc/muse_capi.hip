@@ -95,6 +95,9 @@ struct muse_ctx {
     std::vector<void *> many_host; // host image of many_tab (outlives the asynchronous copy)
     int many_cap = 0;
     double screen_delta = 1e-4;
+    // filter-and-refine Run (run_select): 0 = every Run scores all rows in fp64; 1 = ungrouped N = 4096 Runs screen in
+    // fp32 and re-evaluate in fp64 only the rows that can reach the top-N (muse_ctx_set_screening / MUSE_HIP_SCREEN_RUN)
+    int screening = 0;
     int variant = 0;
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -130,6 +133,7 @@ struct muse_spectrum {
     float2 *xcf = nullptr;
     double *xs = nullptr;
     double *c1 = nullptr; // n == 4096, N < 4096: indicator correlation (xcorr_r16_fast.hip, PADDED)
+    double xmax = -1.0;   // max |X[f]| (lazily, by the first screened Run): scales the fp32 error bound
 };
 
 struct muse_batch {
@@ -169,6 +173,15 @@ struct muse_batch {
     muse_record *cand_host = nullptr;
     int *cnt_host = nullptr;
     int64_t cand_host_cap = 0, cnt_host_cap = 0;
+    // filter-and-refine Run
+    unsigned *scr_flags = nullptr;      // [M] SCR_* bits of the screening pass
+    double *scr_var = nullptr;          // [M] sample variances from the screening pass
+    unsigned char *include = nullptr;   // [M] rows re-evaluated in fp64 (the only ones the selection may take)
+    unsigned long long *scr_keys = nullptr, *scr_cut = nullptr;
+    int64_t scr_cap = 0, scr_keys_cap = 0;
+    int *refine_host = nullptr;         // pinned: pairs re-evaluated by the last screened Run
+    int64_t screen_off_M = -1;          // a screened Run over this many rows re-evaluated too many of them: not again
+    bool scores_exact = true;           // mv / lag hold fp64 results for every row (false after a screened Run)
 };
 
 static int use_device(muse_ctx *ctx)
@@ -211,6 +224,8 @@ extern "C" int muse_ctx_create(int32_t device, muse_ctx **out)
     ctx->device = device;
     if (const char *kv = getenv("MUSE_HIP_KERNEL")) // profiling aid: same meaning as muse_ctx_set_kernel
         ctx->variant = atoi(kv);
+    if (const char *sv = getenv("MUSE_HIP_SCREEN_RUN")) // same meaning as muse_ctx_set_screening
+        ctx->screening = atoi(sv) != 0;
     ctx->num_cus = prop.multiProcessorCount;
     ctx->hbm = (int64_t)prop.totalGlobalMem;
     snprintf(ctx->name, sizeof(ctx->name), "%s (%s)", prop.name, prop.gcnArchName);
@@ -319,6 +334,14 @@ extern "C" int muse_ctx_set_kernel(muse_ctx *ctx, int32_t variant)
     if (!ctx || variant < 0 || variant > 11 || variant == 3 || variant == 4) // 3, 4: retired
         return fail(MUSE_ERR_INVALID, "bad kernel variant");
     ctx->variant = variant;
+    return MUSE_OK;
+}
+
+extern "C" int muse_ctx_set_screening(muse_ctx *ctx, int32_t enable)
+{
+    if (!ctx)
+        return fail(MUSE_ERR_INVALID, "NULL context");
+    ctx->screening = enable != 0;
     return MUSE_OK;
 }
 
@@ -871,6 +894,7 @@ extern "C" int muse_batch_score(muse_batch *b)
     if (b->n >= GENERIC_LDS_MAX_N)
         scratch_lock.lock();
     FusedParams p = base_params(b);
+    b->scores_exact = true;
     // kernel selection: ctx->variant 0 = auto; 1 = generic LDS radix-2; 2, 5..10 force one
     // of the n = 4096 kernels (parity tests run every one of them on the same inputs)
     int variant = KERNEL_GENERIC;
@@ -1100,6 +1124,178 @@ static int ensure_select_ws(muse_batch *b, int64_t M, int64_t G, bool with_gid, 
     return MUSE_OK;
 }
 
+// ---- filter-and-refine Run: ungrouped N = n = 4096 Runs under automatic kernel selection
+constexpr int64_t SCREEN_MIN_ROWS = 16384; // below this the fp64 pass is a fraction of a millisecond anyway
+
+static bool screen_eligible(const muse_batch *b, const int32_t *group_id, int32_t top_n, bool already_scored)
+{
+    const muse_ctx *ctx = b->ctx;
+    const int64_t M = b->g->M;
+    return !already_scored && ctx->screening && ctx->variant == 0 && !group_id && b->n == 4096 && b->N == 4096 &&
+           b->xcf && top_n >= 1 && top_n <= TOPN_DEVICE_MAX && M >= SCREEN_MIN_ROWS && M / 2 < 0x7fffffffLL &&
+           b->screen_off_M != M;
+}
+
+// Error bound of the screening pass's estimates, in its scaled units (score = estimate / (2^-e sigma), the last
+// factor in (0.707, 1.4143]).  Both transforms run on z = A + iB with ||z||_2 <= sqrt(2 (N-1)) * 1.4143 < 128 and
+// the product spectrum is bounded by max|X| * ||Z||_2 / n, so every error term of the standard fp32 FFT analysis
+// (Higham, Accuracy and Stability of Numerical Algorithms, 24.1: ||fl(F x) - F x||_2 <= c log2(n) u ||F x||_2;
+// here three radix-16 passes with twiddles that are products of <= 4 rounded factors, the rounded spectrum table
+// and the complex multiply) scales with u * max|X| * 128; 256 is > 1.5x the sum of those constants (~170).
+// The second term is the rounding of the fp32 input copy (|mean d| <= 8 sigma is enforced by the kernel):
+// ||delta c||_2 <= 2u (90.5 + 8 * 1.4143 * 64) and |delta cc| <= ||delta c||_2 ||xs||_2, ||xs||_2 = 1 / sqrt(N-1).
+static double screen_error_scaled(double xmax)
+{
+    const double u = 5.9604644775390625e-08; // 2^-24
+    return 256.0 * u * 128.0 * xmax + 2e-6;
+}
+
+static int score_screened(muse_batch *b, int32_t max_lag, int32_t top_n, double threshold, int32_t sign_filter,
+                          int32_t abs_scores)
+{
+    muse_ctx *ctx = b->ctx;
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    rc = group_flush(b->g);
+    if (rc)
+        return rc;
+    const int64_t M = b->g->M;
+    rc = ensure_scores(b);
+    if (rc)
+        return rc;
+    const int64_t npairs = (M + 1) / 2;
+    const int64_t nb = (M + TOPN_CHUNK - 1) / TOPN_CHUNK;
+    if (M > b->scr_cap) {
+        (void)hipFree(b->scr_flags);
+        (void)hipFree(b->scr_var);
+        (void)hipFree(b->include);
+        b->scr_flags = nullptr;
+        b->scr_var = nullptr;
+        b->include = nullptr;
+        b->scr_cap = 0;
+        HIP_TRY(hipMalloc(&b->scr_flags, (size_t)M * sizeof(unsigned)));
+        HIP_TRY(hipMalloc(&b->scr_var, (size_t)M * sizeof(double)));
+        HIP_TRY(hipMalloc(&b->include, (size_t)M));
+        b->scr_cap = M;
+    }
+    if (nb * top_n > b->scr_keys_cap) {
+        (void)hipFree(b->scr_keys);
+        b->scr_keys = nullptr;
+        b->scr_keys_cap = 0;
+        HIP_TRY(hipMalloc(&b->scr_keys, (size_t)(nb * top_n) * sizeof(unsigned long long)));
+        b->scr_keys_cap = nb * top_n;
+    }
+    if (!b->scr_cut)
+        HIP_TRY(hipMalloc(&b->scr_cut, sizeof(unsigned long long)));
+    if (!b->refine_host)
+        HIP_TRY(hipHostMalloc((void **)&b->refine_host, sizeof(int), hipHostMallocDefault));
+    if (npairs > b->ovf_cap) {
+        (void)hipFree(b->ovf_list);
+        b->ovf_list = nullptr;
+        b->ovf_cap = 0;
+        HIP_TRY(hipMalloc(&b->ovf_list, (size_t)(2 * npairs) * sizeof(long long)));
+        b->ovf_cap = 2 * npairs;
+    }
+    if (b->sp->xmax < 0.0) { // once per reference: max |X[f]| (X holds the non-redundant half of a real signal's spectrum)
+        std::vector<double2> X((size_t)(b->n / 2 + 1));
+        HIP_TRY(hipMemcpyAsync(X.data(), b->X, X.size() * sizeof(double2), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        double m = 0.0;
+        for (const double2 &x : X)
+            m = std::max(m, std::hypot(x.x, x.y));
+        b->sp->xmax = m;
+    }
+    const double Es = screen_error_scaled(b->sp->xmax);
+    HIP_TRY(hipMemsetAsync(b->scr_flags, 0, (size_t)M * sizeof(unsigned), ctx->stream));
+    HIP_TRY(hipMemsetAsync(b->include, 0, (size_t)M, ctx->stream));
+    HIP_TRY(hipMemsetAsync(b->ovf_count, 0, 2 * sizeof(int), ctx->stream));
+    FusedParams p = base_params(b);
+    p.scr_flags = b->scr_flags;
+    p.scr_var = b->scr_var;
+    p.scr_max_lag = max_lag;
+    p.screen_delta = 2.0 * Es; // every lag whose fp32 |cc| is within 2 E of the fp32 maximum may be the exact argmax
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ctx->timing) {
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, ctx->stream));
+    }
+    HIP_TRY(launch_screen_pass(p, ctx->num_cus, ctx->stream));
+    if (ctx->timing) {
+        HIP_TRY(hipEventRecord(e1, ctx->stream));
+        ctx->events.emplace_back(e0, e1);
+    }
+    ScreenSelect q{};
+    q.mv = b->mv;
+    q.var = b->scr_var;
+    q.flags = b->scr_flags;
+    q.M = M;
+    q.threshold = threshold;
+    q.sign_filter = sign_filter;
+    q.abs_scores = abs_scores ? 1 : 0;
+    q.E = 1.4143 * Es; // score = estimate / (2^-e sigma), 2^-e sigma in (0.7071, 1.4143]
+    HIP_TRY(launch_screen_select(q, top_n, b->selkey, b->scr_keys, b->scr_cut, b->ovf_list, b->ovf_count, b->include,
+                                 ctx->stream));
+    // the fp64 kernel re-evaluates the listed pairs (count stays on the device and bounds its loop)
+    FusedParams r = base_params(b);
+    r.pair_list = b->ovf_list;
+    r.pair_count = b->ovf_count;
+    r.npairs = std::min<long long>(npairs, (long long)ctx->num_cus * 3);
+    HIP_TRY(launch_fused(r, KERNEL_R16_OCC3, ctx->num_cus, ctx->stream));
+    *b->refine_host = 0;
+    HIP_TRY(hipMemcpyAsync(b->refine_host, b->ovf_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    b->scores_exact = false;
+    return MUSE_OK;
+}
+
+// test / measurement hook: the screening pass alone (estimates, SCR_* flags and the bound E in score units)
+extern "C" int muse_batch_screen_estimates(muse_batch *b, int32_t max_lag, double *estimate, uint32_t *flags, double *E)
+{
+    if (!b)
+        return fail(MUSE_ERR_INVALID, "NULL batch");
+    if (b->n != 4096 || b->N != 4096 || !b->xcf)
+        return fail(MUSE_ERR_UNSUPPORTED, "the screening pass is built for series of length 4096");
+    muse_ctx *ctx = b->ctx;
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    const int64_t M = b->g->M;
+    if (M == 0)
+        return MUSE_OK;
+    rc = ensure_select_ws(b, M, M, false, 1, false);
+    if (rc)
+        return rc;
+    rc = score_screened(b, max_lag, 1, 0.0, 0, 1);
+    if (rc)
+        return rc;
+    // (score_screened also ran the selection and the fp64 pass over the rows it picked: fetch the estimates of
+    // the rows it did NOT re-evaluate, and mark the others)
+    std::vector<unsigned char> inc((size_t)M);
+    HIP_TRY(hipMemcpyAsync(inc.data(), b->include, (size_t)M, hipMemcpyDeviceToHost, ctx->stream));
+    if (estimate)
+        HIP_TRY(hipMemcpyAsync(estimate, b->mv, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (flags)
+        HIP_TRY(hipMemcpyAsync(flags, b->scr_flags, (size_t)M * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (estimate) { // rows the fp64 kernel did not touch hold the scaled fp32 value: divide by sigma
+        std::vector<double> var((size_t)M);
+        std::vector<unsigned> fl((size_t)M);
+        HIP_TRY(hipMemcpy(var.data(), b->scr_var, (size_t)M * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(fl.data(), b->scr_flags, (size_t)M * sizeof(unsigned), hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < M; i++)
+            if (!inc[(size_t)i] && !(fl[(size_t)i] & (SCR_NAN | SCR_REFINE)))
+                estimate[i] = var[(size_t)i] > 0.0 ? estimate[i] * (1.0 / std::sqrt(var[(size_t)i])) : 0.0;
+    }
+    if (flags)
+        for (int64_t i = 0; i < M; i++)
+            if (inc[(size_t)i])
+                flags[i] |= 0x80000000u; // re-evaluated: `estimate` holds the fp64 result for this row
+    if (E)
+        *E = 1.4143 * screen_error_scaled(b->sp->xmax);
+    return MUSE_OK;
+}
+
 static int run_select(muse_batch *b, const int32_t *group_id, int32_t G_in, int64_t series_offset, int32_t max_lag,
                       int32_t top_n, double threshold, int32_t sign_filter, int32_t abs_scores,
                       std::vector<muse_record> &out, bool already_scored = false)
@@ -1112,7 +1308,8 @@ static int run_select(muse_batch *b, const int32_t *group_id, int32_t G_in, int6
     if (group_id && G_in < 0)
         return fail(MUSE_ERR_INVALID, "negative group count");
     // Batch.Run re-scores on every call (muse_batch.go:116-122)
-    int rc = already_scored ? MUSE_OK : muse_batch_score(b);
+    const bool screened = screen_eligible(b, group_id, top_n, already_scored);
+    int rc = (already_scored || screened) ? MUSE_OK : muse_batch_score(b);
     if (rc)
         return rc;
     const int64_t G = group_id ? (int64_t)G_in : M;
@@ -1125,6 +1322,11 @@ static int run_select(muse_batch *b, const int32_t *group_id, int32_t G_in, int6
     rc = ensure_select_ws(b, M, G, group_id != nullptr, K, on_device);
     if (rc)
         return rc;
+    if (screened) { // fp32 screening pass, then fp64 for the rows that can reach the top-N (needs the selection workspace)
+        rc = score_screened(b, max_lag, top_n, threshold, sign_filter, abs_scores);
+        if (rc)
+            return rc;
+    }
     if (group_id) {
         const bool same = b->gid_valid && (int64_t)b->gid_host.size() == M &&
                           memcmp(b->gid_host.data(), group_id, (size_t)M * sizeof(int32_t)) == 0;
@@ -1146,6 +1348,7 @@ static int run_select(muse_batch *b, const int32_t *group_id, int32_t G_in, int6
     sp.threshold = threshold;
     sp.sign_filter = sign_filter;
     sp.series_offset = series_offset;
+    sp.include = screened ? b->include : nullptr;
     HIP_TRY(launch_group_reduce(sp, b->gw, b->rec, b->selkey, ctx->stream));
     std::vector<muse_record> cands;
     if (on_device) {
@@ -1160,6 +1363,10 @@ static int run_select(muse_batch *b, const int32_t *group_id, int32_t G_in, int6
         for (int64_t blk = 0; blk < nb; blk++)
             for (int r = 0; r < cnt[(size_t)blk]; r++)
                 cands.push_back(cand[(size_t)(blk * K + r)]);
+        // a screened Run that had to re-evaluate a large part of the rows (few rows certainly pass the filters, or the
+        // scores crowd around the cut) costs more than the plain fp64 pass: not again for this (immutable) set of rows
+        if (screened && (int64_t)*b->refine_host * 4 > (M + 1) / 2)
+            b->screen_off_M = M;
     } else {
         std::vector<muse_record> rec((size_t)G);
         std::vector<unsigned long long> key((size_t)G);
@@ -1243,6 +1450,11 @@ extern "C" int muse_batch_read_scores(muse_batch *b, int32_t *lag, double *mv)
         return fail(MUSE_ERR_INVALID, "NULL output");
     if (M > b->score_cap)
         return fail(MUSE_ERR_INVALID, "the batch has not been scored since the group grew");
+    if (!b->scores_exact) { // the last Run screened in fp32 and re-evaluated only the rows it needed
+        rc = muse_batch_score(b);
+        if (rc)
+            return rc;
+    }
     HIP_TRY(hipMemcpyAsync(lag, b->lag, (size_t)M * sizeof(int), hipMemcpyDeviceToHost, b->ctx->stream));
     HIP_TRY(hipMemcpyAsync(mv, b->mv, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, b->ctx->stream));
     HIP_TRY(hipStreamSynchronize(b->ctx->stream));
@@ -1420,6 +1632,13 @@ extern "C" int muse_batch_free(muse_batch *b)
     if (b->cnt_host)
         (void)hipHostFree(b->cnt_host);
     (void)hipFree(b->cnt);
+    (void)hipFree(b->scr_flags);
+    (void)hipFree(b->scr_var);
+    (void)hipFree(b->include);
+    (void)hipFree(b->scr_keys);
+    (void)hipFree(b->scr_cut);
+    if (b->refine_host)
+        (void)hipHostFree(b->refine_host);
     muse_group *g = b->g;
     muse_ctx *ctx = b->ctx;
     delete b;

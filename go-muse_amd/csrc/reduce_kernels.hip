@@ -106,7 +106,8 @@ __global__ void group_final_kernel(SelectParams sp, GroupWork gw, muse_record *r
         rec[g].score = s;
         rec[g].lag = lg;
         rec[g].group = g;
-        selkey[g] = passed(s, lg, sp) ? abs_bits(s) + 1ull : 0ull;
+        // (filter-and-refine Run: only rows the fp64 kernel has re-evaluated may be selected)
+        selkey[g] = (!sp.include || sp.include[w]) && passed(s, lg, sp) ? abs_bits(s) + 1ull : 0ull;
     }
 }
 
@@ -203,6 +204,199 @@ __global__ __launch_bounds__(256) void topn_kernel(const muse_record *__restrict
     }
     if (t == 0)
         cnt[blockIdx.x] = r;
+}
+
+
+// ------------------------------------------------- filter-and-refine Run (ungrouped, n = 4096)
+// Selection keys of one row from the screening pass's estimate `s` (|s - exact| <= E at every possible argmax) and
+// its SCR_* flags: kmin <= exact key <= kplus, where the exact key is what group_final_kernel computes from the
+// fp64 result (abs_bits(clamped |score|) + 1 if passed() else 0).
+__device__ __forceinline__ void screen_keys(double sv, double var, unsigned f, const ScreenSelect &q,
+                                            unsigned long long &kmin, unsigned long long &kplus)
+{
+    const double s = (f & (SCR_NAN | SCR_REFINE)) || !(var > 0.0) ? 0.0 : sv * (1.0 / sqrt(var));
+    if (f & SCR_NAN) { // exact score NaN: passed() is false whatever the filters
+        kmin = kplus = 0ull;
+        return;
+    }
+    if (f & SCR_REFINE) { // no estimate: may be anything
+        kmin = 0ull;
+        kplus = abs_bits(1.0) + 1ull;
+        return;
+    }
+    const double a = fabs(s);
+    double lo = a - q.E, hi = a + q.E;
+    lo = lo < 0.0 ? 0.0 : (lo > 1.0 ? 1.0 : lo);
+    hi = hi > 1.0 ? 1.0 : hi;
+    const bool lag_may = (f & SCR_IN) != 0u, lag_must = lag_may && !(f & SCR_OUT);
+    bool sign_may = true, sign_must = true;
+    if (q.sign_filter != 0 && q.abs_scores) { // Batch.Run filters the sign of |score| (muse_batch.go:74-77): > 0 unless the score is 0
+        sign_may = q.sign_filter > 0;
+        sign_must = q.sign_filter > 0; // (with lo > 0, required below)
+    } else if (q.sign_filter != 0) {
+        const unsigned want = q.sign_filter > 0 ? SCR_POS : SCR_NEG, other = q.sign_filter > 0 ? SCR_NEG : SCR_POS;
+        const bool small = a <= 4.0 * q.E; // the exact value at the exact argmax may be zero or of either sign
+        sign_may = (f & want) != 0u || small;
+        sign_must = (f & want) != 0u && !(f & other) && !small;
+    }
+    const bool may = lag_may && sign_may && hi >= q.threshold;
+    const bool must = lag_must && sign_must && lo >= q.threshold && lo > 0.0;
+    kplus = may ? abs_bits(hi) + 1ull : 0ull;
+    kmin = must ? abs_bits(lo) + 1ull : 0ull;
+}
+
+// pessimistic key of every row -> selkey
+__global__ void screen_kmin_kernel(ScreenSelect q, unsigned long long *selkey)
+{
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < q.M; i += (long long)gridDim.x * blockDim.x) {
+        unsigned long long kmin, kplus;
+        screen_keys(q.mv[i], q.var[i], q.flags[i], q, kmin, kplus);
+        selkey[i] = kmin;
+    }
+}
+
+// per chunk of TOPN_CHUNK rows: its K largest keys, descending (zero-filled)
+__global__ __launch_bounds__(256) void topn_keys_kernel(const unsigned long long *__restrict__ selkey, long long G, int K,
+                                                        unsigned long long *keys)
+{
+    __shared__ unsigned long long sk[4];
+    __shared__ int si[4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const long long base = (long long)blockIdx.x * TOPN_CHUNK;
+    unsigned long long k[16];
+#pragma unroll
+    for (int m = 0; m < 16; m++) {
+        const long long g = base + t + 256 * m;
+        k[m] = g < G ? selkey[g] : 0ull;
+    }
+    for (int r = 0; r < K; r++) {
+        unsigned long long bk = 0ull;
+        int bm = 0;
+#pragma unroll
+        for (int m = 0; m < 16; m++)
+            if (k[m] > bk) {
+                bk = k[m];
+                bm = m;
+            }
+        const unsigned long long wk = wave_max_u64(bk);
+        if (lane == 0)
+            sk[wave] = wk;
+        __syncthreads();
+        unsigned long long BK = sk[0];
+        BK = sk[1] > BK ? sk[1] : BK;
+        BK = sk[2] > BK ? sk[2] : BK;
+        BK = sk[3] > BK ? sk[3] : BK;
+        int ci = (bk == BK && BK != 0ull) ? (t + 256 * bm) : 0x7fffffff;
+        ci = wave_min_i32(ci);
+        if (lane == 0)
+            si[wave] = ci;
+        __syncthreads();
+        const int CI = min(min(si[0], si[1]), min(si[2], si[3]));
+        if (CI != 0x7fffffff && t == (CI & 255)) {
+            const int mm = CI >> 8;
+#pragma unroll
+            for (int m = 0; m < 16; m++)
+                if (m == mm)
+                    k[m] = 0ull;
+        }
+        if (t == 0)
+            keys[(long long)blockIdx.x * K + r] = BK;
+        __syncthreads();
+    }
+}
+
+// one workgroup: the top_n-th largest of `count` keys (0 when fewer than top_n are non-zero) -> *cut.
+// Destroys `keys`.  top_n rounds over count / 256 keys per thread: microseconds for the usual top_n ~ 20.
+__global__ __launch_bounds__(256) void screen_cut_kernel(unsigned long long *keys, long long count, int top_n,
+                                                         unsigned long long *cut)
+{
+    __shared__ unsigned long long sk[4];
+    __shared__ long long si[4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    unsigned long long BK = 0ull;
+    for (int r = 0; r < top_n; r++) {
+        unsigned long long bk = 0ull;
+        long long bi = 0x7fffffffffffffffLL;
+        for (long long i = t; i < count; i += 256) { // (device-scope loads: thread 0 clears one key per round)
+            const unsigned long long x = __hip_atomic_load(&keys[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (x > bk) {
+                bk = x;
+                bi = i;
+            }
+        }
+        const unsigned long long wk = wave_max_u64(bk);
+        if (lane == 0)
+            sk[wave] = wk;
+        __syncthreads();
+        BK = sk[0];
+        BK = sk[1] > BK ? sk[1] : BK;
+        BK = sk[2] > BK ? sk[2] : BK;
+        BK = sk[3] > BK ? sk[3] : BK;
+        if (BK == 0ull)
+            break; // uniform: fewer than top_n rows certainly pass
+        long long ci = (bk == BK) ? bi : 0x7fffffffffffffffLL;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const long long u = __shfl_xor(ci, o, 64);
+            ci = u < ci ? u : ci;
+        }
+        if (lane == 0)
+            si[wave] = ci;
+        __syncthreads();
+        long long CI = si[0];
+        CI = si[1] < CI ? si[1] : CI;
+        CI = si[2] < CI ? si[2] : CI;
+        CI = si[3] < CI ? si[3] : CI;
+        if (t == 0)
+            __hip_atomic_store(&keys[CI], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        __syncthreads();
+    }
+    if (t == 0)
+        *cut = BK;
+}
+
+// one thread per pair of rows: the pair is re-evaluated (listed for the fp64 kernel, both rows marked in `include`)
+// when either row's optimistic key is non-zero and reaches the cut
+__global__ void screen_compact_kernel(ScreenSelect q, const unsigned long long *cut, long long npairs,
+                                      long long *pair_list, int *pair_count, unsigned char *include)
+{
+    const unsigned long long c = *cut;
+    for (long long pr = blockIdx.x * (long long)blockDim.x + threadIdx.x; pr < npairs; pr += (long long)gridDim.x * blockDim.x) {
+        const long long rA = 2 * pr, rB = rA + 1;
+        unsigned long long kmin, kp;
+        screen_keys(q.mv[rA], q.var[rA], q.flags[rA], q, kmin, kp);
+        bool need = kp != 0ull && kp >= c;
+        if (rB < q.M) {
+            screen_keys(q.mv[rB], q.var[rB], q.flags[rB], q, kmin, kp);
+            need = need || (kp != 0ull && kp >= c);
+        }
+        if (need) {
+            const int slot = atomicAdd(pair_count, 1);
+            pair_list[slot] = pr;
+            include[rA] = 1;
+            if (rB < q.M)
+                include[rB] = 1;
+        }
+    }
+}
+
+hipError_t launch_screen_select(const ScreenSelect &q, int top_n, unsigned long long *selkey, unsigned long long *keys,
+                                unsigned long long *cut, long long *pair_list, int *pair_count, unsigned char *include,
+                                hipStream_t stream)
+{
+    const long long nb = (q.M + TOPN_CHUNK - 1) / TOPN_CHUNK;
+    long long mb = (q.M + 255) / 256;
+    mb = mb > 4096 ? 4096 : (mb < 1 ? 1 : mb);
+    hipLaunchKernelGGL(screen_kmin_kernel, dim3((unsigned)mb), dim3(256), 0, stream, q, selkey);
+    hipLaunchKernelGGL(topn_keys_kernel, dim3((unsigned)nb), dim3(256), 0, stream, selkey, q.M, top_n, keys);
+    hipLaunchKernelGGL(screen_cut_kernel, dim3(1), dim3(256), 0, stream, keys, nb * top_n, top_n, cut);
+    const long long npairs = (q.M + 1) / 2;
+    long long pb = (npairs + 255) / 256;
+    pb = pb > 4096 ? 4096 : (pb < 1 ? 1 : pb);
+    hipLaunchKernelGGL(screen_compact_kernel, dim3((unsigned)pb), dim3(256), 0, stream, q, cut, npairs, pair_list,
+                       pair_count, include);
+    return hipGetLastError();
 }
 
 hipError_t launch_topn(const muse_record *rec, const unsigned long long *selkey, int G, int K, muse_record *cand,

@@ -47,6 +47,9 @@ struct FusedParams {
     const float2 *xcf;   // n entries: conj(X_full[f]) / n, fp32
     const double *xs;    // n entries: zeroPad(zNormalize(ref)/(N-1), n), time domain, fp64
     double screen_delta; // candidate window below the fp32 maximum (scaled units, max |cc| <= 1)
+    unsigned *scr_flags; // screening pass (xcorr_screen_pass_n4096): per-row SCR_* bits, OR-ed in
+    double *scr_var;     // screening pass: per-row sample variance (the estimate in mv is cc32 * 2^e: score = mv / sqrt(var))
+    int scr_max_lag;     // screening pass: the Run's MaxLag (classifies the possible argmax lags)
     int *ovf_count;      // pairs with too many candidates: redone by the fp64 kernel
     int *work_counter;   // dynamic pair hand-out (xcorr_r16_fast.hip, DYN): zeroed before the launch
     int tune;            // experiment bits (MUSE_HIP_FAST_TUNE); 0 in production
@@ -60,6 +63,9 @@ hipError_t launch_fused(const FusedParams &p, int variant, int num_cus, hipStrea
 hipError_t launch_fused_pipe(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_r16_pipe.hip
 hipError_t launch_fused_occ4(const FusedParams &p, int num_cus, int waves_per_simd, hipStream_t stream); // xcorr_r16_occ4.hip
 hipError_t launch_fused_screen(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_r16_screen.hip
+hipError_t launch_screen_pass(const FusedParams &p, int num_cus, hipStream_t stream);  // xcorr_r16_screen.hip (filter-and-refine Run)
+// per-row flags of the screening pass
+enum : unsigned { SCR_IN = 1u, SCR_OUT = 2u, SCR_POS = 4u, SCR_NEG = 8u, SCR_REFINE = 16u, SCR_NAN = 32u };
 hipError_t launch_fused_w8(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_r8_w8.hip
 hipError_t launch_fused_fast(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_r16_fast.hip (N == n == 4096)
 hipError_t launch_fused_multi(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_r16_fast.hip (R references)
@@ -103,7 +109,25 @@ struct SelectParams {
     double threshold;
     int sign_filter;
     long long series_offset;
+    const unsigned char *include; // optional: rows that may be selected (filter-and-refine Run); nullptr = all
 };
+
+// filter-and-refine Run: what the screening pass left per row, the Run's filters and the error bound of the estimate
+struct ScreenSelect {
+    const double *mv;      // fp32 estimate of the signed value at the fp32 argmax, times sigma
+    const double *var;     // sample variance (score estimate = mv / sqrt(var))
+    const unsigned *flags; // SCR_* bits
+    long long M;
+    double threshold;
+    int sign_filter;
+    int abs_scores;
+    double E;              // |estimate - exact| <= E (score units)
+};
+// pessimistic keys -> the top_n-th best of them (*cut) -> pairs whose optimistic key reaches it (pair_list, *pair_count,
+// include[row] = 1); keys: ceil(M / TOPN_CHUNK) * top_n entries of scratch
+hipError_t launch_screen_select(const ScreenSelect &q, int top_n, unsigned long long *selkey, unsigned long long *keys,
+                                unsigned long long *cut, long long *pair_list, int *pair_count, unsigned char *include,
+                                hipStream_t stream);
 
 // per-group winners -> rec[G] (+ selection keys selkey[G]: 0 = filtered out)
 hipError_t launch_group_reduce(const SelectParams &sp, const GroupWork &gw, muse_record *rec,

@@ -812,6 +812,287 @@ __global__ __launch_bounds__(SCR_THREADS, WPC) void xcorr_fused_n4096_screen2(co
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The screening PASS of the filter-and-refine Run (muse_capi.hip: run_select): fp32 only, no
+// re-evaluation.  Per series it writes
+//   mv[row]   the fp32 estimate of the signed score at the fp32 argmax (as a double), |estimate - exact| <= E
+//             for every lag (E: the caller's bound, DESIGN.md "filter and refine"), and
+//   flags[row] (OR-ed in; zeroed by the caller): what the lags whose fp32 |cc| lies within `screen_delta` = 2 E
+//             (scaled units) of the fp32 maximum -- the only lags that can be the exact argmax -- look like:
+//             SCR_IN / SCR_OUT: one of them has |lag| <= / > max_lag;  SCR_POS / SCR_NEG: its value is > 0 / < 0;
+//             SCR_REFINE: fp32 is not trusted for this series (sigma outside 2^+-100, x[0] a far outlier);
+//             SCR_NAN: the exact result is NaN (NaN / Inf samples);  sigma == 0 rows report score 0 at lag 0.
+// The caller turns these into a pessimistic and an optimistic selection key per row, refines (fp64 kernel) every
+// row whose optimistic key reaches the N-th best pessimistic key, and selects among the refined rows only.
+// Registers: 168 (three workgroups of 256 per CU); LDS 37 KB.  Global loads per pair: the batch's 16 spectrum
+// factors per thread (L2), issued while no HBM load is in flight (vmcnt is in-order), and the next pair's rows,
+// issued behind the first transform and consumed at the top of the next iteration.
+namespace scr {
+
+// forward fp32 FFT; pass-1 factors W_4096^(k t) from four per-thread base powers W^t, W^2t, W^4t, W^8t
+// (every factor is a product of at most four correctly rounded table entries)
+template <bool MULXC>
+__device__ __forceinline__ void fft4096b(f2 (&v)[16], f2 *xbuf, const f2 *tw2s, const f2 w1, const f2 w2, const f2 w4,
+                                         const f2 w8, const f2 (&xq)[16], const int t)
+{
+    dft16f(v);
+    {
+        const f2 w3 = cmulf(w1, w2), w5 = cmulf(w4, w1), w6 = cmulf(w4, w2), w7 = cmulf(w4, w3);
+        v[P16(1)] = cmulf(v[P16(1)], w1);
+        v[P16(2)] = cmulf(v[P16(2)], w2);
+        v[P16(3)] = cmulf(v[P16(3)], w3);
+        v[P16(4)] = cmulf(v[P16(4)], w4);
+        v[P16(5)] = cmulf(v[P16(5)], w5);
+        v[P16(6)] = cmulf(v[P16(6)], w6);
+        v[P16(7)] = cmulf(v[P16(7)], w7);
+        v[P16(8)] = cmulf(v[P16(8)], w8);
+        v[P16(9)] = cmulf(v[P16(9)], cmulf(w8, w1));
+        v[P16(10)] = cmulf(v[P16(10)], cmulf(w8, w2));
+        v[P16(11)] = cmulf(v[P16(11)], cmulf(w8, w3));
+        v[P16(12)] = cmulf(v[P16(12)], cmulf(w8, w4));
+        v[P16(13)] = cmulf(v[P16(13)], cmulf(w8, w5));
+        v[P16(14)] = cmulf(v[P16(14)], cmulf(w8, w6));
+        v[P16(15)] = cmulf(v[P16(15)], cmulf(w8, w7));
+    }
+    exchange<false>(v, xbuf, t);
+    dft16f(v);
+    {
+        const int lo = t & 15;
+#pragma unroll
+        for (int k = 1; k < 16; k++)
+            v[P16(k)] = cmulf(v[P16(k)], tw2s[k * 16 + lo]);
+    }
+    exchange<true>(v, xbuf, t);
+    dft16f(v);
+    f2 w[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        w[k] = v[P16(k)];
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        v[k] = MULXC ? cmulf(w[k], xq[k]) : w[k];
+}
+
+} // namespace scr
+
+template <int WPC, bool TIMING = false>
+__global__ __launch_bounds__(SCR_THREADS, WPC) void xcorr_screen_pass_n4096(const FusedParams p)
+{
+    using namespace scr;
+    __shared__ f2 xbuf[SCR_XBUF];
+    __shared__ f2 tw2s[256];
+    __shared__ double red[32]; // [0,16) statistics; [16,24): per wave fp32 maxima (A, B); [24,32): their first indices
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    constexpr double invN = 1.0 / 4096.0, invNm1 = 1.0 / 4095.0;
+    const float window = (float)p.screen_delta;
+    const int max_lag = p.scr_max_lag;
+    float *redf = reinterpret_cast<float *>(red + 16);
+    int *redi = reinterpret_cast<int *>(red + 24);
+    f2 w1, w2, w4, w8;
+    {
+        const float2 tw = p.tw2f[t];
+        tw2s[t] = mk2(tw.x, tw.y);
+        const gptr<float2> tp = scalar_ptr(p.tw1f);
+        w1 = ldg_f2(tp, 256 + t);
+        w2 = ldg_f2(tp, 512 + t);
+        w4 = ldg_f2(tp, 1024 + t);
+        w8 = ldg_f2(tp, 2048 + t);
+    }
+    __syncthreads();
+    PhaseClock<TIMING> clk;
+    clk.start();
+    long long pair = blockIdx.x; // the launcher never starts more workgroups than pairs
+    double ra[16], rb[16], kA, kB;
+    issue_series(ra, kA, p.rows + 2 * pair * p.stride, t);
+    issue_series(rb, kB, p.rows + (2 * pair + 1 < p.M ? 2 * pair + 1 : 2 * pair) * p.stride, t);
+    for (; pair < p.npairs; pair += gridDim.x) {
+        const long long rA = 2 * pair, rB = rA + 1;
+        const bool hasB = rB < p.M;
+        long long nxt = pair + gridDim.x; // clamped: the prefetch is unconditional
+        nxt = nxt < p.npairs ? nxt : p.npairs - 1;
+        const long long nA = 2 * nxt, nB = (nA + 1 < p.M) ? nA + 1 : nA;
+        if (TIMING)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        clk.template stamp<0>();
+        // ---- rows arrive: shifted fp64 sums + provisional fp32 copy; the fp64 samples are dropped here
+        float na[16], nb[16];
+        double q[4];
+        reduce_series(ra, kA, na, q[0], q[1]);
+        reduce_series(rb, kB, nb, q[2], q[3]);
+        fence();
+        // the batch's spectrum factors for the first transform's last pass, while no HBM load is in flight
+        f2 xq[16];
+        {
+            const Tw1FetchF fetch{p.xcf, t};
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                xq[k] = fetch(k);
+        }
+        fence();
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            q[k] = wave_sum_dpp(q[k]);
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                red[wave * 4 + k] = q[k];
+        }
+        lds_barrier();
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            q[k] = uniform((red[k] + red[4 + k]) + (red[8 + k] + red[12 + k]));
+        const double mA = uniform(q[0] * invN), mB = uniform(q[2] * invN); // mean of d
+        const double varA = uniform((q[1] - q[0] * q[0] * invN) * invNm1);
+        const double varB = uniform((q[3] - q[2] * q[2] * invN) * invNm1);
+        const bool nanA = !__builtin_isfinite(varA), nanB = !__builtin_isfinite(varB);
+        const bool zeroA = !nanA && !(varA > 0.0), zeroB = !nanB && !(varB > 0.0);
+        const int eA = (int)((__double_as_longlong(varA) >> 52) & 0x7ff) - 1023;
+        const int eB = (int)((__double_as_longlong(varB) >> 52) & 0x7ff) - 1023;
+        // fp32 is trusted only when sigma is well inside its range and x[0] is no far outlier (|mean d| <= 8 sigma
+        // keeps the rounding of fl32(d) at 2^-24 * O(sigma)); otherwise the row is flagged for the fp64 kernel
+        const bool redoA = !(zeroA || nanA) && (eA > 200 || eA < -200 || mA * mA > 64.0 * varA);
+        const bool redoB = !(zeroB || nanB) && (eB > 200 || eB < -200 || mB * mB > 64.0 * varB);
+        const bool offA = zeroA || nanA || redoA, offB = zeroB || nanB || redoB || !hasB;
+        const float sclA = offA ? 0.f : __int_as_float((127 - (eA >> 1)) << 23);
+        const float sclB = offB ? 0.f : __int_as_float((127 - (eB >> 1)) << 23);
+        const float mAf = offA ? 0.f : (float)mA, mBf = offB ? 0.f : (float)mB;
+        f2 v[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            v[i] = mk2((na[i] - mAf) * sclA, (nb[i] - mBf) * sclB);
+        if (offA || offB) { // block-uniform, rare: such a series contributes exact zeros (its samples may be NaN / Inf)
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                v[i].x = offA ? 0.f : v[i].x;
+                v[i].y = offB ? 0.f : v[i].y;
+            }
+        }
+        clk.template stamp<1>();
+        fft4096b<true>(v, xbuf, tw2s, w1, w2, w4, w8, xq, t);
+        clk.template stamp<2>();
+        // ---- the next pair streams in behind the second transform (no other global load until it is consumed)
+        fence();
+        issue_series(ra, kA, p.rows + nA * p.stride, t);
+        issue_series(rb, kB, p.rows + nB * p.stride, t);
+        fence();
+        fft4096b<false>(v, xbuf, tw2s, w1, w2, w4, w8, xq, t);
+        clk.template stamp<3>();
+        // ---- fp32 maximum of |cc| per series and its first index (lag index 256 k + t)
+        float ma = -1.f, mb = -1.f;
+        int ia = 0, ib = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const float xa = fabsf(v[k].x), xb = fabsf(v[k].y);
+            if (xa > ma) { ma = xa; ia = k; }
+            if (xb > mb) { mb = xb; ib = k; }
+        }
+        {
+            const float WA = wave_max_f32_dpp(ma), WB = wave_max_f32_dpp(mb);
+            int ca = (ma == WA) ? 256 * ia + t : 0x7fffffff, cb = (mb == WB) ? 256 * ib + t : 0x7fffffff;
+            ca = wave_min_i_dpp(ca);
+            cb = wave_min_i_dpp(cb);
+            if (lane == 0) {
+                redf[wave] = WA;
+                redf[4 + wave] = WB;
+                redi[wave] = ca;
+                redi[4 + wave] = cb;
+            }
+        }
+        lds_barrier();
+        float MA = redf[0], MB = redf[4];
+        int LA = redi[0], LB = redi[4];
+#pragma unroll
+        for (int w = 1; w < 4; w++) {
+            const float xa = redf[w], xb = redf[4 + w];
+            const int la = redi[w], lb = redi[4 + w];
+            if (xa > MA || (xa == MA && la < LA)) { MA = xa; LA = la; }
+            if (xb > MB || (xb == MB && lb < LB)) { MB = xb; LB = lb; }
+        }
+        // ---- what the possible exact argmaxes look like: every lag within the window of the maximum.  Hits are rare
+        // (the argmax itself and, at most, a few neighbours): one compare + ballot per element, the classification
+        // only where a lane hits.
+        {
+            const float thA = MA - window, thB = MB - window;
+            unsigned fA = 0u, fB = 0u;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const float xa = v[k].x, xb = v[k].y;
+                const bool ha = fabsf(xa) >= thA, hb = fabsf(xb) >= thB;
+                if (__ballot(ha || hb) != 0ull) { // wave-uniform
+                    const int idx = 256 * k + t;
+                    const int lg = idx > 2048 ? idx - 4096 : idx;
+                    const unsigned in = (lg < 0 ? -lg : lg) <= max_lag ? SCR_IN : SCR_OUT;
+                    if (ha)
+                        fA |= in | (xa > 0.f ? SCR_POS : 0u) | (xa < 0.f ? SCR_NEG : 0u);
+                    if (hb)
+                        fB |= in | (xb > 0.f ? SCR_POS : 0u) | (xb < 0.f ? SCR_NEG : 0u);
+                    // the estimate itself, by the thread that holds the fp32 argmax: the fp32 value with its exact
+                    // power-of-two scale; the selection divides by sigma (scr_var)
+                    if (idx == LA && !offA) {
+                        p.mv[rA] = (double)xa * __longlong_as_double((long long)(1023 + (eA >> 1)) << 52);
+                        p.lag[rA] = lg;
+                    }
+                    if (idx == LB && !offB) {
+                        p.mv[rB] = (double)xb * __longlong_as_double((long long)(1023 + (eB >> 1)) << 52);
+                        p.lag[rB] = lg;
+                    }
+                }
+            }
+            if (__ballot((fA | fB) != 0u) != 0ull) { // waves without a hit have nothing to report
+                // OR over the wave (DPP-free: flags are 4 bits, ballots of each)
+                unsigned wA = 0u, wB = 0u;
+#pragma unroll
+                for (unsigned bit = 1u; bit <= 8u; bit <<= 1) {
+                    wA |= __ballot((fA & bit) != 0u) != 0ull ? bit : 0u;
+                    wB |= __ballot((fB & bit) != 0u) != 0ull ? bit : 0u;
+                }
+                if (lane == 0) { // fire and forget
+                    if (wA && !offA)
+                        atomicOr(&p.scr_flags[rA], wA);
+                    if (wB && !offB)
+                        atomicOr(&p.scr_flags[rB], wB);
+                }
+            }
+            if (t == 0) { // per-series constants of the estimate, and the rows fp32 has nothing to say about
+                p.scr_var[rA] = varA;
+                if (offA) {
+                    p.mv[rA] = nanA ? __builtin_nan("") : 0.0;
+                    p.lag[rA] = 0;
+                    atomicOr(&p.scr_flags[rA], nanA ? SCR_NAN : (redoA ? SCR_REFINE : SCR_IN)); // sigma == 0: score 0 at lag 0, exactly
+                }
+                if (hasB) {
+                    p.scr_var[rB] = varB;
+                    if (offB) {
+                        p.mv[rB] = nanB ? __builtin_nan("") : 0.0;
+                        p.lag[rB] = 0;
+                        atomicOr(&p.scr_flags[rB], nanB ? SCR_NAN : (redoB ? SCR_REFINE : SCR_IN));
+                    }
+                }
+            }
+        }
+        clk.template stamp<4>();
+    }
+    if (TIMING && p.dbg && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NPHASE; i++)
+            p.dbg[((long long)blockIdx.x * 4 + wave) * NPHASE + i] = clk.acc[i];
+    }
+}
+
+hipError_t launch_screen_pass(const FusedParams &p, int num_cus, hipStream_t stream)
+{
+    if (p.N != 4096 || p.n != 4096 || !p.scr_flags || !p.scr_var || !p.xcf)
+        return hipErrorInvalidValue;
+    long long grid = p.npairs;
+    const long long cap = (long long)num_cus * 3;
+    if (grid > cap)
+        grid = cap;
+    hipLaunchKernelGGL((xcorr_screen_pass_n4096<3, false>), dim3((unsigned)grid), dim3(SCR_THREADS), 0, stream, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_fused_screen(const FusedParams &p, int num_cus, hipStream_t stream)
 {
     long long grid = p.npairs;

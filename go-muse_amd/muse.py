@@ -64,6 +64,10 @@ class Engine:
     def set_kernel(self, variant):
         B.check(B.load().muse_ctx_set_kernel(self._h, int(variant)))
 
+    def set_screening(self, enable):
+        """filter-and-refine Run (include/muse_hip.h: muse_ctx_set_screening)"""
+        B.check(B.load().muse_ctx_set_screening(self._h, 1 if enable else 0))
+
     def kernel_timing(self, enable):
         B.check(B.load().muse_ctx_kernel_timing(self._h, 1 if enable else 0))
 
@@ -213,6 +217,24 @@ class DeviceBatch:
         mv = np.zeros(M)
         B.check(B.load().muse_batch_scores(self._h, B.i32ptr(lag), B.dptr(mv)))
         return lag, mv
+
+    def read_scores(self):
+        """(lag, mv) of the last scoring pass without re-scoring (muse_batch_read_scores)"""
+        M = self.dgroup.M
+        lag = np.zeros(M, dtype=np.int32)
+        mv = np.zeros(M)
+        B.check(B.load().muse_batch_read_scores(self._h, B.i32ptr(lag), B.dptr(mv)))
+        return lag, mv
+
+    def screen_estimates(self, max_lag=10):
+        """test hook: (estimates, flags, E) of the fp32 screening pass (include/muse_hip.h)"""
+        M = self.dgroup.M
+        est = np.zeros(M)
+        flags = np.zeros(M, dtype=np.uint32)
+        E = ctypes.c_double(0)
+        B.check(B.load().muse_batch_screen_estimates(self._h, int(max_lag), B.dptr(est),
+                                                      flags.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), ctypes.byref(E)))
+        return est, flags, float(E.value)
 
     def run(self, group_id=None, G=0, max_lag=10, top_n=20, threshold=0.0, sign_filter=0, abs_scores=True):
         cap = max(int(top_n), 1)

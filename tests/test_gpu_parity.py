@@ -857,3 +857,121 @@ def test_grouped_run_sharded_on_group_boundaries(muse, eng, oracle):
     assert s.tolist() == whole[0].tolist() and l.tolist() == whole[1].tolist()
     np.testing.assert_allclose(sc, whole[2], rtol=1e-12)
     assert abs(mean - whole[3]) <= 1e-12
+
+
+# ------------------------------------------------ filter-and-refine Run (fp32 screening pass + fp64 for the rows that matter)
+def _screen_cases(rng, N):
+    ref = np.zeros(N)
+    ref[900:1300] = 1.0
+    ref += 0.1 * rng.standard_normal(N)
+    M = 17000
+    rows = rng.standard_normal((M, N))
+    t = np.arange(N)
+    for i in range(0, M, 3):                                        # planted matches: all lags, both signs, all strengths
+        rows[i] += rng.uniform(-3, 3) * np.roll(ref - ref.mean(), int(rng.integers(-N // 2, N // 2))) * 3.0
+    for i in range(100, 160):                                       # a crowd of nearly equal scores around a cut
+        rows[i] = np.roll(ref, 5) + 0.3 * rows[99] + 1e-7 * (i - 100) * rng.standard_normal(N)
+    for i in range(200, 230):                                       # periodic: many lags tie within any window
+        rows[i] = np.sin(2 * np.pi * (t + i) / 64.0) + 0.01 * rng.standard_normal(N)
+    rows[300] = ref                                                 # score 1 at lag 0
+    # (exact ties in |score| are avoided: their order in the reference's heap depends on rows evicted earlier)
+    rows[301] = -np.roll(ref, -12) + 0.01 * rows[301]               # score ~ -1 inside MaxLag 15
+    rows[302] = np.roll(ref, 16) + 0.02 * rows[302]                 # score ~ 1 just outside MaxLag 15
+    rows[303] = 4.0                                                 # sigma == 0
+    rows[304, 7] = np.nan
+    rows[305] = np.inf
+    rows[306] = rows[306] * 1e60 + np.roll(ref, 3) * 3e60           # sigma outside the fp32 range
+    rows[307] = 1e-70 * (rows[307] + 3 * np.roll(ref, -3))
+    rows[308] = np.roll(ref, 2) + 0.05 * rows[308]
+    rows[308, 0] += 500.0                                           # x[0] a far outlier (the fp32 shift point)
+    rows[309] = 1e6 + 1e-3 * (np.roll(ref, 1) + 0.05 * rows[309])  # large offset, small variation
+    return ref, rows
+
+
+def test_screened_run_equals_fp64_run(muse, eng, oracle):
+    """The filter-and-refine Run (muse_ctx_set_screening) returns the records of the all-fp64 Run: adversarial rows
+    (near ties at the cut, periodic series, NaN / Inf / sigma == 0, sigmas outside the fp32 range, a far-outlier first
+    sample) under every filter combination; the expected records are the oracle's Results over the fp64 scores."""
+    rng = np.random.default_rng(2024)
+    N = 4096
+    ref, rows = _screen_cases(rng, N)
+    dg = muse.DeviceGroup.from_rows(eng, rows)
+    db = muse.DeviceBatch(eng, dg, ref)
+    lag, mv = db.scores()
+    try:
+        eng.set_screening(True)
+        for max_lag in (15, 0, 2048, 4096, 100):
+            for top_n, thr, sign, absf in ((20, 0.0, 0, True), (1, 0.0, 0, True), (200, 0.0, 0, True), (20, 0.3, 0, True),
+                                          (20, 0.0, 1, False), (20, 0.0, -1, False), (50, 0.05, -1, True),
+                                          (20, 0.999, 0, True), (256, 0.0, 1, True)):
+                got = db.run(None, 0, max_lag, top_n, thr, sign, absf)
+                exp = oracle.results(lag, mv, None, 0, absf, max_lag, top_n, thr, sign)
+                key = (max_lag, top_n, thr, sign, absf)
+                assert got[0].tolist() == exp[0].tolist(), key
+                assert got[1].tolist() == exp[1].tolist(), key
+                np.testing.assert_allclose(got[2], exp[2], rtol=1e-12, atol=0, err_msg=str(key))
+        # the all-scores API after a screened Run still returns fp64 results for every row
+        lag2, mv2 = db.read_scores()
+        assert np.array_equal(lag2, lag)
+        np.testing.assert_allclose(mv2, mv, rtol=1e-12, atol=0, equal_nan=True)
+    finally:
+        eng.set_screening(False)
+        db.close()
+
+
+def test_screening_estimates_stay_inside_the_bound(muse, eng, oracle):
+    """|fp32 estimate - fp64 score| <= E for every series the pass did not hand to the fp64 kernel, with E the bound
+    the selection assumes; the flags cover the exact lag (inside / outside MaxLag) and the exact sign."""
+    rng = np.random.default_rng(7)
+    N = 4096
+    ref, rows = _screen_cases(rng, N)
+    dg = muse.DeviceGroup.from_rows(eng, rows)
+    db = muse.DeviceBatch(eng, dg, ref)
+    lag, mv = db.scores()
+    worst = 0.0
+    for max_lag in (15, 700):
+        est, flags, E = db.screen_estimates(max_lag)
+        assert 0 < E < 5e-3
+        refined = (flags >> 31) & 1 == 1
+        nan = np.isnan(mv)
+        assert np.all((flags[nan] & 32) != 0) and np.all((flags[~nan] & 32) == 0)
+        chk = ~refined & ~nan & ((flags & 16) == 0)
+        err = np.abs(np.abs(est[chk]) - np.abs(mv[chk]))
+        assert err.max() <= E, (err.max(), E)
+        worst = max(worst, float(err.max() / E))
+        inside = np.abs(lag[chk]) <= max_lag
+        f = flags[chk]
+        assert np.all((f[inside] & 1) != 0) and np.all((f[~inside] & 2) != 0)
+        big = np.abs(mv[chk]) > 4 * E
+        assert np.all((f[big & (mv[chk] > 0)] & 4) != 0) and np.all((f[big & (mv[chk] < 0)] & 8) != 0)
+        assert np.all((flags[[306, 307, 308]] & 16) != 0)            # sigma out of range, outlier first sample
+    print("screening: worst |estimate - exact| / E = %.3g" % worst)
+    db.close()
+
+
+def test_screened_run_synthetic_matches_fp64_run(muse, eng):
+    """BASELINE's synthetic rect+noise rows (device generated), 131072 of them: screened Run == fp64 Run.  The
+    generator plants exact copies of the reference (score exactly 1 after the clamp), so many rows tie at the top and
+    which of them a Run returns depends on the last bit of each kernel's score: the comparison is on the scores, and on
+    every returned row being a correct member (filters passed, exact score equal to the reported one)."""
+    dg, ref = muse.DeviceGroup.synthetic(eng, 131072, 4096, seed=99)
+    db = muse.DeviceBatch(eng, dg, ref)
+    lag, mv = db.scores()
+    try:
+        for args in ((None, 0, 15, 20, 0.0, 0, True), (None, 0, 4096, 100, 0.2, 0, True), (None, 0, 15, 20, 0.0, -1, False),
+                     (None, 0, 40, 256, 0.0, 1, False)):
+            eng.set_screening(False)
+            exp = db.run(*args)
+            eng.set_screening(True)
+            got = db.run(*args)
+            assert len(got[0]) == len(exp[0]), args
+            np.testing.assert_allclose(got[2], exp[2], rtol=1e-12, atol=0)
+            rows = got[0]
+            assert len(set(rows.tolist())) == len(rows)
+            assert np.all(np.abs(lag[rows]) <= args[2]) and np.array_equal(lag[rows], got[1])
+            exact = np.clip(np.abs(mv[rows]), None, 1.0) if args[6] else np.clip(mv[rows], -1.0, 1.0)
+            np.testing.assert_allclose(got[2], exact, rtol=1e-12, atol=0)
+            assert abs(got[3] - exp[3]) <= 1e-12
+    finally:
+        eng.set_screening(False)
+        db.close()

@@ -224,9 +224,10 @@ int main(int argc, char** argv)
     p.tw1f = f1; p.tw2f = f2_; p.xcf = fx;
     CK(hipMalloc(&p.mv, M * 8)); CK(hipMalloc(&p.lag, M * 4));
     CK(hipDeviceSynchronize());
-    run("screen-only WPC=4", screen_only<4, false>, p, 256 * 4, false);
-    run("screen-only WPC=4 (stamped)", screen_only<4, true>, p, 256 * 4, true);
+    unsigned* fl; CK(hipMalloc(&fl, M * 4)); CK(hipMemset(fl, 0, M * 4)); p.scr_flags = fl; double* sv; CK(hipMalloc(&sv, M * 8)); p.scr_var = sv; p.scr_max_lag = 15; p.screen_delta = 1e-3;
     run("screen-only WPC=3", screen_only<3, false>, p, 256 * 3, false);
-    run("screen-only WPC=4 x4 grid", screen_only<4, false>, p, 256 * 16, false);
+    run("library screening pass", xcorr_screen_pass_n4096<3, false>, p, 256 * 3, false);
+    run("library screening pass (stamped)", xcorr_screen_pass_n4096<3, true>, p, 256 * 3, true);
+    run("screen-only WPC=3 (stamped)", screen_only<3, true>, p, 256 * 3, true);
     return 0;
 }
