@@ -132,6 +132,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    screened, refined_pairs = db.last_run_info()
     if rank == 0:
         total_pairs = float(M) * n_gpus * args.steps
         value = total_pairs / dt
@@ -139,11 +140,12 @@ def main():
         bytes_per_launch = float(M) * (8 * N + 16)
         achieved = bytes_per_launch / k_avg_s / 1e9 if k_avg_s > 0 else 0.0
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "traffic.json" if screened else "traffic_fp64.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("rows") == M and tj.get("length") == N:
+                want = "xcorr_screen_pass" if screened else "xcorr_fused_n4096_fast"
+                if tj.get("rows") == M and tj.get("length") == N and want in tj.get("kernel", "xcorr_fused_n4096_fast"):
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -151,18 +153,22 @@ def main():
             "metric": "series-pairs XCorr/sec at N=4096, 1M-series batch; achieved HBM GB/s",
             "value": value, "unit": "series-pairs/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32+f64" if screened else "f64", "data": "synthetic",
             "config": {"workload": "configs[2]: 1 ref x %d series/GPU, N=%d float64 rect+noise, Run(nil), "
                                    "MaxLag=%d TopN=%d" % (M, N, args.max_lag, args.top_n),
                        "rows_per_gpu": M, "length": N, "fft_len": db.n, "sharding": "rows x %d" % n_gpus,
                        "device": dev_name},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "xcorr_fused_n4096_fast<4>" if db.n == 4096 else ("xcorr_fused_stk_*" if db.n >= 512 else "xcorr_fused_generic"),
+                         "kernel": ("xcorr_screen_pass_n4096<3>" if screened else "xcorr_fused_n4096_fast<4>") if db.n == 4096
+                                   else ("xcorr_fused_stk_*" if db.n >= 512 else "xcorr_fused_generic"),
                          "kernel_ms_avg": k_avg_s * 1e3, "launches_timed": k_cnt,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
             "achieved_hbm_gbps_whole_step": value / n_gpus * (8 * N + 16) / 1e9,
             "top_score": float(out[2][0]) if len(out[2]) else None,
+            # Run path: filter-and-refine = fp32 screening pass over every row (the dominant kernel above; statistics in
+            # fp64) + fp64 re-evaluation of the rows that can reach the top-N; the records are those of the all-fp64 Run
+            "run_path": {"filter_and_refine": screened, "pairs_re_evaluated_in_fp64": refined_pairs},
         }
         if n_gpus == 1 and args.many_refs > 1 and db.n == 4096 and N == 4096:
             # R references against the same resident group in one pass over the rows

@@ -70,6 +70,7 @@ SIGNATURES = {
     "muse_merge_records": (ctypes.c_int, [_recp, _i64, _i32, _i64p, _i32p, _dp, _i32p, _dp]),
     "muse_batch_score_many": (ctypes.c_int, [ctypes.POINTER(_vp), _i32]),
     "muse_batch_read_scores": (ctypes.c_int, [_vp, _i32p, _dp]),
+    "muse_batch_last_run_info": (ctypes.c_int, [_vp, _i32p, _i64p]),
     "muse_batch_screen_estimates": (ctypes.c_int, [_vp, _i32, _dp, ctypes.POINTER(ctypes.c_uint32), _dp]),
     "muse_batch_run_many": (ctypes.c_int, [ctypes.POINTER(_vp), _i32, _i32p, _i32, _i32, _i32, _f64, _i32, _i32,
                                            _i64p, _i32p, _dp, _i32p, _dp]),

@@ -95,9 +95,9 @@ struct muse_ctx {
     std::vector<void *> many_host; // host image of many_tab (outlives the asynchronous copy)
     int many_cap = 0;
     double screen_delta = 1e-4;
-    // filter-and-refine Run (run_select): 0 = every Run scores all rows in fp64; 1 = ungrouped N = 4096 Runs screen in
-    // fp32 and re-evaluate in fp64 only the rows that can reach the top-N (muse_ctx_set_screening / MUSE_HIP_SCREEN_RUN)
-    int screening = 0;
+    // filter-and-refine Run (run_select): 1 = ungrouped N = 4096 Runs screen in fp32 and re-evaluate in fp64 only the
+    // rows that can reach the top-N; 0 = every Run scores all rows in fp64 (muse_ctx_set_screening / MUSE_HIP_SCREEN_RUN)
+    int screening = 1;
     int variant = 0;
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -177,11 +177,12 @@ struct muse_batch {
     unsigned *scr_flags = nullptr;      // [M] SCR_* bits of the screening pass
     double *scr_var = nullptr;          // [M] sample variances from the screening pass
     unsigned char *include = nullptr;   // [M] rows re-evaluated in fp64 (the only ones the selection may take)
-    unsigned long long *scr_keys = nullptr, *scr_cut = nullptr;
+    unsigned long long *scr_keys = nullptr;
     int64_t scr_cap = 0, scr_keys_cap = 0;
     int *refine_host = nullptr;         // pinned: pairs re-evaluated by the last screened Run
     int64_t screen_off_M = -1;          // a screened Run over this many rows re-evaluated too many of them: not again
     bool scores_exact = true;           // mv / lag hold fp64 results for every row (false after a screened Run)
+    bool last_screened = false;         // the last Run took the filter-and-refine path
 };
 
 static int use_device(muse_ctx *ctx)
@@ -1165,7 +1166,6 @@ static int score_screened(muse_batch *b, int32_t max_lag, int32_t top_n, double 
     if (rc)
         return rc;
     const int64_t npairs = (M + 1) / 2;
-    const int64_t nb = (M + TOPN_CHUNK - 1) / TOPN_CHUNK;
     if (M > b->scr_cap) {
         (void)hipFree(b->scr_flags);
         (void)hipFree(b->scr_var);
@@ -1179,15 +1179,14 @@ static int score_screened(muse_batch *b, int32_t max_lag, int32_t top_n, double 
         HIP_TRY(hipMalloc(&b->include, (size_t)M));
         b->scr_cap = M;
     }
-    if (nb * top_n > b->scr_keys_cap) {
+    const int64_t nkeys = screen_select_scratch(M, top_n);
+    if (nkeys > b->scr_keys_cap) {
         (void)hipFree(b->scr_keys);
         b->scr_keys = nullptr;
         b->scr_keys_cap = 0;
-        HIP_TRY(hipMalloc(&b->scr_keys, (size_t)(nb * top_n) * sizeof(unsigned long long)));
-        b->scr_keys_cap = nb * top_n;
+        HIP_TRY(hipMalloc(&b->scr_keys, (size_t)nkeys * sizeof(unsigned long long)));
+        b->scr_keys_cap = nkeys;
     }
-    if (!b->scr_cut)
-        HIP_TRY(hipMalloc(&b->scr_cut, sizeof(unsigned long long)));
     if (!b->refine_host)
         HIP_TRY(hipHostMalloc((void **)&b->refine_host, sizeof(int), hipHostMallocDefault));
     if (npairs > b->ovf_cap) {
@@ -1235,8 +1234,7 @@ static int score_screened(muse_batch *b, int32_t max_lag, int32_t top_n, double 
     q.sign_filter = sign_filter;
     q.abs_scores = abs_scores ? 1 : 0;
     q.E = 1.4143 * Es; // score = estimate / (2^-e sigma), 2^-e sigma in (0.7071, 1.4143]
-    HIP_TRY(launch_screen_select(q, top_n, b->selkey, b->scr_keys, b->scr_cut, b->ovf_list, b->ovf_count, b->include,
-                                 ctx->stream));
+    HIP_TRY(launch_screen_select(q, top_n, b->selkey, b->scr_keys, b->ovf_list, b->ovf_count, b->include, ctx->stream));
     // the fp64 kernel re-evaluates the listed pairs (count stays on the device and bounds its loop)
     FusedParams r = base_params(b);
     r.pair_list = b->ovf_list;
@@ -1246,6 +1244,17 @@ static int score_screened(muse_batch *b, int32_t max_lag, int32_t top_n, double 
     *b->refine_host = 0;
     HIP_TRY(hipMemcpyAsync(b->refine_host, b->ovf_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     b->scores_exact = false;
+    return MUSE_OK;
+}
+
+extern "C" int muse_batch_last_run_info(muse_batch *b, int32_t *screened, int64_t *refined_pairs)
+{
+    if (!b)
+        return fail(MUSE_ERR_INVALID, "NULL batch");
+    if (screened)
+        *screened = b->last_screened ? 1 : 0;
+    if (refined_pairs)
+        *refined_pairs = (b->last_screened && b->refine_host) ? (int64_t)*b->refine_host : 0;
     return MUSE_OK;
 }
 
@@ -1322,6 +1331,7 @@ static int run_select(muse_batch *b, const int32_t *group_id, int32_t G_in, int6
     rc = ensure_select_ws(b, M, G, group_id != nullptr, K, on_device);
     if (rc)
         return rc;
+    b->last_screened = screened;
     if (screened) { // fp32 screening pass, then fp64 for the rows that can reach the top-N (needs the selection workspace)
         rc = score_screened(b, max_lag, top_n, threshold, sign_filter, abs_scores);
         if (rc)
@@ -1636,7 +1646,6 @@ extern "C" int muse_batch_free(muse_batch *b)
     (void)hipFree(b->scr_var);
     (void)hipFree(b->include);
     (void)hipFree(b->scr_keys);
-    (void)hipFree(b->scr_cut);
     if (b->refine_host)
         (void)hipHostFree(b->refine_host);
     muse_group *g = b->g;

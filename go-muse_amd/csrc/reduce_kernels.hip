@@ -305,57 +305,6 @@ __global__ __launch_bounds__(256) void topn_keys_kernel(const unsigned long long
     }
 }
 
-// one workgroup: the top_n-th largest of `count` keys (0 when fewer than top_n are non-zero) -> *cut.
-// Destroys `keys`.  top_n rounds over count / 256 keys per thread: microseconds for the usual top_n ~ 20.
-__global__ __launch_bounds__(256) void screen_cut_kernel(unsigned long long *keys, long long count, int top_n,
-                                                         unsigned long long *cut)
-{
-    __shared__ unsigned long long sk[4];
-    __shared__ long long si[4];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    unsigned long long BK = 0ull;
-    for (int r = 0; r < top_n; r++) {
-        unsigned long long bk = 0ull;
-        long long bi = 0x7fffffffffffffffLL;
-        for (long long i = t; i < count; i += 256) { // (device-scope loads: thread 0 clears one key per round)
-            const unsigned long long x = __hip_atomic_load(&keys[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (x > bk) {
-                bk = x;
-                bi = i;
-            }
-        }
-        const unsigned long long wk = wave_max_u64(bk);
-        if (lane == 0)
-            sk[wave] = wk;
-        __syncthreads();
-        BK = sk[0];
-        BK = sk[1] > BK ? sk[1] : BK;
-        BK = sk[2] > BK ? sk[2] : BK;
-        BK = sk[3] > BK ? sk[3] : BK;
-        if (BK == 0ull)
-            break; // uniform: fewer than top_n rows certainly pass
-        long long ci = (bk == BK) ? bi : 0x7fffffffffffffffLL;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const long long u = __shfl_xor(ci, o, 64);
-            ci = u < ci ? u : ci;
-        }
-        if (lane == 0)
-            si[wave] = ci;
-        __syncthreads();
-        long long CI = si[0];
-        CI = si[1] < CI ? si[1] : CI;
-        CI = si[2] < CI ? si[2] : CI;
-        CI = si[3] < CI ? si[3] : CI;
-        if (t == 0)
-            __hip_atomic_store(&keys[CI], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence();
-        __syncthreads();
-    }
-    if (t == 0)
-        *cut = BK;
-}
-
 // one thread per pair of rows: the pair is re-evaluated (listed for the fp64 kernel, both rows marked in `include`)
 // when either row's optimistic key is non-zero and reaches the cut
 __global__ void screen_compact_kernel(ScreenSelect q, const unsigned long long *cut, long long npairs,
@@ -381,16 +330,35 @@ __global__ void screen_compact_kernel(ScreenSelect q, const unsigned long long *
     }
 }
 
+long long screen_select_scratch(long long M, int top_n)
+{
+    const long long nb = (M + TOPN_CHUNK - 1) / TOPN_CHUNK;
+    return nb * top_n + ((nb * top_n + TOPN_CHUNK - 1) / TOPN_CHUNK + 1) * top_n;
+}
+
 hipError_t launch_screen_select(const ScreenSelect &q, int top_n, unsigned long long *selkey, unsigned long long *keys,
-                                unsigned long long *cut, long long *pair_list, int *pair_count, unsigned char *include,
-                                hipStream_t stream)
+                                long long *pair_list, int *pair_count, unsigned char *include, hipStream_t stream)
 {
     const long long nb = (q.M + TOPN_CHUNK - 1) / TOPN_CHUNK;
     long long mb = (q.M + 255) / 256;
     mb = mb > 4096 ? 4096 : (mb < 1 ? 1 : mb);
     hipLaunchKernelGGL(screen_kmin_kernel, dim3((unsigned)mb), dim3(256), 0, stream, q, selkey);
-    hipLaunchKernelGGL(topn_keys_kernel, dim3((unsigned)nb), dim3(256), 0, stream, selkey, q.M, top_n, keys);
-    hipLaunchKernelGGL(screen_cut_kernel, dim3(1), dim3(256), 0, stream, keys, nb * top_n, top_n, cut);
+    // the top_n largest pessimistic keys: per-chunk top-K lists, reduced again until one chunk holds them in
+    // descending order; its entry top_n - 1 is the cut (0 when fewer than top_n rows certainly pass)
+    unsigned long long *src = keys, *dst = keys + nb * top_n;
+    hipLaunchKernelGGL(topn_keys_kernel, dim3((unsigned)nb), dim3(256), 0, stream, selkey, q.M, top_n, src);
+    long long count = nb * top_n;
+    for (;;) {
+        const long long cb = (count + TOPN_CHUNK - 1) / TOPN_CHUNK;
+        hipLaunchKernelGGL(topn_keys_kernel, dim3((unsigned)cb), dim3(256), 0, stream, src, count, top_n, dst);
+        count = cb * top_n;
+        unsigned long long *tmp = src;
+        src = dst;
+        dst = tmp;
+        if (cb == 1)
+            break;
+    }
+    const unsigned long long *cut = src + (top_n - 1);
     const long long npairs = (q.M + 1) / 2;
     long long pb = (npairs + 255) / 256;
     pb = pb > 4096 ? 4096 : (pb < 1 ? 1 : pb);

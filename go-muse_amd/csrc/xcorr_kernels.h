@@ -123,11 +123,11 @@ struct ScreenSelect {
     int abs_scores;
     double E;              // |estimate - exact| <= E (score units)
 };
-// pessimistic keys -> the top_n-th best of them (*cut) -> pairs whose optimistic key reaches it (pair_list, *pair_count,
-// include[row] = 1); keys: ceil(M / TOPN_CHUNK) * top_n entries of scratch
+// pessimistic keys -> the top_n-th best of them (the cut) -> pairs whose optimistic key reaches it (pair_list,
+// *pair_count, include[row] = 1); keys: screen_select_scratch(M, top_n) entries of scratch
+long long screen_select_scratch(long long M, int top_n);
 hipError_t launch_screen_select(const ScreenSelect &q, int top_n, unsigned long long *selkey, unsigned long long *keys,
-                                unsigned long long *cut, long long *pair_list, int *pair_count, unsigned char *include,
-                                hipStream_t stream);
+                                long long *pair_list, int *pair_count, unsigned char *include, hipStream_t stream);
 
 // per-group winners -> rec[G] (+ selection keys selkey[G]: 0 = filtered out)
 hipError_t launch_group_reduce(const SelectParams &sp, const GroupWork &gw, muse_record *rec,

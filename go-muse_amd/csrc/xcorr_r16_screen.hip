@@ -832,9 +832,13 @@ namespace scr {
 
 // forward fp32 FFT; pass-1 factors W_4096^(k t) from four per-thread base powers W^t, W^2t, W^4t, W^8t
 // (every factor is a product of at most four correctly rounded table entries)
-template <bool MULXC>
+struct NoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
+// `mid` runs between the first transpose and the second pass (the pass kernel issues half of its row prefetch there)
+template <bool MULXC, typename F = NoHook>
 __device__ __forceinline__ void fft4096b(f2 (&v)[16], f2 *xbuf, const f2 *tw2s, const f2 w1, const f2 w2, const f2 w4,
-                                         const f2 w8, const f2 (&xq)[16], const int t)
+                                         const f2 w8, const f2 (&xq)[16], const int t, F mid = F())
 {
     dft16f(v);
     {
@@ -856,6 +860,9 @@ __device__ __forceinline__ void fft4096b(f2 (&v)[16], f2 *xbuf, const f2 *tw2s, 
         v[P16(15)] = cmulf(v[P16(15)], cmulf(w8, w7));
     }
     exchange<false>(v, xbuf, t);
+    fence();
+    mid();
+    fence();
     dft16f(v);
     {
         const int lo = t & 15;
@@ -876,20 +883,19 @@ __device__ __forceinline__ void fft4096b(f2 (&v)[16], f2 *xbuf, const f2 *tw2s, 
 
 } // namespace scr
 
-template <int WPC, bool TIMING = false>
+template <int WPC, bool TIMING = false, bool SPLIT = true>
 __global__ __launch_bounds__(SCR_THREADS, WPC) void xcorr_screen_pass_n4096(const FusedParams p)
 {
     using namespace scr;
     __shared__ f2 xbuf[SCR_XBUF];
     __shared__ f2 tw2s[256];
-    __shared__ double red[32]; // [0,16) statistics; [16,24): per wave fp32 maxima (A, B); [24,32): their first indices
+    __shared__ double red[24]; // [0,16) statistics; [16,20): per wave fp32 maxima (A: 4 floats, B: 4 floats)
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     constexpr double invN = 1.0 / 4096.0, invNm1 = 1.0 / 4095.0;
     const float window = (float)p.screen_delta;
     const int max_lag = p.scr_max_lag;
     float *redf = reinterpret_cast<float *>(red + 16);
-    int *redi = reinterpret_cast<int *>(red + 24);
     f2 w1, w2, w4, w8;
     {
         const float2 tw = p.tw2f[t];
@@ -975,41 +981,33 @@ __global__ __launch_bounds__(SCR_THREADS, WPC) void xcorr_screen_pass_n4096(cons
         // ---- the next pair streams in behind the second transform (no other global load until it is consumed)
         fence();
         issue_series(ra, kA, p.rows + nA * p.stride, t);
-        issue_series(rb, kB, p.rows + nB * p.stride, t);
         fence();
-        fft4096b<false>(v, xbuf, tw2s, w1, w2, w4, w8, xq, t);
+        if (!SPLIT) { // (experiment: the whole prefetch in one burst)
+            issue_series(rb, kB, p.rows + nB * p.stride, t);
+            fence();
+            fft4096b<false>(v, xbuf, tw2s, w1, w2, w4, w8, xq, t);
+        } else {
+            const double *rowB = p.rows + nB * p.stride;
+            fft4096b<false>(v, xbuf, tw2s, w1, w2, w4, w8, xq, t, [&]() { issue_series(rb, kB, rowB, t); });
+        }
         clk.template stamp<3>();
-        // ---- fp32 maximum of |cc| per series and its first index (lag index 256 k + t)
-        float ma = -1.f, mb = -1.f;
-        int ia = 0, ib = 0;
+        // ---- fp32 maximum of |cc| per series (which of several equal maxima reports the estimate does not matter:
+        // the selection works from the flags of ALL lags inside the window, never from the fp32 lag)
+        float ma = 0.f, mb = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; k++) {
-            const float xa = fabsf(v[k].x), xb = fabsf(v[k].y);
-            if (xa > ma) { ma = xa; ia = k; }
-            if (xb > mb) { mb = xb; ib = k; }
+            ma = fmaxf(ma, fabsf(v[k].x));
+            mb = fmaxf(mb, fabsf(v[k].y));
         }
-        {
-            const float WA = wave_max_f32_dpp(ma), WB = wave_max_f32_dpp(mb);
-            int ca = (ma == WA) ? 256 * ia + t : 0x7fffffff, cb = (mb == WB) ? 256 * ib + t : 0x7fffffff;
-            ca = wave_min_i_dpp(ca);
-            cb = wave_min_i_dpp(cb);
-            if (lane == 0) {
-                redf[wave] = WA;
-                redf[4 + wave] = WB;
-                redi[wave] = ca;
-                redi[4 + wave] = cb;
-            }
+        ma = wave_max_f32_dpp(ma);
+        mb = wave_max_f32_dpp(mb);
+        if (lane == 0) {
+            redf[wave] = ma;
+            redf[4 + wave] = mb;
         }
         lds_barrier();
-        float MA = redf[0], MB = redf[4];
-        int LA = redi[0], LB = redi[4];
-#pragma unroll
-        for (int w = 1; w < 4; w++) {
-            const float xa = redf[w], xb = redf[4 + w];
-            const int la = redi[w], lb = redi[4 + w];
-            if (xa > MA || (xa == MA && la < LA)) { MA = xa; LA = la; }
-            if (xb > MB || (xb == MB && lb < LB)) { MB = xb; LB = lb; }
-        }
+        const float MA = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
+        const float MB = fmaxf(fmaxf(redf[4], redf[5]), fmaxf(redf[6], redf[7]));
         // ---- what the possible exact argmaxes look like: every lag within the window of the maximum.  Hits are rare
         // (the argmax itself and, at most, a few neighbours): one compare + ballot per element, the classification
         // only where a lane hits.
@@ -1030,11 +1028,11 @@ __global__ __launch_bounds__(SCR_THREADS, WPC) void xcorr_screen_pass_n4096(cons
                         fB |= in | (xb > 0.f ? SCR_POS : 0u) | (xb < 0.f ? SCR_NEG : 0u);
                     // the estimate itself, by the thread that holds the fp32 argmax: the fp32 value with its exact
                     // power-of-two scale; the selection divides by sigma (scr_var)
-                    if (idx == LA && !offA) {
+                    if (fabsf(xa) == MA && !offA) {
                         p.mv[rA] = (double)xa * __longlong_as_double((long long)(1023 + (eA >> 1)) << 52);
                         p.lag[rA] = lg;
                     }
-                    if (idx == LB && !offB) {
+                    if (fabsf(xb) == MB && !offB) {
                         p.mv[rB] = (double)xb * __longlong_as_double((long long)(1023 + (eB >> 1)) << 52);
                         p.lag[rB] = lg;
                     }

@@ -226,6 +226,12 @@ class DeviceBatch:
         B.check(B.load().muse_batch_read_scores(self._h, B.i32ptr(lag), B.dptr(mv)))
         return lag, mv
 
+    def last_run_info(self):
+        """(screened, refined_pairs) of the last run on this batch (muse_batch_last_run_info)"""
+        scr, ref = ctypes.c_int32(0), ctypes.c_int64(0)
+        B.check(B.load().muse_batch_last_run_info(self._h, ctypes.byref(scr), ctypes.byref(ref)))
+        return bool(scr.value), int(ref.value)
+
     def screen_estimates(self, max_lag=10):
         """test hook: (estimates, flags, E) of the fp32 screening pass (include/muse_hip.h)"""
         M = self.dgroup.M

@@ -89,7 +89,7 @@ int muse_ctx_device_info(muse_ctx *ctx, char *name, int32_t name_cap,
  * The parity tests run every variant on the same inputs; the environment
  * variable MUSE_HIP_KERNEL sets the initial value (profiling aid). */
 int muse_ctx_set_kernel(muse_ctx *ctx, int32_t variant);
-/* Filter-and-refine Run (off by default; MUSE_HIP_SCREEN_RUN=1 sets the initial value).  When enabled, an ungrouped
+/* Filter-and-refine Run (on by default; MUSE_HIP_SCREEN_RUN=0 / enable = 0 turns it off).  When enabled, an ungrouped
  * muse_batch_run / muse_batch_run_shard (group_id == NULL) over >= 16384 series of length 4096 under automatic kernel
  * selection screens every series with an fp32 transform (a bound E on its error is derived from the reference's
  * spectrum), re-evaluates in fp64 exactly those rows whose optimistic selection key reaches the top_n-th best
@@ -103,6 +103,9 @@ int muse_ctx_set_screening(muse_ctx *ctx, int32_t enable);
  * re-evaluated and `estimate` holds its fp64 score) and the bound *E (score units) that the selection assumes on
  * |estimate - exact score|.  Any out pointer may be NULL. */
 int muse_batch_screen_estimates(muse_batch *b, int32_t max_lag, double *estimate, uint32_t *flags, double *E);
+/* Which path the last muse_batch_run / muse_batch_run_shard on this batch took: *screened = 1 for filter-and-refine,
+ * *refined_pairs = pairs of series it re-evaluated in fp64.  Any out pointer may be NULL. */
+int muse_batch_last_run_info(muse_batch *b, int32_t *screened, int64_t *refined_pairs);
 /* HIP-event timing of the fused kernel on the stream it is launched on:
  * enable, run, then read (sum of launch durations in ms, launch count). */
 int muse_ctx_kernel_timing(muse_ctx *ctx, int32_t enable);

@@ -915,7 +915,7 @@ def test_screened_run_equals_fp64_run(muse, eng, oracle):
         assert np.array_equal(lag2, lag)
         np.testing.assert_allclose(mv2, mv, rtol=1e-12, atol=0, equal_nan=True)
     finally:
-        eng.set_screening(False)
+        eng.set_screening(True)   # the default
         db.close()
 
 
@@ -973,5 +973,5 @@ def test_screened_run_synthetic_matches_fp64_run(muse, eng):
             np.testing.assert_allclose(got[2], exact, rtol=1e-12, atol=0)
             assert abs(got[3] - exp[3]) <= 1e-12
     finally:
-        eng.set_screening(False)
+        eng.set_screening(True)   # the default
         db.close()

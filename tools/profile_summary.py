@@ -27,7 +27,7 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2"):
             acc[r.get("Kernel_Name", "")][r.get("Counter_Name", "")].append(float(r.get("Counter_Value", 0)))
         print("\n## %s (%s)" % (sub, os.path.relpath(f, out)))
         for k, cs in acc.items():
-            if "xcorr_fused" not in k:
+            if "xcorr_fused" not in k and "xcorr_screen" not in k:
                 continue
             for c, vals in sorted(cs.items()):
                 print("  %-40s %-28s n=%d mean=%.6g" % (k[:40], c, len(vals), sum(vals) / len(vals)))
@@ -43,20 +43,22 @@ def _mean(sub, counter):
     per = defaultdict(list)
     for f in find(sub, "*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
-            if "xcorr_fused" in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter:
-                per[r.get("Kernel_Name", "")].append(float(r.get("Counter_Value", 0)))
+            name = r.get("Kernel_Name", "")
+            if ("xcorr_fused" in name or "xcorr_screen" in name) and r.get("Counter_Name") == counter:
+                per[name].append(float(r.get("Counter_Value", 0)))
     if not per:
-        return None
-    best = max(per.values(), key=lambda v: sum(v) / len(v))
-    return sum(best) / len(best)
+        return None, None
+    name, best = max(per.items(), key=lambda kv: sum(kv[1]) / len(kv[1]))
+    return sum(best) / len(best), name
 
 
-fetch, write = _mean("pmc_fetch", "FETCH_SIZE"), _mean("pmc_write", "WRITE_SIZE")
+(fetch, kname), (write, _) = _mean("pmc_fetch", "FETCH_SIZE"), _mean("pmc_write", "WRITE_SIZE")
 if fetch is not None and write is not None:
     traffic = (2.0 * fetch + write) * 1024.0
     print("\n## HBM traffic per fused launch: 2*FETCH_SIZE + WRITE_SIZE = %.4g B (FETCH_SIZE %.4g KB, WRITE_SIZE %.4g KB)"
           % (traffic, fetch, write))
     json.dump({"rows": int(os.environ.get("PROFILE_ROWS", "1000000")), "length": 4096,
+               "kernel": kname.split("(")[0].replace("void ", "").replace("muse::", "").strip(),
                "hbm_bytes_per_launch": traffic, "fetch_size_kb": fetch, "write_size_kb": write,
                "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE doubled (gfx950)"},
               open(os.path.join(out, "traffic.json"), "w"))
