@@ -170,6 +170,27 @@ def main():
             # fp64) + fp64 re-evaluation of the rows that can reach the top-N; the records are those of the all-fp64 Run
             "run_path": {"filter_and_refine": screened, "pairs_re_evaluated_in_fp64": refined_pairs},
         }
+        if n_gpus == 1 and screened and not use_dist:
+            # the same Run with screening off (every series scored in fp64), reported next to the default path
+            eng.set_screening(False)
+            step()
+            eng.synchronize()
+            eng.kernel_time()
+            eng.kernel_timing(True)
+            reps = max(3, min(args.steps, 10))
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                step()
+            eng.synchronize()
+            dt64 = (time.perf_counter() - t1) / reps
+            eng.kernel_timing(False)
+            k64_ms, k64_cnt = eng.kernel_time()
+            eng.set_screening(True)
+            k64_s = k64_ms / max(k64_cnt, 1) * 1e-3
+            line["all_fp64_run"] = {"value": float(M) / dt64, "unit": "series-pairs/s", "ms_per_step": dt64 * 1e3,
+                                    "kernel": "xcorr_fused_n4096_fast<4>", "kernel_ms_avg": k64_s * 1e3,
+                                    "roofline_frac": bytes_per_launch / k64_s / 1e9 / HBM_PEAK_GBPS if k64_s > 0 else None,
+                                    "note": "muse_ctx_set_screening(ctx, 0): same records, every row through the fp64 kernel"}
         if n_gpus == 1 and args.many_refs > 1 and db.n == 4096 and N == 4096:
             # R references against the same resident group in one pass over the rows
             R = args.many_refs

@@ -225,10 +225,11 @@ int main(int argc, char** argv)
     CK(hipMalloc(&p.mv, M * 8)); CK(hipMalloc(&p.lag, M * 4));
     CK(hipDeviceSynchronize());
     unsigned* fl; CK(hipMalloc(&fl, M * 4)); CK(hipMemset(fl, 0, M * 4)); p.scr_flags = fl; double* sv; CK(hipMalloc(&sv, M * 8)); p.scr_var = sv; p.scr_max_lag = 15; p.screen_delta = 1e-3;
-    run("screen-only WPC=3", screen_only<3, false>, p, 256 * 3, false);
-    run("library screening pass, split prefetch", xcorr_screen_pass_n4096<3, false, true>, p, 256 * 3, false);
-    run("library screening pass, burst prefetch", xcorr_screen_pass_n4096<3, false, false>, p, 256 * 3, false);
-    run("library screening pass, split (stamped)", xcorr_screen_pass_n4096<3, true, true>, p, 256 * 3, true);
-    run("library screening pass, burst (stamped)", xcorr_screen_pass_n4096<3, true, false>, p, 256 * 3, true);
+    const int which = argc > 2 ? atoi(argv[2]) : 31; // bit mask of the configurations to run
+    if (which & 1) run("screen-only WPC=3", screen_only<3, false>, p, 256 * 3, false);
+    if (which & 2) run("library screening pass, split prefetch", xcorr_screen_pass_n4096<3, false, true>, p, 256 * 3, false);
+    if (which & 4) run("library screening pass, burst prefetch", xcorr_screen_pass_n4096<3, false, false>, p, 256 * 3, false);
+    if (which & 8) run("library screening pass, split (stamped)", xcorr_screen_pass_n4096<3, true, true>, p, 256 * 3, true);
+    if (which & 16) run("library screening pass, burst (stamped)", xcorr_screen_pass_n4096<3, true, false>, p, 256 * 3, true);
     return 0;
 }
