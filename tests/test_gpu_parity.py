@@ -975,3 +975,41 @@ def test_screened_run_synthetic_matches_fp64_run(muse, eng):
     finally:
         eng.set_screening(True)   # the default
         db.close()
+
+
+def test_screened_run_fuzz_filters_and_smooth_series(muse, eng, oracle):
+    """Random Run parameters on two kinds of rows: white noise with planted matches (sharp correlation peaks) and
+    random walks (very smooth correlation: many lags inside any window of the maximum, so few rows `certainly` pass
+    the MaxLag filter and the path has to re-evaluate many rows or give the batch back to the fp64 pass)."""
+    rng = np.random.default_rng(31337)
+    N, M = 4096, 16500
+    for kind in ("noise", "walk"):
+        if kind == "noise":
+            ref = rng.standard_normal(N)
+            rows = rng.standard_normal((M, N))
+            for i in rng.integers(0, M, size=M // 4):
+                rows[i] += rng.uniform(-2, 2) * np.roll(ref, int(rng.integers(-N // 2, N // 2)))
+        else:
+            ref = np.cumsum(rng.standard_normal(N))
+            rows = np.cumsum(rng.standard_normal((M, N)), axis=1)
+            for i in rng.integers(0, M, size=M // 4):
+                rows[i] += rng.uniform(-3, 3) * np.roll(ref, int(rng.integers(-40, 40)))
+        dg = muse.DeviceGroup.from_rows(eng, rows)
+        db = muse.DeviceBatch(eng, dg, ref)
+        lag, mv = db.scores()
+        screened_runs = 0
+        for trial in range(14):
+            max_lag = int(rng.choice([0, 2, 15, 64, 1000, 4096]))
+            top_n = int(rng.choice([1, 3, 20, 100, 256]))
+            thr = float(rng.choice([0.0, 0.02, 0.1, 0.5]))
+            sign = int(rng.choice([0, 1, -1]))
+            absf = bool(rng.random() < 0.5)
+            got = db.run(None, 0, max_lag, top_n, thr, sign, absf)
+            screened_runs += int(db.last_run_info()[0])
+            exp = oracle.results(lag, mv, None, 0, absf, max_lag, top_n, thr, sign)
+            key = (kind, trial, max_lag, top_n, thr, sign, absf)
+            assert got[0].tolist() == exp[0].tolist(), key
+            assert got[1].tolist() == exp[1].tolist(), key
+            np.testing.assert_allclose(got[2], exp[2], rtol=1e-12, atol=0, err_msg=str(key))
+        assert screened_runs >= 1, kind          # the path was exercised (it may switch itself off afterwards)
+        db.close()
