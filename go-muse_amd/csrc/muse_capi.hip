@@ -178,6 +178,9 @@ struct muse_batch {
     double *scr_var = nullptr;          // [M] sample variances from the screening pass
     unsigned char *include = nullptr;   // [M] rows re-evaluated in fp64 (the only ones the selection may take)
     unsigned long long *scr_keys = nullptr;
+    unsigned long long *scr_gmay = nullptr, *scr_gkplus = nullptr; // label groups: per-group bounds
+    int *scr_gcert = nullptr;
+    int64_t scr_gcap = 0;
     int64_t scr_cap = 0, scr_keys_cap = 0;
     int *refine_host = nullptr;         // pinned: pairs re-evaluated by the last screened Run
     int64_t screen_off_M = -1;          // a screened Run over this many rows re-evaluated too many of them: not again
@@ -1132,7 +1135,8 @@ static bool screen_eligible(const muse_batch *b, const int32_t *group_id, int32_
 {
     const muse_ctx *ctx = b->ctx;
     const int64_t M = b->g->M;
-    return !already_scored && ctx->screening && ctx->variant == 0 && !group_id && b->n == 4096 && b->N == 4096 &&
+    (void)group_id; // label groups are handled too (per-group bounds: reduce_kernels.hip, screen_g1..g4)
+    return !already_scored && ctx->screening && ctx->variant == 0 && b->n == 4096 && b->N == 4096 &&
            b->xcf && top_n >= 1 && top_n <= TOPN_DEVICE_MAX && M >= SCREEN_MIN_ROWS && M / 2 < 0x7fffffffLL &&
            b->screen_off_M != M;
 }
@@ -1152,7 +1156,7 @@ static double screen_error_scaled(double xmax)
 }
 
 static int score_screened(muse_batch *b, int32_t max_lag, int32_t top_n, double threshold, int32_t sign_filter,
-                          int32_t abs_scores)
+                          int32_t abs_scores, const int *gid_dev = nullptr, int64_t G = 0)
 {
     muse_ctx *ctx = b->ctx;
     int rc = use_device(ctx);
@@ -1179,7 +1183,19 @@ static int score_screened(muse_batch *b, int32_t max_lag, int32_t top_n, double 
         HIP_TRY(hipMalloc(&b->include, (size_t)M));
         b->scr_cap = M;
     }
-    const int64_t nkeys = screen_select_scratch(M, top_n);
+    const int64_t nkeys = screen_select_scratch(gid_dev ? G : M, top_n);
+    if (gid_dev && G > b->scr_gcap) {
+        (void)hipFree(b->scr_gmay);
+        (void)hipFree(b->scr_gkplus);
+        (void)hipFree(b->scr_gcert);
+        b->scr_gmay = b->scr_gkplus = nullptr;
+        b->scr_gcert = nullptr;
+        b->scr_gcap = 0;
+        HIP_TRY(hipMalloc(&b->scr_gmay, (size_t)G * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc(&b->scr_gkplus, (size_t)G * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc(&b->scr_gcert, (size_t)G * sizeof(int)));
+        b->scr_gcap = G;
+    }
     if (nkeys > b->scr_keys_cap) {
         (void)hipFree(b->scr_keys);
         b->scr_keys = nullptr;
@@ -1234,7 +1250,12 @@ static int score_screened(muse_batch *b, int32_t max_lag, int32_t top_n, double 
     q.sign_filter = sign_filter;
     q.abs_scores = abs_scores ? 1 : 0;
     q.E = 1.4143 * Es; // score = estimate / (2^-e sigma), 2^-e sigma in (0.7071, 1.4143]
-    HIP_TRY(launch_screen_select(q, top_n, b->selkey, b->scr_keys, b->ovf_list, b->ovf_count, b->include, ctx->stream));
+    q.group_id = gid_dev;
+    q.G = (int)G;
+    // (the group scratch borrows the final reduction's arrays: that reduction re-initialises them afterwards)
+    const ScreenGroupWork sgw{b->gw.first, b->gw.key, b->scr_gmay, b->scr_gkplus, b->scr_gcert};
+    HIP_TRY(launch_screen_select(q, top_n, b->selkey, b->scr_keys, sgw, b->ovf_list, b->ovf_count, b->include,
+                                 ctx->stream));
     // the fp64 kernel re-evaluates the listed pairs (count stays on the device and bounds its loop)
     FusedParams r = base_params(b);
     r.pair_list = b->ovf_list;
@@ -1331,12 +1352,6 @@ static int run_select(muse_batch *b, const int32_t *group_id, int32_t G_in, int6
     rc = ensure_select_ws(b, M, G, group_id != nullptr, K, on_device);
     if (rc)
         return rc;
-    b->last_screened = screened;
-    if (screened) { // fp32 screening pass, then fp64 for the rows that can reach the top-N (needs the selection workspace)
-        rc = score_screened(b, max_lag, top_n, threshold, sign_filter, abs_scores);
-        if (rc)
-            return rc;
-    }
     if (group_id) {
         const bool same = b->gid_valid && (int64_t)b->gid_host.size() == M &&
                           memcmp(b->gid_host.data(), group_id, (size_t)M * sizeof(int32_t)) == 0;
@@ -1346,6 +1361,12 @@ static int run_select(muse_batch *b, const int32_t *group_id, int32_t G_in, int6
                                    ctx->stream));
             b->gid_valid = true;
         }
+    }
+    b->last_screened = screened;
+    if (screened) { // fp32 screening pass, then fp64 for the rows that can reach the top-N (needs the selection workspace)
+        rc = score_screened(b, max_lag, top_n, threshold, sign_filter, abs_scores, group_id ? b->gid_dev : nullptr, G);
+        if (rc)
+            return rc;
     }
     SelectParams sp{};
     sp.mv = b->mv;
@@ -1388,6 +1409,8 @@ static int run_select(muse_batch *b, const int32_t *group_id, int32_t G_in, int6
         for (int64_t g = 0; g < G; g++)
             if (key[(size_t)g] != 0ull)
                 cands.push_back(rec[(size_t)g]);
+        if (screened && (int64_t)*b->refine_host * 4 > (M + 1) / 2)
+            b->screen_off_M = M;
     }
     if (!group_id) // ungrouped: global order of the groups is the global series index
         for (auto &r : cands)
@@ -1646,6 +1669,9 @@ extern "C" int muse_batch_free(muse_batch *b)
     (void)hipFree(b->scr_var);
     (void)hipFree(b->include);
     (void)hipFree(b->scr_keys);
+    (void)hipFree(b->scr_gmay);
+    (void)hipFree(b->scr_gkplus);
+    (void)hipFree(b->scr_gcert);
     if (b->refine_host)
         (void)hipHostFree(b->refine_host);
     muse_group *g = b->g;

@@ -52,6 +52,8 @@ __global__ void group_key_kernel(SelectParams sp, GroupWork gw)
         if (g < 0 || g >= sp.G)
             continue;
         atomicMin(&gw.first[g], i);
+        if (sp.include && !sp.include[i])
+            continue; // filter-and-refine Run: this row cannot be the group's record (its score is an estimate)
         const double v = clamp_score(sp.mv[i], sp.abs_scores);
         if (v == v)
             atomicMax(&gw.key[g], abs_bits(v));
@@ -64,6 +66,8 @@ __global__ void group_win_kernel(SelectParams sp, GroupWork gw)
          i += (long long)gridDim.x * blockDim.x) {
         const int g = sp.group_id[i];
         if (g < 0 || g >= sp.G)
+            continue;
+        if (sp.include && !sp.include[i])
             continue;
         const double v = clamp_score(sp.mv[i], sp.abs_scores);
         if (v == v && abs_bits(v) == gw.key[g])
@@ -211,38 +215,51 @@ __global__ __launch_bounds__(256) void topn_kernel(const muse_record *__restrict
 // Selection keys of one row from the screening pass's estimate `s` (|s - exact| <= E at every possible argmax) and
 // its SCR_* flags: kmin <= exact key <= kplus, where the exact key is what group_final_kernel computes from the
 // fp64 result (abs_bits(clamped |score|) + 1 if passed() else 0).
-__device__ __forceinline__ void screen_keys(double sv, double var, unsigned f, const ScreenSelect &q,
-                                            unsigned long long &kmin, unsigned long long &kplus)
+// what the screening pass knows about one row
+struct RowBounds {
+    bool nan;                 // the exact score is NaN
+    double lo, hi;            // clamped |score| bounds: lo <= exact <= hi
+    bool pass_may, pass_must; // Results.passed apart from the Threshold test: may be true / is certainly true
+};
+__device__ __forceinline__ RowBounds row_bounds(double sv, double var, unsigned f, const ScreenSelect &q)
 {
-    const double s = (f & (SCR_NAN | SCR_REFINE)) || !(var > 0.0) ? 0.0 : sv * (1.0 / sqrt(var));
-    if (f & SCR_NAN) { // exact score NaN: passed() is false whatever the filters
-        kmin = kplus = 0ull;
-        return;
+    RowBounds r;
+    r.nan = (f & SCR_NAN) != 0u;
+    if (r.nan || (f & SCR_REFINE)) { // no estimate: may be anything (NaN rows are never selected)
+        r.lo = 0.0;
+        r.hi = 1.0;
+        r.pass_may = !r.nan;
+        r.pass_must = false;
+        return r;
     }
-    if (f & SCR_REFINE) { // no estimate: may be anything
-        kmin = 0ull;
-        kplus = abs_bits(1.0) + 1ull;
-        return;
-    }
+    const double s = var > 0.0 ? sv * (1.0 / sqrt(var)) : 0.0;
     const double a = fabs(s);
     double lo = a - q.E, hi = a + q.E;
-    lo = lo < 0.0 ? 0.0 : (lo > 1.0 ? 1.0 : lo);
-    hi = hi > 1.0 ? 1.0 : hi;
+    r.lo = lo < 0.0 ? 0.0 : (lo > 1.0 ? 1.0 : lo);
+    r.hi = hi > 1.0 ? 1.0 : hi;
     const bool lag_may = (f & SCR_IN) != 0u, lag_must = lag_may && !(f & SCR_OUT);
     bool sign_may = true, sign_must = true;
     if (q.sign_filter != 0 && q.abs_scores) { // Batch.Run filters the sign of |score| (muse_batch.go:74-77): > 0 unless the score is 0
         sign_may = q.sign_filter > 0;
-        sign_must = q.sign_filter > 0; // (with lo > 0, required below)
+        sign_must = q.sign_filter > 0 && r.lo > 0.0;
     } else if (q.sign_filter != 0) {
         const unsigned want = q.sign_filter > 0 ? SCR_POS : SCR_NEG, other = q.sign_filter > 0 ? SCR_NEG : SCR_POS;
         const bool small = a <= 4.0 * q.E; // the exact value at the exact argmax may be zero or of either sign
         sign_may = (f & want) != 0u || small;
         sign_must = (f & want) != 0u && !(f & other) && !small;
     }
-    const bool may = lag_may && sign_may && hi >= q.threshold;
-    const bool must = lag_must && sign_must && lo >= q.threshold && lo > 0.0;
-    kplus = may ? abs_bits(hi) + 1ull : 0ull;
-    kmin = must ? abs_bits(lo) + 1ull : 0ull;
+    r.pass_may = lag_may && sign_may;
+    r.pass_must = lag_must && sign_must;
+    return r;
+}
+__device__ __forceinline__ void screen_keys(double sv, double var, unsigned f, const ScreenSelect &q,
+                                            unsigned long long &kmin, unsigned long long &kplus)
+{
+    const RowBounds r = row_bounds(sv, var, f, q);
+    const bool may = r.pass_may && r.hi >= q.threshold;
+    const bool must = r.pass_must && r.lo >= q.threshold && r.lo > 0.0;
+    kplus = may ? abs_bits(r.hi) + 1ull : 0ull;
+    kmin = must ? abs_bits(r.lo) + 1ull : 0ull;
 }
 
 // pessimistic key of every row -> selkey
@@ -330,23 +347,124 @@ __global__ void screen_compact_kernel(ScreenSelect q, const unsigned long long *
     }
 }
 
-long long screen_select_scratch(long long M, int top_n)
+// ---- label groups (Batch.Run(groupByLabels)): the record of a group is its member with the largest clamped |score|
+// (first index among equals; a NaN first member is never replaced), and the filters apply to that record.
+//   G1: first[g] = lowest member index, glo[g] = max over members of lo (the group's score is at least that)
+//   G2: members with hi >= glo[g] are the only possible winners: the group certainly passes the filters iff all of them
+//       certainly do (gcert), and may pass with a score up to the largest hi among those that may (gmay)
+//   G3: pessimistic / optimistic key per group; the cut is the top_n-th largest pessimistic key
+//   G4: the possible winners of every group whose optimistic key reaches the cut are re-evaluated
+__global__ void screen_g1_kernel(ScreenSelect q, long long *first, unsigned long long *glo)
 {
-    const long long nb = (M + TOPN_CHUNK - 1) / TOPN_CHUNK;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < q.M; i += (long long)gridDim.x * blockDim.x) {
+        const int g = q.group_id[i];
+        if (g < 0 || g >= q.G)
+            continue;
+        atomicMin(&first[g], i);
+        const RowBounds r = row_bounds(q.mv[i], q.var[i], q.flags[i], q);
+        if (!r.nan)
+            atomicMax(&glo[g], abs_bits(r.lo));
+    }
+}
+__global__ void screen_g2_kernel(ScreenSelect q, const unsigned long long *glo, int *gcert, unsigned long long *gmay)
+{
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < q.M; i += (long long)gridDim.x * blockDim.x) {
+        const int g = q.group_id[i];
+        if (g < 0 || g >= q.G)
+            continue;
+        const RowBounds r = row_bounds(q.mv[i], q.var[i], q.flags[i], q);
+        if (r.nan || abs_bits(r.hi) < glo[g])
+            continue; // cannot be the group's record
+        if (!r.pass_must)
+            gcert[g] = 0; // (benign race: every writer stores 0)
+        if (r.pass_may && r.hi >= q.threshold)
+            atomicMax(&gmay[g], abs_bits(r.hi) + 1ull);
+    }
+}
+__global__ void screen_g3_kernel(ScreenSelect q, const long long *first, const unsigned long long *glo, const int *gcert,
+                                 const unsigned long long *gmay, unsigned long long *gkmin, unsigned long long *gkplus)
+{
+    for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < q.G; g += gridDim.x * blockDim.x) {
+        const long long f = first[g];
+        unsigned long long kmin = 0ull, kplus = 0ull;
+        if (f != IDX_NONE && !(q.flags[f] & SCR_NAN)) { // (empty group / NaN first member: never selected)
+            const double lo = __longlong_as_double((long long)glo[g]);
+            kplus = gmay[g];
+            if (gcert[g] && lo >= q.threshold && lo > 0.0)
+                kmin = glo[g] + 1ull;
+        }
+        gkmin[g] = kmin;
+        gkplus[g] = kplus;
+    }
+}
+__global__ void screen_g4_kernel(ScreenSelect q, const unsigned long long *glo, const unsigned long long *gkplus,
+                                 const unsigned long long *cut, long long npairs, long long *pair_list, int *pair_count,
+                                 unsigned char *include)
+{
+    const unsigned long long c = *cut;
+    for (long long pr = blockIdx.x * (long long)blockDim.x + threadIdx.x; pr < npairs; pr += (long long)gridDim.x * blockDim.x) {
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const long long i = 2 * pr + k;
+            if (i >= q.M)
+                continue;
+            const int g = q.group_id[i];
+            if (g < 0 || g >= q.G)
+                continue;
+            const unsigned long long kp = gkplus[g];
+            if (kp == 0ull || kp < c)
+                continue;
+            const RowBounds r = row_bounds(q.mv[i], q.var[i], q.flags[i], q);
+            if (r.nan || abs_bits(r.hi) < glo[g])
+                continue;
+            include[i] = 1;
+            any = true;
+        }
+        if (any) {
+            const int slot = atomicAdd(pair_count, 1);
+            pair_list[slot] = pr;
+        }
+    }
+}
+__global__ void screen_ginit_kernel(int G, long long *first, unsigned long long *glo, int *gcert, unsigned long long *gmay)
+{
+    for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < G; g += gridDim.x * blockDim.x) {
+        first[g] = IDX_NONE;
+        glo[g] = 0ull;
+        gcert[g] = 1;
+        gmay[g] = 0ull;
+    }
+}
+
+long long screen_select_scratch(long long G, int top_n) // G = number of selection units (rows, or label groups)
+{
+    const long long nb = (G + TOPN_CHUNK - 1) / TOPN_CHUNK;
     return nb * top_n + ((nb * top_n + TOPN_CHUNK - 1) / TOPN_CHUNK + 1) * top_n;
 }
 
 hipError_t launch_screen_select(const ScreenSelect &q, int top_n, unsigned long long *selkey, unsigned long long *keys,
-                                long long *pair_list, int *pair_count, unsigned char *include, hipStream_t stream)
+                                const ScreenGroupWork &gw, long long *pair_list, int *pair_count, unsigned char *include,
+                                hipStream_t stream)
 {
-    const long long nb = (q.M + TOPN_CHUNK - 1) / TOPN_CHUNK;
+    const long long units = q.group_id ? (long long)q.G : q.M;
+    const long long nb = (units + TOPN_CHUNK - 1) / TOPN_CHUNK;
     long long mb = (q.M + 255) / 256;
     mb = mb > 4096 ? 4096 : (mb < 1 ? 1 : mb);
-    hipLaunchKernelGGL(screen_kmin_kernel, dim3((unsigned)mb), dim3(256), 0, stream, q, selkey);
+    const int gb = (int)((units + 255) / 256 < 2048 ? (units + 255) / 256 : 2048);
+    if (q.group_id) {
+        hipLaunchKernelGGL(screen_ginit_kernel, dim3(gb), dim3(256), 0, stream, q.G, gw.first, gw.glo, gw.gcert, gw.gmay);
+        hipLaunchKernelGGL(screen_g1_kernel, dim3((unsigned)mb), dim3(256), 0, stream, q, gw.first, gw.glo);
+        hipLaunchKernelGGL(screen_g2_kernel, dim3((unsigned)mb), dim3(256), 0, stream, q, gw.glo, gw.gcert, gw.gmay);
+        hipLaunchKernelGGL(screen_g3_kernel, dim3(gb), dim3(256), 0, stream, q, gw.first, gw.glo, gw.gcert, gw.gmay, selkey,
+                           gw.gkplus);
+    } else {
+        hipLaunchKernelGGL(screen_kmin_kernel, dim3((unsigned)mb), dim3(256), 0, stream, q, selkey);
+    }
     // the top_n largest pessimistic keys: per-chunk top-K lists, reduced again until one chunk holds them in
     // descending order; its entry top_n - 1 is the cut (0 when fewer than top_n rows certainly pass)
     unsigned long long *src = keys, *dst = keys + nb * top_n;
-    hipLaunchKernelGGL(topn_keys_kernel, dim3((unsigned)nb), dim3(256), 0, stream, selkey, q.M, top_n, src);
+    hipLaunchKernelGGL(topn_keys_kernel, dim3((unsigned)nb), dim3(256), 0, stream, selkey, units, top_n, src);
     long long count = nb * top_n;
     for (;;) {
         const long long cb = (count + TOPN_CHUNK - 1) / TOPN_CHUNK;
@@ -362,8 +480,12 @@ hipError_t launch_screen_select(const ScreenSelect &q, int top_n, unsigned long 
     const long long npairs = (q.M + 1) / 2;
     long long pb = (npairs + 255) / 256;
     pb = pb > 4096 ? 4096 : (pb < 1 ? 1 : pb);
-    hipLaunchKernelGGL(screen_compact_kernel, dim3((unsigned)pb), dim3(256), 0, stream, q, cut, npairs, pair_list,
-                       pair_count, include);
+    if (q.group_id)
+        hipLaunchKernelGGL(screen_g4_kernel, dim3((unsigned)pb), dim3(256), 0, stream, q, gw.glo, gw.gkplus, cut, npairs,
+                           pair_list, pair_count, include);
+    else
+        hipLaunchKernelGGL(screen_compact_kernel, dim3((unsigned)pb), dim3(256), 0, stream, q, cut, npairs, pair_list,
+                           pair_count, include);
     return hipGetLastError();
 }
 

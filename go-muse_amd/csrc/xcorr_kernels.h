@@ -122,12 +122,21 @@ struct ScreenSelect {
     int sign_filter;
     int abs_scores;
     double E;              // |estimate - exact| <= E (score units)
+    const int *group_id;   // label groups (device), or nullptr: every series its own group
+    int G;
+};
+// per-group scratch of the grouped filter-and-refine selection (G entries each)
+struct ScreenGroupWork {
+    long long *first;
+    unsigned long long *glo, *gmay, *gkplus;
+    int *gcert;
 };
 // pessimistic keys -> the top_n-th best of them (the cut) -> pairs whose optimistic key reaches it (pair_list,
 // *pair_count, include[row] = 1); keys: screen_select_scratch(M, top_n) entries of scratch
-long long screen_select_scratch(long long M, int top_n);
+long long screen_select_scratch(long long G, int top_n);
 hipError_t launch_screen_select(const ScreenSelect &q, int top_n, unsigned long long *selkey, unsigned long long *keys,
-                                long long *pair_list, int *pair_count, unsigned char *include, hipStream_t stream);
+                                const ScreenGroupWork &gw, long long *pair_list, int *pair_count, unsigned char *include,
+                                hipStream_t stream);
 
 // per-group winners -> rec[G] (+ selection keys selkey[G]: 0 = filtered out)
 hipError_t launch_group_reduce(const SelectParams &sp, const GroupWork &gw, muse_record *rec,

@@ -1013,3 +1013,45 @@ def test_screened_run_fuzz_filters_and_smooth_series(muse, eng, oracle):
             np.testing.assert_allclose(got[2], exp[2], rtol=1e-12, atol=0, err_msg=str(key))
         assert screened_runs >= 1, kind          # the path was exercised (it may switch itself off afterwards)
         db.close()
+
+
+def test_screened_run_with_label_groups(muse, eng, oracle):
+    """Grouped Runs (Batch.Run(groupByLabels)) on the filter-and-refine path: per-group bounds decide which members
+    are re-evaluated.  Group maps from a handful of large groups to thousands of small ones, empty groups, groups
+    whose first member is NaN, and every filter; expected records: the oracle's Results over the fp64 scores."""
+    rng = np.random.default_rng(4242)
+    N, M = 4096, 16600
+    ref = rng.standard_normal(N)
+    rows = rng.standard_normal((M, N))
+    for i in rng.integers(0, M, size=M // 3):
+        rows[i] += rng.uniform(-3, 3) * np.roll(ref, int(rng.integers(-N // 2, N // 2)))
+    rows[5] = 2.0                    # sigma == 0
+    rows[17, 100] = np.nan
+    rows[400] = np.inf
+    rows[900] *= 1e70                # fp32 not trusted
+    dg = muse.DeviceGroup.from_rows(eng, rows)
+    db = muse.DeviceBatch(eng, dg, ref)
+    lag, mv = db.scores()
+    screened_runs = 0
+    for trial in range(24):
+        G = int(rng.choice([3, 40, 700, 5000, 20000]))
+        gid = rng.integers(0, G, size=M).astype(np.int32)
+        if trial % 3 == 0:
+            gid[17] = gid[16]        # a NaN member that is not necessarily first
+            gid[:50] = np.arange(50) % min(G, 50)
+        if trial % 4 == 1:
+            gid = np.sort(gid)       # contiguous groups (the layout a Go Group produces)
+        max_lag = int(rng.choice([0, 15, 200, 4096]))
+        top_n = int(rng.choice([1, 5, 20, 100, 256]))
+        thr = float(rng.choice([0.0, 0.05, 0.3]))
+        sign = int(rng.choice([0, 1, -1]))
+        absf = bool(rng.random() < 0.5)
+        got = db.run(gid, G, max_lag, top_n, thr, sign, absf)
+        screened_runs += int(db.last_run_info()[0])
+        exp = oracle.results(lag, mv, gid, G, absf, max_lag, top_n, thr, sign)
+        key = (trial, G, max_lag, top_n, thr, sign, absf)
+        assert got[0].tolist() == exp[0].tolist(), key
+        assert got[1].tolist() == exp[1].tolist(), key
+        np.testing.assert_allclose(got[2], exp[2], rtol=1e-12, atol=0, err_msg=str(key))
+    assert screened_runs >= 1
+    db.close()
