@@ -1136,7 +1136,7 @@ static bool screen_eligible(const muse_batch *b, const int32_t *group_id, int32_
     const muse_ctx *ctx = b->ctx;
     const int64_t M = b->g->M;
     (void)group_id; // label groups are handled too (per-group bounds: reduce_kernels.hip, screen_g1..g4)
-    return !already_scored && ctx->screening && ctx->variant == 0 && b->n == 4096 && b->N == 4096 &&
+    return !already_scored && ctx->screening && ctx->variant == 0 && b->n == 4096 && b->N > 2048 &&
            b->xcf && top_n >= 1 && top_n <= TOPN_DEVICE_MAX && M >= SCREEN_MIN_ROWS && M / 2 < 0x7fffffffLL &&
            b->screen_off_M != M;
 }
@@ -1151,8 +1151,11 @@ static bool screen_eligible(const muse_batch *b, const int32_t *group_id, int32_
 // ||delta c||_2 <= 2u (90.5 + 8 * 1.4143 * 64) and |delta cc| <= ||delta c||_2 ||xs||_2, ||xs||_2 = 1 / sqrt(N-1).
 static double screen_error_scaled(double xmax)
 {
+    // N < 4096 (zero-padded): the rounded mean is a constant offset of the samples only, not of the pad; it reaches a
+    // lag through the correlation of the sample indicator with the reference, |c1| <= sqrt(N) ||xs||_2 ~ 1, times
+    // 2^-24 * 8 sigma * 1.4143 / sigma < 1e-6 (for N == n that correlation is the reference's sum: 0).
     const double u = 5.9604644775390625e-08; // 2^-24
-    return 256.0 * u * 128.0 * xmax + 2e-6;
+    return 256.0 * u * 128.0 * xmax + 3e-6;
 }
 
 static int score_screened(muse_batch *b, int32_t max_lag, int32_t top_n, double threshold, int32_t sign_filter,
@@ -1284,8 +1287,8 @@ extern "C" int muse_batch_screen_estimates(muse_batch *b, int32_t max_lag, doubl
 {
     if (!b)
         return fail(MUSE_ERR_INVALID, "NULL batch");
-    if (b->n != 4096 || b->N != 4096 || !b->xcf)
-        return fail(MUSE_ERR_UNSUPPORTED, "the screening pass is built for series of length 4096");
+    if (b->n != 4096 || !b->xcf)
+        return fail(MUSE_ERR_UNSUPPORTED, "the screening pass is built for series of length 2049 .. 4096");
     muse_ctx *ctx = b->ctx;
     int rc = use_device(ctx);
     if (rc)

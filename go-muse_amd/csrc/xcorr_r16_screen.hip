@@ -517,6 +517,23 @@ __device__ __forceinline__ void issue_series(double (&r)[16], double &k0, const 
     }
 }
 
+// N < 4096 (leading zero pad of 4096 - N < 2048 samples): element t + 256 i of the padded series is sample
+// t + 256 i - pad; a pad position loads sample 0 instead (clamped index), i.e. the shift point x[0], so its
+// d = x - x[0] is exactly 0 without a mask
+__device__ __forceinline__ void issue_series_padded(double (&r)[16], double &k0, const double *row, const int t, const int pad)
+{
+    const gptr<double> rp = scalar_ptr(row);
+    k0 = rp[0];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        int j = t + 256 * i - pad;
+        if (i < 8) // elements 2048.. are always samples (pad < 2048)
+            j = j < 0 ? 0 : j;
+        const unsigned ju = (unsigned)j & 4095u; // unsigned 12-bit index: saddr + 32-bit voffset, no sign extension per load
+        r[i] = __builtin_nontemporal_load(rp + ju);
+    }
+}
+
 // arrived series -> provisional fp32 copy + this thread's shifted fp64 partial sums
 __device__ __forceinline__ void reduce_series(const double (&r)[16], const double k0, float (&o)[16], double &s1, double &s2)
 {
@@ -883,7 +900,7 @@ __device__ __forceinline__ void fft4096b(f2 (&v)[16], f2 *xbuf, const f2 *tw2s, 
 
 } // namespace scr
 
-template <int WPC, bool TIMING = false, bool SPLIT = true>
+template <int WPC, bool TIMING = false, bool SPLIT = true, bool PADDED = false>
 __global__ __launch_bounds__(SCR_THREADS, WPC) void xcorr_screen_pass_n4096(const FusedParams p)
 {
     using namespace scr;
@@ -892,7 +909,8 @@ __global__ __launch_bounds__(SCR_THREADS, WPC) void xcorr_screen_pass_n4096(cons
     __shared__ double red[24]; // [0,16) statistics; [16,20): per wave fp32 maxima (A: 4 floats, B: 4 floats)
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    constexpr double invN = 1.0 / 4096.0, invNm1 = 1.0 / 4095.0;
+    const int pad = PADDED ? 4096 - p.N : 0; // PADDED: 2048 < N < 4096, leading zeros (xcorr.go:176-181)
+    const double invN = PADDED ? 1.0 / (double)p.N : 1.0 / 4096.0, invNm1 = PADDED ? 1.0 / (double)(p.N - 1) : 1.0 / 4095.0;
     const float window = (float)p.screen_delta;
     const int max_lag = p.scr_max_lag;
     float *redf = reinterpret_cast<float *>(red + 16);
@@ -911,8 +929,14 @@ __global__ __launch_bounds__(SCR_THREADS, WPC) void xcorr_screen_pass_n4096(cons
     clk.start();
     long long pair = blockIdx.x; // the launcher never starts more workgroups than pairs
     double ra[16], rb[16], kA, kB;
-    issue_series(ra, kA, p.rows + 2 * pair * p.stride, t);
-    issue_series(rb, kB, p.rows + (2 * pair + 1 < p.M ? 2 * pair + 1 : 2 * pair) * p.stride, t);
+    auto issue = [&](double (&r)[16], double &k0, const double *row) {
+        if (PADDED)
+            issue_series_padded(r, k0, row, t, pad);
+        else
+            issue_series(r, k0, row, t);
+    };
+    issue(ra, kA, p.rows + 2 * pair * p.stride);
+    issue(rb, kB, p.rows + (2 * pair + 1 < p.M ? 2 * pair + 1 : 2 * pair) * p.stride);
     for (; pair < p.npairs; pair += gridDim.x) {
         const long long rA = 2 * pair, rB = rA + 1;
         const bool hasB = rB < p.M;
@@ -966,8 +990,11 @@ __global__ __launch_bounds__(SCR_THREADS, WPC) void xcorr_screen_pass_n4096(cons
         const float mAf = offA ? 0.f : (float)mA, mBf = offB ? 0.f : (float)mB;
         f2 v[16];
 #pragma unroll
-        for (int i = 0; i < 16; i++)
+        for (int i = 0; i < 16; i++) {
             v[i] = mk2((na[i] - mAf) * sclA, (nb[i] - mBf) * sclB);
+            if (PADDED && i < 8 && t + 256 * i < pad) // the pad stays zero: only samples are centred
+                v[i] = mk2(0.f, 0.f);
+        }
         if (offA || offB) { // block-uniform, rare: such a series contributes exact zeros (its samples may be NaN / Inf)
 #pragma unroll
             for (int i = 0; i < 16; i++) {
@@ -980,15 +1007,15 @@ __global__ __launch_bounds__(SCR_THREADS, WPC) void xcorr_screen_pass_n4096(cons
         clk.template stamp<2>();
         // ---- the next pair streams in behind the second transform (no other global load until it is consumed)
         fence();
-        issue_series(ra, kA, p.rows + nA * p.stride, t);
+        issue(ra, kA, p.rows + nA * p.stride);
         fence();
         if (!SPLIT) { // (experiment: the whole prefetch in one burst)
-            issue_series(rb, kB, p.rows + nB * p.stride, t);
+            issue(rb, kB, p.rows + nB * p.stride);
             fence();
             fft4096b<false>(v, xbuf, tw2s, w1, w2, w4, w8, xq, t);
         } else {
             const double *rowB = p.rows + nB * p.stride;
-            fft4096b<false>(v, xbuf, tw2s, w1, w2, w4, w8, xq, t, [&]() { issue_series(rb, kB, rowB, t); });
+            fft4096b<false>(v, xbuf, tw2s, w1, w2, w4, w8, xq, t, [&]() { issue(rb, kB, rowB); });
         }
         clk.template stamp<3>();
         // ---- fp32 maximum of |cc| per series (which of several equal maxima reports the estimate does not matter:
@@ -1081,13 +1108,16 @@ __global__ __launch_bounds__(SCR_THREADS, WPC) void xcorr_screen_pass_n4096(cons
 
 hipError_t launch_screen_pass(const FusedParams &p, int num_cus, hipStream_t stream)
 {
-    if (p.N != 4096 || p.n != 4096 || !p.scr_flags || !p.scr_var || !p.xcf)
+    if (p.n != 4096 || p.N <= 2048 || p.N > 4096 || !p.scr_flags || !p.scr_var || !p.xcf)
         return hipErrorInvalidValue;
     long long grid = p.npairs;
     const long long cap = (long long)num_cus * 3;
     if (grid > cap)
         grid = cap;
-    hipLaunchKernelGGL((xcorr_screen_pass_n4096<3, false>), dim3((unsigned)grid), dim3(SCR_THREADS), 0, stream, p);
+    if (p.N < 4096)
+        hipLaunchKernelGGL((xcorr_screen_pass_n4096<3, false, true, true>), dim3((unsigned)grid), dim3(SCR_THREADS), 0, stream, p);
+    else
+        hipLaunchKernelGGL((xcorr_screen_pass_n4096<3, false, true, false>), dim3((unsigned)grid), dim3(SCR_THREADS), 0, stream, p);
     return hipGetLastError();
 }
 

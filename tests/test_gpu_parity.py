@@ -862,7 +862,7 @@ def test_grouped_run_sharded_on_group_boundaries(muse, eng, oracle):
 # ------------------------------------------------ filter-and-refine Run (fp32 screening pass + fp64 for the rows that matter)
 def _screen_cases(rng, N):
     ref = np.zeros(N)
-    ref[900:1300] = 1.0
+    ref[N // 5:N // 3] = 1.0
     ref += 0.1 * rng.standard_normal(N)
     M = 17000
     rows = rng.standard_normal((M, N))
@@ -888,12 +888,13 @@ def _screen_cases(rng, N):
     return ref, rows
 
 
-def test_screened_run_equals_fp64_run(muse, eng, oracle):
+@pytest.mark.parametrize("N", [4096, 3000])
+def test_screened_run_equals_fp64_run(muse, eng, oracle, N):
     """The filter-and-refine Run (muse_ctx_set_screening) returns the records of the all-fp64 Run: adversarial rows
     (near ties at the cut, periodic series, NaN / Inf / sigma == 0, sigmas outside the fp32 range, a far-outlier first
-    sample) under every filter combination; the expected records are the oracle's Results over the fp64 scores."""
+    sample) under every filter combination, for N == n and for zero-padded series (N = 3000); the expected records are
+    the oracle's Results over the fp64 scores."""
     rng = np.random.default_rng(2024)
-    N = 4096
     ref, rows = _screen_cases(rng, N)
     dg = muse.DeviceGroup.from_rows(eng, rows)
     db = muse.DeviceBatch(eng, dg, ref)
@@ -909,7 +910,9 @@ def test_screened_run_equals_fp64_run(muse, eng, oracle):
                 key = (max_lag, top_n, thr, sign, absf)
                 assert got[0].tolist() == exp[0].tolist(), key
                 assert got[1].tolist() == exp[1].tolist(), key
-                np.testing.assert_allclose(got[2], exp[2], rtol=1e-12, atol=0, err_msg=str(key))
+                # (N < n: the all-scores kernel corrects for the mean after the transform, the re-evaluating kernel
+                # centres before it: the two fp64 results differ by ~1e-11 relative)
+                np.testing.assert_allclose(got[2], exp[2], rtol=1e-12 if N == 4096 else 1e-9, atol=0, err_msg=str(key))
         # the all-scores API after a screened Run still returns fp64 results for every row
         lag2, mv2 = db.read_scores()
         assert np.array_equal(lag2, lag)
@@ -919,11 +922,11 @@ def test_screened_run_equals_fp64_run(muse, eng, oracle):
         db.close()
 
 
-def test_screening_estimates_stay_inside_the_bound(muse, eng, oracle):
+@pytest.mark.parametrize("N", [4096, 2500])
+def test_screening_estimates_stay_inside_the_bound(muse, eng, oracle, N):
     """|fp32 estimate - fp64 score| <= E for every series the pass did not hand to the fp64 kernel, with E the bound
     the selection assumes; the flags cover the exact lag (inside / outside MaxLag) and the exact sign."""
     rng = np.random.default_rng(7)
-    N = 4096
     ref, rows = _screen_cases(rng, N)
     dg = muse.DeviceGroup.from_rows(eng, rows)
     db = muse.DeviceBatch(eng, dg, ref)
