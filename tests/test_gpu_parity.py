@@ -1058,3 +1058,40 @@ def test_screened_run_with_label_groups(muse, eng, oracle):
         np.testing.assert_allclose(got[2], exp[2], rtol=1e-12, atol=0, err_msg=str(key))
     assert screened_runs >= 1
     db.close()
+
+
+def test_screened_run_degenerate_inputs(muse, eng, oracle):
+    """Inputs on which the screening pass can certify almost nothing: every row constant (sigma == 0: score 0 at lag
+    0), every row NaN, an odd row count, a Threshold above 1, a negative MaxLag, one label group for all rows, every
+    row its own copy of the reference (all scores tie at 1).  The records must still be those of the fp64 Run."""
+    rng = np.random.default_rng(99)
+    N, M = 4096, 16385
+    ref = rng.standard_normal(N)
+    cases = {}
+    cases["constant rows"] = np.tile(rng.uniform(-5, 5, size=(M, 1)), (1, N))
+    nanrows = rng.standard_normal((M, N))
+    nanrows[:, 7] = np.nan
+    cases["NaN rows"] = nanrows
+    noise = rng.standard_normal((M, N))
+    noise[::2] += 2.0 * ref
+    cases["noise"] = noise
+    cases["copies of the reference"] = np.tile(ref, (M, 1)) * rng.uniform(0.5, 2.0, size=(M, 1))
+    for name, rows in cases.items():
+        dg = muse.DeviceGroup.from_rows(eng, rows)
+        db = muse.DeviceBatch(eng, dg, ref)
+        lag, mv = db.scores()
+        one = np.zeros(M, dtype=np.int32)
+        for gid, G, max_lag, top_n, thr, sign, absf in ((None, 0, 15, 20, 0.0, 0, True), (None, 0, 15, 20, 2.0, 0, True),
+                                                        (None, 0, -1, 20, 0.0, 0, True), (one, 1, 15, 5, 0.0, 0, True),
+                                                        (None, 0, 4096, 256, 0.0, -1, False), (one, 1, 4096, 1, 0.5, 1, False)):
+            got = db.run(gid, G, max_lag, top_n, thr, sign, absf)
+            exp = oracle.results(lag, mv, gid, G, absf, max_lag, top_n, thr, sign)
+            key = (name, G, max_lag, top_n, thr, sign, absf)
+            assert len(got[0]) == len(exp[0]), key
+            np.testing.assert_allclose(got[2], exp[2], rtol=1e-12, atol=0, err_msg=str(key))
+            if name != "copies of the reference":       # (exact ties: which of the tied rows is returned is not defined)
+                assert got[0].tolist() == exp[0].tolist(), key
+                assert got[1].tolist() == exp[1].tolist(), key
+            else:
+                assert np.array_equal(lag[got[0]], got[1]), key
+        db.close()
