@@ -98,6 +98,7 @@ struct muse_ctx {
     // filter-and-refine Run (run_select): 1 = ungrouped N = 4096 Runs screen in fp32 and re-evaluate in fp64 only the
     // rows that can reach the top-N; 0 = every Run scores all rows in fp64 (muse_ctx_set_screening / MUSE_HIP_SCREEN_RUN)
     int screening = 1;
+    int64_t screen_min_rows = 32768; // smaller groups: the plain fp64 pass is as fast (tools/screen_crossover.py)
     int variant = 0;
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -228,8 +229,11 @@ extern "C" int muse_ctx_create(int32_t device, muse_ctx **out)
     ctx->device = device;
     if (const char *kv = getenv("MUSE_HIP_KERNEL")) // profiling aid: same meaning as muse_ctx_set_kernel
         ctx->variant = atoi(kv);
-    if (const char *sv = getenv("MUSE_HIP_SCREEN_RUN")) // same meaning as muse_ctx_set_screening
+    if (const char *sv = getenv("MUSE_HIP_SCREEN_RUN")) { // same meaning as muse_ctx_set_screening
         ctx->screening = atoi(sv) != 0;
+        if (atoi(sv) > 1)
+            ctx->screen_min_rows = atoi(sv);
+    }
     ctx->num_cus = prop.multiProcessorCount;
     ctx->hbm = (int64_t)prop.totalGlobalMem;
     snprintf(ctx->name, sizeof(ctx->name), "%s (%s)", prop.name, prop.gcnArchName);
@@ -346,6 +350,7 @@ extern "C" int muse_ctx_set_screening(muse_ctx *ctx, int32_t enable)
     if (!ctx)
         return fail(MUSE_ERR_INVALID, "NULL context");
     ctx->screening = enable != 0;
+    ctx->screen_min_rows = enable > 1 ? enable : 32768;
     return MUSE_OK;
 }
 
@@ -1129,15 +1134,13 @@ static int ensure_select_ws(muse_batch *b, int64_t M, int64_t G, bool with_gid, 
 }
 
 // ---- filter-and-refine Run: ungrouped N = n = 4096 Runs under automatic kernel selection
-constexpr int64_t SCREEN_MIN_ROWS = 16384; // below this the fp64 pass is a fraction of a millisecond anyway
-
 static bool screen_eligible(const muse_batch *b, const int32_t *group_id, int32_t top_n, bool already_scored)
 {
     const muse_ctx *ctx = b->ctx;
     const int64_t M = b->g->M;
     (void)group_id; // label groups are handled too (per-group bounds: reduce_kernels.hip, screen_g1..g4)
     return !already_scored && ctx->screening && ctx->variant == 0 && b->n == 4096 && b->N > 2048 &&
-           b->xcf && top_n >= 1 && top_n <= TOPN_DEVICE_MAX && M >= SCREEN_MIN_ROWS && M / 2 < 0x7fffffffLL &&
+           b->xcf && top_n >= 1 && top_n <= TOPN_DEVICE_MAX && M >= ctx->screen_min_rows && M / 2 < 0x7fffffffLL &&
            b->screen_off_M != M;
 }
 

@@ -64,9 +64,9 @@ class Engine:
     def set_kernel(self, variant):
         B.check(B.load().muse_ctx_set_kernel(self._h, int(variant)))
 
-    def set_screening(self, enable):
-        """filter-and-refine Run (include/muse_hip.h: muse_ctx_set_screening)"""
-        B.check(B.load().muse_ctx_set_screening(self._h, 1 if enable else 0))
+    def set_screening(self, enable, min_rows=None):
+        """filter-and-refine Run (include/muse_hip.h: muse_ctx_set_screening); min_rows: smallest group it is used for"""
+        B.check(B.load().muse_ctx_set_screening(self._h, (int(min_rows) if min_rows and min_rows > 1 else 1) if enable else 0))
 
     def kernel_timing(self, enable):
         B.check(B.load().muse_ctx_kernel_timing(self._h, 1 if enable else 0))

@@ -900,7 +900,7 @@ def test_screened_run_equals_fp64_run(muse, eng, oracle, N):
     db = muse.DeviceBatch(eng, dg, ref)
     lag, mv = db.scores()
     try:
-        eng.set_screening(True)
+        eng.set_screening(True, min_rows=16384)
         for max_lag in (15, 0, 2048, 4096, 100):
             for top_n, thr, sign, absf in ((20, 0.0, 0, True), (1, 0.0, 0, True), (200, 0.0, 0, True), (20, 0.3, 0, True),
                                           (20, 0.0, 1, False), (20, 0.0, -1, False), (50, 0.05, -1, True),
@@ -918,7 +918,7 @@ def test_screened_run_equals_fp64_run(muse, eng, oracle, N):
         assert np.array_equal(lag2, lag)
         np.testing.assert_allclose(mv2, mv, rtol=1e-12, atol=0, equal_nan=True)
     finally:
-        eng.set_screening(True)   # the default
+        eng.set_screening(True)   # the default (Runs over >= 32768 series)
         db.close()
 
 
@@ -976,7 +976,7 @@ def test_screened_run_synthetic_matches_fp64_run(muse, eng):
             np.testing.assert_allclose(got[2], exact, rtol=1e-12, atol=0)
             assert abs(got[3] - exp[3]) <= 1e-12
     finally:
-        eng.set_screening(True)   # the default
+        eng.set_screening(True)   # the default (Runs over >= 32768 series)
         db.close()
 
 
@@ -986,6 +986,7 @@ def test_screened_run_fuzz_filters_and_smooth_series(muse, eng, oracle):
     the MaxLag filter and the path has to re-evaluate many rows or give the batch back to the fp64 pass)."""
     rng = np.random.default_rng(31337)
     N, M = 4096, 16500
+    eng.set_screening(True, min_rows=16384)
     for kind in ("noise", "walk"):
         if kind == "noise":
             ref = rng.standard_normal(N)
@@ -1016,6 +1017,7 @@ def test_screened_run_fuzz_filters_and_smooth_series(muse, eng, oracle):
             np.testing.assert_allclose(got[2], exp[2], rtol=1e-12, atol=0, err_msg=str(key))
         assert screened_runs >= 1, kind          # the path was exercised (it may switch itself off afterwards)
         db.close()
+    eng.set_screening(True)
 
 
 def test_screened_run_with_label_groups(muse, eng, oracle):
@@ -1024,6 +1026,7 @@ def test_screened_run_with_label_groups(muse, eng, oracle):
     whose first member is NaN, and every filter; expected records: the oracle's Results over the fp64 scores."""
     rng = np.random.default_rng(4242)
     N, M = 4096, 16600
+    eng.set_screening(True, min_rows=16384)
     ref = rng.standard_normal(N)
     rows = rng.standard_normal((M, N))
     for i in rng.integers(0, M, size=M // 3):
@@ -1058,6 +1061,7 @@ def test_screened_run_with_label_groups(muse, eng, oracle):
         np.testing.assert_allclose(got[2], exp[2], rtol=1e-12, atol=0, err_msg=str(key))
     assert screened_runs >= 1
     db.close()
+    eng.set_screening(True)
 
 
 def test_screened_run_degenerate_inputs(muse, eng, oracle):
@@ -1066,6 +1070,7 @@ def test_screened_run_degenerate_inputs(muse, eng, oracle):
     row its own copy of the reference (all scores tie at 1).  The records must still be those of the fp64 Run."""
     rng = np.random.default_rng(99)
     N, M = 4096, 16385
+    eng.set_screening(True, min_rows=16384)
     ref = rng.standard_normal(N)
     cases = {}
     cases["constant rows"] = np.tile(rng.uniform(-5, 5, size=(M, 1)), (1, N))
@@ -1095,3 +1100,4 @@ def test_screened_run_degenerate_inputs(muse, eng, oracle):
             else:
                 assert np.array_equal(lag[got[0]], got[1]), key
         db.close()
+    eng.set_screening(True)
