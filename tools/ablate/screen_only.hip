@@ -15,11 +15,18 @@ using namespace muse;
 namespace so {
 using namespace muse::scr;
 // forward fp32 FFT; pass-1 factors from four per-thread base powers W^t, W^2t, W^4t, W^8t (products of <= 4 exact factors)
-template <bool MULXC>
+// ABL (ablation, garbage results): 1 = the second pass's butterflies removed (-170 VALU instructions per transform),
+// 2 = the pass-1 twiddle products removed as well (every factor = w1)
+template <bool MULXC, int ABL = 0>
 __device__ __forceinline__ void fft(f2 (&v)[16], f2 *xbuf, const f2 *tw2s, const f2 w1, const f2 w2, const f2 w4, const f2 w8,
                                     const f2 (&xq)[16], const int t)
 {
     dft16f(v);
+    if (ABL >= 2) {
+#pragma unroll
+        for (int k = 1; k < 16; k++)
+            v[P16(k)] = cmulf(v[P16(k)], w1);
+    } else
     {
         const f2 w3 = cmulf(w1, w2), w5 = cmulf(w4, w1), w6 = cmulf(w4, w2), w7 = cmulf(w4, w3);
         v[P16(1)] = cmulf(v[P16(1)], w1); v[P16(2)] = cmulf(v[P16(2)], w2); v[P16(3)] = cmulf(v[P16(3)], w3);
@@ -31,7 +38,8 @@ __device__ __forceinline__ void fft(f2 (&v)[16], f2 *xbuf, const f2 *tw2s, const
         v[P16(15)] = cmulf(v[P16(15)], cmulf(w8, w7));
     }
     exchange<false>(v, xbuf, t);
-    dft16f(v);
+    if (ABL < 1)
+        dft16f(v);
     {
         const int lo = t & 15;
 #pragma unroll
@@ -50,7 +58,7 @@ __device__ __forceinline__ void fft(f2 (&v)[16], f2 *xbuf, const f2 *tw2s, const
 }
 } // namespace so
 
-template <int WPC, bool TIMING>
+template <int WPC, bool TIMING, int ABL = 0>
 __global__ __launch_bounds__(256, WPC) void screen_only(const FusedParams p)
 {
     using namespace muse::scr;
@@ -126,14 +134,14 @@ __global__ __launch_bounds__(256, WPC) void screen_only(const FusedParams p)
         for (int i = 0; i < 16; i++)
             v[i] = mk2((na[i] - mAf) * sclA, (nb[i] - mBf) * sclB);
         clk.template stamp<1>();
-        so::fft<true>(v, xbuf, tw2s, w1, w2, w4, w8, xq, t);
+        so::fft<true, ABL>(v, xbuf, tw2s, w1, w2, w4, w8, xq, t);
         clk.template stamp<2>();
         // ---- the next pair streams in behind the second transform (no other global load until it is consumed)
         fence();
         issue_series(ra, kA, p.rows + nA * p.stride, t);
         issue_series(rb, kB, p.rows + nB * p.stride, t);
         fence();
-        so::fft<false>(v, xbuf, tw2s, w1, w2, w4, w8, xq, t);
+        so::fft<false, ABL>(v, xbuf, tw2s, w1, w2, w4, w8, xq, t);
         clk.template stamp<3>();
         // ---- fp32 argmax |cc| per series: first index of the maximum (lag index 256 k + t)
         float ma = -1.f, mb = -1.f;
@@ -225,8 +233,10 @@ int main(int argc, char** argv)
     CK(hipMalloc(&p.mv, M * 8)); CK(hipMalloc(&p.lag, M * 4));
     CK(hipDeviceSynchronize());
     unsigned* fl; CK(hipMalloc(&fl, M * 4)); CK(hipMemset(fl, 0, M * 4)); p.scr_flags = fl; double* sv; CK(hipMalloc(&sv, M * 8)); p.scr_var = sv; p.scr_max_lag = 15; p.screen_delta = 1e-3;
-    const int which = argc > 2 ? atoi(argv[2]) : 31; // bit mask of the configurations to run
+    const int which = argc > 2 ? atoi(argv[2]) : 127; // bit mask of the configurations to run
     if (which & 1) run("screen-only WPC=3", screen_only<3, false>, p, 256 * 3, false);
+    if (which & 32) run("screen-only WPC=3, ablation 1 (-340 VALU instructions per pair)", screen_only<3, false, 1>, p, 256 * 3, false);
+    if (which & 64) run("screen-only WPC=3, ablation 2 (-430 VALU instructions per pair)", screen_only<3, false, 2>, p, 256 * 3, false);
     if (which & 2) run("library screening pass, split prefetch", xcorr_screen_pass_n4096<3, false, true>, p, 256 * 3, false);
     if (which & 4) run("library screening pass, burst prefetch", xcorr_screen_pass_n4096<3, false, false>, p, 256 * 3, false);
     if (which & 8) run("library screening pass, split (stamped)", xcorr_screen_pass_n4096<3, true, true>, p, 256 * 3, true);
