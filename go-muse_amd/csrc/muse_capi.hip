@@ -99,6 +99,7 @@ struct muse_ctx {
     // rows that can reach the top-N; 0 = every Run scores all rows in fp64 (muse_ctx_set_screening / MUSE_HIP_SCREEN_RUN)
     int screening = 1;
     int64_t screen_min_rows = 32768; // smaller groups: the plain fp64 pass is as fast (tools/screen_crossover.py)
+    double screen_e_scale = 1.0;     // test aid (MUSE_HIP_SCREEN_E_SCALE): scales the error bound, to exercise the guard
     int variant = 0;
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -184,9 +185,14 @@ struct muse_batch {
     int64_t scr_gcap = 0;
     int64_t scr_cap = 0, scr_keys_cap = 0;
     int *refine_host = nullptr;         // pinned: pairs re-evaluated by the last screened Run
+    double *est_save = nullptr;         // estimates of the listed rows (2 per pair), for the guard of the bound
+    int64_t est_cap = 0;
+    unsigned long long *err_dev = nullptr, *err_host = nullptr; // largest | |estimate| - |fp64 score| | of the last screened Run
+    double last_E = 0.0;                // the bound that Run assumed
     int64_t screen_off_M = -1;          // a screened Run over this many rows re-evaluated too many of them: not again
     bool scores_exact = true;           // mv / lag hold fp64 results for every row (false after a screened Run)
     bool last_screened = false;         // the last Run took the filter-and-refine path
+    int64_t guard_trips = 0;            // Runs redone in fp64 because an estimate left its bound
 };
 
 static int use_device(muse_ctx *ctx)
@@ -234,6 +240,8 @@ extern "C" int muse_ctx_create(int32_t device, muse_ctx **out)
         if (atoi(sv) > 1)
             ctx->screen_min_rows = atoi(sv);
     }
+    if (const char *ev = getenv("MUSE_HIP_SCREEN_E_SCALE"))
+        ctx->screen_e_scale = atof(ev) > 0.0 ? atof(ev) : 1.0;
     ctx->num_cus = prop.multiProcessorCount;
     ctx->hbm = (int64_t)prop.totalGlobalMem;
     snprintf(ctx->name, sizeof(ctx->name), "%s (%s)", prop.name, prop.gcnArchName);
@@ -1211,6 +1219,17 @@ static int score_screened(muse_batch *b, int32_t max_lag, int32_t top_n, double 
     }
     if (!b->refine_host)
         HIP_TRY(hipHostMalloc((void **)&b->refine_host, sizeof(int), hipHostMallocDefault));
+    if (!b->err_host)
+        HIP_TRY(hipHostMalloc((void **)&b->err_host, sizeof(unsigned long long), hipHostMallocDefault));
+    if (!b->err_dev)
+        HIP_TRY(hipMalloc(&b->err_dev, sizeof(unsigned long long)));
+    if (2 * npairs > b->est_cap) {
+        (void)hipFree(b->est_save);
+        b->est_save = nullptr;
+        b->est_cap = 0;
+        HIP_TRY(hipMalloc(&b->est_save, (size_t)(2 * npairs) * sizeof(double)));
+        b->est_cap = 2 * npairs;
+    }
     if (npairs > b->ovf_cap) {
         (void)hipFree(b->ovf_list);
         b->ovf_list = nullptr;
@@ -1227,7 +1246,8 @@ static int score_screened(muse_batch *b, int32_t max_lag, int32_t top_n, double 
             m = std::max(m, std::hypot(x.x, x.y));
         b->sp->xmax = m;
     }
-    const double Es = screen_error_scaled(b->sp->xmax);
+    const double Es = screen_error_scaled(b->sp->xmax) * ctx->screen_e_scale;
+    HIP_TRY(hipMemsetAsync(b->err_dev, 0, sizeof(unsigned long long), ctx->stream));
     HIP_TRY(hipMemsetAsync(b->scr_flags, 0, (size_t)M * sizeof(unsigned), ctx->stream));
     HIP_TRY(hipMemsetAsync(b->include, 0, (size_t)M, ctx->stream));
     HIP_TRY(hipMemsetAsync(b->ovf_count, 0, 2 * sizeof(int), ctx->stream));
@@ -1267,9 +1287,15 @@ static int score_screened(muse_batch *b, int32_t max_lag, int32_t top_n, double 
     r.pair_list = b->ovf_list;
     r.pair_count = b->ovf_count;
     r.npairs = std::min<long long>(npairs, (long long)ctx->num_cus * 3);
+    HIP_TRY(launch_screen_save(q, b->ovf_list, b->ovf_count, b->est_save, ctx->stream));
     HIP_TRY(launch_fused(r, KERNEL_R16_OCC3, ctx->num_cus, ctx->stream));
+    // guard: the re-evaluated rows have an estimate and an fp64 score; the largest difference must respect the bound
+    HIP_TRY(launch_screen_check(b->mv, M, b->ovf_list, b->ovf_count, b->est_save, b->err_dev, ctx->stream));
     *b->refine_host = 0;
+    *b->err_host = 0ull;
+    b->last_E = q.E;
     HIP_TRY(hipMemcpyAsync(b->refine_host, b->ovf_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(b->err_host, b->err_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     b->scores_exact = false;
     return MUSE_OK;
 }
@@ -1330,6 +1356,21 @@ extern "C" int muse_batch_screen_estimates(muse_batch *b, int32_t max_lag, doubl
     if (E)
         *E = 1.4143 * screen_error_scaled(b->sp->xmax);
     return MUSE_OK;
+}
+
+// after the synchronisation of a screened Run: did any re-evaluated row's estimate miss its fp64 score by more than the
+// bound the selection assumed?  (Never observed -- the bound is ~3 600x the measured error -- but if it happens the bound
+// cannot be trusted for the rows that were NOT re-evaluated either: the batch leaves the filter-and-refine path.)
+static bool screen_guard_tripped(muse_batch *b)
+{
+    double err;
+    static_assert(sizeof(err) == sizeof(*b->err_host), "bit copy");
+    memcpy(&err, b->err_host, sizeof(err));
+    if (!(err > b->last_E))
+        return false;
+    b->screen_off_M = b->g->M;
+    b->guard_trips++;
+    return true;
 }
 
 static int run_select(muse_batch *b, const int32_t *group_id, int32_t G_in, int64_t series_offset, int32_t max_lag,
@@ -1404,6 +1445,8 @@ static int run_select(muse_batch *b, const int32_t *group_id, int32_t G_in, int6
         // scores crowd around the cut) costs more than the plain fp64 pass: not again for this (immutable) set of rows
         if (screened && (int64_t)*b->refine_host * 4 > (M + 1) / 2)
             b->screen_off_M = M;
+        if (screened && screen_guard_tripped(b)) // an estimate left its bound: this Run is redone entirely in fp64
+            return run_select(b, group_id, G_in, series_offset, max_lag, top_n, threshold, sign_filter, abs_scores, out, false);
     } else {
         std::vector<muse_record> rec((size_t)G);
         std::vector<unsigned long long> key((size_t)G);
@@ -1417,6 +1460,8 @@ static int run_select(muse_batch *b, const int32_t *group_id, int32_t G_in, int6
                 cands.push_back(rec[(size_t)g]);
         if (screened && (int64_t)*b->refine_host * 4 > (M + 1) / 2)
             b->screen_off_M = M;
+        if (screened && screen_guard_tripped(b))
+            return run_select(b, group_id, G_in, series_offset, max_lag, top_n, threshold, sign_filter, abs_scores, out, false);
     }
     if (!group_id) // ungrouped: global order of the groups is the global series index
         for (auto &r : cands)
@@ -1680,6 +1725,10 @@ extern "C" int muse_batch_free(muse_batch *b)
     (void)hipFree(b->scr_gcert);
     if (b->refine_host)
         (void)hipHostFree(b->refine_host);
+    if (b->err_host)
+        (void)hipHostFree(b->err_host);
+    (void)hipFree(b->err_dev);
+    (void)hipFree(b->est_save);
     muse_group *g = b->g;
     muse_ctx *ctx = b->ctx;
     delete b;

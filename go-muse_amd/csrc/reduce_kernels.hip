@@ -437,6 +437,58 @@ __global__ void screen_ginit_kernel(int G, long long *first, unsigned long long 
     }
 }
 
+// ---- run-time guard of the error bound: the rows that are re-evaluated have both an fp32 estimate and (afterwards) an
+// fp64 score; their largest | |estimate| - |score| | must stay below E, or the Run falls back to the all-fp64 path
+__global__ void screen_save_kernel(ScreenSelect q, const long long *pair_list, const int *pair_count, double *est_save)
+{
+    const int n = *pair_count;
+    for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n; slot += gridDim.x * blockDim.x) {
+        const long long pr = pair_list[slot];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const long long i = 2 * pr + k;
+            double e = -1.0; // no estimate
+            if (i < q.M) {
+                const unsigned f = q.flags[i];
+                const double var = q.var[i];
+                if (!(f & (SCR_NAN | SCR_REFINE)) && var > 0.0)
+                    e = fabs(q.mv[i] * (1.0 / sqrt(var)));
+            }
+            est_save[2 * (long long)slot + k] = e;
+        }
+    }
+}
+__global__ void screen_check_kernel(const double *mv, long long M, const long long *pair_list, const int *pair_count,
+                                    const double *est_save, unsigned long long *err_bits)
+{
+    const int n = *pair_count;
+    for (int slot = blockIdx.x * blockDim.x + threadIdx.x; slot < n; slot += gridDim.x * blockDim.x) {
+        const long long pr = pair_list[slot];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const long long i = 2 * pr + k;
+            const double e = est_save[2 * (long long)slot + k];
+            if (i >= M || e < 0.0)
+                continue;
+            const double x = fabs(mv[i]);
+            if (x == x) // (a NaN score has no estimate to compare with)
+                atomicMax(err_bits, abs_bits(fabs(e - x)));
+        }
+    }
+}
+hipError_t launch_screen_save(const ScreenSelect &q, const long long *pair_list, const int *pair_count, double *est_save,
+                              hipStream_t stream)
+{
+    hipLaunchKernelGGL(screen_save_kernel, dim3(256), dim3(256), 0, stream, q, pair_list, pair_count, est_save);
+    return hipGetLastError();
+}
+hipError_t launch_screen_check(const double *mv, long long M, const long long *pair_list, const int *pair_count,
+                               const double *est_save, unsigned long long *err_bits, hipStream_t stream)
+{
+    hipLaunchKernelGGL(screen_check_kernel, dim3(256), dim3(256), 0, stream, mv, M, pair_list, pair_count, est_save, err_bits);
+    return hipGetLastError();
+}
+
 long long screen_select_scratch(long long G, int top_n) // G = number of selection units (rows, or label groups)
 {
     const long long nb = (G + TOPN_CHUNK - 1) / TOPN_CHUNK;

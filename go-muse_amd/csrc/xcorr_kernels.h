@@ -134,6 +134,12 @@ struct ScreenGroupWork {
 // pessimistic keys -> the top_n-th best of them (the cut) -> pairs whose optimistic key reaches it (pair_list,
 // *pair_count, include[row] = 1); keys: screen_select_scratch(M, top_n) entries of scratch
 long long screen_select_scratch(long long G, int top_n);
+// run-time guard of the bound: estimates of the listed rows saved before the fp64 kernel overwrites them, then the largest
+// | |estimate| - |fp64 score| | over those rows (as the bits of a non-negative double, atomicMax)
+hipError_t launch_screen_save(const ScreenSelect &q, const long long *pair_list, const int *pair_count, double *est_save,
+                              hipStream_t stream);
+hipError_t launch_screen_check(const double *mv, long long M, const long long *pair_list, const int *pair_count,
+                               const double *est_save, unsigned long long *err_bits, hipStream_t stream);
 hipError_t launch_screen_select(const ScreenSelect &q, int top_n, unsigned long long *selkey, unsigned long long *keys,
                                 const ScreenGroupWork &gw, long long *pair_list, int *pair_count, unsigned char *include,
                                 hipStream_t stream);

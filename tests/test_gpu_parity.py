@@ -8,6 +8,7 @@ exact, except rows the oracle flags as rounding-decided ties (top-two |cc| gap
 < 1e-12 relative) -- their count is asserted to be tiny.
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -1101,3 +1102,34 @@ def test_screened_run_degenerate_inputs(muse, eng, oracle):
                 assert np.array_equal(lag[got[0]], got[1]), key
         db.close()
     eng.set_screening(True)
+
+
+def test_screening_bound_guard_falls_back_to_fp64(muse, oracle):
+    """The run-time guard: every re-evaluated row has an fp32 estimate and an fp64 score; if they differ by more than the
+    bound the selection assumed, the Run is redone in fp64 and the batch leaves the filter-and-refine path.  Forced here
+    by shrinking the assumed bound a million-fold (MUSE_HIP_SCREEN_E_SCALE, read when a context is created)."""
+    rng = np.random.default_rng(5)
+    N, M = 4096, 16500
+    ref = rng.standard_normal(N)
+    rows = rng.standard_normal((M, N))
+    for i in rng.integers(0, M, size=M // 4):
+        rows[i] += rng.uniform(-2, 2) * np.roll(ref, int(rng.integers(-100, 100)))
+    os.environ["MUSE_HIP_SCREEN_E_SCALE"] = "1e-6"
+    try:
+        e2 = muse.Engine(0)
+    finally:
+        del os.environ["MUSE_HIP_SCREEN_E_SCALE"]
+    try:
+        e2.set_screening(True, min_rows=16384)
+        dg = muse.DeviceGroup.from_rows(e2, rows)
+        db = muse.DeviceBatch(e2, dg, ref)
+        lag, mv = db.scores()
+        for args in ((None, 0, 100, 20, 0.0, 0, True), (None, 0, 4096, 5, 0.1, -1, False)):
+            got = db.run(*args)
+            assert db.last_run_info()[0] is False          # redone in fp64 (first Run), or not screened any more
+            exp = oracle.results(lag, mv, None, 0, args[6], args[2], args[3], args[4], args[5])
+            assert got[0].tolist() == exp[0].tolist() and got[1].tolist() == exp[1].tolist()
+            np.testing.assert_allclose(got[2], exp[2], rtol=1e-12, atol=0)
+        db.close()
+    finally:
+        e2.close()
