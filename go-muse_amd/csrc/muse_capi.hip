@@ -1169,8 +1169,14 @@ static double screen_error_scaled(double xmax)
     return 256.0 * u * 128.0 * xmax + 3e-6;
 }
 
-static int score_screened(muse_batch *b, int32_t max_lag, int32_t top_n, double threshold, int32_t sign_filter,
-                          int32_t abs_scores, const int *gid_dev = nullptr, int64_t G = 0)
+// The filter-and-refine scoring in three steps, so that the screening pass can be one launch per batch or one launch
+// for several batches (muse_batch_run_many): screen_prepare (workspace, bound, cleared flags), the pass, screen_finish
+// (keys, cut, compaction, fp64 re-evaluation of the listed pairs, guard).
+struct ScreenPlan {
+    double Es = 0.0; // the bound in the pass's scaled units
+};
+
+static int screen_prepare(muse_batch *b, int32_t top_n, const int *gid_dev, int64_t G, ScreenPlan &plan)
 {
     muse_ctx *ctx = b->ctx;
     int rc = use_device(ctx);
@@ -1246,27 +1252,31 @@ static int score_screened(muse_batch *b, int32_t max_lag, int32_t top_n, double 
             m = std::max(m, std::hypot(x.x, x.y));
         b->sp->xmax = m;
     }
-    const double Es = screen_error_scaled(b->sp->xmax) * ctx->screen_e_scale;
+    plan.Es = screen_error_scaled(b->sp->xmax) * ctx->screen_e_scale;
     HIP_TRY(hipMemsetAsync(b->err_dev, 0, sizeof(unsigned long long), ctx->stream));
     HIP_TRY(hipMemsetAsync(b->scr_flags, 0, (size_t)M * sizeof(unsigned), ctx->stream));
     HIP_TRY(hipMemsetAsync(b->include, 0, (size_t)M, ctx->stream));
     HIP_TRY(hipMemsetAsync(b->ovf_count, 0, 2 * sizeof(int), ctx->stream));
+    return MUSE_OK;
+}
+
+static FusedParams screen_pass_params(muse_batch *b, int32_t max_lag, const ScreenPlan &plan)
+{
     FusedParams p = base_params(b);
     p.scr_flags = b->scr_flags;
     p.scr_var = b->scr_var;
     p.scr_max_lag = max_lag;
-    p.screen_delta = 2.0 * Es; // every lag whose fp32 |cc| is within 2 E of the fp32 maximum may be the exact argmax
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (ctx->timing) {
-        HIP_TRY(hipEventCreate(&e0));
-        HIP_TRY(hipEventCreate(&e1));
-        HIP_TRY(hipEventRecord(e0, ctx->stream));
-    }
-    HIP_TRY(launch_screen_pass(p, ctx->num_cus, ctx->stream));
-    if (ctx->timing) {
-        HIP_TRY(hipEventRecord(e1, ctx->stream));
-        ctx->events.emplace_back(e0, e1);
-    }
+    p.screen_delta = 2.0 * plan.Es; // every lag whose fp32 |cc| is within 2 E of the fp32 maximum may be the exact argmax
+    return p;
+}
+
+static int screen_finish(muse_batch *b, int32_t top_n, double threshold, int32_t sign_filter, int32_t abs_scores,
+                         const int *gid_dev, int64_t G, const ScreenPlan &plan)
+{
+    muse_ctx *ctx = b->ctx;
+    const int64_t M = b->g->M;
+    const int64_t npairs = (M + 1) / 2;
+    const double Es = plan.Es;
     ScreenSelect q{};
     q.mv = b->mv;
     q.var = b->scr_var;
@@ -1298,6 +1308,29 @@ static int score_screened(muse_batch *b, int32_t max_lag, int32_t top_n, double 
     HIP_TRY(hipMemcpyAsync(b->err_host, b->err_dev, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     b->scores_exact = false;
     return MUSE_OK;
+}
+
+static int score_screened(muse_batch *b, int32_t max_lag, int32_t top_n, double threshold, int32_t sign_filter,
+                          int32_t abs_scores, const int *gid_dev = nullptr, int64_t G = 0)
+{
+    muse_ctx *ctx = b->ctx;
+    ScreenPlan plan;
+    int rc = screen_prepare(b, top_n, gid_dev, G, plan);
+    if (rc)
+        return rc;
+    const FusedParams p = screen_pass_params(b, max_lag, plan);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ctx->timing) {
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, ctx->stream));
+    }
+    HIP_TRY(launch_screen_pass(p, ctx->num_cus, ctx->stream));
+    if (ctx->timing) {
+        HIP_TRY(hipEventRecord(e1, ctx->stream));
+        ctx->events.emplace_back(e0, e1);
+    }
+    return screen_finish(b, top_n, threshold, sign_filter, abs_scores, gid_dev, G, plan);
 }
 
 extern "C" int muse_batch_last_run_info(muse_batch *b, int32_t *screened, int64_t *refined_pairs)
@@ -1358,6 +1391,22 @@ extern "C" int muse_batch_screen_estimates(muse_batch *b, int32_t max_lag, doubl
     return MUSE_OK;
 }
 
+// the label-group map of a Run on the device (re-sent only when it changed)
+static int upload_group_ids(muse_batch *b, const int32_t *group_id, int64_t M)
+{
+    if (!group_id)
+        return MUSE_OK;
+    const bool same = b->gid_valid && (int64_t)b->gid_host.size() == M &&
+                      memcmp(b->gid_host.data(), group_id, (size_t)M * sizeof(int32_t)) == 0;
+    if (!same) {
+        b->gid_host.assign(group_id, group_id + M);
+        HIP_TRY(hipMemcpyAsync(b->gid_dev, b->gid_host.data(), (size_t)M * sizeof(int), hipMemcpyHostToDevice,
+                               b->ctx->stream));
+        b->gid_valid = true;
+    }
+    return MUSE_OK;
+}
+
 // after the synchronisation of a screened Run: did any re-evaluated row's estimate miss its fp64 score by more than the
 // bound the selection assumed?  (Never observed -- the bound is ~3 600x the measured error -- but if it happens the bound
 // cannot be trusted for the rows that were NOT re-evaluated either: the batch leaves the filter-and-refine path.)
@@ -1375,7 +1424,7 @@ static bool screen_guard_tripped(muse_batch *b)
 
 static int run_select(muse_batch *b, const int32_t *group_id, int32_t G_in, int64_t series_offset, int32_t max_lag,
                       int32_t top_n, double threshold, int32_t sign_filter, int32_t abs_scores,
-                      std::vector<muse_record> &out, bool already_scored = false)
+                      std::vector<muse_record> &out, bool already_scored = false, bool prescreened = false)
 {
     out.clear();
     muse_ctx *ctx = b->ctx;
@@ -1385,7 +1434,8 @@ static int run_select(muse_batch *b, const int32_t *group_id, int32_t G_in, int6
     if (group_id && G_in < 0)
         return fail(MUSE_ERR_INVALID, "negative group count");
     // Batch.Run re-scores on every call (muse_batch.go:116-122)
-    const bool screened = screen_eligible(b, group_id, top_n, already_scored);
+    // (prescreened: muse_batch_run_many has run the screening pass for several batches at once and finished this one)
+    const bool screened = prescreened || screen_eligible(b, group_id, top_n, already_scored);
     int rc = (already_scored || screened) ? MUSE_OK : muse_batch_score(b);
     if (rc)
         return rc;
@@ -1399,18 +1449,11 @@ static int run_select(muse_batch *b, const int32_t *group_id, int32_t G_in, int6
     rc = ensure_select_ws(b, M, G, group_id != nullptr, K, on_device);
     if (rc)
         return rc;
-    if (group_id) {
-        const bool same = b->gid_valid && (int64_t)b->gid_host.size() == M &&
-                          memcmp(b->gid_host.data(), group_id, (size_t)M * sizeof(int32_t)) == 0;
-        if (!same) {
-            b->gid_host.assign(group_id, group_id + M);
-            HIP_TRY(hipMemcpyAsync(b->gid_dev, b->gid_host.data(), (size_t)M * sizeof(int), hipMemcpyHostToDevice,
-                                   ctx->stream));
-            b->gid_valid = true;
-        }
-    }
+    rc = upload_group_ids(b, group_id, M);
+    if (rc)
+        return rc;
     b->last_screened = screened;
-    if (screened) { // fp32 screening pass, then fp64 for the rows that can reach the top-N (needs the selection workspace)
+    if (screened && !prescreened) { // fp32 screening pass, then fp64 for the rows that can reach the top-N (needs the selection workspace)
         rc = score_screened(b, max_lag, top_n, threshold, sign_filter, abs_scores, group_id ? b->gid_dev : nullptr, G);
         if (rc)
             return rc;
@@ -1596,7 +1639,7 @@ extern "C" int muse_batch_score_many(muse_batch *const *bs, int32_t R)
         (void)hipFree(ctx->many_tab);
         ctx->many_tab = nullptr;
         ctx->many_cap = 0;
-        HIP_TRY(hipMalloc(&ctx->many_tab, (size_t)R * 4 * sizeof(void *)));
+        HIP_TRY(hipMalloc(&ctx->many_tab, (size_t)R * 5 * sizeof(void *)));
         ctx->many_cap = R;
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream)); // the previous pass may still be reading the host image
@@ -1651,18 +1694,125 @@ extern "C" int muse_batch_score_many(muse_batch *const *bs, int32_t R)
     return MUSE_OK;
 }
 
+// The filter-and-refine Run for R references over one group (muse_batch_run_many): ONE screening pass reads, reduces and
+// forward-transforms every pair of series once and reports into each reference's arrays; keys, cut, compaction, fp64
+// re-evaluation and guard then run per reference.  Sets `done` when the batches have been screened (otherwise nothing
+// was touched and the caller takes the fp64 one-pass kernel).
+static int screen_many(muse_batch *const *bs, int32_t R, const int32_t *group_id, int32_t G_in, int32_t max_lag,
+                       int32_t top_n, double threshold, int32_t sign_filter, int32_t abs_scores, bool &done)
+{
+    done = false;
+    if (!bs || R < 2 || !bs[0])
+        return MUSE_OK;
+    muse_batch *b0 = bs[0];
+    muse_ctx *ctx = b0->ctx;
+    const int64_t M = b0->g->M;
+    if (sign_filter < -1 || sign_filter > 1 || (group_id && G_in < 0))
+        return MUSE_OK; // (run_select reports the error)
+    for (int r = 0; r < R; r++) {
+        if (!bs[r] || bs[r]->ctx != ctx || bs[r]->g != b0->g)
+            return MUSE_OK; // (muse_batch_score_many reports the error)
+        for (int q = 0; q < r; q++)
+            if (bs[q] == bs[r])
+                return MUSE_OK;
+        if (bs[r]->N != 4096 || !screen_eligible(bs[r], group_id, top_n, false))
+            return MUSE_OK;
+    }
+    const int64_t G = group_id ? (int64_t)G_in : M;
+    if (M == 0 || G == 0 || G > 0x7fffffffLL)
+        return MUSE_OK;
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    const bool on_device = top_n <= TOPN_DEVICE_MAX && G > TOPN_CHUNK / 4;
+    const int K = on_device ? top_n : 1;
+    std::vector<ScreenPlan> plan((size_t)R);
+    double Es_max = 0.0;
+    for (int r = 0; r < R; r++) {
+        rc = ensure_select_ws(bs[r], M, G, group_id != nullptr, K, on_device);
+        if (rc)
+            return rc;
+        rc = upload_group_ids(bs[r], group_id, M);
+        if (rc)
+            return rc;
+        rc = screen_prepare(bs[r], top_n, group_id ? bs[r]->gid_dev : nullptr, G, plan[(size_t)r]);
+        if (rc)
+            return rc;
+        Es_max = std::max(Es_max, plan[(size_t)r].Es);
+    }
+    if (!ctx->zscratch) {
+        const int slots = ctx->num_cus * 4; // one 64 KB slice per resident workgroup of the fp64 one-pass kernel
+        HIP_TRY(hipMalloc(&ctx->zscratch, (size_t)slots * 4096 * sizeof(double2)));
+        ctx->zslots = slots;
+    }
+    if (R > ctx->many_cap) {
+        (void)hipFree(ctx->many_tab);
+        ctx->many_tab = nullptr;
+        ctx->many_cap = 0;
+        HIP_TRY(hipMalloc(&ctx->many_tab, (size_t)R * 5 * sizeof(void *)));
+        ctx->many_cap = R;
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream)); // the previous pass may still be reading the host image
+    std::vector<void *> &tab = ctx->many_host;
+    tab.assign((size_t)R * 5, nullptr);
+    for (int r = 0; r < R; r++) {
+        tab[(size_t)r] = bs[r]->xcf;
+        tab[(size_t)R + r] = bs[r]->mv;
+        tab[(size_t)2 * R + r] = bs[r]->lag;
+        tab[(size_t)3 * R + r] = bs[r]->scr_flags;
+        tab[(size_t)4 * R + r] = bs[r]->scr_var;
+    }
+    HIP_TRY(hipMemcpyAsync(ctx->many_tab, tab.data(), tab.size() * sizeof(void *), hipMemcpyHostToDevice, ctx->stream));
+    ScreenPlan widest;
+    widest.Es = Es_max; // one window for the pass: the widest of the references' (a wider window only flags more lags)
+    FusedParams p = screen_pass_params(b0, max_lag, widest);
+    p.R = R;
+    p.xcf_many = (const float2 *const *)ctx->many_tab;
+    p.mv_many = (double *const *)((void **)ctx->many_tab + R);
+    p.lag_many = (int *const *)((void **)ctx->many_tab + 2 * R);
+    p.flags_many = (unsigned *const *)((void **)ctx->many_tab + 3 * R);
+    p.var_many = (double *const *)((void **)ctx->many_tab + 4 * R);
+    p.zscratch = ctx->zscratch;
+    p.zslots = ctx->zslots;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ctx->timing) {
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, ctx->stream));
+    }
+    HIP_TRY(launch_screen_pass_many(p, ctx->num_cus, ctx->stream));
+    if (ctx->timing) {
+        HIP_TRY(hipEventRecord(e1, ctx->stream));
+        ctx->events.emplace_back(e0, e1);
+    }
+    for (int r = 0; r < R; r++) {
+        rc = screen_finish(bs[r], top_n, threshold, sign_filter, abs_scores, group_id ? bs[r]->gid_dev : nullptr, G,
+                           plan[(size_t)r]);
+        if (rc)
+            return rc;
+    }
+    done = true;
+    return MUSE_OK;
+}
+
 extern "C" int muse_batch_run_many(muse_batch *const *bs, int32_t R, const int32_t *group_id, int32_t G,
                                    int32_t max_lag, int32_t top_n, double threshold, int32_t sign_filter,
                                    int32_t abs_scores, int64_t *out_series, int32_t *out_lag, double *out_score,
                                    int32_t *out_count, double *out_mean_abs)
 {
-    int rc = muse_batch_score_many(bs, R);
+    bool prescreened = false;
+    int rc = screen_many(bs, R, group_id, G, max_lag, top_n, threshold, sign_filter, abs_scores, prescreened);
     if (rc)
         return rc;
+    if (!prescreened) {
+        rc = muse_batch_score_many(bs, R);
+        if (rc)
+            return rc;
+    }
     const size_t cap = (size_t)std::max(top_n, 0);
     for (int r = 0; r < R; r++) {
         std::vector<muse_record> sel;
-        rc = run_select(bs[r], group_id, G, 0, max_lag, top_n, threshold, sign_filter, abs_scores, sel, true);
+        rc = run_select(bs[r], group_id, G, 0, max_lag, top_n, threshold, sign_filter, abs_scores, sel, true, prescreened);
         if (rc)
             return rc;
         emit(sel, out_series ? out_series + cap * r : nullptr, out_lag ? out_lag + cap * r : nullptr,

@@ -32,6 +32,9 @@ struct FusedParams {
     double *const *mv_many;         // R result vectors (M doubles each)
     int *const *lag_many;           // R lag vectors (M ints each)
     const double *const *c1_many;   // N < 4096: R indicator-correlation tables
+    const float2 *const *xcf_many;  // screening pass for R references: R fp32 spectrum tables
+    unsigned *const *flags_many;    //   R flag vectors
+    double *const *var_many;        //   R variance vectors
     double2 *zscratch;              // zslots x 4096 complex: one parked spectrum per (resident) workgroup
     int zslots;
     const double2 *twm;  // [32768]   W_65536^k         (generic kernel; half period)
@@ -64,6 +67,7 @@ hipError_t launch_fused_pipe(const FusedParams &p, int num_cus, hipStream_t stre
 hipError_t launch_fused_occ4(const FusedParams &p, int num_cus, int waves_per_simd, hipStream_t stream); // xcorr_r16_occ4.hip
 hipError_t launch_fused_screen(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_r16_screen.hip
 hipError_t launch_screen_pass(const FusedParams &p, int num_cus, hipStream_t stream);  // xcorr_r16_screen.hip (filter-and-refine Run)
+hipError_t launch_screen_pass_many(const FusedParams &p, int num_cus, hipStream_t stream); // the same for R references in one pass
 // per-row flags of the screening pass
 enum : unsigned { SCR_IN = 1u, SCR_OUT = 2u, SCR_POS = 4u, SCR_NEG = 8u, SCR_REFINE = 16u, SCR_NAN = 32u };
 hipError_t launch_fused_w8(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_r8_w8.hip

@@ -1106,6 +1106,263 @@ __global__ __launch_bounds__(SCR_THREADS, WPC) void xcorr_screen_pass_n4096(cons
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The screening pass for R references that share one group (muse_batch_run_many): every pair of series is read
+// from HBM, reduced and forward-transformed ONCE; its fp32 spectrum Z is parked in this workgroup's 32 KB slice of
+// FusedParams::zscratch (each thread re-reads only what it wrote itself; L2 resident) and, per reference, multiplied by
+// that reference's spectrum factors, transformed back and reported into that reference's arrays (xcf_many / mv_many /
+// lag_many / flags_many / var_many: device tables of R pointers).  The next pair's rows are requested during the LAST
+// reference's transform only, behind its table loads (in-order vmcnt).  N == n == 4096.
+namespace scr {
+
+// a wave-uniform pointer fetched from a device table, forced into SGPRs (the compiler cannot prove uniformity)
+template <typename T>
+__device__ __forceinline__ T *uniform_ptr(T *ptr)
+{
+    const unsigned long long u = (unsigned long long)ptr;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return (T *)(((unsigned long long)hi << 32) | lo);
+}
+
+struct PairStats {
+    double varA, varB;
+    int eA, eB;
+    bool nanA, nanB, redoA, redoB, offA, offB, hasB;
+};
+
+// maxima + flags + estimates of one (pair, reference): the end phase of xcorr_screen_pass_n4096
+__device__ __forceinline__ void report_pair(const f2 (&v)[16], const PairStats &st, double *mv, int *lag, unsigned *flags,
+                                            double *var, const long long rA, const long long rB, const float window,
+                                            const int max_lag, float *redf, const int t, const int lane, const int wave)
+{
+    float ma = 0.f, mb = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        ma = fmaxf(ma, fabsf(v[k].x));
+        mb = fmaxf(mb, fabsf(v[k].y));
+    }
+    ma = wave_max_f32_dpp(ma);
+    mb = wave_max_f32_dpp(mb);
+    if (lane == 0) {
+        redf[wave] = ma;
+        redf[4 + wave] = mb;
+    }
+    lds_barrier();
+    const float MA = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
+    const float MB = fmaxf(fmaxf(redf[4], redf[5]), fmaxf(redf[6], redf[7]));
+    const float thA = MA - window, thB = MB - window;
+    unsigned fA = 0u, fB = 0u;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const float xa = v[k].x, xb = v[k].y;
+        const bool ha = fabsf(xa) >= thA, hb = fabsf(xb) >= thB;
+        if (__ballot(ha || hb) != 0ull) { // wave-uniform
+            const int idx = 256 * k + t;
+            const int lg = idx > 2048 ? idx - 4096 : idx;
+            const unsigned in = (lg < 0 ? -lg : lg) <= max_lag ? SCR_IN : SCR_OUT;
+            if (ha)
+                fA |= in | (xa > 0.f ? SCR_POS : 0u) | (xa < 0.f ? SCR_NEG : 0u);
+            if (hb)
+                fB |= in | (xb > 0.f ? SCR_POS : 0u) | (xb < 0.f ? SCR_NEG : 0u);
+            if (fabsf(xa) == MA && !st.offA) {
+                mv[rA] = (double)xa * __longlong_as_double((long long)(1023 + (st.eA >> 1)) << 52);
+                lag[rA] = lg;
+            }
+            if (fabsf(xb) == MB && !st.offB) {
+                mv[rB] = (double)xb * __longlong_as_double((long long)(1023 + (st.eB >> 1)) << 52);
+                lag[rB] = lg;
+            }
+        }
+    }
+    if (__ballot((fA | fB) != 0u) != 0ull) {
+        unsigned wA = 0u, wB = 0u;
+#pragma unroll
+        for (unsigned bit = 1u; bit <= 8u; bit <<= 1) {
+            wA |= __ballot((fA & bit) != 0u) != 0ull ? bit : 0u;
+            wB |= __ballot((fB & bit) != 0u) != 0ull ? bit : 0u;
+        }
+        if (lane == 0) {
+            if (wA && !st.offA)
+                atomicOr(&flags[rA], wA);
+            if (wB && !st.offB)
+                atomicOr(&flags[rB], wB);
+        }
+    }
+    if (t == 0) {
+        var[rA] = st.varA;
+        if (st.offA) {
+            mv[rA] = st.nanA ? __builtin_nan("") : 0.0;
+            lag[rA] = 0;
+            atomicOr(&flags[rA], st.nanA ? SCR_NAN : (st.redoA ? SCR_REFINE : SCR_IN));
+        }
+        if (st.hasB) {
+            var[rB] = st.varB;
+            if (st.offB) {
+                mv[rB] = st.nanB ? __builtin_nan("") : 0.0;
+                lag[rB] = 0;
+                atomicOr(&flags[rB], st.nanB ? SCR_NAN : (st.redoB ? SCR_REFINE : SCR_IN));
+            }
+        }
+    }
+}
+
+} // namespace scr
+
+template <int WPC>
+__global__ __launch_bounds__(SCR_THREADS, WPC) void xcorr_screen_pass_many_n4096(const FusedParams p)
+{
+    using namespace scr;
+    __shared__ f2 xbuf[SCR_XBUF];
+    __shared__ f2 tw2s[256];
+    __shared__ double red[24];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    constexpr double invN = 1.0 / 4096.0, invNm1 = 1.0 / 4095.0;
+    const float window = (float)p.screen_delta;
+    const int max_lag = p.scr_max_lag;
+    const int R = p.R;
+    float *redf = reinterpret_cast<float *>(red + 16);
+    f2 *const zs = reinterpret_cast<f2 *>(p.zscratch) + (size_t)blockIdx.x * 4096; // resident grid: one slice per workgroup
+    f2 w1, w2, w4, w8;
+    {
+        const float2 tw = p.tw2f[t];
+        tw2s[t] = mk2(tw.x, tw.y);
+        const gptr<float2> tp = scalar_ptr(p.tw1f);
+        w1 = ldg_f2(tp, 256 + t);
+        w2 = ldg_f2(tp, 512 + t);
+        w4 = ldg_f2(tp, 1024 + t);
+        w8 = ldg_f2(tp, 2048 + t);
+    }
+    __syncthreads();
+    long long pair = blockIdx.x;
+    double ra[16], rb[16], kA, kB;
+    issue_series(ra, kA, p.rows + 2 * pair * p.stride, t);
+    issue_series(rb, kB, p.rows + (2 * pair + 1 < p.M ? 2 * pair + 1 : 2 * pair) * p.stride, t);
+    for (; pair < p.npairs; pair += gridDim.x) {
+        const long long rA = 2 * pair, rB = rA + 1;
+        PairStats st;
+        st.hasB = rB < p.M;
+        long long nxt = pair + gridDim.x;
+        nxt = nxt < p.npairs ? nxt : p.npairs - 1;
+        const long long nA = 2 * nxt, nB = (nA + 1 < p.M) ? nA + 1 : nA;
+        float na[16], nb[16];
+        double q[4];
+        reduce_series(ra, kA, na, q[0], q[1]);
+        reduce_series(rb, kB, nb, q[2], q[3]);
+        fence();
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            q[k] = wave_sum_dpp(q[k]);
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                red[wave * 4 + k] = q[k];
+        }
+        lds_barrier();
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            q[k] = uniform((red[k] + red[4 + k]) + (red[8 + k] + red[12 + k]));
+        const double mA = uniform(q[0] * invN), mB = uniform(q[2] * invN);
+        st.varA = uniform((q[1] - q[0] * q[0] * invN) * invNm1);
+        st.varB = uniform((q[3] - q[2] * q[2] * invN) * invNm1);
+        st.nanA = !__builtin_isfinite(st.varA);
+        st.nanB = !__builtin_isfinite(st.varB);
+        const bool zeroA = !st.nanA && !(st.varA > 0.0), zeroB = !st.nanB && !(st.varB > 0.0);
+        st.eA = (int)((__double_as_longlong(st.varA) >> 52) & 0x7ff) - 1023;
+        st.eB = (int)((__double_as_longlong(st.varB) >> 52) & 0x7ff) - 1023;
+        st.redoA = !(zeroA || st.nanA) && (st.eA > 200 || st.eA < -200 || mA * mA > 64.0 * st.varA);
+        st.redoB = !(zeroB || st.nanB) && (st.eB > 200 || st.eB < -200 || mB * mB > 64.0 * st.varB);
+        st.offA = zeroA || st.nanA || st.redoA;
+        st.offB = zeroB || st.nanB || st.redoB || !st.hasB;
+        const float sclA = st.offA ? 0.f : __int_as_float((127 - (st.eA >> 1)) << 23);
+        const float sclB = st.offB ? 0.f : __int_as_float((127 - (st.eB >> 1)) << 23);
+        const float mAf = st.offA ? 0.f : (float)mA, mBf = st.offB ? 0.f : (float)mB;
+        f2 v[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            v[i] = mk2((na[i] - mAf) * sclA, (nb[i] - mBf) * sclB);
+        if (st.offA || st.offB) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                v[i].x = st.offA ? 0.f : v[i].x;
+                v[i].y = st.offB ? 0.f : v[i].y;
+            }
+        }
+        // ---- the pair's spectrum, once: v[k] = Z[256 k + t]; parked for references 1 .. R-1
+        {
+            f2 none0[16];
+            fft4096b<false>(v, xbuf, tw2s, w1, w2, w4, w8, none0, t);
+        }
+        if (R > 1) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                unsigned long long u = (unsigned long long)zs;
+                asm volatile("" : "+s"(u));
+                u += (unsigned long long)(256 * k) * sizeof(f2);
+                asm volatile("" : "+s"(u));
+                f2v zz;
+                zz.x = v[k].x;
+                zz.y = v[k].y;
+                reinterpret_cast<f2v __attribute__((address_space(1))) *>(u)[t] = zz;
+            }
+        }
+        // per reference: table loads first (L2: this reference's spectrum factors and, from the second reference on, the
+        // parked Z), multiply, transform back, report.  The last reference is peeled: only there is the next pair's row
+        // prefetch in flight (its registers must not be live across the loop).
+        auto load_product = [&](const int r) {
+            f2 xq[16];
+            {
+                const Tw1FetchF fetch{uniform_ptr(p.xcf_many[r]), t};
+#pragma unroll
+                for (int k = 0; k < 16; k++)
+                    xq[k] = fetch(k);
+            }
+            if (r > 0) {
+                const Tw1FetchF fz{reinterpret_cast<const float2 *>(zs), t};
+#pragma unroll
+                for (int k = 0; k < 16; k++)
+                    v[k] = fz(k);
+            }
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                v[k] = cmulf(v[k], xq[k]);
+            fence();
+        };
+        f2 none[16];
+        for (int r = 0; r < R - 1; r++) {
+            load_product(r);
+            fft4096b<false>(v, xbuf, tw2s, w1, w2, w4, w8, none, t);
+            report_pair(v, st, uniform_ptr(p.mv_many[r]), uniform_ptr(p.lag_many[r]), uniform_ptr(p.flags_many[r]),
+                        uniform_ptr(p.var_many[r]), rA, rB, window, max_lag, redf, t, lane, wave);
+        }
+        {
+            const int r = R - 1;
+            load_product(r);
+            issue_series(ra, kA, p.rows + nA * p.stride, t); // the next pair streams in behind the last transform
+            fence();
+            const double *rowB = p.rows + nB * p.stride;
+            fft4096b<false>(v, xbuf, tw2s, w1, w2, w4, w8, none, t, [&]() { issue_series(rb, kB, rowB, t); });
+            report_pair(v, st, uniform_ptr(p.mv_many[r]), uniform_ptr(p.lag_many[r]), uniform_ptr(p.flags_many[r]),
+                        uniform_ptr(p.var_many[r]), rA, rB, window, max_lag, redf, t, lane, wave);
+        }
+    }
+}
+
+hipError_t launch_screen_pass_many(const FusedParams &p, int num_cus, hipStream_t stream)
+{
+    if (p.n != 4096 || p.N != 4096 || p.R < 1 || !p.xcf_many || !p.flags_many || !p.var_many || !p.mv_many || !p.lag_many ||
+        !p.zscratch)
+        return hipErrorInvalidValue;
+    long long grid = p.npairs;
+    long long cap = (long long)num_cus * 3;
+    if (cap > p.zslots * 2) // (a slice of zscratch is 4096 double2 = two fp32 slices)
+        cap = p.zslots * 2;
+    if (grid > cap)
+        grid = cap;
+    hipLaunchKernelGGL((xcorr_screen_pass_many_n4096<3>), dim3((unsigned)grid), dim3(SCR_THREADS), 0, stream, p);
+    return hipGetLastError();
+}
+
 hipError_t launch_screen_pass(const FusedParams &p, int num_cus, hipStream_t stream)
 {
     if (p.n != 4096 || p.N <= 2048 || p.N > 4096 || !p.scr_flags || !p.scr_var || !p.xcf)

@@ -1133,3 +1133,54 @@ def test_screening_bound_guard_falls_back_to_fp64(muse, oracle):
         db.close()
     finally:
         e2.close()
+
+
+def test_screened_run_many_references(muse, eng, oracle):
+    """muse_batch_run_many on the filter-and-refine path: one screening pass for all references (rows read and forward
+    transformed once, the fp32 spectrum parked per workgroup), then keys / cut / re-evaluation per reference.  Records per
+    reference = the oracle's Results over that reference's fp64 scores; with and without label groups; references of
+    very different spectra (white noise, a rectangle, a slow sine) share the pass's window."""
+    rng = np.random.default_rng(808)
+    N, M = 4096, 16500
+    t = np.arange(N)
+    refs = [rng.standard_normal(N), np.where((t > 700) & (t < 1500), 1.0, 0.0) + 0.05 * rng.standard_normal(N),
+            np.sin(2 * np.pi * t / 900.0) + 0.1 * rng.standard_normal(N), rng.standard_normal(N),
+            np.cumsum(rng.standard_normal(N))]
+    rows = rng.standard_normal((M, N))
+    for i in rng.integers(0, M, size=M // 3):
+        rows[i] += rng.uniform(-3, 3) * np.roll(refs[int(rng.integers(0, len(refs)))], int(rng.integers(-300, 300)))
+    rows[11] = 7.0
+    rows[12, 9] = np.nan
+    rows[13] *= 1e80
+    dg = muse.DeviceGroup.from_rows(eng, rows)
+    bs = [muse.DeviceBatch(eng, dg, r) for r in refs]
+    exact = [b.scores() for b in bs]
+    eng.set_screening(True, min_rows=16384)
+    try:
+        for trial in range(8):
+            R = int(rng.choice([2, 3, 5]))
+            pick = [int(i) for i in rng.choice(len(refs), size=R, replace=False)]
+            if trial % 2:
+                G = int(rng.choice([50, 3000]))
+                gid = rng.integers(0, G, size=M).astype(np.int32)
+            else:
+                gid, G = None, 0
+            max_lag = int(rng.choice([15, 500, 4096]))
+            top_n = int(rng.choice([1, 20, 100]))
+            thr = float(rng.choice([0.0, 0.1]))
+            sign = int(rng.choice([0, 1, -1]))
+            absf = bool(rng.random() < 0.5)
+            got = muse.run_many([bs[i] for i in pick], gid, G, max_lag, top_n, thr, sign, absf)
+            for j, i in enumerate(pick):
+                lag, mv = exact[i]
+                exp = oracle.results(lag, mv, gid, G, absf, max_lag, top_n, thr, sign)
+                key = (trial, i, G, max_lag, top_n, thr, sign, absf)
+                assert got[j][0].tolist() == exp[0].tolist(), key
+                assert got[j][1].tolist() == exp[1].tolist(), key
+                np.testing.assert_allclose(got[j][2], exp[2], rtol=1e-12, atol=0, err_msg=str(key))
+            if trial == 0:
+                assert bs[pick[0]].last_run_info()[0] is True      # the first call, at least, took the screened path
+    finally:
+        eng.set_screening(True)
+        for b in bs:
+            b.close()
