@@ -68,6 +68,9 @@ def main():
     ap.add_argument("--many-refs", type=int, default=8,
                     help="also time muse_batch_run_many with this many references (N=1 only; 0 = skip); "
                          "reported as an extra object, never as `value`")
+    ap.add_argument("--all-fp64", action="store_true",
+                    help="headline = the Run with filter-and-refine off (every series scored by the fp64 kernel); "
+                         "by default that Run is reported next to the headline as `all_fp64_run`")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the RCCL gather path even with one rank (rehearsal on a 1-GPU box)")
     args = ap.parse_args()
@@ -97,6 +100,8 @@ def main():
     elif pkg.build.stale():
         pkg.build.build()
     eng = pkg.Engine(local_rank)                      # raises without a gfx950 GPU: no fallback
+    if args.all_fp64:
+        eng.set_screening(False)
     dev_name, cus, hbm = eng.device_info()
     M, N = args.rows, args.length
     dg, ref = pkg.DeviceGroup.synthetic(eng, M, N, seed=0x6D757365, global_first=rank * M)
