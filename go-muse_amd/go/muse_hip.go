@@ -53,6 +53,25 @@ func getEngine() (*engine, error) {
 	return defaultEngine, nil
 }
 
+// SetScreening switches the filter-and-refine Run of the default engine (include/muse_hip.h:
+// muse_ctx_set_screening; on by default: Runs over >= 32768 series of length 2049..4096 screen every
+// series in fp32 and re-evaluate in fp64 only the rows that can reach the top-N -- same Scores).
+// minRows > 1 sets the smallest group the path is used for.
+func SetScreening(enable bool, minRows int) error {
+	e, err := getEngine()
+	if err != nil {
+		return err
+	}
+	v := C.int32_t(0)
+	if enable {
+		v = 1
+		if minRows > 1 {
+			v = C.int32_t(minRows)
+		}
+	}
+	return hipError(C.muse_ctx_set_screening(e.ctx, v))
+}
+
 // deviceGroup mirrors Group's rows on the GPU; rows are appended once.
 type deviceGroup struct {
 	g        *C.muse_group
