@@ -526,11 +526,17 @@ __device__ __forceinline__ void issue_series_padded(double (&r)[16], double &k0,
     k0 = rp[0];
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-        int j = t + 256 * i - pad;
-        if (i < 8) // elements 2048.. are always samples (pad < 2048)
+        if (i < 8) { // may fall into the pad: clamped 12-bit index (saddr + 32-bit voffset, no sign extension per load)
+            int j = t + 256 * i - pad;
             j = j < 0 ? 0 : j;
-        const unsigned ju = (unsigned)j & 4095u; // unsigned 12-bit index: saddr + 32-bit voffset, no sign extension per load
-        r[i] = __builtin_nontemporal_load(rp + ju);
+            r[i] = __builtin_nontemporal_load(rp + ((unsigned)j & 4095u));
+        } else { // elements 2048.. are always samples (pad < 2048): scalar base row + 256 i - pad, shared voffset t
+            unsigned long long u = (unsigned long long)row;
+            asm volatile("" : "+s"(u));
+            u += (unsigned long long)(long long)(256 * i - pad) * sizeof(double);
+            asm volatile("" : "+s"(u));
+            r[i] = __builtin_nontemporal_load((gptr<double>)u + t);
+        }
     }
 }
 
