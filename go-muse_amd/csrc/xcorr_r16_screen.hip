@@ -839,8 +839,10 @@ __global__ __launch_bounds__(SCR_THREADS, WPC) void xcorr_fused_n4096_screen2(co
 // ---------------------------------------------------------------------------------------------
 // The screening PASS of the filter-and-refine Run (muse_capi.hip: run_select): fp32 only, no
 // re-evaluation.  Per series it writes
-//   mv[row]   the fp32 estimate of the signed score at the fp32 argmax (as a double), |estimate - exact| <= E
-//             for every lag (E: the caller's bound, DESIGN.md "filter and refine"), and
+//   mv[row]   sigma times the fp32 estimate of the signed score at the fp32 argmax (the fp32 value with its exact
+//             power-of-two scale, as a double) and scr_var[row] = sigma^2: score estimate = mv / sqrt(var), with
+//             |estimate - exact| <= E at every lag (E: the caller's bound); lag[row] is the fp32 argmax
+//             (informational: the selection never uses it), and
 //   flags[row] (OR-ed in; zeroed by the caller): what the lags whose fp32 |cc| lies within `screen_delta` = 2 E
 //             (scaled units) of the fp32 maximum -- the only lags that can be the exact argmax -- look like:
 //             SCR_IN / SCR_OUT: one of them has |lag| <= / > max_lag;  SCR_POS / SCR_NEG: its value is > 0 / < 0;
@@ -853,11 +855,11 @@ __global__ __launch_bounds__(SCR_THREADS, WPC) void xcorr_fused_n4096_screen2(co
 // issued behind the first transform and consumed at the top of the next iteration.
 namespace scr {
 
-// forward fp32 FFT; pass-1 factors W_4096^(k t) from four per-thread base powers W^t, W^2t, W^4t, W^8t
-// (every factor is a product of at most four correctly rounded table entries)
 struct NoHook {
     __device__ __forceinline__ void operator()() const {}
 };
+// forward fp32 FFT; pass-1 factors W_4096^(k t) from four per-thread base powers W^t, W^2t, W^4t, W^8t
+// (every factor is a product of at most four correctly rounded table entries);
 // `mid` runs between the first transpose and the second pass (the pass kernel issues half of its row prefetch there)
 template <bool MULXC, typename F = NoHook>
 __device__ __forceinline__ void fft4096b(f2 (&v)[16], f2 *xbuf, const f2 *tw2s, const f2 w1, const f2 w2, const f2 w4,
