@@ -13,7 +13,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libmuse_hip.so")
-SOURCES = ["xcorr_kernels.hip", "xcorr_r16_pipe.hip", "xcorr_r16_occ4.hip", "xcorr_r16_fast.hip", "xcorr_r16_screen.hip", "xcorr_r8_w8.hip", "xcorr_stockham.hip", "reduce_kernels.hip", "muse_capi.hip"]
+SOURCES = ["xcorr_kernels.hip", "xcorr_r16_pipe.hip", "xcorr_r16_occ4.hip", "xcorr_r16_fast.hip", "xcorr_r16_screen.hip", "xcorr_screen_stk.hip", "xcorr_r8_w8.hip", "xcorr_stockham.hip", "reduce_kernels.hip", "muse_capi.hip"]
 HEADERS = [os.path.join(CSRC, "xcorr_kernels.h"), os.path.join(CSRC, "fft_device.h"), os.path.join(CSRC, "r16_device.h"), os.path.join(ROOT, "include", "muse_hip.h")]
 
 
@@ -34,7 +34,7 @@ def stale():
 
 # per-source extra flags: the fp32 screening kernel must keep scalar fp32 ops (2-cycle
 # issue); SLP packing into v_pk_*_f32 costs v_mov shuffles and issues no faster
-PER_FILE_FLAGS = {"xcorr_r16_screen.hip": ["-fno-slp-vectorize"]}
+PER_FILE_FLAGS = {"xcorr_r16_screen.hip": ["-fno-slp-vectorize"], "xcorr_screen_stk.hip": ["-fno-slp-vectorize"]}
 
 
 def build(force=False, verbose=False, extra_flags=()):

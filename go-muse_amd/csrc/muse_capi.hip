@@ -79,7 +79,7 @@ struct muse_ctx {
     int64_t hbm = 0;
     char name[64] = {0};
     double2 *tw1 = nullptr, *tw2 = nullptr, *twm = nullptr, *tw1w8 = nullptr, *tw1p = nullptr;
-    float2 *tw1f = nullptr, *tw2f = nullptr; // fp32 copies for the screening kernel
+    float2 *tw1f = nullptr, *tw2f = nullptr, *twmf = nullptr; // fp32 copies for the screening kernels
     // many-reference pass (muse_batch_score_many): parked spectra + device pointer tables
     // pinned staging buffers (32 MB each) lent to groups that receive many small appends; allocated once
     // (hipHostMalloc of 32 MB costs milliseconds) and returned when the group is released
@@ -262,6 +262,13 @@ extern "C" int muse_ctx_create(int32_t device, muse_ctx **out)
     HIP_TRY(hipMemcpy(ctx->tw1, t1.data(), t1.size() * sizeof(double2), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ctx->tw2, t2.data(), t2.size() * sizeof(double2), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ctx->twm, tm.data(), tm.size() * sizeof(double2), hipMemcpyHostToDevice));
+    {
+        std::vector<float2> tmf(tm.size());
+        for (size_t k = 0; k < tm.size(); k++)
+            tmf[k] = make_float2((float)tm[k].x, (float)tm[k].y);
+        HIP_TRY(hipMalloc(&ctx->twmf, tmf.size() * sizeof(float2)));
+        HIP_TRY(hipMemcpy(ctx->twmf, tmf.data(), tmf.size() * sizeof(float2), hipMemcpyHostToDevice));
+    }
     std::vector<double2> t1p(16 * 256); // tw1 in the lane order of xcorr_r16_fast.hip's second transform
     for (int k = 0; k < 16; k++)
         for (int t = 0; t < 256; t++)
@@ -303,6 +310,7 @@ static void ctx_release(muse_ctx *ctx)
     (void)hipFree(ctx->tw1);
     (void)hipFree(ctx->tw2);
     (void)hipFree(ctx->twm);
+    (void)hipFree(ctx->twmf);
     (void)hipFree(ctx->tw1f);
     (void)hipFree(ctx->tw1w8);
     (void)hipFree(ctx->tw1p);
@@ -881,6 +889,7 @@ static FusedParams base_params(muse_batch *b)
     p.xcp = b->xcp;
     p.c1 = b->c1;
     p.tw1f = ctx->tw1f;
+    p.twmf = ctx->twmf;
     p.tw2f = ctx->tw2f;
     p.xcf = b->xcf;
     p.xs = b->xs;
@@ -1147,7 +1156,8 @@ static bool screen_eligible(const muse_batch *b, const int32_t *group_id, int32_
     const muse_ctx *ctx = b->ctx;
     const int64_t M = b->g->M;
     (void)group_id; // label groups are handled too (per-group bounds: reduce_kernels.hip, screen_g1..g4)
-    return !already_scored && ctx->screening && ctx->variant == 0 && b->n == 4096 && b->N > 2048 &&
+    const bool length_ok = b->n == 4096 || b->n == 2048 || b->n == 1024 || b->n == 512; // (N > n/2 by construction)
+    return !already_scored && ctx->screening && ctx->variant == 0 && length_ok &&
            b->xcf && top_n >= 1 && top_n <= TOPN_DEVICE_MAX && M >= ctx->screen_min_rows && M / 2 < 0x7fffffffLL &&
            b->screen_off_M != M;
 }
@@ -1160,13 +1170,13 @@ static bool screen_eligible(const muse_batch *b, const int32_t *group_id, int32_
 // and the complex multiply) scales with u * max|X| * 128; 256 is > 1.5x the sum of those constants (~170).
 // The second term is the rounding of the fp32 input copy (|mean d| <= 8 sigma is enforced by the kernel):
 // ||delta c||_2 <= 2u (90.5 + 8 * 1.4143 * 64) and |delta cc| <= ||delta c||_2 ||xs||_2, ||xs||_2 = 1 / sqrt(N-1).
-static double screen_error_scaled(double xmax)
+static double screen_error_scaled(double xmax, int n)
 {
     // N < 4096 (zero-padded): the rounded mean is a constant offset of the samples only, not of the pad; it reaches a
     // lag through the correlation of the sample indicator with the reference, |c1| <= sqrt(N) ||xs||_2 ~ 1, times
     // 2^-24 * 8 sigma * 1.4143 / sigma < 1e-6 (for N == n that correlation is the reference's sum: 0).
     const double u = 5.9604644775390625e-08; // 2^-24
-    return 256.0 * u * 128.0 * xmax + 3e-6;
+    return 256.0 * u * (2.0 * std::sqrt((double)n)) * xmax + 3e-6; // ||z||_2 <= sqrt(2 (N-1)) * 1.4143 <= 2 sqrt(n): 128 at n = 4096
 }
 
 // The filter-and-refine scoring in three steps, so that the screening pass can be one launch per batch or one launch
@@ -1252,7 +1262,7 @@ static int screen_prepare(muse_batch *b, int32_t top_n, const int *gid_dev, int6
             m = std::max(m, std::hypot(x.x, x.y));
         b->sp->xmax = m;
     }
-    plan.Es = screen_error_scaled(b->sp->xmax) * ctx->screen_e_scale;
+    plan.Es = screen_error_scaled(b->sp->xmax, b->n) * ctx->screen_e_scale;
     HIP_TRY(hipMemsetAsync(b->err_dev, 0, sizeof(unsigned long long), ctx->stream));
     HIP_TRY(hipMemsetAsync(b->scr_flags, 0, (size_t)M * sizeof(unsigned), ctx->stream));
     HIP_TRY(hipMemsetAsync(b->include, 0, (size_t)M, ctx->stream));
@@ -1298,7 +1308,7 @@ static int screen_finish(muse_batch *b, int32_t top_n, double threshold, int32_t
     r.pair_count = b->ovf_count;
     r.npairs = std::min<long long>(npairs, (long long)ctx->num_cus * 3);
     HIP_TRY(launch_screen_save(q, b->ovf_list, b->ovf_count, b->est_save, ctx->stream));
-    HIP_TRY(launch_fused(r, KERNEL_R16_OCC3, ctx->num_cus, ctx->stream));
+    HIP_TRY(launch_fused(r, b->n == 4096 ? KERNEL_R16_OCC3 : KERNEL_STOCKHAM, ctx->num_cus, ctx->stream));
     // guard: the re-evaluated rows have an estimate and an fp64 score; the largest difference must respect the bound
     HIP_TRY(launch_screen_check(b->mv, M, b->ovf_list, b->ovf_count, b->est_save, b->err_dev, ctx->stream));
     *b->refine_host = 0;
@@ -1325,7 +1335,7 @@ static int score_screened(muse_batch *b, int32_t max_lag, int32_t top_n, double 
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, ctx->stream));
     }
-    HIP_TRY(launch_screen_pass(p, ctx->num_cus, ctx->stream));
+    HIP_TRY(b->n == 4096 ? launch_screen_pass(p, ctx->num_cus, ctx->stream) : launch_screen_pass_stk(p, ctx->num_cus, ctx->stream));
     if (ctx->timing) {
         HIP_TRY(hipEventRecord(e1, ctx->stream));
         ctx->events.emplace_back(e0, e1);
@@ -1349,8 +1359,8 @@ extern "C" int muse_batch_screen_estimates(muse_batch *b, int32_t max_lag, doubl
 {
     if (!b)
         return fail(MUSE_ERR_INVALID, "NULL batch");
-    if (b->n != 4096 || !b->xcf)
-        return fail(MUSE_ERR_UNSUPPORTED, "the screening pass is built for series of length 2049 .. 4096");
+    if ((b->n != 4096 && b->n != 2048 && b->n != 1024 && b->n != 512) || !b->xcf)
+        return fail(MUSE_ERR_UNSUPPORTED, "the screening pass is built for series of length 257 .. 4096");
     muse_ctx *ctx = b->ctx;
     int rc = use_device(ctx);
     if (rc)
@@ -1387,7 +1397,7 @@ extern "C" int muse_batch_screen_estimates(muse_batch *b, int32_t max_lag, doubl
             if (inc[(size_t)i])
                 flags[i] |= 0x80000000u; // re-evaluated: `estimate` holds the fp64 result for this row
     if (E)
-        *E = 1.4143 * screen_error_scaled(b->sp->xmax);
+        *E = 1.4143 * screen_error_scaled(b->sp->xmax, b->n);
     return MUSE_OK;
 }
 

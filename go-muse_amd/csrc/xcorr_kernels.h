@@ -45,6 +45,7 @@ struct FusedParams {
     int *nil_out;        // optional (generic kernel only): M flags, 1 = sigma == 0 -> (nil,0,0)
     unsigned long long *dbg; // diagnostic builds only (tools/ablate): per-workgroup phase cycle sums
     // fp32 screening kernel (xcorr_r16_screen.hip)
+    const float2 *twmf;  // [32768]   W_65536^k, fp32 (screening pass, n = 512 .. 2048)
     const float2 *tw1f;  // [16][256] W_4096^(k*t), fp32
     const float2 *tw2f;  // [16][16]  W_256^(k*c), fp32
     const float2 *xcf;   // n entries: conj(X_full[f]) / n, fp32
@@ -68,6 +69,7 @@ hipError_t launch_fused_occ4(const FusedParams &p, int num_cus, int waves_per_si
 hipError_t launch_fused_screen(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_r16_screen.hip
 hipError_t launch_screen_pass(const FusedParams &p, int num_cus, hipStream_t stream);  // xcorr_r16_screen.hip (filter-and-refine Run)
 hipError_t launch_screen_pass_many(const FusedParams &p, int num_cus, hipStream_t stream); // the same for R references in one pass
+hipError_t launch_screen_pass_stk(const FusedParams &p, int num_cus, hipStream_t stream);  // xcorr_screen_stk.hip: n = 512, 1024, 2048
 // per-row flags of the screening pass
 enum : unsigned { SCR_IN = 1u, SCR_OUT = 2u, SCR_POS = 4u, SCR_NEG = 8u, SCR_REFINE = 16u, SCR_NAN = 32u };
 hipError_t launch_fused_w8(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_r8_w8.hip

@@ -276,12 +276,15 @@ void xcorr_fused_stk_lds(const FusedParams p)
     const int N = p.N, pad = n - N;
     const double invN = 1.0 / (double)N, invNm1 = 1.0 / (double)(N - 1);
     const double2 *__restrict__ twm = p.twm;
-    const long long ngroups = (p.npairs + G - 1) / G;
+    // optional indirection (filter-and-refine Run): process pair_list[0 .. *pair_count) instead of every pair
+    const long long total = p.pair_list ? (long long)*p.pair_count : p.npairs;
+    const long long ngroups = (total + G - 1) / G;
 
     for (long long it = blockIdx.x; it < ngroups; it += gridDim.x) {
-        const long long pair_raw = it * G + g;
-        const bool live = pair_raw < p.npairs;
-        const long long pair = live ? pair_raw : p.npairs - 1; // idle sub-groups shadow the last pair
+        const long long slot = it * G + g;
+        const bool live = slot < total;
+        const long long sl = live ? slot : total - 1; // idle sub-groups shadow the last pair
+        const long long pair = p.pair_list ? p.pair_list[sl] : sl;
         const long long rA = 2 * pair;
         const bool hasB = rA + 1 < p.M;
         const double *__restrict__ ra = p.rows + rA * p.stride;

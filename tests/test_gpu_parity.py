@@ -873,7 +873,7 @@ def _screen_cases(rng, N):
     for i in range(100, 160):                                       # a crowd of nearly equal scores around a cut
         rows[i] = np.roll(ref, 5) + 0.3 * rows[99] + 1e-7 * (i - 100) * rng.standard_normal(N)
     for i in range(200, 230):                                       # periodic: many lags tie within any window
-        rows[i] = np.sin(2 * np.pi * (t + i) / 64.0) + 0.01 * rng.standard_normal(N)
+        rows[i] = np.sin(2 * np.pi * (t + i) / 64.0) + 0.01 * rng.standard_normal(N)   # (period 64 divides every n)
     rows[300] = ref                                                 # score 1 at lag 0
     # (exact ties in |score| are avoided: their order in the reference's heap depends on rows evicted earlier)
     rows[301] = -np.roll(ref, -12) + 0.01 * rows[301]               # score ~ -1 inside MaxLag 15
@@ -889,12 +889,13 @@ def _screen_cases(rng, N):
     return ref, rows
 
 
-@pytest.mark.parametrize("N", [4096, 3000])
+@pytest.mark.parametrize("N", [4096, 3000, 2048, 1500, 1024, 600, 512])
 def test_screened_run_equals_fp64_run(muse, eng, oracle, N):
     """The filter-and-refine Run (muse_ctx_set_screening) returns the records of the all-fp64 Run: adversarial rows
     (near ties at the cut, periodic series, NaN / Inf / sigma == 0, sigmas outside the fp32 range, a far-outlier first
-    sample) under every filter combination, for N == n and for zero-padded series (N = 3000); the expected records are
-    the oracle's Results over the fp64 scores."""
+    sample) under every filter combination, for N == n and for zero-padded series, at every FFT length the path is built
+    for (4096: radix-16 kernel; 2048 / 1024 / 512: fp32 Stockham kernels); the expected records are the oracle's Results
+    over the fp64 scores."""
     rng = np.random.default_rng(2024)
     ref, rows = _screen_cases(rng, N)
     dg = muse.DeviceGroup.from_rows(eng, rows)
@@ -902,18 +903,22 @@ def test_screened_run_equals_fp64_run(muse, eng, oracle, N):
     lag, mv = db.scores()
     try:
         eng.set_screening(True, min_rows=16384)
+        first = True
         for max_lag in (15, 0, 2048, 4096, 100):
             for top_n, thr, sign, absf in ((20, 0.0, 0, True), (1, 0.0, 0, True), (200, 0.0, 0, True), (20, 0.3, 0, True),
                                           (20, 0.0, 1, False), (20, 0.0, -1, False), (50, 0.05, -1, True),
                                           (20, 0.999, 0, True), (256, 0.0, 1, True)):
                 got = db.run(None, 0, max_lag, top_n, thr, sign, absf)
+                if first:
+                    assert db.last_run_info()[0] is True, N      # the path under test did run
+                    first = False
                 exp = oracle.results(lag, mv, None, 0, absf, max_lag, top_n, thr, sign)
                 key = (max_lag, top_n, thr, sign, absf)
                 assert got[0].tolist() == exp[0].tolist(), key
                 assert got[1].tolist() == exp[1].tolist(), key
-                # (N < n: the all-scores kernel corrects for the mean after the transform, the re-evaluating kernel
-                # centres before it: the two fp64 results differ by ~1e-11 relative)
-                np.testing.assert_allclose(got[2], exp[2], rtol=1e-12 if N == 4096 else 1e-9, atol=0, err_msg=str(key))
+                # (2048 < N < 4096: the all-scores kernel corrects for the mean after the transform, the re-evaluating
+                # kernel centres before it: the two fp64 results differ by ~1e-11 relative)
+                np.testing.assert_allclose(got[2], exp[2], rtol=1e-9 if 2048 < N < 4096 else 1e-12, atol=0, err_msg=str(key))
         # the all-scores API after a screened Run still returns fp64 results for every row
         lag2, mv2 = db.read_scores()
         assert np.array_equal(lag2, lag)
@@ -923,7 +928,7 @@ def test_screened_run_equals_fp64_run(muse, eng, oracle, N):
         db.close()
 
 
-@pytest.mark.parametrize("N", [4096, 2500])
+@pytest.mark.parametrize("N", [4096, 2500, 2048, 1100, 512])
 def test_screening_estimates_stay_inside_the_bound(muse, eng, oracle, N):
     """|fp32 estimate - fp64 score| <= E for every series the pass did not hand to the fp64 kernel, with E the bound
     the selection assumes; the flags cover the exact lag (inside / outside MaxLag) and the exact sign."""
