@@ -98,7 +98,9 @@ struct muse_ctx {
     // filter-and-refine Run (run_select): 1 = ungrouped N = 4096 Runs screen in fp32 and re-evaluate in fp64 only the
     // rows that can reach the top-N; 0 = every Run scores all rows in fp64 (muse_ctx_set_screening / MUSE_HIP_SCREEN_RUN)
     int screening = 1;
-    int64_t screen_min_rows = 32768; // smaller groups: the plain fp64 pass is as fast (tools/screen_crossover.py)
+    // smaller groups: the plain fp64 pass is as fast (tools/screen_crossover.py: the crossover is at ~25 000 rows of 4096
+    // samples).  Default: M * n >= 32768 * 4096 samples; an explicit row count (muse_ctx_set_screening(ctx, rows)) overrides.
+    int64_t screen_min_rows = 0;
     double screen_e_scale = 1.0;     // test aid (MUSE_HIP_SCREEN_E_SCALE): scales the error bound, to exercise the guard
     int variant = 0;
     bool timing = false;
@@ -366,7 +368,7 @@ extern "C" int muse_ctx_set_screening(muse_ctx *ctx, int32_t enable)
     if (!ctx)
         return fail(MUSE_ERR_INVALID, "NULL context");
     ctx->screening = enable != 0;
-    ctx->screen_min_rows = enable > 1 ? enable : 32768;
+    ctx->screen_min_rows = enable > 1 ? enable : 0;
     return MUSE_OK;
 }
 
@@ -1158,7 +1160,8 @@ static bool screen_eligible(const muse_batch *b, const int32_t *group_id, int32_
     (void)group_id; // label groups are handled too (per-group bounds: reduce_kernels.hip, screen_g1..g4)
     const bool length_ok = b->n == 4096 || b->n == 2048 || b->n == 1024 || b->n == 512; // (N > n/2 by construction)
     return !already_scored && ctx->screening && ctx->variant == 0 && length_ok &&
-           b->xcf && top_n >= 1 && top_n <= TOPN_DEVICE_MAX && M >= ctx->screen_min_rows && M / 2 < 0x7fffffffLL &&
+           b->xcf && top_n >= 1 && top_n <= TOPN_DEVICE_MAX && M / 2 < 0x7fffffffLL &&
+           (ctx->screen_min_rows > 0 ? M >= ctx->screen_min_rows : M * (int64_t)b->n >= (int64_t)32768 * 4096) &&
            b->screen_off_M != M;
 }
 

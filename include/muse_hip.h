@@ -90,7 +90,7 @@ int muse_ctx_device_info(muse_ctx *ctx, char *name, int32_t name_cap,
  * variable MUSE_HIP_KERNEL sets the initial value (profiling aid). */
 int muse_ctx_set_kernel(muse_ctx *ctx, int32_t variant);
 /* Filter-and-refine Run (on by default; MUSE_HIP_SCREEN_RUN=0 / enable = 0 turns it off; enable = 1: for Runs over
- * >= 32768 series, where it starts to pay; enable = n > 1: for Runs over >= n series).  When enabled, a
+ * groups of >= 32768 * 4096 samples after padding, where it starts to pay; enable = n > 1: for Runs over >= n series).  When enabled, a
  * muse_batch_run / muse_batch_run_shard (with or without label groups) over that many series of length 257 .. 4096 (FFT
  * lengths 512 .. 4096) under automatic kernel selection screens every series with an fp32 transform (a bound E on its error is derived from the reference's
  * spectrum), re-evaluates in fp64 exactly those rows whose optimistic selection key reaches the top_n-th best
