@@ -1,5 +1,5 @@
 // xcorr_screen_stk.hip -- the fp32 screening pass of the filter-and-refine Run for the FFT lengths
-// n = 512, 1024, 2048 (series of n/2 < N <= n samples, leading zero pad): the radix-16 Stockham structure of
+// n = 512, 1024, 2048 and 8192 (series of n/2 < N <= n samples, leading zero pad): the radix-16 Stockham structure of
 // xcorr_stockham.hip (xcorr_fused_stk_lds) with 8-byte complex values -- half the LDS bytes and twice the resident
 // workgroups of the fp64 kernel (three per CU at 168 VGPRs instead of two).  Same contract as xcorr_screen_pass_n4096 (xcorr_r16_screen.hip): per series an
 // estimate (mv = sigma * estimate, scr_var = sigma^2), the fp32 argmax lag (informational) and the SCR_* flags of every
@@ -210,19 +210,23 @@ __device__ __forceinline__ void lds_transforms_f(f2 (&v)[16], f2 *b, const float
 } // namespace sstk
 
 template <int LOGN>
-__global__ __launch_bounds__(256, 3) void xcorr_screen_pass_stk(const FusedParams p)
+// (second launch-bound: waves per SIMD -- three 256-thread workgroups per CU; the 512-thread build of n = 8192 needs
+// 256 registers (166 spilled at 128): one workgroup per CU, as the fp64 kernel)
+__global__ __launch_bounds__(((1 << LOGN) / 16 > 256 ? (1 << LOGN) / 16 : 256), ((1 << LOGN) / 16 > 256 ? 2 : 3))
+void xcorr_screen_pass_stk(const FusedParams p)
 {
     using namespace occ4;
     using namespace sstk;
     constexpr int n = 1 << LOGN;
-    constexpr int S = n / 16;      // threads per pair
-    constexpr int G = 256 / S;     // pairs per workgroup iteration
-    constexpr int ROWS = S / 16;   // 16-lane rows per pair
+    constexpr int S = n / 16;                 // threads per pair
+    constexpr int G = S >= 256 ? 1 : 256 / S; // pairs per workgroup iteration
+    constexpr int TPB = S * G;                // 256 (n <= 4096) or 512 (n = 8192)
+    constexpr int ROWS = S / 16;              // 16-lane rows per pair
     constexpr int BUF = n + n / 16;
-    static_assert(LOGN >= 9 && LOGN <= 11, "fp32 Stockham screening pass: n = 512, 1024, 2048");
+    static_assert((LOGN >= 9 && LOGN <= 11) || LOGN == 13, "fp32 Stockham screening pass: n = 512, 1024, 2048, 8192");
     __shared__ f2 buf[G * BUF];
-    __shared__ double red[16 * 4];  // per 16-lane row: {sum dA, sum dA^2, sum dB, sum dB^2}
-    __shared__ float rmax[16 * 2];  // per row: fp32 maxima of |cc| (A, B)
+    __shared__ double red[(TPB / 16) * 4];  // per 16-lane row: {sum dA, sum dA^2, sum dB, sum dB^2}
+    __shared__ float rmax[(TPB / 16) * 2];  // per row: fp32 maxima of |cc| (A, B)
     const int t = threadIdx.x;
     const int g = t / S, j = t % S;
     const int row = t >> 4;
@@ -383,10 +387,12 @@ __global__ __launch_bounds__(256, 3) void xcorr_screen_pass_stk(const FusedParam
 template <int LOGN>
 static hipError_t launch_one(const FusedParams &p, int num_cus, hipStream_t stream)
 {
-    constexpr int G = 256 / ((1 << LOGN) / 16);
+    constexpr int S = (1 << LOGN) / 16;
+    constexpr int G = S >= 256 ? 1 : 256 / S;
+    constexpr int TPB = S * G;
     const long long ngroups = (p.npairs + G - 1) / G;
-    const long long grid = std::min<long long>(ngroups, (long long)num_cus * 3 * 4);
-    hipLaunchKernelGGL((xcorr_screen_pass_stk<LOGN>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    const long long grid = std::min<long long>(ngroups, (long long)num_cus * (TPB > 256 ? 1 : 3) * 4);
+    hipLaunchKernelGGL((xcorr_screen_pass_stk<LOGN>), dim3((unsigned)grid), dim3(TPB), 0, stream, p);
     return hipGetLastError();
 }
 
@@ -398,6 +404,7 @@ hipError_t launch_screen_pass_stk(const FusedParams &p, int num_cus, hipStream_t
     case 9: return launch_one<9>(p, num_cus, stream);
     case 10: return launch_one<10>(p, num_cus, stream);
     case 11: return launch_one<11>(p, num_cus, stream);
+    case 13: return launch_one<13>(p, num_cus, stream);
     default: return hipErrorInvalidValue;
     }
 }

@@ -889,7 +889,7 @@ def _screen_cases(rng, N):
     return ref, rows
 
 
-@pytest.mark.parametrize("N", [4096, 3000, 2048, 1500, 1024, 600, 512])
+@pytest.mark.parametrize("N", [8192, 5000, 4096, 3000, 2048, 1500, 1024, 600, 512])
 def test_screened_run_equals_fp64_run(muse, eng, oracle, N):
     """The filter-and-refine Run (muse_ctx_set_screening) returns the records of the all-fp64 Run: adversarial rows
     (near ties at the cut, periodic series, NaN / Inf / sigma == 0, sigmas outside the fp32 range, a far-outlier first

@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 pkg = importlib.import_module("go-muse_amd")
 eng = pkg.get_engine(0)
-for N in (512, 700, 1024, 2048, 4096):
+for N in [int(a) for a in sys.argv[1:]] or (512, 700, 1024, 2048, 4096, 8192):
     M = int(2e9 // (8 * N))
     dg, ref = pkg.DeviceGroup.synthetic(eng, M, N)
     db = pkg.DeviceBatch(eng, dg, ref)
