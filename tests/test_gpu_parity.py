@@ -928,7 +928,7 @@ def test_screened_run_equals_fp64_run(muse, eng, oracle, N):
         db.close()
 
 
-@pytest.mark.parametrize("N", [4096, 2500, 2048, 1100, 512])
+@pytest.mark.parametrize("N", [8192, 6000, 4096, 2500, 2048, 1100, 512])
 def test_screening_estimates_stay_inside_the_bound(muse, eng, oracle, N):
     """|fp32 estimate - fp64 score| <= E for every series the pass did not hand to the fp64 kernel, with E the bound
     the selection assumes; the flags cover the exact lag (inside / outside MaxLag) and the exact sign."""
