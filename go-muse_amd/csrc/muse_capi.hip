@@ -1158,7 +1158,7 @@ static bool screen_eligible(const muse_batch *b, const int32_t *group_id, int32_
     const muse_ctx *ctx = b->ctx;
     const int64_t M = b->g->M;
     (void)group_id; // label groups are handled too (per-group bounds: reduce_kernels.hip, screen_g1..g4)
-    const bool length_ok = b->n == 8192 || b->n == 4096 || b->n == 2048 || b->n == 1024 || b->n == 512; // (N > n/2 by construction)
+    const bool length_ok = b->n >= 512 && b->n <= 65536; // every FFT length with a tuned kernel (N > n/2 by construction)
     return !already_scored && ctx->screening && ctx->variant == 0 && length_ok &&
            b->xcf && top_n >= 1 && top_n <= TOPN_DEVICE_MAX && M / 2 < 0x7fffffffLL &&
            (ctx->screen_min_rows > 0 ? M >= ctx->screen_min_rows : M * (int64_t)b->n >= (int64_t)32768 * 4096) &&
@@ -1179,8 +1179,9 @@ static double screen_error_scaled(double xmax, int n)
     // lag through the correlation of the sample indicator with the reference, |c1| <= sqrt(N) ||xs||_2 ~ 1, times
     // 2^-24 * 8 sigma * 1.4143 / sigma < 1e-6 (for N == n that correlation is the reference's sum: 0).
     const double u = 5.9604644775390625e-08; // 2^-24
-    // (n = 8192 takes four passes per transform instead of three: 320 instead of 256)
-    return (n > 4096 ? 320.0 : 256.0) * u * (2.0 * std::sqrt((double)n)) * xmax + 3e-6; // ||z||_2 <= sqrt(2 (N-1)) * 1.4143 <= 2 sqrt(n): 128 at n = 4096
+    // (n = 8192 takes four passes per transform instead of three: 320 instead of 256; the four-step kernels of
+    // n >= 16384 a radix-R1 sweep with single-entry twiddles plus the three passes of a 4096-point row: 384)
+    return (n > 8192 ? 384.0 : n > 4096 ? 320.0 : 256.0) * u * (2.0 * std::sqrt((double)n)) * xmax + 3e-6; // ||z||_2 <= sqrt(2 (N-1)) * 1.4143 <= 2 sqrt(n): 128 at n = 4096
 }
 
 // The filter-and-refine scoring in three steps, so that the screening pass can be one launch per batch or one launch
@@ -1332,6 +1333,11 @@ static int score_screened(muse_batch *b, int32_t max_lag, int32_t top_n, double 
     int rc = screen_prepare(b, top_n, gid_dev, G, plan);
     if (rc)
         return rc;
+    // long series work in the context's scratch buffer: its pointer must not be swapped (a concurrent
+    // muse_batch_create growing it) between reading it and enqueueing the launches (as in muse_batch_score)
+    std::unique_lock<std::mutex> scratch_lock(ctx->stage_mu, std::defer_lock);
+    if (b->n >= GENERIC_LDS_MAX_N)
+        scratch_lock.lock();
     const FusedParams p = screen_pass_params(b, max_lag, plan);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->timing) {
@@ -1363,8 +1369,8 @@ extern "C" int muse_batch_screen_estimates(muse_batch *b, int32_t max_lag, doubl
 {
     if (!b)
         return fail(MUSE_ERR_INVALID, "NULL batch");
-    if ((b->n != 8192 && b->n != 4096 && b->n != 2048 && b->n != 1024 && b->n != 512) || !b->xcf)
-        return fail(MUSE_ERR_UNSUPPORTED, "the screening pass is built for series of length 257 .. 8192");
+    if (b->n < 512 || b->n > 65536 || !b->xcf)
+        return fail(MUSE_ERR_UNSUPPORTED, "the screening pass is built for series of length 257 .. 65536");
     muse_ctx *ctx = b->ctx;
     int rc = use_device(ctx);
     if (rc)

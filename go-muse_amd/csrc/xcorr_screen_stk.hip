@@ -48,6 +48,17 @@ __device__ __forceinline__ void dft8f(f2 &x0, f2 &x1, f2 &x2, f2 &x3, f2 &x4, f2
 template <int R>
 __device__ __forceinline__ void dft_small_f(f2 (&v)[16])
 {
+    if (R == 16) { // one radix-16 DFT, un-permuted to natural order (register renaming only)
+        dft16f(v);
+        f2 w[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            w[r] = v[P16(r)];
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            v[r] = w[r];
+        return;
+    }
     constexpr int Q = 16 / R;
 #pragma unroll
     for (int m = 0; m < Q; m++) {
@@ -384,6 +395,247 @@ void xcorr_screen_pass_stk(const FusedParams p)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// n = 16384, 32768, 65536 (n = R1 * 4096, R1 = 4, 8, 16): the four-step structure of xcorr_fused_stk_4step
+// (xcorr_stockham.hip) in fp32.  One n-element fp32 slice of FusedParams::gscratch per workgroup (8 n bytes: a quarter of
+// the fp64 kernel's two slices), 34.8 KB of LDS for the on-chip 4096-point rows:
+//   sweep 0: rows -> fp64 shifted statistics, provisional fp32 copy of d = x - x[0] into the slice;
+//   sweep 1: centre + scale, radix R1 over m1, twiddle W_n^(m2 k1), in place;
+//   rows:    each of the R1 rows of 4096 points through lds_transforms_f<12> (times xcf[k1 + R1 k2]), in place;
+//   sweep 2: twiddle + radix R1 over k1 -> cc; first time for the maxima, second time (the slice is read again, the
+//            cheapest way to see every lag once the maximum is known) for the flags and the estimate.
+namespace sstk {
+
+template <int K>
+__device__ __forceinline__ void block_sum_f64(double (&q)[K], double *red, const int lane, const int wave)
+{
+#pragma unroll
+    for (int k = 0; k < K; k++)
+        q[k] = wave_sum_dpp(q[k]);
+    __syncthreads(); // red free
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < K; k++)
+            red[wave * K + k] = q[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; k++)
+        q[k] = (red[k] + red[K + k]) + (red[2 * K + k] + red[3 * K + k]);
+}
+
+} // namespace sstk
+
+template <int LOGN>
+__global__ __launch_bounds__(256, 3) void xcorr_screen_pass_4step(const FusedParams p)
+{
+    using namespace occ4;
+    using namespace sstk;
+    constexpr int n = 1 << LOGN;
+    constexpr int S = n / 16;
+    constexpr int CH = S / 256;
+    constexpr int R1 = n / 4096;
+    constexpr int Q1 = 16 / R1;
+    static_assert(LOGN >= 14 && LOGN <= 16, "fp32 four-step screening pass: n = 16384 ... 65536");
+    __shared__ f2 buf[4096 + 256];
+    __shared__ double red[16];
+    __shared__ float redf[8];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    f2 *const Y = reinterpret_cast<f2 *>(p.gscratch) + (size_t)blockIdx.x * (size_t)n;
+    const int N = p.N, pad = n - N;
+    const double invN = 1.0 / (double)N, invNm1 = 1.0 / (double)(N - 1);
+    const float2 *__restrict__ twm = p.twmf;
+    const float window = (float)p.screen_delta;
+    const int max_lag = p.scr_max_lag;
+
+    for (long long pair = blockIdx.x; pair < p.npairs; pair += gridDim.x) {
+        const long long rA = 2 * pair, rB = rA + 1;
+        const bool hasB = rB < p.M;
+        const double *__restrict__ ra = p.rows + rA * p.stride;
+        const double *__restrict__ rb = p.rows + (hasB ? rB : rA) * p.stride;
+        const double KA = ra[0], KB = rb[0];
+        // twiddle of sweeps 1 and 2: v[m + r Q1] *= W_n^(m2 r), m2 = j + m S (single rounded table entries)
+        const auto twiddle_rows = [&](f2 (&v)[16], const int j) __attribute__((always_inline)) {
+#pragma unroll
+            for (int m = 0; m < Q1; m++) {
+                const int m2 = j + m * S;
+#pragma unroll
+                for (int r = 1; r < R1; r++) {
+                    const int e = (m2 * r * (65536 / n)) & 65535;
+                    const float2 w = twm[e & 32767];
+                    const f2 ws = e >= 32768 ? mk2(-w.x, -w.y) : mk2(w.x, w.y);
+                    v[m + r * Q1] = cmulf(v[m + r * Q1], ws);
+                }
+            }
+        };
+        // ---- sweep 0: statistics (fp64), provisional fp32 copy into the slice
+        double q[4] = {0.0, 0.0, 0.0, 0.0};
+        __syncthreads(); // the previous pair's last reads of the slice are done
+#pragma clang loop unroll(disable)
+        for (int ch = 0; ch < CH; ch++) {
+            const int j = t + 256 * ch;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int e = j + i * S - pad;
+                const int ec = e < 0 ? 0 : e; // a pad position loads x[0]: d = 0 without a mask
+                const double da = __builtin_nontemporal_load(ra + ec) - KA, db = __builtin_nontemporal_load(rb + ec) - KB;
+                Y[j + i * S] = mk2((float)da, (float)db);
+                q[0] += da;
+                q[1] = fma(da, da, q[1]);
+                q[2] += db;
+                q[3] = fma(db, db, q[3]);
+            }
+        }
+        block_sum_f64<4>(q, red, lane, wave); // (its barriers also order sweep 0 before sweep 1)
+        const double mA = q[0] * invN, mB = q[2] * invN;
+        const double varA = (q[1] - q[0] * q[0] * invN) * invNm1, varB = (q[3] - q[2] * q[2] * invN) * invNm1;
+        const bool nanA = !__builtin_isfinite(varA), nanB = !__builtin_isfinite(varB);
+        const bool zeroA = !nanA && !(varA > 0.0), zeroB = !nanB && !(varB > 0.0);
+        const int eA = (int)((__double_as_longlong(varA) >> 52) & 0x7ff) - 1023;
+        const int eB = (int)((__double_as_longlong(varB) >> 52) & 0x7ff) - 1023;
+        const bool redoA = !(zeroA || nanA) && (eA > 200 || eA < -200 || mA * mA > 64.0 * varA);
+        const bool redoB = !(zeroB || nanB) && (eB > 200 || eB < -200 || mB * mB > 64.0 * varB);
+        const bool offA = zeroA || nanA || redoA, offB = zeroB || nanB || redoB || !hasB;
+        const float sclA = offA ? 0.f : __int_as_float((127 - (eA >> 1)) << 23);
+        const float sclB = offB ? 0.f : __int_as_float((127 - (eB >> 1)) << 23);
+        const float mAf = offA ? 0.f : (float)mA, mBf = offB ? 0.f : (float)mB;
+        // ---- sweep 1: centre + scale, radix R1 over m1, twiddle, in place
+#pragma clang loop unroll(disable)
+        for (int ch = 0; ch < CH; ch++) {
+            const int j = t + 256 * ch;
+            f2 v[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const bool valid = j + i * S - pad >= 0;
+                const f2 d = Y[j + i * S];
+                v[i] = mk2((valid && !offA) ? (d.x - mAf) * sclA : 0.f, (valid && !offB) ? (d.y - mBf) * sclB : 0.f);
+            }
+            dft_small_f<R1>(v);
+            twiddle_rows(v, j);
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                Y[j + i * S] = v[i];
+        }
+        __syncthreads();
+        // ---- rows: k1 = 0 .. R1-1, 4096 points each, on chip
+#pragma clang loop unroll(disable)
+        for (int k1 = 0; k1 < R1; k1++) {
+            f2 *const row = Y + k1 * 4096;
+            f2 v[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                v[i] = row[t + 256 * i];
+            lds_transforms_f<12>(v, buf, twm, t, [&](int jj, int r) __attribute__((always_inline)) {
+                const float2 x = p.xcf[k1 + R1 * (jj + 256 * r)];
+                return mk2(x.x, x.y);
+            });
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                row[t + 256 * i] = v[i];
+        }
+        __syncthreads();
+        // ---- sweep 2, first time: the fp32 maxima
+        float ma = 0.f, mb = 0.f;
+#pragma clang loop unroll(disable)
+        for (int ch = 0; ch < CH; ch++) {
+            const int j = t + 256 * ch;
+            f2 v[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                v[i] = Y[j + i * S];
+            twiddle_rows(v, j);
+            dft_small_f<R1>(v);
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                ma = fmaxf(ma, fabsf(v[i].x));
+                mb = fmaxf(mb, fabsf(v[i].y));
+            }
+        }
+        ma = wave_max_f32_dpp(ma);
+        mb = wave_max_f32_dpp(mb);
+        if (lane == 0) {
+            redf[wave] = ma;
+            redf[4 + wave] = mb;
+        }
+        __syncthreads();
+        const float MA = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
+        const float MB = fmaxf(fmaxf(redf[4], redf[5]), fmaxf(redf[6], redf[7]));
+        // ---- sweep 2, second time: every lag within the window of the maximum.  The values are RECOMPUTED here, by a
+        // second copy of the same code: the compiler is free to contract multiply-adds differently in the two copies, so
+        // the holder of the maximum is found with a one-part-in-a-million tolerance instead of an equality (several
+        // threads may then report; any of their values is the maximum to 1e-6 relative, far inside E)
+        {
+            const float thA = MA - window, thB = MB - window;
+            const float topA = MA * 0.999999f, topB = MB * 0.999999f;
+            unsigned fA = 0u, fB = 0u;
+#pragma clang loop unroll(disable)
+            for (int ch = 0; ch < CH; ch++) {
+                const int j = t + 256 * ch;
+                f2 v[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++)
+                    v[i] = Y[j + i * S];
+                twiddle_rows(v, j);
+                dft_small_f<R1>(v);
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const float xa = v[i].x, xb = v[i].y;
+                    const bool ha = fabsf(xa) >= thA, hb = fabsf(xb) >= thB;
+                    if (ha || hb) {
+                        const int idx = j + i * S;
+                        const int lg = idx > n / 2 ? idx - n : idx;
+                        const unsigned in = (lg < 0 ? -lg : lg) <= max_lag ? SCR_IN : SCR_OUT;
+                        if (ha)
+                            fA |= in | (xa > 0.f ? SCR_POS : 0u) | (xa < 0.f ? SCR_NEG : 0u);
+                        if (hb)
+                            fB |= in | (xb > 0.f ? SCR_POS : 0u) | (xb < 0.f ? SCR_NEG : 0u);
+                        if (ha && fabsf(xa) >= topA && !offA) {
+                            p.mv[rA] = (double)xa * __longlong_as_double((long long)(1023 + (eA >> 1)) << 52);
+                            p.lag[rA] = lg;
+                        }
+                        if (hb && fabsf(xb) >= topB && !offB) {
+                            p.mv[rB] = (double)xb * __longlong_as_double((long long)(1023 + (eB >> 1)) << 52);
+                            p.lag[rB] = lg;
+                        }
+                    }
+                }
+            }
+            if (fA && !offA)
+                atomicOr(&p.scr_flags[rA], fA);
+            if (fB && !offB && hasB)
+                atomicOr(&p.scr_flags[rB], fB);
+            if (t == 0) {
+                p.scr_var[rA] = varA;
+                if (offA) {
+                    p.mv[rA] = nanA ? __builtin_nan("") : 0.0;
+                    p.lag[rA] = 0;
+                    atomicOr(&p.scr_flags[rA], nanA ? SCR_NAN : (redoA ? SCR_REFINE : SCR_IN));
+                }
+                if (hasB) {
+                    p.scr_var[rB] = varB;
+                    if (offB) {
+                        p.mv[rB] = nanB ? __builtin_nan("") : 0.0;
+                        p.lag[rB] = 0;
+                        atomicOr(&p.scr_flags[rB], nanB ? SCR_NAN : (redoB ? SCR_REFINE : SCR_IN));
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int LOGN>
+static hipError_t launch_4step(const FusedParams &p, int num_cus, hipStream_t stream)
+{
+    if (!p.gscratch)
+        return hipErrorInvalidValue;
+    // (the fp64 kernels' scratch: 2 x 2 slices of 2 n double2 per CU = room for sixteen n-element fp32 slices per CU)
+    const long long grid = std::min<long long>(p.npairs, (long long)num_cus * 3);
+    hipLaunchKernelGGL((xcorr_screen_pass_4step<LOGN>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
 template <int LOGN>
 static hipError_t launch_one(const FusedParams &p, int num_cus, hipStream_t stream)
 {
@@ -405,6 +657,9 @@ hipError_t launch_screen_pass_stk(const FusedParams &p, int num_cus, hipStream_t
     case 10: return launch_one<10>(p, num_cus, stream);
     case 11: return launch_one<11>(p, num_cus, stream);
     case 13: return launch_one<13>(p, num_cus, stream);
+    case 14: return launch_4step<14>(p, num_cus, stream);
+    case 15: return launch_4step<15>(p, num_cus, stream);
+    case 16: return launch_4step<16>(p, num_cus, stream);
     default: return hipErrorInvalidValue;
     }
 }

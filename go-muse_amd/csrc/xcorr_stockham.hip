@@ -676,7 +676,10 @@ __global__ __launch_bounds__(256, 2) void xcorr_fused_stk_4step(const FusedParam
     const double invN = 1.0 / (double)N, invNm1 = 1.0 / (double)(N - 1);
     const double2 *__restrict__ twm = p.twm;
 
-    for (long long pair = blockIdx.x; pair < p.npairs; pair += gridDim.x) {
+    // optional indirection (filter-and-refine Run): process pair_list[0 .. *pair_count) instead of every pair
+    const long long total = p.pair_list ? (long long)*p.pair_count : p.npairs;
+    for (long long slot = blockIdx.x; slot < total; slot += gridDim.x) {
+        const long long pair = p.pair_list ? p.pair_list[slot] : slot;
         const long long rA = 2 * pair;
         const bool hasB = rA + 1 < p.M;
         const double *__restrict__ ra = p.rows + rA * p.stride;

@@ -91,14 +91,14 @@ int muse_ctx_device_info(muse_ctx *ctx, char *name, int32_t name_cap,
 int muse_ctx_set_kernel(muse_ctx *ctx, int32_t variant);
 /* Filter-and-refine Run (on by default; MUSE_HIP_SCREEN_RUN=0 / enable = 0 turns it off; enable = 1: for Runs over
  * groups of >= 32768 * 4096 samples after padding, where it starts to pay; enable = n > 1: for Runs over >= n series).  When enabled, a
- * muse_batch_run / muse_batch_run_shard (with or without label groups) over that many series of length 257 .. 8192 (FFT
- * lengths 512 .. 8192) under automatic kernel selection screens every series with an fp32 transform (a bound E on its error is derived from the reference's
+ * muse_batch_run / muse_batch_run_shard (with or without label groups) over that many series of length 257 .. 65536 (FFT
+ * lengths 512 .. 65536) under automatic kernel selection screens every series with an fp32 transform (a bound E on its error is derived from the reference's
  * spectrum), re-evaluates in fp64 exactly those rows whose optimistic selection key reaches the top_n-th best
  * pessimistic key, and selects among the re-evaluated rows only: the records returned are the ones the all-fp64 Run
  * returns.  muse_batch_read_scores after such a Run re-scores every row in fp64 first. */
 int muse_ctx_set_screening(muse_ctx *ctx, int32_t enable);
 /* Test / measurement hook: runs the screening pass of the filter-and-refine Run alone (MaxLag = max_lag, TopN = 1, no
- * other filter) over a batch of series of length 257 .. 8192 and returns, per series, the fp32 estimate of the signed score,
+ * other filter) over a batch of series of length 257 .. 65536 and returns, per series, the fp32 estimate of the signed score,
  * the pass's flag word (bit 0 / 1: a possible argmax has |lag| <= / > max_lag; bit 2 / 3: a possible argmax value is
  * > 0 / < 0; bit 4: fp32 not trusted, must be re-evaluated; bit 5: the exact score is NaN; bit 31: the row was
  * re-evaluated and `estimate` holds its fp64 score) and the bound *E (score units) that the selection assumes on

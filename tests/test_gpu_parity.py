@@ -865,7 +865,7 @@ def _screen_cases(rng, N):
     ref = np.zeros(N)
     ref[N // 5:N // 3] = 1.0
     ref += 0.1 * rng.standard_normal(N)
-    M = 17000
+    M = 17000 if N <= 8192 else 1500        # (long series: fewer rows, the tests lower the path's threshold)
     rows = rng.standard_normal((M, N))
     t = np.arange(N)
     for i in range(0, M, 3):                                        # planted matches: all lags, both signs, all strengths
@@ -889,7 +889,7 @@ def _screen_cases(rng, N):
     return ref, rows
 
 
-@pytest.mark.parametrize("N", [8192, 5000, 4096, 3000, 2048, 1500, 1024, 600, 512])
+@pytest.mark.parametrize("N", [65536, 40000, 16384, 8192, 5000, 4096, 3000, 2048, 1500, 1024, 600, 512])
 def test_screened_run_equals_fp64_run(muse, eng, oracle, N):
     """The filter-and-refine Run (muse_ctx_set_screening) returns the records of the all-fp64 Run: adversarial rows
     (near ties at the cut, periodic series, NaN / Inf / sigma == 0, sigmas outside the fp32 range, a far-outlier first
@@ -902,7 +902,7 @@ def test_screened_run_equals_fp64_run(muse, eng, oracle, N):
     db = muse.DeviceBatch(eng, dg, ref)
     lag, mv = db.scores()
     try:
-        eng.set_screening(True, min_rows=16384)
+        eng.set_screening(True, min_rows=1000)
         first = True
         for max_lag in (15, 0, 2048, 4096, 100):
             for top_n, thr, sign, absf in ((20, 0.0, 0, True), (1, 0.0, 0, True), (200, 0.0, 0, True), (20, 0.3, 0, True),
@@ -928,7 +928,7 @@ def test_screened_run_equals_fp64_run(muse, eng, oracle, N):
         db.close()
 
 
-@pytest.mark.parametrize("N", [8192, 6000, 4096, 2500, 2048, 1100, 512])
+@pytest.mark.parametrize("N", [65536, 20000, 8192, 6000, 4096, 2500, 2048, 1100, 512])
 def test_screening_estimates_stay_inside_the_bound(muse, eng, oracle, N):
     """|fp32 estimate - fp64 score| <= E for every series the pass did not hand to the fp64 kernel, with E the bound
     the selection assumes; the flags cover the exact lag (inside / outside MaxLag) and the exact sign."""
@@ -940,7 +940,7 @@ def test_screening_estimates_stay_inside_the_bound(muse, eng, oracle, N):
     worst = 0.0
     for max_lag in (15, 700):
         est, flags, E = db.screen_estimates(max_lag)
-        assert 0 < E < 5e-3
+        assert 0 < E < 2e-2      # (grows with sqrt(n): 1.2e-2 * max|X| at n = 65536)
         refined = (flags >> 31) & 1 == 1
         nan = np.isnan(mv)
         assert np.all((flags[nan] & 32) != 0) and np.all((flags[~nan] & 32) == 0)
