@@ -1026,13 +1026,14 @@ def test_screened_run_fuzz_filters_and_smooth_series(muse, eng, oracle):
     eng.set_screening(True)
 
 
-def test_screened_run_with_label_groups(muse, eng, oracle):
+@pytest.mark.parametrize("N", [4096, 1000, 20000])
+def test_screened_run_with_label_groups(muse, eng, oracle, N):
     """Grouped Runs (Batch.Run(groupByLabels)) on the filter-and-refine path: per-group bounds decide which members
     are re-evaluated.  Group maps from a handful of large groups to thousands of small ones, empty groups, groups
     whose first member is NaN, and every filter; expected records: the oracle's Results over the fp64 scores."""
     rng = np.random.default_rng(4242)
-    N, M = 4096, 16600
-    eng.set_screening(True, min_rows=16384)
+    M = 16600 if N <= 4096 else 2400
+    eng.set_screening(True, min_rows=1000)
     ref = rng.standard_normal(N)
     rows = rng.standard_normal((M, N))
     for i in rng.integers(0, M, size=M // 3):
