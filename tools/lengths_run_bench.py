@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT)
 pkg = importlib.import_module("go-muse_amd")
 eng = pkg.get_engine(0)
 for N in [int(a) for a in sys.argv[1:]] or (512, 700, 1024, 2048, 4096, 8192):
-    M = int(2e9 // (8 * N))
+    M = int(float(os.environ.get("GROUP_GB", "2")) * 1e9 // (8 * N))
     dg, ref = pkg.DeviceGroup.synthetic(eng, M, N)
     db = pkg.DeviceBatch(eng, dg, ref)
     res = {}
