@@ -1275,9 +1275,10 @@ static int screen_prepare(muse_batch *b, int32_t top_n, const int *gid_dev, int6
     return MUSE_OK;
 }
 
-static FusedParams screen_pass_params(muse_batch *b, int32_t max_lag, const ScreenPlan &plan)
+static FusedParams screen_pass_params(muse_batch *b, int32_t max_lag, const ScreenPlan &plan, bool need_sign = true)
 {
     FusedParams p = base_params(b);
+    p.scr_need_sign = need_sign ? 1 : 0;
     p.scr_flags = b->scr_flags;
     p.scr_var = b->scr_var;
     p.scr_max_lag = max_lag;
@@ -1338,7 +1339,8 @@ static int score_screened(muse_batch *b, int32_t max_lag, int32_t top_n, double 
     std::unique_lock<std::mutex> scratch_lock(ctx->stage_mu, std::defer_lock);
     if (b->n >= GENERIC_LDS_MAX_N)
         scratch_lock.lock();
-    const FusedParams p = screen_pass_params(b, max_lag, plan);
+    // (Batch.Run filters the sign of |score|, Muse.Run that of the signed score: only the latter needs the pass's sign flags)
+    const FusedParams p = screen_pass_params(b, max_lag, plan, sign_filter != 0 && !abs_scores);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->timing) {
         HIP_TRY(hipEventCreate(&e0));

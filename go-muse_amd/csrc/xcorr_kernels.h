@@ -54,6 +54,7 @@ struct FusedParams {
     unsigned *scr_flags; // screening pass (xcorr_screen_pass_n4096): per-row SCR_* bits, OR-ed in
     double *scr_var;     // screening pass: per-row sample variance (the estimate in mv is cc32 * 2^e: score = mv / sqrt(var))
     int scr_max_lag;     // screening pass: the Run's MaxLag (classifies the possible argmax lags)
+    int scr_need_sign;   // screening pass (n = 4096): 0 = the Run's filters never look at the sign of a score
     int *ovf_count;      // pairs with too many candidates: redone by the fp64 kernel
     int *work_counter;   // dynamic pair hand-out (xcorr_r16_fast.hip, DYN): zeroed before the launch
     int tune;            // experiment bits (MUSE_HIP_FAST_TUNE); 0 in production

@@ -860,10 +860,11 @@ struct NoHook {
 };
 // forward fp32 FFT; pass-1 factors W_4096^(k t) from four per-thread base powers W^t, W^2t, W^4t, W^8t
 // (every factor is a product of at most four correctly rounded table entries);
-// `mid` runs between the first transpose and the second pass (the pass kernel issues half of its row prefetch there)
-template <bool MULXC, typename F = NoHook>
+// `mid` runs between the first transpose and the second pass, `late` between the second transpose and the last
+// butterflies (the pass kernel reduces the next pair's first series and requests its second one there)
+template <bool MULXC, typename F = NoHook, typename L = NoHook>
 __device__ __forceinline__ void fft4096b(f2 (&v)[16], f2 *xbuf, const f2 *tw2s, const f2 w1, const f2 w2, const f2 w4,
-                                         const f2 w8, const f2 (&xq)[16], const int t, F mid = F())
+                                         const f2 w8, const f2 (&xq)[16], const int t, F mid = F(), L late = L())
 {
     dft16f(v);
     {
@@ -896,6 +897,9 @@ __device__ __forceinline__ void fft4096b(f2 (&v)[16], f2 *xbuf, const f2 *tw2s, 
             v[P16(k)] = cmulf(v[P16(k)], tw2s[k * 16 + lo]);
     }
     exchange<true>(v, xbuf, t);
+    fence();
+    late();
+    fence();
     dft16f(v);
     f2 w[16];
 #pragma unroll
@@ -908,13 +912,15 @@ __device__ __forceinline__ void fft4096b(f2 (&v)[16], f2 *xbuf, const f2 *tw2s, 
 
 } // namespace scr
 
-template <int WPC, bool TIMING = false, bool SPLIT = true, bool PADDED = false>
+// NARROW: 0 <= MaxLag < 256 (only a thread's elements 0 and 15 can be lags inside MaxLag); SIGN: the Run's filters look
+// at the sign of a score (SCR_POS / SCR_NEG are computed).  Both are known to the launcher.
+template <int WPC, bool TIMING = false, bool PADDED = false, bool NARROW = true, bool SIGN = true>
 __global__ __launch_bounds__(SCR_THREADS, WPC) void xcorr_screen_pass_n4096(const FusedParams p)
 {
     using namespace scr;
     __shared__ f2 xbuf[SCR_XBUF];
     __shared__ f2 tw2s[256];
-    __shared__ double red[24]; // [0,16) statistics; [16,20): per wave fp32 maxima (A: 4 floats, B: 4 floats)
+    __shared__ double red[32]; // [0,16) statistics; [16,32): 32 floats, the end phase's per-wave maxima
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int pad = PADDED ? 4096 - p.N : 0; // PADDED: 2048 < N < 4096, leading zeros (xcorr.go:176-181)
@@ -936,15 +942,24 @@ __global__ __launch_bounds__(SCR_THREADS, WPC) void xcorr_screen_pass_n4096(cons
     PhaseClock<TIMING> clk;
     clk.start();
     long long pair = blockIdx.x; // the launcher never starts more workgroups than pairs
-    double ra[16], rb[16], kA, kB;
-    auto issue = [&](double (&r)[16], double &k0, const double *row) {
+    // The next pair's rows come in ONE SERIES AT A TIME through a single 32-register fp64 buffer: series A is requested
+    // behind the first transform (after its spectrum factors: vmcnt is in-order) and reduced to fp32 + sums next to the
+    // second transform's last butterflies, where series B is requested; B is reduced at the top of the next iteration.
+    // (Both series at once cost 64 registers: 8.5 ms against 8.0, tools/ablate/screen_w4.hip.)
+    double raw[16], k0, sA1, sA2;
+    float na[16];
+    auto issue = [&](const double *row) {
         if (PADDED)
-            issue_series_padded(r, k0, row, t, pad);
+            issue_series_padded(raw, k0, row, t, pad);
         else
-            issue_series(r, k0, row, t);
+            issue_series(raw, k0, row, t);
     };
-    issue(ra, kA, p.rows + 2 * pair * p.stride);
-    issue(rb, kB, p.rows + (2 * pair + 1 < p.M ? 2 * pair + 1 : 2 * pair) * p.stride);
+    issue(p.rows + 2 * pair * p.stride);
+    fence();
+    reduce_series(raw, k0, na, sA1, sA2);
+    fence();
+    issue(p.rows + (2 * pair + 1 < p.M ? 2 * pair + 1 : 2 * pair) * p.stride);
+    fence();
     for (; pair < p.npairs; pair += gridDim.x) {
         const long long rA = 2 * pair, rB = rA + 1;
         const bool hasB = rB < p.M;
@@ -954,20 +969,12 @@ __global__ __launch_bounds__(SCR_THREADS, WPC) void xcorr_screen_pass_n4096(cons
         if (TIMING)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         clk.template stamp<0>();
-        // ---- rows arrive: shifted fp64 sums + provisional fp32 copy; the fp64 samples are dropped here
-        float na[16], nb[16];
+        // ---- series B arrives: shifted fp64 sums + provisional fp32 copy; the fp64 samples are dropped here
+        float nb[16];
         double q[4];
-        reduce_series(ra, kA, na, q[0], q[1]);
-        reduce_series(rb, kB, nb, q[2], q[3]);
-        fence();
-        // the batch's spectrum factors for the first transform's last pass, while no HBM load is in flight
-        f2 xq[16];
-        {
-            const Tw1FetchF fetch{p.xcf, t};
-#pragma unroll
-            for (int k = 0; k < 16; k++)
-                xq[k] = fetch(k);
-        }
+        q[0] = sA1;
+        q[1] = sA2;
+        reduce_series(raw, k0, nb, q[2], q[3]);
         fence();
 #pragma unroll
         for (int k = 0; k < 4; k++)
@@ -1011,98 +1018,123 @@ __global__ __launch_bounds__(SCR_THREADS, WPC) void xcorr_screen_pass_n4096(cons
             }
         }
         clk.template stamp<1>();
+        // the batch's spectrum factors for the first transform's last pass, while no HBM load is in flight
+        fence();
+        f2 xq[16];
+        {
+            const Tw1FetchF fetch{p.xcf, t};
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                xq[k] = fetch(k);
+        }
+        fence();
         fft4096b<true>(v, xbuf, tw2s, w1, w2, w4, w8, xq, t);
         clk.template stamp<2>();
         // ---- the next pair streams in behind the second transform (no other global load until it is consumed)
         fence();
-        issue(ra, kA, p.rows + nA * p.stride);
+        issue(p.rows + nA * p.stride);
         fence();
-        if (!SPLIT) { // (experiment: the whole prefetch in one burst)
-            issue(rb, kB, p.rows + nB * p.stride);
-            fence();
-            fft4096b<false>(v, xbuf, tw2s, w1, w2, w4, w8, xq, t);
-        } else {
+        {
             const double *rowB = p.rows + nB * p.stride;
-            fft4096b<false>(v, xbuf, tw2s, w1, w2, w4, w8, xq, t, [&]() { issue(rb, kB, rowB); });
+            fft4096b<false>(v, xbuf, tw2s, w1, w2, w4, w8, xq, t, NoHook(), [&]() {
+                reduce_series(raw, k0, na, sA1, sA2);
+                fence();
+                issue(rowB);
+            });
         }
         clk.template stamp<3>();
-        // ---- fp32 maximum of |cc| per series (which of several equal maxima reports the estimate does not matter:
-        // the selection works from the flags of ALL lags inside the window, never from the fp32 lag)
-        float ma = 0.f, mb = 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            ma = fmaxf(ma, fabsf(v[k].x));
-            mb = fmaxf(mb, fabsf(v[k].y));
-        }
-        ma = wave_max_f32_dpp(ma);
-        mb = wave_max_f32_dpp(mb);
-        if (lane == 0) {
-            redf[wave] = ma;
-            redf[4 + wave] = mb;
-        }
-        lds_barrier();
-        const float MA = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
-        const float MB = fmaxf(fmaxf(redf[4], redf[5]), fmaxf(redf[6], redf[7]));
-        // ---- what the possible exact argmaxes look like: every lag within the window of the maximum.  Hits are rare
-        // (the argmax itself and, at most, a few neighbours): one compare + ballot per element, the classification
-        // only where a lane hits.
+        // ---- what the possible exact argmaxes look like.  Only four facts per series are needed once the maximum M is
+        // known -- is there a lag with |cc| >= M - window inside MaxLag / outside it / with cc > 0 / with cc < 0 -- so each
+        // thread folds its 16 values into maxima BEFORE the barrier (|cc| over its lags inside and outside MaxLag, cc,
+        // -cc), every wave reduces them (DPP), the partials meet in LDS behind ONE barrier and lanes 0 / 1 of wave 0 --
+        // one series each -- finish the row: flags, estimate (the maximum with its exact power-of-two scale; the selection
+        // divides by sigma), variance.  One writer per row: plain stores, no atomics.  A thread's lags inside MaxLag are
+        // its elements k <= klo and k >= khi (lag index 256 k + t); the values themselves are dead across the barrier.
         {
-            const float thA = MA - window, thB = MB - window;
-            unsigned fA = 0u, fB = 0u;
+            int to = t; // (opaque: hoisted out of the pair loop klo / khi would be carried through every transform)
+            asm volatile("" : "+v"(to));
+            const int klo = max_lag >= to ? (max_lag - to) >> 8 : -1;
+            const int khi = (4096 - max_lag - to + 255) >> 8;
+            float inA, outA, inB, outB, posA = 0.f, negA = 0.f, posB = 0.f, negB = 0.f;
+            if (NARROW) {
+                const float a0 = fabsf(v[0].x), a15 = fabsf(v[15].x), b0 = fabsf(v[0].y), b15 = fabsf(v[15].y);
+                const bool i0 = klo >= 0, i15 = khi <= 15;
+                inA = fmaxf(i0 ? a0 : -1.f, i15 ? a15 : -1.f);
+                outA = fmaxf(i0 ? -1.f : a0, i15 ? -1.f : a15);
+                inB = fmaxf(i0 ? b0 : -1.f, i15 ? b15 : -1.f);
+                outB = fmaxf(i0 ? -1.f : b0, i15 ? -1.f : b15);
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const float xa = v[k].x, xb = v[k].y;
-                const bool ha = fabsf(xa) >= thA, hb = fabsf(xb) >= thB;
-                if (__ballot(ha || hb) != 0ull) { // wave-uniform
-                    const int idx = 256 * k + t;
-                    const int lg = idx > 2048 ? idx - 4096 : idx;
-                    const unsigned in = (lg < 0 ? -lg : lg) <= max_lag ? SCR_IN : SCR_OUT;
-                    if (ha)
-                        fA |= in | (xa > 0.f ? SCR_POS : 0u) | (xa < 0.f ? SCR_NEG : 0u);
-                    if (hb)
-                        fB |= in | (xb > 0.f ? SCR_POS : 0u) | (xb < 0.f ? SCR_NEG : 0u);
-                    // the estimate itself, by the thread that holds the fp32 argmax: the fp32 value with its exact
-                    // power-of-two scale; the selection divides by sigma (scr_var)
-                    if (fabsf(xa) == MA && !offA) {
-                        p.mv[rA] = (double)xa * __longlong_as_double((long long)(1023 + (eA >> 1)) << 52);
-                        p.lag[rA] = lg;
-                    }
-                    if (fabsf(xb) == MB && !offB) {
-                        p.mv[rB] = (double)xb * __longlong_as_double((long long)(1023 + (eB >> 1)) << 52);
-                        p.lag[rB] = lg;
-                    }
+                for (int k = 1; k < 15; k++) {
+                    outA = fmaxf(outA, fabsf(v[k].x));
+                    outB = fmaxf(outB, fabsf(v[k].y));
+                }
+            } else {
+                inA = outA = inB = outB = -1.f;
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const bool in = k <= klo || k >= khi;
+                    const float aa = fabsf(v[k].x), ab = fabsf(v[k].y);
+                    inA = fmaxf(inA, in ? aa : -1.f);
+                    outA = fmaxf(outA, in ? -1.f : aa);
+                    inB = fmaxf(inB, in ? ab : -1.f);
+                    outB = fmaxf(outB, in ? -1.f : ab);
                 }
             }
-            if (__ballot((fA | fB) != 0u) != 0ull) { // waves without a hit have nothing to report
-                // OR over the wave (DPP-free: flags are 4 bits, ballots of each)
-                unsigned wA = 0u, wB = 0u;
+            if (SIGN) {
 #pragma unroll
-                for (unsigned bit = 1u; bit <= 8u; bit <<= 1) {
-                    wA |= __ballot((fA & bit) != 0u) != 0ull ? bit : 0u;
-                    wB |= __ballot((fB & bit) != 0u) != 0ull ? bit : 0u;
-                }
-                if (lane == 0) { // fire and forget
-                    if (wA && !offA)
-                        atomicOr(&p.scr_flags[rA], wA);
-                    if (wB && !offB)
-                        atomicOr(&p.scr_flags[rB], wB);
+                for (int k = 0; k < 16; k++) {
+                    posA = fmaxf(posA, v[k].x);
+                    negA = fmaxf(negA, -v[k].x);
+                    posB = fmaxf(posB, v[k].y);
+                    negB = fmaxf(negB, -v[k].y);
                 }
             }
-            if (t == 0) { // per-series constants of the estimate, and the rows fp32 has nothing to say about
-                p.scr_var[rA] = varA;
-                if (offA) {
-                    p.mv[rA] = nanA ? __builtin_nan("") : 0.0;
-                    p.lag[rA] = 0;
-                    atomicOr(&p.scr_flags[rA], nanA ? SCR_NAN : (redoA ? SCR_REFINE : SCR_IN)); // sigma == 0: score 0 at lag 0, exactly
+            // (the DPP maximum is for non-negative values: -1 "no such lag" is shifted to 0)
+            const float wiA = wave_max_f32_dpp(inA + 1.f), woA = wave_max_f32_dpp(outA + 1.f);
+            const float wiB = wave_max_f32_dpp(inB + 1.f), woB = wave_max_f32_dpp(outB + 1.f);
+            float wpA = 0.f, wnA = 0.f, wpB = 0.f, wnB = 0.f;
+            if (SIGN) {
+                wpA = wave_max_f32_dpp(posA);
+                wnA = wave_max_f32_dpp(negA);
+                wpB = wave_max_f32_dpp(posB);
+                wnB = wave_max_f32_dpp(negB);
+            }
+            if (lane == 0) {
+                redf[4 * wave + 0] = wiA;
+                redf[4 * wave + 1] = woA;
+                redf[16 + 4 * wave + 0] = wiB;
+                redf[16 + 4 * wave + 1] = woB;
+                if (SIGN) {
+                    redf[4 * wave + 2] = wpA;
+                    redf[4 * wave + 3] = wnA;
+                    redf[16 + 4 * wave + 2] = wpB;
+                    redf[16 + 4 * wave + 3] = wnB;
                 }
-                if (hasB) {
-                    p.scr_var[rB] = varB;
-                    if (offB) {
-                        p.mv[rB] = nanB ? __builtin_nan("") : 0.0;
-                        p.lag[rB] = 0;
-                        atomicOr(&p.scr_flags[rB], nanB ? SCR_NAN : (redoB ? SCR_REFINE : SCR_IN));
-                    }
+            }
+            lds_barrier();
+            if (t < 2 && (t == 0 || hasB)) {
+                const float *r = redf + 16 * t;
+                const float in = fmaxf(fmaxf(r[0], r[4]), fmaxf(r[8], r[12])) - 1.f, out = fmaxf(fmaxf(r[1], r[5]), fmaxf(r[9], r[13])) - 1.f;
+                const float M = fmaxf(in, out), th = M - window;
+                unsigned f = (in >= th ? SCR_IN : 0u) | (out >= th ? SCR_OUT : 0u);
+                bool positive = true;
+                if (SIGN) { // (cc > 0 / < 0 at a lag inside the window: its |cc| is cc or -cc itself)
+                    const float pos = fmaxf(fmaxf(r[2], r[6]), fmaxf(r[10], r[14])), neg = fmaxf(fmaxf(r[3], r[7]), fmaxf(r[11], r[15]));
+                    f |= ((pos >= th && pos > 0.f) ? SCR_POS : 0u) | ((neg >= th && neg > 0.f) ? SCR_NEG : 0u);
+                    positive = pos == M;
+                } else {
+                    f |= SCR_POS | SCR_NEG; // not looked at
                 }
+                const int e = t ? eB : eA;
+                double est = (double)(positive ? M : -M) * __longlong_as_double((long long)(1023 + (e >> 1)) << 52);
+                if (t ? offB : offA) { // the rows fp32 has nothing to say about; sigma == 0: score 0 at lag 0, exactly
+                    const bool nan = t ? nanB : nanA;
+                    est = nan ? __builtin_nan("") : 0.0;
+                    f = nan ? SCR_NAN : ((t ? redoB : redoA) ? SCR_REFINE : SCR_IN);
+                }
+                p.mv[rA + t] = est;
+                p.scr_flags[rA + t] = f;
+                p.scr_var[rA + t] = t ? varB : varA;
             }
         }
         clk.template stamp<4>();
@@ -1371,18 +1403,30 @@ hipError_t launch_screen_pass_many(const FusedParams &p, int num_cus, hipStream_
     return hipGetLastError();
 }
 
+template <bool PADDED, bool NARROW, bool SIGN>
+static void launch_pass_variant(const FusedParams &p, unsigned grid, hipStream_t stream)
+{
+    hipLaunchKernelGGL((xcorr_screen_pass_n4096<3, false, PADDED, NARROW, SIGN>), dim3(grid), dim3(SCR_THREADS), 0, stream, p);
+}
+
 hipError_t launch_screen_pass(const FusedParams &p, int num_cus, hipStream_t stream)
 {
     if (p.n != 4096 || p.N <= 2048 || p.N > 4096 || !p.scr_flags || !p.scr_var || !p.xcf)
         return hipErrorInvalidValue;
     long long grid = p.npairs;
+    // three resident workgroups per CU (168 VGPRs).  A fourth fits the data flow (tools/ablate/screen_w4.hip: 128 VGPRs)
+    // but the end phase then spills, and a spilled register reloaded behind the row prefetch costs an HBM latency.
     const long long cap = (long long)num_cus * 3;
     if (grid > cap)
         grid = cap;
-    if (p.N < 4096)
-        hipLaunchKernelGGL((xcorr_screen_pass_n4096<3, false, true, true>), dim3((unsigned)grid), dim3(SCR_THREADS), 0, stream, p);
+    const bool padded = p.N < 4096, narrow = p.scr_max_lag >= 0 && p.scr_max_lag < 256, sign = p.scr_need_sign != 0;
+    const unsigned g = (unsigned)grid;
+    if (padded)
+        narrow ? (sign ? launch_pass_variant<true, true, true>(p, g, stream) : launch_pass_variant<true, true, false>(p, g, stream))
+               : (sign ? launch_pass_variant<true, false, true>(p, g, stream) : launch_pass_variant<true, false, false>(p, g, stream));
     else
-        hipLaunchKernelGGL((xcorr_screen_pass_n4096<3, false, true, false>), dim3((unsigned)grid), dim3(SCR_THREADS), 0, stream, p);
+        narrow ? (sign ? launch_pass_variant<false, true, true>(p, g, stream) : launch_pass_variant<false, true, false>(p, g, stream))
+               : (sign ? launch_pass_variant<false, false, true>(p, g, stream) : launch_pass_variant<false, false, false>(p, g, stream));
     return hipGetLastError();
 }
 

@@ -237,9 +237,9 @@ int main(int argc, char** argv)
     if (which & 1) run("screen-only WPC=3", screen_only<3, false>, p, 256 * 3, false);
     if (which & 32) run("screen-only WPC=3, ablation 1 (-340 VALU instructions per pair)", screen_only<3, false, 1>, p, 256 * 3, false);
     if (which & 64) run("screen-only WPC=3, ablation 2 (-430 VALU instructions per pair)", screen_only<3, false, 2>, p, 256 * 3, false);
-    if (which & 2) run("library screening pass, split prefetch", xcorr_screen_pass_n4096<3, false, true>, p, 256 * 3, false);
-    if (which & 4) run("library screening pass, burst prefetch", xcorr_screen_pass_n4096<3, false, false>, p, 256 * 3, false);
-    if (which & 8) run("library screening pass, split (stamped)", xcorr_screen_pass_n4096<3, true, true>, p, 256 * 3, true);
-    if (which & 16) run("library screening pass, burst (stamped)", xcorr_screen_pass_n4096<3, true, false>, p, 256 * 3, true);
+    if (which & 2) run("library screening pass (MaxLag < 256, sign-agnostic Run)", xcorr_screen_pass_n4096<3, false, false, true, false>, p, 256 * 3, false);
+    if (which & 4) run("library screening pass (MaxLag < 256, signed Run)", xcorr_screen_pass_n4096<3, false, false, true, true>, p, 256 * 3, false);
+    if (which & 8) run("library screening pass (sign-agnostic, stamped)", xcorr_screen_pass_n4096<3, true, false, true, false>, p, 256 * 3, true);
+    if (which & 16) run("library screening pass (signed, stamped)", xcorr_screen_pass_n4096<3, true, false, true, true>, p, 256 * 3, true);
     return 0;
 }
