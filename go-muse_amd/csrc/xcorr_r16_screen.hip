@@ -841,18 +841,19 @@ __global__ __launch_bounds__(SCR_THREADS, WPC) void xcorr_fused_n4096_screen2(co
 // re-evaluation.  Per series it writes
 //   mv[row]   sigma times the fp32 estimate of the signed score at the fp32 argmax (the fp32 value with its exact
 //             power-of-two scale, as a double) and scr_var[row] = sigma^2: score estimate = mv / sqrt(var), with
-//             |estimate - exact| <= E at every lag (E: the caller's bound); lag[row] is the fp32 argmax
-//             (informational: the selection never uses it), and
-//   flags[row] (OR-ed in; zeroed by the caller): what the lags whose fp32 |cc| lies within `screen_delta` = 2 E
-//             (scaled units) of the fp32 maximum -- the only lags that can be the exact argmax -- look like:
-//             SCR_IN / SCR_OUT: one of them has |lag| <= / > max_lag;  SCR_POS / SCR_NEG: its value is > 0 / < 0;
+//             |estimate - exact| <= E at every lag (E: the caller's bound), and
+//   flags[row]: what the lags whose fp32 |cc| lies within `screen_delta` = 2 E (scaled units) of the fp32 maximum -- the
+//             only lags that can be the exact argmax -- look like:
+//             SCR_IN / SCR_OUT: one of them has |lag| <= / > max_lag;  SCR_POS / SCR_NEG: its value is > 0 / < 0
+//             (only computed when the Run's filters look at signs: scr_need_sign);
 //             SCR_REFINE: fp32 is not trusted for this series (sigma outside 2^+-100, x[0] a far outlier);
 //             SCR_NAN: the exact result is NaN (NaN / Inf samples);  sigma == 0 rows report score 0 at lag 0.
+//   (lag[row] is not written: the selection never uses the fp32 argmax, and re-evaluated rows get their exact lag.)
 // The caller turns these into a pessimistic and an optimistic selection key per row, refines (fp64 kernel) every
 // row whose optimistic key reaches the N-th best pessimistic key, and selects among the refined rows only.
-// Registers: 168 (three workgroups of 256 per CU); LDS 37 KB.  Global loads per pair: the batch's 16 spectrum
-// factors per thread (L2), issued while no HBM load is in flight (vmcnt is in-order), and the next pair's rows,
-// issued behind the first transform and consumed at the top of the next iteration.
+// Registers: <= 168 (three workgroups of 256 per CU); LDS 37 KB.  Global loads per pair: the batch's 16 spectrum
+// factors per thread (L2), issued while no HBM load is in flight (vmcnt is in-order), and the next pair's rows, one
+// series at a time (see the kernel).
 namespace scr {
 
 struct NoHook {
