@@ -56,7 +56,8 @@ __device__ __forceinline__ void fft(f2 (&v)[16], f2 *xbuf, const f2 *tw2s, const
 } // namespace w4
 
 // END: 0 = bare maxima; 1 = the full end phase (four folded maxima per series, single-writer finish through LDS);
-// 2 = END 1 + the trust rules / dead-series handling at the top
+// 2 = END 1 + the trust rules / dead-series handling at the top; 3 = END 2 with series B requested only after the fold
+// (the transform's values are dead by then: fewer live registers at the tightest point, a shorter window for B)
 template <int WPC, int END = 0>
 __global__ __launch_bounds__(256, WPC) void screen_w4(const FusedParams p)
 {
@@ -151,7 +152,8 @@ __global__ __launch_bounds__(256, WPC) void screen_w4(const FusedParams p)
         w4::fft<false>(v, xbuf, tw2s, w1, w2, w4_, w8, xq, t, NoHook(), [&]() {
             reduce_series(raw, k0, na, sA1, sA2);
             fence();
-            issue_series(raw, k0, rowB, t);
+            if (END != 3)
+                issue_series(raw, k0, rowB, t);
         });
         if (END == 0) { // ---- bare maxima (timing experiment: estimate only)
             float ma = 0.f, mb = 0.f;
@@ -190,6 +192,11 @@ __global__ __launch_bounds__(256, WPC) void screen_w4(const FusedParams p)
                     outA = fmaxf(outA, fabsf(v[k].x));
                     outB = fmaxf(outB, fabsf(v[k].y));
                 }
+            }
+            if (END == 3) {
+                fence();
+                issue_series(raw, k0, rowB, t);
+                fence();
             }
             const float wiA = wave_max_f32_dpp(inA + 1.f), woA = wave_max_f32_dpp(outA + 1.f);
             const float wiB = wave_max_f32_dpp(inB + 1.f), woB = wave_max_f32_dpp(outB + 1.f);
@@ -254,6 +261,8 @@ int main(int argc, char** argv)
     run("one-series prefetch, 4 WG/CU, full end phase", screen_w4<4, 1>, p, 256 * 4);
     run("one-series prefetch, 3 WG/CU, full end phase", screen_w4<3, 1>, p, 256 * 3);
     run("one-series prefetch, 4 WG/CU, full end phase + trust rules", screen_w4<4, 2>, p, 256 * 4);
+    run("one-series prefetch, 4 WG/CU, series B requested after the fold", screen_w4<4, 3>, p, 256 * 4);
+    run("one-series prefetch, 3 WG/CU, series B requested after the fold", screen_w4<3, 3>, p, 256 * 3);
     run("one-series prefetch, 3 WG/CU, full end phase + trust rules", screen_w4<3, 2>, p, 256 * 3);
     return 0;
 }
