@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- go-muse XCorr/Batch.Run hot path on MI355X.
 
-One "step" = one Batch.Run over the resident Group: fused z-norm + FFT xcorr +
-argmax kernel over every series, group max, filter, top-N, (N > 1: RCCL gather
-of per-shard top-N records + merge).  Workload (BASELINE.json configs[2]):
+One "step" = one Batch.Run over the resident Group with EVERY series scored by the
+float64 kernel (the reference's arithmetic, xcorr.go:160-197): fused z-norm + FFT
+xcorr + argmax over every series, group max, filter, top-N, (N > 1: RCCL gather of
+per-shard top-N records + merge).  The library's opt-in filter-and-refine Run (fp32
+screening pass + fp64 re-evaluation) is timed next to it and reported as the extra
+object `filter_and_refine_run`, never as `value`.  Workload (BASELINE.json configs[2]):
 1 reference x 1 000 000 series per GPU, N = 4096 float64, synthetic rect+noise
 generated on the device and resident in HBM before the timed region.
 
@@ -55,6 +58,29 @@ def cpu_baseline(dg, ref, N):
                       "C restatement of go-muse xCorrWithX (not Go/gonum)" % (S, N, threads)}
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N rank processes (one per GPU) BEFORE this
+    process makes any GPU call, relay their output and exit with the worst return code.  (Never re-exec
+    a process that has initialised the GPU.)"""
+    import subprocess
+    n = args.gpus
+    port = int(os.environ.get("MASTER_PORT", "0")) or (29500 + (os.getpid() % 2000))
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1",
+                    "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                    "MUSE_BENCH_CHILD": "1"})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for r, pr in enumerate(procs):
+        c = pr.wait()
+        if c != 0:
+            print("bench.py: rank %d exited with code %d" % (r, c), file=sys.stderr, flush=True)
+            rc = rc or c
+    sys.exit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -68,21 +94,31 @@ def main():
     ap.add_argument("--many-refs", type=int, default=8,
                     help="also time muse_batch_run_many with this many references (N=1 only; 0 = skip); "
                          "reported as an extra object, never as `value`")
-    ap.add_argument("--all-fp64", action="store_true",
-                    help="headline = the Run with filter-and-refine off (every series scored by the fp64 kernel); "
-                         "by default that Run is reported next to the headline as `all_fp64_run`")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the extra objects (filter_and_refine_run, f32_storage_group, many_references)")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the RCCL gather path even with one rank (rehearsal on a 1-GPU box)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        spawn_ranks(args)                                # does not return
+    world = int(env_world) if env_world is not None else 1
+    if world != args.gpus and not (args.gpus == 1 and world == 1):
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node equal to --gpus" % (args.gpus, world))
 
     import numpy as np
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = world > 1 or args.force_dist
+    ndev = torch.cuda.device_count()                     # (does not initialise the GPU on this image)
+    if ndev <= local_rank:
+        sys.exit("bench.py: rank %d needs GPU %d but only %d visible: this engine has no CPU path" % (rank, local_rank, ndev))
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -100,8 +136,7 @@ def main():
     elif pkg.build.stale():
         pkg.build.build()
     eng = pkg.Engine(local_rank)                      # raises without a gfx950 GPU: no fallback
-    if args.all_fp64:
-        eng.set_screening(False)
+    eng.set_screening(False)                          # headline: every series through the float64 kernel
     dev_name, cus, hbm = eng.device_info()
     M, N = args.rows, args.length
     dg, ref = pkg.DeviceGroup.synthetic(eng, M, N, seed=0x6D757365, global_first=rank * M)
@@ -138,19 +173,20 @@ def main():
         dt = float(tt.item())
 
     screened, refined_pairs = db.last_run_info()
+    assert not screened, "the headline Run must not take the fp32 filter-and-refine path"
     if rank == 0:
         total_pairs = float(M) * n_gpus * args.steps
         value = total_pairs / dt
         k_avg_s = (k_ms / max(k_cnt, 1)) * 1e-3
         bytes_per_launch = float(M) * (8 * N + 16)
         achieved = bytes_per_launch / k_avg_s / 1e9 if k_avg_s > 0 else 0.0
+        kname = eng.kernel_name(db) if hasattr(eng, "kernel_name") else "xcorr_fused"
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json" if screened else "traffic_fp64.json")
+        tpath = os.path.join(ROOT, "profiles", "traffic_fp64.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                want = "xcorr_screen_pass" if screened else "xcorr_fused_n4096_fast"
-                if tj.get("rows") == M and tj.get("length") == N and want in tj.get("kernel", "xcorr_fused_n4096_fast"):
+                if tj.get("rows") == M and tj.get("length") == N and tj.get("kernel", "").split("<")[0] == kname.split("<")[0]:
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -158,26 +194,23 @@ def main():
             "metric": "series-pairs XCorr/sec at N=4096, 1M-series batch; achieved HBM GB/s",
             "value": value, "unit": "series-pairs/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32+f64" if screened else "f64", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "configs[2]: 1 ref x %d series/GPU, N=%d float64 rect+noise, Run(nil), "
                                    "MaxLag=%d TopN=%d" % (M, N, args.max_lag, args.top_n),
                        "rows_per_gpu": M, "length": N, "fft_len": db.n, "sharding": "rows x %d" % n_gpus,
                        "device": dev_name},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": ("xcorr_screen_pass_n4096<3>" if screened else "xcorr_fused_n4096_fast<4>") if db.n == 4096
-                                   else ("xcorr_fused_stk_*" if db.n >= 512 else "xcorr_fused_generic"),
-                         "kernel_ms_avg": k_avg_s * 1e3, "launches_timed": k_cnt,
+                         "kernel": kname, "kernel_ms_avg": k_avg_s * 1e3, "launches_timed": k_cnt,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
             "achieved_hbm_gbps_whole_step": value / n_gpus * (8 * N + 16) / 1e9,
             "top_score": float(out[2][0]) if len(out[2]) else None,
-            # Run path: filter-and-refine = fp32 screening pass over every row (the dominant kernel above; statistics in
-            # fp64) + fp64 re-evaluation of the rows that can reach the top-N; the records are those of the all-fp64 Run
-            "run_path": {"filter_and_refine": screened, "pairs_re_evaluated_in_fp64": refined_pairs},
         }
-        if n_gpus == 1 and screened and not use_dist:
-            # the same Run with screening off (every series scored in fp64), reported next to the default path
-            eng.set_screening(False)
+        extras = n_gpus == 1 and not use_dist and not args.no_extras
+        if extras and db.n >= 512:
+            # opt-in filter-and-refine Run (muse_ctx_set_screening(ctx, 1)): fp32 screening pass over every row + fp64
+            # re-evaluation of the rows that can reach the top-N; same records.  An extra object, never `value`.
+            eng.set_screening(True)
             step()
             eng.synchronize()
             eng.kernel_time()
@@ -187,16 +220,19 @@ def main():
             for _ in range(reps):
                 step()
             eng.synchronize()
-            dt64 = (time.perf_counter() - t1) / reps
+            dts = (time.perf_counter() - t1) / reps
             eng.kernel_timing(False)
-            k64_ms, k64_cnt = eng.kernel_time()
-            eng.set_screening(True)
-            k64_s = k64_ms / max(k64_cnt, 1) * 1e-3
-            line["all_fp64_run"] = {"value": float(M) / dt64, "unit": "series-pairs/s", "ms_per_step": dt64 * 1e3,
-                                    "kernel": "xcorr_fused_n4096_fast<4>", "kernel_ms_avg": k64_s * 1e3,
-                                    "roofline_frac": bytes_per_launch / k64_s / 1e9 / HBM_PEAK_GBPS if k64_s > 0 else None,
-                                    "note": "muse_ctx_set_screening(ctx, 0): same records, every row through the fp64 kernel"}
-        if n_gpus == 1 and args.many_refs > 1 and db.n == 4096 and N == 4096:
+            ks_ms, ks_cnt = eng.kernel_time()
+            scr, refined = db.last_run_info()
+            eng.set_screening(False)
+            ks_s = ks_ms / max(ks_cnt, 1) * 1e-3
+            line["filter_and_refine_run"] = {
+                "value": float(M) / dts, "unit": "series-pairs/s", "ms_per_step": dts * 1e3, "dtype": "f32+f64",
+                "took_the_path": bool(scr), "pairs_re_evaluated_in_fp64": refined,
+                "kernel": "xcorr_screen_pass", "kernel_ms_avg": ks_s * 1e3,
+                "roofline_frac": bytes_per_launch / ks_s / 1e9 / HBM_PEAK_GBPS if ks_s > 0 else None,
+                "note": "opt-in (muse_ctx_set_screening): fp32 transforms screen, fp64 re-evaluates what can reach the top-N"}
+        if extras and args.many_refs > 1 and db.n == 4096 and N == 4096:
             # R references against the same resident group in one pass over the rows
             R = args.many_refs
             refs = [ref] + [dg.read(997 * r + 1, 1)[0] for r in range(1, R)]
@@ -210,10 +246,10 @@ def main():
             eng.synchronize()
             dtm = (time.perf_counter() - t1) / reps
             line["many_references"] = {"references": R, "value": R * float(M) / dtm, "unit": "series-pairs/s",
-                                       "ms_per_run": dtm * 1e3,
+                                       "ms_per_run": dtm * 1e3, "dtype": "f64",
                                        "note": "muse_batch_run_many: one pass over the rows for all references"}
             del bs
-        if n_gpus == 1 and not args.no_cpu_baseline:
+        if n_gpus == 1 and not use_dist and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(dg, ref, N)
         print(json.dumps(line), flush=True)
     if use_dist:

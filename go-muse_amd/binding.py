@@ -1,4 +1,4 @@
-"""ctypes binding of libmuse_hip.so -- every symbol include/muse_hip.h declares.
+"""ctypes binding of libmuse_hip.so -- every symbol include/muse_hip.h and include/muse_hip_test.h declare.
 
 Loading the library does not need a GPU (the symbol-export test runs on CPU);
 every compute call does, and fails loudly (MuseError) when the device or the
@@ -37,7 +37,7 @@ class MuseRecord(ctypes.Structure):
 RECORD_DTYPE = np.dtype([("series", "<i8"), ("score", "<f8"), ("lag", "<i4"), ("group", "<i4")])
 _recp = ctypes.POINTER(MuseRecord)
 
-# name -> (restype, argtypes): the complete ABI of include/muse_hip.h
+# name -> (restype, argtypes): the complete ABI of include/muse_hip.h (+ the test hooks of include/muse_hip_test.h)
 SIGNATURES = {
     "muse_abi_version": (ctypes.c_int, []),
     "muse_last_error": (ctypes.c_char_p, []),
@@ -71,6 +71,9 @@ SIGNATURES = {
     "muse_batch_score_many": (ctypes.c_int, [ctypes.POINTER(_vp), _i32]),
     "muse_batch_read_scores": (ctypes.c_int, [_vp, _i32p, _dp]),
     "muse_batch_last_run_info": (ctypes.c_int, [_vp, _i32p, _i64p]),
+    "muse_batch_last_run_path": (ctypes.c_int, [_vp, _i32p]),
+    "muse_batch_kernel_name": (ctypes.c_int, [_vp, ctypes.c_char_p, _i32]),
+    "muse_test_set_screen_bound_scale": (ctypes.c_int, [_vp, _f64]),
     "muse_batch_screen_estimates": (ctypes.c_int, [_vp, _i32, _dp, ctypes.POINTER(ctypes.c_uint32), _dp]),
     "muse_batch_run_many": (ctypes.c_int, [ctypes.POINTER(_vp), _i32, _i32p, _i32, _i32, _i32, _f64, _i32, _i32,
                                            _i64p, _i32p, _dp, _i32p, _dp]),

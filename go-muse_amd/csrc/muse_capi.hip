@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "muse_hip.h"
+#include "muse_hip_test.h"
 #include "xcorr_kernels.h"
 
 using namespace muse;
@@ -78,7 +79,8 @@ struct muse_ctx {
     int num_cus = 0;
     int64_t hbm = 0;
     char name[64] = {0};
-    double2 *tw1 = nullptr, *tw2 = nullptr, *twm = nullptr, *tw1w8 = nullptr, *tw1p = nullptr;
+    double2 *tw1 = nullptr, *tw2 = nullptr, *twm = nullptr;
+    double2 *g2 = nullptr, *g3a = nullptr, *g3b = nullptr; // folded-twiddle tables (xcorr_r16_fold.hip)
     float2 *tw1f = nullptr, *tw2f = nullptr, *twmf = nullptr; // fp32 copies for the screening kernels
     // many-reference pass (muse_batch_score_many): parked spectra + device pointer tables
     // pinned staging buffers (32 MB each) lent to groups that receive many small appends; allocated once
@@ -95,13 +97,14 @@ struct muse_ctx {
     std::vector<void *> many_host; // host image of many_tab (outlives the asynchronous copy)
     int many_cap = 0;
     double screen_delta = 1e-4;
-    // filter-and-refine Run (run_select): 1 = ungrouped N = 4096 Runs screen in fp32 and re-evaluate in fp64 only the
-    // rows that can reach the top-N; 0 = every Run scores all rows in fp64 (muse_ctx_set_screening / MUSE_HIP_SCREEN_RUN)
-    int screening = 1;
+    // filter-and-refine Run (run_select), OPT-IN (muse_ctx_set_screening): 1 = Runs over large groups screen in fp32 and
+    // re-evaluate in fp64 only the rows that can reach the top-N; 0 (default) = every Run scores all rows in fp64, the
+    // arithmetic of the reference (xcorr.go:160-197)
+    int screening = 0;
     // smaller groups: the plain fp64 pass is as fast (tools/screen_crossover.py: the crossover is at ~25 000 rows of 4096
     // samples).  Default: M * n >= 32768 * 4096 samples; an explicit row count (muse_ctx_set_screening(ctx, rows)) overrides.
     int64_t screen_min_rows = 0;
-    double screen_e_scale = 1.0;     // test aid (MUSE_HIP_SCREEN_E_SCALE): scales the error bound, to exercise the guard
+    double screen_e_scale = 1.0;     // test hook (muse_test_set_screen_bound_scale): scales the error bound, to exercise the guard
     int variant = 0;
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -191,7 +194,21 @@ struct muse_batch {
     int64_t est_cap = 0;
     unsigned long long *err_dev = nullptr, *err_host = nullptr; // largest | |estimate| - |fp64 score| | of the last screened Run
     double last_E = 0.0;                // the bound that Run assumed
-    int64_t screen_off_M = -1;          // a screened Run over this many rows re-evaluated too many of them: not again
+    // a screened Run with these filters over this many rows re-evaluated too many of them: the same Run is not
+    // screened again (other filters on the same batch still are); a tripped guard switches the batch off for good
+    struct RunKey {
+        int64_t M = -1, G = 0;
+        int32_t max_lag = 0, top_n = 0, sign_filter = 0, abs_scores = 0, grouped = 0;
+        double threshold = 0.0;
+        bool operator==(const RunKey &o) const
+        {
+            return M == o.M && G == o.G && max_lag == o.max_lag && top_n == o.top_n && sign_filter == o.sign_filter &&
+                   abs_scores == o.abs_scores && grouped == o.grouped && threshold == o.threshold;
+        }
+    };
+    RunKey costly_key;                  // (M = -1: none)
+    bool guard_off = false;
+    int32_t last_path = 0;              // MUSE_RUN_PATH_* of the last Run
     bool scores_exact = true;           // mv / lag hold fp64 results for every row (false after a screened Run)
     bool last_screened = false;         // the last Run took the filter-and-refine path
     int64_t guard_trips = 0;            // Runs redone in fp64 because an estimate left its bound
@@ -235,15 +252,6 @@ extern "C" int muse_ctx_create(int32_t device, muse_ctx **out)
     if (!ctx)
         return fail(MUSE_ERR_NOMEM, "host allocation failed");
     ctx->device = device;
-    if (const char *kv = getenv("MUSE_HIP_KERNEL")) // profiling aid: same meaning as muse_ctx_set_kernel
-        ctx->variant = atoi(kv);
-    if (const char *sv = getenv("MUSE_HIP_SCREEN_RUN")) { // same meaning as muse_ctx_set_screening
-        ctx->screening = atoi(sv) != 0;
-        if (atoi(sv) > 1)
-            ctx->screen_min_rows = atoi(sv);
-    }
-    if (const char *ev = getenv("MUSE_HIP_SCREEN_E_SCALE"))
-        ctx->screen_e_scale = atof(ev) > 0.0 ? atof(ev) : 1.0;
     ctx->num_cus = prop.multiProcessorCount;
     ctx->hbm = (int64_t)prop.totalGlobalMem;
     snprintf(ctx->name, sizeof(ctx->name), "%s (%s)", prop.name, prop.gcnArchName);
@@ -271,18 +279,29 @@ extern "C" int muse_ctx_create(int32_t device, muse_ctx **out)
         HIP_TRY(hipMalloc(&ctx->twmf, tmf.size() * sizeof(float2)));
         HIP_TRY(hipMemcpy(ctx->twmf, tmf.data(), tmf.size() * sizeof(float2), hipMemcpyHostToDevice));
     }
-    std::vector<double2> t1p(16 * 256); // tw1 in the lane order of xcorr_r16_fast.hip's second transform
-    for (int k = 0; k < 16; k++)
-        for (int t = 0; t < 256; t++)
-            fill_twiddle(t1p, (size_t)k * 256 + t, (long long)k * (16 * (t & 15) + (t >> 4)), 4096);
-    HIP_TRY(hipMalloc(&ctx->tw1p, t1p.size() * sizeof(double2)));
-    HIP_TRY(hipMemcpy(ctx->tw1p, t1p.data(), t1p.size() * sizeof(double2), hipMemcpyHostToDevice));
-    std::vector<double2> t8(8 * 512);
-    for (int k = 0; k < 8; k++)
-        for (int t = 0; t < 512; t++)
-            fill_twiddle(t8, (size_t)k * 512 + t, (long long)k * t, 4096);
-    HIP_TRY(hipMalloc(&ctx->tw1w8, t8.size() * sizeof(double2)));
-    HIP_TRY(hipMemcpy(ctx->tw1w8, t8.data(), t8.size() * sizeof(double2), hipMemcpyHostToDevice));
+    {   // generalised-pass factors for delta = u / 256 (fold_device.h): W_512^u, W_1024^u, W_2048^u, W_2048^(u+256), W_4096^(u+256q)
+        const auto fill_g = [](std::vector<double2> &g, size_t stride, size_t idx, long long u) {
+            fill_twiddle(g, 0 * stride + idx, u, 512);
+            fill_twiddle(g, 1 * stride + idx, u, 1024);
+            fill_twiddle(g, 2 * stride + idx, u, 2048);
+            fill_twiddle(g, 3 * stride + idx, u + 256, 2048);
+            for (int q = 0; q < 4; q++)
+                fill_twiddle(g, (size_t)(4 + q) * stride + idx, u + 256 * q, 4096);
+        };
+        std::vector<double2> g2(8 * 16), g3a(8 * 256), g3b(8 * 256);
+        for (int j = 0; j < 16; j++)
+            fill_g(g2, 16, (size_t)j, 16 * j);
+        for (int t = 0; t < 256; t++) {
+            fill_g(g3a, 256, (size_t)t, (t >> 4) + 16 * (t & 15));
+            fill_g(g3b, 256, (size_t)t, t);
+        }
+        HIP_TRY(hipMalloc(&ctx->g2, g2.size() * sizeof(double2)));
+        HIP_TRY(hipMalloc(&ctx->g3a, g3a.size() * sizeof(double2)));
+        HIP_TRY(hipMalloc(&ctx->g3b, g3b.size() * sizeof(double2)));
+        HIP_TRY(hipMemcpy(ctx->g2, g2.data(), g2.size() * sizeof(double2), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ctx->g3a, g3a.data(), g3a.size() * sizeof(double2), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ctx->g3b, g3b.data(), g3b.size() * sizeof(double2), hipMemcpyHostToDevice));
+    }
     std::vector<float2> t1f(t1.size()), t2f(t2.size());
     for (size_t i = 0; i < t1.size(); i++)
         t1f[i] = make_float2((float)t1[i].x, (float)t1[i].y);
@@ -292,8 +311,6 @@ extern "C" int muse_ctx_create(int32_t device, muse_ctx **out)
     HIP_TRY(hipMalloc(&ctx->tw2f, t2f.size() * sizeof(float2)));
     HIP_TRY(hipMemcpy(ctx->tw1f, t1f.data(), t1f.size() * sizeof(float2), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ctx->tw2f, t2f.data(), t2f.size() * sizeof(float2), hipMemcpyHostToDevice));
-    if (const char *dv = getenv("MUSE_HIP_SCREEN_DELTA"))
-        ctx->screen_delta = atof(dv);
     *out = ctx;
     return MUSE_OK;
 }
@@ -314,8 +331,9 @@ static void ctx_release(muse_ctx *ctx)
     (void)hipFree(ctx->twm);
     (void)hipFree(ctx->twmf);
     (void)hipFree(ctx->tw1f);
-    (void)hipFree(ctx->tw1w8);
-    (void)hipFree(ctx->tw1p);
+    (void)hipFree(ctx->g2);
+    (void)hipFree(ctx->g3a);
+    (void)hipFree(ctx->g3b);
     (void)hipFree(ctx->zscratch);
     (void)hipFree(ctx->gscratch);
     for (double *b : ctx->stage_pool)
@@ -357,8 +375,8 @@ extern "C" int muse_ctx_device_info(muse_ctx *ctx, char *name, int32_t name_cap,
 
 extern "C" int muse_ctx_set_kernel(muse_ctx *ctx, int32_t variant)
 {
-    if (!ctx || variant < 0 || variant > 11 || variant == 3 || variant == 4) // 3, 4: retired
-        return fail(MUSE_ERR_INVALID, "bad kernel variant");
+    if (!ctx || !(variant == 0 || variant == 1 || variant == 7 || variant == 10 || variant == 11))
+        return fail(MUSE_ERR_INVALID, "bad kernel variant (0 auto, 1 generic, 7 rescaling n=4096, 10 default n=4096, 11 Stockham)");
     ctx->variant = variant;
     return MUSE_OK;
 }
@@ -886,8 +904,9 @@ static FusedParams base_params(muse_batch *b)
     p.lag = b->lag;
     p.cc_out = nullptr;
     p.nil_out = nullptr;
-    p.tw1w8 = ctx->tw1w8;
-    p.tw1p = ctx->tw1p;
+    p.g2 = ctx->g2;
+    p.g3a = ctx->g3a;
+    p.g3b = ctx->g3b;
     p.xcp = b->xcp;
     p.c1 = b->c1;
     p.tw1f = ctx->tw1f;
@@ -923,26 +942,19 @@ extern "C" int muse_batch_score(muse_batch *b)
         scratch_lock.lock();
     FusedParams p = base_params(b);
     b->scores_exact = true;
-    // kernel selection: ctx->variant 0 = auto; 1 = generic LDS radix-2; 2, 5..10 force one
-    // of the n = 4096 kernels (parity tests run every one of them on the same inputs)
+    // kernel selection: ctx->variant 0 = auto; the others are test hooks (muse_hip_test.h)
     int variant = KERNEL_GENERIC;
     if (b->n == 4096) {
         switch (ctx->variant) {
-        case 0: variant = KERNEL_R16_FAST; break; // fastest measured (profiles/); N < 4096: occ3, below
-        case 2: variant = KERNEL_R16_N4096; break;
-        case 5: variant = KERNEL_R16_PIPE; break;
-        case 6: variant = KERNEL_R16_OCC4; break;
-        case 7: variant = KERNEL_R16_OCC3; break;
-        case 8: variant = KERNEL_R16_SCREEN; break;
-        case 9: variant = KERNEL_R8_W8; break;
-        case 10: variant = KERNEL_R16_FAST; break;
+        case 0: case 10: variant = KERNEL_R16_FOLD; break; // fastest measured (profiles/)
+        case 7: variant = KERNEL_R16_OCC3; break;          // rescales both series before the shared transform
         default: variant = KERNEL_GENERIC; break;
         }
-        if (variant == KERNEL_R16_FAST && b->N != 4096 && !b->c1) // (N < n needs the batch's correction table)
+        if (variant == KERNEL_R16_FOLD && b->N != 4096 && !b->c1) // (N < n needs the batch's correction table)
             variant = KERNEL_R16_OCC3;
         // a group of mixed-unit series (sigmas far apart inside most pairs) makes the default kernel hand most
         // pairs to kernel 7 anyway: once a pass over these rows has shown that, go there directly
-        if (variant == KERNEL_R16_FAST && ctx->variant == 0 && b->handoff_host && b->handoff_M == M &&
+        if (variant == KERNEL_R16_FOLD && ctx->variant == 0 && b->handoff_host && b->handoff_M == M &&
             (long long)*(volatile int *)b->handoff_host * 8 > p.npairs)
             variant = KERNEL_R16_OCC3;
     } else if (((b->n >= 512 && b->n <= 2048) || b->n >= 8192) && (ctx->variant == 0 || ctx->variant == 11)) {
@@ -956,11 +968,10 @@ extern "C" int muse_batch_score(muse_batch *b)
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, ctx->stream));
     }
-    if (variant == KERNEL_R16_SCREEN || variant == KERNEL_R16_FAST) {
-        // pairs with too many near-tie candidates are listed by the screening kernel and
-        // redone by the fp64 kernel right behind it (no host round trip: the count stays on
-        // the device and bounds the second launch's loop)
-        // (the fast kernel lists pairs with a NaN/Inf series, once per such series: 2 entries per pair)
+    if (variant == KERNEL_R16_FOLD) {
+        // pairs with a NaN/Inf series or with sigmas too far apart for one shared transform are listed by the kernel
+        // (once per such series: 2 entries per pair) and redone by the rescaling kernel right behind it (no host round
+        // trip: the count stays on the device and bounds the second launch's loop)
         if (2 * p.npairs > b->ovf_cap) {
             (void)hipFree(b->ovf_list);
             b->ovf_list = nullptr;
@@ -980,7 +991,7 @@ extern "C" int muse_batch_score(muse_batch *b)
         // (mixed-unit metrics: sigmas far apart) is redone at full width; an empty list costs a few microseconds
         q.npairs = std::min<long long>(p.npairs, (long long)ctx->num_cus * 3);
         HIP_TRY(launch_fused(q, KERNEL_R16_OCC3, ctx->num_cus, ctx->stream));
-        if (variant == KERNEL_R16_FAST && p.npairs >= 1024) { // (small groups: a pinned allocation costs more than it can save)
+        if (p.npairs >= 1024) { // (small groups: a pinned allocation costs more than it can save)
             if (!b->handoff_host)
                 HIP_TRY(hipHostMalloc((void **)&b->handoff_host, sizeof(int), hipHostMallocDefault));
             *b->handoff_host = 0;
@@ -1153,16 +1164,38 @@ static int ensure_select_ws(muse_batch *b, int64_t M, int64_t G, bool with_gid, 
 }
 
 // ---- filter-and-refine Run: ungrouped N = n = 4096 Runs under automatic kernel selection
-static bool screen_eligible(const muse_batch *b, const int32_t *group_id, int32_t top_n, bool already_scored)
+static muse_batch::RunKey run_key(const muse_batch *b, const int32_t *group_id, int64_t G, int32_t max_lag, int32_t top_n,
+                                  double threshold, int32_t sign_filter, int32_t abs_scores)
+{
+    muse_batch::RunKey k;
+    k.M = b->g->M;
+    k.G = group_id ? G : 0;
+    k.grouped = group_id ? 1 : 0;
+    k.max_lag = max_lag;
+    k.top_n = top_n;
+    k.threshold = threshold;
+    k.sign_filter = sign_filter;
+    k.abs_scores = abs_scores ? 1 : 0;
+    return k;
+}
+
+// which path a Run with these filters takes (MUSE_RUN_PATH_*); label groups are handled too (per-group bounds:
+// reduce_kernels.hip, screen_g1..g4)
+static int32_t screen_path(const muse_batch *b, const muse_batch::RunKey &key, bool already_scored)
 {
     const muse_ctx *ctx = b->ctx;
     const int64_t M = b->g->M;
-    (void)group_id; // label groups are handled too (per-group bounds: reduce_kernels.hip, screen_g1..g4)
     const bool length_ok = b->n >= 512 && b->n <= 65536; // every FFT length with a tuned kernel (N > n/2 by construction)
-    return !already_scored && ctx->screening && ctx->variant == 0 && length_ok &&
-           b->xcf && top_n >= 1 && top_n <= TOPN_DEVICE_MAX && M / 2 < 0x7fffffffLL &&
-           (ctx->screen_min_rows > 0 ? M >= ctx->screen_min_rows : M * (int64_t)b->n >= (int64_t)32768 * 4096) &&
-           b->screen_off_M != M;
+    const bool eligible = !already_scored && ctx->screening && ctx->variant == 0 && length_ok && b->xcf && key.top_n >= 1 &&
+                          key.top_n <= TOPN_DEVICE_MAX && M / 2 < 0x7fffffffLL &&
+                          (ctx->screen_min_rows > 0 ? M >= ctx->screen_min_rows : M * (int64_t)b->n >= (int64_t)32768 * 4096);
+    if (!eligible)
+        return MUSE_RUN_PATH_FP64;
+    if (b->guard_off)
+        return MUSE_RUN_PATH_FP64_GUARD;
+    if (b->costly_key == key)
+        return MUSE_RUN_PATH_FP64_COSTLY;
+    return MUSE_RUN_PATH_SCREENED;
 }
 
 // Error bound of the screening pass's estimates, in its scaled units (score = estimate / (2^-e sigma), the last
@@ -1366,6 +1399,41 @@ extern "C" int muse_batch_last_run_info(muse_batch *b, int32_t *screened, int64_
     return MUSE_OK;
 }
 
+extern "C" int muse_batch_last_run_path(muse_batch *b, int32_t *path)
+{
+    if (!b || !path)
+        return fail(MUSE_ERR_INVALID, "NULL argument");
+    *path = b->last_path;
+    return MUSE_OK;
+}
+
+// test hook (muse_hip_test.h): scales the error bound the filter-and-refine Run assumes, to exercise its guard
+extern "C" int muse_test_set_screen_bound_scale(muse_ctx *ctx, double scale)
+{
+    if (!ctx || !(scale > 0.0))
+        return fail(MUSE_ERR_INVALID, "bad bound scale");
+    ctx->screen_e_scale = scale;
+    return MUSE_OK;
+}
+
+// the kernel automatic selection takes for this batch's all-scores pass (bench.py names it in its roofline object)
+extern "C" int muse_batch_kernel_name(muse_batch *b, char *name, int32_t cap)
+{
+    if (!b || !name || cap < 1)
+        return fail(MUSE_ERR_INVALID, "NULL argument");
+    const char *k = "xcorr_fused_generic";
+    if (b->n == 4096)
+        k = b->N == 4096 ? "xcorr_fused_n4096_fold<false, false>" : "xcorr_fused_n4096_fold<false, true>";
+    else if (b->n >= 512 && b->n <= 2048)
+        k = "xcorr_fused_stk_lds";
+    else if (b->n == 8192)
+        k = "xcorr_fused_stk_lds<13>";
+    else if (b->n > 8192)
+        k = "xcorr_fused_stk_4step";
+    snprintf(name, (size_t)cap, "%s", k);
+    return MUSE_OK;
+}
+
 // test / measurement hook: the screening pass alone (estimates, SCR_* flags and the bound E in score units)
 extern "C" int muse_batch_screen_estimates(muse_batch *b, int32_t max_lag, double *estimate, uint32_t *flags, double *E)
 {
@@ -1439,7 +1507,7 @@ static bool screen_guard_tripped(muse_batch *b)
     memcpy(&err, b->err_host, sizeof(err));
     if (!(err > b->last_E))
         return false;
-    b->screen_off_M = b->g->M;
+    b->guard_off = true;
     b->guard_trips++;
     return true;
 }
@@ -1457,7 +1525,10 @@ static int run_select(muse_batch *b, const int32_t *group_id, int32_t G_in, int6
         return fail(MUSE_ERR_INVALID, "negative group count");
     // Batch.Run re-scores on every call (muse_batch.go:116-122)
     // (prescreened: muse_batch_run_many has run the screening pass for several batches at once and finished this one)
-    const bool screened = prescreened || screen_eligible(b, group_id, top_n, already_scored);
+    const muse_batch::RunKey rkey = run_key(b, group_id, group_id ? (int64_t)G_in : 0, max_lag, top_n, threshold, sign_filter, abs_scores);
+    const int32_t path = prescreened ? MUSE_RUN_PATH_SCREENED : screen_path(b, rkey, already_scored);
+    const bool screened = path == MUSE_RUN_PATH_SCREENED;
+    b->last_path = path;
     int rc = (already_scored || screened) ? MUSE_OK : muse_batch_score(b);
     if (rc)
         return rc;
@@ -1509,7 +1580,7 @@ static int run_select(muse_batch *b, const int32_t *group_id, int32_t G_in, int6
         // a screened Run that had to re-evaluate a large part of the rows (few rows certainly pass the filters, or the
         // scores crowd around the cut) costs more than the plain fp64 pass: not again for this (immutable) set of rows
         if (screened && (int64_t)*b->refine_host * 4 > (M + 1) / 2)
-            b->screen_off_M = M;
+            b->costly_key = rkey;
         if (screened && screen_guard_tripped(b)) // an estimate left its bound: this Run is redone entirely in fp64
             return run_select(b, group_id, G_in, series_offset, max_lag, top_n, threshold, sign_filter, abs_scores, out, false);
     } else {
@@ -1524,7 +1595,7 @@ static int run_select(muse_batch *b, const int32_t *group_id, int32_t G_in, int6
             if (key[(size_t)g] != 0ull)
                 cands.push_back(rec[(size_t)g]);
         if (screened && (int64_t)*b->refine_host * 4 > (M + 1) / 2)
-            b->screen_off_M = M;
+            b->costly_key = rkey;
         if (screened && screen_guard_tripped(b))
             return run_select(b, group_id, G_in, series_offset, max_lag, top_n, threshold, sign_filter, abs_scores, out, false);
     }
@@ -1708,6 +1779,7 @@ extern "C" int muse_batch_score_many(muse_batch *const *bs, int32_t R)
         q.pair_count = b0->ovf_count;
         q.npairs = std::min<long long>(q.npairs, (long long)ctx->num_cus * 3);
         HIP_TRY(launch_fused(q, KERNEL_R16_OCC3, ctx->num_cus, ctx->stream));
+        bs[r]->scores_exact = true; // mv / lag of every batch now hold fp64 results for every row
     }
     if (ctx->timing) {
         HIP_TRY(hipEventRecord(e1, ctx->stream));
@@ -1737,7 +1809,9 @@ static int screen_many(muse_batch *const *bs, int32_t R, const int32_t *group_id
         for (int q = 0; q < r; q++)
             if (bs[q] == bs[r])
                 return MUSE_OK;
-        if (bs[r]->N != 4096 || !screen_eligible(bs[r], group_id, top_n, false))
+        if (bs[r]->N != 4096 ||
+            screen_path(bs[r], run_key(bs[r], group_id, group_id ? (int64_t)G_in : 0, max_lag, top_n, threshold, sign_filter, abs_scores),
+                        false) != MUSE_RUN_PATH_SCREENED)
             return MUSE_OK;
     }
     const int64_t G = group_id ? (int64_t)G_in : M;

@@ -8,7 +8,7 @@
 
 namespace muse {
 
-enum { KERNEL_GENERIC = 0, KERNEL_R16_N4096 = 1, KERNEL_R16_PIPE = 4, KERNEL_R16_OCC4 = 5, KERNEL_R16_OCC3 = 6, KERNEL_R16_SCREEN = 7, KERNEL_R8_W8 = 8, KERNEL_R16_FAST = 9, KERNEL_STOCKHAM = 10 };
+enum { KERNEL_GENERIC = 0, KERNEL_R16_OCC3 = 6, KERNEL_STOCKHAM = 10, KERNEL_R16_FOLD = 11 };
 
 struct FusedParams {
     const double *rows; // M x N row-major, row stride `stride` doubles
@@ -22,10 +22,12 @@ struct FusedParams {
     const double2 *xc;   // n entries: conj(X_full[f]) * scale
     const double2 *tw1;  // [16][256] W_4096^(k*t)      (tuned kernel)
     const double2 *tw2;  // [16][16]  W_256^(k*c)       (tuned kernel)
-    const double2 *tw1w8; // [8][512]  W_4096^(k*t)      (radix-8 kernel)
-    const double2 *tw1p; // [16][256] W_4096^(k*(16*(t&15) + (t>>4)))   (xcorr_r16_fast.hip, second transform)
-    const double2 *xcp;  // [16][256] xc[256*k + (t>>4) + 16*(t&15)]     (xcorr_r16_fast.hip: xc in lane order)
-    const double *c1;    // [4096] N < n = 4096: correlation of the valid-sample indicator with the reference (xcorr_r16_fast.hip)
+    const double2 *xcp;  // [16][256] xc[256*k + (t>>4) + 16*(t&15)]     (xcorr_r16_fold.hip: xc in lane order)
+    // xcorr_r16_fold.hip: the eight per-thread factors of a generalised 16-point pass (fold_device.h), delta = u / 256
+    const double2 *g2;   // [8][16]  pass 2: u = 16 j
+    const double2 *g3a;  // [8][256] first transform, pass 3: u = (t >> 4) + 16 (t & 15)
+    const double2 *g3b;  // [8][256] second transform, pass 3: u = t
+    const double *c1;    // [4096] N < n = 4096: correlation of the valid-sample indicator with the reference (xcorr_r16_fold.hip)
     // many references in one pass (xcorr_fused_n4096_multi): device arrays of R pointers
     int R;
     const double2 *const *xcp_many; // R lane-ordered spectrum tables
@@ -56,8 +58,7 @@ struct FusedParams {
     int scr_max_lag;     // screening pass: the Run's MaxLag (classifies the possible argmax lags)
     int scr_need_sign;   // screening pass (n = 4096): 0 = the Run's filters never look at the sign of a score
     int *ovf_count;      // pairs with too many candidates: redone by the fp64 kernel
-    int *work_counter;   // dynamic pair hand-out (xcorr_r16_fast.hip, DYN): zeroed before the launch
-    int tune;            // experiment bits (MUSE_HIP_FAST_TUNE); 0 in production
+    int *work_counter;   // dynamic pair hand-out (xcorr_r16_fold.hip): zeroed before the launch
     long long *ovf_list;
     // optional indirection for the fp64 kernels: process pair_list[0 .. *pair_count)
     const long long *pair_list;
@@ -65,19 +66,16 @@ struct FusedParams {
 };
 
 hipError_t launch_fused(const FusedParams &p, int variant, int num_cus, hipStream_t stream);
-hipError_t launch_fused_pipe(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_r16_pipe.hip
-hipError_t launch_fused_occ4(const FusedParams &p, int num_cus, int waves_per_simd, hipStream_t stream); // xcorr_r16_occ4.hip
-hipError_t launch_fused_screen(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_r16_screen.hip
+hipError_t launch_fused_occ4(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_r16_occ4.hip (rescaling / pair-list kernel)
 hipError_t launch_screen_pass(const FusedParams &p, int num_cus, hipStream_t stream);  // xcorr_r16_screen.hip (filter-and-refine Run)
 hipError_t launch_screen_pass_many(const FusedParams &p, int num_cus, hipStream_t stream); // the same for R references in one pass
 hipError_t launch_screen_pass_stk(const FusedParams &p, int num_cus, hipStream_t stream);  // xcorr_screen_stk.hip: n = 512, 1024, 2048
 // per-row flags of the screening pass
 enum : unsigned { SCR_IN = 1u, SCR_OUT = 2u, SCR_POS = 4u, SCR_NEG = 8u, SCR_REFINE = 16u, SCR_NAN = 32u };
-hipError_t launch_fused_w8(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_r8_w8.hip
-hipError_t launch_fused_fast(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_r16_fast.hip (N == n == 4096)
-hipError_t launch_fused_multi(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_r16_fast.hip (R references)
+hipError_t launch_fused_fold(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_r16_fold.hip (n == 4096, default)
+hipError_t launch_fused_multi(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_r16_fold.hip (R references)
 hipError_t launch_fused_stockham(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_stockham.hip (n = 512 .. 2048, 8192 .. 65536)
-// out[256 k + t] = in[256 k + (t >> 4) + 16 (t & 15)], k < 16: a 4096-entry table in the lane order of xcorr_r16_fast.hip
+// out[256 k + t] = in[256 k + (t >> 4) + 16 (t & 15)], k < 16: a 4096-entry table in the lane order of xcorr_r16_fold.hip
 hipError_t launch_lane_order(const double2 *in, double2 *out, hipStream_t stream);
 // c1[k] = sum_{j >= pad} xs[(j + k) mod n]: what a series of ones at the valid (non-pad) positions correlates to
 hipError_t launch_indicator_corr(const double *xs, int n, int pad, double *c1, hipStream_t stream);

@@ -35,188 +35,6 @@
 
 namespace muse {
 
-constexpr int R16_THREADS = 256;
-constexpr int R16_LDS = 16 * 272; // double2 elements: 69,632 B
-
-// Forward FFT of 4096 points spread as v[a] = x[t + 256*a]; on return
-// v[a] = X[t + 256*a].  `lds` is the R16_LDS exchange buffer.
-__device__ __forceinline__ void fft4096(double2 (&v)[16], double2 *lds, const double2 *__restrict__ tw1,
-                                        const double2 *__restrict__ tw2, const int t)
-{
-    const int hi = t >> 4, lo = t & 15;
-    // ---- pass 1: DFT over a, twiddle W_4096^(k1 * t)
-    dft16(v);
-#pragma unroll
-    for (int k = 1; k < 16; k++)
-        v[P16(k)] = cmul(v[P16(k)], tw1[k * 256 + t]);
-    // ---- exchange A: (k1 | b,c) -> (b | k1,c).  pos = 256*k1 + 16*b + c.
-    // writes: consecutive lanes -> consecutive 16-B slots; reads: slot index
-    // == lane (mod 16): conflict-free for ds_write_b128 / ds_read_b128.
-    __syncthreads(); // previous readers of the buffer are done
-#pragma unroll
-    for (int k = 0; k < 16; k++)
-        lds[256 * k + t] = v[P16(k)];
-    __syncthreads();
-#pragma unroll
-    for (int b = 0; b < 16; b++)
-        v[b] = lds[256 * hi + 16 * b + lo];
-    // ---- pass 2: DFT over b (this thread: k1 = hi, c = lo), twiddle W_256^(k2*c)
-    dft16(v);
-#pragma unroll
-    for (int k = 1; k < 16; k++)
-        v[P16(k)] = cmul(v[P16(k)], tw2[k * 16 + lo]);
-    // ---- exchange B: (k2 | k1,c) -> (c | k1,k2).  pos = 272*k2 + 17*k1 + c
-    // (rows padded 16 -> 17 so the transposed read has slot == lane + c mod 16).
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 16; k++)
-        lds[272 * k + 17 * hi + lo] = v[P16(k)];
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < 16; c++)
-        v[c] = lds[272 * hi + 17 * lo + c]; // this thread: k1 = lo, k2 = hi
-    // ---- pass 3: DFT over c; frequency f = k1 + 16*k2 + 256*k3 = t + 256*k3
-    dft16(v);
-    // un-permute (register renaming only)
-    double2 w[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++)
-        w[k] = v[P16(k)];
-#pragma unroll
-    for (int k = 0; k < 16; k++)
-        v[k] = w[k];
-}
-
-__global__ __launch_bounds__(R16_THREADS, 2) void xcorr_fused_n4096(const FusedParams p)
-{
-    __shared__ double2 lds[R16_LDS];
-    __shared__ double red[64];
-    __shared__ int redi[16];
-    const int t = threadIdx.x;
-    const int lane = t & 63, wave = t >> 6;
-    const int N = p.N;
-    const int pad = 4096 - N;
-
-    for (long long pair = blockIdx.x; pair < p.npairs; pair += gridDim.x) {
-        const long long rA = 2 * pair, rB = rA + 1;
-        const bool hasB = rB < p.M;
-        const double *__restrict__ ra = p.rows + rA * p.stride;
-        const double *__restrict__ rb = p.rows + (hasB ? rB : rA) * p.stride;
-
-        // ---- coalesced load: element t + 256*a of the zero-padded rows
-        double2 v[16];
-#pragma unroll
-        for (int a = 0; a < 16; a++) {
-            const int j = t + 256 * a - pad;
-            const int jc = j < 0 ? 0 : j; // always load (a conditional load serialises behind vmcnt(0))
-            const double xa = ra[jc], xb = rb[jc];
-            v[a] = make_double2(j >= 0 ? xa : 0.0, (j >= 0 && hasB) ? xb : 0.0);
-        }
-        // ---- zNormalize both series (xcorr.go:84-95)
-        double s[2] = {0.0, 0.0};
-#pragma unroll
-        for (int a = 0; a < 16; a++) {
-            s[0] += v[a].x;
-            s[1] += v[a].y;
-        }
-        block_sum<2>(s, red);
-        const double ca = -s[0] / (double)N, cb = -s[1] / (double)N;
-        double q[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int a = 0; a < 16; a++) {
-            if (t + 256 * a - pad >= 0) {
-                v[a].x += ca;
-                v[a].y += cb;
-            }
-            q[0] += v[a].x;
-            q[1] = fma(v[a].x, v[a].x, q[1]);
-            q[2] += v[a].y;
-            q[3] = fma(v[a].y, v[a].y, q[3]);
-        }
-        block_sum<4>(q, red + 8);
-        ZnFlags fa, fb;
-        const double ia = zn_scale(q[0], q[1], N, fa);
-        const double ib = zn_scale(q[2], q[3], N, fb);
-        // a sigma == 0 / NaN series contributes zeros, so it cannot leak into
-        // the series it shares the complex transform with
-        const bool deadA = fa.zero || fa.nan, deadB = fb.zero || fb.nan;
-#pragma unroll
-        for (int a = 0; a < 16; a++) {
-            v[a].x = deadA ? 0.0 : v[a].x * ia;
-            v[a].y = deadB ? 0.0 : v[a].y * ib;
-        }
-        // ---- Z = FFT(yA + i yB)
-        fft4096(v, lds, p.tw1, p.tw2, t);
-        // ---- V[f] = Z[f] * conj(X[f]) / n      (f = t + 256*k)
-#pragma unroll
-        for (int k = 0; k < 16; k++)
-            v[k] = cmul(v[k], p.xc[t + 256 * k]);
-        // ---- ccA + i ccB = FFT(V)
-        fft4096(v, lds, p.tw1, p.tw2, t);
-
-        // ---- maxAbsIndex (xcorr.go:39-50) for both series: index = t + 256*k
-        double ma = 0.0, mb = 0.0, sa = 0.0, sb = 0.0;
-        int ka = 0, kb = 0;
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const double aa = fabs(v[k].x), ab = fabs(v[k].y);
-            if (aa > ma) { ma = aa; sa = v[k].x; ka = k; }
-            if (ab > mb) { mb = ab; sb = v[k].y; kb = k; }
-        }
-        double wa = wave_max(ma), wb = wave_max(mb);
-        if (lane == 0) {
-            red[32 + wave] = wa;
-            red[36 + wave] = wb;
-        }
-        __syncthreads();
-        const double MA = fmax(fmax(red[32], red[33]), fmax(red[34], red[35]));
-        const double MB = fmax(fmax(red[36], red[37]), fmax(red[38], red[39]));
-        int ca_i = (ma == MA && MA > 0.0) ? (t + 256 * ka) : 0x7fffffff;
-        int cb_i = (mb == MB && MB > 0.0) ? (t + 256 * kb) : 0x7fffffff;
-        ca_i = wave_min_i(ca_i);
-        cb_i = wave_min_i(cb_i);
-        if (lane == 0) {
-            redi[wave] = ca_i;
-            redi[4 + wave] = cb_i;
-        }
-        __syncthreads();
-        const int IA = min(min(redi[0], redi[1]), min(redi[2], redi[3]));
-        const int IB = min(min(redi[4], redi[5]), min(redi[6], redi[7]));
-        // owner thread writes (lag, mv)
-        {
-            const bool none = (IA == 0x7fffffff); // all |cc| == 0 or NaN: index 0, mv = cc[0]
-            const int idx = none ? 0 : IA;
-            if (t == (idx & 255)) {
-                double mv = none ? v[0].x : sa;
-                int lag = idx > 2048 ? idx - 4096 : idx;
-                if (fa.zero) { mv = 0.0; lag = 0; }
-                if (fa.nan) { mv = __builtin_nan(""); lag = 0; }
-                p.mv[rA] = mv;
-                p.lag[rA] = lag;
-            }
-        }
-        if (hasB) {
-            const bool none = (IB == 0x7fffffff);
-            const int idx = none ? 0 : IB;
-            if (t == (idx & 255)) {
-                double mv = none ? v[0].y : sb;
-                int lag = idx > 2048 ? idx - 4096 : idx;
-                if (fb.zero) { mv = 0.0; lag = 0; }
-                if (fb.nan) { mv = __builtin_nan(""); lag = 0; }
-                p.mv[rB] = mv;
-                p.lag[rB] = lag;
-            }
-        }
-    }
-}
-
-// ======================================================== generic kernel
-// Any power-of-two n in [2, 65536].  The n-element complex work buffer lives in LDS
-// (dynamic: n double2 + 64 doubles) for n <= 8192 and in a per-workgroup global
-// scratch buffer (L2-resident; __syncthreads orders the passes) above that.
-// In-place radix-2 DIF (natural -> bit-reversed), multiply by xc[brev],
-// in-place radix-2 DIT (bit-reversed -> natural).  twm = exp(-2 pi i k/65536), k < 32768.
-
 __device__ __forceinline__ void lds_dif(double2 *z, int n, int logn, const double2 *__restrict__ twm)
 {
     const int T = blockDim.x;
@@ -631,28 +449,12 @@ hipError_t launch_fused(const FusedParams &p, int variant, int num_cus, hipStrea
 {
     if (p.npairs <= 0)
         return hipSuccess;
-    if (variant == KERNEL_R16_FAST)
-        return launch_fused_fast(p, num_cus, stream);
+    if (variant == KERNEL_R16_FOLD)
+        return launch_fused_fold(p, num_cus, stream);
     if (variant == KERNEL_STOCKHAM)
         return launch_fused_stockham(p, num_cus, stream);
-    if (variant == KERNEL_R8_W8)
-        return launch_fused_w8(p, num_cus, stream);
-    if (variant == KERNEL_R16_SCREEN)
-        return launch_fused_screen(p, num_cus, stream);
-    if (variant == KERNEL_R16_OCC4)
-        return launch_fused_occ4(p, num_cus, 4, stream);
     if (variant == KERNEL_R16_OCC3)
-        return launch_fused_occ4(p, num_cus, 3, stream);
-    if (variant == KERNEL_R16_PIPE)
-        return launch_fused_pipe(p, num_cus, stream);
-    if (variant == KERNEL_R16_N4096) {
-        long long grid = p.npairs;
-        const long long cap = (long long)num_cus * 2 * 8; // persistent-ish: grid-stride beyond this
-        if (grid > cap)
-            grid = cap;
-        hipLaunchKernelGGL(xcorr_fused_n4096, dim3((unsigned)grid), dim3(R16_THREADS), 0, stream, p);
-        return hipGetLastError();
-    }
+        return launch_fused_occ4(p, num_cus, stream);
     const bool global_mode = p.n > GENERIC_LDS_MAX_N;
     if (global_mode && !p.gscratch)
         return hipErrorInvalidValue;

@@ -1,0 +1,1053 @@
+// xcorr_r16_fold.hip -- the default n = 4096 fp64 kernel (2048 < N <= 4096), round 2.
+//
+// Mathematics: xCorrWithX, /root/reference/xcorr.go:160-197 (z-normalise, leading zero pad, forward
+// transform, multiply by the conjugate reference spectrum, inverse transform, 1/n, global argmax of |cc|),
+// two series per complex transform as in xcorr_r16_fast.hip, whose data flow this kernel keeps: 256 threads x
+// 16 points, three radix-16 passes per transform, four LDS transposes per pair of which two stay inside a
+// wave, nine workgroup barriers, statistics off the DC bin, a resident grid with dynamic pair hand-out,
+// NaN/Inf and sigma-spread pairs handed to the rescaling kernel.
+//
+// What is new is the ARITHMETIC (fold_device.h).  The round-1 kernel was bound by fp64 VALU issue
+// (1 456 v_*_f64 per wave per pair).  n = 16^3, input index j = 256 a + 16 b + c, output f = k1 + 16 k2 + 256 k3:
+//     X[f] = sum_c W_16^(c (k3 + (k1 + 16 k2)/256))  sum_b W_16^(b (k2 + k1/16))  sum_a W_16^(a k1) x[j]
+// i.e. a plain 16-point DFT followed by two GENERALISED 16-point DFTs whose per-thread phase shift delta
+// (k1/16 for pass 2, (k1 + 16 k2)/256 for pass 3) carries what used to be 2 x 15 twiddle multiplications per
+// thread; each generalised pass is 32 butterflies of 6 FMAs (192 instead of 160 + 60), the plain pass 148
+// instead of 160, and the multiplication by the reference spectrum is folded into the first stage of the second
+// transform's plain pass (196 instead of 64 + 160).  Per thread and pair: 532 + 580 instead of 2 x 600 + 64
+// fp64 instructions in the transforms, and 8 + 16 + 8 table loads from L2 instead of 15 + 16 + 15
+// (fold_device.h: every stage's twiddles are one of eight per-thread constants times 1 or -i).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <algorithm>
+
+#include "fold_device.h"
+#include "r16_device.h"
+
+namespace muse {
+
+// MUSE_FOLD_EXP (tools/ablate only; never defined in the library build): bit 0 = pass-3 factors read from the LDS
+// table instead of L2 (wrong values, same arithmetic), bit 1 = spectrum factors likewise, bit 3 = no result write-out
+#ifndef MUSE_FOLD_EXP
+#define MUSE_FOLD_EXP 0
+#endif
+
+// MUSE_FOLD_OPT: scheduling choices, A/B-ed in tools/ablate/fold_phases.hip (the library builds the default):
+//   bit 0: the previous pair's two results are written by lane 0 of waves 0 and 1 (one series each) instead of lanes 0 / 1 of wave 0
+//   bit 1: the first four factors of a pass-3 transform are requested BEFORE the transpose that precedes it
+//   bit 2: the first spectrum factors are requested before the last stage of the first transform
+//   bit 3: the next pair's first row is requested before the last stage of the second transform, the second row after the argmax
+//   bit 6: the barrier that frees the wave's private quarter sits right behind the first workgroup-wide transpose
+//   bit 7: the second transform's last stage, the argmax and the next pair's row requests interleaved (N == n)
+//   bit 8: the argmax as one running maximum per lane, the next pair's row requests spread over it
+//   bit 4: all eight factors of a pass-3 transform requested at once;  bit 5: both rows requested before the last stage (3 waves per SIMD)
+#ifndef MUSE_FOLD_OPT
+#define MUSE_FOLD_OPT 65
+#endif
+
+namespace foldk {
+
+using namespace occ4;
+using namespace fold;
+
+constexpr int XW = 544; // double2 per wave-private quarter of the 8 x 272 buffer (8 rows x 68)
+
+// The thread index made opaque: everything derived from the copy (lane / wave parts, LDS and table offsets) is
+// recomputed where it is used (a few 32-bit VALU instructions) instead of being hoisted out of the pair loop, where a
+// dozen such values would each hold a register for the whole kernel -- or, at 128 registers, a scratch slot that is
+// reloaded through the vector memory pipe in front of every use.
+#ifndef MUSE_FOLD_FRESH
+#define MUSE_FOLD_FRESH 0
+#endif
+template <int BIT>
+__device__ __forceinline__ int fresh(int t)
+{
+    if (MUSE_FOLD_FRESH & BIT)
+        asm volatile("" : "+v"(t));
+    return t;
+}
+
+// output k of the preceding pass sits in register PERM(k): 0 = natural, 1 = bit-reversed (NR passes)
+template <int PERM>
+__device__ __forceinline__ constexpr int pr(int k)
+{
+    return PERM ? BR16(k) : k;
+}
+
+// Workgroup-wide transpose in two half rounds (layouts and bank analysis: xcorr_r16_fast.hip exchange_cross)
+// TAILBAR: one more barrier right behind the late waves' reads, so that the NEXT use of the buffer (a wave-local
+// transpose into the wave's private quarter) needs none: the waves are still in step here, whereas a barrier in
+// front of that next use also waits out everything the waves drifted apart in between (2.3 k cycles per pair,
+// profiles/r02_fold_phase_stamps.txt).
+template <int MODE, int PERM, bool TAILBAR = false>
+__device__ __forceinline__ void exchange_cross(double2 (&v)[16], double2 *xbuf, const int wave, const int t_)
+{
+    const int t = fresh<1>(t_);
+    const int hi = t >> 4, lo = t & 15;
+    const int wbase = MODE ? 17 * lo + hi : t;
+    const int rbase = 272 * (hi & 7) + (MODE ? 17 * lo : lo);
+    const bool early = wave < 2;
+    lds_barrier(); // buffer free: every wave is done with its previous (wave-local or shared) use
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        xbuf[272 * k + wbase] = v[pr<PERM>(k)];
+    lds_barrier();
+    if (early) {
+        double2 w[16];
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+            w[e] = xbuf[rbase + (MODE ? e : 16 * e)];
+        lds_barrier();
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            xbuf[272 * k + wbase] = v[pr<PERM>(8 + k)];
+        lds_barrier();
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+            v[e] = w[e];
+    } else {
+        lds_barrier();
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            xbuf[272 * k + wbase] = v[pr<PERM>(8 + k)];
+        lds_barrier();
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+            v[e] = xbuf[rbase + (MODE ? e : 16 * e)];
+    }
+    if (TAILBAR)
+        lds_barrier();
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(3))) char *lds_ptr;
+#define MUSE_LDS_ADDR(p) ((unsigned)(unsigned long long)(lds_ptr)(p))
+#else
+#define MUSE_LDS_ADDR(p) 0u
+#endif
+// Wave-local transpose among the sixteen lanes that share hi (layout: xcorr_r16_fast.hip exchange_local)
+template <int PERM>
+__device__ __forceinline__ void exchange_local(double2 (&v)[16], double2 *xw, const int t_)
+{
+    const int t = fresh<2>(t_);
+    const int hl = (t >> 4) & 3, lo = t & 15;
+    const int wbase = 17 * hl + lo;
+    const int rbase = 68 * (lo & 7) + 17 * hl;
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        xw[68 * k + wbase] = v[pr<PERM>(k)];
+    const unsigned waddr = MUSE_LDS_ADDR(xw + wbase), raddr = MUSE_LDS_ADDR(xw + rbase);
+    const unsigned long long first = __ballot(lo < 8); // lanes that read in round 0
+    d2v w[16], d[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        d[k].x = v[pr<PERM>(8 + k)].x;
+        d[k].y = v[pr<PERM>(8 + k)].y;
+    }
+    unsigned long long sv;
+    asm volatile("s_mov_b64 %[sv], exec\n\t"
+                 "s_and_b64 exec, %[sv], %[m]\n\t"
+                 "ds_read_b128 %[w0], %[ra]\n\t"
+                 "ds_read_b128 %[w1], %[ra] offset:16\n\t"
+                 "ds_read_b128 %[w2], %[ra] offset:32\n\t"
+                 "ds_read_b128 %[w3], %[ra] offset:48\n\t"
+                 "ds_read_b128 %[w4], %[ra] offset:64\n\t"
+                 "ds_read_b128 %[w5], %[ra] offset:80\n\t"
+                 "ds_read_b128 %[w6], %[ra] offset:96\n\t"
+                 "ds_read_b128 %[w7], %[ra] offset:112\n\t"
+                 "ds_read_b128 %[w8], %[ra] offset:128\n\t"
+                 "ds_read_b128 %[w9], %[ra] offset:144\n\t"
+                 "ds_read_b128 %[w10], %[ra] offset:160\n\t"
+                 "ds_read_b128 %[w11], %[ra] offset:176\n\t"
+                 "ds_read_b128 %[w12], %[ra] offset:192\n\t"
+                 "ds_read_b128 %[w13], %[ra] offset:208\n\t"
+                 "ds_read_b128 %[w14], %[ra] offset:224\n\t"
+                 "ds_read_b128 %[w15], %[ra] offset:240\n\t"
+                 "s_mov_b64 exec, %[sv]\n\t"
+                 "ds_write_b128 %[wa], %[d0]\n\t"
+                 "ds_write_b128 %[wa], %[d1] offset:1088\n\t"
+                 "ds_write_b128 %[wa], %[d2] offset:2176\n\t"
+                 "ds_write_b128 %[wa], %[d3] offset:3264\n\t"
+                 "ds_write_b128 %[wa], %[d4] offset:4352\n\t"
+                 "ds_write_b128 %[wa], %[d5] offset:5440\n\t"
+                 "ds_write_b128 %[wa], %[d6] offset:6528\n\t"
+                 "ds_write_b128 %[wa], %[d7] offset:7616\n\t"
+                 "s_andn2_b64 exec, %[sv], %[m]\n\t"
+                 "ds_read_b128 %[w0], %[ra]\n\t"
+                 "ds_read_b128 %[w1], %[ra] offset:16\n\t"
+                 "ds_read_b128 %[w2], %[ra] offset:32\n\t"
+                 "ds_read_b128 %[w3], %[ra] offset:48\n\t"
+                 "ds_read_b128 %[w4], %[ra] offset:64\n\t"
+                 "ds_read_b128 %[w5], %[ra] offset:80\n\t"
+                 "ds_read_b128 %[w6], %[ra] offset:96\n\t"
+                 "ds_read_b128 %[w7], %[ra] offset:112\n\t"
+                 "ds_read_b128 %[w8], %[ra] offset:128\n\t"
+                 "ds_read_b128 %[w9], %[ra] offset:144\n\t"
+                 "ds_read_b128 %[w10], %[ra] offset:160\n\t"
+                 "ds_read_b128 %[w11], %[ra] offset:176\n\t"
+                 "ds_read_b128 %[w12], %[ra] offset:192\n\t"
+                 "ds_read_b128 %[w13], %[ra] offset:208\n\t"
+                 "ds_read_b128 %[w14], %[ra] offset:224\n\t"
+                 "ds_read_b128 %[w15], %[ra] offset:240\n\t"
+                 "s_mov_b64 exec, %[sv]\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : [w0] "=&v"(w[0]), [w1] "=&v"(w[1]), [w2] "=&v"(w[2]), [w3] "=&v"(w[3]), [w4] "=&v"(w[4]),
+                   [w5] "=&v"(w[5]), [w6] "=&v"(w[6]), [w7] "=&v"(w[7]), [w8] "=&v"(w[8]), [w9] "=&v"(w[9]),
+                   [w10] "=&v"(w[10]), [w11] "=&v"(w[11]), [w12] "=&v"(w[12]), [w13] "=&v"(w[13]),
+                   [w14] "=&v"(w[14]), [w15] "=&v"(w[15]), [sv] "=&s"(sv)
+                 : [ra] "v"(raddr), [wa] "v"(waddr), [m] "s"(first), [d0] "v"(d[0]), [d1] "v"(d[1]), [d2] "v"(d[2]),
+                   [d3] "v"(d[3]), [d4] "v"(d[4]), [d5] "v"(d[5]), [d6] "v"(d[6]), [d7] "v"(d[7])
+                 : "memory", "scc");
+#pragma unroll
+    for (int e = 0; e < 16; e++)
+        v[e] = make_double2(w[e].x, w[e].y);
+}
+
+// the eight per-thread factors of a generalised pass (fold_device.h):
+//   pass 2 (delta = j / 16): LDS table g2s[16 s + j];  pass 3 (delta = u / 256): lane-ordered global table [8][256]
+struct G2Fetch {
+    const double2 *p;
+    int j;
+    __device__ __forceinline__ double2 operator()(int s) const { return p[16 * s + j]; }
+};
+struct G3Fetch {
+    const double2 *p;
+    int t;
+    __device__ __forceinline__ double2 operator()(int s) const
+    {   // one scalar base per two planes: the odd plane sits at immediate offset -4096 B
+        return ldg2(scalar_ptr_at(p, ((s + 1) & ~1) * 256), t - 256 * (s & 1));
+    }
+};
+
+// generalised pass whose first four factors (ga) were requested earlier; `mid()` runs between stage 3 and stage 4
+template <typename F, typename MID>
+__device__ __forceinline__ void gdft16_nr_pre(double2 (&v)[16], const double2 (&ga)[4], F fetch, MID mid)
+{
+    double2 gb[4];
+    if (MUSE_FOLD_OPT & 16) {
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+            gb[s] = fetch(4 + s);
+        fence();
+    }
+    gdft16_nr_s12(v, ga[0], ga[1]);
+    if (!(MUSE_FOLD_OPT & 16)) {
+        fence();
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+            gb[s] = fetch(4 + s);
+    }
+    fence();
+    gdft16_nr_s3(v, ga[2], ga[3]);
+    fence();
+    mid();
+    fence();
+    gdft16_nr_s4(v, gb[0], gb[1], gb[2], gb[3]);
+}
+
+// LDS record of one pair (one per parity): as in xcorr_r16_fast.hip
+constexpr int REC = 36;
+
+// cross-wave argmax combine + variance + store (lanes 0 / 1, one series each);
+// returns true when the series' statistics are NaN/Inf or the pair's sigmas are too far apart (the pair is redone)
+__device__ __forceinline__ bool finalize(const double *r, const int series, const double invN, const double invNm1,
+                                         double *mv_out, int *lag_out)
+{
+    double m[4], s[4], ix[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        m[w] = r[6 * w + 3 * series];
+        s[w] = r[6 * w + 3 * series + 1];
+        ix[w] = r[6 * w + 3 * series + 2];
+    }
+    const double s2 = (r[24 + series] + r[26 + series]) + (r[28 + series] + r[30 + series]);
+    const Stat st{r[32 + series], s2};
+    double best = m[0], bsv = s[0], bidx = ix[0];
+#pragma unroll
+    for (int w = 1; w < 4; w++) {
+        if (m[w] > best || (m[w] == best && ix[w] < bidx)) {
+            best = m[w];
+            bsv = s[w];
+            bidx = ix[w];
+        }
+    }
+    bool zero, nan;
+    const double var = variance(st, invN, invNm1, zero, nan);
+    const int idx = (best > 0.0) ? (int)bidx : 0; // nothing above 0: index 0, mv = cc[0]
+    double y = __builtin_amdgcn_rsq(var);
+    y = y * fma(-0.5 * var * y, y, 1.5);
+    y = y * fma(-0.5 * var * y, y, 1.5);
+    double mv = ((best > 0.0) ? bsv : s[0]) * y;
+    int lag = idx > 2048 ? idx - 4096 : idx;
+    if (zero) { mv = 0.0; lag = 0; }              // xcorr.go:166-167
+    if (nan) { mv = __builtin_nan(""); lag = 0; } // placeholder: the pair is redone
+    *mv_out = mv;
+    *lag_out = lag;
+    bool redo = nan;
+    if (series == 0 && r[35] != 0.0) { // the pair's other series: sigmas too far apart for one shared transform?
+        const double s2b = (r[25] + r[27]) + (r[29] + r[31]);
+        const Stat sb{r[33], s2b};
+        bool zb, nb;
+        const double varb = variance(sb, invN, invNm1, zb, nb);
+        redo = redo || (!nb && sigma_spread_too_wide(var, varb));
+    }
+    return redo;
+}
+
+// maxAbsIndex (xcorr.go:39-50) over the wave's 16 x 64 values of both series; value of lag index t + 256 m sits in
+// register BR16(m).  Writes the wave's {max |cc|, signed value (cc[0] when nothing is above 0), index} per series.
+__device__ __forceinline__ void wave_argmax_store(const double2 (&v)[16], const int wave, const int lane, double *ra_)
+{
+    double ma = 0.0, mb = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        ma = fmax(ma, fabs(v[k].x));
+        mb = fmax(mb, fabs(v[k].y));
+    }
+    const double wa = wave_max_dpp(ma), wb = wave_max_dpp(mb);
+    int widxA = 0x7fffffff, widxB = 0x7fffffff;
+    double svA = 0.0, svB = 0.0;
+    {
+        unsigned long long selA = 0ull, selB = 0ull;
+        int kA = 0, kB = 0, hiA = 0, hiB = 0;
+#pragma unroll
+        for (int m = 15; m >= 0; m--) { // descending index: the lowest is selected last
+            const int k = BR16(m);
+            const unsigned long long mA_ = __ballot(fabs(v[k].x) == wa);
+            const unsigned long long mB_ = __ballot(fabs(v[k].y) == wb);
+            const bool hA = mA_ != 0ull, hB = mB_ != 0ull; // wave-uniform
+            selA = hA ? mA_ : selA;
+            kA = hA ? m : kA;
+            hiA = hA ? __double2hiint(v[k].x) : hiA;
+            selB = hB ? mB_ : selB;
+            kB = hB ? m : kB;
+            hiB = hB ? __double2hiint(v[k].y) : hiB;
+        }
+        if (wa > 0.0 && selA != 0ull) {
+            const int l = __ffsll((long long)selA) - 1;
+            widxA = wave * 64 + l + 256 * kA;
+            svA = (__builtin_amdgcn_readlane(hiA, l) < 0) ? -wa : wa;
+        }
+        if (wb > 0.0 && selB != 0ull) {
+            const int l = __ffsll((long long)selB) - 1;
+            widxB = wave * 64 + l + 256 * kB;
+            svB = (__builtin_amdgcn_readlane(hiB, l) < 0) ? -wb : wb;
+        }
+    }
+    const double cc0a = v[0].x, cc0b = v[0].y; // index t + 256 * 0 (BR16(0) = 0): cc[0] in wave 0 lane 0
+    if (lane == 0) {
+        ra_[0] = widxA == 0x7fffffff ? 0.0 : wa;
+        ra_[1] = widxA == 0x7fffffff ? cc0a : svA;
+        ra_[2] = (double)widxA;
+        ra_[3] = widxB == 0x7fffffff ? 0.0 : wb;
+        ra_[4] = widxB == 0x7fffffff ? cc0b : svB;
+        ra_[5] = (double)widxB;
+    }
+}
+
+// Per-lane running maxAbsIndex (xcorr.go:39-50: strictly greater replaces, so ascending indices keep the first):
+// `best` is the signed value, m its index among the lane's sixteen lags t + 256 m.
+struct ArgRun {
+    double best;
+    int m;
+};
+__device__ __forceinline__ void arg_consume(ArgRun &r, const double x, const int m)
+{
+    const bool g = fabs(x) > fabs(r.best);
+    r.best = g ? x : r.best;
+    r.m = g ? m : r.m;
+    // pinned here: IR-level passes otherwise sink a whole series' chain below the interleaved row requests (sched_barrier
+    // only binds the machine scheduler) and the consumed values stay live
+    asm volatile("" : "+v"(r.best), "+v"(r.m));
+}
+// lo chain (m = 0..7) and hi chain (m = 8..15), both ascending: the hi chain wins only when strictly greater
+__device__ __forceinline__ ArgRun arg_merge(const ArgRun &lo, const ArgRun &hi)
+{
+    ArgRun r = lo;
+    const bool g = fabs(hi.best) > fabs(lo.best);
+    r.best = g ? hi.best : lo.best;
+    r.m = g ? hi.m : lo.m;
+    return r;
+}
+// the wave's {max |cc|, signed value (cc[0] when nothing is above 0), index} of one series from the lanes' running maxima
+__device__ __forceinline__ void wave_argmax_finish(const ArgRun &r, const int t, const int lane, double *out)
+{
+    const double mine = fabs(r.best);
+    const double wa = wave_max_dpp(mine);
+    const int cand = (mine == wa && wa > 0.0) ? (t + 256 * r.m) : 0x7fffffff;
+    const int widx = wave_min_i_dpp(cand);
+    const int l = widx & 63; // wave-uniform (SGPR)
+    const double sv = readlane_f64(r.best, l);
+    if (lane == 0) { // (nothing above 0: slot 1 of wave 0 keeps cc[0], written there by the caller)
+        out[0] = widx == 0x7fffffff ? 0.0 : wa;
+        if (widx != 0x7fffffff)
+            out[1] = sv;
+        out[2] = (double)widx;
+    }
+}
+
+// spectrum multiply folded into the first stage of the second transform's plain pass:
+// z[b] at v[BR16(b)] (b = k3), xc for k3 = b from the lane-ordered table; four batches of four factors, two in flight
+template <bool PRE, typename F>
+__device__ __forceinline__ void xc_stage1(double2 (&v)[16], double2 (&xa)[4], F xcl)
+{
+    double2 xb[4];
+    // batch i covers butterflies b = 2 i, 2 i + 1: factors xc[2i], xc[2i + 8], xc[2i + 1], xc[2i + 9]
+#define MUSE_XC_LOAD(dst, i)          \
+    dst[0] = xcl(2 * (i));            \
+    dst[1] = xcl(2 * (i) + 8);        \
+    dst[2] = xcl(2 * (i) + 1);        \
+    dst[3] = xcl(2 * (i) + 9);
+#define MUSE_XC_USE(src, i)                                                      \
+    bf_xc(v[BR16(2 * (i))], v[BR16(2 * (i)) + 1], src[0], src[1]);               \
+    bf_xc(v[BR16(2 * (i) + 1)], v[BR16(2 * (i) + 1) + 1], src[2], src[3]);
+    if (!PRE) {
+        MUSE_XC_LOAD(xa, 0)
+    }
+    MUSE_XC_LOAD(xb, 1)
+    fence();
+    MUSE_XC_USE(xa, 0)
+    fence();
+    MUSE_XC_LOAD(xa, 2)
+    MUSE_XC_USE(xb, 1)
+    fence();
+    MUSE_XC_LOAD(xb, 3)
+    MUSE_XC_USE(xa, 2)
+    fence();
+    MUSE_XC_USE(xb, 3)
+#undef MUSE_XC_LOAD
+#undef MUSE_XC_USE
+}
+
+} // namespace foldk
+
+// PADDED (2048 < N < 4096, leading zero pad): as in xcorr_r16_fast.hip -- the transforms run on d, sum d is read
+// off the DC bin and the 16 values a lane ends with are corrected by -m c1[index] before the argmax.
+#ifndef MUSE_FOLD_WPS
+#define MUSE_FOLD_WPS 4
+#endif
+template <bool TIMING = false, bool PADDED = false>
+__global__ __launch_bounds__(OCC_THREADS, MUSE_FOLD_WPS) void xcorr_fused_n4096_fold(const FusedParams p)
+{
+    using namespace occ4;
+    using namespace fold;
+    using namespace foldk;
+    __shared__ double2 xbuf[OCC_XBUF];
+    __shared__ double2 g2s[128];
+    __shared__ double red[2 * REC];
+    __shared__ int next_s[2];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6); // wave-uniform by construction
+    const int hi = t >> 4, lo = t & 15;
+    double2 *const xw = xbuf + XW * wave;
+    const int pad = PADDED ? 4096 - p.N : 0;
+    const double invN = PADDED ? 1.0 / (double)p.N : 1.0 / 4096.0, invNm1 = PADDED ? 1.0 / (double)(p.N - 1) : 1.0 / 4095.0;
+
+    if (t < 128)
+        g2s[t] = p.g2[t];
+    if (t < 2)
+        red[REC * (t) + 34] = -1.0; // no previous pair yet (either parity)
+    __syncthreads();
+    PhaseClock<TIMING> clk;
+    clk.start();
+
+    int parity = 0;
+    const long long total = p.npairs;
+    RawPair raw;
+    issue_row_loads<PADDED>(raw, p, blockIdx.x < total ? (long long)blockIdx.x : 0ll, t, pad);
+
+    long long nextpair = 0;
+    for (long long pair = blockIdx.x; pair < total; pair = nextpair) {
+        const long long rA = 2 * pair;
+        const bool hasB = rA + 1 < p.M;
+        double *const rec = red + REC * parity;
+        const double *const prec = red + REC * (parity ^ 1);
+        if (t == 0) // the pair after this one: claimed now, read behind this pair's barriers
+            next_s[parity] = (int)gridDim.x + atomicAdd(p.work_counter, 1);
+        // ---- consume the prefetched rows: d = x - K (K = the row's first sample) bounds the cancellation in
+        // sum d^2 - (sum d)^2 / N and keeps a large level out of the transform's rounding; sum d is read off the DC bin
+        double2 v[16];
+        {
+            const double KA = raw.ka, KB = raw.kb;
+            double qa = 0.0, qb = 0.0;
+            if (TIMING)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            clk.template stamp<0>();
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                // (PADDED: a pad position was loaded from the clamped index 0, i.e. it holds the row's first
+                // sample K itself, so d = K - K = 0 without any masking)
+                const double da = raw.a[i] - KA, db = raw.b[i] - KB;
+                v[i] = make_double2(da, db);
+                qa = fma(da, da, qa);
+                qb = fma(db, db, qb);
+            }
+            qa = wave_sum_dpp(qa);
+            qb = wave_sum_dpp(qb);
+            if (lane == 0) {
+                rec[24 + 2 * wave] = qa;
+                rec[24 + 2 * wave + 1] = qb;
+            }
+            if (t == 0) {
+                rec[34] = (double)rA;
+                rec[35] = hasB ? 1.0 : 0.0;
+            }
+        }
+        clk.template stamp<1>();
+        constexpr int OPT = MUSE_FOLD_OPT;
+        int tx = t, tg = t; // opaque copies, refreshed in front of the passes that use them
+        const auto xcl = [&](int j) __attribute__((always_inline)) {
+            if (MUSE_FOLD_EXP & 2)
+                return g2s[(8 * j + lo) & 127];
+            return ldg2(scalar_ptr_at(p.xcp, 256 * ((j + 1) & ~1)), tx - 256 * (j & 1));
+        };
+        const auto g3 = [&](const double2 *tab, int s) __attribute__((always_inline)) {
+            if (MUSE_FOLD_EXP & 1)
+                return g2s[(16 * s + lo) & 127];
+            return G3Fetch{tab, tg}(s);
+        };
+        // ================= Z = FFT(dA + i dB) =================
+        // pass 1: plain DFT over a (thread (b, c) = (hi, lo)) -> k1 at v[BR16(k1)]
+        dft16_nr(v);
+        clk.template stamp<2>();
+        exchange_cross<0, 1, (MUSE_FOLD_OPT & 64) != 0>(v, xbuf, wave, t); // -> thread (k1 = hi, c = lo), input b at v[b]
+        // the previous pair's record is complete and visible: write its results
+        if (!(MUSE_FOLD_EXP & 8)) {
+            const bool writer = (OPT & 1) ? (lane == 0 && wave < 2) : (t < 2);
+            const int series = (OPT & 1) ? wave : t;
+            if (writer && prec[34] >= 0.0 && (series == 0 || prec[35] != 0.0)) {
+                const long long row = (long long)prec[34] + series;
+                if (finalize(prec, series, invN, invNm1, p.mv + row, p.lag + row)) {
+                    const int slot = atomicAdd(p.ovf_count, 1);
+                    p.ovf_list[slot] = row >> 1;
+                }
+            }
+        }
+        clk.template stamp<3>();
+        // pass 2: generalised DFT over b, delta = k1 / 16 (carries W_256^(b k1))
+        gdft16_nr(v, G2Fetch{g2s, fresh<4>(t) >> 4});
+        clk.template stamp<4>();
+        double2 ga[4], xa[4];
+        if (OPT & 2) { // pass 3's first factors (L2) travel during the transpose
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                ga[q] = g3(p.g3a, q);
+            fence();
+        }
+        if (!(OPT & 64))
+            lds_barrier(); // waves 2-3 may still be reading this wave's quarter (round 1 above)
+        exchange_local<1>(v, xw, t); // -> thread (k1 = hi, k2 = lo), input c at v[c]
+        clk.template stamp<5>();
+        // pass 3: generalised DFT over c, delta = (k1 + 16 k2) / 256 (carries W_4096^(c k1) W_256^(c k2));
+        // Z[hi + 16 lo + 256 k3] at v[BR16(k3)]
+        tg = fresh<8>(t);
+        if (!(OPT & 2)) {
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                ga[q] = g3(p.g3a, q);
+        }
+        gdft16_nr_pre(v, ga, [&](int q) __attribute__((always_inline)) { return g3(p.g3a, q); },
+                      [&]() __attribute__((always_inline)) {
+                          if (OPT & 4) { // the second transform's first spectrum factors, behind the last stage
+                              xa[0] = xcl(0);
+                              xa[1] = xcl(8);
+                              xa[2] = xcl(1);
+                              xa[3] = xcl(9);
+                          }
+                      });
+        double s1a, s1b;
+        {
+            // bin 0 (lane 0 of wave 0) = (sum dA, sum dB): kept in SGPRs until the record is written; the centred
+            // series' DC bin is exactly 0.  Branch-free on purpose.
+            s1a = readlane_f64(v[0].x, 0);
+            s1b = readlane_f64(v[0].y, 0);
+            if (!PADDED) {
+                v[0].x = (t == 0) ? 0.0 : v[0].x;
+                v[0].y = (t == 0) ? 0.0 : v[0].y;
+            }
+        }
+        clk.template stamp<6>();
+        // ================= ccA + i ccB = FFT(Z conj(X)/n) (unscaled by 1/sigma) =================
+        // element f = 256 a' + 16 b' + c' with a' = k3 (register BR16(a')), b' = lo, c' = hi
+        // pass 1: plain DFT over a' with the spectrum factors folded into its first stage -> m1 at v[m1]
+        tx = fresh<8>(t);
+        xc_stage1<(OPT & 4) != 0>(v, xa, xcl);
+        dft16_rn_s234(v);
+        clk.template stamp<7>();
+        exchange_local<0>(v, xw, t); // (c' = hi, b' = lo) -> (c' = hi, m1 = lo), input b' at v[b']: same wave
+        if (PADDED && wave == 0 && lane == 0) { // every lane needs the means before its argmax: visible behind
+            rec[32] = s1a;                      // the four barriers of the transpose below
+            rec[33] = s1b;
+        }
+        clk.template stamp<8>();
+        // pass 2: generalised DFT over b', delta = m1 / 16, m1 = lo
+        gdft16_nr(v, G2Fetch{g2s, fresh<4>(t) & 15});
+        clk.template stamp<9>();
+        if (OPT & 2) {
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                ga[q] = g3(p.g3b, q);
+            fence();
+        }
+        exchange_cross<1, 1>(v, xbuf, wave, t); // -> thread (m1 = lo, m2 = hi), input c' at v[c']
+        clk.template stamp<10>();
+        // pass 3: generalised DFT over c', delta = (m1 + 16 m2) / 256 = t / 256: cc index t + 256 m3 at v[BR16(m3)]
+        nextpair = __builtin_amdgcn_readfirstlane(next_s[parity]);
+        long long nxt = nextpair; // last iteration: pair 0 (L2-resident dummy)
+        nxt = nxt < total ? nxt : 0;
+        {
+            const auto c1l = [&](int k) __attribute__((always_inline)) {
+                return scalar_ptr_at(p.c1, 256 * ((k + 1) & ~1))[t - 256 * (k & 1)];
+            };
+            tg = fresh<8>(t);
+            if (!(OPT & 2)) {
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    ga[q] = g3(p.g3b, q);
+            }
+            if ((OPT & 128) && !PADDED) {
+                // stages 1..3, then the last stage butterfly by butterfly: each one finishes the lags t + 256 m and
+                // t + 256 (m + 8), which go straight into the lane's running maxima (their registers die), and the next
+                // pair's rows are requested four loads at a time into the registers that just became free -- the HBM
+                // requests are spread over the stage and the argmax instead of one burst behind them that blocks the
+                // wave at issue (profiles/r02_fold_phase_stamps.txt: 7 k of 38 k cycles per pair)
+                double2 gb[4];
+                gdft16_nr_s12(v, ga[0], ga[1]);
+                fence();
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    gb[q] = g3(p.g3b, q + 4);
+                fence();
+                gdft16_nr_s3(v, ga[2], ga[3]);
+                fence();
+                issue_row_firsts(raw, p, nxt);
+                ArgRun loA{0.0, 0}, loB{0.0, 0}, hiA{0.0, 8}, hiB{0.0, 8};
+#pragma unroll
+                for (int m = 0; m < 8; m++) {
+                    const int pos = BR16(m); // even; lag m at v[pos], lag m + 8 at v[pos + 1]
+                    if (m < 4)
+                        bf_gen(v[pos], v[pos + 1], gb[m & 3]);
+                    else
+                        bf_gen_mi(v[pos], v[pos + 1], gb[m & 3]);
+                    if (m == 0 && t == 0) { // cc[0], the value reported when nothing is above 0
+                        rec[1] = v[0].x;
+                        rec[4] = v[0].y;
+                    }
+                    arg_consume(loA, v[pos].x, m);
+                    arg_consume(loB, v[pos].y, m);
+                    arg_consume(hiA, v[pos + 1].x, m + 8);
+                    arg_consume(hiB, v[pos + 1].y, m + 8);
+                    fence();
+                    issue_row_elem(raw, p, nxt, t, 2 * m);
+                    issue_row_elem(raw, p, nxt, t, 2 * m + 1);
+                    fence();
+                }
+                clk.template stamp<11>();
+                const ArgRun ra_ = arg_merge(loA, hiA), rb_ = arg_merge(loB, hiB);
+                wave_argmax_finish(ra_, t, lane, rec + 6 * wave);
+                wave_argmax_finish(rb_, t, lane, rec + 6 * wave + 3);
+            } else {
+            gdft16_nr_pre(v, ga, [&](int q) __attribute__((always_inline)) { return g3(p.g3b, q); },
+                          [&]() __attribute__((always_inline)) {
+                              if (OPT & 8)
+                                  issue_row_loads_half<PADDED, 0>(raw, p, nxt, t, pad);
+                              if (OPT & 32) // (168 registers: both rows)
+                                  issue_row_loads<PADDED>(raw, p, nxt, t, pad);
+                          });
+            if (PADDED) { // cc(d - m 1_valid) = cc(d) - m c1, m = sum d / N
+                const double mA = rec[32] * invN, mB = rec[33] * invN;
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    double cq[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++)
+                        cq[k] = c1l(8 * h + k);
+                    fence();
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const int r = BR16(8 * h + k);
+                        v[r] = make_double2(fma(-mA, cq[k], v[r].x), fma(-mB, cq[k], v[r].y));
+                    }
+                }
+            }
+            clk.template stamp<11>();
+            if (OPT & 256) {
+                // one running maximum per lane and series over ascending lags; a consumed value's registers take the next
+                // pair's row requests, two loads at a time: the requests are spread over the argmax instead of one burst
+                // behind it
+                if (t == 0) { // cc[0], the value reported when nothing is above 0 (overwritten below otherwise)
+                    rec[1] = v[0].x;
+                    rec[4] = v[0].y;
+                }
+                issue_row_firsts(raw, p, nxt);
+                const int tr = fresh<16>(t);
+                ArgRun ra_{0.0, 0}, rb_{0.0, 0};
+#pragma unroll
+                for (int m = 0; m < 16; m++) {
+                    arg_consume(ra_, v[BR16(m)].x, m);
+                    arg_consume(rb_, v[BR16(m)].y, m);
+                    fence();
+                    if (PADDED)
+                        issue_row_elem_padded(raw, p, nxt, tr, m, pad);
+                    else
+                        issue_row_elem(raw, p, nxt, tr, m);
+                    fence();
+                }
+                wave_argmax_finish(ra_, t, lane, rec + 6 * wave);
+                wave_argmax_finish(rb_, t, lane, rec + 6 * wave + 3);
+            } else {
+            wave_argmax_store(v, wave, lane, rec + 6 * wave);
+            fence();
+            if (OPT & 8)
+                issue_row_loads_half<PADDED, 1>(raw, p, nxt, t, pad);
+            else if (!(OPT & 32))
+                issue_row_loads<PADDED>(raw, p, nxt, t, pad);
+            fence();
+            }
+            }
+        }
+        if (wave == 0 && lane == 0) {
+            rec[32] = s1a;
+            rec[33] = s1b;
+        }
+        parity ^= 1;
+        clk.template stamp<12>();
+    }
+    lds_barrier();
+    {
+        const double *const prec = red + REC * (parity ^ 1);
+        if (t < 2 && prec[34] >= 0.0 && (t == 0 || prec[35] != 0.0)) {
+            const long long row = (long long)prec[34] + t;
+            if (finalize(prec, t, invN, invNm1, p.mv + row, p.lag + row)) {
+                const int slot = atomicAdd(p.ovf_count, 1);
+                p.ovf_list[slot] = row >> 1;
+            }
+        }
+    }
+    if (TIMING && p.dbg && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NPHASE; i++)
+            p.dbg[((long long)blockIdx.x * 4 + wave) * NPHASE + i] = clk.acc[i];
+    }
+}
+
+// ============================================================================
+// Many references against one resident group in ONE pass over the rows
+// (the README use case iterates references over a fixed set of
+// series).  Each pair of series is read from HBM and forward-transformed once; its
+// spectrum Z (DC bin zeroed) is parked in a 64 KB per-workgroup slice of a global
+// scratch buffer (L2 / Infinity-Cache resident: every lane re-reads exactly the
+// addresses it wrote) and re-loaded for references 1..R-1, each of which costs one
+// spectrum multiply, one transform and one argmax.  Per (series, reference) that is
+// (1 + R) / (2 R) of the single-reference transform work and 1/R of the HBM bytes.
+//
+// One prefetch buffer serves both kinds of iteration: 16 x (re, im) of Z, or
+// 16 x (row A sample, row B sample) -- the same packing the transform starts from --
+// so every path through the loop defines all of it (no stale live ranges).
+namespace foldk {
+
+constexpr int MSTAT = 12; // per pair: [0,8) sum d^2 partials (2*wave + series), [8,10) sum d, [10] first row, [11] has second row
+constexpr int MTRIP = 26; // per iteration: [0,24) argmax partials, [24] reference index (< 0: nothing to write), [25] pair parity
+
+__device__ __forceinline__ bool finalize_multi(const double *tr, const double *st, const int series, const double invN,
+                                               const double invNm1, double *mv_out, int *lag_out)
+{
+    double m[4], s[4], ix[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        m[w] = tr[6 * w + 3 * series];
+        s[w] = tr[6 * w + 3 * series + 1];
+        ix[w] = tr[6 * w + 3 * series + 2];
+    }
+    const double s2 = (st[series] + st[2 + series]) + (st[4 + series] + st[6 + series]);
+    const Stat stt{st[8 + series], s2};
+    double best = m[0], bsv = s[0], bidx = ix[0];
+#pragma unroll
+    for (int w = 1; w < 4; w++) {
+        if (m[w] > best || (m[w] == best && ix[w] < bidx)) {
+            best = m[w];
+            bsv = s[w];
+            bidx = ix[w];
+        }
+    }
+    bool zero, nan;
+    const double var = variance(stt, invN, invNm1, zero, nan);
+    const int idx = (best > 0.0) ? (int)bidx : 0;
+    double y = __builtin_amdgcn_rsq(var);
+    y = y * fma(-0.5 * var * y, y, 1.5);
+    y = y * fma(-0.5 * var * y, y, 1.5);
+    double mv = ((best > 0.0) ? bsv : s[0]) * y;
+    int lag = idx > 2048 ? idx - 4096 : idx;
+    if (zero) { mv = 0.0; lag = 0; }
+    if (nan) { mv = __builtin_nan(""); lag = 0; }
+    *mv_out = mv;
+    *lag_out = lag;
+    bool redo = nan;
+    if (series == 0 && st[11] != 0.0) { // sigmas too far apart for one shared transform?
+        const Stat sb{st[9], (st[1] + st[3]) + (st[5] + st[7])};
+        bool zb, nb;
+        const double varb = variance(sb, invN, invNm1, zb, nb);
+        redo = redo || (!nb && sigma_spread_too_wide(var, varb));
+    }
+    return redo;
+}
+
+// 16-byte global store through a scalar base (+ element offset `off`) and a lane index
+__device__ __forceinline__ void zstore(double2 *base, long long off, int idx, d2v val)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned long long u = (unsigned long long)base;
+    asm volatile("" : "+s"(u));
+    u += (unsigned long long)(off * 16);
+    asm volatile("" : "+s"(u));
+    ((d2v __attribute__((address_space(1))) *)u)[idx] = val;
+#endif
+}
+
+// the previous iteration's results, written behind the first barrier of the current one
+// (a free function on purpose: a by-reference lambda with two call sites is not inlined and
+// drags the kernel argument struct into private memory)
+__device__ __forceinline__ void finalize_prev_multi(const double *trip, const double *stats, const int cur_ip,
+                                                    const int t, const double invN, const double invNm1,
+                                                    double *const *mv_many, int *const *lag_many, int *ovf_count,
+                                                    long long *ovf_list)
+{
+    const double *const tr = trip + MTRIP * (cur_ip ^ 1);
+    if (t < 2 && tr[24] >= 0.0) {
+        const double *const st = stats + MSTAT * (int)tr[25];
+        if (t == 0 || st[11] != 0.0) {
+            const int r = (int)tr[24];
+            const long long row = (long long)st[10] + t;
+            if (finalize_multi(tr, st, t, invN, invNm1, mv_many[r] + row, lag_many[r] + row) && r == 0) {
+                const int slot = atomicAdd(ovf_count, 1);
+                ovf_list[slot] = row >> 1;
+            }
+        }
+    }
+}
+
+} // namespace foldk
+
+// PADDED (2048 < N < 4096): as in xcorr_fused_n4096_fast -- the parked spectrum keeps its DC bin and every
+// reference's results are corrected by -m c1_r[index] (FusedParams::c1_many) before the argmax.
+template <bool TIMING = false, bool PADDED = false>
+__global__ __launch_bounds__(OCC_THREADS, 4) void xcorr_fused_n4096_fold_multi(const FusedParams p)
+{
+    using namespace occ4;
+    using namespace fold;
+    using namespace foldk;
+    __shared__ double2 xbuf[OCC_XBUF];
+    __shared__ double2 g2s[128];
+    __shared__ double stats[2 * MSTAT];
+    __shared__ double trip[2 * MTRIP];
+    __shared__ int next_s[2];
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int hi = t >> 4, lo = t & 15;
+    double2 *const xw = xbuf + XW * wave;
+    const int pad = PADDED ? 4096 - p.N : 0;
+    const double invN = PADDED ? 1.0 / (double)p.N : 1.0 / 4096.0, invNm1 = PADDED ? 1.0 / (double)(p.N - 1) : 1.0 / 4095.0;
+    const int R = p.R;
+
+    if (t < 128)
+        g2s[t] = p.g2[t];
+    if (t < 2)
+        trip[MTRIP * t + 24] = -1.0;
+    __syncthreads();
+    double2 *const zs = p.zscratch + (size_t)blockIdx.x * 4096; // resident grid: one slice per workgroup
+
+    int ip = 0, pp = 0;
+    const long long total = p.npairs;
+    // prefetch buffer: rows (pre[i] = (A[t + 256 i], B[t + 256 i]), ka/kb = first samples) or Z
+    double2 pre[16];
+    double ka, kb;
+    {
+        RawPair raw;
+        issue_row_loads<PADDED>(raw, p, blockIdx.x < total ? (long long)blockIdx.x : 0ll, t, pad);
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            pre[i] = make_double2(raw.a[i], raw.b[i]);
+        ka = raw.ka;
+        kb = raw.kb;
+    }
+    // one flat loop over (pair, reference) iterations: the prefetch buffer is live across
+    // exactly one back-edge
+    double s1a = 0.0, s1b = 0.0;
+    long long nextpair = 0;
+    int r = 0;
+#pragma clang loop unroll(disable)
+    for (long long pair = blockIdx.x; pair < total;) {
+        {
+            const long long rA = 2 * pair;
+            const bool hasB = rA + 1 < p.M;
+            double *const st = stats + MSTAT * pp;
+            double *const tr = trip + MTRIP * ip;
+            double2 v[16];
+            if (r == 0) {
+                // ---------- rows -> Z = FFT(dA + i dB), as in xcorr_fused_n4096_fast
+                if (t == 0) // claim the pair after this one (read at the last reference, many barriers later)
+                    next_s[pp] = (int)gridDim.x + atomicAdd(p.work_counter, 1);
+                {
+                    double qa = 0.0, qb = 0.0;
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const double da = pre[i].x - ka, db = pre[i].y - kb;
+                        v[i] = make_double2(da, db);
+                        qa = fma(da, da, qa);
+                        qb = fma(db, db, qb);
+                    }
+                    qa = wave_sum_dpp(qa);
+                    qb = wave_sum_dpp(qb);
+                    if (lane == 0) {
+                        st[2 * wave] = qa;
+                        st[2 * wave + 1] = qb;
+                    }
+                    if (t == 0) {
+                        st[10] = (double)rA;
+                        st[11] = hasB ? 1.0 : 0.0;
+                    }
+                }
+                dft16_nr(v);
+                exchange_cross<0, 1, true>(v, xbuf, wave, t);
+                finalize_prev_multi(trip, stats, ip, t, invN, invNm1, p.mv_many, p.lag_many, p.ovf_count, p.ovf_list);
+                gdft16_nr(v, G2Fetch{g2s, hi});
+                exchange_local<1>(v, xw, t);
+                gdft16_nr(v, G3Fetch{p.g3a, t}); // Z[hi + 16 lo + 256 k3] at v[BR16(k3)]
+                s1a = readlane_f64(v[0].x, 0);
+                s1b = readlane_f64(v[0].y, 0);
+                if (!PADDED) {
+                    v[0].x = (t == 0) ? 0.0 : v[0].x;
+                    v[0].y = (t == 0) ? 0.0 : v[0].y;
+                } else if (wave == 0 && lane == 0) { // every lane needs the means before each argmax of this pair
+                    st[8] = s1a;
+                    st[9] = s1b;
+                }
+                if (R > 1) { // park Z: lane t owns zs[256 k + t] (scalar bases: no hoisted VGPR addresses)
+#pragma unroll
+                    for (int k = 0; k < 16; k++) {
+                        d2v z;
+                        z.x = v[k].x;
+                        z.y = v[k].y;
+                        zstore(zs, 256 * ((k + 1) & ~1), t - 256 * (k & 1), z);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; k++)
+                    v[k] = pre[k];
+            }
+            // ---------- V = Z * conj(X_r)/n ; cc = FFT(V) ; argmax
+            {
+                const double2 *xr;
+                { // the table pointer is wave-uniform: keep it in SGPRs
+                    const unsigned long long u = (unsigned long long)p.xcp_many[r];
+                    const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)u);
+                    const unsigned hi32 = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+                    xr = (const double2 *)(((unsigned long long)hi32 << 32) | lo32);
+                }
+                double2 xa[4];
+                xc_stage1<false>(v, xa, [&](int j) __attribute__((always_inline)) {
+                    return ldg2(scalar_ptr_at(xr, 256 * ((j + 1) & ~1)), t - 256 * (j & 1));
+                });
+            }
+            dft16_rn_s234(v);
+            exchange_local<0>(v, xw, t);
+            gdft16_nr(v, G2Fetch{g2s, lo});
+            exchange_cross<1, 1, true>(v, xbuf, wave, t); // (tail barrier: the next iteration may start with a wave-local transpose)
+            if (r > 0) // this iteration's first workgroup barriers were the ones above
+                finalize_prev_multi(trip, stats, ip, t, invN, invNm1, p.mv_many, p.lag_many, p.ovf_count, p.ovf_list);
+            gdft16_nr(v, G3Fetch{p.g3b, t}); // cc index t + 256 m3 at v[BR16(m3)]
+            if (PADDED) { // cc(d - m 1_valid) = cc(d) - m c1_r
+                const double *c1r;
+                {
+                    const unsigned long long u = (unsigned long long)p.c1_many[r];
+                    const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)u);
+                    const unsigned hi32 = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+                    c1r = (const double *)(((unsigned long long)hi32 << 32) | lo32);
+                }
+                const double mA = st[8] * invN, mB = st[9] * invN;
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    const double c = scalar_ptr_at(c1r, 256 * ((k + 1) & ~1))[t - 256 * (k & 1)];
+                    v[BR16(k)] = make_double2(fma(-mA, c, v[BR16(k)].x), fma(-mB, c, v[BR16(k)].y));
+                }
+            }
+            wave_argmax_store(v, wave, lane, tr + 6 * wave);
+            // ---------- request the next iteration's input: Z again, or the next pair's rows
+            fence();
+            if (r + 1 < R) {
+#pragma unroll
+                for (int k = 0; k < 16; k++)
+                    pre[k] = ldg2(scalar_ptr_at((const double2 *)zs, 256 * ((k + 1) & ~1)), t - 256 * (k & 1));
+                ka = 0.0;
+                kb = 0.0;
+            } else {
+                nextpair = __builtin_amdgcn_readfirstlane(next_s[pp]);
+                long long nxt = nextpair < total ? nextpair : 0; // nothing left: pair 0 (L2-resident dummy)
+                RawPair raw;
+                issue_row_loads<PADDED>(raw, p, nxt, t, pad);
+#pragma unroll
+                for (int i = 0; i < 16; i++)
+                    pre[i] = make_double2(raw.a[i], raw.b[i]);
+                ka = raw.ka;
+                kb = raw.kb;
+            }
+            fence();
+            if (wave == 0 && lane == 0) {
+                tr[24] = (double)r;
+                tr[25] = (double)pp;
+                if (r == 0) {
+                    st[8] = s1a;
+                    st[9] = s1b;
+                }
+            }
+            ip ^= 1;
+        }
+        if (++r == R) {
+            r = 0;
+            pair = nextpair;
+            pp ^= 1;
+        }
+    }
+    lds_barrier();
+    finalize_prev_multi(trip, stats, ip, t, invN, invNm1, p.mv_many, p.lag_many, p.ovf_count, p.ovf_list);
+}
+
+// R >= 2 references, n == 4096 (N < 4096: p.c1_many); p.ovf_count and p.work_counter zeroed; a resident grid
+// (pairs are handed out dynamically), one scratch slice per workgroup
+hipError_t launch_fused_multi(const FusedParams &p, int num_cus, hipStream_t stream)
+{
+    const long long grid = std::min<long long>(p.npairs, (long long)num_cus * 4);
+    if (p.zslots < grid || !p.zscratch || !p.work_counter || p.R < 1 || !p.g2 || !p.g3a || !p.g3b)
+        return hipErrorInvalidValue;
+    if (p.N < 4096) {
+        if (!p.c1_many)
+            return hipErrorInvalidValue;
+        hipLaunchKernelGGL((xcorr_fused_n4096_fold_multi<false, true>), dim3((unsigned)grid), dim3(OCC_THREADS), 0, stream, p);
+    } else {
+        hipLaunchKernelGGL((xcorr_fused_n4096_fold_multi<false, false>), dim3((unsigned)grid), dim3(OCC_THREADS), 0, stream, p);
+    }
+    return hipGetLastError();
+}
+
+// n == 4096 (N < 4096: p.c1 required); p.ovf_count / work_counter must be zeroed and p.ovf_list hold 2*npairs entries;
+// a resident grid, pairs handed out by the atomic counter
+hipError_t launch_fused_fold(const FusedParams &p, int num_cus, hipStream_t stream)
+{
+    if (!p.work_counter || !p.g2 || !p.g3a || !p.g3b || !p.xcp)
+        return hipErrorInvalidValue;
+    const long long grid = std::min<long long>(p.npairs, (long long)num_cus * 4);
+    if (p.N < 4096) { // leading zero pad: needs the batch's correction table
+        if (!p.c1)
+            return hipErrorInvalidValue;
+        hipLaunchKernelGGL((xcorr_fused_n4096_fold<false, true>), dim3((unsigned)grid), dim3(OCC_THREADS), 0, stream, p);
+    } else {
+        hipLaunchKernelGGL((xcorr_fused_n4096_fold<false, false>), dim3((unsigned)grid), dim3(OCC_THREADS), 0, stream, p);
+    }
+    return hipGetLastError();
+}
+
+} // namespace muse

@@ -342,30 +342,21 @@ __global__ __launch_bounds__(OCC_THREADS, WPS) void xcorr_fused_n4096_occ4(const
     }
 }
 
-hipError_t launch_fused_occ4(const FusedParams &p, int num_cus, int waves_per_simd, hipStream_t stream)
+hipError_t launch_fused_occ4(const FusedParams &p, int num_cus, hipStream_t stream)
 {
     long long grid = p.npairs;
     // 16x the resident set (each workgroup still loops over ~40 pairs): workgroups that
     // start as others retire keep the CUs' phases decorrelated and balance CU speed
     // differences; measured 12.6 ms (1x) -> 11.5 ms (16x) per 1 M series, flat beyond.
-    int mult = 16;
-    if (const char *m = getenv("MUSE_HIP_GRID_MULT")) // tuning aid
-        mult = atoi(m) > 0 ? atoi(m) : mult;
-    const long long cap = (long long)num_cus * waves_per_simd * mult;
+    constexpr int mult = 16;
+    const long long cap = (long long)num_cus * 3 * mult;
     if (grid > cap)
         grid = cap;
     const dim3 g((unsigned)grid), b(OCC_THREADS);
-    if (waves_per_simd == 3) {
-        if (p.N < 4096)
-            hipLaunchKernelGGL((xcorr_fused_n4096_occ4<true, 3>), g, b, 0, stream, p);
-        else
-            hipLaunchKernelGGL((xcorr_fused_n4096_occ4<false, 3>), g, b, 0, stream, p);
-    } else {
-        if (p.N < 4096)
-            hipLaunchKernelGGL((xcorr_fused_n4096_occ4<true, 4>), g, b, 0, stream, p);
-        else
-            hipLaunchKernelGGL((xcorr_fused_n4096_occ4<false, 4>), g, b, 0, stream, p);
-    }
+    if (p.N < 4096)
+        hipLaunchKernelGGL((xcorr_fused_n4096_occ4<true, 3>), g, b, 0, stream, p);
+    else
+        hipLaunchKernelGGL((xcorr_fused_n4096_occ4<false, 3>), g, b, 0, stream, p);
     return hipGetLastError();
 }
 

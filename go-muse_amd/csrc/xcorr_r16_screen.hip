@@ -1,27 +1,12 @@
-// xcorr_r16_screen.hip -- fp32 screening transform + exact fp64 re-evaluation,
-// n = 4096.
+// xcorr_r16_screen.hip -- the fp32 screening pass of the OPT-IN filter-and-refine Run, n = 4096
+// (muse_ctx_set_screening).  Not on the default path: by default every series is scored by
+// the float64 kernel (xcorr_r16_fold.hip), the arithmetic of the reference (xcorr.go:160-197).
 //
-// Result contract is unchanged: (lag, mv) of xCorrWithX (xcorr.go:160-197) with
-// fp64-accurate scores and exact lags.  Why this shape: the fp64 kernels are
-// bound by fp64 VALU issue, LDS bytes and registers at once, not
-// by HBM.  Only the ARGMAX needs all n lags; the winning VALUE needs one.  So:
-//   1. z-normalisation statistics in fp64 (as before); the centred samples stay
-//      in registers as fp64;
-//   2. both FFTs run in fp32 on a power-of-two-scaled copy (packed fp32 math:
-//      half the VALU cycles, 8-byte complex -> half the LDS traffic, a
-//      FULL-size 34.8 KB transpose buffer: two barriers per transpose and four
-//      workgroups' worth of LDS per CU);
-//   3. every lag whose fp32 |cc| is within `delta` of the fp32 maximum is a
-//      candidate (|cc32 - cc| <= E for all lags => the true argmax is a candidate
-//      when delta >= 2E; E is measured, delta carries a >= 16x margin, see
-//      DESIGN.md); typically ONE candidate per series;
-//   4. each candidate is re-evaluated exactly, in fp64, as the direct sum
-//      cc[L] = sum_j yz[j] * xs[(j + L) mod n]   (xs = zeroPad(zNormalize(ref)/(N-1)),
-//      SURVEY 8 a-8) -- 16 FMAs per thread and one block reduction for up to four
-//      candidates; the result (first index of max |cc64|, its signed value / sigma)
-//      is what is stored;
-//   5. a pair with more than SCR_CAP candidates for a series (periodic data, many
-//      near ties) is appended to an overflow list and redone by the fp64 kernel.
+// What the pass does: z-normalisation statistics in fp64 while the rows arrive, both transforms in fp32 on a
+// power-of-two-scaled fp32 copy of the centred samples, and per series an ESTIMATE of the score plus FLAGS that
+// describe every lag whose fp32 |cc| lies within the error bound of the fp32 maximum (kernel comment below).
+// Nothing the library returns is computed here: rows that can reach the top-N are re-evaluated by the fp64
+// kernels and only those are selected (muse_capi.hip, screen_finish).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -33,7 +18,6 @@ namespace muse {
 
 constexpr int SCR_THREADS = 256;
 constexpr int SCR_XBUF = 16 * 272; // f2 elements: 34,816 B
-constexpr int SCR_CAP = 8;         // candidates per series handled in-kernel
 
 namespace scr {
 
@@ -94,369 +78,6 @@ __device__ __forceinline__ void exchange(f2 (&v)[16], f2 *xbuf, const int t)
         v[e] = xbuf[rbase + (B ? e : 16 * e)];
 }
 
-// forward fp32 FFT: v[a] = x[t + 256 a] -> v[a] = X[t + 256 a]; MULXC multiplies
-// by the batch's fp32 conj(X)/n table on the way out.
-template <bool MULXC>
-__device__ __forceinline__ void fft4096f(f2 (&v)[16], f2 *xbuf, const f2 *tw2s, const float2 *tw1g,
-                                         const float2 *xcg, const int t)
-{
-    // pass 1 + twiddle W_4096^(k1 t): first half of the factors fetched before the
-    // butterflies, second half before the first is consumed (L2 latency overlapped)
-    {
-        const gptr<float2> tp = scalar_ptr(tw1g);
-        f2 ta[8], tb[7];
-#pragma unroll
-        for (int j = 0; j < 8; j++)
-            ta[j] = ldg_f2(tp, (1 + j) * 256 + t);
-        fence();
-        dft16f(v);
-        fence();
-#pragma unroll
-        for (int j = 0; j < 7; j++)
-            tb[j] = ldg_f2(tp, (9 + j) * 256 + t);
-#pragma unroll
-        for (int j = 0; j < 8; j++)
-            v[P16(1 + j)] = cmulf(v[P16(1 + j)], ta[j]);
-        fence();
-#pragma unroll
-        for (int j = 0; j < 7; j++)
-            v[P16(9 + j)] = cmulf(v[P16(9 + j)], tb[j]);
-    }
-    exchange<false>(v, xbuf, t);
-    // pass 2 + twiddle W_256^(k2 c) from the LDS table
-    dft16f(v);
-    {
-        const int lo = t & 15;
-#pragma unroll
-        for (int k = 1; k < 16; k++)
-            v[P16(k)] = cmulf(v[P16(k)], tw2s[k * 16 + lo]);
-    }
-    exchange<true>(v, xbuf, t);
-    // pass 3
-    if (MULXC) {
-        const gptr<float2> xp = scalar_ptr(xcg);
-        f2 xa[8], xb[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++)
-            xa[j] = ldg_f2(xp, 256 * j + t);
-        fence();
-        dft16f(v);
-        fence();
-#pragma unroll
-        for (int j = 0; j < 8; j++)
-            xb[j] = ldg_f2(xp, 256 * (8 + j) + t);
-        f2 w[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++)
-            w[k] = v[P16(k)];
-#pragma unroll
-        for (int j = 0; j < 8; j++)
-            v[j] = cmulf(w[j], xa[j]);
-        fence();
-#pragma unroll
-        for (int j = 0; j < 8; j++)
-            v[8 + j] = cmulf(w[8 + j], xb[j]);
-    } else {
-        dft16f(v);
-        f2 w[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++)
-            w[k] = v[P16(k)];
-#pragma unroll
-        for (int k = 0; k < 16; k++)
-            v[k] = w[k];
-    }
-}
-
-} // namespace scr
-
-template <bool PADDED, bool TIMING = false>
-__global__ __launch_bounds__(SCR_THREADS, 3) void xcorr_fused_n4096_screen(const FusedParams p)
-{
-    using namespace scr;
-    __shared__ f2 xbuf[SCR_XBUF];
-    __shared__ f2 tw2s[256];
-    __shared__ double red[48];      // [0,16) statistics; [16,20) fp32 maxima; [32,48) refinement partials
-    __shared__ int cand[2][SCR_CAP];
-    __shared__ int ccnt[2];
-    const int t = threadIdx.x;
-    const int lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int N = p.N;
-    const int pad = 4096 - N;
-    const double invN = 1.0 / (double)N, invNm1 = 1.0 / (double)(N - 1);
-    const float delta = (float)p.screen_delta;
-    float *redf = reinterpret_cast<float *>(red + 16);
-
-    {
-        const float2 tw = p.tw2f[t];
-        tw2s[t] = mk2(tw.x, tw.y);
-    }
-    if (t < 2)
-        ccnt[t] = 0;
-    __syncthreads();
-    PhaseClock<TIMING> clk;
-    clk.start();
-
-    for (long long pair = blockIdx.x; pair < p.npairs; pair += gridDim.x) {
-        const long long rA = 2 * pair, rB = rA + 1;
-        const bool hasB = rB < p.M;
-        // ---- rows: element t + 256 i (zero-padded), kept in fp64 for the whole pair
-        double da[16], db[16];
-        {
-            const gptr<double> ra = scalar_ptr(p.rows + rA * p.stride);
-            const gptr<double> rb = scalar_ptr(p.rows + (hasB ? rB : rA) * p.stride);
-            const double KA = ra[0], KB = rb[0];
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                if (PADDED) {
-                    int j = t + 256 * i - pad;
-                    j = j < 0 ? 0 : j;
-                    da[i] = __builtin_nontemporal_load(ra + j);
-                    db[i] = __builtin_nontemporal_load(rb + j);
-                } else {
-                    da[i] = __builtin_nontemporal_load(ra + 256 * i + t);
-                    db[i] = __builtin_nontemporal_load(rb + 256 * i + t);
-                }
-            }
-            // d = x - K (K = first sample; pads -> 0): shifted one-pass statistics
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                da[i] -= KA;
-                db[i] -= KB;
-                if (PADDED) {
-                    const bool valid = t + 256 * i - pad >= 0;
-                    da[i] = valid ? da[i] : 0.0;
-                    db[i] = valid ? db[i] : 0.0;
-                }
-            }
-        }
-        if (TIMING)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        clk.template stamp<0>();
-        double q[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            q[0] += da[i];
-            q[1] = fma(da[i], da[i], q[1]);
-            q[2] += db[i];
-            q[3] = fma(db[i], db[i], q[3]);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            q[k] = wave_sum_dpp(q[k]);
-        if (lane == 0) {
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                red[wave * 4 + k] = q[k];
-        }
-        lds_barrier();
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            q[k] = uniform((red[k] + red[4 + k]) + (red[8 + k] + red[12 + k]));
-        if (t < 2)
-            ccnt[t] = 0; // every thread is past the previous pair's reads; next writers are 8 barriers away
-        const double mA = uniform(q[0] * invN), mB = uniform(q[2] * invN); // mean of d
-        const double varA = uniform((q[1] - q[0] * q[0] * invN) * invNm1);
-        const double varB = uniform((q[3] - q[2] * q[2] * invN) * invNm1);
-        const bool nanA = !__builtin_isfinite(varA), nanB = !__builtin_isfinite(varB);
-        const bool zeroA = !nanA && !(varA > 0.0), zeroB = !nanB && !(varB > 0.0);
-        const bool deadA = zeroA || nanA, deadB = zeroB || nanB || !hasB;
-        // centre in fp64 (kept for the exact re-evaluation); fp32 copy scaled by an
-        // exact power of two close to 1/sigma so the transform runs at O(1) magnitude
-        // 2^-(floor(log2 var) / 2): exact power of two within [1/sigma/sqrt2 .. sqrt2/sigma]-ish, from the exponent bits
-        const int eA = (int)((__double_as_longlong(varA) >> 52) & 0x7ff) - 1023;
-        const int eB = (int)((__double_as_longlong(varB) >> 52) & 0x7ff) - 1023;
-        const double sclA = deadA ? 0.0 : __longlong_as_double((long long)(1023 - (eA >> 1)) << 52);
-        const double sclB = deadB ? 0.0 : __longlong_as_double((long long)(1023 - (eB >> 1)) << 52);
-        f2 v[16];
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            if (PADDED) {
-                const bool valid = t + 256 * i - pad >= 0;
-                da[i] = valid ? da[i] - mA : 0.0;
-                db[i] = valid ? db[i] - mB : 0.0;
-            } else {
-                da[i] -= mA;
-                db[i] -= mB;
-            }
-            v[i] = mk2((float)(da[i] * sclA), (float)(db[i] * sclB));
-        }
-        if (deadA || deadB) { // block-uniform, rare: a sigma == 0 / NaN series contributes exact zeros
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                v[i].x = deadA ? 0.f : v[i].x;
-                v[i].y = deadB ? 0.f : v[i].y;
-            }
-        }
-        clk.template stamp<1>();
-        // ---- fp32 screen: cc32 = FFT(FFT(z) * conj(X)/n), same layouts as the fp64 kernels
-        fft4096f<true>(v, xbuf, tw2s, p.tw1f, p.xcf, t);
-        clk.template stamp<2>();
-        fft4096f<false>(v, xbuf, tw2s, p.tw1f, p.xcf, t);
-        clk.template stamp<3>();
-        // ---- fp32 maxima of |cc| per series (block-wide)
-        float ma = 0.f, mb = 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            ma = fmaxf(ma, fabsf(v[k].x));
-            mb = fmaxf(mb, fabsf(v[k].y));
-        }
-        ma = wave_max_f32_dpp(ma);
-        mb = wave_max_f32_dpp(mb);
-        if (lane == 0) {
-            redf[wave] = ma;
-            redf[4 + wave] = mb;
-        }
-        lds_barrier();
-        const float MA = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
-        const float MB = fmaxf(fmaxf(redf[4], redf[5]), fmaxf(redf[6], redf[7]));
-        // ---- candidates: every lag within delta of the maximum (delta in the scaled units,
-        // where the largest possible |cc| is <= 1: scale <= 1/sigma)
-        const float thA = MA - delta, thB = MB - delta;
-        // (wave-uniform test first: a hit is rare -- one (lane, k) per series in general)
-        if (MA > 0.f) {
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const bool hit = fabsf(v[k].x) >= thA;
-                if (__ballot(hit) != 0ull) {
-                    if (hit) {
-                        const int pos = atomicAdd(&ccnt[0], 1);
-                        if (pos < SCR_CAP)
-                            cand[0][pos] = t + 256 * k;
-                    }
-                }
-            }
-        }
-        if (MB > 0.f) {
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const bool hit = fabsf(v[k].y) >= thB;
-                if (__ballot(hit) != 0ull) {
-                    if (hit) {
-                        const int pos = atomicAdd(&ccnt[1], 1);
-                        if (pos < SCR_CAP)
-                            cand[1][pos] = t + 256 * k;
-                    }
-                }
-            }
-        }
-        lds_barrier();
-        clk.template stamp<4>();
-        const int nA = deadA ? 0 : ccnt[0], nB = deadB ? 0 : ccnt[1];
-        const bool overflow = nA > SCR_CAP || nB > SCR_CAP;
-        // ---- exact fp64 re-evaluation of the candidates, four per block reduction
-        double bestA = 0.0, valA = 0.0, bestB = 0.0, valB = 0.0;
-        int lagA = 0x7fffffff, lagB = 0x7fffffff;
-        if (!overflow) {
-            const gptr<double> xs = scalar_ptr(p.xs);
-            const int ne = nA + nB;
-            for (int base = 0; base < ne; base += 4) {
-                double s[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int e = base + j;
-                    if (e < ne) { // block-uniform
-                        const bool isB = e >= nA;
-                        const int L = isB ? cand[1][e - nA] : cand[0][e];
-                        double acc = 0.0;
-                        if (isB) {
-#pragma unroll
-                            for (int i = 0; i < 16; i++)
-                                acc = fma(db[i], xs[(t + 256 * i + L) & 4095], acc);
-                        } else {
-#pragma unroll
-                            for (int i = 0; i < 16; i++)
-                                acc = fma(da[i], xs[(t + 256 * i + L) & 4095], acc);
-                        }
-                        s[j] = acc;
-                    }
-                }
-                if (base > 0)
-                    lds_barrier(); // red[32,48) still being read by thread 0 (rare second chunk)
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-                    s[j] = wave_sum_dpp(s[j]);
-                if (lane == 0) { // own region: the next pair's statistics may be written before thread 0 reads these
-#pragma unroll
-                    for (int j = 0; j < 4; j++)
-                        red[32 + wave * 4 + j] = s[j];
-                }
-                lds_barrier();
-                if (t == 0) {
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const int e = base + j;
-                        if (e < ne) {
-                            const double c = (red[32 + j] + red[36 + j]) + (red[40 + j] + red[44 + j]);
-                            const bool isB = e >= nA;
-                            const int L = isB ? cand[1][e - nA] : cand[0][e];
-                            const double a = fabs(c);
-                            if (isB) {
-                                if (a > bestB || (a == bestB && L < lagB)) { bestB = a; valB = c; lagB = L; }
-                            } else {
-                                if (a > bestA || (a == bestA && L < lagA)) { bestA = a; valA = c; lagA = L; }
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        clk.template stamp<5>();
-        // ---- results (thread 0 owns both series), or hand the pair to the fp64 kernel
-        if (t == 0) {
-            if (overflow) {
-                const int slot = atomicAdd(p.ovf_count, 1);
-                p.ovf_list[slot] = pair;
-            } else {
-                // nothing above zero (all |cc32| == 0): index 0, value cc[0] = 0 here
-                double mvA = (lagA == 0x7fffffff) ? 0.0 : valA * (1.0 / sqrt(varA));
-                double mvB = (lagB == 0x7fffffff) ? 0.0 : valB * (1.0 / sqrt(varB));
-                int lA = (lagA == 0x7fffffff) ? 0 : (lagA > 2048 ? lagA - 4096 : lagA);
-                int lB = (lagB == 0x7fffffff) ? 0 : (lagB > 2048 ? lagB - 4096 : lagB);
-                if (zeroA) { mvA = 0.0; lA = 0; }
-                if (nanA) { mvA = __builtin_nan(""); lA = 0; }
-                if (zeroB) { mvB = 0.0; lB = 0; }
-                if (nanB) { mvB = __builtin_nan(""); lB = 0; }
-                p.mv[rA] = mvA;
-                p.lag[rA] = lA;
-                if (hasB) {
-                    p.mv[rB] = mvB;
-                    p.lag[rB] = lB;
-                }
-            }
-        }
-        clk.template stamp<6>();
-    }
-    if (TIMING && p.dbg && lane == 0) {
-#pragma unroll
-        for (int i = 0; i < NPHASE; i++)
-            p.dbg[((long long)blockIdx.x * 4 + wave) * NPHASE + i] = clk.acc[i];
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------
-// Second generation (N == n == 4096): the same screen + exact re-evaluation, rebuilt so that no
-// memory latency sits on the dependent chain and the register footprint allows three waves
-// per SIMD:
-//   * the next pair's rows are prefetched ONE SERIES AT A TIME into a single 32-register fp64
-//     buffer: series A during the first transform, series B during the second.  As soon as a
-//     series has arrived it is reduced to its shifted fp64 sums (sum d, sum d^2, d = x - x[0])
-//     and a PROVISIONAL fp32 copy fl32(d); the fp64 samples are dropped there.
-//   * once both sums are known the fp32 copy is centred and scaled by an exact power of two
-//     near 1/sigma, in fp32: c = (fl32(d) - fl32(mean d)) * 2^-e.  The constant error
-//     mean - fl32(mean) is harmless: the reference spectrum has X[0] = 0 and its time-domain
-//     form sums to zero over the full circle (N == n), so any constant offset of the series
-//     contributes nothing to any lag.  What is left is the rounding of fl32(d), 2^-24 |d|: it is
-//     bounded relative to sigma by handing a pair to the fp64 kernel when |mean d| > 8 sigma
-//     (x[0] a far outlier) or sigma is outside 2^+-100 (fp32 range).
-//   * the exact re-evaluation of the candidate lags runs on that centred fp32 copy in fp64
-//     arithmetic against the fp64 reference: score error ~ 2^-24 / sqrt(N) (1e-9 absolute),
-//     three orders below the 1e-6 relative parity bar for any score a series can attain as its
-//     maximum over 4096 lags.
-namespace scr {
-
 struct Tw1FetchF {
     const float2 *p;
     int t;
@@ -469,37 +90,6 @@ struct Tw1FetchF {
         return ldg_f2((gptr<float2>)u, t - 256 * (k & 1));
     }
 };
-
-// forward fp32 FFT, v[a] = x[t + 256 a] -> v[a] = X[t + 256 a].  The pass-1 factors W_4096^(k t) depend on the
-// thread only and live in registers for the whole kernel (twc[k-1]); pass 2 reads the LDS table; MULXC multiplies
-// by the batch's fp32 conj(X)/n entries, which the caller fetched (xq[k] = xcf[256 k + t]) BEFORE it issued the
-// row prefetch: no global load is issued in here, so nothing ever waits behind the HBM stream (vmcnt is in-order).
-template <bool MULXC>
-__device__ __forceinline__ void fft4096r(f2 (&v)[16], f2 *xbuf, const f2 *tw2s, const f2 (&twc)[15], const f2 (&xq)[16],
-                                         const int t)
-{
-    dft16f(v);
-#pragma unroll
-    for (int k = 1; k < 16; k++)
-        v[P16(k)] = cmulf(v[P16(k)], twc[k - 1]);
-    exchange<false>(v, xbuf, t);
-    dft16f(v);
-    {
-        const int lo = t & 15;
-#pragma unroll
-        for (int k = 1; k < 16; k++)
-            v[P16(k)] = cmulf(v[P16(k)], tw2s[k * 16 + lo]);
-    }
-    exchange<true>(v, xbuf, t);
-    dft16f(v);
-    f2 w[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++)
-        w[k] = v[P16(k)];
-#pragma unroll
-    for (int k = 0; k < 16; k++)
-        v[k] = MULXC ? cmulf(w[k], xq[k]) : w[k];
-}
 
 // one series' 16 samples per thread (element t + 256 i) + its first sample; coalesced
 // nontemporal loads, one scalar base per four 2 KB slices (no 64-bit VALU address arithmetic)
@@ -556,284 +146,6 @@ __device__ __forceinline__ void reduce_series(const double (&r)[16], const doubl
 
 } // namespace scr
 
-template <int WPC, bool TIMING = false>
-__global__ __launch_bounds__(SCR_THREADS, WPC) void xcorr_fused_n4096_screen2(const FusedParams p)
-{
-    using namespace scr;
-    __shared__ f2 xbuf[SCR_XBUF];
-    __shared__ f2 tw2s[256];
-    __shared__ double xsl[4096];    // the reference in the time domain (fp64), for the exact re-evaluation
-    __shared__ double red[48];      // [0,16) statistics; [16,20) fp32 maxima; [32,48) refinement partials
-    __shared__ int cand[2][SCR_CAP];
-    __shared__ int ccnt[2];
-    const int t = threadIdx.x;
-    const int lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    constexpr double invN = 1.0 / 4096.0, invNm1 = 1.0 / 4095.0;
-    f2 twc[15];
-    {
-        const Tw1FetchF fetch{p.tw1f, t};
-#pragma unroll
-        for (int k = 1; k < 16; k++)
-            twc[k - 1] = fetch(k);
-#pragma unroll
-        for (int i = 0; i < 16; i++)
-            xsl[256 * i + t] = p.xs[256 * i + t];
-    }
-    const float delta = (float)p.screen_delta;
-    float *redf = reinterpret_cast<float *>(red + 16);
-
-    {
-        const float2 tw = p.tw2f[t];
-        tw2s[t] = mk2(tw.x, tw.y);
-    }
-    if (t < 2)
-        ccnt[t] = 0;
-    __syncthreads();
-    PhaseClock<TIMING> clk;
-    clk.start();
-
-    long long pair = blockIdx.x; // the launcher never starts more workgroups than pairs
-    // ---- prologue: series A of the first pair reduced, series B in flight
-    float na[16];
-    double raw[16];
-    double sA1, sA2, kB;
-    {
-        double kA;
-        issue_series(raw, kA, p.rows + 2 * pair * p.stride, t);
-        fence();
-        reduce_series(raw, kA, na, sA1, sA2);
-        fence();
-        const long long rB = (2 * pair + 1 < p.M) ? 2 * pair + 1 : 2 * pair;
-        issue_series(raw, kB, p.rows + rB * p.stride, t);
-        fence();
-    }
-
-    for (; pair < p.npairs; pair += gridDim.x) {
-        const long long rA = 2 * pair, rB = rA + 1;
-        const bool hasB = rB < p.M;
-        long long nxt = pair + gridDim.x; // clamped: the prefetch is unconditional
-        nxt = nxt < p.npairs ? nxt : p.npairs - 1;
-        const long long nA = 2 * nxt, nB = (nA + 1 < p.M) ? nA + 1 : nA;
-        // ---- series B arrives: sums + provisional fp32 copy
-        if (TIMING)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        clk.template stamp<0>();
-        float nb[16];
-        double q[4];
-        q[0] = sA1;
-        q[1] = sA2;
-        reduce_series(raw, kB, nb, q[2], q[3]);
-        fence();
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            q[k] = wave_sum_dpp(q[k]);
-        if (lane == 0) {
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                red[wave * 4 + k] = q[k];
-        }
-        lds_barrier();
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            q[k] = uniform((red[k] + red[4 + k]) + (red[8 + k] + red[12 + k]));
-        if (t < 2)
-            ccnt[t] = 0; // every thread is past the previous pair's reads; next writers are 8 barriers away
-        const double mA = uniform(q[0] * invN), mB = uniform(q[2] * invN); // mean of d
-        const double varA = uniform((q[1] - q[0] * q[0] * invN) * invNm1);
-        const double varB = uniform((q[3] - q[2] * q[2] * invN) * invNm1);
-        const bool nanA = !__builtin_isfinite(varA), nanB = !__builtin_isfinite(varB);
-        const bool zeroA = !nanA && !(varA > 0.0), zeroB = !nanB && !(varB > 0.0);
-        const bool deadA = zeroA || nanA, deadB = zeroB || nanB || !hasB;
-        // exact power of two near 1/sigma from the exponent bits of the variance
-        const int eA = (int)((__double_as_longlong(varA) >> 52) & 0x7ff) - 1023;
-        const int eB = (int)((__double_as_longlong(varB) >> 52) & 0x7ff) - 1023;
-        // fp32 is only trusted when sigma is well inside its range and x[0] is no far outlier
-        // (|mean d| <= 8 sigma keeps the rounding of fl32(d) at 2^-24 * O(sigma)); else the fp64 kernel redoes the pair
-        const bool redoA = !deadA && (eA > 200 || eA < -200 || mA * mA > 64.0 * varA);
-        const bool redoB = !deadB && (eB > 200 || eB < -200 || mB * mB > 64.0 * varB);
-        const bool redo = redoA || redoB;
-        const bool offA = deadA || redo, offB = deadB || redo;
-        const float sclA = offA ? 0.f : __int_as_float((127 - (eA >> 1)) << 23);
-        const float sclB = offB ? 0.f : __int_as_float((127 - (eB >> 1)) << 23);
-        const float mAf = offA ? 0.f : (float)mA, mBf = offB ? 0.f : (float)mB;
-        f2 v[16], c[16];
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            v[i] = mk2((na[i] - mAf) * sclA, (nb[i] - mBf) * sclB);
-            c[i] = v[i];
-        }
-        if (offA || offB) { // block-uniform, rare: such a series contributes exact zeros (its samples may be NaN / Inf)
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                v[i].x = offA ? 0.f : v[i].x;
-                v[i].y = offB ? 0.f : v[i].y;
-                c[i] = v[i];
-            }
-        }
-        clk.template stamp<1>();
-        // ---- first transform; the next pair's series A streams in behind it (table loads first: in-order vmcnt)
-        double kA;
-        f2 xq[16];
-        fence();
-        {
-            const Tw1FetchF fetch{p.xcf, t};
-#pragma unroll
-            for (int k = 0; k < 16; k++)
-                xq[k] = fetch(k);
-        }
-        fence();
-        issue_series(raw, kA, p.rows + nA * p.stride, t);
-        fence();
-        fft4096r<true>(v, xbuf, tw2s, twc, xq, t);
-        fence();
-        if (TIMING)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        clk.template stamp<2>();
-        reduce_series(raw, kA, na, sA1, sA2);
-        fence();
-        issue_series(raw, kB, p.rows + nB * p.stride, t);
-        fence();
-        clk.template stamp<3>();
-        // ---- second transform; series B streams in behind it
-        fft4096r<false>(v, xbuf, tw2s, twc, xq, t);
-        clk.template stamp<4>();
-        // ---- fp32 maxima of |cc| per series (block-wide)
-        float ma = 0.f, mb = 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            ma = fmaxf(ma, fabsf(v[k].x));
-            mb = fmaxf(mb, fabsf(v[k].y));
-        }
-        ma = wave_max_f32_dpp(ma);
-        mb = wave_max_f32_dpp(mb);
-        if (lane == 0) {
-            redf[wave] = ma;
-            redf[4 + wave] = mb;
-        }
-        lds_barrier();
-        const float MA = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
-        const float MB = fmaxf(fmaxf(redf[4], redf[5]), fmaxf(redf[6], redf[7]));
-        const float thA = MA - delta, thB = MB - delta;
-        if (MA > 0.f) {
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const bool hit = fabsf(v[k].x) >= thA;
-                if (__ballot(hit) != 0ull) {
-                    if (hit) {
-                        const int pos = atomicAdd(&ccnt[0], 1);
-                        if (pos < SCR_CAP)
-                            cand[0][pos] = t + 256 * k;
-                    }
-                }
-            }
-        }
-        if (MB > 0.f) {
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const bool hit = fabsf(v[k].y) >= thB;
-                if (__ballot(hit) != 0ull) {
-                    if (hit) {
-                        const int pos = atomicAdd(&ccnt[1], 1);
-                        if (pos < SCR_CAP)
-                            cand[1][pos] = t + 256 * k;
-                    }
-                }
-            }
-        }
-        lds_barrier();
-        clk.template stamp<5>();
-        const int nCA = offA ? 0 : ccnt[0], nCB = offB ? 0 : ccnt[1];
-        const bool overflow = redo || nCA > SCR_CAP || nCB > SCR_CAP;
-        // ---- exact re-evaluation of the candidates (fp64 arithmetic on the centred fp32 copy), two per block reduction
-        double bestA = 0.0, valA = 0.0, bestB = 0.0, valB = 0.0;
-        int lagA = 0x7fffffff, lagB = 0x7fffffff;
-        if (!overflow) {
-            const int ne = nCA + nCB;
-            for (int base = 0; base < ne; base += 2) {
-                double s[2] = {0.0, 0.0};
-#pragma unroll
-                for (int j = 0; j < 2; j++) {
-                    const int e = base + j;
-                    if (e < ne) { // block-uniform
-                        const bool isB = e >= nCA;
-                        const int L = isB ? cand[1][e - nCA] : cand[0][e];
-                        double acc = 0.0;
-                        if (isB) {
-#pragma unroll
-                            for (int i = 0; i < 16; i++)
-                                acc = fma((double)c[i].y, xsl[(t + 256 * i + L) & 4095], acc);
-                        } else {
-#pragma unroll
-                            for (int i = 0; i < 16; i++)
-                                acc = fma((double)c[i].x, xsl[(t + 256 * i + L) & 4095], acc);
-                        }
-                        s[j] = acc;
-                    }
-                }
-                if (base > 0)
-                    lds_barrier(); // red[32,48) still being read by thread 0 (rare second chunk)
-#pragma unroll
-                for (int j = 0; j < 2; j++)
-                    s[j] = wave_sum_dpp(s[j]);
-                if (lane == 0) {
-#pragma unroll
-                    for (int j = 0; j < 2; j++)
-                        red[32 + wave * 2 + j] = s[j];
-                }
-                lds_barrier();
-                if (t == 0) {
-#pragma unroll
-                    for (int j = 0; j < 2; j++) {
-                        const int e = base + j;
-                        if (e < ne) {
-                            const double cs = (red[32 + j] + red[34 + j]) + (red[36 + j] + red[38 + j]);
-                            const bool isB = e >= nCA;
-                            const int L = isB ? cand[1][e - nCA] : cand[0][e];
-                            const double a = fabs(cs);
-                            if (isB) {
-                                if (a > bestB || (a == bestB && L < lagB)) { bestB = a; valB = cs; lagB = L; }
-                            } else {
-                                if (a > bestA || (a == bestA && L < lagA)) { bestA = a; valA = cs; lagA = L; }
-                            }
-                        }
-                    }
-                }
-            }
-        }
-        clk.template stamp<6>();
-        if (t == 0) {
-            if (overflow) {
-                const int slot = atomicAdd(p.ovf_count, 1);
-                p.ovf_list[slot] = pair;
-            } else {
-                // the sums carry the power-of-two scale: value = sum * 2^(e>>1) / sigma
-                const double uA = __longlong_as_double((long long)(1023 + (eA >> 1)) << 52);
-                const double uB = __longlong_as_double((long long)(1023 + (eB >> 1)) << 52);
-                double mvA = (lagA == 0x7fffffff) ? 0.0 : valA * uA * (1.0 / sqrt(varA));
-                double mvB = (lagB == 0x7fffffff) ? 0.0 : valB * uB * (1.0 / sqrt(varB));
-                int lA = (lagA == 0x7fffffff) ? 0 : (lagA > 2048 ? lagA - 4096 : lagA);
-                int lB = (lagB == 0x7fffffff) ? 0 : (lagB > 2048 ? lagB - 4096 : lagB);
-                if (zeroA) { mvA = 0.0; lA = 0; }
-                if (nanA) { mvA = __builtin_nan(""); lA = 0; }
-                if (zeroB) { mvB = 0.0; lB = 0; }
-                if (nanB) { mvB = __builtin_nan(""); lB = 0; }
-                p.mv[rA] = mvA;
-                p.lag[rA] = lA;
-                if (hasB) {
-                    p.mv[rB] = mvB;
-                    p.lag[rB] = lB;
-                }
-            }
-        }
-        clk.template stamp<7>();
-    }
-    if (TIMING && p.dbg && lane == 0) {
-#pragma unroll
-        for (int i = 0; i < NPHASE; i++)
-            p.dbg[((long long)blockIdx.x * 4 + wave) * NPHASE + i] = clk.acc[i];
-    }
-}
 
 
 // ---------------------------------------------------------------------------------------------
@@ -1428,28 +740,6 @@ hipError_t launch_screen_pass(const FusedParams &p, int num_cus, hipStream_t str
     else
         narrow ? (sign ? launch_pass_variant<false, true, true>(p, g, stream) : launch_pass_variant<false, true, false>(p, g, stream))
                : (sign ? launch_pass_variant<false, false, true>(p, g, stream) : launch_pass_variant<false, false, false>(p, g, stream));
-    return hipGetLastError();
-}
-
-hipError_t launch_fused_screen(const FusedParams &p, int num_cus, hipStream_t stream)
-{
-    long long grid = p.npairs;
-    int mult = 1; // resident workgroups per CU x mult (MUSE_HIP_GRID_MULT: tuning aid)
-    if (const char *m = getenv("MUSE_HIP_GRID_MULT"))
-        mult = atoi(m) > 0 ? atoi(m) : mult;
-    int wpc = 2; // resident workgroups per CU: the second-generation kernel holds 70 KB of LDS
-    static const bool first_gen = getenv("MUSE_HIP_SCREEN_GEN1") != nullptr; // tuning aid: the first-generation kernel
-    if (p.N < 4096 || first_gen)
-        wpc = 3;
-    const long long cap = (long long)num_cus * wpc * mult;
-    if (grid > cap)
-        grid = cap;
-    if (p.N < 4096)
-        hipLaunchKernelGGL(xcorr_fused_n4096_screen<true>, dim3((unsigned)grid), dim3(SCR_THREADS), 0, stream, p);
-    else if (first_gen)
-        hipLaunchKernelGGL(xcorr_fused_n4096_screen<false>, dim3((unsigned)grid), dim3(SCR_THREADS), 0, stream, p);
-    else
-        hipLaunchKernelGGL((xcorr_fused_n4096_screen2<2, false>), dim3((unsigned)grid), dim3(SCR_THREADS), 0, stream, p);
     return hipGetLastError();
 }
 

@@ -28,8 +28,7 @@
 // workgroup iteration; <13> (n = 8192): one pair per 512-thread workgroup, four passes.
 // xcorr_fused_stk_4step<LOGN> (n = 16384 ... 65536): the long series as a four-step transform
 // (radix-R1 sweeps in place in a global scratch slice, 4096-point rows on chip) -- what
-// automatic selection uses; xcorr_fused_stk_glb<LOGN>: the plain four-pass version through two
-// scratch slices, kept for A/B (MUSE_HIP_FAST_TUNE=2).
+// automatic selection uses.
 // All of them bring both series of a pair to O(1) with exact powers of two before the shared
 // transform (fft_device.h, pow2_inv_sigma) and apply 1/sigma to the winning value only.
 #include <hip/hip_runtime.h>
@@ -408,243 +407,6 @@ void xcorr_fused_stk_lds(const FusedParams p)
 }
 
 // ---------------------------------------------------------------------------
-// xcorr_fused_stk_glb<LOGN> (n = 8192 ... 65536): one pair per 256-thread workgroup at a
-// time, four passes per transform, the work buffers are two n-element complex slices of a
-// global scratch buffer per workgroup (ping-pong; L2 / Infinity-Cache traffic, ordered by
-// __syncthreads as in the radix-2 generic kernel).  Every thread walks n/4096 chunks of 16
-// points per pass.  The last forward pass, the spectrum multiply and the first transposed
-// pass are fused in registers; the last transposed pass feeds the argmax without a store:
-// 13 buffer sweeps per pair (radix 2: 2 log2 n + 3 = 29 ... 35).
-template <int LOGN>
-__global__ __launch_bounds__(256, 2) void xcorr_fused_stk_glb(const FusedParams p)
-{
-    using namespace occ4;
-    using namespace stk;
-    constexpr int n = 1 << LOGN;
-    constexpr int S = n / 16;
-    constexpr int CH = S / 256;      // chunks per thread and pass
-    constexpr int R1 = n / 4096;     // first radix (2, 4, 8, 16); passes 2-4 are radix 16
-    constexpr int Q1 = 16 / R1;
-    constexpr int NS2 = R1, NS3 = 16 * R1; // Ns of passes 2 and 3 (pass 4: Ns = 256 R1 = S)
-    static_assert(LOGN >= 14 && LOGN <= 16, "global Stockham kernel: n = 16384 ... 65536");
-    __shared__ double red[64];
-    __shared__ int redi[16];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    double2 *const X0 = p.gscratch + (size_t)blockIdx.x * (size_t)(2 * n);
-    double2 *const X1 = X0 + n;
-    const int N = p.N, pad = n - N;
-    const double invN = 1.0 / (double)N, invNm1 = 1.0 / (double)(N - 1);
-    const double2 *__restrict__ twm = p.twm;
-
-    for (long long pair = blockIdx.x; pair < p.npairs; pair += gridDim.x) {
-        const long long rA = 2 * pair;
-        const bool hasB = rA + 1 < p.M;
-        const double *__restrict__ ra = p.rows + rA * p.stride;
-        const double *__restrict__ rb = p.rows + (hasB ? rA + 1 : rA) * p.stride;
-        const double KA = ra[0], KB = rb[0];
-        // ---- sweep 0: rows -> d = x - K (leading zero pad) into X0, shifted statistics
-        double q[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma clang loop unroll(disable)
-        for (int ch = 0; ch < CH; ch++) {
-            const int j = t + 256 * ch;
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const int e = j + i * S - pad;
-                const int ec = e < 0 ? 0 : e;
-                double da = __builtin_nontemporal_load(ra + ec) - KA, db = __builtin_nontemporal_load(rb + ec) - KB;
-                da = e >= 0 ? da : 0.0;
-                db = e >= 0 ? db : 0.0;
-                X0[j + i * S] = make_double2(da, db);
-                q[0] += da;
-                q[1] = fma(da, da, q[1]);
-                q[2] += db;
-                q[3] = fma(db, db, q[3]);
-            }
-        }
-        block_sum<4>(q, red); // includes the barrier that orders sweep 0 before pass 1
-        const Stat stA{q[0], q[1]}, stB{q[2], q[3]};
-        bool zeroA, nanA, zeroB, nanB;
-        const double varA0 = variance(stA, invN, invNm1, zeroA, nanA);
-        const double varB0 = variance(stB, invN, invNm1, zeroB, nanB);
-        const bool deadA = zeroA || nanA, deadB = zeroB || nanB || !hasB;
-        const double sA = deadA ? 1.0 : pow2_inv_sigma(varA0), sB = deadB ? 1.0 : pow2_inv_sigma(varB0); // see the LDS kernel
-        const double varA = varA0 * sA * sA, varB = varB0 * sB * sB;
-        const double mA = q[0] * invN * sA, mB = q[2] * invN * sB;
-        // ---- pass 1 (radix R1, Ns = 1): X0 -> X1, mean removed on the way in
-#pragma clang loop unroll(disable)
-        for (int ch = 0; ch < CH; ch++) {
-            const int j = t + 256 * ch;
-            double2 v[16];
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const bool valid = j + i * S - pad >= 0;
-                const double2 d = X0[j + i * S];
-                v[i].x = (valid && !deadA) ? fma(d.x, sA, -mA) : 0.0;
-                v[i].y = (valid && !deadB) ? fma(d.y, sB, -mB) : 0.0;
-            }
-            dft_small<R1>(v);
-#pragma unroll
-            for (int m = 0; m < Q1; m++)
-#pragma unroll
-                for (int r = 0; r < R1; r++)
-                    X1[(j + m * S) * R1 + r] = v[m + r * Q1];
-        }
-        __syncthreads();
-        // ---- pass 2 (Ns = R1): X1 -> X0
-#pragma clang loop unroll(disable)
-        for (int ch = 0; ch < CH; ch++) {
-            const int j = t + 256 * ch;
-            double2 v[16];
-#pragma unroll
-            for (int i = 0; i < 16; i++)
-                v[i] = X1[j + i * S];
-            fwd16(v, twm, j % NS2, 16 * NS2);
-            const int base = (j / NS2) * (16 * NS2) + (j % NS2);
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-                X0[base + r * NS2] = v[P16(r)];
-        }
-        __syncthreads();
-        // ---- pass 3 (Ns = 16 R1): X0 -> X1
-#pragma clang loop unroll(disable)
-        for (int ch = 0; ch < CH; ch++) {
-            const int j = t + 256 * ch;
-            double2 v[16];
-#pragma unroll
-            for (int i = 0; i < 16; i++)
-                v[i] = X0[j + i * S];
-            fwd16(v, twm, j % NS3, 16 * NS3);
-            const int base = (j / NS3) * (16 * NS3) + (j % NS3);
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-                X1[base + r * NS3] = v[P16(r)];
-        }
-        __syncthreads();
-        // ---- pass 4 (Ns = S) + spectrum multiply + pass 4^T, in registers: X1 -> X0
-#pragma clang loop unroll(disable)
-        for (int ch = 0; ch < CH; ch++) {
-            const int j = t + 256 * ch;
-            double2 v[16], w[16];
-#pragma unroll
-            for (int i = 0; i < 16; i++)
-                v[i] = X1[j + i * S];
-            fwd16(v, twm, j, n); // X[j + r S] at v[P16(r)]
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-                w[r] = cmul(v[P16(r)], p.xc[j + r * S]);
-            trn16(w, twm, j, n);
-#pragma unroll
-            for (int s = 0; s < 16; s++)
-                X0[j + s * S] = w[P16(s)];
-        }
-        __syncthreads();
-        // ---- pass 3^T: X0 -> X1
-#pragma clang loop unroll(disable)
-        for (int ch = 0; ch < CH; ch++) {
-            const int j = t + 256 * ch;
-            double2 v[16];
-            const int base = (j / NS3) * (16 * NS3) + (j % NS3);
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-                v[r] = X0[base + r * NS3];
-            trn16(v, twm, j % NS3, 16 * NS3);
-#pragma unroll
-            for (int s = 0; s < 16; s++)
-                X1[j + s * S] = v[P16(s)];
-        }
-        __syncthreads();
-        // ---- pass 2^T: X1 -> X0
-#pragma clang loop unroll(disable)
-        for (int ch = 0; ch < CH; ch++) {
-            const int j = t + 256 * ch;
-            double2 v[16];
-            const int base = (j / NS2) * (16 * NS2) + (j % NS2);
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-                v[r] = X1[base + r * NS2];
-            trn16(v, twm, j % NS2, 16 * NS2);
-#pragma unroll
-            for (int s = 0; s < 16; s++)
-                X0[j + s * S] = v[P16(s)];
-        }
-        __syncthreads();
-        // ---- pass 1^T + per-thread argmax (register i of chunk ch holds cc[j + i S])
-        double ma = 0.0, mb = 0.0, sa = 0.0, sb = 0.0, cc0a = 0.0, cc0b = 0.0;
-        int ia = 0x7fffffff, ib = 0x7fffffff;
-#pragma clang loop unroll(disable)
-        for (int ch = 0; ch < CH; ch++) {
-            const int j = t + 256 * ch;
-            double2 v[16];
-#pragma unroll
-            for (int m = 0; m < Q1; m++)
-#pragma unroll
-                for (int r = 0; r < R1; r++)
-                    v[m + r * Q1] = X0[(j + m * S) * R1 + r];
-            dft_small<R1>(v);
-            if (ch == 0) {
-                cc0a = v[0].x; // thread 0: cc[0]
-                cc0b = v[0].y;
-            }
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const double aa = fabs(v[i].x), ab = fabs(v[i].y);
-                const int idx = j + i * S;
-                if (aa > ma || (aa == ma && aa > 0.0 && idx < ia)) { ma = aa; sa = v[i].x; ia = idx; }
-                if (ab > mb || (ab == mb && ab > 0.0 && idx < ib)) { mb = ab; sb = v[i].y; ib = idx; }
-            }
-        }
-        // ---- block argmax (first index of the maximum), owner thread stores
-        {
-            const double wa = wave_max(ma), wb = wave_max(mb);
-            if (lane == 0) {
-                red[32 + wave] = wa;
-                red[36 + wave] = wb;
-            }
-            if (t == 0) {
-                red[40] = cc0a;
-                red[41] = cc0b;
-            }
-            __syncthreads();
-            const double MA = fmax(fmax(red[32], red[33]), fmax(red[34], red[35]));
-            const double MB = fmax(fmax(red[36], red[37]), fmax(red[38], red[39]));
-            int ca = (ma == MA && MA > 0.0) ? ia : 0x7fffffff;
-            int cb = (mb == MB && MB > 0.0) ? ib : 0x7fffffff;
-            ca = wave_min_i(ca);
-            cb = wave_min_i(cb);
-            if (lane == 0) {
-                redi[wave] = ca;
-                redi[4 + wave] = cb;
-            }
-            __syncthreads();
-            const int IA = min(min(redi[0], redi[1]), min(redi[2], redi[3]));
-            const int IB = min(min(redi[4], redi[5]), min(redi[6], redi[7]));
-            for (int sidx = 0; sidx < 2; sidx++) {
-                if (sidx == 1 && !hasB)
-                    break;
-                const int I = sidx ? IB : IA;
-                const bool none = I == 0x7fffffff;
-                const bool owner = none ? (t == 0) : ((sidx ? ib : ia) == I && (sidx ? mb : ma) == (sidx ? MB : MA));
-                if (owner) {
-                    const double var = sidx ? varB : varA;
-                    const bool zero = sidx ? zeroB : zeroA, nan = sidx ? nanB : nanA;
-                    double y = __builtin_amdgcn_rsq(var);
-                    y = y * fma(-0.5 * var * y, y, 1.5);
-                    y = y * fma(-0.5 * var * y, y, 1.5);
-                    const int idx = none ? 0 : I;
-                    double mv = (none ? red[40 + sidx] : (sidx ? sb : sa)) * y;
-                    int lag = idx > n / 2 ? idx - n : idx;
-                    if (zero) { mv = 0.0; lag = 0; }
-                    if (nan) { mv = __builtin_nan(""); lag = 0; }
-                    p.mv[rA + sidx] = mv;
-                    p.lag[rA + sidx] = lag;
-                }
-            }
-            __syncthreads(); // red / redi / the scratch slices are free for the next pair
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
 // xcorr_fused_stk_4step<LOGN> (n = R1 * 4096, R1 = 4, 8, 16): the long-series path as a
 // four-step transform, n1 = R1 (in-thread), n2 = 4096 (on chip through LDS):
 //   X[k1 + R1 k2] = sum_m2 W_4096^(m2 k2) [ W_n^(m2 k1) sum_m1 W_R1^(m1 k1) x[m1 4096 + m2] ]
@@ -890,16 +652,6 @@ static hipError_t launch_stk_4step(const FusedParams &p, int num_cus, hipStream_
 }
 
 template <int LOGN>
-static hipError_t launch_stk_glb(const FusedParams &p, int num_cus, hipStream_t stream)
-{
-    if (!p.gscratch)
-        return hipErrorInvalidValue;
-    const long long grid = std::min<long long>(p.npairs, (long long)num_cus * STOCKHAM_GLOBAL_WGS_PER_CU);
-    hipLaunchKernelGGL((xcorr_fused_stk_glb<LOGN>), dim3((unsigned)grid), dim3(256), 0, stream, p);
-    return hipGetLastError();
-}
-
-template <int LOGN>
 static hipError_t launch_stk_lds(const FusedParams &p, int num_cus, hipStream_t stream)
 {
     constexpr int S = (1 << LOGN) / 16;
@@ -915,17 +667,15 @@ static hipError_t launch_stk_lds(const FusedParams &p, int num_cus, hipStream_t 
 // n = 512, 1024, 2048 (LDS) and 8192 ... 65536 (global scratch: 2 n complex per workgroup); any N in (n/2, n]
 hipError_t launch_fused_stockham(const FusedParams &p0, int num_cus, hipStream_t stream)
 {
-    FusedParams p = p0;
-    if (const char *d = getenv("MUSE_HIP_FAST_TUNE")) // tuning aid: bit 1 = four-pass global kernel instead of four-step
-        p.tune = atoi(d);
+    const FusedParams &p = p0;
     switch (p.logn) {
     case 9: return launch_stk_lds<9>(p, num_cus, stream);
     case 10: return launch_stk_lds<10>(p, num_cus, stream);
     case 11: return launch_stk_lds<11>(p, num_cus, stream);
     case 13: return launch_stk_lds<13>(p, num_cus, stream);
-    case 14: return p.tune & 2 ? launch_stk_glb<14>(p, num_cus, stream) : launch_stk_4step<14>(p, num_cus, stream);
-    case 15: return p.tune & 2 ? launch_stk_glb<15>(p, num_cus, stream) : launch_stk_4step<15>(p, num_cus, stream);
-    case 16: return p.tune & 2 ? launch_stk_glb<16>(p, num_cus, stream) : launch_stk_4step<16>(p, num_cus, stream);
+    case 14: return launch_stk_4step<14>(p, num_cus, stream);
+    case 15: return launch_stk_4step<15>(p, num_cus, stream);
+    case 16: return launch_stk_4step<16>(p, num_cus, stream);
     default: return hipErrorInvalidValue;
     }
 }

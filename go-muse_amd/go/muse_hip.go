@@ -23,6 +23,7 @@ import (
 	"fmt"
 	"runtime"
 	"sort"
+	"sync"
 	"unsafe"
 )
 
@@ -37,25 +38,34 @@ func hipError(status C.int) error {
 // engine is one muse_ctx (one GPU).  A process-wide default is created lazily.
 type engine struct{ ctx *C.muse_ctx }
 
-var defaultEngine *engine
+var (
+	defaultEngine    *engine
+	defaultEngineErr error
+	defaultEngineOne sync.Once
+)
 
+// getEngine creates the process-wide context exactly once, however many goroutines race to the first
+// use (muse_test.go:203-214 drives one Muse from many goroutines).  A failed creation is remembered:
+// there is no CPU fallback to retry into.
 func getEngine() (*engine, error) {
-	if defaultEngine == nil {
+	defaultEngineOne.Do(func() {
 		e := &engine{}
-		// cgo calls that use muse_last_error must stay on one OS thread
+		// a cgo call and the muse_last_error that explains it must run on one OS thread
 		runtime.LockOSThread()
 		defer runtime.UnlockOSThread()
 		if err := hipError(C.muse_ctx_create(0, &e.ctx)); err != nil {
-			return nil, err
+			defaultEngineErr = err
+			return
 		}
 		defaultEngine = e
-	}
-	return defaultEngine, nil
+	})
+	return defaultEngine, defaultEngineErr
 }
 
 // SetScreening switches the filter-and-refine Run of the default engine (include/muse_hip.h:
-// muse_ctx_set_screening; on by default: Runs over >= 32768 series of length 2049..4096 screen every
-// series in fp32 and re-evaluate in fp64 only the rows that can reach the top-N -- same Scores).
+// muse_ctx_set_screening; OFF by default -- every series is scored in float64 like the reference --;
+// when on, Runs over large groups screen every series in fp32 and re-evaluate in fp64 only the rows that
+// can reach the top-N: same Scores).
 // minRows > 1 sets the smallest group the path is used for.
 func SetScreening(enable bool, minRows int) error {
 	e, err := getEngine()
@@ -146,6 +156,13 @@ func NewBatch(ref *Series, comp *Group, results *Results, cc int) (*Batch, error
 		return nil, fmt.Errorf("Invalid input query, %v", err)
 	}
 	C.muse_batch_free(mb)
+	// the device batch Run creates lazily is released with the Batch (muse_batch_free takes no error path)
+	runtime.SetFinalizer(b, func(b *Batch) {
+		if b.batch != nil {
+			C.muse_batch_free(b.batch)
+			b.batch = nil
+		}
+	})
 	return b, nil
 }
 

@@ -65,8 +65,18 @@ class Engine:
         B.check(B.load().muse_ctx_set_kernel(self._h, int(variant)))
 
     def set_screening(self, enable, min_rows=None):
-        """filter-and-refine Run (include/muse_hip.h: muse_ctx_set_screening); min_rows: smallest group it is used for"""
+        """OPT-IN filter-and-refine Run (include/muse_hip.h: muse_ctx_set_screening); min_rows: smallest group it is used for"""
         B.check(B.load().muse_ctx_set_screening(self._h, (int(min_rows) if min_rows and min_rows > 1 else 1) if enable else 0))
+
+    def set_screen_bound_scale(self, scale):
+        """test hook (include/muse_hip_test.h): scales the error bound the filter-and-refine Run assumes"""
+        B.check(B.load().muse_test_set_screen_bound_scale(self._h, float(scale)))
+
+    def kernel_name(self, dbatch):
+        """name of the kernel automatic selection takes for this batch's all-scores pass"""
+        name = ctypes.create_string_buffer(128)
+        B.check(B.load().muse_batch_kernel_name(dbatch._h, name, 128))
+        return name.value.decode()
 
     def kernel_timing(self, enable):
         B.check(B.load().muse_ctx_kernel_timing(self._h, 1 if enable else 0))
@@ -232,8 +242,16 @@ class DeviceBatch:
         B.check(B.load().muse_batch_last_run_info(self._h, ctypes.byref(scr), ctypes.byref(ref)))
         return bool(scr.value), int(ref.value)
 
+    RUN_PATHS = {0: "fp64", 1: "screened", 2: "fp64 (these filters were costly to screen)", 3: "fp64 (guard tripped)"}
+
+    def last_run_path(self):
+        """MUSE_RUN_PATH_* of the last run on this batch (muse_batch_last_run_path)"""
+        path = ctypes.c_int32(0)
+        B.check(B.load().muse_batch_last_run_path(self._h, ctypes.byref(path)))
+        return int(path.value)
+
     def screen_estimates(self, max_lag=10):
-        """test hook: (estimates, flags, E) of the fp32 screening pass (include/muse_hip.h)"""
+        """test hook: (estimates, flags, E) of the fp32 screening pass (include/muse_hip_test.h)"""
         M = self.dgroup.M
         est = np.zeros(M)
         flags = np.zeros(M, dtype=np.uint32)

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MUSE_HIP_ABI_VERSION 1
+#define MUSE_HIP_ABI_VERSION 2
 
 typedef enum muse_status {
     MUSE_OK = 0,
@@ -77,40 +77,34 @@ int muse_ctx_synchronize(muse_ctx *ctx);
 /* name: >= 64 bytes.  Any out pointer may be NULL. */
 int muse_ctx_device_info(muse_ctx *ctx, char *name, int32_t name_cap,
                          int32_t *compute_units, int64_t *hbm_bytes);
-/* Kernel variant for the fused pass: 0 = auto (fastest kernel built for the
- * FFT length), 1 = force the generic radix-2 kernel; forcing one n = 4096 kernel: 2 = first (simple) fp64 kernel,
- * 5 = register-prefetch pipeline, 6 / 7 = half-round transposes at 4 / 3
- * waves per SIMD (7 also serves as the rescaling hand-off kernel), 8 = fp32 screening
- * + exact fp64 re-evaluation (experimental), 9 = 512-thread radix-8
- * (experimental), 10 = wave-local transposes + deferred statistics (what auto
- * picks for n == 4096).  For n != 4096: 11 = radix-16
- * Stockham kernels (n = 512 ... 2048 and 8192 through LDS, 16384 ... 65536
- * through a global scratch buffer; what auto picks for n >= 512), 1 = radix-2.
- * The parity tests run every variant on the same inputs; the environment
- * variable MUSE_HIP_KERNEL sets the initial value (profiling aid). */
-int muse_ctx_set_kernel(muse_ctx *ctx, int32_t variant);
-/* Filter-and-refine Run (on by default; MUSE_HIP_SCREEN_RUN=0 / enable = 0 turns it off; enable = 1: for Runs over
- * groups of >= 32768 * 4096 samples after padding, where it starts to pay; enable = n > 1: for Runs over >= n series).  When enabled, a
- * muse_batch_run / muse_batch_run_shard (with or without label groups) over that many series of length 257 .. 65536 (FFT
- * lengths 512 .. 65536) under automatic kernel selection screens every series with an fp32 transform (a bound E on its error is derived from the reference's
+/* Filter-and-refine Run: OPT-IN (off by default: every Run scores every series with the float64 kernel, the
+ * arithmetic of the reference, xcorr.go:160-197).  enable = 1: Runs over groups of >= 32768 * 4096 samples after
+ * padding, where it starts to pay; enable = n > 1: Runs over >= n series; 0: off.  When enabled, a muse_batch_run /
+ * muse_batch_run_shard / muse_batch_run_many (with or without label groups) over that many series of length
+ * 257 .. 65536 screens every series with an fp32 transform (a bound E on its error is derived from the reference's
  * spectrum), re-evaluates in fp64 exactly those rows whose optimistic selection key reaches the top_n-th best
  * pessimistic key, and selects among the re-evaluated rows only: the records returned are the ones the all-fp64 Run
- * returns.  muse_batch_read_scores after such a Run re-scores every row in fp64 first. */
+ * returns (a run-time guard re-does the Run in fp64 if an estimate is found outside the bound).
+ * muse_batch_read_scores after such a Run re-scores every row in fp64 first. */
 int muse_ctx_set_screening(muse_ctx *ctx, int32_t enable);
-/* Test / measurement hook: runs the screening pass of the filter-and-refine Run alone (MaxLag = max_lag, TopN = 1, no
- * other filter) over a batch of series of length 257 .. 65536 and returns, per series, the fp32 estimate of the signed score,
- * the pass's flag word (bit 0 / 1: a possible argmax has |lag| <= / > max_lag; bit 2 / 3: a possible argmax value is
- * > 0 / < 0; bit 4: fp32 not trusted, must be re-evaluated; bit 5: the exact score is NaN; bit 31: the row was
- * re-evaluated and `estimate` holds its fp64 score) and the bound *E (score units) that the selection assumes on
- * |estimate - exact score|.  Any out pointer may be NULL. */
-int muse_batch_screen_estimates(muse_batch *b, int32_t max_lag, double *estimate, uint32_t *flags, double *E);
 /* Which path the last muse_batch_run / muse_batch_run_shard on this batch took: *screened = 1 for filter-and-refine,
  * *refined_pairs = pairs of series it re-evaluated in fp64.  Any out pointer may be NULL. */
 int muse_batch_last_run_info(muse_batch *b, int32_t *screened, int64_t *refined_pairs);
+/* ... and why: MUSE_RUN_PATH_FP64 (screening off or the Run not eligible), _SCREENED, _FP64_COSTLY (an earlier
+ * screened Run with exactly these filters over these rows re-evaluated more than a quarter of the pairs: the plain
+ * fp64 pass is cheaper for it; other filters on the same batch are still screened), _FP64_GUARD (an estimate was once
+ * found outside the bound: the batch stays on the fp64 path). */
+#define MUSE_RUN_PATH_FP64 0
+#define MUSE_RUN_PATH_SCREENED 1
+#define MUSE_RUN_PATH_FP64_COSTLY 2
+#define MUSE_RUN_PATH_FP64_GUARD 3
+int muse_batch_last_run_path(muse_batch *b, int32_t *path);
 /* HIP-event timing of the fused kernel on the stream it is launched on:
  * enable, run, then read (sum of launch durations in ms, launch count). */
 int muse_ctx_kernel_timing(muse_ctx *ctx, int32_t enable);
 int muse_ctx_kernel_time(muse_ctx *ctx, double *total_ms, int64_t *launches);
+/* Name of the kernel automatic selection takes for this batch's all-scores pass (name: >= 64 bytes). */
+int muse_batch_kernel_name(muse_batch *b, char *name, int32_t name_cap);
 
 /* -------------------------------------------------------------- group */
 /* Device-resident row-major M x N float64 comparison matrix; replaces the
@@ -144,7 +138,10 @@ int muse_group_free(muse_group *g);
  * N == group length (MUSE_ERR_LENGTH), n = nextPowOf2(N), reference spectrum
  * FFT(zeroPad(zNormalize(ref)/(N-1), n)) computed on the device and kept
  * resident.  MUSE_ERR_ZERO_STD when sigma(ref) == 0; MUSE_ERR_EMPTY when
- * N < 1.  ref is copied, not mutated. */
+ * N < 1.  ref is copied, not mutated.
+ * Divergence: N == 1 is rejected with MUSE_ERR_INVALID.  The reference accepts it (New / NewBatch divide by
+ * N - 1 = 0: every score is NaN and never passes Results.passed), so the observable outcome -- no scores -- is the
+ * same, but here it is an error at creation instead of an empty result. */
 int muse_batch_create(muse_ctx *ctx, muse_group *g, const double *ref,
                       int32_t N, muse_batch **out);
 /* A batch for another group against the SAME reference: shares src's

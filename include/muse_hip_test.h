@@ -1,0 +1,33 @@
+/*
+ * muse_hip_test.h -- TEST AND MEASUREMENT HOOKS of libmuse_hip.so.  Not part of the drop-in boundary: nothing a
+ * go-muse host binds lives here (INTEGRATION.md binds include/muse_hip.h only).  Used by tests/, tools/ and bench.py.
+ */
+#ifndef MUSE_HIP_TEST_H
+#define MUSE_HIP_TEST_H
+
+#include "muse_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Forces the kernel of the all-scores pass (muse_batch_score): 0 = automatic (default), 1 = generic radix-2 kernel
+ * (any power-of-two n), 7 = the n = 4096 kernel that rescales both series before the shared transform (the hand-off
+ * target of the default kernel), 10 = the default n = 4096 kernel, 11 = radix-16 Stockham / four-step kernels
+ * (n = 512 .. 2048, 8192 .. 65536).  The parity tests run every kernel on the same inputs. */
+int muse_ctx_set_kernel(muse_ctx *ctx, int32_t variant);
+/* Scales the error bound the filter-and-refine Run assumes for its fp32 estimates (1.0 = the derived bound): the
+ * guard test shrinks it a million-fold to force the fp64 re-run. */
+int muse_test_set_screen_bound_scale(muse_ctx *ctx, double scale);
+/* Runs the screening pass of the filter-and-refine Run alone (MaxLag = max_lag, TopN = 1, no other filter) over a
+ * batch of series of length 257 .. 65536 and returns, per series, the fp32 estimate of the signed score, the pass's
+ * flag word (bit 0 / 1: a possible argmax has |lag| <= / > max_lag; bit 2 / 3: a possible argmax value is > 0 / < 0;
+ * bit 4: fp32 not trusted, must be re-evaluated; bit 5: the exact score is NaN; bit 31: the row was re-evaluated and
+ * `estimate` holds its fp64 score) and the bound *E (score units) that the selection assumes on
+ * |estimate - exact score|.  Any out pointer may be NULL. */
+int muse_batch_screen_estimates(muse_batch *b, int32_t max_lag, double *estimate, uint32_t *flags, double *E);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -255,9 +255,8 @@ def test_scores_match_oracle_all_lengths(muse, eng, oracle, N, M):
 
 @pytest.mark.parametrize("N", [2049, 3000, 4095, 4096])
 def test_every_kernel_variant_matches_oracle(muse, eng, oracle, N):
-    """auto (0), generic (1), each fp64 n = 4096 kernel generation (2, 5, 6, 7, 9) and the
-    fp32-screen + fp64-re-evaluation kernel (8) on the same inputs, incl. N < n padding, sigma == 0,
-    NaN / Inf rows and an odd row count."""
+    """auto (0), generic radix-2 (1), the rescaling n = 4096 kernel (7) and the default n = 4096 kernel forced (10) on
+    the same inputs, incl. N < n padding, sigma == 0, NaN / Inf rows and an odd row count."""
     ref, rows = _rows(65, N, N)
     rows[10, 5] = np.nan          # NaN row: (lag 0, mv NaN), must not disturb its pair partner
     rows[12, :] = np.inf
@@ -274,7 +273,7 @@ def test_every_kernel_variant_matches_oracle(muse, eng, oracle, N):
     assert db.n == 4096
     olag, omv, gap = oracle.batch_scores(ref, rows)
     try:
-        for variant in (0, 1, 2, 5, 6, 7, 8, 9, 10):
+        for variant in (0, 1, 7, 10):
             eng.set_kernel(variant)
             lag, mv = db.scores()
             assert math.isnan(mv[10]) and lag[10] == 0 and math.isnan(mv[12]) and lag[12] == 0, variant
@@ -433,9 +432,9 @@ def test_cpp_host_mirror_reference_tests(muse):
     assert "all host tests passed" in r.stdout
 
 
-def test_screen_kernel_many_near_ties_overflow_path(muse, eng, oracle):
-    """periodic series have many lags within the fp32 window of the maximum: the screening
-    kernel must hand those pairs to the fp64 kernel (overflow list) and still match."""
+def test_periodic_series_many_near_ties(muse, eng, oracle):
+    """periodic series have many lags whose |cc| is within rounding of the maximum: scores must match, lags outside
+    the oracle-flagged ties too (every n = 4096 kernel)."""
     N = 4096
     t = np.arange(N)
     rng = np.random.default_rng(12)
@@ -445,11 +444,12 @@ def test_screen_kernel_many_near_ties_overflow_path(muse, eng, oracle):
     db = muse.DeviceBatch(eng, muse.DeviceGroup.from_rows(eng, rows), ref)
     olag, omv, gap = oracle.batch_scores(ref, rows)
     try:
-        eng.set_kernel(8)
-        lag, mv = db.scores()
+        for variant in (0, 7, 1):
+            eng.set_kernel(variant)
+            lag, mv = db.scores()
+            assert_scores_match(lag, mv, olag, omv, gap)
     finally:
         eng.set_kernel(0)
-    assert_scores_match(lag, mv, olag, omv, gap)
 
 
 @pytest.mark.parametrize("N", [512, 1000, 4096, 5000])
@@ -903,17 +903,15 @@ def test_screened_run_equals_fp64_run(muse, eng, oracle, N):
     lag, mv = db.scores()
     try:
         eng.set_screening(True, min_rows=1000)
-        first = True
         for max_lag in (15, 0, 2048, 4096, 100):
             for top_n, thr, sign, absf in ((20, 0.0, 0, True), (1, 0.0, 0, True), (200, 0.0, 0, True), (20, 0.3, 0, True),
                                           (20, 0.0, 1, False), (20, 0.0, -1, False), (50, 0.05, -1, True),
                                           (20, 0.999, 0, True), (256, 0.0, 1, True)):
                 got = db.run(None, 0, max_lag, top_n, thr, sign, absf)
-                if first:
-                    assert db.last_run_info()[0] is True, N      # the path under test did run
-                    first = False
-                exp = oracle.results(lag, mv, None, 0, absf, max_lag, top_n, thr, sign)
                 key = (max_lag, top_n, thr, sign, absf)
+                # the path under test ran for EVERY combination (a costly one only switches itself off, not the batch)
+                assert db.last_run_path() == 1 and db.last_run_info()[0] is True, (N, key)
+                exp = oracle.results(lag, mv, None, 0, absf, max_lag, top_n, thr, sign)
                 assert got[0].tolist() == exp[0].tolist(), key
                 assert got[1].tolist() == exp[1].tolist(), key
                 # (2048 < N < 4096: the all-scores kernel corrects for the mean after the transform, the re-evaluating
@@ -924,7 +922,7 @@ def test_screened_run_equals_fp64_run(muse, eng, oracle, N):
         assert np.array_equal(lag2, lag)
         np.testing.assert_allclose(mv2, mv, rtol=1e-12, atol=0, equal_nan=True)
     finally:
-        eng.set_screening(True)   # the default (Runs over >= 32768 series)
+        eng.set_screening(False)  # the default: opt-in
         db.close()
 
 
@@ -982,7 +980,7 @@ def test_screened_run_synthetic_matches_fp64_run(muse, eng):
             np.testing.assert_allclose(got[2], exact, rtol=1e-12, atol=0)
             assert abs(got[3] - exp[3]) <= 1e-12
     finally:
-        eng.set_screening(True)   # the default (Runs over >= 32768 series)
+        eng.set_screening(False)  # the default: opt-in
         db.close()
 
 
@@ -1023,7 +1021,7 @@ def test_screened_run_fuzz_filters_and_smooth_series(muse, eng, oracle):
             np.testing.assert_allclose(got[2], exp[2], rtol=1e-12, atol=0, err_msg=str(key))
         assert screened_runs >= 1, kind          # the path was exercised (it may switch itself off afterwards)
         db.close()
-    eng.set_screening(True)
+    eng.set_screening(False)
 
 
 @pytest.mark.parametrize("N", [4096, 1000, 20000])
@@ -1068,7 +1066,7 @@ def test_screened_run_with_label_groups(muse, eng, oracle, N):
         np.testing.assert_allclose(got[2], exp[2], rtol=1e-12, atol=0, err_msg=str(key))
     assert screened_runs >= 1
     db.close()
-    eng.set_screening(True)
+    eng.set_screening(False)
 
 
 def test_screened_run_degenerate_inputs(muse, eng, oracle):
@@ -1107,25 +1105,22 @@ def test_screened_run_degenerate_inputs(muse, eng, oracle):
             else:
                 assert np.array_equal(lag[got[0]], got[1]), key
         db.close()
-    eng.set_screening(True)
+    eng.set_screening(False)
 
 
 def test_screening_bound_guard_falls_back_to_fp64(muse, oracle):
     """The run-time guard: every re-evaluated row has an fp32 estimate and an fp64 score; if they differ by more than the
     bound the selection assumed, the Run is redone in fp64 and the batch leaves the filter-and-refine path.  Forced here
-    by shrinking the assumed bound a million-fold (MUSE_HIP_SCREEN_E_SCALE, read when a context is created)."""
+    by shrinking the assumed bound a million-fold through the test hook muse_test_set_screen_bound_scale."""
     rng = np.random.default_rng(5)
     N, M = 4096, 16500
     ref = rng.standard_normal(N)
     rows = rng.standard_normal((M, N))
     for i in rng.integers(0, M, size=M // 4):
         rows[i] += rng.uniform(-2, 2) * np.roll(ref, int(rng.integers(-100, 100)))
-    os.environ["MUSE_HIP_SCREEN_E_SCALE"] = "1e-6"
+    e2 = muse.Engine(0)
     try:
-        e2 = muse.Engine(0)
-    finally:
-        del os.environ["MUSE_HIP_SCREEN_E_SCALE"]
-    try:
+        e2.set_screen_bound_scale(1e-6)
         e2.set_screening(True, min_rows=16384)
         dg = muse.DeviceGroup.from_rows(e2, rows)
         db = muse.DeviceBatch(e2, dg, ref)
@@ -1133,6 +1128,7 @@ def test_screening_bound_guard_falls_back_to_fp64(muse, oracle):
         for args in ((None, 0, 100, 20, 0.0, 0, True), (None, 0, 4096, 5, 0.1, -1, False)):
             got = db.run(*args)
             assert db.last_run_info()[0] is False          # redone in fp64 (first Run), or not screened any more
+            assert db.last_run_path() == 3                  # ... because the guard tripped
             exp = oracle.results(lag, mv, None, 0, args[6], args[2], args[3], args[4], args[5])
             assert got[0].tolist() == exp[0].tolist() and got[1].tolist() == exp[1].tolist()
             np.testing.assert_allclose(got[2], exp[2], rtol=1e-12, atol=0)
@@ -1187,6 +1183,6 @@ def test_screened_run_many_references(muse, eng, oracle):
             if trial == 0:
                 assert bs[pick[0]].last_run_info()[0] is True      # the first call, at least, took the screened path
     finally:
-        eng.set_screening(True)
+        eng.set_screening(False)
         for b in bs:
             b.close()

@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 pkg = importlib.import_module("go-muse_amd")
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-variants = [int(v) for v in sys.argv[3:]] or [2, 5, 7, 8, 9]
+variants = [int(v) for v in sys.argv[3:]] or [7, 10]
 eng = pkg.get_engine(0)
 dg, ref = pkg.DeviceGroup.synthetic(eng, rows, 4096)
 db = pkg.DeviceBatch(eng, dg, ref)
