@@ -53,7 +53,7 @@ SIGNATURES = {
     "muse_group_create": (ctypes.c_int, [_vp, _i64, _i32, ctypes.POINTER(_vp)]),
     "muse_group_append": (ctypes.c_int, [_vp, _dp, _i64, _i64]),
     "muse_group_upload": (ctypes.c_int, [_vp, _dp, _i64, _i32, _i64, ctypes.POINTER(_vp)]),
-    "muse_group_fill_synthetic": (ctypes.c_int, [_vp, _i64, _i64, _i64, ctypes.c_uint64, _dp]),
+    "muse_group_fill_synthetic": (ctypes.c_int, [_vp, _i64, _i64, _i64, ctypes.c_uint64, ctypes.c_uint32, _dp]),
     "muse_group_shape": (ctypes.c_int, [_vp, _i64p, _i32p]),
     "muse_group_read": (ctypes.c_int, [_vp, _i64, _i64, _dp]),
     "muse_group_free": (ctypes.c_int, [_vp]),
@@ -74,6 +74,7 @@ SIGNATURES = {
     "muse_batch_last_run_path": (ctypes.c_int, [_vp, _i32p]),
     "muse_batch_kernel_name": (ctypes.c_int, [_vp, ctypes.c_char_p, _i32]),
     "muse_test_set_screen_bound_scale": (ctypes.c_int, [_vp, _f64]),
+    "muse_test_screen_bound": (ctypes.c_int, [_i32, _f64, _dp]),
     "muse_batch_screen_estimates": (ctypes.c_int, [_vp, _i32, _dp, ctypes.POINTER(ctypes.c_uint32), _dp]),
     "muse_batch_run_many": (ctypes.c_int, [ctypes.POINTER(_vp), _i32, _i32p, _i32, _i32, _i32, _f64, _i32, _i32,
                                            _i64p, _i32p, _dp, _i32p, _dp]),

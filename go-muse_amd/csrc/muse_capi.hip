@@ -212,6 +212,7 @@ struct muse_batch {
     bool scores_exact = true;           // mv / lag hold fp64 results for every row (false after a screened Run)
     bool last_screened = false;         // the last Run took the filter-and-refine path
     int64_t guard_trips = 0;            // Runs redone in fp64 because an estimate left its bound
+    uint64_t guard_salt = 0;            // varies the guard's row sample from Run to Run
 };
 
 static int use_device(muse_ctx *ctx)
@@ -575,7 +576,7 @@ extern "C" int muse_group_upload(muse_ctx *ctx, const double *rows, int64_t M, i
 }
 
 extern "C" int muse_group_fill_synthetic(muse_group *g, int64_t first, int64_t count, int64_t global_first,
-                                         uint64_t seed, double *ref_out)
+                                         uint64_t seed, uint32_t flags, double *ref_out)
 {
     if (!g || first < 0 || count < 0 || first > g->M)
         return fail(MUSE_ERR_INVALID, "bad synthetic fill range");
@@ -588,7 +589,7 @@ extern "C" int muse_group_fill_synthetic(muse_group *g, int64_t first, int64_t c
     rc = group_reserve(g, first + count);
     if (rc)
         return rc;
-    HIP_TRY(launch_synth(g->rows, g->stride, first, count, global_first, g->N, seed, g->ctx->stream));
+    HIP_TRY(launch_synth(g->rows, g->stride, first, count, global_first, g->N, seed, flags, g->ctx->stream));
     g->M = std::max(g->M, first + count);
     if (ref_out) {
         double *d = nullptr;
@@ -1198,23 +1199,36 @@ static int32_t screen_path(const muse_batch *b, const muse_batch::RunKey &key, b
     return MUSE_RUN_PATH_SCREENED;
 }
 
-// Error bound of the screening pass's estimates, in its scaled units (score = estimate / (2^-e sigma), the last
-// factor in (0.707, 1.4143]).  Both transforms run on z = A + iB with ||z||_2 <= sqrt(2 (N-1)) * 1.4143 < 128 and
-// the product spectrum is bounded by max|X| * ||Z||_2 / n, so every error term of the standard fp32 FFT analysis
-// (Higham, Accuracy and Stability of Numerical Algorithms, 24.1: ||fl(F x) - F x||_2 <= c log2(n) u ||F x||_2;
-// here three radix-16 passes with twiddles that are products of <= 4 rounded factors, the rounded spectrum table
-// and the complex multiply) scales with u * max|X| * 128; 256 is > 1.5x the sum of those constants (~170).
+// Error bound of the screening pass's estimates, in its SCALED units (docs/screen_error_bound.md derives every number;
+// tests/test_abi_cpu.py re-sums the per-stage constants and compares).  The pass scales each centred series by
+// scl = 2^-(e >> 1), e = exponent of its variance, so scl * sigma lies in [1, 2) and
+//     score = estimate / (scl * sigma),   |score error| <= |estimate error|            (scl * sigma >= 1),
+//     ||z||_2 <= sqrt(2) * 2 * sqrt(N - 1) < 2 sqrt(2 n)      (z = A + iB: 181 at n = 4096).
+// Both transforms run on z and the product spectrum is bounded by max|X| * ||Z||_2 / n, so every error term of the
+// standard fp32 FFT analysis (Higham, Accuracy and Stability of Numerical Algorithms, Thm 24.2: per radix-2 stage
+// eta = mu + gamma_4 (sqrt 2 + mu)) scales with u * max|X| * ||z||_2.  First-order constants: 6.66 u per radix-2 stage
+// (rounded butterfly constants), 15.3 u per scaling by a twiddle that is a product of <= 4 rounded factors, 3.83 u per
+// scaling by a single rounded table entry (pass-2 twiddles, the spectrum table, the four-step twiddle):
+//     n = 4096:  2 (12 * 6.66 + 15.3 + 3.83) + 3.83 = 202   -> 256 used
+//     n = 8192:  2 (13 * 6.66 + 3 * 15.3)    + 3.83 = 269   -> 320 used
+//     n = 65536: 2 (16 * 6.66 + 15.3 + 2 * 3.83) + 3.83 = 263 -> 384 used
 // The second term is the rounding of the fp32 input copy (|mean d| <= 8 sigma is enforced by the kernel):
-// ||delta c||_2 <= 2u (90.5 + 8 * 1.4143 * 64) and |delta cc| <= ||delta c||_2 ||xs||_2, ||xs||_2 = 1 / sqrt(N-1).
+// ||delta c||_2 <= 2u (2 + 16) sqrt(N) and |delta cc| <= ||delta c||_2 ||xs||_2, ||xs||_2 = 1 / sqrt(N-1): 2.2e-6, plus
+// (N < n) 1e-6 for the rounded mean acting through the indicator correlation: 3e-6 used.
 static double screen_error_scaled(double xmax, int n)
 {
-    // N < 4096 (zero-padded): the rounded mean is a constant offset of the samples only, not of the pad; it reaches a
-    // lag through the correlation of the sample indicator with the reference, |c1| <= sqrt(N) ||xs||_2 ~ 1, times
-    // 2^-24 * 8 sigma * 1.4143 / sigma < 1e-6 (for N == n that correlation is the reference's sum: 0).
     const double u = 5.9604644775390625e-08; // 2^-24
-    // (n = 8192 takes four passes per transform instead of three: 320 instead of 256; the four-step kernels of
-    // n >= 16384 a radix-R1 sweep with single-entry twiddles plus the three passes of a 4096-point row: 384)
-    return (n > 8192 ? 384.0 : n > 4096 ? 320.0 : 256.0) * u * (2.0 * std::sqrt((double)n)) * xmax + 3e-6; // ||z||_2 <= sqrt(2 (N-1)) * 1.4143 <= 2 sqrt(n): 128 at n = 4096
+    const double C = n > 8192 ? 384.0 : n > 4096 ? 320.0 : 256.0;
+    return C * u * (2.0 * std::sqrt(2.0 * (double)n)) * xmax + 3e-6;
+}
+
+// test hook (muse_hip_test.h): the bound for an FFT length and max|X|
+extern "C" int muse_test_screen_bound(int32_t n, double xmax, double *Es)
+{
+    if (!Es || n < 2)
+        return fail(MUSE_ERR_INVALID, "bad arguments");
+    *Es = screen_error_scaled(xmax, n);
+    return MUSE_OK;
 }
 
 // The filter-and-refine scoring in three steps, so that the screening pass can be one launch per batch or one launch
@@ -1277,12 +1291,12 @@ static int screen_prepare(muse_batch *b, int32_t top_n, const int *gid_dev, int6
         HIP_TRY(hipHostMalloc((void **)&b->err_host, sizeof(unsigned long long), hipHostMallocDefault));
     if (!b->err_dev)
         HIP_TRY(hipMalloc(&b->err_dev, sizeof(unsigned long long)));
-    if (2 * npairs > b->est_cap) {
+    if (4 * npairs > b->est_cap) { // two estimates per listed pair; the list holds the selection's pairs plus the guard sample
         (void)hipFree(b->est_save);
         b->est_save = nullptr;
         b->est_cap = 0;
-        HIP_TRY(hipMalloc(&b->est_save, (size_t)(2 * npairs) * sizeof(double)));
-        b->est_cap = 2 * npairs;
+        HIP_TRY(hipMalloc(&b->est_save, (size_t)(4 * npairs) * sizeof(double)));
+        b->est_cap = 4 * npairs;
     }
     if (npairs > b->ovf_cap) {
         (void)hipFree(b->ovf_list);
@@ -1334,13 +1348,17 @@ static int screen_finish(muse_batch *b, int32_t top_n, double threshold, int32_t
     q.threshold = threshold;
     q.sign_filter = sign_filter;
     q.abs_scores = abs_scores ? 1 : 0;
-    q.E = 1.4143 * Es; // score = estimate / (2^-e sigma), 2^-e sigma in (0.7071, 1.4143]
+    q.E = Es; // score = estimate / (scl sigma) with scl sigma in [1, 2): the score's error is at most the estimate's
     q.group_id = gid_dev;
     q.G = (int)G;
     // (the group scratch borrows the final reduction's arrays: that reduction re-initialises them afterwards)
     const ScreenGroupWork sgw{b->gw.first, b->gw.key, b->scr_gmay, b->scr_gkplus, b->scr_gcert};
     HIP_TRY(launch_screen_select(q, top_n, b->selkey, b->scr_keys, sgw, b->ovf_list, b->ovf_count, b->include,
                                  ctx->stream));
+    // guard sample (one pair in 1024, a different set every Run): re-evaluated like the listed pairs, so the check of the
+    // bound below is not confined to rows the selection wanted anyway
+    HIP_TRY(launch_screen_sample(npairs, M, 0x6d757365ull + 0x9E3779B97F4A7C15ull * (unsigned long long)(++b->guard_salt),
+                                 b->ovf_list, b->ovf_count, b->include, ctx->stream));
     // the fp64 kernel re-evaluates the listed pairs (count stays on the device and bounds its loop)
     FusedParams r = base_params(b);
     r.pair_list = b->ovf_list;
@@ -1477,7 +1495,7 @@ extern "C" int muse_batch_screen_estimates(muse_batch *b, int32_t max_lag, doubl
             if (inc[(size_t)i])
                 flags[i] |= 0x80000000u; // re-evaluated: `estimate` holds the fp64 result for this row
     if (E)
-        *E = 1.4143 * screen_error_scaled(b->sp->xmax, b->n);
+        *E = screen_error_scaled(b->sp->xmax, b->n);
     return MUSE_OK;
 }
 

@@ -52,7 +52,7 @@ __global__ void group_key_kernel(SelectParams sp, GroupWork gw)
         if (g < 0 || g >= sp.G)
             continue;
         atomicMin(&gw.first[g], i);
-        if (sp.include && !sp.include[i])
+        if (sp.include && sp.include[i] != 1)
             continue; // filter-and-refine Run: this row cannot be the group's record (its score is an estimate)
         const double v = clamp_score(sp.mv[i], sp.abs_scores);
         if (v == v)
@@ -67,7 +67,7 @@ __global__ void group_win_kernel(SelectParams sp, GroupWork gw)
         const int g = sp.group_id[i];
         if (g < 0 || g >= sp.G)
             continue;
-        if (sp.include && !sp.include[i])
+        if (sp.include && sp.include[i] != 1)
             continue;
         const double v = clamp_score(sp.mv[i], sp.abs_scores);
         if (v == v && abs_bits(v) == gw.key[g])
@@ -111,7 +111,7 @@ __global__ void group_final_kernel(SelectParams sp, GroupWork gw, muse_record *r
         rec[g].lag = lg;
         rec[g].group = g;
         // (filter-and-refine Run: only rows the fp64 kernel has re-evaluated may be selected)
-        selkey[g] = (!sp.include || sp.include[w]) && passed(s, lg, sp) ? abs_bits(s) + 1ull : 0ull;
+        selkey[g] = (!sp.include || sp.include[w] == 1) && passed(s, lg, sp) ? abs_bits(s) + 1ull : 0ull;
     }
 }
 
@@ -476,6 +476,41 @@ __global__ void screen_check_kernel(const double *mv, long long M, const long lo
         }
     }
 }
+// Guard sample: one pair in 1024, chosen by a hash of (pair, salt), is appended to the re-evaluation list although the
+// selection does not need it, so that the check below also sees rows the bound alone vouches for (a violated bound on
+// an unrefined row would otherwise be invisible).  The sampled rows get exact scores but stay OUT of the selection
+// (include = 2, unless the selection listed them itself): a label group's record is its member with the largest score and
+// the filters apply to that record, so a sampled member of a group whose possible winners were not re-evaluated must
+// not stand in for them.
+__global__ void screen_sample_kernel(long long npairs, long long M, unsigned long long salt, long long *pair_list,
+                                     int *pair_count, unsigned char *include)
+{
+    for (long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x; p < npairs; p += (long long)gridDim.x * blockDim.x) {
+        unsigned long long x = (unsigned long long)p * 0x9E3779B97F4A7C15ull + salt;
+        x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+        x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+        x ^= x >> 31;
+        if ((x & 1023ull) != 0ull)
+            continue;
+        const int slot = atomicAdd(pair_count, 1);
+        pair_list[slot] = p;
+        if (include[2 * p] == 0)
+            include[2 * p] = 2;
+        if (2 * p + 1 < M && include[2 * p + 1] == 0)
+            include[2 * p + 1] = 2;
+    }
+}
+hipError_t launch_screen_sample(long long npairs, long long M, unsigned long long salt, long long *pair_list, int *pair_count,
+                                unsigned char *include, hipStream_t stream)
+{
+    if (npairs <= 0)
+        return hipSuccess;
+    const long long blocks = (npairs + 255) / 256;
+    hipLaunchKernelGGL(screen_sample_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, stream, npairs, M,
+                       salt, pair_list, pair_count, include);
+    return hipGetLastError();
+}
+
 hipError_t launch_screen_save(const ScreenSelect &q, const long long *pair_list, const int *pair_count, double *est_save,
                               hipStream_t stream)
 {

@@ -90,7 +90,7 @@ hipError_t launch_direct(const double *x, int lenx, const double *y, int leny, i
                          int normalize_y, double x_scale, double cc_scale, double *cc, int *lag, double *mv,
                          int *status, hipStream_t stream);
 hipError_t launch_synth(double *rows, long long stride, long long first, long long count, long long global_first,
-                        int N, unsigned long long seed, hipStream_t stream);
+                        int N, unsigned long long seed, unsigned flags, hipStream_t stream);
 hipError_t launch_synth_ref(double *ref, int N, unsigned long long seed, hipStream_t stream);
 
 // ---- group max / filter / top-N (reduce_kernels.hip)
@@ -141,6 +141,9 @@ struct ScreenGroupWork {
 long long screen_select_scratch(long long G, int top_n);
 // run-time guard of the bound: estimates of the listed rows saved before the fp64 kernel overwrites them, then the largest
 // | |estimate| - |fp64 score| | over those rows (as the bits of a non-negative double, atomicMax)
+// guard sample: appends one pair in 1024 (hash of pair and salt) to the list and marks its rows re-evaluated
+hipError_t launch_screen_sample(long long npairs, long long M, unsigned long long salt, long long *pair_list, int *pair_count,
+                                unsigned char *include, hipStream_t stream);
 hipError_t launch_screen_save(const ScreenSelect &q, const long long *pair_list, const int *pair_count, double *est_save,
                               hipStream_t stream);
 hipError_t launch_screen_check(const double *mv, long long M, const long long *pair_list, const int *pair_count,

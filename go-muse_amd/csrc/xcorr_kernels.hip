@@ -360,15 +360,15 @@ __device__ __forceinline__ double gauss(uint64_t seed, uint64_t row, uint64_t t)
     const double u2 = (double)(h2 >> 11) * (1.0 / 9007199254740992.0);        // [0,1)
     return sqrt(-2.0 * log(u1)) * cospi(2.0 * u2);
 }
-__device__ __forceinline__ double synth_value(uint64_t seed, long long grow, int t, int N)
+__device__ __forceinline__ double synth_value(uint64_t seed, long long grow, int t, int N, unsigned flags = 0u)
 {
     const uint64_t REF_ROW = 0xFFFFFFFFFFFFFFFFull;
     uint64_t row = (uint64_t)grow;
     if (grow >= 0) {
         const uint64_t kind = mix64(seed ^ (row * 0xA24BAED4963EE407ull)) & 1023ull;
-        if (kind == 0) // constant row, dyadic value: sum and mean are exact
+        if (kind == 0 && !(flags & MUSE_SYNTH_NO_CONSTANTS)) // constant row, dyadic value: sum and mean are exact
             return 0.5 * (double)(1 + (row % 7));
-        if (kind == 1)
+        if (kind == 1 && !(flags & MUSE_SYNTH_NO_COPIES)) // exact copy of the reference
             row = REF_ROW;
     } else {
         row = REF_ROW;
@@ -394,14 +394,14 @@ __device__ __forceinline__ double synth_value(uint64_t seed, long long grow, int
 }
 
 __global__ void synth_fill_kernel(double *rows, long long stride, long long first, long long count,
-                                  long long global_first, int N, unsigned long long seed)
+                                  long long global_first, int N, unsigned long long seed, unsigned flags)
 {
     const long long total = count * (long long)N;
     for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
          e += (long long)gridDim.x * blockDim.x) {
         const long long r = e / N;
         const int t = (int)(e - r * N);
-        rows[(first + r) * stride + t] = synth_value(seed, global_first + r, t, N);
+        rows[(first + r) * stride + t] = synth_value(seed, global_first + r, t, N, flags);
     }
 }
 __global__ void synth_ref_kernel(double *ref, int N, unsigned long long seed)
@@ -514,12 +514,12 @@ hipError_t launch_direct(const double *x, int lenx, const double *y, int leny, i
 }
 
 hipError_t launch_synth(double *rows, long long stride, long long first, long long count, long long global_first,
-                        int N, unsigned long long seed, hipStream_t stream)
+                        int N, unsigned long long seed, unsigned flags, hipStream_t stream)
 {
     if (count <= 0)
         return hipSuccess;
     hipLaunchKernelGGL(synth_fill_kernel, dim3(4096), dim3(256), 0, stream, rows, stride, first, count, global_first,
-                       N, seed);
+                       N, seed, flags);
     return hipGetLastError();
 }
 hipError_t launch_synth_ref(double *ref, int N, unsigned long long seed, hipStream_t stream)

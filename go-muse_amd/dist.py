@@ -4,6 +4,10 @@ exchange step is the gather of each shard's top-N candidate records
 (top_n x 24 B per rank) -- one all_gather over RCCL/xGMI (backend "nccl") or
 gloo (CPU tests) -- followed by the Results merge (muse_merge_records).
 
+Process set-up (bench.py does exactly this): initialise torch's GPU runtime first
+(torch.cuda.set_device(local_rank); dist.init_process_group("nccl", ...)), THEN create the
+Engine -- torch bundles its own HIP runtime and must be the first to open the device.
+
 Correctness condition: with grouped runs every label group must
 live on ONE shard (shard on group boundaries); Run(nil) is always exact.
 """

@@ -146,12 +146,14 @@ class DeviceGroup:
         return g
 
     @classmethod
-    def synthetic(cls, engine, M, N, seed=0x6D757365, global_first=0):
-        """rect+noise workload generated on the device; returns (group, ref)."""
+    def synthetic(cls, engine, M, N, seed=0x6D757365, global_first=0, copies=True, constants=True):
+        """rect+noise workload generated on the device; returns (group, ref).  copies / constants: plant the
+        1-in-1024 exact copies of the reference / constant rows (muse_hip.h, MUSE_SYNTH_NO_*)."""
         g = cls(engine, N, M)
         ref = np.zeros(N)
+        flags = (0 if copies else 1) | (0 if constants else 2)
         B.check(B.load().muse_group_fill_synthetic(g._h, 0, int(M), int(global_first),
-                                                   ctypes.c_uint64(seed), B.dptr(ref)))
+                                                   ctypes.c_uint64(seed), ctypes.c_uint32(flags), B.dptr(ref)))
         return g, ref
 
     def append(self, rows):

@@ -123,10 +123,15 @@ int muse_group_upload(muse_ctx *ctx, const double *rows, int64_t M, int32_t N,
  * SURVEY 8d (after example_test.go:15-20), keyed by (seed, global row index =
  * global_first + local row, sample index): bench/test utility; rows become
  * part of the group (size grows to first+count if needed). ref_out (N doubles,
- * host, may be NULL) receives the reference series of the workload. */
+ * host, may be NULL) receives the reference series of the workload.
+ * By default 1 row in 1024 is an exact copy of the reference (score 1, lag 0) and 1 in 1024 a constant row
+ * (sigma == 0 path), as SURVEY 8d prescribes; flags switch either off (a workload whose top-N is NOT a tie
+ * among copies). */
+#define MUSE_SYNTH_NO_COPIES 1u
+#define MUSE_SYNTH_NO_CONSTANTS 2u
 int muse_group_fill_synthetic(muse_group *g, int64_t first, int64_t count,
                               int64_t global_first, uint64_t seed,
-                              double *ref_out);
+                              uint32_t flags, double *ref_out);
 int muse_group_shape(muse_group *g, int64_t *M, int32_t *N);
 /* D2H copy of rows [first, first+count) (dense, N doubles per row): lets a
  * checker feed byte-identical inputs to a CPU oracle. */

@@ -19,6 +19,8 @@ int muse_ctx_set_kernel(muse_ctx *ctx, int32_t variant);
 /* Scales the error bound the filter-and-refine Run assumes for its fp32 estimates (1.0 = the derived bound): the
  * guard test shrinks it a million-fold to force the fp64 re-run. */
 int muse_test_set_screen_bound_scale(muse_ctx *ctx, double scale);
+/* The bound itself, in the pass's scaled units, for FFT length n and max |X| (host only; docs/screen_error_bound.md). */
+int muse_test_screen_bound(int32_t n, double xmax, double *Es);
 /* Runs the screening pass of the filter-and-refine Run alone (MaxLag = max_lag, TopN = 1, no other filter) over a
  * batch of series of length 257 .. 65536 and returns, per series, the fp32 estimate of the signed score, the pass's
  * flag word (bit 0 / 1: a possible argmax has |lag| <= / > max_lag; bit 2 / 3: a possible argmax value is > 0 / < 0;

@@ -147,3 +147,31 @@ def test_cpp_host_mirror_builds_and_fails_loudly_without_gpu(muse):
         pytest.skip("a GPU is present: covered by the gpu-marked test")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
     assert r.returncode == 2 and "no HIP device" in r.stdout
+
+
+def test_screen_bound_constants(muse):
+    """docs/screen_error_bound.md: the library's bound on the fp32 screening pass's error is at least the sum of the
+    per-stage constants of the standard fp32 FFT error analysis (re-derived here), for every FFT length."""
+    import ctypes as C
+    u = 2.0 ** -24
+    stage = u + 4 * math.sqrt(2) * u              # eta per radix-2 stage with rounded butterfly constants
+    prod4 = (4 * u + 3 * 2 * math.sqrt(2) * u) + 2 * math.sqrt(2) * u   # scaling by a product of <= 4 rounded entries
+    single = u + 2 * math.sqrt(2) * u             # scaling by one rounded table entry
+    for n in (512, 1024, 2048, 4096, 8192, 16384, 32768, 65536):
+        t = int(math.log2(n))
+        if n == 4096:
+            scal = prod4 + single                 # pass 1: products, pass 2: LDS table
+        elif n <= 2048:
+            scal = 2 * prod4                      # Stockham, three passes
+        elif n == 8192:
+            scal = 3 * prod4                      # Stockham, four passes
+        else:
+            scal = single + prod4 + single        # four-step twiddle + a 4096-point row
+        c_needed = (2 * (t * stage + scal) + single) / u
+        for xmax in (0.05, 1.0, 7.5):
+            Es = C.c_double(0)
+            muse.binding.check(muse.binding.load().muse_test_screen_bound(n, xmax, C.byref(Es)))
+            norm_z = 2.0 * math.sqrt(2.0 * n)     # ||z||_2 < sqrt 2 * 2 sqrt(N-1): scl * sigma in [1, 2)
+            needed = c_needed * u * norm_z * xmax + 36 * u * math.sqrt(n / (n - 1.0)) + 1e-6 * (1 if n > 0 else 0)
+            assert Es.value >= needed, (n, xmax, Es.value, needed)
+            assert Es.value <= 2.0 * needed       # ... and not wastefully above it

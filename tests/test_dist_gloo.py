@@ -1,9 +1,11 @@
 """world_size-2 gloo test (CPU) of the sharded Batch.Run path:
 each rank owns a contiguous row shard, produces its local top-N candidate
 records, one all_gather of top_n x 24-byte records, then muse_merge_records.
-On CPU the per-shard records come from the oracle (the GPU kernels are covered
-by -m gpu tests); what is exercised here is exactly the N > 1 code in
-go-muse_amd/dist.py plus the host-side merge in libmuse_hip.so."""
+On CPU each rank's DeviceBatch is replaced by a stub with the same run_shard
+signature whose records come from the oracle (the GPU kernels are covered by
+-m gpu tests, incl. run_sharded over backend nccl at world size 1); everything
+after it -- dist.run_sharded, the all_gather, the merge in libmuse_hip.so --
+is the code the ranks run on GPUs."""
 import os
 import socket
 import sys
@@ -23,18 +25,35 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _shard_records(muse, oracle_py, ref, rows, lo, hi, gid, G, args):
-    """local Results.Update/Fetch over rows [lo, hi) -> records with GLOBAL indices"""
-    lag, mv, _ = oracle_py.batch_scores(ref, rows[lo:hi])
-    g_local = None if gid is None else gid[lo:hi]
-    idx, lg, sc, _ = oracle_py.results(lag, mv, g_local, G, args["abs"], args["max_lag"], args["top_n"],
-                                       args["thr"], args["sign"])
-    rec = np.zeros(len(idx), dtype=muse.binding.RECORD_DTYPE)
-    rec["series"] = idx + lo
-    rec["lag"] = lg
-    rec["score"] = sc
-    rec["group"] = (idx + lo) if gid is None else gid[lo:hi][idx]
-    return rec
+class StubBatch:
+    """Stands in for DeviceBatch on a box without a GPU: same run_shard signature and contract (this shard's top-N
+    candidate records with GLOBAL series indices and global group ids), computed by the CPU checker.  Everything
+    downstream of it -- dist.run_sharded -> gather_records (all_gather) -> merge_records (libmuse_hip.so) -- is the
+    product code path the ranks run on GPUs."""
+
+    def __init__(self, muse, oracle_py, ref, local_rows):
+        self.muse, self.oracle_py, self.ref, self.rows = muse, oracle_py, ref, local_rows
+        self.calls = 0
+
+    def run_shard(self, group_id=None, G=0, series_offset=0, max_lag=10, top_n=20, threshold=0.0, sign_filter=0,
+                  abs_scores=True):
+        self.calls += 1
+        rec_dtype = self.muse.binding.RECORD_DTYPE
+        if len(self.rows) == 0:
+            return np.zeros(0, dtype=rec_dtype)
+        lag, mv, _ = self.oracle_py.batch_scores(self.ref, self.rows)
+        if group_id is None:
+            gl, Gl = None, 0
+        else:   # the checker wants dense local ids; the records carry the global ones
+            uniq, gl = np.unique(np.asarray(group_id), return_inverse=True)
+            gl, Gl = gl.astype(np.int32), len(uniq)
+        idx, lg, sc, _ = self.oracle_py.results(lag, mv, gl, Gl, abs_scores, max_lag, top_n, threshold, sign_filter)
+        rec = np.zeros(len(idx), dtype=rec_dtype)
+        rec["series"] = idx + series_offset
+        rec["lag"] = lg
+        rec["score"] = sc
+        rec["group"] = (idx + series_offset) if group_id is None else np.asarray(group_id)[idx]
+        return rec
 
 
 def _worker(rank, world, port, q):
@@ -52,45 +71,59 @@ def _worker(rank, world, port, q):
         rows = rng.standard_normal((M, N))
         rows[::9] += np.roll(ref, 3) * rng.uniform(0.5, 3.0, (len(rows[::9]), 1))
         rows[500] = 2.0                               # sigma == 0
+        lag, mv, _ = oracle_py.batch_scores(ref, rows)
         out = {}
-        for name, grouped in (("ungrouped", False), ("grouped", True)):
-            args = dict(abs=True, max_lag=8, top_n=12, thr=0.1, sign=0)
-            if grouped:   # label groups of 7 consecutive series; shards cut on group boundaries
-                gid = (np.arange(M) // 7).astype(np.int32)
-                G = int(gid.max()) + 1
-                lo, hi = muse.dist.shard_bounds(M, world, rank, align=14)
-            else:
-                gid, G = None, 0
+        cases = [("ungrouped", None), ("grouped by 7", (np.arange(M) // 7).astype(np.int32)),
+                 # two label groups only: with three ranks one shard is EMPTY and must still take part in the gather
+                 ("two groups", (np.arange(M) >= 400).astype(np.int32))]
+        for name, gid in cases:
+            kw = dict(max_lag=8, top_n=12, threshold=0.1, sign_filter=0, abs_scores=True)
+            if gid is None:
+                G = 0
                 lo, hi = muse.dist.shard_bounds(M, world, rank)
-            rec = _shard_records(muse, oracle_py, ref, rows, lo, hi, gid, G, args)
-            allrec = muse.dist.gather_records(rec, args["top_n"])
-            s, l, sc, mean = muse.merge_records(allrec, args["top_n"])
-            lag, mv, _ = oracle_py.batch_scores(ref, rows)
+            else:
+                G = int(gid.max()) + 1
+                lo, hi = muse.dist.shard_bounds_grouped(gid, world, rank)
+            stub = StubBatch(muse, oracle_py, ref, rows[lo:hi])
+            s, l, sc, mean = muse.dist.run_sharded(stub, lo, None if gid is None else gid[lo:hi], G, **kw)
             es, el, esc, emean = oracle_py.results(lag, mv, gid, G, True, 8, 12, 0.1, 0)
-            out[name] = (s.tolist() == es.tolist() and l.tolist() == el.tolist()
-                         and sc.tolist() == esc.tolist() and mean == emean, len(allrec), (lo, hi))
+            out[name] = (stub.calls == 1 and s.tolist() == es.tolist() and l.tolist() == el.tolist()
+                         and sc.tolist() == esc.tolist() and mean == emean, (lo, hi))
         q.put((rank, out))
     finally:
         dist.destroy_process_group()
 
 
-def test_sharded_run_world_size_2_gloo():
+def _run_world(world):
     muse = pkg()
     muse.build.build()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=180) for _ in procs]
+    res = [q.get(timeout=240) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, out in res:
-        for name, (ok, nrec, bounds) in out.items():
+    return res
+
+
+def test_sharded_run_world_size_2_gloo():
+    for rank, out in _run_world(2):
+        for name, (ok, bounds) in out.items():
             assert ok, (rank, name, bounds)
-            assert nrec <= 24
+
+
+def test_sharded_run_world_size_3_with_an_empty_shard_gloo():
+    res = _run_world(3)
+    empties = 0
+    for rank, out in res:
+        for name, (ok, bounds) in out.items():
+            assert ok, (rank, name, bounds)
+        empties += int(out["two groups"][1][0] == out["two groups"][1][1])
+    assert empties >= 1       # the case under test did occur
 
 
 def test_shard_bounds_cover_and_align():

@@ -26,6 +26,11 @@ TIE_GAP = 1e-12
 def muse():
     m = pkg()
     m.build.build()
+    # torch's bundled HIP runtime must come up before libmuse_hip.so's (the RCCL test below shares this process with the
+    # engine; the other order leaves torch without a visible GPU).  bench.py does the same: torch.cuda first.
+    import torch
+    if torch.cuda.is_available():
+        torch.cuda.init()
     return m
 
 
@@ -1186,3 +1191,211 @@ def test_screened_run_many_references(muse, eng, oracle):
         eng.set_screening(False)
         for b in bs:
             b.close()
+
+
+def test_run_sharded_over_rccl_world_size_1(muse, eng, oracle):
+    """dist.run_sharded with backend "nccl" (= RCCL) in this process as the only rank: the device-side all_gather of
+    the shard's records + merge must reproduce the unsharded Run (ungrouped and grouped), incl. a non-zero series
+    offset.  (World sizes > 1: gloo tests on CPU; the 8-GPU run is the driver's.)"""
+    import socket
+    import torch
+    import torch.distributed as dist
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        dg, ref = muse.DeviceGroup.synthetic(eng, 40000, 4096, seed=321, copies=False)   # (copies tie at 1.0: order undefined)
+        db = muse.DeviceBatch(eng, dg, ref)
+        lag, mv = db.scores()
+        gid = (np.arange(40000) // 50).astype(np.int32)
+        for g, G, off in ((None, 0, 0), (None, 0, 123456), (gid, 800, 0)):
+            got = muse.dist.run_sharded(db, off, g, G, 15, 20, 0.0, 0, True, device=torch.device("cuda", 0))
+            exp = oracle.results(lag, mv, g, G, True, 15, 20, 0.0, 0)
+            assert (got[0] - off).tolist() == exp[0].tolist() and got[1].tolist() == exp[1].tolist()
+            np.testing.assert_allclose(got[2], exp[2], rtol=1e-12, atol=0)
+            assert got[3] == exp[3]
+        db.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_costly_filters_switch_off_only_themselves(muse, eng, oracle):
+    """a screened Run that re-evaluates more than a quarter of its pairs (random walks under a small MaxLag:
+    almost nothing certainly passes) goes back to the fp64 pass for THOSE filters only; benign filters on the same
+    batch stay on the filter-and-refine path, and every Run returns the fp64 records."""
+    rng = np.random.default_rng(77)
+    N, M = 4096, 16500
+    ref = np.cumsum(rng.standard_normal(N))
+    rows = np.cumsum(rng.standard_normal((M, N)), axis=1)
+    eng.set_screening(True, min_rows=16384)
+    try:
+        db = muse.DeviceBatch(eng, muse.DeviceGroup.from_rows(eng, rows), ref)
+        lag, mv = db.scores()
+        costly = (None, 0, 2, 20, 0.0, 0, True)
+        benign = (None, 0, 4096, 20, 0.0, 0, True)
+        paths = []
+        for args in (costly, benign, costly, benign):
+            got = db.run(*args)
+            paths.append(db.last_run_path())
+            exp = oracle.results(lag, mv, None, 0, args[6], args[2], args[3], args[4], args[5])
+            assert got[0].tolist() == exp[0].tolist() and got[1].tolist() == exp[1].tolist(), args
+        assert paths[0] == 1 and db.last_run_info is not None
+        assert paths[1] == 1 and paths[3] == 1, paths          # benign filters: screened before and after
+        if paths[2] != 1:                                        # the costly Run did hand itself back ...
+            assert paths[2] == 2, paths                          # ... for being costly, nothing else
+        db.close()
+    finally:
+        eng.set_screening(False)
+
+
+def test_scores_many_after_a_screened_run_is_one_pass(muse, eng, oracle):
+    """the one-pass many-references kernel leaves exact fp64 scores in every batch, so reading them back
+    after an earlier screened Run must not re-score batch by batch (launch count of the timed pass = 1)."""
+    rng = np.random.default_rng(5150)
+    N, M, R = 4096, 16500, 3
+    rows = rng.standard_normal((M, N))
+    refs = [rng.standard_normal(N) for _ in range(R)]
+    dg = muse.DeviceGroup.from_rows(eng, rows)
+    bs = [muse.DeviceBatch(eng, dg, r) for r in refs]
+    eng.set_screening(True, min_rows=16384)
+    try:
+        for b in bs:
+            b.run(None, 0, 15, 20, 0.0, 0, True)
+            assert b.last_run_info()[0] is True
+        eng.kernel_time()
+        eng.kernel_timing(True)
+        got = muse.scores_many(bs)
+        eng.synchronize()
+        eng.kernel_timing(False)
+        ms, launches = eng.kernel_time()
+        assert launches == 1, launches
+        for r in range(R):
+            olag, omv, gap = oracle.batch_scores(refs[r], rows)
+            assert_scores_match(got[r][0], got[r][1], olag, omv, gap)
+    finally:
+        eng.set_screening(False)
+        for b in bs:
+            b.close()
+
+
+@pytest.mark.parametrize("N", [512, 1024, 2048, 3000, 4096, 8192, 16384, 65536])
+def test_screening_error_on_adversarial_inputs(muse, eng, oracle, N):
+    """docs/screen_error_bound.md section 5: inputs built to maximise the fp32 pass's error -- +-1 sequences (no
+    cancellation anywhere), chirps (flat spectra), single spikes, |mean d| just inside the 8 sigma limit (first sample
+    a far outlier), variance mantissas just below 2 with ODD exponents in both series of a pair (scl * sigma -> 2: the
+    largest ||z||_2 the scaling allows), periodic rows with many near-tie lags -- against a reference with a large
+    max|X| (a sine: one dominant bin).  Worst |estimate - exact| over every row the pass vouches for: <= E / 8."""
+    rng = np.random.default_rng(1234 + N)
+    t = np.arange(N)
+    M = 2048 if N <= 8192 else 256
+    ref = np.sin(2 * np.pi * 5 * t / N) + 0.05 * rng.standard_normal(N)
+    rows = np.empty((M, N))
+    q = M // 8
+    rows[0 * q:1 * q] = rng.choice([-1.0, 1.0], size=(q, N))
+    f0 = rng.uniform(0.0, 0.1, size=(q, 1))
+    f1 = rng.uniform(0.2, 0.5, size=(q, 1))
+    rows[1 * q:2 * q] = np.cos(2 * np.pi * (f0 * t + 0.5 * (f1 - f0) * t * t / N))
+    spikes = 1e-3 * rng.standard_normal((q, N))
+    spikes[np.arange(q), rng.integers(1, N, size=q)] += 1.0
+    rows[2 * q:3 * q] = spikes
+    out = rng.standard_normal((q, N))
+    out[:, 0] += 7.5 * np.sqrt(N)                  # |mean d| = |x[0] - mean| ~ 7.5 sigma' ... (sigma includes the outlier)
+    rows[3 * q:4 * q] = out
+    odd = rng.standard_normal((2 * q, N)) + 0.5 * np.roll(ref, 7)
+    sd = odd.std(axis=1, ddof=1, keepdims=True)
+    rows[4 * q:6 * q] = odd / sd * np.sqrt(1.998 * 2.0 ** rng.choice([-21, -3, 1, 9, 41], size=(2 * q, 1)))
+    rows[6 * q:7 * q] = np.sin(2 * np.pi * (t[None, :] + rng.integers(0, 64, size=(q, 1))) / 64.0) + 1e-3 * rng.standard_normal((q, N))
+    rows[7 * q:] = rng.standard_normal((M - 7 * q, N)) + rng.uniform(-3, 3, size=(M - 7 * q, 1)) * np.roll(ref, -11)
+    dg = muse.DeviceGroup.from_rows(eng, rows)
+    db = muse.DeviceBatch(eng, dg, ref)
+    lag, mv = db.scores()
+    olag, omv, gap = oracle.batch_scores(ref, rows, nthreads=16)
+    assert_scores_match(lag, mv, olag, omv, gap, max_ties=max(2, M // 8))   # the fp64 kernels first (periodic rows tie)
+    est, flags, E = db.screen_estimates(N)     # (MaxLag = N: no lag filter, so the pass's selection re-evaluates few rows)
+    vouched = ((flags >> 31) & 1 == 0) & ((flags & (16 | 32)) == 0)
+    assert vouched.sum() > M // 2                                            # the pass did vouch for most rows
+    err = np.abs(np.abs(est[vouched]) - np.abs(mv[vouched]))
+    worst = float(err.max() / E)
+    print("N = %d: worst |estimate - exact| / E = %.3g over %d rows (E = %.3g)" % (N, worst, int(vouched.sum()), E))
+    assert worst <= 1.0 / 8.0, (worst, E)
+    db.close()
+
+
+def test_screened_run_1m_rows_no_planted_copies(muse, eng, oracle):
+    """BASELINE's 1 M x 4096 shape WITHOUT the planted copies of the reference (muse_hip.h,
+    MUSE_SYNTH_NO_COPIES), so the top-N is a field of distinct scores instead of a thousand-way tie at 1.0 and a
+    screening bug that dropped a candidate could not hide.  The screened Run's records are checked (a) against the
+    oracle's Results over the GPU's own fp64 scores of all rows (membership, order, lags) and (b) row by row against
+    the CPU oracle's scores of the returned rows (copied back byte-identical)."""
+    M, N = 1_000_000, 4096
+    dg, ref = muse.DeviceGroup.synthetic(eng, M, N, seed=0x5EED, copies=False)
+    db = muse.DeviceBatch(eng, dg, ref)
+    lag, mv = db.scores()
+    assert np.sum(np.abs(np.abs(mv) - 1.0) < 1e-9) == 0                      # no copies indeed
+    eng.set_screening(True)
+    try:
+        rng = np.random.default_rng(3)
+        cases = [(None, 0, 15, 20, 0.0, 0, True), (None, 0, 4096, 100, 0.0, 0, True), (None, 0, 15, 20, 0.0, -1, False),
+                 (None, 0, 100, 256, 0.05, 1, False)]
+        gid = rng.integers(0, 20000, size=M).astype(np.int32)
+        cases.append((gid, 20000, 15, 20, 0.0, 0, True))
+        for args in cases:
+            got = db.run(*args)
+            assert db.last_run_path() == 1, args                             # the path under test ran
+            scr, pairs = db.last_run_info()
+            exp = oracle.results(lag, mv, args[0], args[1], args[6], args[2], args[3], args[4], args[5])
+            assert got[0].tolist() == exp[0].tolist() and got[1].tolist() == exp[1].tolist(), args
+            np.testing.assert_allclose(got[2], exp[2], rtol=1e-12, atol=0)
+            assert len(set(np.round(got[2], 12).tolist())) > len(got[2]) // 2   # distinct scores, not a tie at the top
+            if len(got[0]):
+                back = np.concatenate([dg.read(int(i), 1) for i in got[0]])
+                olag, omv, gap = oracle.batch_scores(ref, back)
+                s = np.clip(np.abs(omv), None, 1.0) if args[6] else np.clip(omv, -1.0, 1.0)
+                np.testing.assert_allclose(got[2], s, rtol=1e-9, atol=0)
+                assert np.all((got[1] == olag) | (gap < 1e-12))
+            print("no-copies Run %s: %d pairs re-evaluated (%.3f %% of the pairs, incl. the 1/1024 guard sample)"
+                  % (str(args[1:]), pairs, 100.0 * pairs / (M / 2)))
+    finally:
+        eng.set_screening(False)
+        db.close()
+
+
+def test_screened_run_soak_1m_rows(muse, eng):
+    """tools/screen_soak.py in the suite (5 trials): random filters / label groups on the 1 M synthetic rows, screened Run
+    against the all-fp64 Run of the same batch."""
+    M = 1_000_000
+    dg, ref = muse.DeviceGroup.synthetic(eng, M, 4096, seed=2027)
+    db = muse.DeviceBatch(eng, dg, ref)
+    lag, mv = db.scores()
+    rng = np.random.default_rng(11)
+    try:
+        for trial in range(5):
+            if trial % 3 == 2:
+                G = int(rng.choice([100, 20000, 300000]))
+                gid = rng.integers(0, G, size=M).astype(np.int32)
+            else:
+                gid, G = None, 0
+            max_lag = int(rng.choice([0, 5, 15, 100, 2048, 4096]))
+            top_n = int(rng.choice([1, 5, 20, 100, 256]))
+            thr = float(rng.choice([0.0, 0.1, 0.4, 0.9]))
+            sign = int(rng.choice([0, 1, -1]))
+            absf = bool(rng.random() < 0.5)
+            eng.set_screening(False)
+            exp = db.run(gid, G, max_lag, top_n, thr, sign, absf)
+            eng.set_screening(True)
+            got = db.run(gid, G, max_lag, top_n, thr, sign, absf)
+            key = (trial, G, max_lag, top_n, thr, sign, absf, db.last_run_path())
+            assert len(got[0]) == len(exp[0]), key
+            np.testing.assert_allclose(got[2], exp[2], rtol=1e-12, atol=0, err_msg=str(key))
+            rows = got[0]
+            assert np.array_equal(lag[rows], got[1]), key
+            exact = np.clip(np.abs(mv[rows]), None, 1.0) if absf else np.clip(mv[rows], -1.0, 1.0)
+            np.testing.assert_allclose(got[2], exact, rtol=1e-12, atol=0, err_msg=str(key))
+            assert len(rows) == 0 or np.all(np.abs(lag[rows]) <= max_lag), key
+    finally:
+        eng.set_screening(False)
+        db.close()

@@ -4,13 +4,13 @@
 #   2) --pmc passes (separately): FETCH_SIZE ; WRITE_SIZE ; SQ counters
 # Summaries are written under gpurun_out/prof_<tag>/ ; copy the ones to keep into profiles/.
 set -o pipefail
-TAG=${1:-r01}
+TAG=${1:-r02}
 STEPS=${2:-5}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /root/repo
 export TMPDIR=/tmp
-ARGS="bench.py --steps $STEPS --warmup 1 --no-cpu-baseline --many-refs 0"
+ARGS="bench.py --steps $STEPS --warmup 1 --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1 || { tail -5 $OUT/trace.log; exit 1; }
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $ARGS > $OUT/pmc_fetch.log 2>&1 || { tail -5 $OUT/pmc_fetch.log; exit 1; }
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $ARGS > $OUT/pmc_write.log 2>&1 || { tail -5 $OUT/pmc_write.log; exit 1; }
