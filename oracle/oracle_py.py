@@ -19,13 +19,15 @@ _i32p = ctypes.POINTER(ctypes.c_int32)
 _i64p = ctypes.POINTER(ctypes.c_int64)
 
 
+_FAST_SO = os.path.join(_HERE, "libmuse_cpu_fast.so")
+
+
 def build(force=False):
-    src = os.path.join(_HERE, "muse_oracle.c")
-    if (not force and os.path.exists(_SO)
-            and os.path.getmtime(_SO) >= os.path.getmtime(src)):
-        return _SO
-    subprocess.check_call(["make", "-C", _HERE, "-B", "libmuse_oracle.so"],
-                          stdout=subprocess.DEVNULL)
+    for so, src in ((_SO, "muse_oracle.c"), (_FAST_SO, "muse_cpu_fast.c")):
+        srcp = os.path.join(_HERE, src)
+        if not force and os.path.exists(so) and os.path.getmtime(so) >= os.path.getmtime(srcp):
+            continue
+        subprocess.check_call(["make", "-C", _HERE, "-B", os.path.basename(so)], stdout=subprocess.DEVNULL)
     return _SO
 
 
@@ -160,6 +162,44 @@ def batch_scores(ref, rows, nthreads=1, want_gap=True):
     if rc:
         raise ValueError("bad arguments")
     return lag, mv, gap
+
+
+_fast = None
+
+
+def build_fast(force=False):
+    """(Re)build libmuse_cpu_fast.so on THIS host: it is compiled -march=native, so a copy built elsewhere (the build
+    container) must not be trusted on another CPU -- bench.py forces a rebuild before timing."""
+    global _fast
+    srcp = os.path.join(_HERE, "muse_cpu_fast.c")
+    if force or not os.path.exists(_FAST_SO) or os.path.getmtime(_FAST_SO) < os.path.getmtime(srcp):
+        subprocess.check_call(["make", "-C", _HERE, "-B", os.path.basename(_FAST_SO)], stdout=subprocess.DEVNULL)
+        _fast = None
+    return _FAST_SO
+
+
+def fast_batch_scores(ref, rows, nthreads=1):
+    """The TIMED CPU baseline (muse_cpu_fast.c: same algorithm, radix-4 Stockham FFT, -O3 -march=native): per-series
+    (lag int32[M], mv f64[M]).  Built on the box it runs on (-march=native).  Not the checker."""
+    global _fast
+    if _fast is None:
+        build_fast()
+        _fast = ctypes.CDLL(_FAST_SO)
+        _fast.fast_batch_scores.argtypes = [_dp, _dp, _i64, _i64, _i64, ctypes.c_int, _i32p, _dp]
+    ref = _f64(ref)
+    rows = np.asarray(rows, dtype=np.float64)
+    assert rows.ndim == 2 and rows.strides[1] == 8
+    M, N = rows.shape
+    stride = rows.strides[0] // 8 if M > 1 else N
+    lag = np.zeros(M, dtype=np.int32)
+    mv = np.zeros(M)
+    rc = _fast.fast_batch_scores(_d(ref), rows.ctypes.data_as(_dp), M, N, stride, int(nthreads),
+                                 lag.ctypes.data_as(_i32p), _d(mv))
+    if rc == 1:
+        raise ValueError("Invalid input query, Standard deviation of zero")
+    if rc:
+        raise ValueError("bad arguments")
+    return lag, mv
 
 
 def results(lag, mv, group_id=None, G=0, abs_scores=True, max_lag=10, top_n=20,

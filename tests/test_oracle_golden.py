@@ -195,3 +195,23 @@ def test_results_heap_topn_and_order(oracle):
     idx, lg, sc, _ = oracle.results(lag, np.array([0.5, 0.5, 0.1, 0.4, 2.0, -3.0]),
                                     gid, 3, True, 10, 5, 0.0, 0)
     assert idx.tolist() == [4, 0, 3] and sc.tolist() == [1.0, 0.5, 0.4]
+
+
+def test_fast_cpu_port_matches_oracle(oracle):
+    """oracle/muse_cpu_fast.c (the TIMED cpu_baseline of bench.py: radix-4 Stockham FFT, -O3 -march=native) against the
+    checker on the same rows: scores to 1e-12 relative, lags equal outside oracle-flagged ties; sigma == 0 rows,
+    zero-padded lengths, several threads."""
+    import numpy as np
+    rng = np.random.default_rng(17)
+    for N in (8, 100, 480, 512, 1000, 4096, 5000):
+        M = 37
+        ref = rng.standard_normal(N)
+        rows = rng.standard_normal((M, N))
+        rows[::5] += rng.uniform(-3, 3, size=(len(rows[::5]), 1)) * np.roll(ref, 3)
+        rows[7] = 4.25                                  # sigma == 0 -> (0, 0.0)
+        olag, omv, gap = oracle.batch_scores(ref, rows)
+        for nt in (1, 3):
+            lag, mv = oracle.fast_batch_scores(ref, rows, nthreads=nt)
+            assert mv[7] == 0.0 and lag[7] == 0
+            np.testing.assert_allclose(mv, omv, rtol=1e-12, atol=1e-15)
+            assert np.all((lag == olag) | (gap < 1e-12)), N
