@@ -244,6 +244,36 @@ def main():
                 "kernel": "xcorr_screen_pass", "kernel_ms_avg": ks_s * 1e3,
                 "roofline_frac": bytes_per_launch / ks_s / 1e9 / HBM_PEAK_GBPS if ks_s > 0 else None,
                 "note": "opt-in (muse_ctx_set_screening): fp32 transforms screen, fp64 re-evaluates what can reach the top-N"}
+        if extras and db.n == 4096:
+            # SURVEY 8f-3, opt-in float32-STORAGE group (muse_group_create_f32): the same workload rounded to float32 in
+            # HBM, widened exactly on consumption, float64 arithmetic.  Its own denominator: 4 N + 16 bytes per series.
+            try:
+                dg32, ref32 = pkg.DeviceGroup.synthetic(eng, M, N, seed=0x6D757365, f32=True)
+                db32 = pkg.DeviceBatch(eng, dg32, ref32)
+                db32.run(None, 0, args.max_lag, args.top_n, 0.0, 0, True)
+                eng.synchronize()
+                eng.kernel_time()
+                eng.kernel_timing(True)
+                reps = max(3, min(args.steps, 10))
+                t1 = time.perf_counter()
+                for _ in range(reps):
+                    db32.run(None, 0, args.max_lag, args.top_n, 0.0, 0, True)
+                eng.synchronize()
+                dt32 = (time.perf_counter() - t1) / reps
+                eng.kernel_timing(False)
+                k32_ms, k32_cnt = eng.kernel_time()
+                k32_s = k32_ms / max(k32_cnt, 1) * 1e-3
+                b32 = float(M) * (4 * N + 16)
+                line["f32_storage_group"] = {
+                    "value": float(M) / dt32, "unit": "series-pairs/s", "ms_per_step": dt32 * 1e3, "dtype": "f64 arithmetic on f32-stored rows",
+                    "kernel_ms_avg": k32_s * 1e3, "algorithmic_bytes_per_launch": b32,
+                    "roofline_frac": b32 / k32_s / 1e9 / HBM_PEAK_GBPS if k32_s > 0 else None,
+                    "note": "opt-in muse_group_create_f32: half the HBM bytes; inputs rounded to float32 (scores are the "
+                            "reference's on the rounded rows, not within 1e-6 of the float64 inputs' in general)"}
+                db32.close()
+                dg32.close()
+            except Exception as e:            # (e.g. not enough HBM next to the float64 group)
+                line["f32_storage_group"] = {"error": str(e)}
         if extras and args.many_refs > 1 and db.n == 4096 and N == 4096:
             # R references against the same resident group in one pass over the rows
             R = args.many_refs

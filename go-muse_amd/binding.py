@@ -51,6 +51,7 @@ SIGNATURES = {
     "muse_ctx_kernel_timing": (ctypes.c_int, [_vp, _i32]),
     "muse_ctx_kernel_time": (ctypes.c_int, [_vp, _dp, _i64p]),
     "muse_group_create": (ctypes.c_int, [_vp, _i64, _i32, ctypes.POINTER(_vp)]),
+    "muse_group_create_f32": (ctypes.c_int, [_vp, _i64, _i32, ctypes.POINTER(_vp)]),
     "muse_group_append": (ctypes.c_int, [_vp, _dp, _i64, _i64]),
     "muse_group_upload": (ctypes.c_int, [_vp, _dp, _i64, _i32, _i64, ctypes.POINTER(_vp)]),
     "muse_group_fill_synthetic": (ctypes.c_int, [_vp, _i64, _i64, _i64, ctypes.c_uint64, ctypes.c_uint32, _dp]),

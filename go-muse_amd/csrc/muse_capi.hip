@@ -118,7 +118,11 @@ struct muse_ctx {
 struct muse_group {
     std::atomic<int> refs{1}; // the handle itself + one per batch built on it
     muse_ctx *ctx = nullptr;
-    double *rows = nullptr;
+    double *rows = nullptr; // float64 storage (the default: what the reference holds)
+    float *rows32 = nullptr; // float32 storage (muse_group_create_f32, opt-in): exactly one of the two is used
+    bool f32 = false;
+    size_t elem() const { return f32 ? sizeof(float) : sizeof(double); }
+    void *base() const { return f32 ? (void *)rows32 : (void *)rows; }
     int64_t cap = 0, M = 0, stride = 0; // M counts staged rows too
     int32_t N = 0;
     // Small appends (Group.Add calls muse_group_append once per Series) are packed into
@@ -424,7 +428,18 @@ extern "C" int muse_ctx_kernel_time(muse_ctx *ctx, double *total_ms, int64_t *la
 }
 
 // ------------------------------------------------------------------- group
+static int group_create(muse_ctx *ctx, int64_t capacity_rows, int32_t N, bool f32, muse_group **out);
 extern "C" int muse_group_create(muse_ctx *ctx, int64_t capacity_rows, int32_t N, muse_group **out)
+{
+    return group_create(ctx, capacity_rows, N, false, out);
+}
+extern "C" int muse_group_create_f32(muse_ctx *ctx, int64_t capacity_rows, int32_t N, muse_group **out)
+{
+    if (N <= 2048 || N > 4096) // (the float32-row loaders are built into the n = 4096 kernels)
+        return fail(MUSE_ERR_UNSUPPORTED, "float32-storage groups are built for series of length 2049 .. 4096 (got %d)", N);
+    return group_create(ctx, capacity_rows, N, true, out);
+}
+static int group_create(muse_ctx *ctx, int64_t capacity_rows, int32_t N, bool f32, muse_group **out)
 {
     if (!out)
         return fail(MUSE_ERR_INVALID, "out is NULL");
@@ -441,13 +456,16 @@ extern "C" int muse_group_create(muse_ctx *ctx, int64_t capacity_rows, int32_t N
     g->N = N;
     g->stride = N;
     g->cap = capacity_rows;
+    g->f32 = f32;
     if (capacity_rows > 0) {
-        hipError_t e = hipMalloc(&g->rows, (size_t)capacity_rows * (size_t)N * sizeof(double));
+        void *mem = nullptr;
+        hipError_t e = hipMalloc(&mem, (size_t)capacity_rows * (size_t)N * g->elem());
         if (e != hipSuccess) {
             delete g;
-            return fail(MUSE_ERR_NOMEM, "hipMalloc of %lld x %d doubles failed: %s", (long long)capacity_rows, N,
+            return fail(MUSE_ERR_NOMEM, "hipMalloc of %lld x %d samples failed: %s", (long long)capacity_rows, N,
                         hipGetErrorString(e));
         }
+        (f32 ? (void *&)g->rows32 : (void *&)g->rows) = mem;
     }
     ctx->refs.fetch_add(1);
     *out = g;
@@ -459,17 +477,17 @@ static int group_reserve(muse_group *g, int64_t rows)
     if (rows <= g->cap)
         return MUSE_OK;
     int64_t ncap = std::max<int64_t>(rows, g->cap * 2);
-    double *nr = nullptr;
-    hipError_t e = hipMalloc(&nr, (size_t)ncap * (size_t)g->N * sizeof(double));
+    void *nr = nullptr;
+    hipError_t e = hipMalloc(&nr, (size_t)ncap * (size_t)g->N * g->elem());
     if (e != hipSuccess)
         return fail(MUSE_ERR_NOMEM, "hipMalloc of %lld rows failed: %s", (long long)ncap, hipGetErrorString(e));
     if (g->M > 0) {
-        HIP_TRY(hipMemcpyAsync(nr, g->rows, (size_t)g->M * (size_t)g->N * sizeof(double), hipMemcpyDeviceToDevice,
+        HIP_TRY(hipMemcpyAsync(nr, g->base(), (size_t)g->M * (size_t)g->N * g->elem(), hipMemcpyDeviceToDevice,
                                g->ctx->stream));
         HIP_TRY(hipStreamSynchronize(g->ctx->stream));
     }
-    (void)hipFree(g->rows);
-    g->rows = nr;
+    (void)hipFree(g->base());
+    (g->f32 ? (void *&)g->rows32 : (void *&)g->rows) = nr;
     g->cap = ncap;
     return MUSE_OK;
 }
@@ -480,8 +498,8 @@ static int group_flush(muse_group *g)
     if (!g->staged)
         return MUSE_OK;
     const int64_t first = g->M - g->staged;
-    HIP_TRY(hipMemcpyAsync(g->rows + first * g->stride, g->stage[g->cur],
-                           (size_t)g->staged * (size_t)g->N * sizeof(double), hipMemcpyHostToDevice, g->ctx->stream));
+    HIP_TRY(hipMemcpyAsync((char *)g->base() + (size_t)(first * g->stride) * g->elem(), g->stage[g->cur],
+                           (size_t)g->staged * (size_t)g->N * g->elem(), hipMemcpyHostToDevice, g->ctx->stream));
     HIP_TRY(hipEventRecord(g->stage_done[g->cur], g->ctx->stream));
     g->staged = 0;
     g->cur ^= 1;
@@ -508,8 +526,10 @@ extern "C" int muse_group_append(muse_group *g, const double *rows, int64_t coun
     bool small = (size_t)count * row_bytes < STAGE_BYTES / 4 && row_bytes <= STAGE_BYTES;
     if (small && !g->stage[0] && g->small_appends++ == 0)
         small = false;
+    if (g->f32) // float32 storage: every append is narrowed on the host into the pinned staging pair (half the PCIe bytes too)
+        small = true;
     if (small && !g->stage[0]) { // borrow the staging pair from the context's pool
-        g->stage_rows = std::max<int64_t>(1, (int64_t)(STAGE_BYTES / row_bytes));
+        g->stage_rows = std::max<int64_t>(1, (int64_t)(STAGE_BYTES / ((size_t)g->N * g->elem())));
         for (int i = 0; i < 2; i++) {
             double *buf = nullptr;
             {
@@ -554,7 +574,14 @@ extern "C" int muse_group_append(muse_group *g, const double *rows, int64_t coun
             if (rc)
                 return rc;
         }
-        memcpy(g->stage[g->cur] + g->staged * g->N, rows + r * row_stride, row_bytes);
+        if (g->f32) {
+            float *dst = (float *)g->stage[g->cur] + g->staged * g->N;
+            const double *src = rows + r * row_stride;
+            for (int32_t j = 0; j < g->N; j++)
+                dst[j] = (float)src[j];
+        } else {
+            memcpy(g->stage[g->cur] + g->staged * g->N, rows + r * row_stride, row_bytes);
+        }
         g->staged++;
         g->M++;
     }
@@ -589,7 +616,10 @@ extern "C" int muse_group_fill_synthetic(muse_group *g, int64_t first, int64_t c
     rc = group_reserve(g, first + count);
     if (rc)
         return rc;
-    HIP_TRY(launch_synth(g->rows, g->stride, first, count, global_first, g->N, seed, flags, g->ctx->stream));
+    if (g->f32)
+        HIP_TRY(launch_synth_f32(g->rows32, g->stride, first, count, global_first, g->N, seed, flags, g->ctx->stream));
+    else
+        HIP_TRY(launch_synth(g->rows, g->stride, first, count, global_first, g->N, seed, flags, g->ctx->stream));
     g->M = std::max(g->M, first + count);
     if (ref_out) {
         double *d = nullptr;
@@ -630,6 +660,15 @@ extern "C" int muse_group_read(muse_group *g, int64_t first, int64_t count, doub
     if (rc)
         return rc;
     HIP_TRY(hipStreamSynchronize(g->ctx->stream));
+    if (g->f32) { // widened exactly: the checker sees the values the kernels see
+        std::vector<float> tmp((size_t)count * (size_t)g->N);
+        HIP_TRY(hipMemcpy2D(tmp.data(), (size_t)g->N * sizeof(float), g->rows32 + first * g->stride,
+                            (size_t)g->stride * sizeof(float), (size_t)g->N * sizeof(float), (size_t)count,
+                            hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < tmp.size(); i++)
+            out[i] = (double)tmp[i];
+        return MUSE_OK;
+    }
     HIP_TRY(hipMemcpy2D(out, (size_t)g->N * sizeof(double), g->rows + first * g->stride,
                         (size_t)g->stride * sizeof(double), (size_t)g->N * sizeof(double), (size_t)count,
                         hipMemcpyDeviceToHost));
@@ -642,7 +681,7 @@ static void group_release(muse_group *g)
         return;
     (void)hipSetDevice(g->ctx->device);
     (void)hipStreamSynchronize(g->ctx->stream);
-    (void)hipFree(g->rows);
+    (void)hipFree(g->base());
     for (int i = 0; i < 2; i++) {
         if (g->stage[i]) { // back to the context's pool (the stream is idle: no upload reads it any more)
             std::lock_guard<std::mutex> lock(g->ctx->stage_mu);
@@ -888,7 +927,8 @@ static FusedParams base_params(muse_batch *b)
     muse_ctx *ctx = b->ctx;
     const int64_t M = b->g->M;
     FusedParams p{};
-    p.rows = b->g->rows;
+    p.rows = b->g->f32 ? nullptr : b->g->rows;
+    p.rows32 = b->g->f32 ? b->g->rows32 : nullptr;
     p.M = M;
     p.stride = b->g->stride;
     p.npairs = (M + 1) / 2;
@@ -951,6 +991,8 @@ extern "C" int muse_batch_score(muse_batch *b)
         case 7: variant = KERNEL_R16_OCC3; break;          // rescales both series before the shared transform
         default: variant = KERNEL_GENERIC; break;
         }
+        if (b->g->f32 && variant == KERNEL_GENERIC)
+            return fail(MUSE_ERR_UNSUPPORTED, "the generic kernel does not read float32-storage groups");
         if (variant == KERNEL_R16_FOLD && b->N != 4096 && !b->c1) // (N < n needs the batch's correction table)
             variant = KERNEL_R16_OCC3;
         // a group of mixed-unit series (sigmas far apart inside most pairs) makes the default kernel hand most
@@ -1187,7 +1229,7 @@ static int32_t screen_path(const muse_batch *b, const muse_batch::RunKey &key, b
     const muse_ctx *ctx = b->ctx;
     const int64_t M = b->g->M;
     const bool length_ok = b->n >= 512 && b->n <= 65536; // every FFT length with a tuned kernel (N > n/2 by construction)
-    const bool eligible = !already_scored && ctx->screening && ctx->variant == 0 && length_ok && b->xcf && key.top_n >= 1 &&
+    const bool eligible = !already_scored && ctx->screening && ctx->variant == 0 && length_ok && b->xcf && !b->g->f32 && key.top_n >= 1 &&
                           key.top_n <= TOPN_DEVICE_MAX && M / 2 < 0x7fffffffLL &&
                           (ctx->screen_min_rows > 0 ? M >= ctx->screen_min_rows : M * (int64_t)b->n >= (int64_t)32768 * 4096);
     if (!eligible)
@@ -1457,8 +1499,8 @@ extern "C" int muse_batch_screen_estimates(muse_batch *b, int32_t max_lag, doubl
 {
     if (!b)
         return fail(MUSE_ERR_INVALID, "NULL batch");
-    if (b->n < 512 || b->n > 65536 || !b->xcf)
-        return fail(MUSE_ERR_UNSUPPORTED, "the screening pass is built for series of length 257 .. 65536");
+    if (b->n < 512 || b->n > 65536 || !b->xcf || b->g->f32)
+        return fail(MUSE_ERR_UNSUPPORTED, "the screening pass is built for float64 groups of series of length 257 .. 65536");
     muse_ctx *ctx = b->ctx;
     int rc = use_device(ctx);
     if (rc)
@@ -1716,7 +1758,7 @@ extern "C" int muse_batch_score_many(muse_batch *const *bs, int32_t R)
     muse_ctx *ctx = b0->ctx;
     // the one-pass kernel is built for N == n == 4096 (and is only taken under automatic kernel
     // selection); everything else scores the batches one after the other
-    bool one_pass = R > 1 && b0->n == 4096 && (ctx->variant == 0 || ctx->variant == 10);
+    bool one_pass = R > 1 && b0->n == 4096 && !b0->g->f32 && (ctx->variant == 0 || ctx->variant == 10);
     for (int r = 0; r < R && one_pass; r++)
         one_pass = bs[r]->N == b0->N && (b0->N == 4096 || bs[r]->c1 != nullptr);
     if (!one_pass) {

@@ -214,13 +214,37 @@ struct RawPair {
 };
 // Unconditional coalesced nontemporal loads (a conditional prefetch parks `raw`
 // in scratch; a per-element `if` serialises the loads): the caller clamps `pair`.
-template <bool PADDED>
+// F32: the group stores float32 rows (muse_group_create_f32, opt-in: half the HBM bytes); every sample is widened to
+// float64 exactly when it is consumed, the arithmetic is the float64 arithmetic of the float64 groups.
+template <bool PADDED, bool F32 = false>
 __device__ __forceinline__ void issue_row_loads(RawPair &r, const FusedParams &p, long long pair, int t, int pad)
 {
     if (MUSE_ABLATE & 2)
         pair &= 7;
     const long long rA = 2 * pair;
     const long long rB = (rA + 1 < p.M) ? rA + 1 : rA;
+    if (F32) {
+        const gptr<float> ra = scalar_ptr(p.rows32 + rA * p.stride);
+        const gptr<float> rb = scalar_ptr(p.rows32 + rB * p.stride);
+        r.ka = (double)ra[0];
+        r.kb = (double)rb[0];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            if (PADDED) {
+                int j = t + 256 * i - pad;
+                if (i < 8)
+                    j = j < 0 ? 0 : j;
+                const unsigned ju = (unsigned)j & 4095u;
+                r.a[i] = (double)__builtin_nontemporal_load(ra + ju);
+                r.b[i] = (double)__builtin_nontemporal_load(rb + ju);
+            } else { // one scalar base per four 1 KB slices (immediate offsets -2048 .. +1024 B) + the shared VGPR offset 4 t
+                const int c = (i & ~3) * 256 + 512;
+                r.a[i] = (double)__builtin_nontemporal_load(scalar_ptr_at(p.rows32 + rA * p.stride, c) + (256 * i - c) + t);
+                r.b[i] = (double)__builtin_nontemporal_load(scalar_ptr_at(p.rows32 + rB * p.stride, c) + (256 * i - c) + t);
+            }
+        }
+        return;
+    }
     const gptr<double> ra = scalar_ptr(p.rows + rA * p.stride);
     const gptr<double> rb = scalar_ptr(p.rows + rB * p.stride);
     r.ka = ra[0];

@@ -11,7 +11,8 @@ namespace muse {
 enum { KERNEL_GENERIC = 0, KERNEL_R16_OCC3 = 6, KERNEL_STOCKHAM = 10, KERNEL_R16_FOLD = 11 };
 
 struct FusedParams {
-    const double *rows; // M x N row-major, row stride `stride` doubles
+    const double *rows; // M x N row-major, row stride `stride` elements (float64 groups)
+    const float *rows32; // the same for float32-storage groups (muse_group_create_f32); exactly one of the two is set
     long long M;
     long long stride;
     long long npairs; // ceil(M/2): one workgroup pass handles two series
@@ -91,6 +92,8 @@ hipError_t launch_direct(const double *x, int lenx, const double *y, int leny, i
                          int *status, hipStream_t stream);
 hipError_t launch_synth(double *rows, long long stride, long long first, long long count, long long global_first,
                         int N, unsigned long long seed, unsigned flags, hipStream_t stream);
+hipError_t launch_synth_f32(float *rows, long long stride, long long first, long long count, long long global_first,
+                            int N, unsigned long long seed, unsigned flags, hipStream_t stream);
 hipError_t launch_synth_ref(double *ref, int N, unsigned long long seed, hipStream_t stream);
 
 // ---- group max / filter / top-N (reduce_kernels.hip)

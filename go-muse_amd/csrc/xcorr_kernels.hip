@@ -393,7 +393,8 @@ __device__ __forceinline__ double synth_value(uint64_t seed, long long grow, int
     return rect + 0.1 * gauss(seed, row, (uint64_t)t);
 }
 
-__global__ void synth_fill_kernel(double *rows, long long stride, long long first, long long count,
+template <typename T>
+__global__ void synth_fill_kernel(T *rows, long long stride, long long first, long long count,
                                   long long global_first, int N, unsigned long long seed, unsigned flags)
 {
     const long long total = count * (long long)N;
@@ -401,7 +402,7 @@ __global__ void synth_fill_kernel(double *rows, long long stride, long long firs
          e += (long long)gridDim.x * blockDim.x) {
         const long long r = e / N;
         const int t = (int)(e - r * N);
-        rows[(first + r) * stride + t] = synth_value(seed, global_first + r, t, N, flags);
+        rows[(first + r) * stride + t] = (T)synth_value(seed, global_first + r, t, N, flags);
     }
 }
 __global__ void synth_ref_kernel(double *ref, int N, unsigned long long seed)
@@ -518,7 +519,17 @@ hipError_t launch_synth(double *rows, long long stride, long long first, long lo
 {
     if (count <= 0)
         return hipSuccess;
-    hipLaunchKernelGGL(synth_fill_kernel, dim3(4096), dim3(256), 0, stream, rows, stride, first, count, global_first,
+    hipLaunchKernelGGL(synth_fill_kernel<double>, dim3(4096), dim3(256), 0, stream, rows, stride, first, count, global_first,
+                       N, seed, flags);
+    return hipGetLastError();
+}
+// the same workload rounded to float32 (float32-storage groups)
+hipError_t launch_synth_f32(float *rows, long long stride, long long first, long long count, long long global_first,
+                            int N, unsigned long long seed, unsigned flags, hipStream_t stream)
+{
+    if (count <= 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(synth_fill_kernel<float>, dim3(4096), dim3(256), 0, stream, rows, stride, first, count, global_first,
                        N, seed, flags);
     return hipGetLastError();
 }

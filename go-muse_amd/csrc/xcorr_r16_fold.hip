@@ -41,6 +41,7 @@ namespace muse {
 //   bit 6: the barrier that frees the wave's private quarter sits right behind the first workgroup-wide transpose
 //   bit 7: the second transform's last stage, the argmax and the next pair's row requests interleaved (N == n)
 //   bit 8: the argmax as one running maximum per lane, the next pair's row requests spread over it
+//   bit 9: (with bit 8) the running-maximum argmax, but the row requests stay one burst behind it
 //   bit 4: all eight factors of a pass-3 transform requested at once;  bit 5: both rows requested before the last stage (3 waves per SIMD)
 #ifndef MUSE_FOLD_OPT
 #define MUSE_FOLD_OPT 65
@@ -57,6 +58,9 @@ constexpr int XW = 544; // double2 per wave-private quarter of the 8 x 272 buffe
 // recomputed where it is used (a few 32-bit VALU instructions) instead of being hoisted out of the pair loop, where a
 // dozen such values would each hold a register for the whole kernel -- or, at 128 registers, a scratch slot that is
 // reloaded through the vector memory pipe in front of every use.
+#ifndef MUSE_FOLD_F32_EARLY
+#define MUSE_FOLD_F32_EARLY 1
+#endif
 #ifndef MUSE_FOLD_FRESH
 #define MUSE_FOLD_FRESH 0
 #endif
@@ -427,7 +431,8 @@ __device__ __forceinline__ void xc_stage1(double2 (&v)[16], double2 (&xa)[4], F 
 #ifndef MUSE_FOLD_WPS
 #define MUSE_FOLD_WPS 4
 #endif
-template <bool TIMING = false, bool PADDED = false>
+// F32: float32-storage group (half the HBM bytes; samples widened exactly on consumption, same float64 arithmetic)
+template <bool TIMING = false, bool PADDED = false, bool F32 = false>
 __global__ __launch_bounds__(OCC_THREADS, MUSE_FOLD_WPS) void xcorr_fused_n4096_fold(const FusedParams p)
 {
     using namespace occ4;
@@ -456,7 +461,7 @@ __global__ __launch_bounds__(OCC_THREADS, MUSE_FOLD_WPS) void xcorr_fused_n4096_
     int parity = 0;
     const long long total = p.npairs;
     RawPair raw;
-    issue_row_loads<PADDED>(raw, p, blockIdx.x < total ? (long long)blockIdx.x : 0ll, t, pad);
+    issue_row_loads<PADDED, F32>(raw, p, blockIdx.x < total ? (long long)blockIdx.x : 0ll, t, pad);
 
     long long nextpair = 0;
     for (long long pair = blockIdx.x; pair < total; pair = nextpair) {
@@ -654,7 +659,7 @@ __global__ __launch_bounds__(OCC_THREADS, MUSE_FOLD_WPS) void xcorr_fused_n4096_
                               if (OPT & 8)
                                   issue_row_loads_half<PADDED, 0>(raw, p, nxt, t, pad);
                               if (OPT & 32) // (168 registers: both rows)
-                                  issue_row_loads<PADDED>(raw, p, nxt, t, pad);
+                                  issue_row_loads<PADDED, F32>(raw, p, nxt, t, pad);
                           });
             if (PADDED) { // cc(d - m 1_valid) = cc(d) - m c1, m = sum d / N
                 const double mA = rec[32] * invN, mB = rec[33] * invN;
@@ -681,29 +686,47 @@ __global__ __launch_bounds__(OCC_THREADS, MUSE_FOLD_WPS) void xcorr_fused_n4096_
                     rec[1] = v[0].x;
                     rec[4] = v[0].y;
                 }
-                issue_row_firsts(raw, p, nxt);
+                constexpr bool SPREAD = !(OPT & 512); // bit 9: the requests stay one burst behind the argmax
+                if (SPREAD)
+                    issue_row_firsts(raw, p, nxt);
                 const int tr = fresh<16>(t);
                 ArgRun ra_{0.0, 0}, rb_{0.0, 0};
 #pragma unroll
                 for (int m = 0; m < 16; m++) {
                     arg_consume(ra_, v[BR16(m)].x, m);
                     arg_consume(rb_, v[BR16(m)].y, m);
-                    fence();
-                    if (PADDED)
-                        issue_row_elem_padded(raw, p, nxt, tr, m, pad);
-                    else
-                        issue_row_elem(raw, p, nxt, tr, m);
-                    fence();
+                    if (SPREAD) {
+                        fence();
+                        if (PADDED)
+                            issue_row_elem_padded(raw, p, nxt, tr, m, pad);
+                        else
+                            issue_row_elem(raw, p, nxt, tr, m);
+                        fence();
+                    }
                 }
                 wave_argmax_finish(ra_, t, lane, rec + 6 * wave);
                 wave_argmax_finish(rb_, t, lane, rec + 6 * wave + 3);
+                if (!SPREAD) {
+                    fence();
+                    issue_row_loads<PADDED, F32>(raw, p, nxt, t, pad);
+                    fence();
+                }
             } else {
+            // float32 rows take 34 registers instead of 66: room to request them BEFORE the argmax, which then runs under
+            // the HBM latency (float64 rows: behind it, there is no register left to land them in)
+            constexpr bool EARLY = F32 && (MUSE_FOLD_F32_EARLY != 0);
+            if (EARLY) {
+                fence();
+                issue_row_loads<PADDED, F32>(raw, p, nxt, t, pad);
+                fence();
+            }
             wave_argmax_store(v, wave, lane, rec + 6 * wave);
+            clk.template stamp<13>();
             fence();
             if (OPT & 8)
                 issue_row_loads_half<PADDED, 1>(raw, p, nxt, t, pad);
-            else if (!(OPT & 32))
-                issue_row_loads<PADDED>(raw, p, nxt, t, pad);
+            else if (!(OPT & 32) && !EARLY)
+                issue_row_loads<PADDED, F32>(raw, p, nxt, t, pad);
             fence();
             }
             }
@@ -1040,12 +1063,18 @@ hipError_t launch_fused_fold(const FusedParams &p, int num_cus, hipStream_t stre
     if (!p.work_counter || !p.g2 || !p.g3a || !p.g3b || !p.xcp)
         return hipErrorInvalidValue;
     const long long grid = std::min<long long>(p.npairs, (long long)num_cus * 4);
-    if (p.N < 4096) { // leading zero pad: needs the batch's correction table
-        if (!p.c1)
-            return hipErrorInvalidValue;
-        hipLaunchKernelGGL((xcorr_fused_n4096_fold<false, true>), dim3((unsigned)grid), dim3(OCC_THREADS), 0, stream, p);
+    if (p.N < 4096 && !p.c1) // leading zero pad: needs the batch's correction table
+        return hipErrorInvalidValue;
+    const dim3 g((unsigned)grid), b(OCC_THREADS);
+    if (p.rows32) {
+        if (p.N < 4096)
+            hipLaunchKernelGGL((xcorr_fused_n4096_fold<false, true, true>), g, b, 0, stream, p);
+        else
+            hipLaunchKernelGGL((xcorr_fused_n4096_fold<false, false, true>), g, b, 0, stream, p);
+    } else if (p.N < 4096) {
+        hipLaunchKernelGGL((xcorr_fused_n4096_fold<false, true>), g, b, 0, stream, p);
     } else {
-        hipLaunchKernelGGL((xcorr_fused_n4096_fold<false, false>), dim3((unsigned)grid), dim3(OCC_THREADS), 0, stream, p);
+        hipLaunchKernelGGL((xcorr_fused_n4096_fold<false, false>), g, b, 0, stream, p);
     }
     return hipGetLastError();
 }

@@ -40,7 +40,7 @@ namespace occ4 {
 // Without MULXC (the second FFT) the next pair's row loads are issued just before
 // the last butterflies: they stay in flight during pass 3 and the argmax, the only
 // stretch with no other global access and the registers to spare.
-template <int P0, bool MULXC, bool PADDED, bool TIMING>
+template <int P0, bool MULXC, bool PADDED, bool TIMING, bool F32>
 __device__ __forceinline__ void fft4096(double2 (&v)[16], double2 *xbuf, const double2 *tw2s,
                                         const double2 *__restrict__ tw1g, const double2 *__restrict__ xcg,
                                         const double2 dc, const int t, const int wave, PhaseClock<TIMING> &clk,
@@ -85,7 +85,7 @@ __device__ __forceinline__ void fft4096(double2 (&v)[16], double2 *xbuf, const d
             v[8 + j] = cmul(w[8 + j], xb[j]);
     } else {
         fence();
-        issue_row_loads<PADDED>(raw, p, next_pair, t, pad);
+        issue_row_loads<PADDED, F32>(raw, p, next_pair, t, pad);
         fence();
         dft16(v);
         double2 w[16];
@@ -138,7 +138,7 @@ __device__ __forceinline__ void finalize(const double *r, const Stat &st, double
 
 } // namespace occ4
 
-template <bool PADDED, int WPS, bool TIMING = false>
+template <bool PADDED, int WPS, bool TIMING = false, bool F32 = false>
 __global__ __launch_bounds__(OCC_THREADS, WPS) void xcorr_fused_n4096_occ4(const FusedParams p)
 {
     using namespace occ4;
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(OCC_THREADS, WPS) void xcorr_fused_n4096_occ4(const
         long long first = 0;
         if (blockIdx.x < total)
             first = p.pair_list ? p.pair_list[blockIdx.x] : (long long)blockIdx.x;
-        issue_row_loads<PADDED>(raw, p, first, t, pad);
+        issue_row_loads<PADDED, F32>(raw, p, first, t, pad);
     }
 
     for (long long it = blockIdx.x; it < total; it += gridDim.x) {
@@ -264,10 +264,10 @@ __global__ __launch_bounds__(OCC_THREADS, WPS) void xcorr_fused_n4096_occ4(const
                            // workgroup re-reads (L2-resident) -- re-reading the own pair cost 2.4 % HBM traffic
         if (it + gridDim.x < total)
             nxt = p.pair_list ? p.pair_list[it + gridDim.x] : it + gridDim.x;
-        fft4096<2, true, PADDED>(v, xbuf, tw2s, p.tw1, p.xc, dc, t, wave, clk, raw, p, nxt, pad);
+        fft4096<2, true, PADDED, TIMING, F32>(v, xbuf, tw2s, p.tw1, p.xc, dc, t, wave, clk, raw, p, nxt, pad);
         clk.template stamp<7>();
         // ---- ccA + i ccB = FFT(V)   (unscaled by 1/sigma)
-        fft4096<8, false, PADDED>(v, xbuf, tw2s, p.tw1, p.xc, dc, t, wave, clk, raw, p, nxt, pad);
+        fft4096<8, false, PADDED, TIMING, F32>(v, xbuf, tw2s, p.tw1, p.xc, dc, t, wave, clk, raw, p, nxt, pad);
 
         // ---- maxAbsIndex (xcorr.go:39-50), index = t + 256 k.  Per thread only
         // max |cc| is tracked; the wave's first index attaining the wave maximum and
@@ -353,7 +353,12 @@ hipError_t launch_fused_occ4(const FusedParams &p, int num_cus, hipStream_t stre
     if (grid > cap)
         grid = cap;
     const dim3 g((unsigned)grid), b(OCC_THREADS);
-    if (p.N < 4096)
+    if (p.rows32) {
+        if (p.N < 4096)
+            hipLaunchKernelGGL((xcorr_fused_n4096_occ4<true, 3, false, true>), g, b, 0, stream, p);
+        else
+            hipLaunchKernelGGL((xcorr_fused_n4096_occ4<false, 3, false, true>), g, b, 0, stream, p);
+    } else if (p.N < 4096)
         hipLaunchKernelGGL((xcorr_fused_n4096_occ4<true, 3>), g, b, 0, stream, p);
     else
         hipLaunchKernelGGL((xcorr_fused_n4096_occ4<false, 3>), g, b, 0, stream, p);

@@ -128,28 +128,31 @@ def next_pow2(val):
 
 
 class DeviceGroup:
-    """Device-resident M x N float64 matrix (muse_group)."""
+    """Device-resident M x N matrix (muse_group): float64 storage by default; f32=True keeps the rows as float32 in HBM
+    (muse_group_create_f32, opt-in: half the bytes per Run, samples rounded on the way in, arithmetic still float64)."""
 
-    def __init__(self, engine, N, capacity=0):
+    def __init__(self, engine, N, capacity=0, f32=False):
         self.engine = engine
         self._h = ctypes.c_void_p()
-        B.check(B.load().muse_group_create(engine._h, int(capacity), int(N), ctypes.byref(self._h)))
+        create = B.load().muse_group_create_f32 if f32 else B.load().muse_group_create
+        B.check(create(engine._h, int(capacity), int(N), ctypes.byref(self._h)))
         self.N = int(N)
+        self.f32 = bool(f32)
 
     @classmethod
-    def from_rows(cls, engine, rows):
+    def from_rows(cls, engine, rows, f32=False):
         rows = np.asarray(rows, dtype=np.float64)
         if rows.ndim != 2:
             raise ValueError("rows must be 2-D")
-        g = cls(engine, rows.shape[1], rows.shape[0])
+        g = cls(engine, rows.shape[1], rows.shape[0], f32=f32)
         g.append(rows)
         return g
 
     @classmethod
-    def synthetic(cls, engine, M, N, seed=0x6D757365, global_first=0, copies=True, constants=True):
+    def synthetic(cls, engine, M, N, seed=0x6D757365, global_first=0, copies=True, constants=True, f32=False):
         """rect+noise workload generated on the device; returns (group, ref).  copies / constants: plant the
         1-in-1024 exact copies of the reference / constant rows (muse_hip.h, MUSE_SYNTH_NO_*)."""
-        g = cls(engine, N, M)
+        g = cls(engine, N, M, f32=f32)
         ref = np.zeros(N)
         flags = (0 if copies else 1) | (0 if constants else 2)
         B.check(B.load().muse_group_fill_synthetic(g._h, 0, int(M), int(global_first),

@@ -112,6 +112,16 @@ int muse_batch_kernel_name(muse_batch *b, char *name, int32_t name_cap);
  * per group).  Never mutated by any run. */
 int muse_group_create(muse_ctx *ctx, int64_t capacity_rows, int32_t N,
                       muse_group **out);
+/* OPT-IN float32-STORAGE group: the rows are kept as float32 in HBM -- half the bytes the float64 group
+ * streams per Run -- and widened exactly to float64 as the kernels consume them; all arithmetic stays float64.
+ * muse_group_append narrows the caller's float64 samples (round to nearest) on the way in, so scores are those of
+ * the reference applied to the ROUNDED inputs, not to the caller's: they no longer match the float64 reference to
+ * 1e-6 in general (relative input perturbation 6e-8 per sample), which is why this is never the default.
+ * Built for series of length 2049 .. 4096 (FFT length 4096); MUSE_ERR_UNSUPPORTED otherwise.  Such a group works
+ * with muse_batch_create / _score(s) / _run / _run_shard / _score_many (one pass per reference); the opt-in
+ * filter-and-refine Run does not apply to it.  muse_group_read returns the stored values widened to float64. */
+int muse_group_create_f32(muse_ctx *ctx, int64_t capacity_rows, int32_t N,
+                          muse_group **out);
 /* Appends count rows read from host memory (row_stride in doubles, >= N).
  * This is what Group.Add calls once per Series (count = 1) or per slab. */
 int muse_group_append(muse_group *g, const double *rows, int64_t count,

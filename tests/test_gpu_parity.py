@@ -1399,3 +1399,71 @@ def test_screened_run_soak_1m_rows(muse, eng):
     finally:
         eng.set_screening(False)
         db.close()
+
+
+@pytest.mark.parametrize("N", [4096, 3000])
+def test_f32_storage_group_matches_oracle_on_rounded_rows(muse, eng, oracle, N):
+    """SURVEY 8f-3, opt-in float32-STORAGE group: rows are rounded to float32 on the way in and widened exactly when the
+    kernels consume them; arithmetic stays float64.  So the scores equal the oracle's on the ROUNDED rows (read back
+    byte-identical through muse_group_read) to the usual 1e-6 / exact-lag bar -- incl. sigma == 0, NaN / Inf rows,
+    pairs with sigmas far apart (hand-off kernel reading float32 rows too), an odd row count, appends in several
+    pieces -- and differ from the float64 group's scores only by the input rounding."""
+    rng = np.random.default_rng(909 + N)
+    M = 515
+    ref = rng.standard_normal(N)
+    rows = rng.standard_normal((M, N))
+    rows[::4] += rng.uniform(-3, 3, size=(len(rows[::4]), 1)) * np.roll(ref, 5)
+    rows[10, 5] = np.nan
+    rows[12, :] = np.inf
+    rows[20, :] = 3.5                       # sigma == 0
+    rows[30] *= 1e20                        # partner of row 31: sigmas 1e20 apart -> rescaling kernel
+    rows[41] *= 1e-25
+    dg = muse.DeviceGroup(eng, N, 0, f32=True)
+    dg.append(rows[:7])                     # one small piece, single rows, a slab
+    for i in range(7, 20):
+        dg.append(rows[i])
+    dg.append(rows[20:])
+    assert dg.M == M
+    back = dg.read(0, M)
+    assert np.array_equal(back, rows.astype(np.float32).astype(np.float64), equal_nan=True)
+    db = muse.DeviceBatch(eng, dg, ref)
+    lag, mv = db.scores()
+    olag, omv, gap = oracle.batch_scores(ref, back)
+    assert math.isnan(mv[10]) and math.isnan(mv[12]) and mv[20] == 0.0 and lag[20] == 0
+    assert_scores_match(lag, mv, olag, omv, gap)
+    got = db.run(None, 0, 15, 10, 0.0, 0, True)
+    exp = oracle.results(olag, omv, None, 0, True, 15, 10, 0.0, 0)
+    assert got[0].tolist() == exp[0].tolist() and got[1].tolist() == exp[1].tolist()
+    np.testing.assert_allclose(got[2], exp[2], rtol=1e-9, atol=0)
+    # against the float64 group: same lags on clear maxima, scores within the input rounding
+    d64 = muse.DeviceBatch(eng, muse.DeviceGroup.from_rows(eng, rows), ref)
+    lag64, mv64 = d64.scores()
+    ok = ~np.isnan(mv64) & (gap > 1e-3)
+    assert np.array_equal(lag[ok], lag64[ok])
+    assert np.nanmax(np.abs(mv[ok] - mv64[ok])) < 1e-5
+    with pytest.raises(muse.MuseError):
+        muse.DeviceGroup(eng, 1000, 0, f32=True)       # built for 2049 .. 4096 only
+    db.close()
+    d64.close()
+
+
+def test_f32_storage_group_synthetic_run(muse, eng, oracle):
+    """the synthetic workload in a float32-storage group: every row against the oracle on the stored values, Run, the
+    many-references entry point (one pass per reference on such a group) and the sharded Run."""
+    M, N = 4000, 4096
+    dg, ref = muse.DeviceGroup.synthetic(eng, M, N, seed=77, copies=False, f32=True)
+    db = muse.DeviceBatch(eng, dg, ref)
+    rows = dg.read(0, M)
+    lag, mv = db.scores()
+    olag, omv, gap = oracle.batch_scores(ref, rows, nthreads=8)
+    assert_scores_match(lag, mv, olag, omv, gap, max_ties=1)
+    ref2 = rows[17].copy()
+    db2 = muse.DeviceBatch(eng, dg, ref2)
+    both = muse.scores_many([db, db2])
+    o2 = oracle.batch_scores(ref2, rows, nthreads=8)
+    assert_scores_match(both[1][0], both[1][1], o2[0], o2[1], o2[2], max_ties=1)
+    rec = db.run_shard(None, 0, 1000, 15, 5, 0.0, 0, True)
+    exp = oracle.results(olag, omv, None, 0, True, 15, 5, 0.0, 0)
+    assert (rec["series"] - 1000).tolist() == exp[0].tolist()
+    db.close()
+    db2.close()

@@ -7,8 +7,11 @@
 #include <cmath>
 #include "../../go-muse_amd/csrc/xcorr_r16_fold.hip"
 using namespace muse;
+#ifndef HARNESS_F32
+#define HARNESS_F32 0
+#endif
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
-__global__ void fill(double* r, long long n) { for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll) { unsigned long long h = i * 0x9E3779B97F4A7C15ull; h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32; r[i] = (double)(h >> 11) * (1.0 / 9007199254740992.0) - 0.5; } }
+template <typename T> __global__ void fill(T* r, long long n) { for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += gridDim.x * 256ll) { unsigned long long h = i * 0x9E3779B97F4A7C15ull; h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32; r[i] = (T)((double)(h >> 11) * (1.0 / 9007199254740992.0) - 0.5); } }
 static double2 tw(long long num, long long den) { num %= den; double a = -2 * M_PI * (double)num / (double)den; return make_double2(cos(a), sin(a)); }
 static void fill_g(std::vector<double2>& g, size_t stride, size_t idx, long long u)
 {
@@ -18,15 +21,20 @@ static void fill_g(std::vector<double2>& g, size_t stride, size_t idx, long long
 template <bool T> void launch(const FusedParams& p, int grid)
 {
     CK(hipMemsetAsync(p.ovf_count, 0, 8));
-    hipLaunchKernelGGL((xcorr_fused_n4096_fold<T, false>), dim3(grid), dim3(256), 0, 0, p);
+    hipLaunchKernelGGL((xcorr_fused_n4096_fold<T, false, HARNESS_F32 != 0>), dim3(grid), dim3(256), 0, 0, p);
 }
 int main(int argc, char** argv)
 {
     long long M = argc > 1 ? atoll(argv[1]) : 1000000;
     const int reps = getenv("REPS") ? atoi(getenv("REPS")) : 9;
     FusedParams p{}; p.M = M; p.stride = 4096; p.npairs = M / 2; p.N = 4096; p.n = 4096; p.logn = 12; p.normalize_y = 1;
+#if HARNESS_F32
+    float* rows; CK(hipMalloc(&rows, M * 4096 * 4)); p.rows32 = rows;
+    hipLaunchKernelGGL(fill<float>, dim3(4096), dim3(256), 0, 0, rows, M * 4096);
+#else
     double* rows; CK(hipMalloc(&rows, M * 4096 * 8)); p.rows = rows;
-    hipLaunchKernelGGL(fill, dim3(4096), dim3(256), 0, 0, rows, M * 4096);
+    hipLaunchKernelGGL(fill<double>, dim3(4096), dim3(256), 0, 0, rows, M * 4096);
+#endif
     std::vector<double2> g2(128), g3a(2048), g3b(2048), xc(4096);
     for (int j = 0; j < 16; j++) fill_g(g2, 16, j, 16 * j);
     for (int t = 0; t < 256; t++) { fill_g(g3a, 256, t, (t >> 4) + 16 * (t & 15)); fill_g(g3b, 256, t, t); }
@@ -47,20 +55,20 @@ int main(int argc, char** argv)
     for (int r = 0; r < reps; r++) {
         CK(hipMemsetAsync(p.ovf_count, 0, 8));
         CK(hipEventRecord(e0));
-        hipLaunchKernelGGL((xcorr_fused_n4096_fold<false, false>), dim3(grid), dim3(256), 0, 0, p);
+        hipLaunchKernelGGL((xcorr_fused_n4096_fold<false, false, HARNESS_F32 != 0>), dim3(grid), dim3(256), 0, 0, p);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ts.push_back(ms);
     }
     std::sort(ts.begin(), ts.end());
-    printf("FOLD grid=%d (%d WG/CU): median %.3f ms  min %.3f ms  (%.1f%% of 8 TB/s)\n", grid, wpc, ts[ts.size() / 2], ts[0], M * 32784.0 / (ts[ts.size() / 2] * 1e-3) / 8e12 * 100);
+    printf("FOLD grid=%d (%d WG/CU): median %.3f ms  min %.3f ms  (%.1f%% of 8 TB/s on %d B per series)\n", grid, wpc, ts[ts.size() / 2], ts[0], M * (HARNESS_F32 ? 16400.0 : 32784.0) / (ts[ts.size() / 2] * 1e-3) / 8e12 * 100, HARNESS_F32 ? 16400 : 32784);
     if (getenv("NOSTAMP")) return 0;
-    const char* names[16] = {"row load wait", "shift+sumsq", "F1 pass1", "F1 xchg A (cross)+finalize", "F1 pass2 (g)", "barrier + F1 xchg B (local)", "F1 pass3 (g) + DC", "F2 pass1 + xc", "F2 xchg A (local)", "F2 pass2 (g)", "F2 xchg B (cross)", "F2 pass3 (g)", "argmax+store+row request", "", "", ""};
+    const char* names[16] = {"row load wait", "shift+sumsq", "F1 pass1", "F1 xchg A (cross)+finalize", "F1 pass2 (g)", "barrier + F1 xchg B (local)", "F1 pass3 (g) + DC", "F2 pass1 + xc", "F2 xchg A (local)", "F2 pass2 (g)", "F2 xchg B (cross)", "F2 pass3 (g)", "row request (after stamp 13)", "argmax+store", "", ""};
     unsigned long long* dbg; CK(hipMalloc(&dbg, (size_t)grid * 4 * 16 * 8)); CK(hipMemset(dbg, 0, (size_t)grid * 4 * 16 * 8)); p.dbg = dbg;
     launch<true>(p, grid); CK(hipDeviceSynchronize());
     CK(hipMemset(dbg, 0, (size_t)grid * 4 * 16 * 8));
     CK(hipMemsetAsync(p.ovf_count, 0, 8));
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL((xcorr_fused_n4096_fold<true, false>), dim3(grid), dim3(256), 0, 0, p);
+    hipLaunchKernelGGL((xcorr_fused_n4096_fold<true, false, HARNESS_F32 != 0>), dim3(grid), dim3(256), 0, 0, p);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     std::vector<unsigned long long> h((size_t)grid * 4 * 16);
@@ -69,8 +77,8 @@ int main(int argc, char** argv)
     printf("stamped build: %.3f ms, %.1f pairs per workgroup\n", ms, pairs_per_wg);
     double tot = 0; double s[16] = {0};
     for (int w = 0; w < grid * 4; w++) for (int i = 0; i < 16; i++) s[i] += (double)h[(size_t)w * 16 + i];
-    for (int i = 0; i < 13; i++) tot += s[i];
-    for (int i = 0; i < 13; i++) printf("  %-30s %9.0f ticks/pair/wave  %5.1f%%\n", names[i], s[i] / (grid * 4) / pairs_per_wg, 100.0 * s[i] / tot);
+    for (int i = 0; i < 14; i++) tot += s[i];
+    for (int i = 0; i < 14; i++) printf("  %-30s %9.0f ticks/pair/wave  %5.1f%%\n", names[i], s[i] / (grid * 4) / pairs_per_wg, 100.0 * s[i] / tot);
     printf("  total %.0f ticks/pair/wave\n", tot / (grid * 4) / pairs_per_wg);
     return 0;
 }
