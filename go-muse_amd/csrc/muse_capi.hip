@@ -81,6 +81,7 @@ struct muse_ctx {
     char name[64] = {0};
     double2 *tw1 = nullptr, *tw2 = nullptr, *twm = nullptr;
     double2 *g2 = nullptr, *g3a = nullptr, *g3b = nullptr; // folded-twiddle tables (xcorr_r16_fold.hip)
+    double2 *gsmall[3] = {nullptr, nullptr, nullptr};      // the same for n = 512, 1024, 2048 (xcorr_small.hip): [8][n/16]
     float2 *tw1f = nullptr, *tw2f = nullptr, *twmf = nullptr; // fp32 copies for the screening kernels
     // many-reference pass (muse_batch_score_many): parked spectra + device pointer tables
     // pinned staging buffers (32 MB each) lent to groups that receive many small appends; allocated once
@@ -306,6 +307,20 @@ extern "C" int muse_ctx_create(int32_t device, muse_ctx **out)
         HIP_TRY(hipMemcpy(ctx->g2, g2.data(), g2.size() * sizeof(double2), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(ctx->g3a, g3a.data(), g3a.size() * sizeof(double2), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(ctx->g3b, g3b.data(), g3b.size() * sizeof(double2), hipMemcpyHostToDevice));
+        for (int k = 0; k < 3; k++) { // n = 512 << k: delta = j / S, S = n / 16: W_(2S)^j, W_(4S)^j, W_(8S)^j, W_(8S)^(j+S), W_n^(j+qS)
+            const int S = (512 << k) / 16;
+            std::vector<double2> gs((size_t)8 * S);
+            for (int j = 0; j < S; j++) {
+                fill_twiddle(gs, (size_t)0 * S + j, j, 2 * S);
+                fill_twiddle(gs, (size_t)1 * S + j, j, 4 * S);
+                fill_twiddle(gs, (size_t)2 * S + j, j, 8 * S);
+                fill_twiddle(gs, (size_t)3 * S + j, j + S, 8 * S);
+                for (int q = 0; q < 4; q++)
+                    fill_twiddle(gs, (size_t)(4 + q) * S + j, j + q * S, 16 * S);
+            }
+            HIP_TRY(hipMalloc(&ctx->gsmall[k], gs.size() * sizeof(double2)));
+            HIP_TRY(hipMemcpy(ctx->gsmall[k], gs.data(), gs.size() * sizeof(double2), hipMemcpyHostToDevice));
+        }
     }
     std::vector<float2> t1f(t1.size()), t2f(t2.size());
     for (size_t i = 0; i < t1.size(); i++)
@@ -339,6 +354,8 @@ static void ctx_release(muse_ctx *ctx)
     (void)hipFree(ctx->g2);
     (void)hipFree(ctx->g3a);
     (void)hipFree(ctx->g3b);
+    for (int k = 0; k < 3; k++)
+        (void)hipFree(ctx->gsmall[k]);
     (void)hipFree(ctx->zscratch);
     (void)hipFree(ctx->gscratch);
     for (double *b : ctx->stage_pool)
@@ -380,8 +397,8 @@ extern "C" int muse_ctx_device_info(muse_ctx *ctx, char *name, int32_t name_cap,
 
 extern "C" int muse_ctx_set_kernel(muse_ctx *ctx, int32_t variant)
 {
-    if (!ctx || !(variant == 0 || variant == 1 || variant == 7 || variant == 10 || variant == 11))
-        return fail(MUSE_ERR_INVALID, "bad kernel variant (0 auto, 1 generic, 7 rescaling n=4096, 10 default n=4096, 11 Stockham)");
+    if (!ctx || !(variant == 0 || variant == 1 || variant == 7 || variant == 10 || variant == 11 || variant == 12))
+        return fail(MUSE_ERR_INVALID, "bad kernel variant (0 auto, 1 generic, 7 rescaling n=4096, 10 default n=4096, 11 Stockham, 12 n<=2048)");
     ctx->variant = variant;
     return MUSE_OK;
 }
@@ -428,6 +445,9 @@ extern "C" int muse_ctx_kernel_time(muse_ctx *ctx, double *total_ms, int64_t *la
 }
 
 // ------------------------------------------------------------------- group
+// Every group allocation starts with GROUP_GUARD readable (zeroed) elements in front of row 0: the kernels for zero-padded
+// series (xcorr_small.hip) read up to n - N samples in front of a row without clamping and mask them afterwards.
+constexpr size_t GROUP_GUARD = 4096;
 static int group_create(muse_ctx *ctx, int64_t capacity_rows, int32_t N, bool f32, muse_group **out);
 extern "C" int muse_group_create(muse_ctx *ctx, int64_t capacity_rows, int32_t N, muse_group **out)
 {
@@ -459,12 +479,16 @@ static int group_create(muse_ctx *ctx, int64_t capacity_rows, int32_t N, bool f3
     g->f32 = f32;
     if (capacity_rows > 0) {
         void *mem = nullptr;
-        hipError_t e = hipMalloc(&mem, (size_t)capacity_rows * (size_t)N * g->elem());
+        hipError_t e = hipMalloc(&mem, ((size_t)capacity_rows * (size_t)N + GROUP_GUARD) * g->elem());
+        if (e == hipSuccess)
+            e = hipMemset(mem, 0, GROUP_GUARD * g->elem());
         if (e != hipSuccess) {
+            (void)hipFree(mem);
             delete g;
             return fail(MUSE_ERR_NOMEM, "hipMalloc of %lld x %d samples failed: %s", (long long)capacity_rows, N,
                         hipGetErrorString(e));
         }
+        mem = (char *)mem + GROUP_GUARD * g->elem();
         (f32 ? (void *&)g->rows32 : (void *&)g->rows) = mem;
     }
     ctx->refs.fetch_add(1);
@@ -478,15 +502,21 @@ static int group_reserve(muse_group *g, int64_t rows)
         return MUSE_OK;
     int64_t ncap = std::max<int64_t>(rows, g->cap * 2);
     void *nr = nullptr;
-    hipError_t e = hipMalloc(&nr, (size_t)ncap * (size_t)g->N * g->elem());
-    if (e != hipSuccess)
+    hipError_t e = hipMalloc(&nr, ((size_t)ncap * (size_t)g->N + GROUP_GUARD) * g->elem());
+    if (e == hipSuccess)
+        e = hipMemset(nr, 0, GROUP_GUARD * g->elem());
+    if (e != hipSuccess) {
+        (void)hipFree(nr);
         return fail(MUSE_ERR_NOMEM, "hipMalloc of %lld rows failed: %s", (long long)ncap, hipGetErrorString(e));
+    }
+    nr = (char *)nr + GROUP_GUARD * g->elem();
     if (g->M > 0) {
         HIP_TRY(hipMemcpyAsync(nr, g->base(), (size_t)g->M * (size_t)g->N * g->elem(), hipMemcpyDeviceToDevice,
                                g->ctx->stream));
         HIP_TRY(hipStreamSynchronize(g->ctx->stream));
     }
-    (void)hipFree(g->base());
+    if (g->base())
+        (void)hipFree((char *)g->base() - GROUP_GUARD * g->elem());
     (g->f32 ? (void *&)g->rows32 : (void *&)g->rows) = nr;
     g->cap = ncap;
     return MUSE_OK;
@@ -681,7 +711,8 @@ static void group_release(muse_group *g)
         return;
     (void)hipSetDevice(g->ctx->device);
     (void)hipStreamSynchronize(g->ctx->stream);
-    (void)hipFree(g->base());
+    if (g->base())
+        (void)hipFree((char *)g->base() - GROUP_GUARD * g->elem());
     for (int i = 0; i < 2; i++) {
         if (g->stage[i]) { // back to the context's pool (the stream is idle: no upload reads it any more)
             std::lock_guard<std::mutex> lock(g->ctx->stage_mu);
@@ -948,6 +979,7 @@ static FusedParams base_params(muse_batch *b)
     p.g2 = ctx->g2;
     p.g3a = ctx->g3a;
     p.g3b = ctx->g3b;
+    p.gsmall = (b->logn >= 9 && b->logn <= 11) ? ctx->gsmall[b->logn - 9] : nullptr;
     p.xcp = b->xcp;
     p.c1 = b->c1;
     p.tw1f = ctx->tw1f;
@@ -1000,6 +1032,8 @@ extern "C" int muse_batch_score(muse_batch *b)
         if (variant == KERNEL_R16_FOLD && ctx->variant == 0 && b->handoff_host && b->handoff_M == M &&
             (long long)*(volatile int *)b->handoff_host * 8 > p.npairs)
             variant = KERNEL_R16_OCC3;
+    } else if (b->n >= 512 && b->n <= 2048 && (ctx->variant == 0 || ctx->variant == 12)) {
+        variant = KERNEL_SMALL; // half-round transposes at 16 waves per CU (xcorr_small.hip)
     } else if (((b->n >= 512 && b->n <= 2048) || b->n >= 8192) && (ctx->variant == 0 || ctx->variant == 11)) {
         variant = KERNEL_STOCKHAM; // radix-16 Stockham through LDS / global scratch (xcorr_stockham.hip)
     }
@@ -1407,7 +1441,7 @@ static int screen_finish(muse_batch *b, int32_t top_n, double threshold, int32_t
     r.pair_count = b->ovf_count;
     r.npairs = std::min<long long>(npairs, (long long)ctx->num_cus * 3);
     HIP_TRY(launch_screen_save(q, b->ovf_list, b->ovf_count, b->est_save, ctx->stream));
-    HIP_TRY(launch_fused(r, b->n == 4096 ? KERNEL_R16_OCC3 : KERNEL_STOCKHAM, ctx->num_cus, ctx->stream));
+    HIP_TRY(launch_fused(r, b->n == 4096 ? KERNEL_R16_OCC3 : b->n <= 2048 ? KERNEL_SMALL : KERNEL_STOCKHAM, ctx->num_cus, ctx->stream));
     // guard: the re-evaluated rows have an estimate and an fp64 score; the largest difference must respect the bound
     HIP_TRY(launch_screen_check(b->mv, M, b->ovf_list, b->ovf_count, b->est_save, b->err_dev, ctx->stream));
     *b->refine_host = 0;
@@ -1485,7 +1519,7 @@ extern "C" int muse_batch_kernel_name(muse_batch *b, char *name, int32_t cap)
     if (b->n == 4096)
         k = b->N == 4096 ? "xcorr_fused_n4096_fold<false, false>" : "xcorr_fused_n4096_fold<false, true>";
     else if (b->n >= 512 && b->n <= 2048)
-        k = "xcorr_fused_stk_lds";
+        k = "xcorr_fused_small";
     else if (b->n == 8192)
         k = "xcorr_fused_stk_lds<13>";
     else if (b->n > 8192)

@@ -8,7 +8,7 @@
 
 namespace muse {
 
-enum { KERNEL_GENERIC = 0, KERNEL_R16_OCC3 = 6, KERNEL_STOCKHAM = 10, KERNEL_R16_FOLD = 11 };
+enum { KERNEL_GENERIC = 0, KERNEL_R16_OCC3 = 6, KERNEL_STOCKHAM = 10, KERNEL_R16_FOLD = 11, KERNEL_SMALL = 12 };
 
 struct FusedParams {
     const double *rows; // M x N row-major, row stride `stride` elements (float64 groups)
@@ -28,6 +28,7 @@ struct FusedParams {
     const double2 *g2;   // [8][16]  pass 2: u = 16 j
     const double2 *g3a;  // [8][256] first transform, pass 3: u = (t >> 4) + 16 (t & 15)
     const double2 *g3b;  // [8][256] second transform, pass 3: u = t
+    const double2 *gsmall; // [8][n/16] xcorr_small.hip (n = 512, 1024, 2048): last-pass factors, delta = j / (n/16), lane-ordered
     const double *c1;    // [4096] N < n = 4096: correlation of the valid-sample indicator with the reference (xcorr_r16_fold.hip)
     // many references in one pass (xcorr_fused_n4096_multi): device arrays of R pointers
     int R;
@@ -75,6 +76,7 @@ hipError_t launch_screen_pass_stk(const FusedParams &p, int num_cus, hipStream_t
 enum : unsigned { SCR_IN = 1u, SCR_OUT = 2u, SCR_POS = 4u, SCR_NEG = 8u, SCR_REFINE = 16u, SCR_NAN = 32u };
 hipError_t launch_fused_fold(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_r16_fold.hip (n == 4096, default)
 hipError_t launch_fused_multi(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_r16_fold.hip (R references)
+hipError_t launch_fused_small(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_small.hip (n = 512, 1024, 2048: default)
 hipError_t launch_fused_stockham(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_stockham.hip (n = 512 .. 2048, 8192 .. 65536)
 // out[256 k + t] = in[256 k + (t >> 4) + 16 (t & 15)], k < 16: a 4096-entry table in the lane order of xcorr_r16_fold.hip
 hipError_t launch_lane_order(const double2 *in, double2 *out, hipStream_t stream);

@@ -452,6 +452,8 @@ hipError_t launch_fused(const FusedParams &p, int variant, int num_cus, hipStrea
         return hipSuccess;
     if (variant == KERNEL_R16_FOLD)
         return launch_fused_fold(p, num_cus, stream);
+    if (variant == KERNEL_SMALL)
+        return launch_fused_small(p, num_cus, stream);
     if (variant == KERNEL_STOCKHAM)
         return launch_fused_stockham(p, num_cus, stream);
     if (variant == KERNEL_R16_OCC3)

@@ -1,0 +1,510 @@
+// xcorr_small.hip -- fp64 kernels for the FFT lengths n = 512, 1024, 2048 (256 < N <= 2048), round 2.
+//
+// Mathematics: xCorrWithX, /root/reference/xcorr.go:160-197, two series per complex transform, radix-16 Stockham
+// passes as in xcorr_stockham.hip (n = R1 * 16 * 16, R1 = 2, 4, 8; every thread owns the 16 points x[j + i S],
+// S = n / 16; S threads per pair).  What is different from the round-1 kernels of these lengths:
+//   * Occupancy.  Round 1 kept a full padded work buffer per pair (n complex = 69.6 KB per 256-thread workgroup):
+//     two workgroups = 8 waves per CU, and every profile said the kernels were bound by that, not by arithmetic
+//     (profiles/r01_sizes_*: 24-27 % of the HBM roofline).  Here every transpose runs in TWO HALF ROUNDS through a
+//     buffer of n / 2 points (8.7 KB per wave, 34.8 KB per workgroup: four workgroups = 16 waves per CU at 128
+//     VGPRs), and in both transposes EVERY lane reads eight values per round (no idle half as in the n = 4096
+//     kernel's wave-local transposes):
+//       A (after the radix-R1 pass): writer j, output (m, r) -> position (j + m S) R1 + r; reader j reads j + i S.
+//         Round h carries the positions [8 S h, 8 S (h + 1)): the outputs m in [h Q1/2, (h+1) Q1/2) of every lane, read
+//         back as the inputs i in [8 h, 8 h + 8) of every lane.
+//       B (between the radix-16 passes, Ns = R1): writer j = g R1 + m, output r -> position g 16 R1 + r R1 + m.
+//         Round h: the lanes with g in [8 h, 8 h + 8) write all sixteen outputs; every lane reads its inputs
+//         i in [8 h, 8 h + 8).
+//   * No workgroup barrier for n <= 1024: a pair lives inside one wave (n = 512: two pairs per wave) and LDS
+//     operations of one wave execute in order.  n = 2048: a pair spans two waves, the half rounds are separated by
+//     workgroup barriers (as in xcorr_r16_fold.hip's workgroup-wide transposes).
+//   * Arithmetic: every radix-16 pass is a generalised 16-point transform with the twiddles folded into the
+//     butterflies (fold_device.h: 192 instructions and eight table entries per pass instead of 264 and four), and the
+//     second transform is the forward algorithm again (xcorr_stockham.hip, lds_transforms).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <algorithm>
+
+#include "fold_device.h"
+#include "r16_device.h"
+
+namespace muse {
+
+namespace small {
+
+using namespace occ4;
+using namespace fold;
+
+constexpr int padk(int x) { return x + (x >> 4); }
+__device__ __forceinline__ double2 ldg2u(gptr<double2> p, unsigned i)
+{
+    const d2v x = ((gptr<d2v>)p)[i];
+    return make_double2(x.x, x.y);
+}
+
+// ---- reductions over the S lanes of a pair; every lane of the pair gets the result
+template <int S>
+__device__ __forceinline__ double pair_sum(double v, double *xw, const int wave)
+{
+    if (S == 32) {
+        v += dpp_f64<0xB1>(v);
+        v += dpp_f64<0x4E>(v);
+        v += dpp_f64<0x141>(v);
+        v += dpp_f64<0x140>(v); // the lane's 16-lane row
+        return v + __shfl_xor(v, 16, 64);
+    }
+    v = wave_sum_dpp(v);
+    if (S == 128) { // two waves per pair: through the (idle) exchange buffer of the partner wave
+        lds_barrier();
+        xw[0] = v;
+        lds_barrier();
+        v += (xw + ((wave & 1) ? -544 * 2 : 544 * 2))[0]; // xw is the wave's own slice, as doubles (544 double2 per wave)
+    }
+    return v;
+}
+template <int S>
+__device__ __forceinline__ double pair_max(double v, double *xw, const int wave)
+{
+    if (S == 32) {
+        v = fmax(v, dpp_f64<0xB1>(v));
+        v = fmax(v, dpp_f64<0x4E>(v));
+        v = fmax(v, dpp_f64<0x141>(v));
+        v = fmax(v, dpp_f64<0x140>(v));
+        return fmax(v, __shfl_xor(v, 16, 64));
+    }
+    v = wave_max_dpp(v);
+    if (S == 128) {
+        lds_barrier();
+        xw[0] = v;
+        lds_barrier();
+        v = fmax(v, (xw + ((wave & 1) ? -544 * 2 : 544 * 2))[0]);
+    }
+    return v;
+}
+template <int S>
+__device__ __forceinline__ int pair_min_i(int v, double *xw, const int wave)
+{
+    if (S == 32) {
+        v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));
+        v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));
+        v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));
+        v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));
+        return min(v, __shfl_xor(v, 16, 64));
+    }
+    v = wave_min_i_dpp(v);
+    if (S == 128) {
+        lds_barrier();
+        ((int *)xw)[0] = v;
+        lds_barrier();
+        v = min(v, ((int *)(xw + ((wave & 1) ? -544 * 2 : 544 * 2)))[0]);
+    }
+    return v;
+}
+
+// plain radix-R DFTs on the registers m + s (16 / R), natural order in place (as xcorr_stockham.hip, dft_small)
+__device__ __forceinline__ void r_dft2(double2 &a, double2 &b) { bf_one(a, b); }
+__device__ __forceinline__ void r_dft4(double2 &a, double2 &b, double2 &c, double2 &d)
+{
+    bf_one(a, c); // (a + c, a - c)
+    bf_one(b, d); // (b + d, b - d)
+    bf_one(a, b); // X0 = a, X2 = b
+    bf_mi(c, d);  // X1 = c = (a-c) - i (b-d), X3 = d
+    const double2 t = b;
+    b = c;
+    c = t; // natural order: a = X0, b = X1, c = X2, d = X3
+}
+__device__ __forceinline__ void r_dft8(double2 &x0, double2 &x1, double2 &x2, double2 &x3, double2 &x4, double2 &x5,
+                                       double2 &x6, double2 &x7)
+{
+    bf_one(x0, x4);
+    bf_one(x1, x5);
+    bf_one(x2, x6);
+    bf_one(x3, x7); // x0..x3 = sums (even outputs), x4..x7 = differences (odd outputs, to be twiddled by W8^k)
+    // even half: DFT4 of (x0, x1, x2, x3) -> X0, X2, X4, X6
+    bf_one(x0, x2);
+    bf_one(x1, x3);
+    bf_one(x0, x1); // x0 = X0, x1 = X4
+    bf_mi(x2, x3);  // x2 = X2, x3 = X6
+    // odd half: DFT4 of (x4, W8 x5, -i x6, W8^3 x7) -> X1, X3, X5, X7, the twiddles folded into the butterflies
+    bf_mi(x4, x6);    // x4 = d0 - i d2, x6 = d0 + i d2
+    bf_mi(x5, x7);    // x5 = d1 - i d3, x7 = d1 + i d3       (W8 d1 + W8^3 d3 = W8 (d1 - i d3))
+    bf_w8(x4, x5);    // x4 = X1 = (d0 - i d2) + W8 (d1 - i d3),  x5 = X5
+    bf_w8_mi(x6, x7); // x6 = X3 = (d0 + i d2) + W8^3 (d1 + i d3), x7 = X7
+    // natural order
+    const double2 X0 = x0, X4 = x1, X2 = x2, X6 = x3, X1 = x4, X5 = x5, X3 = x6, X7 = x7;
+    x0 = X0; x1 = X1; x2 = X2; x3 = X3; x4 = X4; x5 = X5; x6 = X6; x7 = X7;
+}
+template <int R>
+__device__ __forceinline__ void r_dft(double2 (&v)[16])
+{
+    constexpr int Q = 16 / R;
+#pragma unroll
+    for (int m = 0; m < Q; m++) {
+        if (R == 2)
+            r_dft2(v[m], v[m + Q]);
+        else if (R == 4)
+            r_dft4(v[m], v[m + Q], v[m + 2 * Q], v[m + 3 * Q]);
+        else
+            r_dft8(v[m], v[m + Q], v[m + 2 * Q], v[m + 3 * Q], v[m + 4 * Q], v[m + 5 * Q], v[m + 6 * Q], v[m + 7 * Q]);
+    }
+}
+
+// generalised radix-16 pass with phase delta = m / NS, factors from the W_65536 half-period table (xcorr_stockham.hip, fwd16g)
+template <int NS>
+__device__ __forceinline__ double2 tw_factor(const double2 *__restrict__ twm, const int m, const int s)
+{
+    constexpr int U = 4096 / NS;
+    const int idx = s == 0 ? 8 * U * m : s == 1 ? 4 * U * m : s == 2 ? 2 * U * m : s == 3 ? 2 * U * m + 8192
+                                                                                           : U * m + 4096 * (s - 4);
+    return ldg2u(scalar_ptr(twm), (unsigned)idx); // scalar base + UNSIGNED 32-bit lane offset: no 64-bit address arithmetic
+}
+
+// generalised pass whose first four factors were requested earlier (before the transpose that precedes the pass: their L2
+// latency then runs under the transpose instead of in front of the first butterfly); the other four are requested behind
+// the second stage
+template <typename F>
+__device__ __forceinline__ void gpass_pre(double2 (&v)[16], const double2 (&ga)[4], F fetch)
+{
+    double2 gb[4];
+    gdft16_nr_s12(v, ga[0], ga[1]);
+    fence();
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+        gb[s] = fetch(4 + s);
+    fence();
+    gdft16_nr_s3(v, ga[2], ga[3]);
+    gdft16_nr_s4(v, gb[0], gb[1], gb[2], gb[3]);
+}
+
+// forward transform of the pair's n points: v[i] = x[j + i S] -> X[j + r S] at v[BR16(r)].  b: the pair's half buffer.
+// gs: the last pass's eight factors per thread, lane-ordered [8][S] (FusedParams::gsmall): coalesced 16-byte loads --
+// out of the generic W_65536 table the same factors are 64 different cache lines per wave instruction.
+template <int LOGN>
+__device__ __forceinline__ void forward(double2 (&v)[16], double2 *b, const double2 *__restrict__ twm,
+                                        const double2 *__restrict__ gs, const int j_)
+{
+    constexpr int n = 1 << LOGN, S = n / 16, R1 = n / 256, Q1 = 16 / R1, HQ = Q1 / 2;
+    int j = j_;
+    asm volatile("" : "+v"(j)); // addresses are derived here, per call (not hoisted out of the pair loop)
+    j &= S - 1;                 // (range for the compiler: 32-bit table offsets)
+    // pairs inside one wave need no hardware barrier (LDS operations of a wave execute in order), but the COMPILER must
+    // not move a lane's reads above its writes: other lanes' data arrives through them
+    const auto sync = [&]() __attribute__((always_inline)) {
+        if (S > 64) {
+            lds_barrier();
+        } else {
+            fence();
+            asm volatile("" ::: "memory");
+            fence();
+        }
+    };
+    const int rbase = j + (j >> 4);              // padpos(j + i S) = rbase + i padk(S)
+    const int w1 = j * R1 + ((j * R1) >> 4);     // padpos((j + m S) R1 + r) = w1 + r + m padk(S R1)
+    r_dft<R1>(v);                                // pass 1: output (m, r) at v[m + r Q1]
+    double2 w[16], ga[4];
+    const int m2 = j & (R1 - 1);
+#pragma unroll
+    for (int s = 0; s < 4; s++) // pass 2's first factors travel during transpose A
+        ga[s] = tw_factor<R1>(twm, m2, s);
+    fence();
+    // ---- transpose A, two half rounds
+    sync(); // (previous readers of the buffer are done)
+#pragma unroll
+    for (int m = 0; m < HQ; m++)
+#pragma unroll
+        for (int r = 0; r < R1; r++)
+            b[w1 + r + m * padk(S * R1)] = v[m + r * Q1];
+    sync();
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        w[i] = b[rbase + i * padk(S)];
+    sync();
+#pragma unroll
+    for (int m = 0; m < HQ; m++)
+#pragma unroll
+        for (int r = 0; r < R1; r++)
+            b[w1 + r + m * padk(S * R1)] = v[HQ + m + r * Q1];
+    sync();
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        w[8 + i] = b[rbase + i * padk(S)];
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+        v[i] = w[i];
+    gpass_pre(v, ga, [&](int s) __attribute__((always_inline)) { return tw_factor<R1>(twm, m2, s); }); // pass 2: Ns = R1; output r at v[BR16(r)]
+#pragma unroll
+    for (int s = 0; s < 4; s++) // pass 3's first factors travel during transpose B
+        ga[s] = ldg2u(scalar_ptr_at(gs, s * S), (unsigned)j);
+    fence();
+    // ---- transpose B: lanes with g = j / R1 < 8 write in round 0, the others in round 1; everybody reads 8 + 8
+    const int g = j / R1, mm = j & (R1 - 1);
+    const int wb = (g & 7) * padk(16 * R1) + mm; // position (g - 8 h) 16 R1 + r R1 + m, padded: + r R1 + (r R1 >> 4)
+    const bool lower = g < 8;
+    sync();
+    if (lower) {
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            b[wb + r * R1 + ((r * R1) >> 4)] = v[BR16(r)];
+    }
+    sync();
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        w[i] = b[rbase + i * padk(S)];
+    sync();
+    if (!lower) {
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            b[wb + r * R1 + ((r * R1) >> 4)] = v[BR16(r)];
+    }
+    sync();
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        w[8 + i] = b[rbase + i * padk(S)];
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+        v[i] = w[i];
+    // pass 3: Ns = S, delta = j / S; X[j + r S] at v[BR16(r)]
+    gpass_pre(v, ga, [&](int s) __attribute__((always_inline)) { return ldg2u(scalar_ptr_at(gs, s * S), (unsigned)j); });
+}
+
+} // namespace small
+
+// PADDED: N < n (leading zero pad); N == n needs no per-sample validity masks
+// Workgroup: 256 threads (n <= 1024: pairs never leave a wave, the workgroup is only a scheduling unit) or the 128 threads
+// of ONE pair (n = 2048: the barriers of the half rounds then couple the pair's two waves and nobody else).
+template <int LOGN, bool PADDED>
+__global__ __launch_bounds__((LOGN == 11 ? 128 : 256), 4) void xcorr_fused_small(const FusedParams p)
+{
+    using namespace occ4;
+    using namespace fold;
+    using namespace small;
+    constexpr int n = 1 << LOGN;
+    constexpr int S = n / 16;   // threads per pair: 32, 64, 128
+    constexpr int TPB = LOGN == 11 ? 128 : 256;
+    constexpr int G = TPB / S;  // pairs per workgroup iteration: 8, 4, 1
+    static_assert(LOGN >= 9 && LOGN <= 11, "n = 512, 1024, 2048");
+    __shared__ double2 xbuf[(TPB / 64) * 544]; // 8.7 KB per wave: half-round buffers of the pairs (8 S 17/16 double2 per pair)
+    const int t = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    // (S >= 64: a wave works on one pair -- the pair slot is wave-uniform and everything derived from it stays scalar)
+    const int g = S >= 64 ? __builtin_amdgcn_readfirstlane(t / S) : t / S, j = t % S;
+    double2 *const b = xbuf + g * (8 * S + S / 2);
+    double *const xw = (double *)(xbuf + 544 * wave); // the wave's slice, for the two-wave reductions (n = 2048)
+    const int N = PADDED ? p.N : n, pad = PADDED ? n - N : 0;
+    const double invN = 1.0 / (double)N, invNm1 = 1.0 / (double)(N - 1);
+    const double2 *__restrict__ twm = p.twm;
+    const double2 *__restrict__ gs = p.gsmall;
+    // optional indirection (filter-and-refine Run): process pair_list[0 .. *pair_count) instead of every pair
+    const long long total = p.pair_list ? (long long)*p.pair_count : p.npairs;
+    const long long ngroups = (total + G - 1) / G;
+
+    // The rows of the NEXT iteration are requested behind the per-lane argmax of the current one (the transform registers
+    // are free then) and consumed at the top of the loop: element j + i S of the padded series is sample j + i S - pad; a pad
+    // position reads up to `pad` samples IN FRONT of the row (the end of the previous row, or the guard the group
+    // allocation keeps in front of row 0: muse_capi.hip, GROUP_GUARD) and is masked -- no clamp, so every load is one
+    // base plus a compile-time offset.
+    double xa[16], xb[16], KA, KB;
+    const auto request = [&](long long it2) __attribute__((always_inline)) {
+        if (it2 >= ngroups)
+            it2 = ngroups - 1; // (nothing left: an L2-hot dummy)
+        const long long slot = it2 * G + g;
+        const long long sl = slot < total ? slot : total - 1;
+        const long long pair = p.pair_list ? p.pair_list[sl] : sl;
+        const long long rA = 2 * pair;
+        const bool hasB = rA + 1 < p.M;
+        int jr = j;
+        asm volatile("" : "+v"(jr)); // (offsets derived per request, not hoisted)
+        jr &= S - 1;                 // (the range the compiler no longer sees: keeps global offsets 32-bit, saddr + voffset loads)
+        const double *ra = p.rows + rA * p.stride, *rb = p.rows + (hasB ? rA + 1 : rA) * p.stride;
+        if (S >= 64) { // the wave works on one pair: scalar bases + the shared VGPR offset 8 j
+            KA = scalar_ptr(ra)[0];
+            KB = scalar_ptr(rb)[0];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                xa[i] = __builtin_nontemporal_load(scalar_ptr_at(ra - pad, i * S) + (unsigned)jr);
+                xb[i] = __builtin_nontemporal_load(scalar_ptr_at(rb - pad, i * S) + (unsigned)jr);
+            }
+        } else { // two pairs per wave: one 64-bit base per lane and row, immediate offsets 256 i bytes
+            KA = ra[0];
+            KB = rb[0];
+            const double *la = ra - pad + jr, *lb = rb - pad + jr;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                xa[i] = __builtin_nontemporal_load(la + i * S);
+                xb[i] = __builtin_nontemporal_load(lb + i * S);
+            }
+        }
+    };
+    if (blockIdx.x < ngroups)
+        request(blockIdx.x);
+    for (long long it = blockIdx.x; it < ngroups; it += gridDim.x) {
+        const long long slot = it * G + g;
+        const bool live = slot < total;
+        const long long sl = live ? slot : total - 1; // idle sub-groups shadow the last pair
+        const long long pair = p.pair_list ? p.pair_list[sl] : sl;
+        const long long rA = 2 * pair;
+        const bool hasB = rA + 1 < p.M;
+        // ---- d = x - K with K the first sample, shifted statistics
+        double2 v[16];
+        int js = j;
+        asm volatile("" : "+v"(js)); // (per-sample validity derived per iteration, not hoisted: 16 masks)
+        js &= S - 1;
+        double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const bool valid = !PADDED || js + i * S - pad >= 0;
+            const double da = valid ? xa[i] - KA : 0.0, db = valid ? xb[i] - KB : 0.0;
+            v[i] = make_double2(da, db);
+            q0 += da;
+            q1 = fma(da, da, q1);
+            q2 += db;
+            q3 = fma(db, db, q3);
+        }
+        q0 = pair_sum<S>(q0, xw, wave);
+        q1 = pair_sum<S>(q1, xw, wave);
+        q2 = pair_sum<S>(q2, xw, wave);
+        q3 = pair_sum<S>(q3, xw, wave);
+        const Stat stA{q0, q1}, stB{q2, q3};
+        bool zeroA, nanA, zeroB, nanB;
+        const double varA0 = variance(stA, invN, invNm1, zeroA, nanA);
+        const double varB0 = variance(stB, invN, invNm1, zeroB, nanB);
+        const bool deadA = zeroA || nanA, deadB = zeroB || nanB || !hasB;
+        // both series go into the shared transform at O(1): exact power-of-two scales close to 1/sigma
+        // (fft_device.h, pow2_inv_sigma), folded into the mean removal; the variances scale along exactly
+        const double sA = deadA ? 1.0 : pow2_inv_sigma(varA0), sB = deadB ? 1.0 : pow2_inv_sigma(varB0);
+        const double varA = varA0 * sA * sA, varB = varB0 * sB * sB;
+        const double mA = q0 * invN * sA, mB = q2 * invN * sB;
+        asm volatile("" : "+v"(js));
+        js &= S - 1;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const bool valid = !PADDED || js + i * S - pad >= 0;
+            v[i].x = valid ? fma(v[i].x, sA, -mA) : 0.0;
+            v[i].y = valid ? fma(v[i].y, sB, -mB) : 0.0;
+        }
+        if (deadA || deadB) { // uniform over the pair, rare: a sigma == 0 / NaN series (or the missing partner of an odd
+                              // last row) must contribute exact zeros to the shared complex transform
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                v[i].x = deadA ? 0.0 : v[i].x;
+                v[i].y = deadB ? 0.0 : v[i].y;
+            }
+        }
+        // ---- Z = FFT(yA + i yB);  V = Z conj(X)/n;  ccA + i ccB = FFT(V)
+        forward<LOGN>(v, b, twm, gs, j);
+        { // V = Z conj(X)/n in place, the factors in four batches of four (two in flight: 32 registers), then the
+          // registers renamed to natural order (X[j + r S] sits at v[BR16(r)])
+            int jx = j;
+            asm volatile("" : "+v"(jx)); // (the table offsets are derived here, not hoisted out of the pair loop)
+            jx &= S - 1;
+            const auto xcl = [&](int r) __attribute__((always_inline)) { return ldg2u(scalar_ptr_at(p.xc, r * S), (unsigned)jx); };
+            double2 xq[2][4];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                xq[0][k] = xcl(k);
+#pragma unroll
+            for (int bt = 0; bt < 4; bt++) {
+                fence();
+                if (bt < 3) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        xq[(bt + 1) & 1][k] = xcl(4 * (bt + 1) + k);
+                }
+                fence();
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int r = 4 * bt + k;
+                    v[BR16(r)] = cmul(v[BR16(r)], xq[bt & 1][k]);
+                }
+            }
+            double2 w[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                w[r] = v[BR16(r)];
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                v[r] = w[r];
+        }
+        forward<LOGN>(v, b, twm, gs, j); // cc[j + r S] at v[BR16(r)]
+        // ---- maxAbsIndex (xcorr.go:39-50) per series: ascending r = ascending index for this thread
+        double sa = 0.0, sb = 0.0; // signed value of the lane's first maximum of |cc|, and its register index
+        int ra_ = 0, rb_ = 0;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const double xa = v[BR16(r)].x, xb = v[BR16(r)].y;
+            const bool ga = fabs(xa) > fabs(sa), gb = fabs(xb) > fabs(sb);
+            sa = ga ? xa : sa;
+            ra_ = ga ? r : ra_;
+            sb = gb ? xb : sb;
+            rb_ = gb ? r : rb_;
+        }
+        const double ma = fabs(sa), mb = fabs(sb);
+        const int ia = j + ra_ * S, ib = j + rb_ * S;
+        const double cc0a = v[0].x, cc0b = v[0].y; // (lane 0: cc[0], reported when nothing is above 0)
+        fence();
+        request(it + gridDim.x); // the next iteration's rows: in flight during the reductions and the result write-out
+        fence();
+        const double pa = pair_max<S>(ma, xw, wave), pb = pair_max<S>(mb, xw, wave);
+        const int ca = pair_min_i<S>((ma == pa && pa > 0.0) ? ia : 0x7fffffff, xw, wave);
+        const int cb = pair_min_i<S>((mb == pb && pb > 0.0) ? ib : 0x7fffffff, xw, wave);
+        // the lane that owns the winning index writes the result (nothing above 0: lane 0 reports cc[0] at index 0)
+        if (live) {
+            const bool ownA = ca == 0x7fffffff ? j == 0 : (ia == ca && ma == pa);
+            if (ownA) {
+                double y = __builtin_amdgcn_rsq(varA);
+                y = y * fma(-0.5 * varA * y, y, 1.5);
+                y = y * fma(-0.5 * varA * y, y, 1.5);
+                double mv = (ca == 0x7fffffff ? cc0a : sa) * y;
+                const int idx = ca == 0x7fffffff ? 0 : ca;
+                int lag = idx > n / 2 ? idx - n : idx;
+                if (zeroA) { mv = 0.0; lag = 0; }               // xcorr.go:166-167
+                if (nanA) { mv = __builtin_nan(""); lag = 0; }
+                p.mv[rA] = mv;
+                p.lag[rA] = lag;
+            }
+            const bool ownB = cb == 0x7fffffff ? j == 0 : (ib == cb && mb == pb);
+            if (ownB && hasB) {
+                double y = __builtin_amdgcn_rsq(varB);
+                y = y * fma(-0.5 * varB * y, y, 1.5);
+                y = y * fma(-0.5 * varB * y, y, 1.5);
+                double mv = (cb == 0x7fffffff ? cc0b : sb) * y;
+                const int idx = cb == 0x7fffffff ? 0 : cb;
+                int lag = idx > n / 2 ? idx - n : idx;
+                if (zeroB) { mv = 0.0; lag = 0; }
+                if (nanB) { mv = __builtin_nan(""); lag = 0; }
+                p.mv[rA + 1] = mv;
+                p.lag[rA + 1] = lag;
+            }
+        }
+    }
+}
+
+template <int LOGN>
+static hipError_t launch_small_n(const FusedParams &p, int num_cus, hipStream_t stream)
+{
+    constexpr int TPB = LOGN == 11 ? 128 : 256;
+    constexpr int G = TPB / ((1 << LOGN) / 16);
+    const long long ngroups = (p.npairs + G - 1) / G;
+    const long long grid = std::min<long long>(ngroups, (long long)num_cus * (1024 / TPB) * 8);
+    if (p.N < (1 << LOGN))
+        hipLaunchKernelGGL((xcorr_fused_small<LOGN, true>), dim3((unsigned)grid), dim3(TPB), 0, stream, p);
+    else
+        hipLaunchKernelGGL((xcorr_fused_small<LOGN, false>), dim3((unsigned)grid), dim3(TPB), 0, stream, p);
+    return hipGetLastError();
+}
+
+// n = 512, 1024, 2048 (float64 rows); any N in (n/2, n]
+hipError_t launch_fused_small(const FusedParams &p, int num_cus, hipStream_t stream)
+{
+    if (!p.rows || !p.twm || !p.xc || !p.gsmall)
+        return hipErrorInvalidValue;
+    switch (p.logn) {
+    case 9: return launch_small_n<9>(p, num_cus, stream);
+    case 10: return launch_small_n<10>(p, num_cus, stream);
+    case 11: return launch_small_n<11>(p, num_cus, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+} // namespace muse

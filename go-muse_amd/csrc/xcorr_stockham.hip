@@ -36,6 +36,7 @@
 #include <stdlib.h>
 #include <algorithm>
 
+#include "fold_device.h"
 #include "r16_device.h"
 
 namespace muse {
@@ -177,74 +178,121 @@ __device__ __forceinline__ int row_min_i_dpp(int v)
 
 __device__ __forceinline__ int padpos(int pos) { return pos + (pos >> 4); }
 
-// The on-chip part shared by the LDS kernels and the four-step kernel's row stage: forward
-// transform of the n points held as v[i] = x[j + i S] by the S = n/16 threads of a pair
-// (work buffer b, padded), multiply output X[j + r S] by xcf(r), transposed transform; on
-// return v[i] = result[j + i S].  Must be called by every thread of the workgroup (barriers).
-template <int LOGN, typename XcF>
-__device__ __forceinline__ void lds_transforms(double2 (&v)[16], double2 *b, const double2 *__restrict__ twm, const int j,
-                                               XcF xcf)
+// forward radix-16 pass as a GENERALISED 16-point transform (fold_device.h): the pre-twiddles W_(16 Ns)^(s m),
+// s = 0..15, are a geometric sequence, i.e. the pass is  X[k] = sum_s x[s] W_16^(s (k + m / Ns))  with the
+// per-thread phase delta = m / Ns, and every twiddle multiplication folds into the butterflies' FMAs: 192 instructions
+// and eight table entries instead of 15 complex multiplies + a plain DFT + eleven twiddle products (264) and four.
+// Factors: w2 = W_(2Ns)^m, w4 = W_(4Ns)^m, w8 = W_(8Ns)^m, w8 W_8, w16 W_16^q = W_(16Ns)^(m + q Ns), all inside the
+// half-period W_65536 table.  Natural in, output r at v[BR16(r)].
+template <int NS>
+__device__ __forceinline__ void fwd16g(double2 (&v)[16], const double2 *__restrict__ twm, int m)
+{
+    static_assert(NS >= 2 && 32768 % NS == 0, "Ns");
+    constexpr int U = 4096 / NS; // index step of W_(16 Ns)
+    fold::gdft16_nr(v, [&](int s) __attribute__((always_inline)) {
+        const int idx = s == 0 ? 8 * U * m : s == 1 ? 4 * U * m : s == 2 ? 2 * U * m : s == 3 ? 2 * U * m + 8192
+                                                                                               : U * m + 4096 * (s - 4);
+        return twm[idx];
+    });
+}
+
+// Forward transform of the n points held as v[i] = x[j + i S] by the S = n/16 threads of a pair (work buffer b,
+// padded): radix-R1 pass, then NP - 1 generalised radix-16 passes; on return X[j + r S] sits at v[BR16(r)].
+// XC: the input is multiplied by xcf(i) first (the reference spectrum, folded in front of the first pass).
+// Must be called by every thread of the workgroup (barriers); ENTRY_SYNC: the buffer may still be read by others.
+// LDS positions: padpos(x) = x + (x >> 4).  Every access below is written as ONE per-thread base plus a compile-time
+// offset (S, S R1 and 16 Ns are multiples of 16, and r < R1 / m < Ns never carry into the next block of 16), so a pass
+// costs two address registers instead of sixteen: left to itself the compiler hoists ~100 addresses out of the pair
+// loop and the kernels spilled 33 .. 128 registers at 256 (round 1).
+constexpr int padk(int x) { return x + (x >> 4); } // for compile-time multiples of 16 (or offsets that do not carry)
+
+template <int LOGN, bool ENTRY_SYNC>
+__device__ __forceinline__ void lds_forward(double2 (&v)[16], double2 *b, const double2 *__restrict__ twm, const int j_)
 {
     constexpr int n = 1 << LOGN;
     constexpr int S = n / 16;
     constexpr int NP = (LOGN + 3) / 4;
     constexpr int R1 = n >> (4 * (NP - 1));
     constexpr int Q1 = 16 / R1;
+    int j = j_;
+    asm volatile("" : "+v"(j)); // (addresses are derived here, per call, not hoisted)
+    const int rbase = j + (j >> 4);                 // padpos(j + i S) = rbase + i padk(S)
+    const int w1base = j * R1 + ((j * R1) >> 4);    // padpos((j + m S) R1 + r) = w1base + r + m padk(S R1)
     dft_small<R1>(v); // pass 1: Ns = 1, butterflies q = j + m S on registers m + s Q1
+    if (ENTRY_SYNC)
+        __syncthreads(); // every thread is past its last read of the buffer
 #pragma unroll
     for (int m = 0; m < Q1; m++)
 #pragma unroll
         for (int r = 0; r < R1; r++)
-            b[padpos((j + m * S) * R1 + r)] = v[m + r * Q1];
+            b[w1base + r + m * padk(S * R1)] = v[m + r * Q1];
     __syncthreads();
-#pragma unroll
-    for (int pp = 2; pp <= NP; pp++) { // radix-16 passes, Ns = R1 16^(pp-2); the last has Ns = S
-        const int Ns = R1 << (4 * (pp - 2));
+    { // pass 2: Ns = R1
 #pragma unroll
         for (int i = 0; i < 16; i++)
-            v[i] = b[padpos(j + i * S)];
-        fwd16(v, twm, j % Ns, 16 * Ns);
-        if (pp < NP) {
-            __syncthreads(); // every thread has read its inputs
-            const int base = (j / Ns) * (16 * Ns) + (j % Ns);
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-                b[padpos(base + r * Ns)] = v[P16(r)];
-            __syncthreads();
-        }
+            v[i] = b[rbase + i * padk(S)];
+        fwd16g<R1>(v, twm, j % R1);
     }
-    { // output X[j + r S] at v[P16(r)]: spectrum multiply
+    if (NP >= 3) { // pass 3: Ns = 16 R1
+        constexpr int Ns = R1;
+        __syncthreads(); // every thread has read its inputs
+        const int base = (j / Ns) * (16 * Ns) + (j % Ns);
+        const int wbase = base + (base >> 4); // padpos(base + r Ns) = wbase + r Ns + (r Ns >> 4): (base & 15) + (r Ns & 15) < 16
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            b[wbase + r * Ns + ((r * Ns) >> 4)] = v[BR16(r)];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            v[i] = b[rbase + i * padk(S)];
+        fwd16g<16 * R1>(v, twm, j % (16 * R1));
+    }
+    if (NP >= 4) { // pass 4: Ns = 256 R1
+        constexpr int Ns = 16 * R1;
+        __syncthreads();
+        const int base = (j / Ns) * (16 * Ns) + (j % Ns);
+        const int wbase = base + (base >> 4);
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            b[wbase + r * padk(Ns)] = v[BR16(r)];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+            v[i] = b[rbase + i * padk(S)];
+        fwd16g<256 * R1>(v, twm, j % (256 * R1));
+    }
+}
+
+// The on-chip part shared by the LDS kernels and the four-step kernel's row stage: forward transform, multiply
+// output X[j + r S] by xcf(r), forward transform again (the unnormalised DFT applied twice to Z conj(X)/n gives the
+// correlation of the packed pair directly: xcorr_r16_fold.hip); on return v[i] = result[j + i S].  The first transform
+// leaves X[j + r S] in the thread that owns j -- exactly the layout the second one starts from, so there is no
+// reorder pass (round 1 ran the TRANSPOSED passes backwards for the same reason; post-twiddled passes cannot fold
+// their multiplications into FMAs, pre-twiddled ones can).
+template <int LOGN, typename XcF>
+__device__ __forceinline__ void lds_transforms(double2 (&v)[16], double2 *b, const double2 *__restrict__ twm, const int j,
+                                               XcF xcf)
+{
+    lds_forward<LOGN, false>(v, b, twm, j);
+    {
         double2 w[16];
 #pragma unroll
         for (int r = 0; r < 16; r++)
-            w[r] = cmul(v[P16(r)], xcf(r));
+            w[r] = cmul(v[BR16(r)], xcf(r));
 #pragma unroll
         for (int r = 0; r < 16; r++)
             v[r] = w[r];
     }
+    lds_forward<LOGN, true>(v, b, twm, j);
+    {
+        double2 w[16];
 #pragma unroll
-    for (int pp = NP; pp >= 2; pp--) {
-        const int Ns = R1 << (4 * (pp - 2));
-        trn16(v, twm, j % Ns, 16 * Ns); // pass pp^T: output s at v[P16(s)] -> position j + s S
-        __syncthreads();                // every thread is past its last read of the buffer
+        for (int r = 0; r < 16; r++)
+            w[r] = v[BR16(r)];
 #pragma unroll
-        for (int s = 0; s < 16; s++)
-            b[padpos(j + s * S)] = v[P16(s)];
-        __syncthreads();
-        if (pp > 2) { // read the positions pass pp-1 wrote
-            const int Np = R1 << (4 * (pp - 3));
-            const int base = (j / Np) * (16 * Np) + (j % Np);
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-                v[r] = b[padpos(base + r * Np)];
-        }
+        for (int r = 0; r < 16; r++)
+            v[r] = w[r];
     }
-#pragma unroll
-    for (int m = 0; m < Q1; m++)
-#pragma unroll
-        for (int r = 0; r < R1; r++)
-            v[m + r * Q1] = b[padpos((j + m * S) * R1 + r)];
-    dft_small<R1>(v); // pass 1^T
 }
 
 } // namespace stk
