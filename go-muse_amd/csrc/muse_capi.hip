@@ -75,7 +75,8 @@ extern "C" int64_t muse_next_pow2(double val)
 // ----------------------------------------------------------------- handles
 struct muse_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // every kernel of the context
+    hipStream_t copy_stream = nullptr; // host -> HBM uploads of muse_group_append: run beside a score pass
     int num_cus = 0;
     int64_t hbm = 0;
     char name[64] = {0};
@@ -135,6 +136,10 @@ struct muse_group {
     int64_t staged = 0;     // rows waiting in stage[cur]
     int64_t stage_rows = 0; // capacity of one staging buffer, in rows
     int small_appends = 0;  // the first small append goes straight to the device (Muse.Run: one upload per group)
+    // uploads run on the context's copy stream; `uploaded` is recorded behind the last one enqueued and the compute stream
+    // waits for it (hipStreamWaitEvent) before a kernel reads the rows: an append of NEW rows overlaps a running score pass
+    hipEvent_t uploaded = nullptr;
+    bool upload_pending = false;
 };
 
 // The reference spectrum and the tables derived from it: shared (reference-counted) by the batches
@@ -263,6 +268,7 @@ extern "C" int muse_ctx_create(int32_t device, muse_ctx **out)
     snprintf(ctx->name, sizeof(ctx->name), "%s (%s)", prop.name, prop.gcnArchName);
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
     std::vector<double2> t1(16 * 256), t2(16 * 16), tm(GENERIC_MAX_N / 2);
     for (int k = 0; k < 16; k++)
         for (int t = 0; t < 256; t++)
@@ -342,6 +348,10 @@ static void ctx_release(muse_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream)
         (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->copy_stream) {
+        (void)hipStreamSynchronize(ctx->copy_stream);
+        (void)hipStreamDestroy(ctx->copy_stream);
+    }
     for (auto &e : ctx->events) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
@@ -477,6 +487,10 @@ static int group_create(muse_ctx *ctx, int64_t capacity_rows, int32_t N, bool f3
     g->stride = N;
     g->cap = capacity_rows;
     g->f32 = f32;
+    if (hipEventCreateWithFlags(&g->uploaded, hipEventDisableTiming) != hipSuccess) {
+        delete g;
+        return fail(MUSE_ERR_HIP, "hipEventCreate failed");
+    }
     if (capacity_rows > 0) {
         void *mem = nullptr;
         hipError_t e = hipMalloc(&mem, ((size_t)capacity_rows * (size_t)N + GROUP_GUARD) * g->elem());
@@ -510,6 +524,8 @@ static int group_reserve(muse_group *g, int64_t rows)
         return fail(MUSE_ERR_NOMEM, "hipMalloc of %lld rows failed: %s", (long long)ncap, hipGetErrorString(e));
     }
     nr = (char *)nr + GROUP_GUARD * g->elem();
+    HIP_TRY(hipStreamSynchronize(g->ctx->copy_stream)); // uploads into the old allocation have landed
+    HIP_TRY(hipStreamSynchronize(g->ctx->stream));      // no kernel is still reading it
     if (g->M > 0) {
         HIP_TRY(hipMemcpyAsync(nr, g->base(), (size_t)g->M * (size_t)g->N * g->elem(), hipMemcpyDeviceToDevice,
                                g->ctx->stream));
@@ -529,11 +545,27 @@ static int group_flush(muse_group *g)
         return MUSE_OK;
     const int64_t first = g->M - g->staged;
     HIP_TRY(hipMemcpyAsync((char *)g->base() + (size_t)(first * g->stride) * g->elem(), g->stage[g->cur],
-                           (size_t)g->staged * (size_t)g->N * g->elem(), hipMemcpyHostToDevice, g->ctx->stream));
-    HIP_TRY(hipEventRecord(g->stage_done[g->cur], g->ctx->stream));
+                           (size_t)g->staged * (size_t)g->N * g->elem(), hipMemcpyHostToDevice, g->ctx->copy_stream));
+    HIP_TRY(hipEventRecord(g->stage_done[g->cur], g->ctx->copy_stream));
+    HIP_TRY(hipEventRecord(g->uploaded, g->ctx->copy_stream));
+    g->upload_pending = true;
     g->staged = 0;
     g->cur ^= 1;
     HIP_TRY(hipEventSynchronize(g->stage_done[g->cur])); // the other buffer's last upload has landed
+    return MUSE_OK;
+}
+
+// staged rows enqueued for upload, and the compute stream ordered behind every upload enqueued so far: call before
+// anything on the compute stream reads the rows
+static int group_ready(muse_group *g)
+{
+    int rc = group_flush(g);
+    if (rc)
+        return rc;
+    if (g->upload_pending) {
+        HIP_TRY(hipStreamWaitEvent(g->ctx->stream, g->uploaded, 0));
+        g->upload_pending = false;
+    }
     return MUSE_OK;
 }
 
@@ -573,7 +605,7 @@ extern "C" int muse_group_append(muse_group *g, const double *rows, int64_t coun
                 HIP_TRY(hipHostMalloc((void **)&buf, STAGE_BYTES, hipHostMallocDefault));
             g->stage[i] = buf;
             HIP_TRY(hipEventCreateWithFlags(&g->stage_done[i], hipEventDisableTiming));
-            HIP_TRY(hipEventRecord(g->stage_done[i], g->ctx->stream));
+            HIP_TRY(hipEventRecord(g->stage_done[i], g->ctx->copy_stream));
         }
     }
     if (!small) { // a slab: upload it directly (synchronously: the caller's memory is not retained)
@@ -583,10 +615,12 @@ extern "C" int muse_group_append(muse_group *g, const double *rows, int64_t coun
         rc = group_reserve(g, g->M + count);
         if (rc)
             return rc;
+        // (on the copy stream: the caller's memory is not retained, so the call waits for the copy -- but not for a score
+        // pass that may be running on the compute stream over the rows uploaded earlier)
         HIP_TRY(hipMemcpy2DAsync(g->rows + g->M * g->stride, (size_t)g->stride * sizeof(double), rows,
                                  (size_t)row_stride * sizeof(double), row_bytes, (size_t)count, hipMemcpyHostToDevice,
-                                 g->ctx->stream));
-        HIP_TRY(hipStreamSynchronize(g->ctx->stream));
+                                 g->ctx->copy_stream));
+        HIP_TRY(hipStreamSynchronize(g->ctx->copy_stream));
         g->M += count;
         return MUSE_OK;
     }
@@ -640,7 +674,7 @@ extern "C" int muse_group_fill_synthetic(muse_group *g, int64_t first, int64_t c
     int rc = use_device(g->ctx);
     if (rc)
         return rc;
-    rc = group_flush(g);
+    rc = group_ready(g);
     if (rc)
         return rc;
     rc = group_reserve(g, first + count);
@@ -686,9 +720,10 @@ extern "C" int muse_group_read(muse_group *g, int64_t first, int64_t count, doub
     int rc = use_device(g->ctx);
     if (rc)
         return rc;
-    rc = group_flush(g);
+    rc = group_ready(g);
     if (rc)
         return rc;
+    HIP_TRY(hipStreamSynchronize(g->ctx->copy_stream));
     HIP_TRY(hipStreamSynchronize(g->ctx->stream));
     if (g->f32) { // widened exactly: the checker sees the values the kernels see
         std::vector<float> tmp((size_t)count * (size_t)g->N);
@@ -710,7 +745,10 @@ static void group_release(muse_group *g)
     if (!g || g->refs.fetch_sub(1) != 1)
         return;
     (void)hipSetDevice(g->ctx->device);
+    (void)hipStreamSynchronize(g->ctx->copy_stream);
     (void)hipStreamSynchronize(g->ctx->stream);
+    if (g->uploaded)
+        (void)hipEventDestroy(g->uploaded);
     if (g->base())
         (void)hipFree((char *)g->base() - GROUP_GUARD * g->elem());
     for (int i = 0; i < 2; i++) {
@@ -999,7 +1037,7 @@ extern "C" int muse_batch_score(muse_batch *b)
     int rc = use_device(ctx);
     if (rc)
         return rc;
-    rc = group_flush(b->g); // rows still in the staging buffer are uploaded ahead of the kernel
+    rc = group_ready(b->g); // rows still in the staging buffer are uploaded (copy stream) ahead of the kernel
     if (rc)
         return rc;
     const int64_t M = b->g->M;
@@ -1320,7 +1358,7 @@ static int screen_prepare(muse_batch *b, int32_t top_n, const int *gid_dev, int6
     int rc = use_device(ctx);
     if (rc)
         return rc;
-    rc = group_flush(b->g);
+    rc = group_ready(b->g);
     if (rc)
         return rc;
     const int64_t M = b->g->M;
@@ -1806,7 +1844,7 @@ extern "C" int muse_batch_score_many(muse_batch *const *bs, int32_t R)
     int rc = use_device(ctx);
     if (rc)
         return rc;
-    rc = group_flush(b0->g);
+    rc = group_ready(b0->g);
     if (rc)
         return rc;
     const int64_t M = b0->g->M;

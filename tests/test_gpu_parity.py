@@ -1468,3 +1468,31 @@ def test_f32_storage_group_synthetic_run(muse, eng, oracle):
     assert (rec["series"] - 1000).tolist() == exp[0].tolist()
     db.close()
     db2.close()
+
+
+def test_append_overlaps_a_running_score_pass(muse, eng, oracle):
+    """muse_group_append uploads on the context's copy stream, so new rows can be sent while a score pass
+    over the rows uploaded earlier is still running on the compute stream; the next pass is ordered behind the uploads
+    (hipStreamWaitEvent) and sees every row.  Slab appends, per-Series appends through the staging pair, and a
+    reallocation in between."""
+    rng = np.random.default_rng(8086)
+    N = 4096
+    ref = rng.standard_normal(N)
+    first = rng.standard_normal((3000, N)) + rng.uniform(-2, 2, size=(3000, 1)) * np.roll(ref, 4)
+    more = rng.standard_normal((700, N)) + rng.uniform(-2, 2, size=(700, 1)) * np.roll(ref, -9)
+    dg = muse.DeviceGroup(eng, N, 3200)                  # (capacity below the final size: one reallocation on the way)
+    dg.append(first)
+    db = muse.DeviceBatch(eng, dg, ref)
+    db.score()                                           # asynchronous: the kernel is (or will be) running ...
+    dg.append(more[:300])                                # ... while this slab goes up on the copy stream
+    for r in more[300:340]:
+        dg.append(r)                                     # per-Series appends (staging pair)
+    db.score()                                           # second pass, again not waited for
+    dg.append(more[340:])                                # grows the allocation: waits for both streams
+    assert dg.M == 3700
+    lag, mv = db.scores()
+    rows = np.concatenate([first, more])
+    assert np.array_equal(dg.read(0, 3700), rows)
+    olag, omv, gap = oracle.batch_scores(ref, rows, nthreads=8)
+    assert_scores_match(lag, mv, olag, omv, gap)
+    db.close()
