@@ -82,7 +82,7 @@ struct muse_ctx {
     char name[64] = {0};
     double2 *tw1 = nullptr, *tw2 = nullptr, *twm = nullptr;
     double2 *g2 = nullptr, *g3a = nullptr, *g3b = nullptr; // folded-twiddle tables (xcorr_r16_fold.hip)
-    double2 *gsmall[3] = {nullptr, nullptr, nullptr};      // the same for n = 512, 1024, 2048 (xcorr_small.hip): [8][n/16]
+    double2 *gsmall[4] = {nullptr, nullptr, nullptr, nullptr}; // the same for n = 512, 1024, 2048 (xcorr_small.hip): [8][n/16]; n = 8192: [8][32] + [8][512]
     float2 *tw1f = nullptr, *tw2f = nullptr, *twmf = nullptr; // fp32 copies for the screening kernels
     // many-reference pass (muse_batch_score_many): parked spectra + device pointer tables
     // pinned staging buffers (32 MB each) lent to groups that receive many small appends; allocated once
@@ -313,16 +313,22 @@ extern "C" int muse_ctx_create(int32_t device, muse_ctx **out)
         HIP_TRY(hipMemcpy(ctx->g2, g2.data(), g2.size() * sizeof(double2), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(ctx->g3a, g3a.data(), g3a.size() * sizeof(double2), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(ctx->g3b, g3b.data(), g3b.size() * sizeof(double2), hipMemcpyHostToDevice));
-        for (int k = 0; k < 3; k++) { // n = 512 << k: delta = j / S, S = n / 16: W_(2S)^j, W_(4S)^j, W_(8S)^j, W_(8S)^(j+S), W_n^(j+qS)
-            const int S = (512 << k) / 16;
-            std::vector<double2> gs((size_t)8 * S);
-            for (int j = 0; j < S; j++) {
-                fill_twiddle(gs, (size_t)0 * S + j, j, 2 * S);
-                fill_twiddle(gs, (size_t)1 * S + j, j, 4 * S);
-                fill_twiddle(gs, (size_t)2 * S + j, j, 8 * S);
-                fill_twiddle(gs, (size_t)3 * S + j, j + S, 8 * S);
-                for (int q = 0; q < 4; q++)
-                    fill_twiddle(gs, (size_t)(4 + q) * S + j, j + q * S, 16 * S);
+        // xcorr_small.hip's passes behind the second one: phase m / L, m = j mod L, for L = 16 R1 (and L = 256 R1 = S, n = 8192):
+        // W_(2L)^m, W_(4L)^m, W_(8L)^m, W_(8L)^(m+L), W_(16L)^(m+qL), lane-ordered
+        for (int k = 0; k < 4; k++) {
+            const int n = k < 3 ? (512 << k) : 8192, S = n / 16;
+            std::vector<double2> gs;
+            for (int L = (k < 3 ? S : 32); L <= S; L *= 16) {
+                const size_t o = gs.size();
+                gs.resize(o + (size_t)8 * L);
+                for (int m = 0; m < L; m++) {
+                    fill_twiddle(gs, o + (size_t)0 * L + m, m, 2 * L);
+                    fill_twiddle(gs, o + (size_t)1 * L + m, m, 4 * L);
+                    fill_twiddle(gs, o + (size_t)2 * L + m, m, 8 * L);
+                    fill_twiddle(gs, o + (size_t)3 * L + m, m + L, 8 * L);
+                    for (int q = 0; q < 4; q++)
+                        fill_twiddle(gs, o + (size_t)(4 + q) * L + m, m + q * L, 16 * L);
+                }
             }
             HIP_TRY(hipMalloc(&ctx->gsmall[k], gs.size() * sizeof(double2)));
             HIP_TRY(hipMemcpy(ctx->gsmall[k], gs.data(), gs.size() * sizeof(double2), hipMemcpyHostToDevice));
@@ -364,7 +370,7 @@ static void ctx_release(muse_ctx *ctx)
     (void)hipFree(ctx->g2);
     (void)hipFree(ctx->g3a);
     (void)hipFree(ctx->g3b);
-    for (int k = 0; k < 3; k++)
+    for (int k = 0; k < 4; k++)
         (void)hipFree(ctx->gsmall[k]);
     (void)hipFree(ctx->zscratch);
     (void)hipFree(ctx->gscratch);
@@ -1017,7 +1023,7 @@ static FusedParams base_params(muse_batch *b)
     p.g2 = ctx->g2;
     p.g3a = ctx->g3a;
     p.g3b = ctx->g3b;
-    p.gsmall = (b->logn >= 9 && b->logn <= 11) ? ctx->gsmall[b->logn - 9] : nullptr;
+    p.gsmall = (b->logn >= 9 && b->logn <= 11) ? ctx->gsmall[b->logn - 9] : b->logn == 13 ? ctx->gsmall[3] : nullptr;
     p.xcp = b->xcp;
     p.c1 = b->c1;
     p.tw1f = ctx->tw1f;
@@ -1070,7 +1076,7 @@ extern "C" int muse_batch_score(muse_batch *b)
         if (variant == KERNEL_R16_FOLD && ctx->variant == 0 && b->handoff_host && b->handoff_M == M &&
             (long long)*(volatile int *)b->handoff_host * 8 > p.npairs)
             variant = KERNEL_R16_OCC3;
-    } else if (b->n >= 512 && b->n <= 2048 && (ctx->variant == 0 || ctx->variant == 12)) {
+    } else if (((b->n >= 512 && b->n <= 2048) || b->n == 8192) && (ctx->variant == 0 || ctx->variant == 12)) {
         variant = KERNEL_SMALL; // half-round transposes at 16 waves per CU (xcorr_small.hip)
     } else if (((b->n >= 512 && b->n <= 2048) || b->n >= 8192) && (ctx->variant == 0 || ctx->variant == 11)) {
         variant = KERNEL_STOCKHAM; // radix-16 Stockham through LDS / global scratch (xcorr_stockham.hip)
@@ -1479,7 +1485,7 @@ static int screen_finish(muse_batch *b, int32_t top_n, double threshold, int32_t
     r.pair_count = b->ovf_count;
     r.npairs = std::min<long long>(npairs, (long long)ctx->num_cus * 3);
     HIP_TRY(launch_screen_save(q, b->ovf_list, b->ovf_count, b->est_save, ctx->stream));
-    HIP_TRY(launch_fused(r, b->n == 4096 ? KERNEL_R16_OCC3 : b->n <= 2048 ? KERNEL_SMALL : KERNEL_STOCKHAM, ctx->num_cus, ctx->stream));
+    HIP_TRY(launch_fused(r, b->n == 4096 ? KERNEL_R16_OCC3 : (b->n <= 2048 || b->n == 8192) ? KERNEL_SMALL : KERNEL_STOCKHAM, ctx->num_cus, ctx->stream));
     // guard: the re-evaluated rows have an estimate and an fp64 score; the largest difference must respect the bound
     HIP_TRY(launch_screen_check(b->mv, M, b->ovf_list, b->ovf_count, b->est_save, b->err_dev, ctx->stream));
     *b->refine_host = 0;
@@ -1556,10 +1562,8 @@ extern "C" int muse_batch_kernel_name(muse_batch *b, char *name, int32_t cap)
     const char *k = "xcorr_fused_generic";
     if (b->n == 4096)
         k = b->N == 4096 ? "xcorr_fused_n4096_fold<false, false>" : "xcorr_fused_n4096_fold<false, true>";
-    else if (b->n >= 512 && b->n <= 2048)
+    else if ((b->n >= 512 && b->n <= 2048) || b->n == 8192)
         k = "xcorr_fused_small";
-    else if (b->n == 8192)
-        k = "xcorr_fused_stk_lds<13>";
     else if (b->n > 8192)
         k = "xcorr_fused_stk_4step";
     snprintf(name, (size_t)cap, "%s", k);

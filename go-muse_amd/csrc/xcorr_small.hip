@@ -43,9 +43,10 @@ __device__ __forceinline__ double2 ldg2u(gptr<double2> p, unsigned i)
     return make_double2(x.x, x.y);
 }
 
-// ---- reductions over the S lanes of a pair; every lane of the pair gets the result
+// ---- reductions over the S lanes of a pair; every lane of the pair gets the result.  S > 64 (one pair per workgroup,
+// S / 64 waves): through `red`, S / 64 doubles of LDS, two workgroup barriers.
 template <int S>
-__device__ __forceinline__ double pair_sum(double v, double *xw, const int wave)
+__device__ __forceinline__ double pair_sum(double v, double *red, const int wave)
 {
     if (S == 32) {
         v += dpp_f64<0xB1>(v);
@@ -55,16 +56,19 @@ __device__ __forceinline__ double pair_sum(double v, double *xw, const int wave)
         return v + __shfl_xor(v, 16, 64);
     }
     v = wave_sum_dpp(v);
-    if (S == 128) { // two waves per pair: through the (idle) exchange buffer of the partner wave
+    if (S > 64) {
         lds_barrier();
-        xw[0] = v;
+        red[wave] = v;
         lds_barrier();
-        v += (xw + ((wave & 1) ? -544 * 2 : 544 * 2))[0]; // xw is the wave's own slice, as doubles (544 double2 per wave)
+        v = red[0];
+#pragma unroll
+        for (int w = 1; w < S / 64; w++)
+            v += red[w];
     }
     return v;
 }
 template <int S>
-__device__ __forceinline__ double pair_max(double v, double *xw, const int wave)
+__device__ __forceinline__ double pair_max(double v, double *red, const int wave)
 {
     if (S == 32) {
         v = fmax(v, dpp_f64<0xB1>(v));
@@ -74,16 +78,19 @@ __device__ __forceinline__ double pair_max(double v, double *xw, const int wave)
         return fmax(v, __shfl_xor(v, 16, 64));
     }
     v = wave_max_dpp(v);
-    if (S == 128) {
+    if (S > 64) {
         lds_barrier();
-        xw[0] = v;
+        red[wave] = v;
         lds_barrier();
-        v = fmax(v, (xw + ((wave & 1) ? -544 * 2 : 544 * 2))[0]);
+        v = red[0];
+#pragma unroll
+        for (int w = 1; w < S / 64; w++)
+            v = fmax(v, red[w]);
     }
     return v;
 }
 template <int S>
-__device__ __forceinline__ int pair_min_i(int v, double *xw, const int wave)
+__device__ __forceinline__ int pair_min_i(int v, double *red, const int wave)
 {
     if (S == 32) {
         v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));
@@ -93,11 +100,15 @@ __device__ __forceinline__ int pair_min_i(int v, double *xw, const int wave)
         return min(v, __shfl_xor(v, 16, 64));
     }
     v = wave_min_i_dpp(v);
-    if (S == 128) {
+    if (S > 64) {
+        int *ri = (int *)red;
         lds_barrier();
-        ((int *)xw)[0] = v;
+        ri[wave] = v;
         lds_barrier();
-        v = min(v, ((int *)(xw + ((wave & 1) ? -544 * 2 : 544 * 2)))[0]);
+        v = ri[0];
+#pragma unroll
+        for (int w = 1; w < S / 64; w++)
+            v = min(v, ri[w]);
     }
     return v;
 }
@@ -180,11 +191,60 @@ __device__ __forceinline__ void gpass_pre(double2 (&v)[16], const double2 (&ga)[
 // forward transform of the pair's n points: v[i] = x[j + i S] -> X[j + r S] at v[BR16(r)].  b: the pair's half buffer.
 // gs: the last pass's eight factors per thread, lane-ordered [8][S] (FusedParams::gsmall): coalesced 16-byte loads --
 // out of the generic W_65536 table the same factors are 64 different cache lines per wave instruction.
+// One more level: transpose B (Ns -> 16 Ns) in two half rounds, then the generalised pass with phase (j mod 16 Ns) / (16 Ns)
+// whose factors come lane-ordered from `tab` ([8][16 Ns], index j mod 16 Ns).  The lanes of the lower half of the pair
+// (j < S / 2) write all sixteen outputs in round 0, the others in round 1; everybody reads 8 + 8.
+template <int S, int NS, typename SYNC>
+__device__ __forceinline__ void level(double2 (&v)[16], double2 *b, const double2 *__restrict__ tab, const int j, const int rbase,
+                                      SYNC sync)
+{
+    constexpr int NS2 = 16 * NS;
+    double2 w[16], ga[4];
+    const unsigned m3 = (unsigned)(j & (NS2 - 1));
+#pragma unroll
+    for (int s = 0; s < 4; s++) // the pass's first factors travel during the transpose
+        ga[s] = ldg2u(scalar_ptr_at(tab, s * NS2), m3);
+    fence();
+    const int g = j / NS, mm = j & (NS - 1);
+    // position (g mod S/(2 NS)) 16 NS + r NS + m, padded
+    const int gl = g & (S / (2 * NS) - 1);
+    const int wb = gl * padk(16 * NS) + mm + (NS >= 16 ? (mm >> 4) : 0);
+    const bool lower = j < S / 2;
+    sync();
+    if (lower) {
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            b[wb + (NS >= 16 ? r * padk(NS) : r * NS + ((r * NS) >> 4))] = v[BR16(r)];
+    }
+    sync();
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        w[i] = b[rbase + i * padk(S)];
+    sync();
+    if (!lower) {
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            b[wb + (NS >= 16 ? r * padk(NS) : r * NS + ((r * NS) >> 4))] = v[BR16(r)];
+    }
+    sync();
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        w[8 + i] = b[rbase + i * padk(S)];
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+        v[i] = w[i];
+    gpass_pre(v, ga, [&](int s) __attribute__((always_inline)) { return ldg2u(scalar_ptr_at(tab, s * NS2), m3); });
+}
+
+// forward transform of the pair's n points: v[i] = x[j + i S] -> X[j + r S] at v[BR16(r)].  b: the pair's half buffer.
+// gs: the factors of the passes behind the second one, lane-ordered (FusedParams::gsmall): [8][16 R1], then (n = 8192)
+// [8][256 R1] -- coalesced 16-byte loads; out of the generic W_65536 table the same factors are up to 64 different cache
+// lines per wave instruction.
 template <int LOGN>
 __device__ __forceinline__ void forward(double2 (&v)[16], double2 *b, const double2 *__restrict__ twm,
                                         const double2 *__restrict__ gs, const int j_)
 {
-    constexpr int n = 1 << LOGN, S = n / 16, R1 = n / 256, Q1 = 16 / R1, HQ = Q1 / 2;
+    constexpr int n = 1 << LOGN, S = n / 16, NP = (LOGN + 3) / 4, R1 = n >> (4 * (NP - 1)), Q1 = 16 / R1, HQ = Q1 / 2;
     int j = j_;
     asm volatile("" : "+v"(j)); // addresses are derived here, per call (not hoisted out of the pair loop)
     j &= S - 1;                 // (range for the compiler: 32-bit table offsets)
@@ -202,70 +262,42 @@ __device__ __forceinline__ void forward(double2 (&v)[16], double2 *b, const doub
     const int rbase = j + (j >> 4);              // padpos(j + i S) = rbase + i padk(S)
     const int w1 = j * R1 + ((j * R1) >> 4);     // padpos((j + m S) R1 + r) = w1 + r + m padk(S R1)
     r_dft<R1>(v);                                // pass 1: output (m, r) at v[m + r Q1]
-    double2 w[16], ga[4];
-    const int m2 = j & (R1 - 1);
+    {
+        double2 w[16], ga[4];
+        const int m2 = j & (R1 - 1);
 #pragma unroll
-    for (int s = 0; s < 4; s++) // pass 2's first factors travel during transpose A
-        ga[s] = tw_factor<R1>(twm, m2, s);
-    fence();
-    // ---- transpose A, two half rounds
-    sync(); // (previous readers of the buffer are done)
+        for (int s = 0; s < 4; s++) // pass 2's first factors travel during transpose A
+            ga[s] = tw_factor<R1>(twm, m2, s);
+        fence();
+        // ---- transpose A, two half rounds: the lower / upper half of the positions
+        sync(); // (previous readers of the buffer are done)
 #pragma unroll
-    for (int m = 0; m < HQ; m++)
+        for (int m = 0; m < HQ; m++)
 #pragma unroll
-        for (int r = 0; r < R1; r++)
-            b[w1 + r + m * padk(S * R1)] = v[m + r * Q1];
-    sync();
+            for (int r = 0; r < R1; r++)
+                b[w1 + r + m * padk(S * R1)] = v[m + r * Q1];
+        sync();
 #pragma unroll
-    for (int i = 0; i < 8; i++)
-        w[i] = b[rbase + i * padk(S)];
-    sync();
+        for (int i = 0; i < 8; i++)
+            w[i] = b[rbase + i * padk(S)];
+        sync();
 #pragma unroll
-    for (int m = 0; m < HQ; m++)
+        for (int m = 0; m < HQ; m++)
 #pragma unroll
-        for (int r = 0; r < R1; r++)
-            b[w1 + r + m * padk(S * R1)] = v[HQ + m + r * Q1];
-    sync();
+            for (int r = 0; r < R1; r++)
+                b[w1 + r + m * padk(S * R1)] = v[HQ + m + r * Q1];
+        sync();
 #pragma unroll
-    for (int i = 0; i < 8; i++)
-        w[8 + i] = b[rbase + i * padk(S)];
+        for (int i = 0; i < 8; i++)
+            w[8 + i] = b[rbase + i * padk(S)];
 #pragma unroll
-    for (int i = 0; i < 16; i++)
-        v[i] = w[i];
-    gpass_pre(v, ga, [&](int s) __attribute__((always_inline)) { return tw_factor<R1>(twm, m2, s); }); // pass 2: Ns = R1; output r at v[BR16(r)]
-#pragma unroll
-    for (int s = 0; s < 4; s++) // pass 3's first factors travel during transpose B
-        ga[s] = ldg2u(scalar_ptr_at(gs, s * S), (unsigned)j);
-    fence();
-    // ---- transpose B: lanes with g = j / R1 < 8 write in round 0, the others in round 1; everybody reads 8 + 8
-    const int g = j / R1, mm = j & (R1 - 1);
-    const int wb = (g & 7) * padk(16 * R1) + mm; // position (g - 8 h) 16 R1 + r R1 + m, padded: + r R1 + (r R1 >> 4)
-    const bool lower = g < 8;
-    sync();
-    if (lower) {
-#pragma unroll
-        for (int r = 0; r < 16; r++)
-            b[wb + r * R1 + ((r * R1) >> 4)] = v[BR16(r)];
+        for (int i = 0; i < 16; i++)
+            v[i] = w[i];
+        gpass_pre(v, ga, [&](int s) __attribute__((always_inline)) { return tw_factor<R1>(twm, m2, s); }); // pass 2: Ns = R1
     }
-    sync();
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-        w[i] = b[rbase + i * padk(S)];
-    sync();
-    if (!lower) {
-#pragma unroll
-        for (int r = 0; r < 16; r++)
-            b[wb + r * R1 + ((r * R1) >> 4)] = v[BR16(r)];
-    }
-    sync();
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-        w[8 + i] = b[rbase + i * padk(S)];
-#pragma unroll
-    for (int i = 0; i < 16; i++)
-        v[i] = w[i];
-    // pass 3: Ns = S, delta = j / S; X[j + r S] at v[BR16(r)]
-    gpass_pre(v, ga, [&](int s) __attribute__((always_inline)) { return ldg2u(scalar_ptr_at(gs, s * S), (unsigned)j); });
+    level<S, R1>(v, b, gs, j, rbase, sync); // pass 3: Ns = 16 R1
+    if (NP >= 4)
+        level<S, 16 * R1>(v, b, gs + 8 * 16 * R1, j, rbase, sync); // pass 4 (n = 8192): Ns = 256 R1 = S
 }
 
 } // namespace small
@@ -274,23 +306,23 @@ __device__ __forceinline__ void forward(double2 (&v)[16], double2 *b, const doub
 // Workgroup: 256 threads (n <= 1024: pairs never leave a wave, the workgroup is only a scheduling unit) or the 128 threads
 // of ONE pair (n = 2048: the barriers of the half rounds then couple the pair's two waves and nobody else).
 template <int LOGN, bool PADDED>
-__global__ __launch_bounds__((LOGN == 11 ? 128 : 256), 4) void xcorr_fused_small(const FusedParams p)
+__global__ __launch_bounds__((LOGN >= 11 ? (1 << LOGN) / 16 : 256), 4) void xcorr_fused_small(const FusedParams p)
 {
     using namespace occ4;
     using namespace fold;
     using namespace small;
     constexpr int n = 1 << LOGN;
     constexpr int S = n / 16;   // threads per pair: 32, 64, 128
-    constexpr int TPB = LOGN == 11 ? 128 : 256;
-    constexpr int G = TPB / S;  // pairs per workgroup iteration: 8, 4, 1
-    static_assert(LOGN >= 9 && LOGN <= 11, "n = 512, 1024, 2048");
+    constexpr int TPB = LOGN >= 11 ? S : 256;
+    constexpr int G = TPB / S;  // pairs per workgroup iteration: 8, 4, 1, 1
+    static_assert((LOGN >= 9 && LOGN <= 11) || LOGN == 13, "n = 512, 1024, 2048, 8192");
+    __shared__ double red[8]; // multi-wave pair reductions (n >= 2048)
     __shared__ double2 xbuf[(TPB / 64) * 544]; // 8.7 KB per wave: half-round buffers of the pairs (8 S 17/16 double2 per pair)
     const int t = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     // (S >= 64: a wave works on one pair -- the pair slot is wave-uniform and everything derived from it stays scalar)
     const int g = S >= 64 ? __builtin_amdgcn_readfirstlane(t / S) : t / S, j = t % S;
     double2 *const b = xbuf + g * (8 * S + S / 2);
-    double *const xw = (double *)(xbuf + 544 * wave); // the wave's slice, for the two-wave reductions (n = 2048)
     const int N = PADDED ? p.N : n, pad = PADDED ? n - N : 0;
     const double invN = 1.0 / (double)N, invNm1 = 1.0 / (double)(N - 1);
     const double2 *__restrict__ twm = p.twm;
@@ -361,10 +393,10 @@ __global__ __launch_bounds__((LOGN == 11 ? 128 : 256), 4) void xcorr_fused_small
             q2 += db;
             q3 = fma(db, db, q3);
         }
-        q0 = pair_sum<S>(q0, xw, wave);
-        q1 = pair_sum<S>(q1, xw, wave);
-        q2 = pair_sum<S>(q2, xw, wave);
-        q3 = pair_sum<S>(q3, xw, wave);
+        q0 = pair_sum<S>(q0, red, wave);
+        q1 = pair_sum<S>(q1, red, wave);
+        q2 = pair_sum<S>(q2, red, wave);
+        q3 = pair_sum<S>(q3, red, wave);
         const Stat stA{q0, q1}, stB{q2, q3};
         bool zeroA, nanA, zeroB, nanB;
         const double varA0 = variance(stA, invN, invNm1, zeroA, nanA);
@@ -445,9 +477,9 @@ __global__ __launch_bounds__((LOGN == 11 ? 128 : 256), 4) void xcorr_fused_small
         fence();
         request(it + gridDim.x); // the next iteration's rows: in flight during the reductions and the result write-out
         fence();
-        const double pa = pair_max<S>(ma, xw, wave), pb = pair_max<S>(mb, xw, wave);
-        const int ca = pair_min_i<S>((ma == pa && pa > 0.0) ? ia : 0x7fffffff, xw, wave);
-        const int cb = pair_min_i<S>((mb == pb && pb > 0.0) ? ib : 0x7fffffff, xw, wave);
+        const double pa = pair_max<S>(ma, red, wave), pb = pair_max<S>(mb, red, wave);
+        const int ca = pair_min_i<S>((ma == pa && pa > 0.0) ? ia : 0x7fffffff, red, wave);
+        const int cb = pair_min_i<S>((mb == pb && pb > 0.0) ? ib : 0x7fffffff, red, wave);
         // the lane that owns the winning index writes the result (nothing above 0: lane 0 reports cc[0] at index 0)
         if (live) {
             const bool ownA = ca == 0x7fffffff ? j == 0 : (ia == ca && ma == pa);
@@ -483,7 +515,7 @@ __global__ __launch_bounds__((LOGN == 11 ? 128 : 256), 4) void xcorr_fused_small
 template <int LOGN>
 static hipError_t launch_small_n(const FusedParams &p, int num_cus, hipStream_t stream)
 {
-    constexpr int TPB = LOGN == 11 ? 128 : 256;
+    constexpr int TPB = LOGN >= 11 ? (1 << LOGN) / 16 : 256;
     constexpr int G = TPB / ((1 << LOGN) / 16);
     const long long ngroups = (p.npairs + G - 1) / G;
     const long long grid = std::min<long long>(ngroups, (long long)num_cus * (1024 / TPB) * 8);
@@ -494,7 +526,7 @@ static hipError_t launch_small_n(const FusedParams &p, int num_cus, hipStream_t 
     return hipGetLastError();
 }
 
-// n = 512, 1024, 2048 (float64 rows); any N in (n/2, n]
+// n = 512, 1024, 2048, 8192 (float64 rows); any N in (n/2, n]
 hipError_t launch_fused_small(const FusedParams &p, int num_cus, hipStream_t stream)
 {
     if (!p.rows || !p.twm || !p.xc || !p.gsmall)
@@ -503,6 +535,7 @@ hipError_t launch_fused_small(const FusedParams &p, int num_cus, hipStream_t str
     case 9: return launch_small_n<9>(p, num_cus, stream);
     case 10: return launch_small_n<10>(p, num_cus, stream);
     case 11: return launch_small_n<11>(p, num_cus, stream);
+    case 13: return launch_small_n<13>(p, num_cus, stream);
     default: return hipErrorInvalidValue;
     }
 }

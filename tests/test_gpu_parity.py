@@ -457,13 +457,13 @@ def test_periodic_series_many_near_ties(muse, eng, oracle):
         eng.set_kernel(0)
 
 
-@pytest.mark.parametrize("N", [512, 1000, 4096, 5000])
+@pytest.mark.parametrize("N", [512, 1000, 4096, 5000, 16384, 20000, 65536])
 def test_config5_mixed_lengths_label_grouped(muse, eng, oracle, N):
-    """BASELINE config 5 (the <= 8192 part): one (ref, Group) pair per series length
+    """BASELINE config 5 (every length class, 512 ... 65536): one (ref, Group) pair per series length
     (the reference has no mixed-length Group: group.go:45-51, muse_batch.go:24-28), label
     groups of 10 hosts per graph, Batch.Run(["graph"]) through the host mirror, checked
     against the oracle's Batch.Run/Results semantics.  N = 1000 / 5000 are zero-padded to
-    1024 / 8192 (xcorr.go:176-181); N = 512 / 4096 are circular (no padding)."""
+    1024 / 8192, N = 20000 to 32768 (xcorr.go:176-181); the powers of two are circular (no padding)."""
     rng = np.random.default_rng(N)
     graphs, hosts = 40, 10
     t = np.arange(N)
@@ -584,7 +584,7 @@ def test_many_references_large(muse, eng):
 
 
 @pytest.mark.parametrize("N", [257, 480, 512, 700, 1000, 1024, 1025, 1500, 2048,
-                               4097, 5000, 8192, 10000, 16384, 20000, 32768, 40000, 65536])
+                               4097, 5000, 6000, 8192, 10000, 16384, 20000, 32768, 40000, 65536])
 def test_stockham_kernels_match_oracle_and_generic(muse, eng, oracle, N):
     """n = 512 ... 2048 (LDS) and 8192 ... 65536 (global scratch): the radix-16 Stockham kernels
     (auto / variant 11) against the oracle and the radix-2 generic kernel (variant 1) on the same
@@ -602,13 +602,14 @@ def test_stockham_kernels_match_oracle_and_generic(muse, eng, oracle, N):
     olag, omv, gap = oracle.batch_scores(ref, rows)
     try:
         got = {}
-        for variant in (0, 11, 12, 1) if db.n <= 2048 else (0, 11, 1):
+        small = db.n <= 2048 or db.n == 8192     # lengths the half-round kernel (xcorr_small.hip) is built for
+        for variant in (0, 11, 12, 1) if small else (0, 11, 1):
             eng.set_kernel(variant)
             lag, mv = db.scores()
             assert math.isnan(mv[10]) and lag[10] == 0 and math.isnan(mv[12]) and lag[12] == 0, variant
             assert_scores_match(lag, mv, olag, omv, gap)
             got[variant] = (lag, mv)
-        auto = 12 if db.n <= 2048 else 11       # what automatic selection takes for this length
+        auto = 12 if small else 11               # what automatic selection takes for this length
         assert np.array_equal(got[0][0], got[auto][0]) and np.array_equal(got[0][1], got[auto][1], equal_nan=True)
     finally:
         eng.set_kernel(0)
