@@ -82,7 +82,7 @@ struct muse_ctx {
     char name[64] = {0};
     double2 *tw1 = nullptr, *tw2 = nullptr, *twm = nullptr;
     double2 *g2 = nullptr, *g3a = nullptr, *g3b = nullptr; // folded-twiddle tables (xcorr_r16_fold.hip)
-    double2 *gsmall[4] = {nullptr, nullptr, nullptr, nullptr}; // the same for n = 512, 1024, 2048 (xcorr_small.hip): [8][n/16]; n = 8192: [8][32] + [8][512]
+    double2 *gsmall[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // the same for xcorr_small.hip: n = 512, 1024, 2048: [8][n/16]; n = 8192: [8][32] + [8][512]; n = 16384: [8][64] + [8][1024]
     float2 *tw1f = nullptr, *tw2f = nullptr, *twmf = nullptr; // fp32 copies for the screening kernels
     // many-reference pass (muse_batch_score_many): parked spectra + device pointer tables
     // pinned staging buffers (32 MB each) lent to groups that receive many small appends; allocated once
@@ -315,10 +315,10 @@ extern "C" int muse_ctx_create(int32_t device, muse_ctx **out)
         HIP_TRY(hipMemcpy(ctx->g3b, g3b.data(), g3b.size() * sizeof(double2), hipMemcpyHostToDevice));
         // xcorr_small.hip's passes behind the second one: phase m / L, m = j mod L, for L = 16 R1 (and L = 256 R1 = S, n = 8192):
         // W_(2L)^m, W_(4L)^m, W_(8L)^m, W_(8L)^(m+L), W_(16L)^(m+qL), lane-ordered
-        for (int k = 0; k < 4; k++) {
-            const int n = k < 3 ? (512 << k) : 8192, S = n / 16;
+        for (int k = 0; k < 5; k++) {
+            const int n = k < 3 ? (512 << k) : (2048 << (k - 1)), S = n / 16;
             std::vector<double2> gs;
-            for (int L = (k < 3 ? S : 32); L <= S; L *= 16) {
+            for (int L = (k < 3 ? S : S / 16); L <= S; L *= 16) {
                 const size_t o = gs.size();
                 gs.resize(o + (size_t)8 * L);
                 for (int m = 0; m < L; m++) {
@@ -370,7 +370,7 @@ static void ctx_release(muse_ctx *ctx)
     (void)hipFree(ctx->g2);
     (void)hipFree(ctx->g3a);
     (void)hipFree(ctx->g3b);
-    for (int k = 0; k < 4; k++)
+    for (int k = 0; k < 5; k++)
         (void)hipFree(ctx->gsmall[k]);
     (void)hipFree(ctx->zscratch);
     (void)hipFree(ctx->gscratch);
@@ -463,7 +463,7 @@ extern "C" int muse_ctx_kernel_time(muse_ctx *ctx, double *total_ms, int64_t *la
 // ------------------------------------------------------------------- group
 // Every group allocation starts with GROUP_GUARD readable (zeroed) elements in front of row 0: the kernels for zero-padded
 // series (xcorr_small.hip) read up to n - N samples in front of a row without clamping and mask them afterwards.
-constexpr size_t GROUP_GUARD = 4096;
+constexpr size_t GROUP_GUARD = 8192;
 static int group_create(muse_ctx *ctx, int64_t capacity_rows, int32_t N, bool f32, muse_group **out);
 extern "C" int muse_group_create(muse_ctx *ctx, int64_t capacity_rows, int32_t N, muse_group **out)
 {
@@ -1023,7 +1023,7 @@ static FusedParams base_params(muse_batch *b)
     p.g2 = ctx->g2;
     p.g3a = ctx->g3a;
     p.g3b = ctx->g3b;
-    p.gsmall = (b->logn >= 9 && b->logn <= 11) ? ctx->gsmall[b->logn - 9] : b->logn == 13 ? ctx->gsmall[3] : nullptr;
+    p.gsmall = (b->logn >= 9 && b->logn <= 11) ? ctx->gsmall[b->logn - 9] : (b->logn == 13 || b->logn == 14) ? ctx->gsmall[b->logn - 10] : nullptr;
     p.xcp = b->xcp;
     p.c1 = b->c1;
     p.tw1f = ctx->tw1f;
@@ -1076,7 +1076,7 @@ extern "C" int muse_batch_score(muse_batch *b)
         if (variant == KERNEL_R16_FOLD && ctx->variant == 0 && b->handoff_host && b->handoff_M == M &&
             (long long)*(volatile int *)b->handoff_host * 8 > p.npairs)
             variant = KERNEL_R16_OCC3;
-    } else if (((b->n >= 512 && b->n <= 2048) || b->n == 8192) && (ctx->variant == 0 || ctx->variant == 12)) {
+    } else if (((b->n >= 512 && b->n <= 2048) || b->n == 8192 || b->n == 16384) && (ctx->variant == 0 || ctx->variant == 12)) {
         variant = KERNEL_SMALL; // half-round transposes at 16 waves per CU (xcorr_small.hip)
     } else if (((b->n >= 512 && b->n <= 2048) || b->n >= 8192) && (ctx->variant == 0 || ctx->variant == 11)) {
         variant = KERNEL_STOCKHAM; // radix-16 Stockham through LDS / global scratch (xcorr_stockham.hip)
@@ -1485,7 +1485,7 @@ static int screen_finish(muse_batch *b, int32_t top_n, double threshold, int32_t
     r.pair_count = b->ovf_count;
     r.npairs = std::min<long long>(npairs, (long long)ctx->num_cus * 3);
     HIP_TRY(launch_screen_save(q, b->ovf_list, b->ovf_count, b->est_save, ctx->stream));
-    HIP_TRY(launch_fused(r, b->n == 4096 ? KERNEL_R16_OCC3 : (b->n <= 2048 || b->n == 8192) ? KERNEL_SMALL : KERNEL_STOCKHAM, ctx->num_cus, ctx->stream));
+    HIP_TRY(launch_fused(r, b->n == 4096 ? KERNEL_R16_OCC3 : (b->n <= 2048 || b->n == 8192 || b->n == 16384) ? KERNEL_SMALL : KERNEL_STOCKHAM, ctx->num_cus, ctx->stream));
     // guard: the re-evaluated rows have an estimate and an fp64 score; the largest difference must respect the bound
     HIP_TRY(launch_screen_check(b->mv, M, b->ovf_list, b->ovf_count, b->est_save, b->err_dev, ctx->stream));
     *b->refine_host = 0;
@@ -1562,9 +1562,9 @@ extern "C" int muse_batch_kernel_name(muse_batch *b, char *name, int32_t cap)
     const char *k = "xcorr_fused_generic";
     if (b->n == 4096)
         k = b->N == 4096 ? "xcorr_fused_n4096_fold<false, false>" : "xcorr_fused_n4096_fold<false, true>";
-    else if ((b->n >= 512 && b->n <= 2048) || b->n == 8192)
+    else if ((b->n >= 512 && b->n <= 2048) || b->n == 8192 || b->n == 16384)
         k = "xcorr_fused_small";
-    else if (b->n > 8192)
+    else if (b->n > 16384)
         k = "xcorr_fused_stk_4step";
     snprintf(name, (size_t)cap, "%s", k);
     return MUSE_OK;
@@ -1834,9 +1834,11 @@ extern "C" int muse_batch_score_many(muse_batch *const *bs, int32_t R)
     muse_ctx *ctx = b0->ctx;
     // the one-pass kernel is built for N == n == 4096 (and is only taken under automatic kernel
     // selection); everything else scores the batches one after the other
-    bool one_pass = R > 1 && b0->n == 4096 && !b0->g->f32 && (ctx->variant == 0 || ctx->variant == 10);
+    const bool small_n = (b0->n >= 512 && b0->n <= 2048) || b0->n == 8192 || b0->n == 16384; // xcorr_small.hip's lengths
+    bool one_pass = R > 1 && !b0->g->f32 &&
+                    ((b0->n == 4096 && (ctx->variant == 0 || ctx->variant == 10)) || (small_n && (ctx->variant == 0 || ctx->variant == 12)));
     for (int r = 0; r < R && one_pass; r++)
-        one_pass = bs[r]->N == b0->N && (b0->N == 4096 || bs[r]->c1 != nullptr);
+        one_pass = bs[r]->N == b0->N && (small_n || b0->N == 4096 || bs[r]->c1 != nullptr);
     if (!one_pass) {
         for (int r = 0; r < R; r++) {
             int rc = muse_batch_score(bs[r]);
@@ -1875,7 +1877,7 @@ extern "C" int muse_batch_score_many(muse_batch *const *bs, int32_t R)
     std::vector<void *> &tab = ctx->many_host;
     tab.assign((size_t)R * 4, nullptr);
     for (int r = 0; r < R; r++) {
-        tab[(size_t)r] = bs[r]->xcp;
+        tab[(size_t)r] = small_n ? bs[r]->xc : bs[r]->xcp;
         tab[(size_t)R + r] = bs[r]->mv;
         tab[(size_t)2 * R + r] = bs[r]->lag;
         tab[(size_t)3 * R + r] = bs[r]->c1;
@@ -1906,10 +1908,15 @@ extern "C" int muse_batch_score_many(muse_batch *const *bs, int32_t R)
         HIP_TRY(hipEventRecord(e0, ctx->stream));
     }
     HIP_TRY(hipMemsetAsync(b0->ovf_count, 0, 2 * sizeof(int), ctx->stream));
-    HIP_TRY(launch_fused_multi(p, ctx->num_cus, ctx->stream));
+    if (small_n) { // (this kernel isolates dead series itself: nothing is handed on)
+        HIP_TRY(launch_fused_small(p, ctx->num_cus, ctx->stream));
+        for (int r = 0; r < R; r++)
+            bs[r]->scores_exact = true;
+    } else
+        HIP_TRY(launch_fused_multi(p, ctx->num_cus, ctx->stream));
     // pairs holding a NaN/Inf series (listed once, by reference 0): redone per reference by the
     // kernel that isolates the dead series before the shared transform
-    for (int r = 0; r < R; r++) {
+    for (int r = 0; r < R && !small_n; r++) {
         FusedParams q = base_params(bs[r]);
         q.pair_list = b0->ovf_list;
         q.pair_count = b0->ovf_count;

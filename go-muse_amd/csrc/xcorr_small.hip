@@ -300,12 +300,24 @@ __device__ __forceinline__ void forward(double2 (&v)[16], double2 *b, const doub
         level<S, 16 * R1>(v, b, gs + 8 * 16 * R1, j, rbase, sync); // pass 4 (n = 8192): Ns = 256 R1 = S
 }
 
+// a wave-uniform pointer fetched from a device table, forced into SGPRs (the compiler cannot prove uniformity)
+template <typename T>
+__device__ __forceinline__ T *uniform_ptr(T *ptr)
+{
+    const unsigned long long u = (unsigned long long)ptr;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return (T *)(((unsigned long long)hi << 32) | lo);
+}
+
 } // namespace small
 
 // PADDED: N < n (leading zero pad); N == n needs no per-sample validity masks
 // Workgroup: 256 threads (n <= 1024: pairs never leave a wave, the workgroup is only a scheduling unit) or the 128 threads
 // of ONE pair (n = 2048: the barriers of the half rounds then couple the pair's two waves and nobody else).
-template <int LOGN, bool PADDED>
+// MULTI: R references against the group in one pass (muse_batch_score_many): rows are loaded, reduced and transformed
+// once; the pair's spectrum is parked lane-ordered in the workgroup's slice of p.zscratch (L2 / MALL resident, every
+// thread re-reads only what it wrote) and every reference takes product, second transform and argmax from there.
+template <int LOGN, bool PADDED, bool MULTI>
 __global__ __launch_bounds__((LOGN >= 11 ? (1 << LOGN) / 16 : 256), 4) void xcorr_fused_small(const FusedParams p)
 {
     using namespace occ4;
@@ -314,9 +326,9 @@ __global__ __launch_bounds__((LOGN >= 11 ? (1 << LOGN) / 16 : 256), 4) void xcor
     constexpr int n = 1 << LOGN;
     constexpr int S = n / 16;   // threads per pair: 32, 64, 128
     constexpr int TPB = LOGN >= 11 ? S : 256;
-    constexpr int G = TPB / S;  // pairs per workgroup iteration: 8, 4, 1, 1
-    static_assert((LOGN >= 9 && LOGN <= 11) || LOGN == 13, "n = 512, 1024, 2048, 8192");
-    __shared__ double red[8]; // multi-wave pair reductions (n >= 2048)
+    constexpr int G = TPB / S;  // pairs per workgroup iteration: 8, 4, 1, 1, 1
+    static_assert((LOGN >= 9 && LOGN <= 11) || LOGN == 13 || LOGN == 14, "n = 512, 1024, 2048, 8192, 16384");
+    __shared__ double red[16]; // multi-wave pair reductions (n >= 2048)
     __shared__ double2 xbuf[(TPB / 64) * 544]; // 8.7 KB per wave: half-round buffers of the pairs (8 S 17/16 double2 per pair)
     const int t = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -425,12 +437,36 @@ __global__ __launch_bounds__((LOGN >= 11 ? (1 << LOGN) / 16 : 256), 4) void xcor
         }
         // ---- Z = FFT(yA + i yB);  V = Z conj(X)/n;  ccA + i ccB = FFT(V)
         forward<LOGN>(v, b, twm, gs, j);
+        // the workgroup's slice of the spectrum scratch: element i of thread gt at [i][gt] (scalar base + 32-bit lane offset)
+        const long long ZT = (long long)gridDim.x * TPB;
+        const auto zslot = [&](int i) __attribute__((always_inline)) {
+            int gt = t;
+            asm volatile("" : "+v"(gt)); // (derived per use, not hoisted)
+            gt &= TPB - 1;
+            return (d2v __attribute__((address_space(1))) *)scalar_ptr_at(p.zscratch, i * ZT + (long long)blockIdx.x * TPB) + (unsigned)gt;
+        };
+        if (MULTI) {
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                *zslot(i) = d2v{v[i].x, v[i].y};
+        }
+        const int R = MULTI ? p.R : 1;
+        for (int ref = 0; ref < R; ref++) {
+        const double2 *__restrict__ xcr = MULTI ? uniform_ptr(p.xcp_many[ref]) : p.xc;
+        if (MULTI) {
+            fence();
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const d2v z = *zslot(i);
+                v[i] = make_double2(z.x, z.y);
+            }
+        }
         { // V = Z conj(X)/n in place, the factors in four batches of four (two in flight: 32 registers), then the
           // registers renamed to natural order (X[j + r S] sits at v[BR16(r)])
             int jx = j;
             asm volatile("" : "+v"(jx)); // (the table offsets are derived here, not hoisted out of the pair loop)
             jx &= S - 1;
-            const auto xcl = [&](int r) __attribute__((always_inline)) { return ldg2u(scalar_ptr_at(p.xc, r * S), (unsigned)jx); };
+            const auto xcl = [&](int r) __attribute__((always_inline)) { return ldg2u(scalar_ptr_at(xcr, r * S), (unsigned)jx); };
             double2 xq[2][4];
 #pragma unroll
             for (int k = 0; k < 4; k++)
@@ -475,7 +511,8 @@ __global__ __launch_bounds__((LOGN >= 11 ? (1 << LOGN) / 16 : 256), 4) void xcor
         const int ia = j + ra_ * S, ib = j + rb_ * S;
         const double cc0a = v[0].x, cc0b = v[0].y; // (lane 0: cc[0], reported when nothing is above 0)
         fence();
-        request(it + gridDim.x); // the next iteration's rows: in flight during the reductions and the result write-out
+        if (!MULTI)
+            request(it + gridDim.x); // the next iteration's rows: in flight during the reductions and the result write-out
         fence();
         const double pa = pair_max<S>(ma, red, wave), pb = pair_max<S>(mb, red, wave);
         const int ca = pair_min_i<S>((ma == pa && pa > 0.0) ? ia : 0x7fffffff, red, wave);
@@ -492,8 +529,8 @@ __global__ __launch_bounds__((LOGN >= 11 ? (1 << LOGN) / 16 : 256), 4) void xcor
                 int lag = idx > n / 2 ? idx - n : idx;
                 if (zeroA) { mv = 0.0; lag = 0; }               // xcorr.go:166-167
                 if (nanA) { mv = __builtin_nan(""); lag = 0; }
-                p.mv[rA] = mv;
-                p.lag[rA] = lag;
+                (MULTI ? p.mv_many[ref] : p.mv)[rA] = mv;
+                (MULTI ? p.lag_many[ref] : p.lag)[rA] = lag;
             }
             const bool ownB = cb == 0x7fffffff ? j == 0 : (ib == cb && mb == pb);
             if (ownB && hasB) {
@@ -505,9 +542,14 @@ __global__ __launch_bounds__((LOGN >= 11 ? (1 << LOGN) / 16 : 256), 4) void xcor
                 int lag = idx > n / 2 ? idx - n : idx;
                 if (zeroB) { mv = 0.0; lag = 0; }
                 if (nanB) { mv = __builtin_nan(""); lag = 0; }
-                p.mv[rA + 1] = mv;
-                p.lag[rA + 1] = lag;
+                (MULTI ? p.mv_many[ref] : p.mv)[rA + 1] = mv;
+                (MULTI ? p.lag_many[ref] : p.lag)[rA + 1] = lag;
             }
+        }
+        } // (references)
+        if (MULTI) { // (requested inside the loop the 64 row registers would be live across all references)
+            fence();
+            request(it + gridDim.x);
         }
     }
 }
@@ -518,24 +560,37 @@ static hipError_t launch_small_n(const FusedParams &p, int num_cus, hipStream_t 
     constexpr int TPB = LOGN >= 11 ? (1 << LOGN) / 16 : 256;
     constexpr int G = TPB / ((1 << LOGN) / 16);
     const long long ngroups = (p.npairs + G - 1) / G;
+    if (p.R > 1) { // one pass for R references: exactly the resident workgroups, each with its slice of the spectrum scratch
+        if (!p.xcp_many || !p.mv_many || !p.lag_many || !p.zscratch)
+            return hipErrorInvalidValue;
+        const long long grid = std::min<long long>(ngroups, (long long)num_cus * (1024 / TPB));
+        if ((size_t)grid * TPB * 16 > (size_t)p.zslots * 4096)
+            return hipErrorInvalidValue;
+        if (p.N < (1 << LOGN))
+            hipLaunchKernelGGL((xcorr_fused_small<LOGN, true, true>), dim3((unsigned)grid), dim3(TPB), 0, stream, p);
+        else
+            hipLaunchKernelGGL((xcorr_fused_small<LOGN, false, true>), dim3((unsigned)grid), dim3(TPB), 0, stream, p);
+        return hipGetLastError();
+    }
     const long long grid = std::min<long long>(ngroups, (long long)num_cus * (1024 / TPB) * 8);
     if (p.N < (1 << LOGN))
-        hipLaunchKernelGGL((xcorr_fused_small<LOGN, true>), dim3((unsigned)grid), dim3(TPB), 0, stream, p);
+        hipLaunchKernelGGL((xcorr_fused_small<LOGN, true, false>), dim3((unsigned)grid), dim3(TPB), 0, stream, p);
     else
-        hipLaunchKernelGGL((xcorr_fused_small<LOGN, false>), dim3((unsigned)grid), dim3(TPB), 0, stream, p);
+        hipLaunchKernelGGL((xcorr_fused_small<LOGN, false, false>), dim3((unsigned)grid), dim3(TPB), 0, stream, p);
     return hipGetLastError();
 }
 
-// n = 512, 1024, 2048, 8192 (float64 rows); any N in (n/2, n]
+// n = 512, 1024, 2048, 8192, 16384 (float64 rows); any N in (n/2, n]
 hipError_t launch_fused_small(const FusedParams &p, int num_cus, hipStream_t stream)
 {
-    if (!p.rows || !p.twm || !p.xc || !p.gsmall)
+    if (!p.rows || !p.twm || (!p.xc && p.R <= 1) || !p.gsmall)
         return hipErrorInvalidValue;
     switch (p.logn) {
     case 9: return launch_small_n<9>(p, num_cus, stream);
     case 10: return launch_small_n<10>(p, num_cus, stream);
     case 11: return launch_small_n<11>(p, num_cus, stream);
     case 13: return launch_small_n<13>(p, num_cus, stream);
+    case 14: return launch_small_n<14>(p, num_cus, stream);
     default: return hipErrorInvalidValue;
     }
 }

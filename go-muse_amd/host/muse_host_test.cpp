@@ -237,9 +237,43 @@ static void TestRunConcurrentCallers()
     }
 }
 
+// First use from many threads at once: the process-wide engine (Engine::Default(), the Go shim's sync.Once getEngine) is
+// created inside the first New / NewBatch -- here eight threads race for it (the pattern of muse_test.go:203-214 with a
+// cold package).  Must run before any other test touches the engine.
+static void TestFirstUseConcurrent()
+{
+    const int N = 256, T = 8;
+    std::vector<double> base(N);
+    for (int i = 0; i < N; i++)
+        base[i] = std::sin(0.05 * i) + (i >= 100 && i < 120 ? 2.0 : 0.0) + 1e-3 * ((i * 2654435761u) % 97);
+    std::vector<Scores> out(T);
+    std::vector<std::thread> th;
+    for (int w = 0; w < T; w++)
+        th.emplace_back([&, w] {
+            auto ref = NewSeries(base, NewLabels({{"graph", "ref"}}));
+            std::vector<double> y(N);
+            for (int i = 0; i < N; i++)
+                y[i] = base[(i + 3) % N] * 2.0 + 1.0;
+            auto m = New(ref, NewResults(N, 4, 0, SignFilter_ANY)); // <- first use of the engine, T threads at once
+            m->Run({NewSeries(y, NewLabels({{"graph", "g"}, {"host", "h" + std::to_string(w)}}))});
+            out[w] = m->Results_->Fetch().first;
+        });
+    for (auto &t : th)
+        t.join();
+    for (int w = 0; w < T; w++) {
+        EXPECT(out[w].size() == 1, "first use, thread %d: %zu scores", w, out[w].size());
+        if (out[w].size() == 1 && out[0].size() == 1) {
+            EXPECT(out[w][0].Lag == out[0][0].Lag, "first use, thread %d: lag %d vs %d", w, out[w][0].Lag, out[0][0].Lag);
+            EXPECT(std::fabs(out[w][0].PercentScore - out[0][0].PercentScore) <= 1e-12, "first use, thread %d: score", w);
+            EXPECT(out[w][0].PercentScore > 0.99, "first use, thread %d: score %g", w, out[w][0].PercentScore);
+        }
+    }
+}
+
 int main()
 {
     try {
+        TestFirstUseConcurrent();
         TestBatchRunSimple();
         TestBatchRunMultiDimensional();
         TestBatchRunWithLargerGroup();

@@ -529,13 +529,14 @@ def test_group_append_staging_paths(muse, eng, oracle):
     assert np.array_equal(lag3[:M], lag) and np.array_equal(mv3[:M], mv)
 
 
-@pytest.mark.parametrize("N", [4096, 3000])
+@pytest.mark.parametrize("N", [4096, 3000, 512, 700, 1024, 1500, 2048, 6000, 8192, 10000, 16384])
 @pytest.mark.parametrize("R,M", [(2, 65), (5, 300), (1, 40)])
 def test_many_references_one_pass_matches_single_batches(muse, eng, oracle, R, M, N):
     """muse_batch_score_many: R references against one resident group in one pass over the rows
     (each pair transformed once, its spectrum parked in the per-workgroup scratch slice) must give
     what R separate batches give -- and what the oracle gives -- incl. NaN/Inf/constant rows and an
-    odd row count (N = 3000: the leading-zero-pad build with per-reference correction tables)."""
+    odd row count (N = 3000: the leading-zero-pad build with per-reference correction tables; n = 512 ... 2048, 8192,
+    16384: the half-round kernel's one-pass build)."""
     rng = np.random.default_rng(1000 + R)
     rows = rng.standard_normal((M, N))
     rows[3, 100] = np.nan
@@ -602,7 +603,7 @@ def test_stockham_kernels_match_oracle_and_generic(muse, eng, oracle, N):
     olag, omv, gap = oracle.batch_scores(ref, rows)
     try:
         got = {}
-        small = db.n <= 2048 or db.n == 8192     # lengths the half-round kernel (xcorr_small.hip) is built for
+        small = db.n <= 2048 or db.n in (8192, 16384)   # lengths the half-round kernel (xcorr_small.hip) is built for
         for variant in (0, 11, 12, 1) if small else (0, 11, 1):
             eng.set_kernel(variant)
             lag, mv = db.scores()
