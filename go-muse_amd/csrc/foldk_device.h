@@ -1,0 +1,413 @@
+// foldk_device.h -- the building blocks of the n = 4096 folded-arithmetic transforms shared by xcorr_r16_fold.hip (one
+// pair per workgroup pass) and xcorr_long.hip (the 4096-point rows of the four-step transform): the two LDS
+// transposes in half rounds, factor fetchers, the generalised pass with early factors, the spectrum multiply folded
+// into the second transform's first stage, and the record / argmax helpers of the n = 4096 kernel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "fold_device.h"
+#include "r16_device.h"
+
+namespace muse {
+
+// MUSE_FOLD_EXP (tools/ablate only; never defined in the library build): bit 0 = pass-3 factors read from the LDS
+// table instead of L2 (wrong values, same arithmetic), bit 1 = spectrum factors likewise, bit 3 = no result write-out
+#ifndef MUSE_FOLD_EXP
+#define MUSE_FOLD_EXP 0
+#endif
+
+// MUSE_FOLD_OPT: scheduling choices, A/B-ed in tools/ablate/fold_phases.hip (the library builds the default):
+//   bit 0: the previous pair's two results are written by lane 0 of waves 0 and 1 (one series each) instead of lanes 0 / 1 of wave 0
+//   bit 1: the first four factors of a pass-3 transform are requested BEFORE the transpose that precedes it
+//   bit 2: the first spectrum factors are requested before the last stage of the first transform
+//   bit 3: the next pair's first row is requested before the last stage of the second transform, the second row after the argmax
+//   bit 6: the barrier that frees the wave's private quarter sits right behind the first workgroup-wide transpose
+//   bit 7: the second transform's last stage, the argmax and the next pair's row requests interleaved (N == n)
+//   bit 8: the argmax as one running maximum per lane, the next pair's row requests spread over it
+//   bit 9: (with bit 8) the running-maximum argmax, but the row requests stay one burst behind it
+//   bit 4: all eight factors of a pass-3 transform requested at once;  bit 5: both rows requested before the last stage (3 waves per SIMD)
+#ifndef MUSE_FOLD_OPT
+#define MUSE_FOLD_OPT 65
+#endif
+
+namespace foldk {
+
+using namespace occ4;
+using namespace fold;
+
+constexpr int XW = 544; // double2 per wave-private quarter of the 8 x 272 buffer (8 rows x 68)
+
+// The thread index made opaque: everything derived from the copy (lane / wave parts, LDS and table offsets) is
+// recomputed where it is used (a few 32-bit VALU instructions) instead of being hoisted out of the pair loop, where a
+// dozen such values would each hold a register for the whole kernel -- or, at 128 registers, a scratch slot that is
+// reloaded through the vector memory pipe in front of every use.
+#ifndef MUSE_FOLD_F32_EARLY
+#define MUSE_FOLD_F32_EARLY 1
+#endif
+#ifndef MUSE_FOLD_FRESH
+#define MUSE_FOLD_FRESH 0
+#endif
+template <int BIT>
+__device__ __forceinline__ int fresh(int t)
+{
+    if (MUSE_FOLD_FRESH & BIT)
+        asm volatile("" : "+v"(t));
+    return t;
+}
+
+// output k of the preceding pass sits in register PERM(k): 0 = natural, 1 = bit-reversed (NR passes)
+template <int PERM>
+__device__ __forceinline__ constexpr int pr(int k)
+{
+    return PERM ? BR16(k) : k;
+}
+
+// Workgroup-wide transpose in two half rounds (layouts and bank analysis: xcorr_r16_fast.hip exchange_cross)
+// TAILBAR: one more barrier right behind the late waves' reads, so that the NEXT use of the buffer (a wave-local
+// transpose into the wave's private quarter) needs none: the waves are still in step here, whereas a barrier in
+// front of that next use also waits out everything the waves drifted apart in between (2.3 k cycles per pair,
+// profiles/r02_fold_phase_stamps.txt).
+template <int MODE, int PERM, bool TAILBAR = false>
+__device__ __forceinline__ void exchange_cross(double2 (&v)[16], double2 *xbuf, const int wave, const int t_)
+{
+    const int t = fresh<1>(t_);
+    const int hi = t >> 4, lo = t & 15;
+    const int wbase = MODE ? 17 * lo + hi : t;
+    const int rbase = 272 * (hi & 7) + (MODE ? 17 * lo : lo);
+    const bool early = wave < 2;
+    lds_barrier(); // buffer free: every wave is done with its previous (wave-local or shared) use
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        xbuf[272 * k + wbase] = v[pr<PERM>(k)];
+    lds_barrier();
+    if (early) {
+        double2 w[16];
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+            w[e] = xbuf[rbase + (MODE ? e : 16 * e)];
+        lds_barrier();
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            xbuf[272 * k + wbase] = v[pr<PERM>(8 + k)];
+        lds_barrier();
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+            v[e] = w[e];
+    } else {
+        lds_barrier();
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            xbuf[272 * k + wbase] = v[pr<PERM>(8 + k)];
+        lds_barrier();
+#pragma unroll
+        for (int e = 0; e < 16; e++)
+            v[e] = xbuf[rbase + (MODE ? e : 16 * e)];
+    }
+    if (TAILBAR)
+        lds_barrier();
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(3))) char *lds_ptr;
+#define MUSE_LDS_ADDR(p) ((unsigned)(unsigned long long)(lds_ptr)(p))
+#else
+#define MUSE_LDS_ADDR(p) 0u
+#endif
+// Wave-local transpose among the sixteen lanes that share hi (layout: xcorr_r16_fast.hip exchange_local)
+template <int PERM>
+__device__ __forceinline__ void exchange_local(double2 (&v)[16], double2 *xw, const int t_)
+{
+    const int t = fresh<2>(t_);
+    const int hl = (t >> 4) & 3, lo = t & 15;
+    const int wbase = 17 * hl + lo;
+    const int rbase = 68 * (lo & 7) + 17 * hl;
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        xw[68 * k + wbase] = v[pr<PERM>(k)];
+    const unsigned waddr = MUSE_LDS_ADDR(xw + wbase), raddr = MUSE_LDS_ADDR(xw + rbase);
+    const unsigned long long first = __ballot(lo < 8); // lanes that read in round 0
+    d2v w[16], d[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        d[k].x = v[pr<PERM>(8 + k)].x;
+        d[k].y = v[pr<PERM>(8 + k)].y;
+    }
+    unsigned long long sv;
+    asm volatile("s_mov_b64 %[sv], exec\n\t"
+                 "s_and_b64 exec, %[sv], %[m]\n\t"
+                 "ds_read_b128 %[w0], %[ra]\n\t"
+                 "ds_read_b128 %[w1], %[ra] offset:16\n\t"
+                 "ds_read_b128 %[w2], %[ra] offset:32\n\t"
+                 "ds_read_b128 %[w3], %[ra] offset:48\n\t"
+                 "ds_read_b128 %[w4], %[ra] offset:64\n\t"
+                 "ds_read_b128 %[w5], %[ra] offset:80\n\t"
+                 "ds_read_b128 %[w6], %[ra] offset:96\n\t"
+                 "ds_read_b128 %[w7], %[ra] offset:112\n\t"
+                 "ds_read_b128 %[w8], %[ra] offset:128\n\t"
+                 "ds_read_b128 %[w9], %[ra] offset:144\n\t"
+                 "ds_read_b128 %[w10], %[ra] offset:160\n\t"
+                 "ds_read_b128 %[w11], %[ra] offset:176\n\t"
+                 "ds_read_b128 %[w12], %[ra] offset:192\n\t"
+                 "ds_read_b128 %[w13], %[ra] offset:208\n\t"
+                 "ds_read_b128 %[w14], %[ra] offset:224\n\t"
+                 "ds_read_b128 %[w15], %[ra] offset:240\n\t"
+                 "s_mov_b64 exec, %[sv]\n\t"
+                 "ds_write_b128 %[wa], %[d0]\n\t"
+                 "ds_write_b128 %[wa], %[d1] offset:1088\n\t"
+                 "ds_write_b128 %[wa], %[d2] offset:2176\n\t"
+                 "ds_write_b128 %[wa], %[d3] offset:3264\n\t"
+                 "ds_write_b128 %[wa], %[d4] offset:4352\n\t"
+                 "ds_write_b128 %[wa], %[d5] offset:5440\n\t"
+                 "ds_write_b128 %[wa], %[d6] offset:6528\n\t"
+                 "ds_write_b128 %[wa], %[d7] offset:7616\n\t"
+                 "s_andn2_b64 exec, %[sv], %[m]\n\t"
+                 "ds_read_b128 %[w0], %[ra]\n\t"
+                 "ds_read_b128 %[w1], %[ra] offset:16\n\t"
+                 "ds_read_b128 %[w2], %[ra] offset:32\n\t"
+                 "ds_read_b128 %[w3], %[ra] offset:48\n\t"
+                 "ds_read_b128 %[w4], %[ra] offset:64\n\t"
+                 "ds_read_b128 %[w5], %[ra] offset:80\n\t"
+                 "ds_read_b128 %[w6], %[ra] offset:96\n\t"
+                 "ds_read_b128 %[w7], %[ra] offset:112\n\t"
+                 "ds_read_b128 %[w8], %[ra] offset:128\n\t"
+                 "ds_read_b128 %[w9], %[ra] offset:144\n\t"
+                 "ds_read_b128 %[w10], %[ra] offset:160\n\t"
+                 "ds_read_b128 %[w11], %[ra] offset:176\n\t"
+                 "ds_read_b128 %[w12], %[ra] offset:192\n\t"
+                 "ds_read_b128 %[w13], %[ra] offset:208\n\t"
+                 "ds_read_b128 %[w14], %[ra] offset:224\n\t"
+                 "ds_read_b128 %[w15], %[ra] offset:240\n\t"
+                 "s_mov_b64 exec, %[sv]\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : [w0] "=&v"(w[0]), [w1] "=&v"(w[1]), [w2] "=&v"(w[2]), [w3] "=&v"(w[3]), [w4] "=&v"(w[4]),
+                   [w5] "=&v"(w[5]), [w6] "=&v"(w[6]), [w7] "=&v"(w[7]), [w8] "=&v"(w[8]), [w9] "=&v"(w[9]),
+                   [w10] "=&v"(w[10]), [w11] "=&v"(w[11]), [w12] "=&v"(w[12]), [w13] "=&v"(w[13]),
+                   [w14] "=&v"(w[14]), [w15] "=&v"(w[15]), [sv] "=&s"(sv)
+                 : [ra] "v"(raddr), [wa] "v"(waddr), [m] "s"(first), [d0] "v"(d[0]), [d1] "v"(d[1]), [d2] "v"(d[2]),
+                   [d3] "v"(d[3]), [d4] "v"(d[4]), [d5] "v"(d[5]), [d6] "v"(d[6]), [d7] "v"(d[7])
+                 : "memory", "scc");
+#pragma unroll
+    for (int e = 0; e < 16; e++)
+        v[e] = make_double2(w[e].x, w[e].y);
+}
+
+// the eight per-thread factors of a generalised pass (fold_device.h):
+//   pass 2 (delta = j / 16): LDS table g2s[16 s + j];  pass 3 (delta = u / 256): lane-ordered global table [8][256]
+struct G2Fetch {
+    const double2 *p;
+    int j;
+    __device__ __forceinline__ double2 operator()(int s) const { return p[16 * s + j]; }
+};
+struct G3Fetch {
+    const double2 *p;
+    int t;
+    __device__ __forceinline__ double2 operator()(int s) const
+    {   // one scalar base per two planes: the odd plane sits at immediate offset -4096 B
+        return ldg2(scalar_ptr_at(p, ((s + 1) & ~1) * 256), t - 256 * (s & 1));
+    }
+};
+
+// generalised pass whose first four factors (ga) were requested earlier; `mid()` runs between stage 3 and stage 4
+template <typename F, typename MID>
+__device__ __forceinline__ void gdft16_nr_pre(double2 (&v)[16], const double2 (&ga)[4], F fetch, MID mid)
+{
+    double2 gb[4];
+    if (MUSE_FOLD_OPT & 16) {
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+            gb[s] = fetch(4 + s);
+        fence();
+    }
+    gdft16_nr_s12(v, ga[0], ga[1]);
+    if (!(MUSE_FOLD_OPT & 16)) {
+        fence();
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+            gb[s] = fetch(4 + s);
+    }
+    fence();
+    gdft16_nr_s3(v, ga[2], ga[3]);
+    fence();
+    mid();
+    fence();
+    gdft16_nr_s4(v, gb[0], gb[1], gb[2], gb[3]);
+}
+
+// LDS record of one pair (one per parity): as in xcorr_r16_fast.hip
+constexpr int REC = 36;
+
+// cross-wave argmax combine + variance + store (lanes 0 / 1, one series each);
+// returns true when the series' statistics are NaN/Inf or the pair's sigmas are too far apart (the pair is redone)
+__device__ __forceinline__ bool finalize(const double *r, const int series, const double invN, const double invNm1,
+                                         double *mv_out, int *lag_out)
+{
+    double m[4], s[4], ix[4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        m[w] = r[6 * w + 3 * series];
+        s[w] = r[6 * w + 3 * series + 1];
+        ix[w] = r[6 * w + 3 * series + 2];
+    }
+    const double s2 = (r[24 + series] + r[26 + series]) + (r[28 + series] + r[30 + series]);
+    const Stat st{r[32 + series], s2};
+    double best = m[0], bsv = s[0], bidx = ix[0];
+#pragma unroll
+    for (int w = 1; w < 4; w++) {
+        if (m[w] > best || (m[w] == best && ix[w] < bidx)) {
+            best = m[w];
+            bsv = s[w];
+            bidx = ix[w];
+        }
+    }
+    bool zero, nan;
+    const double var = variance(st, invN, invNm1, zero, nan);
+    const int idx = (best > 0.0) ? (int)bidx : 0; // nothing above 0: index 0, mv = cc[0]
+    double y = __builtin_amdgcn_rsq(var);
+    y = y * fma(-0.5 * var * y, y, 1.5);
+    y = y * fma(-0.5 * var * y, y, 1.5);
+    double mv = ((best > 0.0) ? bsv : s[0]) * y;
+    int lag = idx > 2048 ? idx - 4096 : idx;
+    if (zero) { mv = 0.0; lag = 0; }              // xcorr.go:166-167
+    if (nan) { mv = __builtin_nan(""); lag = 0; } // placeholder: the pair is redone
+    *mv_out = mv;
+    *lag_out = lag;
+    bool redo = nan;
+    if (series == 0 && r[35] != 0.0) { // the pair's other series: sigmas too far apart for one shared transform?
+        const double s2b = (r[25] + r[27]) + (r[29] + r[31]);
+        const Stat sb{r[33], s2b};
+        bool zb, nb;
+        const double varb = variance(sb, invN, invNm1, zb, nb);
+        redo = redo || (!nb && sigma_spread_too_wide(var, varb));
+    }
+    return redo;
+}
+
+// maxAbsIndex (xcorr.go:39-50) over the wave's 16 x 64 values of both series; value of lag index t + 256 m sits in
+// register BR16(m).  Writes the wave's {max |cc|, signed value (cc[0] when nothing is above 0), index} per series.
+__device__ __forceinline__ void wave_argmax_store(const double2 (&v)[16], const int wave, const int lane, double *ra_)
+{
+    double ma = 0.0, mb = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        ma = fmax(ma, fabs(v[k].x));
+        mb = fmax(mb, fabs(v[k].y));
+    }
+    const double wa = wave_max_dpp(ma), wb = wave_max_dpp(mb);
+    int widxA = 0x7fffffff, widxB = 0x7fffffff;
+    double svA = 0.0, svB = 0.0;
+    {
+        unsigned long long selA = 0ull, selB = 0ull;
+        int kA = 0, kB = 0, hiA = 0, hiB = 0;
+#pragma unroll
+        for (int m = 15; m >= 0; m--) { // descending index: the lowest is selected last
+            const int k = BR16(m);
+            const unsigned long long mA_ = __ballot(fabs(v[k].x) == wa);
+            const unsigned long long mB_ = __ballot(fabs(v[k].y) == wb);
+            const bool hA = mA_ != 0ull, hB = mB_ != 0ull; // wave-uniform
+            selA = hA ? mA_ : selA;
+            kA = hA ? m : kA;
+            hiA = hA ? __double2hiint(v[k].x) : hiA;
+            selB = hB ? mB_ : selB;
+            kB = hB ? m : kB;
+            hiB = hB ? __double2hiint(v[k].y) : hiB;
+        }
+        if (wa > 0.0 && selA != 0ull) {
+            const int l = __ffsll((long long)selA) - 1;
+            widxA = wave * 64 + l + 256 * kA;
+            svA = (__builtin_amdgcn_readlane(hiA, l) < 0) ? -wa : wa;
+        }
+        if (wb > 0.0 && selB != 0ull) {
+            const int l = __ffsll((long long)selB) - 1;
+            widxB = wave * 64 + l + 256 * kB;
+            svB = (__builtin_amdgcn_readlane(hiB, l) < 0) ? -wb : wb;
+        }
+    }
+    const double cc0a = v[0].x, cc0b = v[0].y; // index t + 256 * 0 (BR16(0) = 0): cc[0] in wave 0 lane 0
+    if (lane == 0) {
+        ra_[0] = widxA == 0x7fffffff ? 0.0 : wa;
+        ra_[1] = widxA == 0x7fffffff ? cc0a : svA;
+        ra_[2] = (double)widxA;
+        ra_[3] = widxB == 0x7fffffff ? 0.0 : wb;
+        ra_[4] = widxB == 0x7fffffff ? cc0b : svB;
+        ra_[5] = (double)widxB;
+    }
+}
+
+// Per-lane running maxAbsIndex (xcorr.go:39-50: strictly greater replaces, so ascending indices keep the first):
+// `best` is the signed value, m its index among the lane's sixteen lags t + 256 m.
+struct ArgRun {
+    double best;
+    int m;
+};
+__device__ __forceinline__ void arg_consume(ArgRun &r, const double x, const int m)
+{
+    const bool g = fabs(x) > fabs(r.best);
+    r.best = g ? x : r.best;
+    r.m = g ? m : r.m;
+    // pinned here: IR-level passes otherwise sink a whole series' chain below the interleaved row requests (sched_barrier
+    // only binds the machine scheduler) and the consumed values stay live
+    asm volatile("" : "+v"(r.best), "+v"(r.m));
+}
+// lo chain (m = 0..7) and hi chain (m = 8..15), both ascending: the hi chain wins only when strictly greater
+__device__ __forceinline__ ArgRun arg_merge(const ArgRun &lo, const ArgRun &hi)
+{
+    ArgRun r = lo;
+    const bool g = fabs(hi.best) > fabs(lo.best);
+    r.best = g ? hi.best : lo.best;
+    r.m = g ? hi.m : lo.m;
+    return r;
+}
+// the wave's {max |cc|, signed value (cc[0] when nothing is above 0), index} of one series from the lanes' running maxima
+__device__ __forceinline__ void wave_argmax_finish(const ArgRun &r, const int t, const int lane, double *out)
+{
+    const double mine = fabs(r.best);
+    const double wa = wave_max_dpp(mine);
+    const int cand = (mine == wa && wa > 0.0) ? (t + 256 * r.m) : 0x7fffffff;
+    const int widx = wave_min_i_dpp(cand);
+    const int l = widx & 63; // wave-uniform (SGPR)
+    const double sv = readlane_f64(r.best, l);
+    if (lane == 0) { // (nothing above 0: slot 1 of wave 0 keeps cc[0], written there by the caller)
+        out[0] = widx == 0x7fffffff ? 0.0 : wa;
+        if (widx != 0x7fffffff)
+            out[1] = sv;
+        out[2] = (double)widx;
+    }
+}
+
+// spectrum multiply folded into the first stage of the second transform's plain pass:
+// z[b] at v[BR16(b)] (b = k3), xc for k3 = b from the lane-ordered table; four batches of four factors, two in flight
+template <bool PRE, typename F>
+__device__ __forceinline__ void xc_stage1(double2 (&v)[16], double2 (&xa)[4], F xcl)
+{
+    double2 xb[4];
+    // batch i covers butterflies b = 2 i, 2 i + 1: factors xc[2i], xc[2i + 8], xc[2i + 1], xc[2i + 9]
+#define MUSE_XC_LOAD(dst, i)          \
+    dst[0] = xcl(2 * (i));            \
+    dst[1] = xcl(2 * (i) + 8);        \
+    dst[2] = xcl(2 * (i) + 1);        \
+    dst[3] = xcl(2 * (i) + 9);
+#define MUSE_XC_USE(src, i)                                                      \
+    bf_xc(v[BR16(2 * (i))], v[BR16(2 * (i)) + 1], src[0], src[1]);               \
+    bf_xc(v[BR16(2 * (i) + 1)], v[BR16(2 * (i) + 1) + 1], src[2], src[3]);
+    if (!PRE) {
+        MUSE_XC_LOAD(xa, 0)
+    }
+    MUSE_XC_LOAD(xb, 1)
+    fence();
+    MUSE_XC_USE(xa, 0)
+    fence();
+    MUSE_XC_LOAD(xa, 2)
+    MUSE_XC_USE(xb, 1)
+    fence();
+    MUSE_XC_LOAD(xb, 3)
+    MUSE_XC_USE(xa, 2)
+    fence();
+    MUSE_XC_USE(xb, 3)
+#undef MUSE_XC_LOAD
+#undef MUSE_XC_USE
+}
+
+} // namespace foldk
+
+} // namespace muse

@@ -82,6 +82,7 @@ struct muse_ctx {
     char name[64] = {0};
     double2 *tw1 = nullptr, *tw2 = nullptr, *twm = nullptr;
     double2 *g2 = nullptr, *g3a = nullptr, *g3b = nullptr; // folded-twiddle tables (xcorr_r16_fold.hip)
+    double2 *twl[3] = {nullptr, nullptr, nullptr};          // xcorr_long.hip (n = 16384, 32768, 65536): [n/4096][4096] W_n^(m2 k1), built on first use
     double2 *gsmall[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // the same for xcorr_small.hip: n = 512, 1024, 2048: [8][n/16]; n = 8192: [8][32] + [8][512]; n = 16384: [8][64] + [8][1024]
     float2 *tw1f = nullptr, *tw2f = nullptr, *twmf = nullptr; // fp32 copies for the screening kernels
     // many-reference pass (muse_batch_score_many): parked spectra + device pointer tables
@@ -372,6 +373,8 @@ static void ctx_release(muse_ctx *ctx)
     (void)hipFree(ctx->g3b);
     for (int k = 0; k < 5; k++)
         (void)hipFree(ctx->gsmall[k]);
+    for (int k = 0; k < 3; k++)
+        (void)hipFree(ctx->twl[k]);
     (void)hipFree(ctx->zscratch);
     (void)hipFree(ctx->gscratch);
     for (double *b : ctx->stage_pool)
@@ -413,8 +416,8 @@ extern "C" int muse_ctx_device_info(muse_ctx *ctx, char *name, int32_t name_cap,
 
 extern "C" int muse_ctx_set_kernel(muse_ctx *ctx, int32_t variant)
 {
-    if (!ctx || !(variant == 0 || variant == 1 || variant == 7 || variant == 10 || variant == 11 || variant == 12))
-        return fail(MUSE_ERR_INVALID, "bad kernel variant (0 auto, 1 generic, 7 rescaling n=4096, 10 default n=4096, 11 Stockham, 12 n<=2048)");
+    if (!ctx || !(variant == 0 || variant == 1 || variant == 7 || variant == 10 || variant == 11 || variant == 12 || variant == 13))
+        return fail(MUSE_ERR_INVALID, "bad kernel variant (0 auto, 1 generic, 7 rescaling n=4096, 10 default n=4096, 11 Stockham, 12 half-round, 13 long series)");
     ctx->variant = variant;
     return MUSE_OK;
 }
@@ -889,9 +892,10 @@ extern "C" int muse_batch_create(muse_ctx *ctx, muse_group *g, const double *ref
         e = hipMalloc(&sp->xcf, (size_t)n * sizeof(float2));
     if (e == hipSuccess)
         e = hipMalloc(&sp->xs, (size_t)n * sizeof(double));
-    if (e == hipSuccess && n == 4096)
+    const bool long_n = n == 16384 || n == 32768 || n == 65536; // xcorr_long.hip: spectrum rows in lane order, sweep twiddles
+    if (e == hipSuccess && (n == 4096 || long_n))
         e = hipMalloc(&sp->xcp, (size_t)n * sizeof(double2));
-    if (e == hipSuccess && n == 4096 && N < 4096)
+    if (e == hipSuccess && (n == 4096 || long_n) && N < n)
         e = hipMalloc(&sp->c1, (size_t)n * sizeof(double));
     if (e != hipSuccess) {
         muse_batch_free(b);
@@ -915,6 +919,36 @@ extern "C" int muse_batch_create(muse_ctx *ctx, muse_group *g, const double *ref
         if (e != hipSuccess) {
             muse_batch_free(b);
             return fail(MUSE_ERR_HIP, "lane-order table: %s", hipGetErrorString(e));
+        }
+    }
+    if (long_n) {
+        const int li = ilog2(n) - 14, R1 = (int)(n / 4096);
+        if (!ctx->twl[li]) {
+            std::lock_guard<std::mutex> lock(ctx->stage_mu);
+            if (!ctx->twl[li]) {
+                std::vector<double2> tl((size_t)n);
+                for (int k1 = 0; k1 < R1; k1++)
+                    for (int m2 = 0; m2 < 4096; m2++)
+                        fill_twiddle(tl, (size_t)k1 * 4096 + m2, (long long)k1 * m2, n);
+                double2 *d = nullptr;
+                e = hipMalloc(&d, tl.size() * sizeof(double2));
+                if (e == hipSuccess)
+                    e = hipMemcpy(d, tl.data(), tl.size() * sizeof(double2), hipMemcpyHostToDevice);
+                if (e == hipSuccess)
+                    ctx->twl[li] = d;
+                else
+                    (void)hipFree(d);
+            }
+        }
+        if (e == hipSuccess)
+            e = launch_lane_order_rows(b->xc, b->xcp, R1, ctx->stream);
+        if (e == hipSuccess && b->c1)
+            e = launch_indicator_corr(b->xs, (int)n, (int)(n - N), b->c1, ctx->stream);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            muse_batch_free(b);
+            return fail(MUSE_ERR_HIP, "long-series tables: %s", hipGetErrorString(e));
         }
     }
     if (zero) { // muse_batch.go:39-41
@@ -1026,6 +1060,7 @@ static FusedParams base_params(muse_batch *b)
     p.gsmall = (b->logn >= 9 && b->logn <= 11) ? ctx->gsmall[b->logn - 9] : (b->logn == 13 || b->logn == 14) ? ctx->gsmall[b->logn - 10] : nullptr;
     p.xcp = b->xcp;
     p.c1 = b->c1;
+    p.twl = (b->logn >= 14 && b->logn <= 16) ? ctx->twl[b->logn - 14] : nullptr;
     p.tw1f = ctx->tw1f;
     p.twmf = ctx->twmf;
     p.tw2f = ctx->tw2f;
@@ -1076,6 +1111,8 @@ extern "C" int muse_batch_score(muse_batch *b)
         if (variant == KERNEL_R16_FOLD && ctx->variant == 0 && b->handoff_host && b->handoff_M == M &&
             (long long)*(volatile int *)b->handoff_host * 8 > p.npairs)
             variant = KERNEL_R16_OCC3;
+    } else if (b->xcp && p.twl && ((b->n >= 32768 && ctx->variant == 0) || (b->n >= 16384 && ctx->variant == 13))) {
+        variant = KERNEL_LONG; // four-step, 4096-point rows on the n = 4096 kernel's transforms (xcorr_long.hip)
     } else if (((b->n >= 512 && b->n <= 2048) || b->n == 8192 || b->n == 16384) && (ctx->variant == 0 || ctx->variant == 12)) {
         variant = KERNEL_SMALL; // half-round transposes at 16 waves per CU (xcorr_small.hip)
     } else if (((b->n >= 512 && b->n <= 2048) || b->n >= 8192) && (ctx->variant == 0 || ctx->variant == 11)) {
@@ -1119,6 +1156,25 @@ extern "C" int muse_batch_score(muse_batch *b)
             b->handoff_M = M;
             HIP_TRY(hipMemcpyAsync(b->handoff_host, b->ovf_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         }
+    } else if (variant == KERNEL_LONG) {
+        // as above: NaN / Inf and sigma-spread pairs are listed (one entry per pair) and redone by the four-step kernel that
+        // isolates and rescales the series first
+        if (2 * p.npairs > b->ovf_cap) {
+            (void)hipFree(b->ovf_list);
+            b->ovf_list = nullptr;
+            b->ovf_cap = 0;
+            HIP_TRY(hipMalloc(&b->ovf_list, (size_t)(2 * p.npairs) * sizeof(long long)));
+            b->ovf_cap = 2 * p.npairs;
+        }
+        p.ovf_count = b->ovf_count;
+        p.ovf_list = b->ovf_list;
+        HIP_TRY(hipMemsetAsync(b->ovf_count, 0, 2 * sizeof(int), ctx->stream));
+        HIP_TRY(launch_fused(p, variant, ctx->num_cus, ctx->stream));
+        FusedParams q = p;
+        q.pair_list = b->ovf_list;
+        q.pair_count = b->ovf_count;
+        q.npairs = std::min<long long>(p.npairs, (long long)ctx->num_cus * STOCKHAM_GLOBAL_WGS_PER_CU);
+        HIP_TRY(launch_fused(q, KERNEL_STOCKHAM, ctx->num_cus, ctx->stream));
     } else {
         HIP_TRY(launch_fused(p, variant, ctx->num_cus, ctx->stream));
     }
@@ -1565,7 +1621,7 @@ extern "C" int muse_batch_kernel_name(muse_batch *b, char *name, int32_t cap)
     else if ((b->n >= 512 && b->n <= 2048) || b->n == 8192 || b->n == 16384)
         k = "xcorr_fused_small";
     else if (b->n > 16384)
-        k = "xcorr_fused_stk_4step";
+        k = "xcorr_fused_long";
     snprintf(name, (size_t)cap, "%s", k);
     return MUSE_OK;
 }

@@ -77,6 +77,12 @@ __device__ __forceinline__ double2 ldg2(gptr<double2> p, int i)
     const d2v x = ((gptr<d2v>)p)[i];
     return make_double2(x.x, x.y);
 }
+// the same with an UNSIGNED 32-bit lane offset (scalar base + voffset, no 64-bit address arithmetic)
+__device__ __forceinline__ double2 ldg2u(gptr<double2> p, unsigned i)
+{
+    const d2v x = ((gptr<d2v>)p)[i];
+    return make_double2(x.x, x.y);
+}
 
 // One LDS transpose in two half rounds through the 8 x 272 buffer (positions in
 // double2 units).  Layouts (same bank analysis as xcorr_kernels.hip):

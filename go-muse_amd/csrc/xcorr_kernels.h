@@ -8,7 +8,7 @@
 
 namespace muse {
 
-enum { KERNEL_GENERIC = 0, KERNEL_R16_OCC3 = 6, KERNEL_STOCKHAM = 10, KERNEL_R16_FOLD = 11, KERNEL_SMALL = 12 };
+enum { KERNEL_GENERIC = 0, KERNEL_R16_OCC3 = 6, KERNEL_STOCKHAM = 10, KERNEL_R16_FOLD = 11, KERNEL_SMALL = 12, KERNEL_LONG = 13 };
 
 struct FusedParams {
     const double *rows; // M x N row-major, row stride `stride` elements (float64 groups)
@@ -29,7 +29,8 @@ struct FusedParams {
     const double2 *g3a;  // [8][256] first transform, pass 3: u = (t >> 4) + 16 (t & 15)
     const double2 *g3b;  // [8][256] second transform, pass 3: u = t
     const double2 *gsmall; // [8][n/16] xcorr_small.hip (n = 512, 1024, 2048): last-pass factors, delta = j / (n/16), lane-ordered
-    const double *c1;    // [4096] N < n = 4096: correlation of the valid-sample indicator with the reference (xcorr_r16_fold.hip)
+    const double2 *twl;  // [n/4096][4096] W_n^(m2 k1): the sweeps' twiddles of the long-series kernel (xcorr_long.hip)
+    const double *c1;    // [n] (n = 4096 and the long-series kernel) N < n: correlation of the valid-sample indicator with the reference (xcorr_r16_fold.hip)
     // many references in one pass (xcorr_fused_n4096_multi): device arrays of R pointers
     int R;
     const double2 *const *xcp_many; // R lane-ordered spectrum tables
@@ -78,6 +79,9 @@ hipError_t launch_fused_fold(const FusedParams &p, int num_cus, hipStream_t stre
 hipError_t launch_fused_multi(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_r16_fold.hip (R references)
 hipError_t launch_fused_small(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_small.hip (n = 512, 1024, 2048: default)
 hipError_t launch_fused_stockham(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_stockham.hip (n = 512 .. 2048, 8192 .. 65536)
+hipError_t launch_fused_long(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_long.hip (n = 32768, 65536: default; 16384)
+// out[4096 k1 + 256 k + t] = in[k1 + R1 (256 k + (t >> 4) + 16 (t & 15))]: the spectrum rows of the long-series kernel in lane order
+hipError_t launch_lane_order_rows(const double2 *in, double2 *out, int R1, hipStream_t stream);
 // out[256 k + t] = in[256 k + (t >> 4) + 16 (t & 15)], k < 16: a 4096-entry table in the lane order of xcorr_r16_fold.hip
 hipError_t launch_lane_order(const double2 *in, double2 *out, hipStream_t stream);
 // c1[k] = sum_{j >= pad} xs[(j + k) mod n]: what a series of ones at the valid (non-pad) positions correlates to
@@ -89,6 +93,9 @@ constexpr int GENERIC_LDS_MAX_N = 8192;  // larger n: the radix-2 passes run in 
 constexpr int GENERIC_MAX_N = 65536;
 constexpr int GENERIC_GLOBAL_WGS_PER_CU = 2;
 constexpr int STOCKHAM_GLOBAL_WGS_PER_CU = 2; // each holds two n-element complex scratch slices
+#ifndef MUSE_LONG_WGS_PER_CU
+#define MUSE_LONG_WGS_PER_CU 4 // xcorr_long.hip: resident workgroups per CU, one n-element slice each (tools/ablate A/B builds override)
+#endif
 hipError_t launch_direct(const double *x, int lenx, const double *y, int leny, int n, int normalize_x,
                          int normalize_y, double x_scale, double cc_scale, double *cc, int *lag, double *mv,
                          int *status, hipStream_t stream);

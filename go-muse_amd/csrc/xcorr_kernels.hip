@@ -440,6 +440,18 @@ hipError_t launch_indicator_corr(const double *xs, int n, int pad, double *c1, h
     return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void lane_order_rows_kernel(const double2 *__restrict__ in, double2 *__restrict__ out, int R1)
+{
+    const int t = threadIdx.x, k = blockIdx.x, k1 = blockIdx.y;
+    out[4096 * k1 + 256 * k + t] = in[k1 + R1 * (256 * k + (t >> 4) + 16 * (t & 15))];
+}
+
+hipError_t launch_lane_order_rows(const double2 *in, double2 *out, int R1, hipStream_t stream)
+{
+    hipLaunchKernelGGL(lane_order_rows_kernel, dim3(16, (unsigned)R1), dim3(256), 0, stream, in, out, R1);
+    return hipGetLastError();
+}
+
 hipError_t launch_lane_order(const double2 *in, double2 *out, hipStream_t stream)
 {
     hipLaunchKernelGGL(lane_order_kernel, dim3(16), dim3(256), 0, stream, in, out);
@@ -454,6 +466,8 @@ hipError_t launch_fused(const FusedParams &p, int variant, int num_cus, hipStrea
         return launch_fused_fold(p, num_cus, stream);
     if (variant == KERNEL_SMALL)
         return launch_fused_small(p, num_cus, stream);
+    if (variant == KERNEL_LONG)
+        return launch_fused_long(p, num_cus, stream);
     if (variant == KERNEL_STOCKHAM)
         return launch_fused_stockham(p, num_cus, stream);
     if (variant == KERNEL_R16_OCC3)

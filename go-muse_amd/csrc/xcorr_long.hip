@@ -1,0 +1,479 @@
+// xcorr_long.hip -- long series, n = 16384 (test hook), 32768, 65536: xCorrWithX (/root/reference/xcorr.go:160-197) as a
+// four-step transform whose 4096-point rows run on the n = 4096 kernel's folded-arithmetic machinery
+// (foldk_device.h) at 16 waves per CU.
+//
+// n = R1 * 4096 (R1 = 4, 8, 16), input index m1 * 4096 + m2, spectrum index k1 + R1 * k2, lag index l1 * 4096 + l2:
+//   Z[k1 + R1 k2]   = sum_m2 W_4096^(m2 k2) [ W_n^(m2 k1) sum_m1 W_R1^(m1 k1) d[m1 4096 + m2] ]
+//   cc[l1 4096 + l2] = sum_k1 W_R1^(k1 l1) [ W_n^(k1 l2) sum_k2 W_4096^(k2 l2) Z[k1 + R1 k2] xc[k1 + R1 k2] ]
+// sweep 1: rows of the group -> d = x - K (K = the series' first sample), shifted statistics, radix R1 over m1 in
+//          registers, twiddle W_n^(m2 k1) -> the workgroup's scratch slice Y[k1][m2] (n complex, L2 / MALL / HBM);
+// rows:    for each k1 the 4096 points Y[k1][.] -> forward transform, multiply by xc[k1 + R1 k2] (folded into the first
+//          stage of the second transform), forward transform -> back to Y[k1][.]: exactly the n = 4096 kernel's two
+//          transforms (three radix-16 passes each, half-round LDS transposes, 34.8 KB of LDS per workgroup);
+// sweep 2: twiddle W_n^(k1 l2), radix R1 over k1 -> cc; (N < n: minus mean * c1[lag]) ; running argmax.
+// The pair crosses the scratch slice four times (2 writes + 2 reads of 16 n bytes) next to its 16 N bytes of HBM input:
+// that traffic, not arithmetic, bounds the kernel.
+//
+// As in xcorr_r16_fold.hip both series of a pair share one complex transform UNSCALED (their statistics are only known
+// behind sweep 1): pairs with a NaN / Inf series or with sigmas too far apart are listed and redone by the kernel that
+// rescales first (xcorr_stockham.hip, xcorr_fused_stk_4step).  N == n: the mean is never subtracted -- bin 0 of the
+// centred series is exactly 0 and is zeroed in row 0.  N < n (leading zero pad, xcorr.go:176-181): the transforms run on
+// d and every lag is corrected by -mean(d) c1[lag], c1 = the correlation of the valid-sample indicator with the
+// reference (one table per batch).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <algorithm>
+
+#include "xcorr_kernels.h"
+#include "fft_device.h"
+#include "foldk_device.h"
+
+// MUSE_LONG_EXP (tools/ablate only; never defined in the library build; results are wrong): bit 0 = no rows phase, bit 1 = rows
+// loaded and stored but not transformed, bit 2 = no sweep 2, bit 3 = sweep 1 without its stores
+#ifndef MUSE_LONG_EXP
+#define MUSE_LONG_EXP 0
+#endif
+
+namespace muse {
+
+namespace lng {
+
+using namespace occ4;
+using namespace fold;
+using namespace foldk;
+
+template <int R>
+__device__ __forceinline__ constexpr int brev(int k)
+{
+    int r = 0;
+    for (int b = 1; b < R; b <<= 1)
+        r = (r << 1) | ((k & b) ? 1 : 0);
+    return r;
+}
+
+// radix-R DFT (forward sign) over the registers m + s Q1, s = 0 .. R-1 natural; output k at register m + brev<R>(k) Q1
+template <int R>
+__device__ __forceinline__ void sweep_dft(double2 (&v)[16])
+{
+    constexpr int Q1 = 16 / R;
+    if (R == 16) {
+        dft16_nr(v); // (148 instructions; output k at v[BR16(k)])
+        return;
+    }
+#pragma unroll
+    for (int len = R; len >= 2; len >>= 1) {
+        const int half = len / 2;
+#pragma unroll
+        for (int base = 0; base < R; base += len) {
+#pragma unroll
+            for (int k = 0; k < half; k++) {
+                // W_len^k = c - i s (constants after unrolling)
+                const double c = __builtin_cos(6.283185307179586476925 * (double)k / (double)len);
+                const double s = __builtin_sin(6.283185307179586476925 * (double)k / (double)len);
+#pragma unroll
+                for (int m = 0; m < Q1; m++) {
+                    double2 &a = v[m + (base + k) * Q1], &b = v[m + (base + k + half) * Q1];
+                    const double2 u = a, x = b;
+                    a = make_double2(u.x + x.x, u.y + x.y);
+                    const double dx = u.x - x.x, dy = u.y - x.y;
+                    if (k == 0)
+                        b = make_double2(dx, dy);
+                    else if (4 * k == len)
+                        b = make_double2(dy, -dx);
+                    else
+                        b = make_double2(fma(dy, s, dx * c), fma(-dx, s, dy * c));
+                }
+            }
+        }
+    }
+}
+
+// the n = 4096 kernel's pair of transforms on one row (xcorr_r16_fold.hip, default scheduling): x[t + 256 i] at v[i] ->
+// FFT, times the lane-ordered spectrum row `xrow`, FFT -> element t + 256 m at v[BR16(m)].  zero0: bin 0 is zeroed.
+__device__ __forceinline__ void row_transforms(double2 (&v)[16], double2 *xbuf, double2 *xw, const double2 *g2s,
+                                               const double2 *__restrict__ g3a, const double2 *__restrict__ g3b,
+                                               const double2 *__restrict__ xrow, const int t, const int wave, const bool zero0)
+{
+    int tx = t, tg = t;
+    const auto xcl = [&](int j) __attribute__((always_inline)) {
+        return ldg2(scalar_ptr_at(xrow, 256 * ((j + 1) & ~1)), tx - 256 * (j & 1));
+    };
+    const auto g3 = [&](const double2 *tab, int s) __attribute__((always_inline)) { return G3Fetch{tab, tg}(s); };
+    double2 ga[4], xa[4];
+    // ---- first transform: plain pass over a, generalised passes over b (delta = k1 / 16) and c (delta = (k1 + 16 k2) / 256)
+    dft16_nr(v);
+    exchange_cross<0, 1, true>(v, xbuf, wave, t);
+    gdft16_nr(v, G2Fetch{g2s, t >> 4});
+    exchange_local<1>(v, xw, t);
+    tg = fresh<8>(t);
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        ga[q] = g3(g3a, q);
+    gdft16_nr_pre(v, ga, [&](int q) __attribute__((always_inline)) { return g3(g3a, q); }, [&]() __attribute__((always_inline)) {});
+    if (zero0) {
+        v[0].x = (t == 0) ? 0.0 : v[0].x;
+        v[0].y = (t == 0) ? 0.0 : v[0].y;
+    }
+    // ---- second transform: plain pass with the spectrum factors folded into its first stage, then the two generalised ones
+    tx = fresh<8>(t);
+    xc_stage1<false>(v, xa, xcl);
+    dft16_rn_s234(v);
+    exchange_local<0>(v, xw, t);
+    gdft16_nr(v, G2Fetch{g2s, t & 15});
+    exchange_cross<1, 1>(v, xbuf, wave, t);
+    tg = fresh<8>(t);
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        ga[q] = g3(g3b, q);
+    gdft16_nr_pre(v, ga, [&](int q) __attribute__((always_inline)) { return g3(g3b, q); }, [&]() __attribute__((always_inline)) {});
+}
+
+} // namespace lng
+
+// QD: quads (256 threads: the unit of a sweep chunk and of a row transform) per workgroup.  QD = 1: four independent
+// workgroups per CU, four pairs (slices) in flight per CU; QD = 4: one 1024-thread workgroup per CU whose quads take
+// chunks and rows in turn -- one pair per CU in flight, i.e. a quarter of the scratch footprint (n = 32768: 128 MB chip-wide,
+// inside the 256 MiB Infinity Cache) for the same 16 waves per CU; the quads' transposes then share the workgroup barriers.
+template <int LOGN, bool PADDED, int QD>
+__global__ __launch_bounds__(256 * QD, 4) void xcorr_fused_long(const FusedParams p)
+{
+    using namespace occ4;
+    using namespace fold;
+    using namespace foldk;
+    using namespace lng;
+    constexpr int n = 1 << LOGN;
+    constexpr int S = n / 16;     // a thread's 16 elements of a sweep: j + i S
+    constexpr int CH = S / 256;   // chunks of 256 threads x 16 elements per sweep
+    constexpr int R1 = n / 4096;  // rows
+    constexpr int Q1 = 16 / R1;   // butterflies of radix R1 per thread and chunk
+    constexpr int NW = 4 * QD;    // waves
+    static_assert(LOGN >= 14 && LOGN <= 16, "n = 16384, 32768, 65536");
+    static_assert(QD == 1 || QD == 4, "one or four quads");
+    __shared__ double2 xbuf_all[QD * OCC_XBUF];
+    __shared__ double2 g2s[128];
+    __shared__ double red[4 * NW + 2 * NW + 2];
+    __shared__ int redi[2 * NW];
+    const int tw = threadIdx.x, lane = tw & 63;
+    const int wave_all = __builtin_amdgcn_readfirstlane(tw >> 6);
+    const int qd = QD == 1 ? 0 : (wave_all >> 2), wave = wave_all & 3; // quad, wave of the quad (wave-uniform)
+    const int t = tw & 255;                                            // thread of the quad
+    double2 *const xbuf = xbuf_all + qd * OCC_XBUF;
+    double2 *const xw = xbuf + XW * wave;
+    double2 *const Y = p.gscratch + (size_t)blockIdx.x * (size_t)n; // the workgroup's slice
+    const int N = PADDED ? p.N : n, pad = n - N;
+    const double invN = 1.0 / (double)N, invNm1 = 1.0 / (double)(N - 1);
+    const double2 *__restrict__ twl = p.twl; // [R1][4096] W_n^(m2 k1)
+    // addresses: a scalar base formed where it is used plus one 32-bit lane offset (nothing 64-bit per lane, nothing
+    // hoisted out of the loops into registers the transforms need)
+    typedef d2v __attribute__((address_space(1))) *gd2;
+    const auto yat = [&](long long off) __attribute__((always_inline)) { return (gd2)scalar_ptr_at(Y, off); };
+    const auto opaque = [](int x) __attribute__((always_inline)) {
+        asm volatile("" : "+v"(x));
+        return x;
+    };
+    constexpr int T = Q1 * (R1 - 1), NB = (T + 3) / 4; // twiddle factors per thread and chunk: (m, k1 >= 1) at f = m (R1 - 1) + k1 - 1
+    const auto tw_load = [&](int f, unsigned jj) __attribute__((always_inline)) {
+        const int m = f / (R1 - 1), k1 = 1 + f % (R1 - 1);
+        return ldg2u(scalar_ptr_at(twl, k1 * 4096 + m * S), jj);
+    };
+    if (tw < 128)
+        g2s[tw] = p.g2[tw];
+    __syncthreads();
+
+    for (long long pair = blockIdx.x; pair < p.npairs; pair += gridDim.x) {
+        const long long rA = 2 * pair;
+        const bool hasB = rA + 1 < p.M;
+        const double *__restrict__ ra = p.rows + rA * p.stride;
+        const double *__restrict__ rb = p.rows + (hasB ? rA + 1 : rA) * p.stride;
+        const double KA = ra[0], KB = rb[0];
+        // ---------------- sweep 1
+        double q[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma clang loop unroll(disable)
+        for (int ch = qd; ch < CH; ch += QD) {
+            const int j = opaque(t + 256 * ch) & (S - 1);
+            double2 v[16];
+            // all 32 requests first (a request behind a consumer would wait for it: the address asm statements keep program
+            // order), then the values in request order
+            double xa[16], xb[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                if (PADDED) {
+                    const int e = j + i * S - pad;
+                    const unsigned ec = (unsigned)(e < 0 ? 0 : e);
+                    xa[i] = __builtin_nontemporal_load(scalar_ptr(ra) + ec);
+                    xb[i] = __builtin_nontemporal_load(scalar_ptr(rb) + ec);
+                } else {
+                    xa[i] = __builtin_nontemporal_load(scalar_ptr_at(ra, i * S) + (unsigned)j);
+                    xb[i] = __builtin_nontemporal_load(scalar_ptr_at(rb, i * S) + (unsigned)j);
+                }
+            }
+            fence();
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                double da = xa[i] - KA, db = xb[i] - KB;
+                if (PADDED) {
+                    const bool valid = j + i * S - pad >= 0;
+                    da = valid ? da : 0.0;
+                    db = valid ? db : 0.0;
+                }
+                v[i] = make_double2(da, db);
+                q[0] += da;
+                q[1] = fma(da, da, q[1]);
+                q[2] += db;
+                q[3] = fma(db, db, q[3]);
+            }
+            // the sweep's twiddles W_n^(m2 k1), k1 >= 1: T factors per thread and chunk in batches of four, two batches in
+            // flight; the first one travels behind the row requests
+            double2 wq[2][4];
+            {
+                const unsigned jw = (unsigned)(opaque(t + 256 * ch) & (S - 1));
+#pragma unroll
+                for (int f = 0; f < 4 && f < T; f++)
+                    wq[0][f] = tw_load(f, jw);
+            }
+            fence();
+            sweep_dft<R1>(v);
+            const unsigned js = (unsigned)(opaque(t + 256 * ch) & (S - 1));
+#pragma unroll
+            for (int m = 0; m < Q1; m++) { // row 0: no twiddle
+                if (MUSE_LONG_EXP & 8) {   // (keeps the values alive without the store)
+                    asm volatile("" ::"v"(v[m].x), "v"(v[m].y));
+                } else
+                    yat((long long)m * S)[js] = d2v{v[m].x, v[m].y};
+            }
+#pragma unroll
+            for (int bt = 0; bt < NB; bt++) {
+                fence();
+                if (bt + 1 < NB) {
+#pragma unroll
+                    for (int f = 4 * (bt + 1); f < 4 * (bt + 2) && f < T; f++)
+                        wq[(bt + 1) & 1][f & 3] = tw_load(f, js);
+                }
+                fence();
+#pragma unroll
+                for (int f = 4 * bt; f < 4 * (bt + 1) && f < T; f++) {
+                    // element m2 = j + m S of row k1: register m + brev(k1) Q1, position j + (m + k1 Q1) S
+                    const int m = f / (R1 - 1), k1 = 1 + f % (R1 - 1);
+                    const double2 z = cmul(v[m + brev<R1>(k1) * Q1], wq[bt & 1][f & 3]);
+                    if (MUSE_LONG_EXP & 8) {
+                        asm volatile("" ::"v"(z.x), "v"(z.y));
+                    } else
+                        yat((long long)(m + k1 * Q1) * S)[js] = d2v{z.x, z.y};
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const double w = wave_sum_dpp(q[k]);
+            if (lane == 0)
+                red[4 * wave_all + k] = w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            double w = red[k];
+#pragma unroll
+            for (int x = 1; x < NW; x++)
+                w += red[4 * x + k];
+            q[k] = w;
+        }
+        q[0] = readlane_f64(q[0], 0); // (workgroup-uniform: into SGPRs, not four VGPR pairs across the row transforms)
+        q[1] = readlane_f64(q[1], 0);
+        q[2] = readlane_f64(q[2], 0);
+        q[3] = readlane_f64(q[3], 0);
+        bool zeroA, nanA, zeroB, nanB;
+        const double varA = variance(Stat{q[0], q[1]}, invN, invNm1, zeroA, nanA);
+        const double varB = variance(Stat{q[2], q[3]}, invN, invNm1, zeroB, nanB);
+        const double mA = q[0] * invN, mB = q[2] * invN;
+        __syncthreads(); // the slice is complete (and `red` is free again)
+        // ---------------- rows
+#pragma clang loop unroll(disable)
+        for (int k1 = qd; k1 < ((MUSE_LONG_EXP & 1) ? 0 : R1); k1 += QD) {
+            double2 *const row = Y + k1 * 4096;
+            double2 v[16];
+            {
+                const unsigned tl = (unsigned)(opaque(t) & 255);
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const d2v z = ((gd2)scalar_ptr_at(row, 256 * i))[tl];
+                    v[i] = make_double2(z.x, z.y);
+                }
+            }
+            if (!(MUSE_LONG_EXP & 2))
+                row_transforms(v, xbuf, xw, g2s, p.g3a, p.g3b, p.xcp + k1 * 4096, t, wave, !PADDED && k1 == 0);
+            {
+                const unsigned tl = (unsigned)(opaque(t) & 255);
+#pragma unroll
+                for (int m = 0; m < 16; m++)
+                    ((gd2)scalar_ptr_at(row, 256 * m))[tl] = d2v{v[BR16(m)].x, v[BR16(m)].y};
+            }
+        }
+        __syncthreads();
+        // ---------------- sweep 2 with the running argmax (maxAbsIndex, xcorr.go:39-50: first index of the greatest |cc|)
+        double ma = 0.0, mb = 0.0, sa = 0.0, sb = 0.0, cc0a = 0.0, cc0b = 0.0;
+        int ia = 0x7fffffff, ib = 0x7fffffff;
+#pragma clang loop unroll(disable)
+        for (int ch = qd; ch < ((MUSE_LONG_EXP & 4) ? 0 : CH); ch += QD) {
+            const int j = opaque(t + 256 * ch) & (S - 1);
+            double2 v[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const d2v z = yat((long long)i * S)[(unsigned)j];
+                v[i] = make_double2(z.x, z.y);
+            }
+            {
+                double2 wq[2][4];
+#pragma unroll
+                for (int f = 0; f < 4 && f < T; f++)
+                    wq[0][f] = tw_load(f, (unsigned)j);
+#pragma unroll
+                for (int bt = 0; bt < NB; bt++) {
+                    fence();
+                    if (bt + 1 < NB) {
+#pragma unroll
+                        for (int f = 4 * (bt + 1); f < 4 * (bt + 2) && f < T; f++)
+                            wq[(bt + 1) & 1][f & 3] = tw_load(f, (unsigned)j);
+                    }
+                    fence();
+#pragma unroll
+                    for (int f = 4 * bt; f < 4 * (bt + 1) && f < T; f++) {
+                        const int m = f / (R1 - 1), k1 = 1 + f % (R1 - 1);
+                        v[m + k1 * Q1] = cmul(v[m + k1 * Q1], wq[bt & 1][f & 3]);
+                    }
+                }
+            }
+            sweep_dft<R1>(v);
+            // the chunk's first maximum per lane (ascending i = ascending lag index: strictly greater keeps the first) ...
+            double csa = 0.0, csb = 0.0;
+            int cia = 0, cib = 0;
+            const int jc = opaque(t + 256 * ch) & (S - 1);
+#pragma unroll
+            for (int i = 0; i < 16; i++) { // i = m + l1 Q1: lag index j + i S
+                const int m = i % Q1, l1 = i / Q1;
+                double2 c = v[m + brev<R1>(l1) * Q1];
+                if (PADDED) {
+                    const double c1 = scalar_ptr_at(p.c1, i * S)[(unsigned)jc];
+                    c = make_double2(fma(-mA, c1, c.x), fma(-mB, c1, c.y));
+                }
+                if (i == 0) { // (lane 0 of chunk 0: cc[0], the value reported when nothing is above 0)
+                    cc0a = ch == 0 ? c.x : cc0a; // (chunk 0 belongs to quad 0)
+                    cc0b = ch == 0 ? c.y : cc0b;
+                }
+                const bool ga = fabs(c.x) > fabs(csa), gb = fabs(c.y) > fabs(csb);
+                csa = ga ? c.x : csa;
+                cia = ga ? i : cia;
+                csb = gb ? c.y : csb;
+                cib = gb ? i : cib;
+            }
+            // ... merged into the lane's running one (chunks are not in index order: ties go to the lower index)
+            {
+                const int xa_ = jc + cia * S, xb_ = jc + cib * S;
+                const double ca_ = fabs(csa), cb_ = fabs(csb);
+                const bool ta = (ca_ > ma) | ((ca_ == ma) & (ca_ > 0.0) & (xa_ < ia));
+                const bool tb = (cb_ > mb) | ((cb_ == mb) & (cb_ > 0.0) & (xb_ < ib));
+                ma = ta ? ca_ : ma;
+                sa = ta ? csa : sa;
+                ia = ta ? xa_ : ia;
+                mb = tb ? cb_ : mb;
+                sb = tb ? csb : sb;
+                ib = tb ? xb_ : ib;
+            }
+        }
+        // ---------------- workgroup argmax (first index of the maximum); the owner thread stores
+        {
+            constexpr int RM = 4 * NW, RC = 4 * NW + 2 * NW; // red: [RM + x] wave maxima A, [RM + NW + x] B, [RC], [RC + 1] cc[0]
+            const double wa = wave_max(ma), wb = wave_max(mb);
+            if (lane == 0) {
+                red[RM + wave_all] = wa;
+                red[RM + NW + wave_all] = wb;
+            }
+            if (tw == 0) {
+                red[RC] = cc0a;
+                red[RC + 1] = cc0b;
+            }
+            __syncthreads();
+            double MA = red[RM], MB = red[RM + NW];
+#pragma unroll
+            for (int x = 1; x < NW; x++) {
+                MA = fmax(MA, red[RM + x]);
+                MB = fmax(MB, red[RM + NW + x]);
+            }
+            int ca = (ma == MA && MA > 0.0) ? ia : 0x7fffffff;
+            int cb = (mb == MB && MB > 0.0) ? ib : 0x7fffffff;
+            ca = wave_min_i(ca);
+            cb = wave_min_i(cb);
+            if (lane == 0) {
+                redi[wave_all] = ca;
+                redi[NW + wave_all] = cb;
+            }
+            __syncthreads();
+            int IA = redi[0], IB = redi[NW];
+#pragma unroll
+            for (int x = 1; x < NW; x++) {
+                IA = min(IA, redi[x]);
+                IB = min(IB, redi[NW + x]);
+            }
+#pragma unroll
+            for (int sidx = 0; sidx < 2; sidx++) {
+                if (sidx == 1 && !hasB)
+                    break;
+                const int I = sidx ? IB : IA;
+                const bool none = I == 0x7fffffff;
+                const bool owner = none ? (tw == 0) : ((sidx ? ib : ia) == I && (sidx ? mb : ma) == (sidx ? MB : MA));
+                if (owner) {
+                    const double var = sidx ? varB : varA;
+                    const bool zero = sidx ? zeroB : zeroA, nan = sidx ? nanB : nanA;
+                    double y = __builtin_amdgcn_rsq(var);
+                    y = y * fma(-0.5 * var * y, y, 1.5);
+                    y = y * fma(-0.5 * var * y, y, 1.5);
+                    const int idx = none ? 0 : I;
+                    double mv = (none ? red[RC + sidx] : (sidx ? sb : sa)) * y;
+                    int lag = idx > n / 2 ? idx - n : idx;
+                    if (zero) { mv = 0.0; lag = 0; }              // xcorr.go:166-167
+                    if (nan) { mv = __builtin_nan(""); lag = 0; } // placeholder: the pair is redone
+                    p.mv[rA + sidx] = mv;
+                    p.lag[rA + sidx] = lag;
+                }
+            }
+            // a NaN / Inf series poisons its partner through the shared transform, and sigmas too far apart cost the
+            // smaller series its precision: such pairs are redone by the kernel that isolates and rescales first
+            if (tw == 0 && (nanA || (hasB && (nanB || sigma_spread_too_wide(varA, varB))))) {
+                const int slot = atomicAdd(p.ovf_count, 1);
+                p.ovf_list[slot] = pair;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// MUSE_LONG_QD: quads per workgroup.  The library builds 1; 4 is a tools/ablate A/B build (measured slower at n = 32768
+// and 65536, profiles/r02_long_series.txt: the slices' reuse distance, not their sum, decides what the Infinity Cache keeps)
+#ifndef MUSE_LONG_QD
+#define MUSE_LONG_QD 1
+#endif
+template <int LOGN, int QD>
+static hipError_t launch_long_n(const FusedParams &p, int num_cus, hipStream_t stream)
+{
+    const long long grid = std::min<long long>(p.npairs, (long long)num_cus * (QD == 4 ? 1 : MUSE_LONG_WGS_PER_CU));
+    if (p.N < (1 << LOGN))
+        hipLaunchKernelGGL((xcorr_fused_long<LOGN, true, QD>), dim3((unsigned)grid), dim3(256 * QD), 0, stream, p);
+    else
+        hipLaunchKernelGGL((xcorr_fused_long<LOGN, false, QD>), dim3((unsigned)grid), dim3(256 * QD), 0, stream, p);
+    return hipGetLastError();
+}
+
+// n = 16384, 32768, 65536 (float64 rows, every pair: no pair list); N in (n/2, n], N < n needs p.c1
+hipError_t launch_fused_long(const FusedParams &p, int num_cus, hipStream_t stream)
+{
+    if (!p.rows || !p.gscratch || !p.twl || !p.xcp || !p.g2 || !p.g3a || !p.g3b || !p.ovf_list || !p.ovf_count || p.pair_list ||
+        (p.N < p.n && !p.c1))
+        return hipErrorInvalidValue;
+    switch (p.logn) {
+    case 14: return launch_long_n<14, MUSE_LONG_QD>(p, num_cus, stream);
+    case 15: return launch_long_n<15, MUSE_LONG_QD>(p, num_cus, stream);
+    case 16: return launch_long_n<16, MUSE_LONG_QD>(p, num_cus, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+} // namespace muse

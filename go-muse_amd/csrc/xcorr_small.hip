@@ -37,11 +37,6 @@ using namespace occ4;
 using namespace fold;
 
 constexpr int padk(int x) { return x + (x >> 4); }
-__device__ __forceinline__ double2 ldg2u(gptr<double2> p, unsigned i)
-{
-    const d2v x = ((gptr<d2v>)p)[i];
-    return make_double2(x.x, x.y);
-}
 
 // ---- reductions over the S lanes of a pair; every lane of the pair gets the result.  S > 64 (one pair per workgroup,
 // S / 64 waves): through `red`, S / 64 doubles of LDS, two workgroup barriers.

@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256, 2) void xcorr_fused_stk_4step(const FusedParam
     __shared__ double red[64];
     __shared__ int redi[16];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    double2 *const Y = p.gscratch + (size_t)blockIdx.x * (size_t)(2 * n);
+    double2 *const Y = p.gscratch + (size_t)blockIdx.x * (size_t)n; // the workgroup's slice: one pair
     const int N = p.N, pad = n - N;
     const double invN = 1.0 / (double)N, invNm1 = 1.0 / (double)(N - 1);
     const double2 *__restrict__ twm = p.twm;
@@ -689,12 +689,16 @@ __global__ __launch_bounds__(256, 2) void xcorr_fused_stk_4step(const FusedParam
     }
 }
 
+// resident workgroups (each with an n-element scratch slice the pair crosses four times): per 8 CUs
+#ifndef MUSE_4STEP_WGS_PER_8CU
+#define MUSE_4STEP_WGS_PER_8CU 16
+#endif
 template <int LOGN>
 static hipError_t launch_stk_4step(const FusedParams &p, int num_cus, hipStream_t stream)
 {
     if (!p.gscratch)
         return hipErrorInvalidValue;
-    const long long grid = std::min<long long>(p.npairs, (long long)num_cus * STOCKHAM_GLOBAL_WGS_PER_CU);
+    const long long grid = std::min<long long>(p.npairs, (long long)num_cus * MUSE_4STEP_WGS_PER_8CU / 8);
     hipLaunchKernelGGL((xcorr_fused_stk_4step<LOGN>), dim3((unsigned)grid), dim3(256), 0, stream, p);
     return hipGetLastError();
 }

@@ -247,19 +247,29 @@ static void TestFirstUseConcurrent()
     for (int i = 0; i < N; i++)
         base[i] = std::sin(0.05 * i) + (i >= 100 && i < 120 ? 2.0 : 0.0) + 1e-3 * ((i * 2654435761u) % 97);
     std::vector<Scores> out(T);
+    std::vector<int> status(T, 0);
+    std::vector<std::string> what(T);
     std::vector<std::thread> th;
     for (int w = 0; w < T; w++)
         th.emplace_back([&, w] {
-            auto ref = NewSeries(base, NewLabels({{"graph", "ref"}}));
-            std::vector<double> y(N);
-            for (int i = 0; i < N; i++)
-                y[i] = base[(i + 3) % N] * 2.0 + 1.0;
-            auto m = New(ref, NewResults(N, 4, 0, SignFilter_ANY)); // <- first use of the engine, T threads at once
-            m->Run({NewSeries(y, NewLabels({{"graph", "g"}, {"host", "h" + std::to_string(w)}}))});
-            out[w] = m->Results_->Fetch().first;
+            try {
+                auto ref = NewSeries(base, NewLabels({{"graph", "ref"}}));
+                std::vector<double> y(N);
+                for (int i = 0; i < N; i++)
+                    y[i] = base[(i + 3) % N] * 2.0 + 1.0;
+                auto m = New(ref, NewResults(N, 4, 0, SignFilter_ANY)); // <- first use of the engine, T threads at once
+                m->Run({NewSeries(y, NewLabels({{"graph", "g"}, {"host", "h" + std::to_string(w)}}))});
+                out[w] = m->Results_->Fetch().first;
+            } catch (const Error &e) { // (an exception must not leave a thread: reported by the main thread below)
+                status[w] = e.status;
+                what[w] = e.what();
+            }
         });
     for (auto &t : th)
         t.join();
+    for (int w = 0; w < T; w++)
+        if (status[w])
+            throw Error(status[w], what[w]);
     for (int w = 0; w < T; w++) {
         EXPECT(out[w].size() == 1, "first use, thread %d: %zu scores", w, out[w].size());
         if (out[w].size() == 1 && out[0].size() == 1) {

@@ -604,13 +604,14 @@ def test_stockham_kernels_match_oracle_and_generic(muse, eng, oracle, N):
     try:
         got = {}
         small = db.n <= 2048 or db.n in (8192, 16384)   # lengths the half-round kernel (xcorr_small.hip) is built for
-        for variant in (0, 11, 12, 1) if small else (0, 11, 1):
+        variants = ((0, 11, 12, 1) if small else (0, 11, 1)) + ((13,) if db.n >= 16384 else ())   # 13: xcorr_long.hip
+        for variant in variants:
             eng.set_kernel(variant)
             lag, mv = db.scores()
             assert math.isnan(mv[10]) and lag[10] == 0 and math.isnan(mv[12]) and lag[12] == 0, variant
             assert_scores_match(lag, mv, olag, omv, gap)
             got[variant] = (lag, mv)
-        auto = 12 if small else 11               # what automatic selection takes for this length
+        auto = 13 if db.n >= 32768 else 12 if small else 11      # what automatic selection takes for this length
         assert np.array_equal(got[0][0], got[auto][0]) and np.array_equal(got[0][1], got[auto][1], equal_nan=True)
     finally:
         eng.set_kernel(0)

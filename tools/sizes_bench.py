@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Fused-kernel time per FFT length: automatic kernel selection against the radix-2 generic kernel.
-usage: sizes_bench.py [bytes_per_group] [N ...]"""
+usage: sizes_bench.py [bytes_per_group] [N ...]   (SIZES_AUTO_ONLY=1: skip the generic kernel)"""
 import importlib
 import os
 import sys
@@ -16,7 +16,7 @@ for N in Ns:
     dg, ref = pkg.DeviceGroup.synthetic(eng, rows, N)
     db = pkg.DeviceBatch(eng, dg, ref)
     out = []
-    for variant in (0, 1):
+    for variant in ((0,) if os.environ.get("SIZES_AUTO_ONLY") else (0, 1)):
         if variant == 1 and db.n == 4096:
             continue
         eng.set_kernel(variant)
