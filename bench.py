@@ -107,7 +107,7 @@ def main():
                     help="also time muse_batch_run_many with this many references (N=1 only; 0 = skip); "
                          "reported as an extra object, never as `value`")
     ap.add_argument("--no-extras", action="store_true",
-                    help="skip the extra objects (filter_and_refine_run, f32_storage_group, many_references)")
+                    help="skip the extra objects (filter_and_refine_run, f32_storage_group, many_references, config5_lengths)")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the RCCL gather path even with one rank (rehearsal on a 1-GPU box)")
     args = ap.parse_args()
@@ -291,6 +291,34 @@ def main():
                                        "ms_per_run": dtm * 1e3, "dtype": "f64",
                                        "note": "muse_batch_run_many: one pass over the rows for all references"}
             del bs
+        if extras:
+            # BASELINE config 5's lengths (N zero-padded to the next power of two), float64: one all-scores pass per length
+            # over a ~1 GB group of its own; per length the kernel automatic selection takes and its share of the HBM
+            # roofline on 8 N + 16 algorithmic bytes per series.  Parity per length: tests/test_gpu_parity.py.
+            per_len = []
+            for Nl in (512, 1000, 5000, 16384, 65536):
+                try:
+                    rows_l = max(2048, min(400_000, (1 << 30) // (8 * Nl)))
+                    dgl, refl = pkg.DeviceGroup.synthetic(eng, rows_l, Nl, seed=0x6D757365)
+                    dbl = pkg.DeviceBatch(eng, dgl, refl)
+                    dbl.score()
+                    eng.synchronize()
+                    eng.kernel_time()
+                    eng.kernel_timing(True)
+                    for _ in range(3):
+                        dbl.score()
+                    eng.synchronize()
+                    eng.kernel_timing(False)
+                    kl_ms, kl_cnt = eng.kernel_time()
+                    kl_s = kl_ms / max(kl_cnt, 1) * 1e-3
+                    per_len.append({"N": Nl, "fft_len": dbl.n, "rows": rows_l, "kernel": eng.kernel_name(dbl),
+                                    "kernel_ms_avg": kl_s * 1e3, "series_per_s": rows_l / kl_s,
+                                    "roofline_frac": rows_l * (8.0 * Nl + 16.0) / kl_s / 1e9 / HBM_PEAK_GBPS})
+                    dbl.close()
+                    dgl.close()
+                except Exception as e:
+                    per_len.append({"N": Nl, "error": str(e)})
+            line["config5_lengths"] = per_len
         if n_gpus == 1 and not use_dist and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(dg, ref, N)
         print(json.dumps(line), flush=True)
