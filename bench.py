@@ -293,12 +293,12 @@ def main():
             del bs
         if extras:
             # BASELINE config 5's lengths (N zero-padded to the next power of two), float64: one all-scores pass per length
-            # over a ~1 GB group of its own; per length the kernel automatic selection takes and its share of the HBM
+            # over a ~4 GB group of its own; per length the kernel automatic selection takes and its share of the HBM
             # roofline on 8 N + 16 algorithmic bytes per series.  Parity per length: tests/test_gpu_parity.py.
             per_len = []
             for Nl in (512, 1000, 5000, 16384, 65536):
                 try:
-                    rows_l = max(2048, min(400_000, (1 << 30) // (8 * Nl)))
+                    rows_l = max(2048, min(400_000, (1 << 32) // (8 * Nl)))
                     dgl, refl = pkg.DeviceGroup.synthetic(eng, rows_l, Nl, seed=0x6D757365)
                     dbl = pkg.DeviceBatch(eng, dgl, refl)
                     dbl.score()
