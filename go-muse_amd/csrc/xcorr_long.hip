@@ -34,6 +34,21 @@
 #define MUSE_LONG_EXP 0
 #endif
 
+// MUSE_LONG_NT: bit 0 = the scratch slice is stored non-temporally, bit 1 = loaded non-temporally.  Measured
+// (tools/ablate/long_nt.sh, profiles/r02_long_series.txt): loads only is best (+5 %: a slice line is read once, and the tables
+// every workgroup shares keep their place in L2); the library builds that.
+#ifndef MUSE_LONG_NT
+#define MUSE_LONG_NT 2
+#endif
+#define MUSE_LONG_ST(ptr, val)                          \
+    do {                                                \
+        if (MUSE_LONG_NT & 1)                           \
+            __builtin_nontemporal_store((val), (ptr));  \
+        else                                            \
+            *(ptr) = (val);                             \
+    } while (0)
+#define MUSE_LONG_LD(ptr) ((MUSE_LONG_NT & 2) ? __builtin_nontemporal_load(ptr) : *(ptr))
+
 namespace muse {
 
 namespace lng {
@@ -239,7 +254,7 @@ __global__ __launch_bounds__(256 * QD, 4) void xcorr_fused_long(const FusedParam
                 if (MUSE_LONG_EXP & 8) {   // (keeps the values alive without the store)
                     asm volatile("" ::"v"(v[m].x), "v"(v[m].y));
                 } else
-                    yat((long long)m * S)[js] = d2v{v[m].x, v[m].y};
+                    MUSE_LONG_ST(yat((long long)m * S) + js, (d2v{v[m].x, v[m].y}));
             }
 #pragma unroll
             for (int bt = 0; bt < NB; bt++) {
@@ -258,7 +273,7 @@ __global__ __launch_bounds__(256 * QD, 4) void xcorr_fused_long(const FusedParam
                     if (MUSE_LONG_EXP & 8) {
                         asm volatile("" ::"v"(z.x), "v"(z.y));
                     } else
-                        yat((long long)(m + k1 * Q1) * S)[js] = d2v{z.x, z.y};
+                        MUSE_LONG_ST(yat((long long)(m + k1 * Q1) * S) + js, (d2v{z.x, z.y}));
                 }
             }
         }
@@ -295,7 +310,7 @@ __global__ __launch_bounds__(256 * QD, 4) void xcorr_fused_long(const FusedParam
                 const unsigned tl = (unsigned)(opaque(t) & 255);
 #pragma unroll
                 for (int i = 0; i < 16; i++) {
-                    const d2v z = ((gd2)scalar_ptr_at(row, 256 * i))[tl];
+                    const d2v z = MUSE_LONG_LD((gd2)scalar_ptr_at(row, 256 * i) + tl);
                     v[i] = make_double2(z.x, z.y);
                 }
             }
@@ -305,7 +320,7 @@ __global__ __launch_bounds__(256 * QD, 4) void xcorr_fused_long(const FusedParam
                 const unsigned tl = (unsigned)(opaque(t) & 255);
 #pragma unroll
                 for (int m = 0; m < 16; m++)
-                    ((gd2)scalar_ptr_at(row, 256 * m))[tl] = d2v{v[BR16(m)].x, v[BR16(m)].y};
+                    MUSE_LONG_ST((gd2)scalar_ptr_at(row, 256 * m) + tl, (d2v{v[BR16(m)].x, v[BR16(m)].y}));
             }
         }
         __syncthreads();
@@ -318,7 +333,7 @@ __global__ __launch_bounds__(256 * QD, 4) void xcorr_fused_long(const FusedParam
             double2 v[16];
 #pragma unroll
             for (int i = 0; i < 16; i++) {
-                const d2v z = yat((long long)i * S)[(unsigned)j];
+                const d2v z = MUSE_LONG_LD(yat((long long)i * S) + (unsigned)j);
                 v[i] = make_double2(z.x, z.y);
             }
             {
