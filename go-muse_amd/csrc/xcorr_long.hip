@@ -24,9 +24,7 @@
 #include <stdint.h>
 #include <algorithm>
 
-#include "xcorr_kernels.h"
-#include "fft_device.h"
-#include "foldk_device.h"
+#include "long_device.h"
 
 // MUSE_LONG_EXP (tools/ablate only; never defined in the library build; results are wrong): bit 0 = no rows phase, bit 1 = rows
 // loaded and stored but not transformed, bit 2 = no sweep 2, bit 3 = sweep 1 without its stores
@@ -50,100 +48,6 @@
 #define MUSE_LONG_LD(ptr) ((MUSE_LONG_NT & 2) ? __builtin_nontemporal_load(ptr) : *(ptr))
 
 namespace muse {
-
-namespace lng {
-
-using namespace occ4;
-using namespace fold;
-using namespace foldk;
-
-template <int R>
-__device__ __forceinline__ constexpr int brev(int k)
-{
-    int r = 0;
-    for (int b = 1; b < R; b <<= 1)
-        r = (r << 1) | ((k & b) ? 1 : 0);
-    return r;
-}
-
-// radix-R DFT (forward sign) over the registers m + s Q1, s = 0 .. R-1 natural; output k at register m + brev<R>(k) Q1
-template <int R>
-__device__ __forceinline__ void sweep_dft(double2 (&v)[16])
-{
-    constexpr int Q1 = 16 / R;
-    if (R == 16) {
-        dft16_nr(v); // (148 instructions; output k at v[BR16(k)])
-        return;
-    }
-#pragma unroll
-    for (int len = R; len >= 2; len >>= 1) {
-        const int half = len / 2;
-#pragma unroll
-        for (int base = 0; base < R; base += len) {
-#pragma unroll
-            for (int k = 0; k < half; k++) {
-                // W_len^k = c - i s (constants after unrolling)
-                const double c = __builtin_cos(6.283185307179586476925 * (double)k / (double)len);
-                const double s = __builtin_sin(6.283185307179586476925 * (double)k / (double)len);
-#pragma unroll
-                for (int m = 0; m < Q1; m++) {
-                    double2 &a = v[m + (base + k) * Q1], &b = v[m + (base + k + half) * Q1];
-                    const double2 u = a, x = b;
-                    a = make_double2(u.x + x.x, u.y + x.y);
-                    const double dx = u.x - x.x, dy = u.y - x.y;
-                    if (k == 0)
-                        b = make_double2(dx, dy);
-                    else if (4 * k == len)
-                        b = make_double2(dy, -dx);
-                    else
-                        b = make_double2(fma(dy, s, dx * c), fma(-dx, s, dy * c));
-                }
-            }
-        }
-    }
-}
-
-// the n = 4096 kernel's pair of transforms on one row (xcorr_r16_fold.hip, default scheduling): x[t + 256 i] at v[i] ->
-// FFT, times the lane-ordered spectrum row `xrow`, FFT -> element t + 256 m at v[BR16(m)].  zero0: bin 0 is zeroed.
-__device__ __forceinline__ void row_transforms(double2 (&v)[16], double2 *xbuf, double2 *xw, const double2 *g2s,
-                                               const double2 *__restrict__ g3a, const double2 *__restrict__ g3b,
-                                               const double2 *__restrict__ xrow, const int t, const int wave, const bool zero0)
-{
-    int tx = t, tg = t;
-    const auto xcl = [&](int j) __attribute__((always_inline)) {
-        return ldg2(scalar_ptr_at(xrow, 256 * ((j + 1) & ~1)), tx - 256 * (j & 1));
-    };
-    const auto g3 = [&](const double2 *tab, int s) __attribute__((always_inline)) { return G3Fetch{tab, tg}(s); };
-    double2 ga[4], xa[4];
-    // ---- first transform: plain pass over a, generalised passes over b (delta = k1 / 16) and c (delta = (k1 + 16 k2) / 256)
-    dft16_nr(v);
-    exchange_cross<0, 1, true>(v, xbuf, wave, t);
-    gdft16_nr(v, G2Fetch{g2s, t >> 4});
-    exchange_local<1>(v, xw, t);
-    tg = fresh<8>(t);
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-        ga[q] = g3(g3a, q);
-    gdft16_nr_pre(v, ga, [&](int q) __attribute__((always_inline)) { return g3(g3a, q); }, [&]() __attribute__((always_inline)) {});
-    if (zero0) {
-        v[0].x = (t == 0) ? 0.0 : v[0].x;
-        v[0].y = (t == 0) ? 0.0 : v[0].y;
-    }
-    // ---- second transform: plain pass with the spectrum factors folded into its first stage, then the two generalised ones
-    tx = fresh<8>(t);
-    xc_stage1<false>(v, xa, xcl);
-    dft16_rn_s234(v);
-    exchange_local<0>(v, xw, t);
-    gdft16_nr(v, G2Fetch{g2s, t & 15});
-    exchange_cross<1, 1>(v, xbuf, wave, t);
-    tg = fresh<8>(t);
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-        ga[q] = g3(g3b, q);
-    gdft16_nr_pre(v, ga, [&](int q) __attribute__((always_inline)) { return g3(g3b, q); }, [&]() __attribute__((always_inline)) {});
-}
-
-} // namespace lng
 
 // QD: quads (256 threads: the unit of a sweep chunk and of a row transform) per workgroup.  QD = 1: four independent
 // workgroups per CU, four pairs (slices) in flight per CU; QD = 4: one 1024-thread workgroup per CU whose quads take
