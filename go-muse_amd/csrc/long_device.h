@@ -1,6 +1,5 @@
-// long_device.h -- pieces shared by the long-series kernels (xcorr_long.hip: one fused kernel per pair and workgroup;
-// xcorr_long_batched.hip: one kernel per phase over a batch of pairs): the in-register radix-R1 butterflies of the sweeps and
-// the n = 4096 kernel's pair of transforms applied to one 4096-point row.
+// long_device.h -- building blocks of the long-series kernel (xcorr_long.hip): the in-register radix-R1 butterflies of the
+// sweeps and the n = 4096 kernel's pair of transforms applied to one 4096-point row.
 #pragma once
 #include <hip/hip_runtime.h>
 

@@ -76,11 +76,6 @@ extern "C" int64_t muse_next_pow2(double val)
 struct muse_ctx {
     int device = 0;
     hipStream_t stream = nullptr;      // every kernel of the context
-    // xcorr_long_batched.hip: two streams the batches of a long-series pass alternate between (forked from / joined to `stream`),
-    // partial statistics and argmax candidates of two batches; created on first use
-    hipStream_t long_aux[2] = {nullptr, nullptr};
-    hipEvent_t long_ev[3] = {nullptr, nullptr, nullptr};
-    double *long_part = nullptr, *long_cand = nullptr;
     hipStream_t copy_stream = nullptr; // host -> HBM uploads of muse_group_append: run beside a score pass
     int num_cus = 0;
     int64_t hbm = 0;
@@ -239,16 +234,6 @@ static int use_device(muse_ctx *ctx)
     return MUSE_OK;
 }
 
-// automatic selection for n >= 32768: 1 = one kernel per phase over cache-sized batches (xcorr_long_batched.hip), 0 = the fused
-// kernel (xcorr_long.hip); the other one stays a test hook (13 / 14)
-#ifndef MUSE_LONG_DEFAULT_IS_BATCHED
-#define MUSE_LONG_DEFAULT_IS_BATCHED 0
-#endif
-constexpr size_t LONG_BATCH_SLOTS = 16384; // (pairs x chunks) of one batch the statistics / candidate buffers hold
-#ifndef MUSE_LONG_BATCH_MB
-#define MUSE_LONG_BATCH_MB 64 // slice bytes of one batch (two batches in flight)
-#endif
-
 // ----------------------------------------------------------------- context
 static void fill_twiddle(std::vector<double2> &v, size_t i, long long num, long long den)
 {
@@ -378,16 +363,6 @@ static void ctx_release(muse_ctx *ctx)
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
     }
-    for (int k = 0; k < 2; k++)
-        if (ctx->long_aux[k]) {
-            (void)hipStreamSynchronize(ctx->long_aux[k]);
-            (void)hipStreamDestroy(ctx->long_aux[k]);
-        }
-    for (int k = 0; k < 3; k++)
-        if (ctx->long_ev[k])
-            (void)hipEventDestroy(ctx->long_ev[k]);
-    (void)hipFree(ctx->long_part);
-    (void)hipFree(ctx->long_cand);
     (void)hipFree(ctx->tw1);
     (void)hipFree(ctx->tw2);
     (void)hipFree(ctx->twm);
@@ -441,8 +416,8 @@ extern "C" int muse_ctx_device_info(muse_ctx *ctx, char *name, int32_t name_cap,
 
 extern "C" int muse_ctx_set_kernel(muse_ctx *ctx, int32_t variant)
 {
-    if (!ctx || !(variant == 0 || variant == 1 || variant == 7 || variant == 10 || variant == 11 || variant == 12 || variant == 13 || variant == 14))
-        return fail(MUSE_ERR_INVALID, "bad kernel variant (0 auto, 1 generic, 7 rescaling n=4096, 10 default n=4096, 11 Stockham, 12 half-round, 13 long series fused, 14 long series batched)");
+    if (!ctx || !(variant == 0 || variant == 1 || variant == 7 || variant == 10 || variant == 11 || variant == 12 || variant == 13))
+        return fail(MUSE_ERR_INVALID, "bad kernel variant (0 auto, 1 generic, 7 rescaling n=4096, 10 default n=4096, 11 Stockham, 12 half-round, 13 long series)");
     ctx->variant = variant;
     return MUSE_OK;
 }
@@ -1136,8 +1111,6 @@ extern "C" int muse_batch_score(muse_batch *b)
         if (variant == KERNEL_R16_FOLD && ctx->variant == 0 && b->handoff_host && b->handoff_M == M &&
             (long long)*(volatile int *)b->handoff_host * 8 > p.npairs)
             variant = KERNEL_R16_OCC3;
-    } else if (b->xcp && p.twl && b->n >= 32768 && (ctx->variant == 14 || (ctx->variant == 0 && MUSE_LONG_DEFAULT_IS_BATCHED))) {
-        variant = KERNEL_LONG_BATCHED; // four-step, one kernel per phase over cache-sized batches (xcorr_long_batched.hip)
     } else if (b->xcp && p.twl && ((b->n >= 32768 && ctx->variant == 0) || (b->n >= 16384 && ctx->variant == 13))) {
         variant = KERNEL_LONG; // four-step, 4096-point rows on the n = 4096 kernel's transforms (xcorr_long.hip)
     } else if (((b->n >= 512 && b->n <= 2048) || b->n == 8192 || b->n == 16384) && (ctx->variant == 0 || ctx->variant == 12)) {
@@ -1183,7 +1156,7 @@ extern "C" int muse_batch_score(muse_batch *b)
             b->handoff_M = M;
             HIP_TRY(hipMemcpyAsync(b->handoff_host, b->ovf_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         }
-    } else if (variant == KERNEL_LONG || variant == KERNEL_LONG_BATCHED) {
+    } else if (variant == KERNEL_LONG) {
         // as above: NaN / Inf and sigma-spread pairs are listed (one entry per pair) and redone by the four-step kernel that
         // isolates and rescales the series first
         if (2 * p.npairs > b->ovf_cap) {
@@ -1196,27 +1169,7 @@ extern "C" int muse_batch_score(muse_batch *b)
         p.ovf_count = b->ovf_count;
         p.ovf_list = b->ovf_list;
         HIP_TRY(hipMemsetAsync(b->ovf_count, 0, 2 * sizeof(int), ctx->stream));
-        if (variant == KERNEL_LONG_BATCHED) {
-            // batches of pairs whose slices (two batches in flight) stay inside the Infinity Cache: 2 x 64 MB
-            const int batch = (int)std::max<int64_t>(16, ((int64_t)MUSE_LONG_BATCH_MB << 20) / ((int64_t)b->n * (int64_t)sizeof(double2)));
-            const size_t CH = (size_t)b->n / 4096;
-            if (!ctx->long_aux[0]) {
-                for (int k = 0; k < 2; k++)
-                    HIP_TRY(hipStreamCreateWithFlags(&ctx->long_aux[k], hipStreamNonBlocking));
-                for (int k = 0; k < 3; k++)
-                    HIP_TRY(hipEventCreateWithFlags(&ctx->long_ev[k], hipEventDisableTiming));
-                // (sized for the largest batch: n = 32768 -> 128 pairs x 8 chunks; n = 65536 -> 64 x 16)
-                HIP_TRY(hipMalloc(&ctx->long_part, (size_t)2 * LONG_BATCH_SLOTS * 4 * sizeof(double)));
-                HIP_TRY(hipMalloc(&ctx->long_cand, (size_t)2 * LONG_BATCH_SLOTS * 8 * sizeof(double)));
-            }
-            if ((size_t)2 * (size_t)batch * (size_t)b->n > ctx->gscratch_elems || (size_t)batch * CH > LONG_BATCH_SLOTS)
-                return fail(MUSE_ERR_HIP, "long-series scratch too small");
-            p.lpart = ctx->long_part;
-            p.lcand = ctx->long_cand;
-            HIP_TRY(launch_fused_long_batched(p, batch, ctx->stream, ctx->long_aux[0], ctx->long_aux[1], ctx->long_ev[0],
-                                              ctx->long_ev[1], ctx->long_ev[2]));
-        } else
-            HIP_TRY(launch_fused(p, variant, ctx->num_cus, ctx->stream));
+        HIP_TRY(launch_fused(p, variant, ctx->num_cus, ctx->stream));
         FusedParams q = p;
         q.pair_list = b->ovf_list;
         q.pair_count = b->ovf_count;
