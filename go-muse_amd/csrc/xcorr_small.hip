@@ -205,6 +205,55 @@ __device__ __forceinline__ void level(double2 (&v)[16], double2 *b, const double
     const int gl = g & (S / (2 * NS) - 1);
     const int wb = gl * padk(16 * NS) + mm + (NS >= 16 ? (mm >> 4) : 0);
     const bool lower = j < S / 2;
+    if constexpr (S <= 64 && NS < 16) {
+        // Both halves of the writers sit in ONE wave (S = 64: lanes 0-31 / 32-63; S = 32: rows 0, 2 / 1, 3 of two pairs): masked,
+        // each half round would cost sixteen ds_write_b128 whose price (the 13-cycle register transfer) does not shrink with the
+        // mask.  Instead the halves trade registers (v_permlane32_swap / v_permlane16_swap, gfx950): outputs r + 8 of the lower
+        // columns move to the upper lanes and outputs r of the upper columns to the lower lanes, so that EVERY lane writes
+        // eight values per round -- 16 full stores instead of 32 half-empty ones on the one LDS pipe the CU's 16 waves share,
+        // for 32 VALU swaps on a SIMD that has slack.  The slot of a value only depends on its column modulo S / 2 and on
+        // its output index: both rounds use the same per-lane base, 8 outputs further for the upper lanes.  Measured on one box
+        // (A/B builds): n = 512 34.0 -> 37.5 % of the roofline, N = 480 30.5 -> 33.5 %, n = 1024 unchanged (38.7 %).
+        double2 lo8[8], hi8[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            unsigned a[4] = {(unsigned)__double2loint(v[BR16(r)].x), (unsigned)__double2hiint(v[BR16(r)].x),
+                             (unsigned)__double2loint(v[BR16(r)].y), (unsigned)__double2hiint(v[BR16(r)].y)};
+            unsigned c[4] = {(unsigned)__double2loint(v[BR16(r + 8)].x), (unsigned)__double2hiint(v[BR16(r + 8)].x),
+                             (unsigned)__double2loint(v[BR16(r + 8)].y), (unsigned)__double2hiint(v[BR16(r + 8)].y)};
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                if (S == 64) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(a[d], c[d], false, false);
+                    a[d] = sw[0];
+                    c[d] = sw[1];
+                } else {
+                    const auto sw = __builtin_amdgcn_permlane16_swap(a[d], c[d], false, false);
+                    a[d] = sw[0];
+                    c[d] = sw[1];
+                }
+            }
+            lo8[r] = make_double2(__hiloint2double((int)a[1], (int)a[0]), __hiloint2double((int)a[3], (int)a[2]));
+            hi8[r] = make_double2(__hiloint2double((int)c[1], (int)c[0]), __hiloint2double((int)c[3], (int)c[2]));
+        }
+        const int wbh = wb + (lower ? 0 : 8 * NS + ((8 * NS) >> 4)); // (8 NS is a multiple of 16: no carry into the pad)
+        sync();
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+            b[wbh + r * NS + ((r * NS) >> 4)] = lo8[r];
+        sync();
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            w[i] = b[rbase + i * padk(S)];
+        sync();
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+            b[wbh + r * NS + ((r * NS) >> 4)] = hi8[r];
+        sync();
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            w[8 + i] = b[rbase + i * padk(S)];
+    } else {
     sync();
     if (lower) {
 #pragma unroll
@@ -225,6 +274,7 @@ __device__ __forceinline__ void level(double2 (&v)[16], double2 *b, const double
 #pragma unroll
     for (int i = 0; i < 8; i++)
         w[8 + i] = b[rbase + i * padk(S)];
+    }
 #pragma unroll
     for (int i = 0; i < 16; i++)
         v[i] = w[i];
@@ -291,7 +341,7 @@ __device__ __forceinline__ void forward(double2 (&v)[16], double2 *b, const doub
         gpass_pre(v, ga, [&](int s) __attribute__((always_inline)) { return tw_factor<R1>(twm, m2, s); }); // pass 2: Ns = R1
     }
     level<S, R1>(v, b, gs, j, rbase, sync); // pass 3: Ns = 16 R1
-    if (NP >= 4)
+    if constexpr (NP >= 4)
         level<S, 16 * R1>(v, b, gs + 8 * 16 * R1, j, rbase, sync); // pass 4 (n = 8192): Ns = 256 R1 = S
 }
 
