@@ -37,6 +37,16 @@ using namespace occ4;
 using namespace fold;
 
 constexpr int padk(int x) { return x + (x >> 4); }
+// MUSE_SMALL_EXP (tools/ablate only; never defined in the library build; results are wrong): table values read from a 1 KB LDS
+// array instead of L2 -- bit 0 the lane-ordered pass factors, bit 1 the spectrum factors, bit 2 the W_65536 factors of pass 2
+#ifndef MUSE_SMALL_EXP
+#define MUSE_SMALL_EXP 0
+#endif
+__device__ __forceinline__ double2 fake_lds(unsigned i)
+{
+    __shared__ double2 fk[64];
+    return fk[i & 63];
+}
 
 // ---- reductions over the S lanes of a pair; every lane of the pair gets the result.  S > 64 (one pair per workgroup,
 // S / 64 waves): through `red`, S / 64 doubles of LDS, two workgroup barriers.
@@ -163,6 +173,8 @@ __device__ __forceinline__ double2 tw_factor(const double2 *__restrict__ twm, co
     constexpr int U = 4096 / NS;
     const int idx = s == 0 ? 8 * U * m : s == 1 ? 4 * U * m : s == 2 ? 2 * U * m : s == 3 ? 2 * U * m + 8192
                                                                                            : U * m + 4096 * (s - 4);
+    if (MUSE_SMALL_EXP & 4)
+        return fake_lds((unsigned)idx);
     return ldg2u(scalar_ptr(twm), (unsigned)idx); // scalar base + UNSIGNED 32-bit lane offset: no 64-bit address arithmetic
 }
 
@@ -198,7 +210,7 @@ __device__ __forceinline__ void level(double2 (&v)[16], double2 *b, const double
     const unsigned m3 = (unsigned)(j & (NS2 - 1));
 #pragma unroll
     for (int s = 0; s < 4; s++) // the pass's first factors travel during the transpose
-        ga[s] = ldg2u(scalar_ptr_at(tab, s * NS2), m3);
+        ga[s] = (MUSE_SMALL_EXP & 1) ? fake_lds(m3 + s) : ldg2u(scalar_ptr_at(tab, s * NS2), m3);
     fence();
     const int g = j / NS, mm = j & (NS - 1);
     // position (g mod S/(2 NS)) 16 NS + r NS + m, padded
@@ -278,7 +290,7 @@ __device__ __forceinline__ void level(double2 (&v)[16], double2 *b, const double
 #pragma unroll
     for (int i = 0; i < 16; i++)
         v[i] = w[i];
-    gpass_pre(v, ga, [&](int s) __attribute__((always_inline)) { return ldg2u(scalar_ptr_at(tab, s * NS2), m3); });
+    gpass_pre(v, ga, [&](int s) __attribute__((always_inline)) { return (MUSE_SMALL_EXP & 1) ? fake_lds(m3 + s) : ldg2u(scalar_ptr_at(tab, s * NS2), m3); });
 }
 
 // forward transform of the pair's n points: v[i] = x[j + i S] -> X[j + r S] at v[BR16(r)].  b: the pair's half buffer.
@@ -286,8 +298,8 @@ __device__ __forceinline__ void level(double2 (&v)[16], double2 *b, const double
 // [8][256 R1] -- coalesced 16-byte loads; out of the generic W_65536 table the same factors are up to 64 different cache
 // lines per wave instruction.
 template <int LOGN>
-__device__ __forceinline__ void forward(double2 (&v)[16], double2 *b, const double2 *__restrict__ twm,
-                                        const double2 *__restrict__ gs, const int j_)
+__device__ __forceinline__ void forward(double2 (&v)[16], double2 *b, const double2 *g2l, const double2 *__restrict__ gs,
+                                        const int j_)
 {
     constexpr int n = 1 << LOGN, S = n / 16, NP = (LOGN + 3) / 4, R1 = n >> (4 * (NP - 1)), Q1 = 16 / R1, HQ = Q1 / 2;
     int j = j_;
@@ -311,8 +323,8 @@ __device__ __forceinline__ void forward(double2 (&v)[16], double2 *b, const doub
         double2 w[16], ga[4];
         const int m2 = j & (R1 - 1);
 #pragma unroll
-        for (int s = 0; s < 4; s++) // pass 2's first factors travel during transpose A
-            ga[s] = tw_factor<R1>(twm, m2, s);
+        for (int s = 0; s < 4; s++) // pass 2's factors: 8 x R1 values, from the workgroup's LDS copy (a broadcast read)
+            ga[s] = g2l[s * R1 + m2];
         fence();
         // ---- transpose A, two half rounds: the lower / upper half of the positions
         sync(); // (previous readers of the buffer are done)
@@ -338,7 +350,7 @@ __device__ __forceinline__ void forward(double2 (&v)[16], double2 *b, const doub
 #pragma unroll
         for (int i = 0; i < 16; i++)
             v[i] = w[i];
-        gpass_pre(v, ga, [&](int s) __attribute__((always_inline)) { return tw_factor<R1>(twm, m2, s); }); // pass 2: Ns = R1
+        gpass_pre(v, ga, [&](int s) __attribute__((always_inline)) { return g2l[s * R1 + m2]; }); // pass 2: Ns = R1
     }
     level<S, R1>(v, b, gs, j, rbase, sync); // pass 3: Ns = 16 R1
     if constexpr (NP >= 4)
@@ -394,6 +406,11 @@ __global__ __launch_bounds__((LOGN >= 11 ? (1 << LOGN) / 16 : 256), 4) void xcor
     constexpr int G = TPB / S;  // pairs per workgroup iteration: 8, 4, 1, 1, 1
     static_assert((LOGN >= 9 && LOGN <= 11) || LOGN == 13 || LOGN == 14, "n = 512, 1024, 2048, 8192, 16384");
     __shared__ double red[16]; // multi-wave pair reductions (n >= 2048)
+    // pass 2's eight factors per phase m2 / R1: 8 x R1 distinct values for the whole workgroup.  Gathered per lane from the
+    // W_65536 table they were the kernel's longest stall (scattered L2 lines in front of the first butterfly of a pass:
+    // tools/ablate/small_exp.sh, + 15-20 % with them out of the way); from LDS they are one broadcast read each.
+    constexpr int NP_ = (LOGN + 3) / 4, R1_ = n >> (4 * (NP_ - 1));
+    __shared__ double2 g2l[8 * R1_];
     __shared__ double2 xbuf[(TPB / 64) * 544]; // 8.7 KB per wave: half-round buffers of the pairs (8 S 17/16 double2 per pair)
     const int t = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -405,6 +422,9 @@ __global__ __launch_bounds__((LOGN >= 11 ? (1 << LOGN) / 16 : 256), 4) void xcor
     const double invN = 1.0 / (double)N, invNm1 = 1.0 / (double)(N - 1);
     const double2 *__restrict__ twm = p.twm;
     const double2 *__restrict__ gs = p.gsmall;
+    if (t < 8 * R1_)
+        g2l[t] = tw_factor<R1_>(twm, t % R1_, t / R1_);
+    __syncthreads();
     // optional indirection (filter-and-refine Run): process pair_list[0 .. *pair_count) instead of every pair
     const long long total = p.pair_list ? (long long)*p.pair_count : p.npairs;
     const long long ngroups = (total + G - 1) / G;
@@ -502,7 +522,7 @@ __global__ __launch_bounds__((LOGN >= 11 ? (1 << LOGN) / 16 : 256), 4) void xcor
             }
         }
         // ---- Z = FFT(yA + i yB);  V = Z conj(X)/n;  ccA + i ccB = FFT(V)
-        forward<LOGN>(v, b, twm, gs, j);
+        forward<LOGN>(v, b, g2l, gs, j);
         // the workgroup's slice of the spectrum scratch: element i of thread gt at [i][gt] (scalar base + 32-bit lane offset)
         const long long ZT = (long long)gridDim.x * TPB;
         const auto zslot = [&](int i) __attribute__((always_inline)) {
@@ -532,7 +552,9 @@ __global__ __launch_bounds__((LOGN >= 11 ? (1 << LOGN) / 16 : 256), 4) void xcor
             int jx = j;
             asm volatile("" : "+v"(jx)); // (the table offsets are derived here, not hoisted out of the pair loop)
             jx &= S - 1;
-            const auto xcl = [&](int r) __attribute__((always_inline)) { return ldg2u(scalar_ptr_at(xcr, r * S), (unsigned)jx); };
+            const auto xcl = [&](int r) __attribute__((always_inline)) {
+                return (MUSE_SMALL_EXP & 2) ? fake_lds((unsigned)(jx + r)) : ldg2u(scalar_ptr_at(xcr, r * S), (unsigned)jx);
+            };
             double2 xq[2][4];
 #pragma unroll
             for (int k = 0; k < 4; k++)
@@ -560,7 +582,7 @@ __global__ __launch_bounds__((LOGN >= 11 ? (1 << LOGN) / 16 : 256), 4) void xcor
             for (int r = 0; r < 16; r++)
                 v[r] = w[r];
         }
-        forward<LOGN>(v, b, twm, gs, j); // cc[j + r S] at v[BR16(r)]
+        forward<LOGN>(v, b, g2l, gs, j); // cc[j + r S] at v[BR16(r)]
         // ---- maxAbsIndex (xcorr.go:39-50) per series: ascending r = ascending index for this thread
         double sa = 0.0, sb = 0.0; // signed value of the lane's first maximum of |cc|, and its register index
         int ra_ = 0, rb_ = 0;
