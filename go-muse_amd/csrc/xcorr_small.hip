@@ -118,6 +118,82 @@ __device__ __forceinline__ int pair_min_i(int v, double *red, const int wave)
     return v;
 }
 
+// S > 64 (the pair's S / 64 waves are the workgroup): several reductions through ONE exchange and ONE workgroup barrier each.
+// `red` holds three regions of 4 x 16 doubles (sums, maxima, indices) that are never reused before the many barriers of the
+// transforms in between have passed.  (Separate pair_sum / pair_max / pair_min_i calls cost two barriers apiece: 16 per pair.)
+template <int S>
+__device__ __forceinline__ void pair_sum4(double &q0, double &q1, double &q2, double &q3, double *red, const int wave)
+{
+    if (S <= 64) {
+        q0 = pair_sum<S>(q0, red, wave);
+        q1 = pair_sum<S>(q1, red, wave);
+        q2 = pair_sum<S>(q2, red, wave);
+        q3 = pair_sum<S>(q3, red, wave);
+        return;
+    }
+    constexpr int NW = S / 64;
+    const double w0 = wave_sum_dpp(q0), w1 = wave_sum_dpp(q1), w2 = wave_sum_dpp(q2), w3 = wave_sum_dpp(q3);
+    red[wave] = w0; // (every lane of the wave stores the same value)
+    red[16 + wave] = w1;
+    red[32 + wave] = w2;
+    red[48 + wave] = w3;
+    lds_barrier();
+    q0 = red[0];
+    q1 = red[16];
+    q2 = red[32];
+    q3 = red[48];
+#pragma unroll
+    for (int w = 1; w < NW; w++) {
+        q0 += red[w];
+        q1 += red[16 + w];
+        q2 += red[32 + w];
+        q3 += red[48 + w];
+    }
+}
+template <int S>
+__device__ __forceinline__ void pair_max2(double &a, double &b, double *red, const int wave)
+{
+    if (S <= 64) {
+        a = pair_max<S>(a, red, wave);
+        b = pair_max<S>(b, red, wave);
+        return;
+    }
+    constexpr int NW = S / 64;
+    const double wa = wave_max_dpp(a), wb = wave_max_dpp(b);
+    red[64 + wave] = wa;
+    red[80 + wave] = wb;
+    lds_barrier();
+    a = red[64];
+    b = red[80];
+#pragma unroll
+    for (int w = 1; w < NW; w++) {
+        a = fmax(a, red[64 + w]);
+        b = fmax(b, red[80 + w]);
+    }
+}
+template <int S>
+__device__ __forceinline__ void pair_min_i2(int &a, int &b, double *red, const int wave)
+{
+    if (S <= 64) {
+        a = pair_min_i<S>(a, red, wave);
+        b = pair_min_i<S>(b, red, wave);
+        return;
+    }
+    constexpr int NW = S / 64;
+    int *ri = (int *)(red + 96);
+    const int wa = wave_min_i_dpp(a), wb = wave_min_i_dpp(b);
+    ri[wave] = wa;
+    ri[16 + wave] = wb;
+    lds_barrier();
+    a = ri[0];
+    b = ri[16];
+#pragma unroll
+    for (int w = 1; w < NW; w++) {
+        a = min(a, ri[w]);
+        b = min(b, ri[16 + w]);
+    }
+}
+
 // plain radix-R DFTs on the registers m + s (16 / R), natural order in place (as xcorr_stockham.hip, dft_small)
 __device__ __forceinline__ void r_dft2(double2 &a, double2 &b) { bf_one(a, b); }
 __device__ __forceinline__ void r_dft4(double2 &a, double2 &b, double2 &c, double2 &d)
@@ -405,7 +481,7 @@ __global__ __launch_bounds__((LOGN >= 11 ? (1 << LOGN) / 16 : 256), 4) void xcor
     constexpr int TPB = LOGN >= 11 ? S : 256;
     constexpr int G = TPB / S;  // pairs per workgroup iteration: 8, 4, 1, 1, 1
     static_assert((LOGN >= 9 && LOGN <= 11) || LOGN == 13 || LOGN == 14, "n = 512, 1024, 2048, 8192, 16384");
-    __shared__ double red[16]; // multi-wave pair reductions (n >= 2048)
+    __shared__ double red[112]; // multi-wave pair reductions (n >= 2048): sums [4][16], maxima [2][16], indices [2][16] ints
     // pass 2's eight factors per phase m2 / R1: 8 x R1 distinct values for the whole workgroup.  Gathered per lane from the
     // W_65536 table they were the kernel's longest stall (scattered L2 lines in front of the first butterfly of a pass:
     // tools/ablate/small_exp.sh, + 15-20 % with them out of the way); from LDS they are one broadcast read each.
@@ -491,10 +567,7 @@ __global__ __launch_bounds__((LOGN >= 11 ? (1 << LOGN) / 16 : 256), 4) void xcor
             q2 += db;
             q3 = fma(db, db, q3);
         }
-        q0 = pair_sum<S>(q0, red, wave);
-        q1 = pair_sum<S>(q1, red, wave);
-        q2 = pair_sum<S>(q2, red, wave);
-        q3 = pair_sum<S>(q3, red, wave);
+        pair_sum4<S>(q0, q1, q2, q3, red, wave);
         const Stat stA{q0, q1}, stB{q2, q3};
         bool zeroA, nanA, zeroB, nanB;
         const double varA0 = variance(stA, invN, invNm1, zeroA, nanA);
@@ -602,9 +675,10 @@ __global__ __launch_bounds__((LOGN >= 11 ? (1 << LOGN) / 16 : 256), 4) void xcor
         if (!MULTI)
             request(it + gridDim.x); // the next iteration's rows: in flight during the reductions and the result write-out
         fence();
-        const double pa = pair_max<S>(ma, red, wave), pb = pair_max<S>(mb, red, wave);
-        const int ca = pair_min_i<S>((ma == pa && pa > 0.0) ? ia : 0x7fffffff, red, wave);
-        const int cb = pair_min_i<S>((mb == pb && pb > 0.0) ? ib : 0x7fffffff, red, wave);
+        double pa = ma, pb = mb;
+        pair_max2<S>(pa, pb, red, wave);
+        int ca = (ma == pa && pa > 0.0) ? ia : 0x7fffffff, cb = (mb == pb && pb > 0.0) ? ib : 0x7fffffff;
+        pair_min_i2<S>(ca, cb, red, wave);
         // the lane that owns the winning index writes the result (nothing above 0: lane 0 reports cc[0] at index 0)
         if (live) {
             const bool ownA = ca == 0x7fffffff ? j == 0 : (ia == ca && ma == pa);
