@@ -1,26 +1,33 @@
-// xcorr_small.hip -- fp64 kernels for the FFT lengths n = 512, 1024, 2048 (256 < N <= 2048), round 2.
+// xcorr_small.hip -- fp64 kernels for the FFT lengths n = 512, 1024, 2048, 8192, 16384 (every config-5 length whose pair of
+// series fits one workgroup's registers; n = 4096 has its own kernel, xcorr_r16_fold.hip), round 2.
 //
 // Mathematics: xCorrWithX, /root/reference/xcorr.go:160-197, two series per complex transform, radix-16 Stockham
-// passes as in xcorr_stockham.hip (n = R1 * 16 * 16, R1 = 2, 4, 8; every thread owns the 16 points x[j + i S],
-// S = n / 16; S threads per pair).  What is different from the round-1 kernels of these lengths:
+// passes as in xcorr_stockham.hip (n = R1 * 16^(P-1): P = 3 with R1 = 2, 4, 8 for n <= 2048, P = 4 with R1 = 2, 4 for
+// n = 8192, 16384; every thread owns the 16 points x[j + i S], S = n / 16; S threads per pair).  What is different from
+// the round-1 kernels of these lengths:
 //   * Occupancy.  Round 1 kept a full padded work buffer per pair (n complex = 69.6 KB per 256-thread workgroup):
 //     two workgroups = 8 waves per CU, and every profile said the kernels were bound by that, not by arithmetic
 //     (profiles/r01_sizes_*: 24-27 % of the HBM roofline).  Here every transpose runs in TWO HALF ROUNDS through a
-//     buffer of n / 2 points (8.7 KB per wave, 34.8 KB per workgroup: four workgroups = 16 waves per CU at 128
-//     VGPRs), and in both transposes EVERY lane reads eight values per round (no idle half as in the n = 4096
-//     kernel's wave-local transposes):
+//     buffer of n / 2 points (8.7 KB per wave: 16 waves per CU at 128 VGPRs for every length), and in all transposes
+//     EVERY lane reads eight values per round (no idle half as in the n = 4096 kernel's wave-local transposes):
 //       A (after the radix-R1 pass): writer j, output (m, r) -> position (j + m S) R1 + r; reader j reads j + i S.
 //         Round h carries the positions [8 S h, 8 S (h + 1)): the outputs m in [h Q1/2, (h+1) Q1/2) of every lane, read
 //         back as the inputs i in [8 h, 8 h + 8) of every lane.
-//       B (between the radix-16 passes, Ns = R1): writer j = g R1 + m, output r -> position g 16 R1 + r R1 + m.
-//         Round h: the lanes with g in [8 h, 8 h + 8) write all sixteen outputs; every lane reads its inputs
-//         i in [8 h, 8 h + 8).
+//       B (between radix-16 passes, Ns -> 16 Ns): writer j = g Ns + m, output r -> position g 16 Ns + r Ns + m.
+//         Round h: the lower / upper half of the columns write all sixteen outputs; every lane reads its inputs
+//         i in [8 h, 8 h + 8).  Where both halves sit in one wave (n = 512, 1024) they first trade eight registers
+//         (v_permlane16/32_swap) so that every lane stores eight values in each round (level()).
 //   * No workgroup barrier for n <= 1024: a pair lives inside one wave (n = 512: two pairs per wave) and LDS
-//     operations of one wave execute in order.  n = 2048: a pair spans two waves, the half rounds are separated by
-//     workgroup barriers (as in xcorr_r16_fold.hip's workgroup-wide transposes).
+//     operations of one wave execute in order.  n >= 2048: a pair spans 2, 8 or 16 waves = the workgroup, the half rounds
+//     are separated by workgroup barriers; its reductions share one exchange and one barrier per kind (pair_sum4 ...).
 //   * Arithmetic: every radix-16 pass is a generalised 16-point transform with the twiddles folded into the
 //     butterflies (fold_device.h: 192 instructions and eight table entries per pass instead of 264 and four), and the
 //     second transform is the forward algorithm again (xcorr_stockham.hip, lds_transforms).
+//   * Tables: pass 2's 8 x R1 factors from an LDS copy (a broadcast read; gathered per lane out of the W_65536 table they
+//     were the longest stall of the kernel), the later passes' from lane-ordered per-length tables (coalesced).
+//   * Lanes are relabelled to columns so that LDS read groups and write groups meet no bank conflicts (column_of_lane()).
+//   * MULTI: R references in one pass (muse_batch_score_many): the pair's spectrum is parked per workgroup and every
+//     reference takes product, second transform and argmax from there.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
