@@ -55,6 +55,24 @@ __device__ __forceinline__ double2 fake_lds(unsigned i)
     return fk[i & 63];
 }
 
+// the values of the two 16-lane rows of a 32-lane pair side by side (lane i of row 0 with lane i of row 1), in both rows:
+// v_permlane16_swap(v, v) leaves [row 0, row 0, row 2, row 2] and [row 1, row 1, row 3, row 3] -- one VALU instruction per
+// dword where __shfl_xor(v, 16) is a ds_bpermute round trip through the LDS crossbar
+__device__ __forceinline__ void rows_side_by_side(const int v, int &even, int &odd)
+{
+    const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    even = (int)r[0];
+    odd = (int)r[1];
+}
+__device__ __forceinline__ void rows_side_by_side(const double v, double &even, double &odd)
+{
+    int el, eh, ol, oh;
+    rows_side_by_side(__double2loint(v), el, ol);
+    rows_side_by_side(__double2hiint(v), eh, oh);
+    even = __hiloint2double(eh, el);
+    odd = __hiloint2double(oh, ol);
+}
+
 // ---- reductions over the S lanes of a pair; every lane of the pair gets the result.  S > 64 (one pair per workgroup,
 // S / 64 waves): through `red`, S / 64 doubles of LDS, two workgroup barriers.
 template <int S>
@@ -65,7 +83,9 @@ __device__ __forceinline__ double pair_sum(double v, double *red, const int wave
         v += dpp_f64<0x4E>(v);
         v += dpp_f64<0x141>(v);
         v += dpp_f64<0x140>(v); // the lane's 16-lane row
-        return v + __shfl_xor(v, 16, 64);
+        double e, o;
+        rows_side_by_side(v, e, o);
+        return e + o;
     }
     v = wave_sum_dpp(v);
     if (S > 64) {
@@ -87,7 +107,9 @@ __device__ __forceinline__ double pair_max(double v, double *red, const int wave
         v = fmax(v, dpp_f64<0x4E>(v));
         v = fmax(v, dpp_f64<0x141>(v));
         v = fmax(v, dpp_f64<0x140>(v));
-        return fmax(v, __shfl_xor(v, 16, 64));
+        double e, o;
+        rows_side_by_side(v, e, o);
+        return fmax(e, o);
     }
     v = wave_max_dpp(v);
     if (S > 64) {
@@ -109,7 +131,9 @@ __device__ __forceinline__ int pair_min_i(int v, double *red, const int wave)
         v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true));
         v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true));
         v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true));
-        return min(v, __shfl_xor(v, 16, 64));
+        int e, o;
+        rows_side_by_side(v, e, o);
+        return min(e, o);
     }
     v = wave_min_i_dpp(v);
     if (S > 64) {
