@@ -214,9 +214,10 @@ int muse_merge_records(const muse_record *records, int64_t count, int32_t top_n,
  * Group).  The R batches must share the context and the group; each is
  * scored exactly as muse_batch_score would, but in ONE pass over the rows:
  * every pair of series is read and forward-transformed once and correlated
- * against all R reference spectra (FFT length 4096, i.e. 2048 < N <= 4096;
- * other lengths and forced kernel variants score the batches one after the
- * other).  Results land in each
+ * against all R reference spectra (FFT lengths 512 ... 16384, i.e.
+ * 256 < N <= 16384; shorter and longer series, float32-storage groups and
+ * forced kernel variants score the batches one after the other).  Results
+ * land in each
  * batch's own buffers (muse_batch_scores / _run on a batch re-score it). */
 int muse_batch_score_many(muse_batch *const *batches, int32_t R);
 /* Copies back the (lag, signed mv) of the last scoring pass WITHOUT re-scoring
