@@ -1617,7 +1617,8 @@ extern "C" int muse_batch_kernel_name(muse_batch *b, char *name, int32_t cap)
         return fail(MUSE_ERR_INVALID, "NULL argument");
     const char *k = "xcorr_fused_generic";
     if (b->n == 4096)
-        k = b->N == 4096 ? "xcorr_fused_n4096_fold<false, false>" : "xcorr_fused_n4096_fold<false, true>";
+        k = b->g->f32 ? (b->N == 4096 ? "xcorr_fused_n4096_fold<false, false, true>" : "xcorr_fused_n4096_fold<false, true, true>")
+                      : (b->N == 4096 ? "xcorr_fused_n4096_fold<false, false, false>" : "xcorr_fused_n4096_fold<false, true, false>");
     else if ((b->n >= 512 && b->n <= 2048) || b->n == 8192 || b->n == 16384)
         k = "xcorr_fused_small";
     else if (b->n > 16384)
