@@ -116,7 +116,10 @@ __global__ __launch_bounds__(256 * QD, 4) void xcorr_fused_long(const FusedParam
             double xa[16], xb[16];
 #pragma unroll
             for (int i = 0; i < 16; i++) {
-                if (PADDED) {
+                if (PADDED && i >= 8) { // (pad < n / 2: always inside the row -- scalar base, no clamp)
+                    xa[i] = __builtin_nontemporal_load(scalar_ptr_at(ra, (long long)i * S - pad) + (unsigned)j);
+                    xb[i] = __builtin_nontemporal_load(scalar_ptr_at(rb, (long long)i * S - pad) + (unsigned)j);
+                } else if (PADDED) {
                     const int e = j + i * S - pad;
                     const unsigned ec = (unsigned)(e < 0 ? 0 : e);
                     xa[i] = __builtin_nontemporal_load(scalar_ptr(ra) + ec);
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(256 * QD, 4) void xcorr_fused_long(const FusedParam
             for (int i = 0; i < 16; i++) {
                 double da = xa[i] - KA, db = xb[i] - KB;
                 if (PADDED) {
-                    const bool valid = j + i * S - pad >= 0;
+                    const bool valid = i >= 8 || j + i * S - pad >= 0; // (pad < n / 2: the upper half is always data)
                     da = valid ? da : 0.0;
                     db = valid ? db : 0.0;
                 }

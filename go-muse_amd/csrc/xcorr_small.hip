@@ -590,7 +590,7 @@ __global__ __launch_bounds__((LOGN >= 11 ? (1 << LOGN) / 16 : 256), 4) void xcor
         double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-            const bool valid = !PADDED || js + i * S - pad >= 0;
+            const bool valid = !PADDED || i >= 8 || js + i * S - pad >= 0; // (pad < n / 2: the upper half is always data)
             const double da = valid ? xa[i] - KA : 0.0, db = valid ? xb[i] - KB : 0.0;
             v[i] = make_double2(da, db);
             q0 += da;
@@ -613,7 +613,7 @@ __global__ __launch_bounds__((LOGN >= 11 ? (1 << LOGN) / 16 : 256), 4) void xcor
         js &= S - 1;
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-            const bool valid = !PADDED || js + i * S - pad >= 0;
+            const bool valid = !PADDED || i >= 8 || js + i * S - pad >= 0; // (pad < n / 2: the upper half is always data)
             v[i].x = valid ? fma(v[i].x, sA, -mA) : 0.0;
             v[i].y = valid ? fma(v[i].y, sB, -mB) : 0.0;
         }
