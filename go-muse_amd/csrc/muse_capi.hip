@@ -76,7 +76,6 @@ extern "C" int64_t muse_next_pow2(double val)
 struct muse_ctx {
     int device = 0;
     hipStream_t stream = nullptr;      // every kernel of the context
-    double *team_ws = nullptr; // xcorr_long_team.hip: LONG_TEAM_CAP x 1024 doubles (counters, partial statistics, candidates)
     hipStream_t copy_stream = nullptr; // host -> HBM uploads of muse_group_append: run beside a score pass
     int num_cus = 0;
     int64_t hbm = 0;
@@ -235,13 +234,6 @@ static int use_device(muse_ctx *ctx)
     return MUSE_OK;
 }
 
-// automatic selection for n >= 32768: 1 = a team of workgroups per pair (xcorr_long_team.hip), 0 = a pair per workgroup
-// (xcorr_long.hip); the other one stays a test hook (13 / 14)
-#ifndef MUSE_LONG_DEFAULT_IS_TEAM
-#define MUSE_LONG_DEFAULT_IS_TEAM 0
-#endif
-constexpr size_t LONG_TEAM_CAP = 256; // teams the workspace is sized for (1 024 resident workgroups / 8 = 128 at n = 32768)
-
 // ----------------------------------------------------------------- context
 static void fill_twiddle(std::vector<double2> &v, size_t i, long long num, long long den)
 {
@@ -371,7 +363,6 @@ static void ctx_release(muse_ctx *ctx)
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
     }
-    (void)hipFree(ctx->team_ws);
     (void)hipFree(ctx->tw1);
     (void)hipFree(ctx->tw2);
     (void)hipFree(ctx->twm);
@@ -425,8 +416,8 @@ extern "C" int muse_ctx_device_info(muse_ctx *ctx, char *name, int32_t name_cap,
 
 extern "C" int muse_ctx_set_kernel(muse_ctx *ctx, int32_t variant)
 {
-    if (!ctx || !(variant == 0 || variant == 1 || variant == 7 || variant == 10 || variant == 11 || variant == 12 || variant == 13 || variant == 14))
-        return fail(MUSE_ERR_INVALID, "bad kernel variant (0 auto, 1 generic, 7 rescaling n=4096, 10 default n=4096, 11 Stockham, 12 half-round, 13 long series per workgroup, 14 long series per team)");
+    if (!ctx || !(variant == 0 || variant == 1 || variant == 7 || variant == 10 || variant == 11 || variant == 12 || variant == 13))
+        return fail(MUSE_ERR_INVALID, "bad kernel variant (0 auto, 1 generic, 7 rescaling n=4096, 10 default n=4096, 11 Stockham, 12 half-round, 13 long series)");
     ctx->variant = variant;
     return MUSE_OK;
 }
@@ -1120,8 +1111,6 @@ extern "C" int muse_batch_score(muse_batch *b)
         if (variant == KERNEL_R16_FOLD && ctx->variant == 0 && b->handoff_host && b->handoff_M == M &&
             (long long)*(volatile int *)b->handoff_host * 8 > p.npairs)
             variant = KERNEL_R16_OCC3;
-    } else if (b->xcp && p.twl && b->n >= 32768 && (ctx->variant == 14 || (ctx->variant == 0 && MUSE_LONG_DEFAULT_IS_TEAM))) {
-        variant = KERNEL_LONG_TEAM; // four-step, a team of n / 4096 workgroups per pair (xcorr_long_team.hip)
     } else if (b->xcp && p.twl && ((b->n >= 32768 && ctx->variant == 0) || (b->n >= 16384 && ctx->variant == 13))) {
         variant = KERNEL_LONG; // four-step, 4096-point rows on the n = 4096 kernel's transforms (xcorr_long.hip)
     } else if (((b->n >= 512 && b->n <= 2048) || b->n == 8192 || b->n == 16384) && (ctx->variant == 0 || ctx->variant == 12)) {
@@ -1167,7 +1156,7 @@ extern "C" int muse_batch_score(muse_batch *b)
             b->handoff_M = M;
             HIP_TRY(hipMemcpyAsync(b->handoff_host, b->ovf_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         }
-    } else if (variant == KERNEL_LONG || variant == KERNEL_LONG_TEAM) {
+    } else if (variant == KERNEL_LONG) {
         // as above: NaN / Inf and sigma-spread pairs are listed (one entry per pair) and redone by the four-step kernel that
         // isolates and rescales the series first
         if (2 * p.npairs > b->ovf_cap) {
@@ -1180,13 +1169,6 @@ extern "C" int muse_batch_score(muse_batch *b)
         p.ovf_count = b->ovf_count;
         p.ovf_list = b->ovf_list;
         HIP_TRY(hipMemsetAsync(b->ovf_count, 0, 2 * sizeof(int), ctx->stream));
-        if (variant == KERNEL_LONG_TEAM) {
-            if (!ctx->team_ws)
-                HIP_TRY(hipMalloc(&ctx->team_ws, (size_t)LONG_TEAM_CAP * 1024 * sizeof(double)));
-            p.team_ws = ctx->team_ws;
-            p.team_cap = (int)std::min<size_t>(LONG_TEAM_CAP, ctx->gscratch_elems / ((size_t)2 * (size_t)b->n));
-            HIP_TRY(hipMemsetAsync(ctx->team_ws, 0, (size_t)LONG_TEAM_CAP * 1024 * sizeof(double), ctx->stream));
-        }
         HIP_TRY(launch_fused(p, variant, ctx->num_cus, ctx->stream));
         FusedParams q = p;
         q.pair_list = b->ovf_list;

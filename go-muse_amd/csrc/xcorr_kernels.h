@@ -8,7 +8,7 @@
 
 namespace muse {
 
-enum { KERNEL_GENERIC = 0, KERNEL_R16_OCC3 = 6, KERNEL_STOCKHAM = 10, KERNEL_R16_FOLD = 11, KERNEL_SMALL = 12, KERNEL_LONG = 13, KERNEL_LONG_TEAM = 14 };
+enum { KERNEL_GENERIC = 0, KERNEL_R16_OCC3 = 6, KERNEL_STOCKHAM = 10, KERNEL_R16_FOLD = 11, KERNEL_SMALL = 12, KERNEL_LONG = 13 };
 
 struct FusedParams {
     const double *rows; // M x N row-major, row stride `stride` elements (float64 groups)
@@ -29,9 +29,6 @@ struct FusedParams {
     const double2 *g3a;  // [8][256] first transform, pass 3: u = (t >> 4) + 16 (t & 15)
     const double2 *g3b;  // [8][256] second transform, pass 3: u = t
     const double2 *gsmall; // [8][n/16] xcorr_small.hip (n = 512, 1024, 2048): last-pass factors, delta = j / (n/16), lane-ordered
-    // xcorr_long_team.hip: per-team workspace (counters, partial statistics, argmax candidates), teams it is sized for
-    double *team_ws;
-    int team_cap;
     const double2 *twl;  // [n/4096][4096] W_n^(m2 k1): the sweeps' twiddles of the long-series kernel (xcorr_long.hip)
     const double *c1;    // [n] (n = 4096 and the long-series kernel) N < n: correlation of the valid-sample indicator with the reference (xcorr_r16_fold.hip)
     // many references in one pass (xcorr_fused_n4096_multi): device arrays of R pointers
@@ -82,8 +79,7 @@ hipError_t launch_fused_fold(const FusedParams &p, int num_cus, hipStream_t stre
 hipError_t launch_fused_multi(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_r16_fold.hip (R references)
 hipError_t launch_fused_small(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_small.hip (n = 512, 1024, 2048: default)
 hipError_t launch_fused_stockham(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_stockham.hip (n = 512 .. 2048, 8192 .. 65536)
-hipError_t launch_fused_long(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_long.hip (n = 16384 ... 65536: a pair per workgroup)
-hipError_t launch_fused_long_team(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_long_team.hip (n = 32768, 65536: a pair per team of workgroups)
+hipError_t launch_fused_long(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_long.hip (n = 32768, 65536: default; 16384)
 // out[4096 k1 + 256 k + t] = in[k1 + R1 (256 k + (t >> 4) + 16 (t & 15))]: the spectrum rows of the long-series kernel in lane order
 hipError_t launch_lane_order_rows(const double2 *in, double2 *out, int R1, hipStream_t stream);
 // out[256 k + t] = in[256 k + (t >> 4) + 16 (t & 15)], k < 16: a 4096-entry table in the lane order of xcorr_r16_fold.hip

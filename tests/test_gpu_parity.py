@@ -605,7 +605,6 @@ def test_stockham_kernels_match_oracle_and_generic(muse, eng, oracle, N):
         got = {}
         small = db.n <= 2048 or db.n in (8192, 16384)   # lengths the half-round kernel (xcorr_small.hip) is built for
         variants = ((0, 11, 12, 1) if small else (0, 11, 1)) + ((13,) if db.n >= 16384 else ())   # 13: xcorr_long.hip
-        variants += (14,) if db.n >= 32768 else ()                     # 14: xcorr_long_team.hip
         for variant in variants:
             eng.set_kernel(variant)
             lag, mv = db.scores()
