@@ -45,7 +45,8 @@ using namespace fold;
 
 constexpr int padk(int x) { return x + (x >> 4); }
 // MUSE_SMALL_EXP (tools/ablate only; never defined in the library build; results are wrong): table values read from a 1 KB LDS
-// array instead of L2 -- bit 0 the lane-ordered pass factors, bit 1 the spectrum factors, bit 2 the W_65536 factors of pass 2
+// array instead of L2 -- bit 0 the lane-ordered pass factors, bit 1 the spectrum factors, bit 2 the W_65536 factors of pass 2;
+// bit 3 = the transposes of multi-wave pairs without their workgroup barriers
 #ifndef MUSE_SMALL_EXP
 #define MUSE_SMALL_EXP 0
 #endif
@@ -415,7 +416,7 @@ __device__ __forceinline__ void forward(double2 (&v)[16], double2 *b, const doub
     // pairs inside one wave need no hardware barrier (LDS operations of a wave execute in order), but the COMPILER must
     // not move a lane's reads above its writes: other lanes' data arrives through them
     const auto sync = [&]() __attribute__((always_inline)) {
-        if (S > 64) {
+        if (S > 64 && !(MUSE_SMALL_EXP & 8)) { // (ablation bit 3: no workgroup barriers in the transposes)
             lds_barrier();
         } else {
             fence();

@@ -6,6 +6,6 @@ cd "$(dirname "$0")/../.."
 for w in "$@"; do
     python3 go-muse_amd/build.py -DMUSE_SMALL_EXP=$w > /dev/null 2>&1
     echo "== MUSE_SMALL_EXP=$w"
-    SIZES_AUTO_ONLY=1 python3 tools/sizes_bench.py 8000000000 512 1024 2048 8192
+    SIZES_AUTO_ONLY=1 python3 tools/sizes_bench.py 8000000000 ${SIZES_LIST:-512 1024 2048 8192}
 done
 python3 go-muse_amd/build.py > /dev/null 2>&1
