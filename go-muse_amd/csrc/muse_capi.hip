@@ -1111,7 +1111,7 @@ extern "C" int muse_batch_score(muse_batch *b)
         if (variant == KERNEL_R16_FOLD && ctx->variant == 0 && b->handoff_host && b->handoff_M == M &&
             (long long)*(volatile int *)b->handoff_host * 8 > p.npairs)
             variant = KERNEL_R16_OCC3;
-    } else if (b->xcp && p.twl && ((b->n >= 32768 && ctx->variant == 0) || (b->n >= 16384 && ctx->variant == 13))) {
+    } else if (b->xcp && p.twl && (b->N == b->n || b->c1) && ((b->n >= 32768 && ctx->variant == 0) || (b->n >= 16384 && ctx->variant == 13))) {
         variant = KERNEL_LONG; // four-step, 4096-point rows on the n = 4096 kernel's transforms (xcorr_long.hip)
     } else if (((b->n >= 512 && b->n <= 2048) || b->n == 8192 || b->n == 16384) && (ctx->variant == 0 || ctx->variant == 12)) {
         variant = KERNEL_SMALL; // half-round transposes at 16 waves per CU (xcorr_small.hip)
