@@ -49,12 +49,8 @@
 
 namespace muse {
 
-// QD: quads (256 threads: the unit of a sweep chunk and of a row transform) per workgroup.  QD = 1: four independent
-// workgroups per CU, four pairs (slices) in flight per CU; QD = 4: one 1024-thread workgroup per CU whose quads take
-// chunks and rows in turn -- one pair per CU in flight, i.e. a quarter of the scratch footprint (n = 32768: 128 MB chip-wide,
-// inside the 256 MiB Infinity Cache) for the same 16 waves per CU; the quads' transposes then share the workgroup barriers.
-template <int LOGN, bool PADDED, int QD>
-__global__ __launch_bounds__(256 * QD, 4) void xcorr_fused_long(const FusedParams p)
+template <int LOGN, bool PADDED>
+__global__ __launch_bounds__(256, 4) void xcorr_fused_long(const FusedParams p)
 {
     using namespace occ4;
     using namespace fold;
@@ -65,18 +61,14 @@ __global__ __launch_bounds__(256 * QD, 4) void xcorr_fused_long(const FusedParam
     constexpr int CH = S / 256;   // chunks of 256 threads x 16 elements per sweep
     constexpr int R1 = n / 4096;  // rows
     constexpr int Q1 = 16 / R1;   // butterflies of radix R1 per thread and chunk
-    constexpr int NW = 4 * QD;    // waves
+    constexpr int NW = 4;         // waves
     static_assert(LOGN >= 14 && LOGN <= 16, "n = 16384, 32768, 65536");
-    static_assert(QD == 1 || QD == 4, "one or four quads");
-    __shared__ double2 xbuf_all[QD * OCC_XBUF];
+    __shared__ double2 xbuf[OCC_XBUF];
     __shared__ double2 g2s[128];
     __shared__ double red[4 * NW + 2 * NW + 2];
     __shared__ int redi[2 * NW];
-    const int tw = threadIdx.x, lane = tw & 63;
-    const int wave_all = __builtin_amdgcn_readfirstlane(tw >> 6);
-    const int qd = QD == 1 ? 0 : (wave_all >> 2), wave = wave_all & 3; // quad, wave of the quad (wave-uniform)
-    const int t = tw & 255;                                            // thread of the quad
-    double2 *const xbuf = xbuf_all + qd * OCC_XBUF;
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     double2 *const xw = xbuf + XW * wave;
     double2 *const Y = p.gscratch + (size_t)blockIdx.x * (size_t)n; // the workgroup's slice
     const int N = PADDED ? p.N : n, pad = n - N;
@@ -95,8 +87,8 @@ __global__ __launch_bounds__(256 * QD, 4) void xcorr_fused_long(const FusedParam
         const int m = f / (R1 - 1), k1 = 1 + f % (R1 - 1);
         return ldg2u(scalar_ptr_at(twl, k1 * 4096 + m * S), jj);
     };
-    if (tw < 128)
-        g2s[tw] = p.g2[tw];
+    if (t < 128)
+        g2s[t] = p.g2[t];
     __syncthreads();
 
     for (long long pair = blockIdx.x; pair < p.npairs; pair += gridDim.x) {
@@ -108,7 +100,7 @@ __global__ __launch_bounds__(256 * QD, 4) void xcorr_fused_long(const FusedParam
         // ---------------- sweep 1
         double q[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma clang loop unroll(disable)
-        for (int ch = qd; ch < CH; ch += QD) {
+        for (int ch = 0; ch < CH; ch++) {
             const int j = opaque(t + 256 * ch) & (S - 1);
             double2 v[16];
             // all 32 requests first (a request behind a consumer would wait for it: the address asm statements keep program
@@ -188,7 +180,7 @@ __global__ __launch_bounds__(256 * QD, 4) void xcorr_fused_long(const FusedParam
         for (int k = 0; k < 4; k++) {
             const double w = wave_sum_dpp(q[k]);
             if (lane == 0)
-                red[4 * wave_all + k] = w;
+                red[4 * wave + k] = w;
         }
         __syncthreads();
 #pragma unroll
@@ -210,7 +202,7 @@ __global__ __launch_bounds__(256 * QD, 4) void xcorr_fused_long(const FusedParam
         __syncthreads(); // the slice is complete (and `red` is free again)
         // ---------------- rows
 #pragma clang loop unroll(disable)
-        for (int k1 = qd; k1 < ((MUSE_LONG_EXP & 1) ? 0 : R1); k1 += QD) {
+        for (int k1 = 0; k1 < ((MUSE_LONG_EXP & 1) ? 0 : R1); k1++) {
             double2 *const row = Y + k1 * 4096;
             double2 v[16];
             {
@@ -235,7 +227,7 @@ __global__ __launch_bounds__(256 * QD, 4) void xcorr_fused_long(const FusedParam
         double ma = 0.0, mb = 0.0, sa = 0.0, sb = 0.0, cc0a = 0.0, cc0b = 0.0;
         int ia = 0x7fffffff, ib = 0x7fffffff;
 #pragma clang loop unroll(disable)
-        for (int ch = qd; ch < ((MUSE_LONG_EXP & 4) ? 0 : CH); ch += QD) {
+        for (int ch = 0; ch < ((MUSE_LONG_EXP & 4) ? 0 : CH); ch++) {
             const int j = opaque(t + 256 * ch) & (S - 1);
             double2 v[16];
 #pragma unroll
@@ -278,7 +270,7 @@ __global__ __launch_bounds__(256 * QD, 4) void xcorr_fused_long(const FusedParam
                     c = make_double2(fma(-mA, c1, c.x), fma(-mB, c1, c.y));
                 }
                 if (i == 0) { // (lane 0 of chunk 0: cc[0], the value reported when nothing is above 0)
-                    cc0a = ch == 0 ? c.x : cc0a; // (chunk 0 belongs to quad 0)
+                    cc0a = ch == 0 ? c.x : cc0a;
                     cc0b = ch == 0 ? c.y : cc0b;
                 }
                 const bool ga = fabs(c.x) > fabs(csa), gb = fabs(c.y) > fabs(csb);
@@ -306,10 +298,10 @@ __global__ __launch_bounds__(256 * QD, 4) void xcorr_fused_long(const FusedParam
             constexpr int RM = 4 * NW, RC = 4 * NW + 2 * NW; // red: [RM + x] wave maxima A, [RM + NW + x] B, [RC], [RC + 1] cc[0]
             const double wa = wave_max(ma), wb = wave_max(mb);
             if (lane == 0) {
-                red[RM + wave_all] = wa;
-                red[RM + NW + wave_all] = wb;
+                red[RM + wave] = wa;
+                red[RM + NW + wave] = wb;
             }
-            if (tw == 0) {
+            if (t == 0) {
                 red[RC] = cc0a;
                 red[RC + 1] = cc0b;
             }
@@ -325,8 +317,8 @@ __global__ __launch_bounds__(256 * QD, 4) void xcorr_fused_long(const FusedParam
             ca = wave_min_i(ca);
             cb = wave_min_i(cb);
             if (lane == 0) {
-                redi[wave_all] = ca;
-                redi[NW + wave_all] = cb;
+                redi[wave] = ca;
+                redi[NW + wave] = cb;
             }
             __syncthreads();
             int IA = redi[0], IB = redi[NW];
@@ -341,7 +333,7 @@ __global__ __launch_bounds__(256 * QD, 4) void xcorr_fused_long(const FusedParam
                     break;
                 const int I = sidx ? IB : IA;
                 const bool none = I == 0x7fffffff;
-                const bool owner = none ? (tw == 0) : ((sidx ? ib : ia) == I && (sidx ? mb : ma) == (sidx ? MB : MA));
+                const bool owner = none ? (t == 0) : ((sidx ? ib : ia) == I && (sidx ? mb : ma) == (sidx ? MB : MA));
                 if (owner) {
                     const double var = sidx ? varB : varA;
                     const bool zero = sidx ? zeroB : zeroA, nan = sidx ? nanB : nanA;
@@ -359,7 +351,7 @@ __global__ __launch_bounds__(256 * QD, 4) void xcorr_fused_long(const FusedParam
             }
             // a NaN / Inf series poisons its partner through the shared transform, and sigmas too far apart cost the
             // smaller series its precision: such pairs are redone by the kernel that isolates and rescales first
-            if (tw == 0 && (nanA || (hasB && (nanB || sigma_spread_too_wide(varA, varB))))) {
+            if (t == 0 && (nanA || (hasB && (nanB || sigma_spread_too_wide(varA, varB))))) {
                 const int slot = atomicAdd(p.ovf_count, 1);
                 p.ovf_list[slot] = pair;
             }
@@ -368,19 +360,14 @@ __global__ __launch_bounds__(256 * QD, 4) void xcorr_fused_long(const FusedParam
     }
 }
 
-// MUSE_LONG_QD: quads per workgroup.  The library builds 1; 4 is a tools/ablate A/B build (measured slower at n = 32768
-// and 65536, profiles/r02_long_series.txt: the slices' reuse distance, not their sum, decides what the Infinity Cache keeps)
-#ifndef MUSE_LONG_QD
-#define MUSE_LONG_QD 1
-#endif
-template <int LOGN, int QD>
+template <int LOGN>
 static hipError_t launch_long_n(const FusedParams &p, int num_cus, hipStream_t stream)
 {
-    const long long grid = std::min<long long>(p.npairs, (long long)num_cus * (QD == 4 ? 1 : MUSE_LONG_WGS_PER_CU));
+    const long long grid = std::min<long long>(p.npairs, (long long)num_cus * MUSE_LONG_WGS_PER_CU);
     if (p.N < (1 << LOGN))
-        hipLaunchKernelGGL((xcorr_fused_long<LOGN, true, QD>), dim3((unsigned)grid), dim3(256 * QD), 0, stream, p);
+        hipLaunchKernelGGL((xcorr_fused_long<LOGN, true>), dim3((unsigned)grid), dim3(256), 0, stream, p);
     else
-        hipLaunchKernelGGL((xcorr_fused_long<LOGN, false, QD>), dim3((unsigned)grid), dim3(256 * QD), 0, stream, p);
+        hipLaunchKernelGGL((xcorr_fused_long<LOGN, false>), dim3((unsigned)grid), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 
@@ -391,9 +378,9 @@ hipError_t launch_fused_long(const FusedParams &p, int num_cus, hipStream_t stre
         (p.N < p.n && !p.c1))
         return hipErrorInvalidValue;
     switch (p.logn) {
-    case 14: return launch_long_n<14, MUSE_LONG_QD>(p, num_cus, stream);
-    case 15: return launch_long_n<15, MUSE_LONG_QD>(p, num_cus, stream);
-    case 16: return launch_long_n<16, MUSE_LONG_QD>(p, num_cus, stream);
+    case 14: return launch_long_n<14>(p, num_cus, stream);
+    case 15: return launch_long_n<15>(p, num_cus, stream);
+    case 16: return launch_long_n<16>(p, num_cus, stream);
     default: return hipErrorInvalidValue;
     }
 }
