@@ -584,6 +584,33 @@ def test_many_references_large(muse, eng):
         np.testing.assert_allclose(got[r][1], smv, rtol=1e-11, atol=0, equal_nan=True)
 
 
+@pytest.mark.parametrize("N", [512, 1000, 2048, 5000, 8192, 16384, 40000, 65536])
+def test_per_length_kernels_at_scale_match_the_stockham_kernels(muse, eng, oracle, N):
+    """~ 0.5 GB of synthetic rows per length (several resident sets of workgroups, odd row counts, planted copies and constant
+    rows): the per-length default kernels (xcorr_small.hip / xcorr_long.hip: persistent loops, rows requested one iteration
+    ahead, pair lists) against round 1's independent Stockham kernels (test hook 11) on EVERY row -- lags exact, scores to
+    rounding -- and against the oracle on a sample of rows."""
+    M = max(1001, (1 << 29) // (8 * N)) | 1
+    dg, ref = muse.DeviceGroup.synthetic(eng, M, N, seed=4242 + N)
+    db = muse.DeviceBatch(eng, dg, ref)
+    try:
+        lag, mv = db.scores()
+        eng.set_kernel(11)
+        slag, smv = db.scores()
+    finally:
+        eng.set_kernel(0)
+    same = lag == slag
+    # (near-ties between two lags may resolve differently in two implementations: a handful at most, and then the scores agree)
+    assert int((~same).sum()) <= 3
+    np.testing.assert_allclose(mv, smv, rtol=1e-10, atol=1e-13, equal_nan=True)
+    pick = np.unique(np.concatenate(([0, 1, M - 2, M - 1], np.random.default_rng(N).integers(0, M, size=24))))
+    rows = np.stack([dg.read(int(i), 1)[0] for i in pick])
+    olag, omv, gap = oracle.batch_scores(ref, rows)
+    assert_scores_match(lag[pick], mv[pick], olag, omv, gap, max_ties=1)
+    db.close()
+    dg.close()
+
+
 @pytest.mark.parametrize("N", [257, 480, 512, 700, 1000, 1024, 1025, 1500, 2048,
                                4097, 5000, 6000, 8192, 10000, 16384, 20000, 32768, 40000, 65536])
 def test_stockham_kernels_match_oracle_and_generic(muse, eng, oracle, N):
