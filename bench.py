@@ -110,6 +110,9 @@ def main():
                     help="skip the extra objects (filter_and_refine_run, f32_storage_group, many_references, config5_lengths)")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the RCCL gather path even with one rank (rehearsal on a 1-GPU box)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="rehearsal of the N-rank flow on a 1-GPU box: every rank uses GPU 0 and the gather runs over gloo "
+                         "(RCCL refuses two ranks on one device); the line it prints is not a measurement")
     args = ap.parse_args()
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
@@ -129,14 +132,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = world > 1 or args.force_dist
     ndev = torch.cuda.device_count()                     # (does not initialise the GPU on this image)
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     if ndev <= local_rank:
         sys.exit("bench.py: rank %d needs GPU %d but only %d visible: this engine has no CPU path" % (rank, local_rank, ndev))
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=max(world, 1),
-                                device_id=torch.device("cuda", local_rank))
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=max(world, 1))
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=max(world, 1),
+                                    device_id=torch.device("cuda", local_rank))
     n_gpus = max(world, 1)
 
     pkg = importlib.import_module("go-muse_amd")
@@ -153,7 +161,7 @@ def main():
     M, N = args.rows, args.length
     dg, ref = pkg.DeviceGroup.synthetic(eng, M, N, seed=0x6D757365, global_first=rank * M)
     db = pkg.DeviceBatch(eng, dg, ref)
-    tdev = torch.device("cuda", local_rank)
+    tdev = None if args.rehearse_on_one_gpu else torch.device("cuda", local_rank)   # (gloo gathers host tensors)
 
     def step():
         if use_dist:
@@ -180,7 +188,7 @@ def main():
     eng.kernel_timing(False)
     k_ms, k_cnt = eng.kernel_time()
     if use_dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device=tdev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=tdev if tdev is not None else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
@@ -207,6 +215,7 @@ def main():
             "value": value, "unit": "series-pairs/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "rehearsal": bool(args.rehearse_on_one_gpu),
             "config": {"workload": "configs[2]: 1 ref x %d series/GPU, N=%d float64 rect+noise, Run(nil), "
                                    "MaxLag=%d TopN=%d" % (M, N, args.max_lag, args.top_n),
                        "rows_per_gpu": M, "length": N, "fft_len": db.n, "sharding": "rows x %d" % n_gpus,

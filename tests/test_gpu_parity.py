@@ -1528,3 +1528,26 @@ def test_append_overlaps_a_running_score_pass(muse, eng, oracle):
     olag, omv, gap = oracle.batch_scores(ref, rows, nthreads=8)
     assert_scores_match(lag, mv, olag, omv, gap)
     db.close()
+
+
+def test_bench_two_ranks_rehearsal_on_one_gpu():
+    """`python bench.py --gpus 2` without a launcher: the parent spawns two rank processes before touching the GPU, both ranks
+    score their own shard (global row offsets), the per-shard records are gathered and merged, rank 0 prints ONE JSON line with
+    n_gpus = 2 -- rehearsed here with both ranks on GPU 0 and the gather over gloo (RCCL refuses two ranks on one device; the
+    RCCL path itself is covered at world size 1 above and by `--force-dist`)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env["MASTER_PORT"] = "29641"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rows", "20001", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-extras", "--rehearse-on-one-gpu"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rehearsal"] is True and d["dtype"] == "f64" and d["scaling"] == "weak"
+    assert d["value"] > 0 and d["config"]["rows_per_gpu"] == 20001
+    # the planted copy of the reference (synthetic row of rank 0) tops the merged list
+    assert abs(d["top_score"] - 1.0) < 1e-9
