@@ -175,3 +175,25 @@ def test_screen_bound_constants(muse):
             needed = c_needed * u * norm_z * xmax + 36 * u * math.sqrt(n / (n - 1.0)) + 1e-6 * (1 if n > 0 else 0)
             assert Es.value >= needed, (n, xmax, Es.value, needed)
             assert Es.value <= 2.0 * needed       # ... and not wastefully above it
+
+
+def test_lane_relabelling_removes_the_modelled_lds_bank_conflicts():
+    """tools/lds_bank_sim.py models the read / write lane groups of ds_read_b128 / ds_write_b128 (MI355X_MICROARCH.md, LDS) on the
+    half-round transposes of xcorr_small.hip: with column = lane every read costs 8 LDS cycles and every transpose-A write 16; the
+    kernel's lane -> column maps (column_of_lane<LOGN>, mirrored in the tool) bring them to the conflict-free 4 and 8, and the maps
+    are bijections.  (Measured: SQ_LDS_BANK_CONFLICT 1.02e8 -> 0 at n = 1024, profiles/r02_small_final_counters.txt.)"""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("lds_bank_sim", os.path.join(root, "tools", "lds_bank_sim.py"))
+    sim = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sim)
+    for logn in (10, 11, 13, 14):
+        W = sim.shape(logn)[4]
+        assert sorted(sim.column_of_lane(logn, l) for l in range(W)) == list(range(W))
+        rd0, wa0, _ = sim.cycles(logn, identity=True)
+        rd, wa, wbs = sim.cycles(logn)
+        assert (rd0, wa0) == (8, 16.0) and (rd, wa) == (4, 8.0)
+        assert wbs[0] <= 8.0
+    # the kernel source carries the same map: the XOR terms of column bit 3 and the parity of column bit 4
+    src = open(os.path.join(root, "go-muse_amd", "csrc", "xcorr_small.hip")).read()
+    assert "((l >> 4) ^ (l >> 3) ^ (l >> 2)) & 1" in src and "(LOGN == 10 || LOGN == 14) ? (l >> 1) : l" in src
