@@ -11,50 +11,12 @@
 
 namespace muse {
 
-// MUSE_FOLD_EXP (tools/ablate only; never defined in the library build): bit 0 = pass-3 factors read from the LDS
-// table instead of L2 (wrong values, same arithmetic), bit 1 = spectrum factors likewise, bit 3 = no result write-out
-#ifndef MUSE_FOLD_EXP
-#define MUSE_FOLD_EXP 0
-#endif
-
-// MUSE_FOLD_OPT: scheduling choices, A/B-ed in tools/ablate/fold_phases.hip (the library builds the default):
-//   bit 0: the previous pair's two results are written by lane 0 of waves 0 and 1 (one series each) instead of lanes 0 / 1 of wave 0
-//   bit 1: the first four factors of a pass-3 transform are requested BEFORE the transpose that precedes it
-//   bit 2: the first spectrum factors are requested before the last stage of the first transform
-//   bit 3: the next pair's first row is requested before the last stage of the second transform, the second row after the argmax
-//   bit 6: the barrier that frees the wave's private quarter sits right behind the first workgroup-wide transpose
-//   bit 7: the second transform's last stage, the argmax and the next pair's row requests interleaved (N == n)
-//   bit 8: the argmax as one running maximum per lane, the next pair's row requests spread over it
-//   bit 9: (with bit 8) the running-maximum argmax, but the row requests stay one burst behind it
-//   bit 4: all eight factors of a pass-3 transform requested at once;  bit 5: both rows requested before the last stage (3 waves per SIMD)
-#ifndef MUSE_FOLD_OPT
-#define MUSE_FOLD_OPT 65
-#endif
-
 namespace foldk {
 
 using namespace occ4;
 using namespace fold;
 
 constexpr int XW = 544; // double2 per wave-private quarter of the 8 x 272 buffer (8 rows x 68)
-
-// The thread index made opaque: everything derived from the copy (lane / wave parts, LDS and table offsets) is
-// recomputed where it is used (a few 32-bit VALU instructions) instead of being hoisted out of the pair loop, where a
-// dozen such values would each hold a register for the whole kernel -- or, at 128 registers, a scratch slot that is
-// reloaded through the vector memory pipe in front of every use.
-#ifndef MUSE_FOLD_F32_EARLY
-#define MUSE_FOLD_F32_EARLY 1
-#endif
-#ifndef MUSE_FOLD_FRESH
-#define MUSE_FOLD_FRESH 0
-#endif
-template <int BIT>
-__device__ __forceinline__ int fresh(int t)
-{
-    if (MUSE_FOLD_FRESH & BIT)
-        asm volatile("" : "+v"(t));
-    return t;
-}
 
 // output k of the preceding pass sits in register PERM(k): 0 = natural, 1 = bit-reversed (NR passes)
 template <int PERM>
@@ -71,7 +33,7 @@ __device__ __forceinline__ constexpr int pr(int k)
 template <int MODE, int PERM, bool TAILBAR = false>
 __device__ __forceinline__ void exchange_cross(double2 (&v)[16], double2 *xbuf, const int wave, const int t_)
 {
-    const int t = fresh<1>(t_);
+    const int t = t_;
     const int hi = t >> 4, lo = t & 15;
     const int wbase = MODE ? 17 * lo + hi : t;
     const int rbase = 272 * (hi & 7) + (MODE ? 17 * lo : lo);
@@ -118,7 +80,7 @@ typedef __attribute__((address_space(3))) char *lds_ptr;
 template <int PERM>
 __device__ __forceinline__ void exchange_local(double2 (&v)[16], double2 *xw, const int t_)
 {
-    const int t = fresh<2>(t_);
+    const int t = t_;
     const int hl = (t >> 4) & 3, lo = t & 15;
     const int wbase = 17 * hl + lo;
     const int rbase = 68 * (lo & 7) + 17 * hl;
@@ -208,28 +170,23 @@ struct G3Fetch {
     }
 };
 
-// generalised pass whose first four factors (ga) were requested earlier; `mid()` runs between stage 3 and stage 4
-template <typename F, typename MID>
-__device__ __forceinline__ void gdft16_nr_pre(double2 (&v)[16], const double2 (&ga)[4], F fetch, MID mid)
+// generalised pass with its factors in L2 (pass 3): the second batch of four is requested behind the second stage
+// (two batches in flight would not fit 128 registers), stages separated by scheduling fences
+template <typename F>
+__device__ __forceinline__ void gdft16_nr_l2(double2 (&v)[16], F fetch)
 {
-    double2 gb[4];
-    if (MUSE_FOLD_OPT & 16) {
+    double2 ga[4], gb[4];
 #pragma unroll
-        for (int s = 0; s < 4; s++)
-            gb[s] = fetch(4 + s);
-        fence();
-    }
+    for (int s = 0; s < 4; s++)
+        ga[s] = fetch(s);
     gdft16_nr_s12(v, ga[0], ga[1]);
-    if (!(MUSE_FOLD_OPT & 16)) {
-        fence();
+    fence();
 #pragma unroll
-        for (int s = 0; s < 4; s++)
-            gb[s] = fetch(4 + s);
-    }
+    for (int s = 0; s < 4; s++)
+        gb[s] = fetch(4 + s);
     fence();
     gdft16_nr_s3(v, ga[2], ga[3]);
     fence();
-    mid();
     fence();
     gdft16_nr_s4(v, gb[0], gb[1], gb[2], gb[3]);
 }
@@ -334,53 +291,12 @@ __device__ __forceinline__ void wave_argmax_store(const double2 (&v)[16], const 
     }
 }
 
-// Per-lane running maxAbsIndex (xcorr.go:39-50: strictly greater replaces, so ascending indices keep the first):
-// `best` is the signed value, m its index among the lane's sixteen lags t + 256 m.
-struct ArgRun {
-    double best;
-    int m;
-};
-__device__ __forceinline__ void arg_consume(ArgRun &r, const double x, const int m)
-{
-    const bool g = fabs(x) > fabs(r.best);
-    r.best = g ? x : r.best;
-    r.m = g ? m : r.m;
-    // pinned here: IR-level passes otherwise sink a whole series' chain below the interleaved row requests (sched_barrier
-    // only binds the machine scheduler) and the consumed values stay live
-    asm volatile("" : "+v"(r.best), "+v"(r.m));
-}
-// lo chain (m = 0..7) and hi chain (m = 8..15), both ascending: the hi chain wins only when strictly greater
-__device__ __forceinline__ ArgRun arg_merge(const ArgRun &lo, const ArgRun &hi)
-{
-    ArgRun r = lo;
-    const bool g = fabs(hi.best) > fabs(lo.best);
-    r.best = g ? hi.best : lo.best;
-    r.m = g ? hi.m : lo.m;
-    return r;
-}
-// the wave's {max |cc|, signed value (cc[0] when nothing is above 0), index} of one series from the lanes' running maxima
-__device__ __forceinline__ void wave_argmax_finish(const ArgRun &r, const int t, const int lane, double *out)
-{
-    const double mine = fabs(r.best);
-    const double wa = wave_max_dpp(mine);
-    const int cand = (mine == wa && wa > 0.0) ? (t + 256 * r.m) : 0x7fffffff;
-    const int widx = wave_min_i_dpp(cand);
-    const int l = widx & 63; // wave-uniform (SGPR)
-    const double sv = readlane_f64(r.best, l);
-    if (lane == 0) { // (nothing above 0: slot 1 of wave 0 keeps cc[0], written there by the caller)
-        out[0] = widx == 0x7fffffff ? 0.0 : wa;
-        if (widx != 0x7fffffff)
-            out[1] = sv;
-        out[2] = (double)widx;
-    }
-}
-
 // spectrum multiply folded into the first stage of the second transform's plain pass:
 // z[b] at v[BR16(b)] (b = k3), xc for k3 = b from the lane-ordered table; four batches of four factors, two in flight
-template <bool PRE, typename F>
-__device__ __forceinline__ void xc_stage1(double2 (&v)[16], double2 (&xa)[4], F xcl)
+template <typename F>
+__device__ __forceinline__ void xc_stage1(double2 (&v)[16], F xcl)
 {
-    double2 xb[4];
+    double2 xa[4], xb[4];
     // batch i covers butterflies b = 2 i, 2 i + 1: factors xc[2i], xc[2i + 8], xc[2i + 1], xc[2i + 9]
 #define MUSE_XC_LOAD(dst, i)          \
     dst[0] = xcl(2 * (i));            \
@@ -390,9 +306,7 @@ __device__ __forceinline__ void xc_stage1(double2 (&v)[16], double2 (&xa)[4], F 
 #define MUSE_XC_USE(src, i)                                                      \
     bf_xc(v[BR16(2 * (i))], v[BR16(2 * (i)) + 1], src[0], src[1]);               \
     bf_xc(v[BR16(2 * (i) + 1)], v[BR16(2 * (i) + 1) + 1], src[2], src[3]);
-    if (!PRE) {
-        MUSE_XC_LOAD(xa, 0)
-    }
+    MUSE_XC_LOAD(xa, 0)
     MUSE_XC_LOAD(xb, 1)
     fence();
     MUSE_XC_USE(xa, 0)

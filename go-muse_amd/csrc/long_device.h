@@ -67,38 +67,26 @@ __device__ __forceinline__ void row_transforms(double2 (&v)[16], double2 *xbuf, 
                                                const double2 *__restrict__ g3a, const double2 *__restrict__ g3b,
                                                const double2 *__restrict__ xrow, const int t, const int wave, const bool zero0)
 {
-    int tx = t, tg = t;
     const auto xcl = [&](int j) __attribute__((always_inline)) {
-        return ldg2(scalar_ptr_at(xrow, 256 * ((j + 1) & ~1)), tx - 256 * (j & 1));
+        return ldg2(scalar_ptr_at(xrow, 256 * ((j + 1) & ~1)), t - 256 * (j & 1));
     };
-    const auto g3 = [&](const double2 *tab, int s) __attribute__((always_inline)) { return G3Fetch{tab, tg}(s); };
-    double2 ga[4], xa[4];
     // ---- first transform: plain pass over a, generalised passes over b (delta = k1 / 16) and c (delta = (k1 + 16 k2) / 256)
     dft16_nr(v);
     exchange_cross<0, 1, true>(v, xbuf, wave, t);
     gdft16_nr(v, G2Fetch{g2s, t >> 4});
     exchange_local<1>(v, xw, t);
-    tg = fresh<8>(t);
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-        ga[q] = g3(g3a, q);
-    gdft16_nr_pre(v, ga, [&](int q) __attribute__((always_inline)) { return g3(g3a, q); }, [&]() __attribute__((always_inline)) {});
+    gdft16_nr_l2(v, G3Fetch{g3a, t});
     if (zero0) {
         v[0].x = (t == 0) ? 0.0 : v[0].x;
         v[0].y = (t == 0) ? 0.0 : v[0].y;
     }
     // ---- second transform: plain pass with the spectrum factors folded into its first stage, then the two generalised ones
-    tx = fresh<8>(t);
-    xc_stage1<false>(v, xa, xcl);
+    xc_stage1(v, xcl);
     dft16_rn_s234(v);
     exchange_local<0>(v, xw, t);
     gdft16_nr(v, G2Fetch{g2s, t & 15});
     exchange_cross<1, 1>(v, xbuf, wave, t);
-    tg = fresh<8>(t);
-#pragma unroll
-    for (int q = 0; q < 4; q++)
-        ga[q] = g3(g3b, q);
-    gdft16_nr_pre(v, ga, [&](int q) __attribute__((always_inline)) { return g3(g3b, q); }, [&]() __attribute__((always_inline)) {});
+    gdft16_nr_l2(v, G3Fetch{g3b, t});
 }
 
 } // namespace lng

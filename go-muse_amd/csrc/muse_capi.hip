@@ -467,6 +467,7 @@ extern "C" int muse_ctx_kernel_time(muse_ctx *ctx, double *total_ms, int64_t *la
 // Every group allocation starts with GROUP_GUARD readable (zeroed) elements in front of row 0: the kernels for zero-padded
 // series (xcorr_small.hip) read up to n - N samples in front of a row without clamping and mask them afterwards.
 constexpr size_t GROUP_GUARD = 8192;
+static_assert(GROUP_GUARD >= (size_t)SMALL_MAX_N / 2, "xcorr_small.hip reads up to n - N < n / 2 samples in front of row 0");
 static int group_create(muse_ctx *ctx, int64_t capacity_rows, int32_t N, bool f32, muse_group **out);
 extern "C" int muse_group_create(muse_ctx *ctx, int64_t capacity_rows, int32_t N, muse_group **out)
 {
@@ -821,7 +822,7 @@ static hipError_t ensure_gscratch(muse_ctx *ctx, int64_t n)
 {
     if (n < GENERIC_LDS_MAX_N) // generic kernel above 8192: one slice per workgroup; Stockham from 8192: up to two
         return hipSuccess;
-    const size_t need = (size_t)ctx->num_cus * std::max(GENERIC_GLOBAL_WGS_PER_CU, 2 * STOCKHAM_GLOBAL_WGS_PER_CU) * (size_t)n;
+    const size_t need = (size_t)ctx->num_cus * GSCRATCH_SLICES_PER_CU * (size_t)n;
     std::lock_guard<std::mutex> lock(ctx->stage_mu); // launches that use the buffer hold the same lock (muse_batch_score)
     if (need <= ctx->gscratch_elems)
         return hipSuccess;
@@ -923,7 +924,7 @@ extern "C" int muse_batch_create(muse_ctx *ctx, muse_group *g, const double *ref
     }
     if (long_n) {
         const int li = ilog2(n) - 14, R1 = (int)(n / 4096);
-        if (!ctx->twl[li]) {
+        { // (first use per length: rare, so always under the lock -- no unlocked read of the pointer another thread may be storing)
             std::lock_guard<std::mutex> lock(ctx->stage_mu);
             if (!ctx->twl[li]) {
                 std::vector<double2> tl((size_t)n);
@@ -1050,6 +1051,7 @@ static FusedParams base_params(muse_batch *b)
     p.tw2 = ctx->tw2;
     p.twm = ctx->twm;
     p.gscratch = ctx->gscratch;
+    p.gscratch_slices = b->n > 0 ? (long long)(ctx->gscratch_elems / (size_t)b->n) : 0;
     p.mv = b->mv;
     p.lag = b->lag;
     p.cc_out = nullptr;
@@ -1474,7 +1476,9 @@ static int screen_prepare(muse_batch *b, int32_t top_n, const int *gid_dev, int6
         HIP_TRY(hipMalloc(&b->est_save, (size_t)(4 * npairs) * sizeof(double)));
         b->est_cap = 4 * npairs;
     }
-    if (npairs > b->ovf_cap) {
+    // the list takes the selection's pairs (at most npairs) plus the guard sample (about npairs / 1024, not de-duplicated
+    // against the selection): 2 npairs entries, the same capacity the fp64 pass's hand-off list has
+    if (2 * npairs > b->ovf_cap) {
         (void)hipFree(b->ovf_list);
         b->ovf_list = nullptr;
         b->ovf_cap = 0;
@@ -2255,6 +2259,7 @@ static int single_pair(muse_ctx *ctx, const double *x, int lenx, const double *y
         if (n > GENERIC_LDS_MAX_N) {
             SP_TRY(hipMalloc(&dscr, (size_t)n * sizeof(double2)));
             p.gscratch = dscr;
+            p.gscratch_slices = 1;
         }
         SP_TRY(launch_fused(p, KERNEL_GENERIC, ctx->num_cus, ctx->stream));
         SP_TRY(hipMemcpyAsync(&lg, dlag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));

@@ -18,16 +18,8 @@ namespace occ4 {
 
 __device__ __forceinline__ void fence() { __builtin_amdgcn_sched_barrier(0); }
 // LDS-only barrier (does not drain outstanding global loads)
-// MUSE_ABLATE (tools/ablate only; never defined in the library build): bit 0 = no LDS transposes and no workgroup
-// barriers (register permutations keep the data flow), bit 1 = every workgroup re-reads the same eight pairs of
-// rows (L2-resident: no HBM traffic, the load instructions stay).  Same arithmetic, garbage results.
-#ifndef MUSE_ABLATE
-#define MUSE_ABLATE 0
-#endif
 __device__ __forceinline__ void lds_barrier()
 {
-    if (MUSE_ABLATE & 1)
-        return;
     fence();
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     fence();
@@ -225,8 +217,6 @@ struct RawPair {
 template <bool PADDED, bool F32 = false>
 __device__ __forceinline__ void issue_row_loads(RawPair &r, const FusedParams &p, long long pair, int t, int pad)
 {
-    if (MUSE_ABLATE & 2)
-        pair &= 7;
     const long long rA = 2 * pair;
     const long long rB = (rA + 1 < p.M) ? rA + 1 : rA;
     if (F32) {
@@ -272,68 +262,6 @@ __device__ __forceinline__ void issue_row_loads(RawPair &r, const FusedParams &p
             r.b[i] = __builtin_nontemporal_load(scalar_ptr_at(p.rows + rB * p.stride, c) + (256 * i - c) + t);
         }
     }
-}
-
-// The same, one row at a time (ROW 0: first series + its first sample, ROW 1: second series): the two requests
-// can sit in different phases of the pair loop.
-template <bool PADDED, int ROW>
-__device__ __forceinline__ void issue_row_loads_half(RawPair &r, const FusedParams &p, long long pair, int t, int pad)
-{
-    if (MUSE_ABLATE & 2)
-        pair &= 7;
-    const long long rA = 2 * pair;
-    const long long rB = (rA + 1 < p.M) ? rA + 1 : rA;
-    const long long row = ROW ? rB : rA;
-    double(&dst)[16] = ROW ? r.b : r.a;
-    const gptr<double> rp = scalar_ptr(p.rows + row * p.stride);
-    (ROW ? r.kb : r.ka) = rp[0];
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-        if (PADDED) {
-            int j = t + 256 * i - pad;
-            if (i < 8)
-                j = j < 0 ? 0 : j;
-            const unsigned ju = (unsigned)j & 4095u;
-            dst[i] = __builtin_nontemporal_load(rp + ju);
-        } else {
-            const int c = (i & ~3) * 256 + 512;
-            dst[i] = __builtin_nontemporal_load(scalar_ptr_at(p.rows + row * p.stride, c) + (256 * i - c) + t);
-        }
-    }
-}
-
-// one element of both rows (the caller clamps `pair`; N == n only)
-__device__ __forceinline__ void issue_row_elem(RawPair &r, const FusedParams &p, long long pair, int t, int i)
-{
-    if (MUSE_ABLATE & 2)
-        pair &= 7;
-    const long long rA = 2 * pair;
-    const long long rB = (rA + 1 < p.M) ? rA + 1 : rA;
-    const int c = (i & ~3) * 256 + 512;
-    r.a[i] = __builtin_nontemporal_load(scalar_ptr_at(p.rows + rA * p.stride, c) + (256 * i - c) + t);
-    r.b[i] = __builtin_nontemporal_load(scalar_ptr_at(p.rows + rB * p.stride, c) + (256 * i - c) + t);
-}
-__device__ __forceinline__ void issue_row_elem_padded(RawPair &r, const FusedParams &p, long long pair, int t, int i, int pad)
-{
-    if (MUSE_ABLATE & 2)
-        pair &= 7;
-    const long long rA = 2 * pair;
-    const long long rB = (rA + 1 < p.M) ? rA + 1 : rA;
-    int j = t + 256 * i - pad;
-    if (i < 8)
-        j = j < 0 ? 0 : j;
-    const unsigned ju = (unsigned)j & 4095u;
-    r.a[i] = __builtin_nontemporal_load(scalar_ptr(p.rows + rA * p.stride) + ju);
-    r.b[i] = __builtin_nontemporal_load(scalar_ptr(p.rows + rB * p.stride) + ju);
-}
-__device__ __forceinline__ void issue_row_firsts(RawPair &r, const FusedParams &p, long long pair)
-{
-    if (MUSE_ABLATE & 2)
-        pair &= 7;
-    const long long rA = 2 * pair;
-    const long long rB = (rA + 1 < p.M) ? rA + 1 : rA;
-    r.ka = scalar_ptr(p.rows + rA * p.stride)[0];
-    r.kb = scalar_ptr(p.rows + rB * p.stride)[0];
 }
 
 // shifted sums of one series: sum d, sum d^2  (d = x - x[0])

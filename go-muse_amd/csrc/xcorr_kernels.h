@@ -66,6 +66,7 @@ struct FusedParams {
     // optional indirection for the fp64 kernels: process pair_list[0 .. *pair_count)
     const long long *pair_list;
     const int *pair_count;
+    long long gscratch_slices; // n-element slices `gscratch` holds: a kernel that works in it launches no more workgroups than fit
 };
 
 hipError_t launch_fused(const FusedParams &p, int variant, int num_cus, hipStream_t stream);
@@ -89,13 +90,19 @@ hipError_t launch_indicator_corr(const double *xs, int n, int pad, double *c1, h
 hipError_t launch_ref_spectrum(const double *ref_dev, int N, int n, int logn, int normalize, double x_scale,
                                double xc_scale, const double2 *twm, double2 *X, double2 *xc, float2 *xcf, double *xs,
                                double2 *gscratch, int *status, hipStream_t stream);
+constexpr int SMALL_MAX_N = 16384;       // largest FFT length of xcorr_small.hip (it reads n - N samples in front of a row unclamped:
+                                         // FusedParams::rows must carry that many readable elements in front of row 0, muse_capi.hip GROUP_GUARD)
 constexpr int GENERIC_LDS_MAX_N = 8192;  // larger n: the radix-2 passes run in gscratch
 constexpr int GENERIC_MAX_N = 65536;
 constexpr int GENERIC_GLOBAL_WGS_PER_CU = 2;
-constexpr int STOCKHAM_GLOBAL_WGS_PER_CU = 2; // each holds two n-element complex scratch slices
-#ifndef MUSE_LONG_WGS_PER_CU
-#define MUSE_LONG_WGS_PER_CU 4 // xcorr_long.hip: resident workgroups per CU, one n-element slice each (tools/ablate A/B builds override)
-#endif
+constexpr int STOCKHAM_GLOBAL_WGS_PER_CU = 2; // xcorr_fused_stk_4step: resident workgroups per CU, one n-element slice each (two for the two-sided xCorr)
+constexpr int LONG_WGS_PER_CU = 4;            // xcorr_long.hip: resident workgroups per CU, one n-element slice each
+// n-element complex slices of the context's scratch buffer per CU (muse_capi.hip, ensure_gscratch): every kernel that works in it
+// launches at most this many workgroups per CU times the slices each of them uses, and checks FusedParams::gscratch_slices
+constexpr int GSCRATCH_SLICES_PER_CU = 4;
+static_assert(LONG_WGS_PER_CU <= GSCRATCH_SLICES_PER_CU && GENERIC_GLOBAL_WGS_PER_CU <= GSCRATCH_SLICES_PER_CU &&
+                  2 * STOCKHAM_GLOBAL_WGS_PER_CU <= GSCRATCH_SLICES_PER_CU,
+              "the scratch buffer is sized for GSCRATCH_SLICES_PER_CU slices per CU");
 hipError_t launch_direct(const double *x, int lenx, const double *y, int leny, int n, int normalize_x,
                          int normalize_y, double x_scale, double cc_scale, double *cc, int *lag, double *mv,
                          int *status, hipStream_t stream);

@@ -488,6 +488,8 @@ hipError_t launch_fused(const FusedParams &p, int variant, int num_cus, hipStrea
     const long long cap = (long long)num_cus * (global_mode ? GENERIC_GLOBAL_WGS_PER_CU : 16); // global mode: one scratch slice each
     if (grid > cap)
         grid = cap;
+    if (global_mode && grid > p.gscratch_slices)
+        return hipErrorInvalidValue;
     hipLaunchKernelGGL(xcorr_fused_generic, dim3((unsigned)grid), dim3(256), lds, stream, p);
     return hipGetLastError();
 }

@@ -26,26 +26,10 @@
 
 #include "long_device.h"
 
-// MUSE_LONG_EXP (tools/ablate only; never defined in the library build; results are wrong): bit 0 = no rows phase, bit 1 = rows
-// loaded and stored but not transformed, bit 2 = no sweep 2, bit 3 = sweep 1 without its stores
-#ifndef MUSE_LONG_EXP
-#define MUSE_LONG_EXP 0
-#endif
-
-// MUSE_LONG_NT: bit 0 = the scratch slice is stored non-temporally, bit 1 = loaded non-temporally.  Measured
-// (tools/ablate/long_nt.sh, profiles/r02_long_series.txt): loads only is best (+5 %: a slice line is read once, and the tables
-// every workgroup shares keep their place in L2); the library builds that.
-#ifndef MUSE_LONG_NT
-#define MUSE_LONG_NT 2
-#endif
-#define MUSE_LONG_ST(ptr, val)                          \
-    do {                                                \
-        if (MUSE_LONG_NT & 1)                           \
-            __builtin_nontemporal_store((val), (ptr));  \
-        else                                            \
-            *(ptr) = (val);                             \
-    } while (0)
-#define MUSE_LONG_LD(ptr) ((MUSE_LONG_NT & 2) ? __builtin_nontemporal_load(ptr) : *(ptr))
+// Cache policy of the scratch slice (measured, profiles/r02_long_series.txt): plain stores, NON-TEMPORAL loads (+5 %: a
+// slice line is read once, and the tables every workgroup shares keep their place in L2).
+#define SLICE_ST(ptr, val) (*(ptr) = (val))
+#define SLICE_LD(ptr) __builtin_nontemporal_load(ptr)
 
 namespace muse {
 
@@ -150,10 +134,7 @@ __global__ __launch_bounds__(256, 4) void xcorr_fused_long(const FusedParams p)
             const unsigned js = (unsigned)(opaque(t + 256 * ch) & (S - 1));
 #pragma unroll
             for (int m = 0; m < Q1; m++) { // row 0: no twiddle
-                if (MUSE_LONG_EXP & 8) {   // (keeps the values alive without the store)
-                    asm volatile("" ::"v"(v[m].x), "v"(v[m].y));
-                } else
-                    MUSE_LONG_ST(yat((long long)m * S) + js, (d2v{v[m].x, v[m].y}));
+                SLICE_ST(yat((long long)m * S) + js, (d2v{v[m].x, v[m].y}));
             }
 #pragma unroll
             for (int bt = 0; bt < NB; bt++) {
@@ -169,10 +150,7 @@ __global__ __launch_bounds__(256, 4) void xcorr_fused_long(const FusedParams p)
                     // element m2 = j + m S of row k1: register m + brev(k1) Q1, position j + (m + k1 Q1) S
                     const int m = f / (R1 - 1), k1 = 1 + f % (R1 - 1);
                     const double2 z = cmul(v[m + brev<R1>(k1) * Q1], wq[bt & 1][f & 3]);
-                    if (MUSE_LONG_EXP & 8) {
-                        asm volatile("" ::"v"(z.x), "v"(z.y));
-                    } else
-                        MUSE_LONG_ST(yat((long long)(m + k1 * Q1) * S) + js, (d2v{z.x, z.y}));
+                    SLICE_ST(yat((long long)(m + k1 * Q1) * S) + js, (d2v{z.x, z.y}));
                 }
             }
         }
@@ -202,24 +180,23 @@ __global__ __launch_bounds__(256, 4) void xcorr_fused_long(const FusedParams p)
         __syncthreads(); // the slice is complete (and `red` is free again)
         // ---------------- rows
 #pragma clang loop unroll(disable)
-        for (int k1 = 0; k1 < ((MUSE_LONG_EXP & 1) ? 0 : R1); k1++) {
+        for (int k1 = 0; k1 < R1; k1++) {
             double2 *const row = Y + k1 * 4096;
             double2 v[16];
             {
                 const unsigned tl = (unsigned)(opaque(t) & 255);
 #pragma unroll
                 for (int i = 0; i < 16; i++) {
-                    const d2v z = MUSE_LONG_LD((gd2)scalar_ptr_at(row, 256 * i) + tl);
+                    const d2v z = SLICE_LD((gd2)scalar_ptr_at(row, 256 * i) + tl);
                     v[i] = make_double2(z.x, z.y);
                 }
             }
-            if (!(MUSE_LONG_EXP & 2))
-                row_transforms(v, xbuf, xw, g2s, p.g3a, p.g3b, p.xcp + k1 * 4096, t, wave, !PADDED && k1 == 0);
+            row_transforms(v, xbuf, xw, g2s, p.g3a, p.g3b, p.xcp + k1 * 4096, t, wave, !PADDED && k1 == 0);
             {
                 const unsigned tl = (unsigned)(opaque(t) & 255);
 #pragma unroll
                 for (int m = 0; m < 16; m++)
-                    MUSE_LONG_ST((gd2)scalar_ptr_at(row, 256 * m) + tl, (d2v{v[BR16(m)].x, v[BR16(m)].y}));
+                    SLICE_ST((gd2)scalar_ptr_at(row, 256 * m) + tl, (d2v{v[BR16(m)].x, v[BR16(m)].y}));
             }
         }
         __syncthreads();
@@ -227,12 +204,12 @@ __global__ __launch_bounds__(256, 4) void xcorr_fused_long(const FusedParams p)
         double ma = 0.0, mb = 0.0, sa = 0.0, sb = 0.0, cc0a = 0.0, cc0b = 0.0;
         int ia = 0x7fffffff, ib = 0x7fffffff;
 #pragma clang loop unroll(disable)
-        for (int ch = 0; ch < ((MUSE_LONG_EXP & 4) ? 0 : CH); ch++) {
+        for (int ch = 0; ch < CH; ch++) {
             const int j = opaque(t + 256 * ch) & (S - 1);
             double2 v[16];
 #pragma unroll
             for (int i = 0; i < 16; i++) {
-                const d2v z = MUSE_LONG_LD(yat((long long)i * S) + (unsigned)j);
+                const d2v z = SLICE_LD(yat((long long)i * S) + (unsigned)j);
                 v[i] = make_double2(z.x, z.y);
             }
             {
@@ -363,7 +340,9 @@ __global__ __launch_bounds__(256, 4) void xcorr_fused_long(const FusedParams p)
 template <int LOGN>
 static hipError_t launch_long_n(const FusedParams &p, int num_cus, hipStream_t stream)
 {
-    const long long grid = std::min<long long>(p.npairs, (long long)num_cus * MUSE_LONG_WGS_PER_CU);
+    const long long grid = std::min<long long>(p.npairs, (long long)num_cus * LONG_WGS_PER_CU);
+    if (grid > p.gscratch_slices) // one n-element slice per workgroup
+        return hipErrorInvalidValue;
     if (p.N < (1 << LOGN))
         hipLaunchKernelGGL((xcorr_fused_long<LOGN, true>), dim3((unsigned)grid), dim3(256), 0, stream, p);
     else

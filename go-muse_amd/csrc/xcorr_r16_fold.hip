@@ -29,12 +29,9 @@ namespace muse {
 
 // PADDED (2048 < N < 4096, leading zero pad): as in xcorr_r16_fast.hip -- the transforms run on d, sum d is read
 // off the DC bin and the 16 values a lane ends with are corrected by -m c1[index] before the argmax.
-#ifndef MUSE_FOLD_WPS
-#define MUSE_FOLD_WPS 4
-#endif
 // F32: float32-storage group (half the HBM bytes; samples widened exactly on consumption, same float64 arithmetic)
 template <bool TIMING = false, bool PADDED = false, bool F32 = false>
-__global__ __launch_bounds__(OCC_THREADS, MUSE_FOLD_WPS) void xcorr_fused_n4096_fold(const FusedParams p)
+__global__ __launch_bounds__(OCC_THREADS, 4) void xcorr_fused_n4096_fold(const FusedParams p)
 {
     using namespace occ4;
     using namespace fold;
@@ -102,67 +99,30 @@ __global__ __launch_bounds__(OCC_THREADS, MUSE_FOLD_WPS) void xcorr_fused_n4096_
             }
         }
         clk.template stamp<1>();
-        constexpr int OPT = MUSE_FOLD_OPT;
-        int tx = t, tg = t; // opaque copies, refreshed in front of the passes that use them
-        const auto xcl = [&](int j) __attribute__((always_inline)) {
-            if (MUSE_FOLD_EXP & 2)
-                return g2s[(8 * j + lo) & 127];
-            return ldg2(scalar_ptr_at(p.xcp, 256 * ((j + 1) & ~1)), tx - 256 * (j & 1));
-        };
-        const auto g3 = [&](const double2 *tab, int s) __attribute__((always_inline)) {
-            if (MUSE_FOLD_EXP & 1)
-                return g2s[(16 * s + lo) & 127];
-            return G3Fetch{tab, tg}(s);
-        };
         // ================= Z = FFT(dA + i dB) =================
         // pass 1: plain DFT over a (thread (b, c) = (hi, lo)) -> k1 at v[BR16(k1)]
         dft16_nr(v);
         clk.template stamp<2>();
-        exchange_cross<0, 1, (MUSE_FOLD_OPT & 64) != 0>(v, xbuf, wave, t); // -> thread (k1 = hi, c = lo), input b at v[b]
-        // the previous pair's record is complete and visible: write its results
-        if (!(MUSE_FOLD_EXP & 8)) {
-            const bool writer = (OPT & 1) ? (lane == 0 && wave < 2) : (t < 2);
-            const int series = (OPT & 1) ? wave : t;
-            if (writer && prec[34] >= 0.0 && (series == 0 || prec[35] != 0.0)) {
-                const long long row = (long long)prec[34] + series;
-                if (finalize(prec, series, invN, invNm1, p.mv + row, p.lag + row)) {
-                    const int slot = atomicAdd(p.ovf_count, 1);
-                    p.ovf_list[slot] = row >> 1;
-                }
+        // -> thread (k1 = hi, c = lo), input b at v[b]; the tail barrier frees the wave's private quarter for the
+        // wave-local transpose below while the waves are still in step
+        exchange_cross<0, 1, true>(v, xbuf, wave, t);
+        // the previous pair's record is complete and visible: lane 0 of waves 0 / 1 writes one series' result each
+        if (lane == 0 && wave < 2 && prec[34] >= 0.0 && (wave == 0 || prec[35] != 0.0)) {
+            const long long row = (long long)prec[34] + wave;
+            if (finalize(prec, wave, invN, invNm1, p.mv + row, p.lag + row)) {
+                const int slot = atomicAdd(p.ovf_count, 1);
+                p.ovf_list[slot] = row >> 1;
             }
         }
         clk.template stamp<3>();
         // pass 2: generalised DFT over b, delta = k1 / 16 (carries W_256^(b k1))
-        gdft16_nr(v, G2Fetch{g2s, fresh<4>(t) >> 4});
+        gdft16_nr(v, G2Fetch{g2s, t >> 4});
         clk.template stamp<4>();
-        double2 ga[4], xa[4];
-        if (OPT & 2) { // pass 3's first factors (L2) travel during the transpose
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-                ga[q] = g3(p.g3a, q);
-            fence();
-        }
-        if (!(OPT & 64))
-            lds_barrier(); // waves 2-3 may still be reading this wave's quarter (round 1 above)
         exchange_local<1>(v, xw, t); // -> thread (k1 = hi, k2 = lo), input c at v[c]
         clk.template stamp<5>();
         // pass 3: generalised DFT over c, delta = (k1 + 16 k2) / 256 (carries W_4096^(c k1) W_256^(c k2));
         // Z[hi + 16 lo + 256 k3] at v[BR16(k3)]
-        tg = fresh<8>(t);
-        if (!(OPT & 2)) {
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-                ga[q] = g3(p.g3a, q);
-        }
-        gdft16_nr_pre(v, ga, [&](int q) __attribute__((always_inline)) { return g3(p.g3a, q); },
-                      [&]() __attribute__((always_inline)) {
-                          if (OPT & 4) { // the second transform's first spectrum factors, behind the last stage
-                              xa[0] = xcl(0);
-                              xa[1] = xcl(8);
-                              xa[2] = xcl(1);
-                              xa[3] = xcl(9);
-                          }
-                      });
+        gdft16_nr_l2(v, G3Fetch{p.g3a, t});
         double s1a, s1b;
         {
             // bin 0 (lane 0 of wave 0) = (sum dA, sum dB): kept in SGPRs until the record is written; the centred
@@ -178,8 +138,9 @@ __global__ __launch_bounds__(OCC_THREADS, MUSE_FOLD_WPS) void xcorr_fused_n4096_
         // ================= ccA + i ccB = FFT(Z conj(X)/n) (unscaled by 1/sigma) =================
         // element f = 256 a' + 16 b' + c' with a' = k3 (register BR16(a')), b' = lo, c' = hi
         // pass 1: plain DFT over a' with the spectrum factors folded into its first stage -> m1 at v[m1]
-        tx = fresh<8>(t);
-        xc_stage1<(OPT & 4) != 0>(v, xa, xcl);
+        xc_stage1(v, [&](int j) __attribute__((always_inline)) {
+            return ldg2(scalar_ptr_at(p.xcp, 256 * ((j + 1) & ~1)), t - 256 * (j & 1));
+        });
         dft16_rn_s234(v);
         clk.template stamp<7>();
         exchange_local<0>(v, xw, t); // (c' = hi, b' = lo) -> (c' = hi, m1 = lo), input b' at v[b']: same wave
@@ -189,149 +150,48 @@ __global__ __launch_bounds__(OCC_THREADS, MUSE_FOLD_WPS) void xcorr_fused_n4096_
         }
         clk.template stamp<8>();
         // pass 2: generalised DFT over b', delta = m1 / 16, m1 = lo
-        gdft16_nr(v, G2Fetch{g2s, fresh<4>(t) & 15});
+        gdft16_nr(v, G2Fetch{g2s, t & 15});
         clk.template stamp<9>();
-        if (OPT & 2) {
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-                ga[q] = g3(p.g3b, q);
-            fence();
-        }
         exchange_cross<1, 1>(v, xbuf, wave, t); // -> thread (m1 = lo, m2 = hi), input c' at v[c']
         clk.template stamp<10>();
         // pass 3: generalised DFT over c', delta = (m1 + 16 m2) / 256 = t / 256: cc index t + 256 m3 at v[BR16(m3)]
         nextpair = __builtin_amdgcn_readfirstlane(next_s[parity]);
         long long nxt = nextpair; // last iteration: pair 0 (L2-resident dummy)
         nxt = nxt < total ? nxt : 0;
-        {
+        gdft16_nr_l2(v, G3Fetch{p.g3b, t});
+        if (PADDED) { // cc(d - m 1_valid) = cc(d) - m c1, m = sum d / N
             const auto c1l = [&](int k) __attribute__((always_inline)) {
                 return scalar_ptr_at(p.c1, 256 * ((k + 1) & ~1))[t - 256 * (k & 1)];
             };
-            tg = fresh<8>(t);
-            if (!(OPT & 2)) {
+            const double mA = rec[32] * invN, mB = rec[33] * invN;
 #pragma unroll
-                for (int q = 0; q < 4; q++)
-                    ga[q] = g3(p.g3b, q);
-            }
-            if ((OPT & 128) && !PADDED) {
-                // stages 1..3, then the last stage butterfly by butterfly: each one finishes the lags t + 256 m and
-                // t + 256 (m + 8), which go straight into the lane's running maxima (their registers die), and the next
-                // pair's rows are requested four loads at a time into the registers that just became free -- the HBM
-                // requests are spread over the stage and the argmax instead of one burst behind them that blocks the
-                // wave at issue (profiles/r02_fold_phase_stamps.txt: 7 k of 38 k cycles per pair)
-                double2 gb[4];
-                gdft16_nr_s12(v, ga[0], ga[1]);
+            for (int h = 0; h < 2; h++) {
+                double cq[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    cq[k] = c1l(8 * h + k);
                 fence();
 #pragma unroll
-                for (int q = 0; q < 4; q++)
-                    gb[q] = g3(p.g3b, q + 4);
-                fence();
-                gdft16_nr_s3(v, ga[2], ga[3]);
-                fence();
-                issue_row_firsts(raw, p, nxt);
-                ArgRun loA{0.0, 0}, loB{0.0, 0}, hiA{0.0, 8}, hiB{0.0, 8};
-#pragma unroll
-                for (int m = 0; m < 8; m++) {
-                    const int pos = BR16(m); // even; lag m at v[pos], lag m + 8 at v[pos + 1]
-                    if (m < 4)
-                        bf_gen(v[pos], v[pos + 1], gb[m & 3]);
-                    else
-                        bf_gen_mi(v[pos], v[pos + 1], gb[m & 3]);
-                    if (m == 0 && t == 0) { // cc[0], the value reported when nothing is above 0
-                        rec[1] = v[0].x;
-                        rec[4] = v[0].y;
-                    }
-                    arg_consume(loA, v[pos].x, m);
-                    arg_consume(loB, v[pos].y, m);
-                    arg_consume(hiA, v[pos + 1].x, m + 8);
-                    arg_consume(hiB, v[pos + 1].y, m + 8);
-                    fence();
-                    issue_row_elem(raw, p, nxt, t, 2 * m);
-                    issue_row_elem(raw, p, nxt, t, 2 * m + 1);
-                    fence();
+                for (int k = 0; k < 8; k++) {
+                    const int r = BR16(8 * h + k);
+                    v[r] = make_double2(fma(-mA, cq[k], v[r].x), fma(-mB, cq[k], v[r].y));
                 }
-                clk.template stamp<11>();
-                const ArgRun ra_ = arg_merge(loA, hiA), rb_ = arg_merge(loB, hiB);
-                wave_argmax_finish(ra_, t, lane, rec + 6 * wave);
-                wave_argmax_finish(rb_, t, lane, rec + 6 * wave + 3);
-            } else {
-            gdft16_nr_pre(v, ga, [&](int q) __attribute__((always_inline)) { return g3(p.g3b, q); },
-                          [&]() __attribute__((always_inline)) {
-                              if (OPT & 8)
-                                  issue_row_loads_half<PADDED, 0>(raw, p, nxt, t, pad);
-                              if (OPT & 32) // (168 registers: both rows)
-                                  issue_row_loads<PADDED, F32>(raw, p, nxt, t, pad);
-                          });
-            if (PADDED) { // cc(d - m 1_valid) = cc(d) - m c1, m = sum d / N
-                const double mA = rec[32] * invN, mB = rec[33] * invN;
-#pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    double cq[8];
-#pragma unroll
-                    for (int k = 0; k < 8; k++)
-                        cq[k] = c1l(8 * h + k);
-                    fence();
-#pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        const int r = BR16(8 * h + k);
-                        v[r] = make_double2(fma(-mA, cq[k], v[r].x), fma(-mB, cq[k], v[r].y));
-                    }
-                }
-            }
-            clk.template stamp<11>();
-            if (OPT & 256) {
-                // one running maximum per lane and series over ascending lags; a consumed value's registers take the next
-                // pair's row requests, two loads at a time: the requests are spread over the argmax instead of one burst
-                // behind it
-                if (t == 0) { // cc[0], the value reported when nothing is above 0 (overwritten below otherwise)
-                    rec[1] = v[0].x;
-                    rec[4] = v[0].y;
-                }
-                constexpr bool SPREAD = !(OPT & 512); // bit 9: the requests stay one burst behind the argmax
-                if (SPREAD)
-                    issue_row_firsts(raw, p, nxt);
-                const int tr = fresh<16>(t);
-                ArgRun ra_{0.0, 0}, rb_{0.0, 0};
-#pragma unroll
-                for (int m = 0; m < 16; m++) {
-                    arg_consume(ra_, v[BR16(m)].x, m);
-                    arg_consume(rb_, v[BR16(m)].y, m);
-                    if (SPREAD) {
-                        fence();
-                        if (PADDED)
-                            issue_row_elem_padded(raw, p, nxt, tr, m, pad);
-                        else
-                            issue_row_elem(raw, p, nxt, tr, m);
-                        fence();
-                    }
-                }
-                wave_argmax_finish(ra_, t, lane, rec + 6 * wave);
-                wave_argmax_finish(rb_, t, lane, rec + 6 * wave + 3);
-                if (!SPREAD) {
-                    fence();
-                    issue_row_loads<PADDED, F32>(raw, p, nxt, t, pad);
-                    fence();
-                }
-            } else {
-            // float32 rows take 34 registers instead of 66: room to request them BEFORE the argmax, which then runs under
-            // the HBM latency (float64 rows: behind it, there is no register left to land them in)
-            constexpr bool EARLY = F32 && (MUSE_FOLD_F32_EARLY != 0);
-            if (EARLY) {
-                fence();
-                issue_row_loads<PADDED, F32>(raw, p, nxt, t, pad);
-                fence();
-            }
-            wave_argmax_store(v, wave, lane, rec + 6 * wave);
-            clk.template stamp<13>();
-            fence();
-            if (OPT & 8)
-                issue_row_loads_half<PADDED, 1>(raw, p, nxt, t, pad);
-            else if (!(OPT & 32) && !EARLY)
-                issue_row_loads<PADDED, F32>(raw, p, nxt, t, pad);
-            fence();
-            }
             }
         }
+        clk.template stamp<11>();
+        // float32 rows take 34 registers instead of 66: room to request them BEFORE the argmax, which then runs under
+        // the HBM latency (float64 rows: behind it, there is no register left to land them in)
+        if (F32) {
+            fence();
+            issue_row_loads<PADDED, F32>(raw, p, nxt, t, pad);
+            fence();
+        }
+        wave_argmax_store(v, wave, lane, rec + 6 * wave);
+        clk.template stamp<13>();
+        fence();
+        if (!F32)
+            issue_row_loads<PADDED, F32>(raw, p, nxt, t, pad);
+        fence();
         if (wave == 0 && lane == 0) {
             rec[32] = s1a;
             rec[33] = s1b;
@@ -572,8 +432,7 @@ __global__ __launch_bounds__(OCC_THREADS, 4) void xcorr_fused_n4096_fold_multi(c
                     const unsigned hi32 = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
                     xr = (const double2 *)(((unsigned long long)hi32 << 32) | lo32);
                 }
-                double2 xa[4];
-                xc_stage1<false>(v, xa, [&](int j) __attribute__((always_inline)) {
+                xc_stage1(v, [&](int j) __attribute__((always_inline)) {
                     return ldg2(scalar_ptr_at(xr, 256 * ((j + 1) & ~1)), t - 256 * (j & 1));
                 });
             }

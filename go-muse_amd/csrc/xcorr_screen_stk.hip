@@ -630,8 +630,10 @@ static hipError_t launch_4step(const FusedParams &p, int num_cus, hipStream_t st
 {
     if (!p.gscratch)
         return hipErrorInvalidValue;
-    // (the fp64 kernels' scratch: 2 x 2 slices of 2 n double2 per CU = room for sixteen n-element fp32 slices per CU)
+    // (one n-element fp32 slice per workgroup = half an fp64 slice)
     const long long grid = std::min<long long>(p.npairs, (long long)num_cus * 3);
+    if (grid > 2 * p.gscratch_slices)
+        return hipErrorInvalidValue;
     hipLaunchKernelGGL((xcorr_screen_pass_4step<LOGN>), dim3((unsigned)grid), dim3(256), 0, stream, p);
     return hipGetLastError();
 }

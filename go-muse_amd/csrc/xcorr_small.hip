@@ -44,18 +44,6 @@ using namespace occ4;
 using namespace fold;
 
 constexpr int padk(int x) { return x + (x >> 4); }
-// MUSE_SMALL_EXP (tools/ablate only; never defined in the library build; results are wrong): table values read from a 1 KB LDS
-// array instead of L2 -- bit 0 the lane-ordered pass factors, bit 1 the spectrum factors, bit 2 the W_65536 factors of pass 2;
-// bit 3 = the transposes of multi-wave pairs without their workgroup barriers
-#ifndef MUSE_SMALL_EXP
-#define MUSE_SMALL_EXP 0
-#endif
-__device__ __forceinline__ double2 fake_lds(unsigned i)
-{
-    __shared__ double2 fk[64];
-    return fk[i & 63];
-}
-
 // the values of the two 16-lane rows of a 32-lane pair side by side (lane i of row 0 with lane i of row 1), in both rows:
 // v_permlane16_swap(v, v) leaves [row 0, row 0, row 2, row 2] and [row 1, row 1, row 3, row 3] -- one VALU instruction per
 // dword where __shfl_xor(v, 16) is a ds_bpermute round trip through the LDS crossbar
@@ -281,8 +269,6 @@ __device__ __forceinline__ double2 tw_factor(const double2 *__restrict__ twm, co
     constexpr int U = 4096 / NS;
     const int idx = s == 0 ? 8 * U * m : s == 1 ? 4 * U * m : s == 2 ? 2 * U * m : s == 3 ? 2 * U * m + 8192
                                                                                            : U * m + 4096 * (s - 4);
-    if (MUSE_SMALL_EXP & 4)
-        return fake_lds((unsigned)idx);
     return ldg2u(scalar_ptr(twm), (unsigned)idx); // scalar base + UNSIGNED 32-bit lane offset: no 64-bit address arithmetic
 }
 
@@ -318,7 +304,7 @@ __device__ __forceinline__ void level(double2 (&v)[16], double2 *b, const double
     const unsigned m3 = (unsigned)(j & (NS2 - 1));
 #pragma unroll
     for (int s = 0; s < 4; s++) // the pass's first factors travel during the transpose
-        ga[s] = (MUSE_SMALL_EXP & 1) ? fake_lds(m3 + s) : ldg2u(scalar_ptr_at(tab, s * NS2), m3);
+        ga[s] = ldg2u(scalar_ptr_at(tab, s * NS2), m3);
     fence();
     const int g = j / NS, mm = j & (NS - 1);
     // position (g mod S/(2 NS)) 16 NS + r NS + m, padded
@@ -398,7 +384,7 @@ __device__ __forceinline__ void level(double2 (&v)[16], double2 *b, const double
 #pragma unroll
     for (int i = 0; i < 16; i++)
         v[i] = w[i];
-    gpass_pre(v, ga, [&](int s) __attribute__((always_inline)) { return (MUSE_SMALL_EXP & 1) ? fake_lds(m3 + s) : ldg2u(scalar_ptr_at(tab, s * NS2), m3); });
+    gpass_pre(v, ga, [&](int s) __attribute__((always_inline)) { return ldg2u(scalar_ptr_at(tab, s * NS2), m3); });
 }
 
 // forward transform of the pair's n points: v[i] = x[j + i S] -> X[j + r S] at v[BR16(r)].  b: the pair's half buffer.
@@ -416,7 +402,7 @@ __device__ __forceinline__ void forward(double2 (&v)[16], double2 *b, const doub
     // pairs inside one wave need no hardware barrier (LDS operations of a wave execute in order), but the COMPILER must
     // not move a lane's reads above its writes: other lanes' data arrives through them
     const auto sync = [&]() __attribute__((always_inline)) {
-        if (S > 64 && !(MUSE_SMALL_EXP & 8)) { // (ablation bit 3: no workgroup barriers in the transposes)
+        if (S > 64) {
             lds_barrier();
         } else {
             fence();
@@ -658,7 +644,7 @@ __global__ __launch_bounds__((LOGN >= 11 ? (1 << LOGN) / 16 : 256), 4) void xcor
             asm volatile("" : "+v"(jx)); // (the table offsets are derived here, not hoisted out of the pair loop)
             jx &= S - 1;
             const auto xcl = [&](int r) __attribute__((always_inline)) {
-                return (MUSE_SMALL_EXP & 2) ? fake_lds((unsigned)(jx + r)) : ldg2u(scalar_ptr_at(xcr, r * S), (unsigned)jx);
+                return ldg2u(scalar_ptr_at(xcr, r * S), (unsigned)jx);
             };
             double2 xq[2][4];
 #pragma unroll

@@ -689,16 +689,15 @@ __global__ __launch_bounds__(256, 2) void xcorr_fused_stk_4step(const FusedParam
     }
 }
 
-// resident workgroups (each with an n-element scratch slice the pair crosses four times): per 8 CUs
-#ifndef MUSE_4STEP_WGS_PER_8CU
-#define MUSE_4STEP_WGS_PER_8CU 16
-#endif
 template <int LOGN>
 static hipError_t launch_stk_4step(const FusedParams &p, int num_cus, hipStream_t stream)
 {
     if (!p.gscratch)
         return hipErrorInvalidValue;
-    const long long grid = std::min<long long>(p.npairs, (long long)num_cus * MUSE_4STEP_WGS_PER_8CU / 8);
+    // resident workgroups, each with an n-element scratch slice the pair crosses four times
+    const long long grid = std::min<long long>(p.npairs, (long long)num_cus * STOCKHAM_GLOBAL_WGS_PER_CU);
+    if (grid > p.gscratch_slices)
+        return hipErrorInvalidValue;
     hipLaunchKernelGGL((xcorr_fused_stk_4step<LOGN>), dim3((unsigned)grid), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
