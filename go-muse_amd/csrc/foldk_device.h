@@ -30,12 +30,13 @@ __device__ __forceinline__ constexpr int pr(int k)
 // transpose into the wave's private quarter) needs none: the waves are still in step here, whereas a barrier in
 // front of that next use also waits out everything the waves drifted apart in between (2.3 k cycles per pair,
 // profiles/r02_fold_phase_stamps.txt).
+// wcol (MODE 0): the column the writer holds (t unless pass 1 ran on relabelled columns: r16_device.h, wide_column)
 template <int MODE, int PERM, bool TAILBAR = false>
-__device__ __forceinline__ void exchange_cross(double2 (&v)[16], double2 *xbuf, const int wave, const int t_)
+__device__ __forceinline__ void exchange_cross(double2 (&v)[16], double2 *xbuf, const int wave, const int t_, const int wcol = -1)
 {
     const int t = t_;
     const int hi = t >> 4, lo = t & 15;
-    const int wbase = MODE ? 17 * lo + hi : t;
+    const int wbase = MODE ? 17 * lo + hi : (wcol >= 0 ? wcol : t);
     const int rbase = 272 * (hi & 7) + (MODE ? 17 * lo : lo);
     const bool early = wave < 2;
     lds_barrier(); // buffer free: every wave is done with its previous (wave-local or shared) use
@@ -168,6 +169,31 @@ struct G3Fetch {
     {   // one scalar base per two planes: the odd plane sits at immediate offset -4096 B
         return ldg2(scalar_ptr_at(p, ((s + 1) & ~1) * 256), t - 256 * (s & 1));
     }
+};
+
+// the eight factors of a pass from TWO table entries: w8 (plane 2) and w16 (plane 4); w4 = w8^2, w2 = w4^2, w8 W_8 and
+// w16 W_16^q by constant multiplications (24 fp64 instructions instead of six 16-byte L2 loads per thread)
+struct G3Derived {
+    double2 g[8];
+    __device__ __forceinline__ static double2 sq(const double2 w) { return make_double2(fma_(w.x, w.x, -(w.y * w.y)), (w.x + w.x) * w.y); }
+    __device__ __forceinline__ static double2 mulc(const double2 w, const double c, const double s) // w (c - i s)
+    {
+        return make_double2(fma_(w.y, s, w.x * c), fma_(-w.x, s, w.y * c));
+    }
+    __device__ __forceinline__ G3Derived(const double2 *tab, int t)
+    {
+        constexpr double H = 0.70710678118654752440;
+        const double2 w8 = G3Fetch{tab, t}(2), w16 = G3Fetch{tab, t}(4);
+        g[2] = w8;
+        g[4] = w16;
+        g[1] = sq(w8);
+        g[0] = sq(g[1]);
+        g[3] = make_double2(H * (w8.x + w8.y), H * (w8.y - w8.x)); // w8 W_8
+        g[5] = mulc(w16, C16_1, S16_1);
+        g[6] = make_double2(H * (w16.x + w16.y), H * (w16.y - w16.x));
+        g[7] = mulc(w16, S16_1, C16_1);
+    }
+    __device__ __forceinline__ double2 operator()(int s) const { return g[s]; }
 };
 
 // generalised pass with its factors in L2 (pass 3): the second batch of four is requested behind the second stage

@@ -264,6 +264,57 @@ __device__ __forceinline__ void issue_row_loads(RawPair &r, const FusedParams &p
     }
 }
 
+// 16-byte row loads (N == n == 4096, float64 rows): lane (m = lane & 31, h = lane >> 5) of wave w requests, for i' = 0 .. 7, the
+// two CONSECUTIVE samples 256 (i' + 8 h) + 64 w + 2 m (+1) of each row -- 16 global_load_dwordx4 per pair instead of 32
+// global_load_dwordx2 (the request costs per instruction, profiles/r02_fold_f32_and_tail_experiments.txt); the pair lands in
+// (r.a[i'], r.a[i' + 8]).  widen_rows() then trades the upper half-wave's first sample for the lower half-wave's second one
+// (v_permlane32_swap, gfx950: 32 VALU per pair), after which lane (m, h) holds COLUMN 64 w + 2 m + h of both rows:
+// r.a[i] = A[256 i + col], r.b[i] = B[256 i + col], i = 0 .. 15 -- the layout pass 1 wants, on a relabelled column.
+__device__ __forceinline__ int wide_column(int t) { return (t & ~63) | ((t & 31) << 1) | ((t >> 5) & 1); }
+template <bool SK>
+__device__ __forceinline__ void issue_row_loads_wide(RawPair &r, const FusedParams &p, long long pair, int t)
+{
+    const long long rA = 2 * pair;
+    const long long rB = (rA + 1 < p.M) ? rA + 1 : rA;
+    if (SK) { // the rows' first samples through the scalar cache (uniform address): no vector memory instruction
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef const double __attribute__((address_space(4))) *cptr;
+        r.ka = *(cptr)(unsigned long long)(p.rows + rA * p.stride);
+        r.kb = *(cptr)(unsigned long long)(p.rows + rB * p.stride);
+#endif
+    } else {
+        r.ka = scalar_ptr(p.rows + rA * p.stride)[0];
+        r.kb = scalar_ptr(p.rows + rB * p.stride)[0];
+    }
+    const int lo16 = ((t >> 5) & 1) * 1024 + (t >> 6) * 32 + (t & 31); // in 16-byte units: (2048 h + 64 w + 2 m) / 2
+#pragma unroll
+    for (int i = 0; i < 8; i++) { // one scalar base per four 2 KB slices (immediate offsets -4096 .. +2048 B)
+        const int c = (i & ~3) * 256 + 512;
+        const d2v xa = __builtin_nontemporal_load((gptr<d2v>)scalar_ptr_at(p.rows + rA * p.stride, c) + (128 * i - c / 2) + lo16);
+        const d2v xb = __builtin_nontemporal_load((gptr<d2v>)scalar_ptr_at(p.rows + rB * p.stride, c) + (128 * i - c / 2) + lo16);
+        r.a[i] = xa.x;
+        r.a[i + 8] = xa.y;
+        r.b[i] = xb.x;
+        r.b[i + 8] = xb.y;
+    }
+}
+__device__ __forceinline__ void swap_halves(double &first, double &second)
+{
+    // v_permlane32_swap vdst, src: lanes 32-63 of vdst <-> lanes 0-31 of src
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(first), (unsigned)__double2loint(second), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(first), (unsigned)__double2hiint(second), false, false);
+    first = __hiloint2double((int)hi[0], (int)lo[0]);
+    second = __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ __forceinline__ void widen_rows(RawPair &r)
+{
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        swap_halves(r.a[i], r.a[i + 8]);
+        swap_halves(r.b[i], r.b[i + 8]);
+    }
+}
+
 // shifted sums of one series: sum d, sum d^2  (d = x - x[0])
 struct Stat {
     double s1, s2;

@@ -30,7 +30,9 @@ namespace muse {
 // PADDED (2048 < N < 4096, leading zero pad): as in xcorr_r16_fast.hip -- the transforms run on d, sum d is read
 // off the DC bin and the 16 values a lane ends with are corrected by -m c1[index] before the argmax.
 // F32: float32-storage group (half the HBM bytes; samples widened exactly on consumption, same float64 arithmetic)
-template <bool TIMING = false, bool PADDED = false, bool F32 = false>
+// VAR (measurement builds, tools/ablate/fold_phases.hip; N == n, float64 rows only): bit 0 = 16-byte row loads, bit 1 = the rows'
+// first samples through the scalar cache, bit 2 = pass-3 factors derived from two table entries
+template <bool TIMING = false, bool PADDED = false, bool F32 = false, int VAR = 0>
 __global__ __launch_bounds__(OCC_THREADS, 4) void xcorr_fused_n4096_fold(const FusedParams p)
 {
     using namespace occ4;
@@ -59,7 +61,14 @@ __global__ __launch_bounds__(OCC_THREADS, 4) void xcorr_fused_n4096_fold(const F
     int parity = 0;
     const long long total = p.npairs;
     RawPair raw;
-    issue_row_loads<PADDED, F32>(raw, p, blockIdx.x < total ? (long long)blockIdx.x : 0ll, t, pad);
+    constexpr bool WIDE = (VAR & 1) && !PADDED && !F32;
+    const auto request_rows = [&](long long pr) __attribute__((always_inline)) {
+        if (WIDE)
+            issue_row_loads_wide<(VAR & 2) != 0>(raw, p, pr, t);
+        else
+            issue_row_loads<PADDED, F32>(raw, p, pr, t, pad);
+    };
+    request_rows(blockIdx.x < total ? (long long)blockIdx.x : 0ll);
 
     long long nextpair = 0;
     for (long long pair = blockIdx.x; pair < total; pair = nextpair) {
@@ -78,6 +87,8 @@ __global__ __launch_bounds__(OCC_THREADS, 4) void xcorr_fused_n4096_fold(const F
             if (TIMING)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             clk.template stamp<0>();
+            if (WIDE)
+                widen_rows(raw);
 #pragma unroll
             for (int i = 0; i < 16; i++) {
                 // (PADDED: a pad position was loaded from the clamped index 0, i.e. it holds the row's first
@@ -105,7 +116,7 @@ __global__ __launch_bounds__(OCC_THREADS, 4) void xcorr_fused_n4096_fold(const F
         clk.template stamp<2>();
         // -> thread (k1 = hi, c = lo), input b at v[b]; the tail barrier frees the wave's private quarter for the
         // wave-local transpose below while the waves are still in step
-        exchange_cross<0, 1, true>(v, xbuf, wave, t);
+        exchange_cross<0, 1, true>(v, xbuf, wave, t, WIDE ? wide_column(t) : -1);
         // the previous pair's record is complete and visible: lane 0 of waves 0 / 1 writes one series' result each
         if (lane == 0 && wave < 2 && prec[34] >= 0.0 && (wave == 0 || prec[35] != 0.0)) {
             const long long row = (long long)prec[34] + wave;
@@ -122,7 +133,10 @@ __global__ __launch_bounds__(OCC_THREADS, 4) void xcorr_fused_n4096_fold(const F
         clk.template stamp<5>();
         // pass 3: generalised DFT over c, delta = (k1 + 16 k2) / 256 (carries W_4096^(c k1) W_256^(c k2));
         // Z[hi + 16 lo + 256 k3] at v[BR16(k3)]
-        gdft16_nr_l2(v, G3Fetch{p.g3a, t});
+        if (VAR & 4)
+            gdft16_nr_l2(v, G3Derived(p.g3a, t));
+        else
+            gdft16_nr_l2(v, G3Fetch{p.g3a, t});
         double s1a, s1b;
         {
             // bin 0 (lane 0 of wave 0) = (sum dA, sum dB): kept in SGPRs until the record is written; the centred
@@ -158,7 +172,10 @@ __global__ __launch_bounds__(OCC_THREADS, 4) void xcorr_fused_n4096_fold(const F
         nextpair = __builtin_amdgcn_readfirstlane(next_s[parity]);
         long long nxt = nextpair; // last iteration: pair 0 (L2-resident dummy)
         nxt = nxt < total ? nxt : 0;
-        gdft16_nr_l2(v, G3Fetch{p.g3b, t});
+        if (VAR & 4)
+            gdft16_nr_l2(v, G3Derived(p.g3b, t));
+        else
+            gdft16_nr_l2(v, G3Fetch{p.g3b, t});
         if (PADDED) { // cc(d - m 1_valid) = cc(d) - m c1, m = sum d / N
             const auto c1l = [&](int k) __attribute__((always_inline)) {
                 return scalar_ptr_at(p.c1, 256 * ((k + 1) & ~1))[t - 256 * (k & 1)];
@@ -183,14 +200,14 @@ __global__ __launch_bounds__(OCC_THREADS, 4) void xcorr_fused_n4096_fold(const F
         // the HBM latency (float64 rows: behind it, there is no register left to land them in)
         if (F32) {
             fence();
-            issue_row_loads<PADDED, F32>(raw, p, nxt, t, pad);
+            request_rows(nxt);
             fence();
         }
         wave_argmax_store(v, wave, lane, rec + 6 * wave);
         clk.template stamp<13>();
         fence();
         if (!F32)
-            issue_row_loads<PADDED, F32>(raw, p, nxt, t, pad);
+            request_rows(nxt);
         fence();
         if (wave == 0 && lane == 0) {
             rec[32] = s1a;

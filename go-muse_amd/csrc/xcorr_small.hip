@@ -761,8 +761,11 @@ static hipError_t launch_small_n(const FusedParams &p, int num_cus, hipStream_t 
 }
 
 // n = 512, 1024, 2048, 8192, 16384 (float64 rows); any N in (n/2, n]
+// p.rows must carry n - N < n / 2 readable elements in front of row 0 (zero-padded rows are read unclamped and masked;
+// muse_capi.hip allocates every group with GROUP_GUARD >= SMALL_MAX_N / 2 such elements)
 hipError_t launch_fused_small(const FusedParams &p, int num_cus, hipStream_t stream)
 {
+    static_assert((1 << 14) <= SMALL_MAX_N, "the largest length built below");
     if (!p.rows || !p.twm || (!p.xc && p.R <= 1) || !p.gsmall)
         return hipErrorInvalidValue;
     switch (p.logn) {
