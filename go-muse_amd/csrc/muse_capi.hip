@@ -2315,3 +2315,154 @@ extern "C" int muse_xcorr(muse_ctx *ctx, const double *x, int32_t lenx, const do
     const double cc_scale = normalize ? 1.0 / ((double)n * (double)(n - 1)) : 1.0 / (double)n;
     return single_pair(ctx, x, lenx, y, leny, n, normalize, normalize, 1.0, cc_scale, cc, lag, mv, is_nil);
 }
+
+// ---- batched two-sided xCorr (xcorr.go:102-153)
+extern "C" int muse_xcorr_groups(muse_group *gx, muse_group *gy, int32_t n, int32_t normalize, int32_t *lag, double *mv,
+                                 int32_t *is_nil, double *cc)
+{
+    if (!gx || !gy || gx->ctx != gy->ctx)
+        return fail(MUSE_ERR_INVALID, "the two groups must share a context");
+    if (gx->f32 || gy->f32)
+        return fail(MUSE_ERR_UNSUPPORTED, "xCorr is not built for float32-storage groups");
+    muse_ctx *ctx = gx->ctx;
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    if (gx->M != gy->M)
+        return fail(MUSE_ERR_LENGTH, "xCorr pairs row i of x with row i of y: %lld vs %lld rows", (long long)gx->M, (long long)gy->M);
+    const int64_t M = gx->M;
+    if (M == 0)
+        return MUSE_OK;
+    if (!lag || !mv)
+        return fail(MUSE_ERR_INVALID, "NULL output");
+    const int32_t Nx = gx->N, Ny = gy->N;
+    n = std::max(n, std::max(Nx, Ny)); // xcorr.go:104-106
+    if (normalize && (Nx < 2 || Ny < 2))
+        return fail(MUSE_ERR_INVALID, "series length 1 has no sample standard deviation");
+    rc = group_ready(gx);
+    if (!rc)
+        rc = group_ready(gy);
+    if (rc)
+        return rc;
+    if (!is_pow2(n) || n < 512 || n > GENERIC_MAX_N) {
+        // FFT lengths without a batched kernel (the reference's n = 5 tables, short series): pair by pair through the
+        // single-pair path (generic radix-2 kernel, or the direct kernel for n that is not a power of two)
+        std::vector<double> x((size_t)Nx), y((size_t)Ny);
+        HIP_TRY(hipStreamSynchronize(ctx->copy_stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        for (int64_t i = 0; i < M; i++) {
+            HIP_TRY(hipMemcpy(x.data(), gx->rows + i * gx->stride, (size_t)Nx * sizeof(double), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(y.data(), gy->rows + i * gy->stride, (size_t)Ny * sizeof(double), hipMemcpyDeviceToHost));
+            int32_t nil = 0;
+            rc = muse_xcorr(ctx, x.data(), Nx, y.data(), Ny, n, normalize, cc ? cc + (size_t)i * (size_t)n : nullptr, lag + i, mv + i, &nil);
+            if (rc)
+                return rc;
+            if (cc && nil)
+                std::fill(cc + (size_t)i * (size_t)n, cc + (size_t)(i + 1) * (size_t)n, 0.0);
+            if (is_nil)
+                is_nil[i] = nil;
+        }
+        return MUSE_OK;
+    }
+    hipError_t e = ensure_gscratch(ctx, n);
+    if (e != hipSuccess)
+        return fail(MUSE_ERR_NOMEM, "scratch: %s", hipGetErrorString(e));
+    double *dmv = nullptr, *dcc = nullptr;
+    int *dlag = nullptr, *dnil = nullptr;
+    auto cleanup = [&]() { (void)hipFree(dmv); (void)hipFree(dcc); (void)hipFree(dlag); (void)hipFree(dnil); };
+    e = hipMalloc(&dmv, (size_t)M * sizeof(double));
+    if (e == hipSuccess)
+        e = hipMalloc(&dlag, (size_t)M * sizeof(int));
+    if (e == hipSuccess)
+        e = hipMalloc(&dnil, (size_t)M * sizeof(int));
+    if (e == hipSuccess && cc)
+        e = hipMalloc(&dcc, (size_t)M * (size_t)n * sizeof(double));
+    if (e == hipSuccess && cc)
+        e = hipMemsetAsync(dcc, 0, (size_t)M * (size_t)n * sizeof(double), ctx->stream);
+    if (e != hipSuccess) {
+        cleanup();
+        return fail(MUSE_ERR_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e));
+    }
+    {
+        // long series work in the context's scratch buffer: its pointer must not be swapped between reading it and the launch
+        std::unique_lock<std::mutex> scratch_lock(ctx->stage_mu, std::defer_lock);
+        if (n >= GENERIC_LDS_MAX_N)
+            scratch_lock.lock();
+        FusedParams p{};
+        p.rows = gy->rows;
+        p.stride = gy->stride;
+        p.N = Ny;
+        p.xrows = gx->rows;
+        p.xstride = gx->stride;
+        p.Nx = Nx;
+        p.M = M;
+        p.npairs = M;
+        p.n = n;
+        p.logn = ilog2(n);
+        p.normalize_y = normalize ? 1 : 0;
+        p.twm = ctx->twm;
+        p.gscratch = ctx->gscratch;
+        p.gscratch_slices = (long long)(ctx->gscratch_elems / (size_t)n);
+        p.mv = dmv;
+        p.lag = dlag;
+        p.nil_out = dnil;
+        p.cc_out = dcc;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (ctx->timing) {
+            e = hipEventCreate(&e0);
+            if (e == hipSuccess)
+                e = hipEventCreate(&e1);
+            if (e == hipSuccess)
+                e = hipEventRecord(e0, ctx->stream);
+        }
+        if (e == hipSuccess)
+            e = launch_two_sided(p, ctx->num_cus, ctx->stream);
+        if (e == hipSuccess && ctx->timing) {
+            e = hipEventRecord(e1, ctx->stream);
+            if (e == hipSuccess)
+                ctx->events.emplace_back(e0, e1);
+        }
+    }
+    std::vector<int> nil((size_t)M);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(lag, dlag, (size_t)M * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(mv, dmv, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(nil.data(), dnil, (size_t)M * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && cc)
+        e = hipMemcpyAsync(cc, dcc, (size_t)M * (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(ctx->stream);
+    cleanup();
+    if (e != hipSuccess)
+        return fail(MUSE_ERR_HIP, "two-sided xCorr: %s", hipGetErrorString(e));
+    for (int64_t i = 0; i < M; i++) {
+        if (is_nil)
+            is_nil[i] = nil[(size_t)i];
+        if (cc && !nil[(size_t)i] && mv[i] != mv[i]) // NaN / Inf statistics: the reference's cc is NaN throughout
+            std::fill(cc + (size_t)i * (size_t)n, cc + (size_t)(i + 1) * (size_t)n, std::numeric_limits<double>::quiet_NaN());
+    }
+    return MUSE_OK;
+}
+
+extern "C" int muse_xcorr_batch(muse_ctx *ctx, const double *x_rows, const double *y_rows, int64_t M, int32_t lenx, int32_t leny,
+                                int32_t n, int32_t normalize, int32_t *lag, double *mv, int32_t *is_nil, double *cc)
+{
+    if (!ctx || M < 0 || lenx < 1 || leny < 1 || (M > 0 && (!x_rows || !y_rows)))
+        return fail(MUSE_ERR_INVALID, "bad xCorr batch arguments");
+    if (M == 0)
+        return MUSE_OK;
+    muse_group *gx = nullptr, *gy = nullptr;
+    int rc = muse_group_upload(ctx, x_rows, M, lenx, lenx, &gx);
+    if (!rc)
+        rc = muse_group_upload(ctx, y_rows, M, leny, leny, &gy);
+    if (!rc)
+        rc = muse_xcorr_groups(gx, gy, n, normalize, lag, mv, is_nil, cc);
+    const std::string msg = rc ? g_last_error : std::string();
+    muse_group_free(gx);
+    muse_group_free(gy);
+    if (rc)
+        g_last_error = msg;
+    return rc;
+}

@@ -67,6 +67,10 @@ struct FusedParams {
     const long long *pair_list;
     const int *pair_count;
     long long gscratch_slices; // n-element slices `gscratch` holds: a kernel that works in it launches no more workgroups than fit
+    // two-sided xCorr (xcorr_two_sided.hip): pair i = (x_i = xrows + i xstride, length Nx; y_i = rows + i stride, length N)
+    const double *xrows;
+    long long xstride;
+    int Nx;
 };
 
 hipError_t launch_fused(const FusedParams &p, int variant, int num_cus, hipStream_t stream);
@@ -81,6 +85,7 @@ hipError_t launch_fused_multi(const FusedParams &p, int num_cus, hipStream_t str
 hipError_t launch_fused_small(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_small.hip (n = 512, 1024, 2048: default)
 hipError_t launch_fused_stockham(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_stockham.hip (n = 512 .. 2048, 8192 .. 65536)
 hipError_t launch_fused_long(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_long.hip (n = 32768, 65536: default; 16384)
+hipError_t launch_two_sided(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_two_sided.hip (xCorr, n = 512 .. 65536)
 // out[4096 k1 + 256 k + t] = in[k1 + R1 (256 k + (t >> 4) + 16 (t & 15))]: the spectrum rows of the long-series kernel in lane order
 hipError_t launch_lane_order_rows(const double2 *in, double2 *out, int R1, hipStream_t stream);
 // out[256 k + t] = in[256 k + (t >> 4) + 16 (t & 15)], k < 16: a 4096-entry table in the lane order of xcorr_r16_fold.hip

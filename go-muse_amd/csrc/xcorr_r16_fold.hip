@@ -40,7 +40,10 @@ __global__ __launch_bounds__(OCC_THREADS, 4) void xcorr_fused_n4096_fold(const F
     using namespace foldk;
     __shared__ double2 xbuf[OCC_XBUF];
     __shared__ double2 g2s[128];
-    __shared__ double red[2 * REC];
+    // records of the pairs in flight: the one being written plus (BATCH) the ones waiting for their results to be
+    // written out together, one series per lane, every BATCH pairs
+    constexpr int BATCH = (VAR & 8) ? 8 : 1, NREC = BATCH + 1;
+    __shared__ double red[NREC * REC];
     __shared__ int next_s[2];
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -52,9 +55,24 @@ __global__ __launch_bounds__(OCC_THREADS, 4) void xcorr_fused_n4096_fold(const F
 
     if (t < 128)
         g2s[t] = p.g2[t];
-    if (t < 2)
-        red[REC * (t) + 34] = -1.0; // no previous pair yet (either parity)
+    if (t < NREC)
+        red[REC * (t) + 34] = -1.0; // no pair yet
     __syncthreads();
+    // results of records [first, first + count) (ring slots modulo NREC): lane 2 k + s of wave 0 writes series s of record first + k
+    const auto write_out = [&](int first, int count) __attribute__((always_inline)) {
+        if (wave == 0 && lane < 2 * count) {
+            const double *const r = red + REC * ((first + (lane >> 1)) % NREC);
+            const int series = lane & 1;
+            if (r[34] >= 0.0 && (series == 0 || r[35] != 0.0)) {
+                const long long row = (long long)r[34] + series;
+                if (finalize(r, series, invN, invNm1, p.mv + row, p.lag + row)) {
+                    const int slot = atomicAdd(p.ovf_count, 1);
+                    p.ovf_list[slot] = row >> 1;
+                }
+            }
+        }
+    };
+    int cnt = 0, done = 0; // pairs this workgroup has started / written out
     PhaseClock<TIMING> clk;
     clk.start();
 
@@ -74,7 +92,7 @@ __global__ __launch_bounds__(OCC_THREADS, 4) void xcorr_fused_n4096_fold(const F
     for (long long pair = blockIdx.x; pair < total; pair = nextpair) {
         const long long rA = 2 * pair;
         const bool hasB = rA + 1 < p.M;
-        double *const rec = red + REC * parity;
+        double *const rec = red + REC * (BATCH > 1 ? cnt % NREC : parity);
         const double *const prec = red + REC * (parity ^ 1);
         if (t == 0) // the pair after this one: claimed now, read behind this pair's barriers
             next_s[parity] = (int)gridDim.x + atomicAdd(p.work_counter, 1);
@@ -117,6 +135,13 @@ __global__ __launch_bounds__(OCC_THREADS, 4) void xcorr_fused_n4096_fold(const F
         // -> thread (k1 = hi, c = lo), input b at v[b]; the tail barrier frees the wave's private quarter for the
         // wave-local transpose below while the waves are still in step
         exchange_cross<0, 1, true>(v, xbuf, wave, t, WIDE ? wide_column(t) : -1);
+        if (BATCH > 1) {
+            // the records of the pairs before this one are complete and visible: every BATCH pairs their results are written
+            if (cnt - done == BATCH) {
+                write_out(done, BATCH);
+                done += BATCH;
+            }
+        } else
         // the previous pair's record is complete and visible: lane 0 of waves 0 / 1 writes one series' result each
         if (lane == 0 && wave < 2 && prec[34] >= 0.0 && (wave == 0 || prec[35] != 0.0)) {
             const long long row = (long long)prec[34] + wave;
@@ -214,10 +239,13 @@ __global__ __launch_bounds__(OCC_THREADS, 4) void xcorr_fused_n4096_fold(const F
             rec[33] = s1b;
         }
         parity ^= 1;
+        cnt++;
         clk.template stamp<12>();
     }
     lds_barrier();
-    {
+    if (BATCH > 1) {
+        write_out(done, cnt - done);
+    } else {
         const double *const prec = red + REC * (parity ^ 1);
         if (t < 2 && prec[34] >= 0.0 && (t == 0 || prec[35] != 0.0)) {
             const long long row = (long long)prec[34] + t;

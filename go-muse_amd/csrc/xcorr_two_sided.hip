@@ -1,0 +1,452 @@
+// xcorr_two_sided.hip -- the batched two-sided xCorr.
+//
+// Mathematics: xCorr, /root/reference/xcorr.go:102-153 -- for each of M independent pairs (x, y): optional zNormalize of
+// both (xcorr.go:108-128; sigma == 0 -> (nil, 0, 0)), leading zero pad of both to n (129-130), X = FFT(x), Y = FFT(y),
+// cc = IFFT(X conj(Y)) (134-138), scale 1 / (n (n - 1)) when normalized, else 1 / n (139-143) -- n - 1 of the FFT length,
+// not of the series length --, global first-strict argmax of |cc| and lag unwrap (145-150).
+//
+// One complex transform serves both series of a pair: z = x + i y, Z = FFT(z).  With Zm[f] = Z[-f mod n]
+//     X[f] = (Z[f] + conj(Zm[f])) / 2,   Y[f] = (Z[f] - conj(Zm[f])) / 2i
+//     P[f] = X[f] conj(Y[f]):   Re P = Im(Z[f] Zm[f]) / 2,   Im P = (|Z[f]|^2 - |Zm[f]|^2) / 4
+// and cc = IFFT(P) is real, so FFT(conj(P) / n) = cc: a pair costs two FORWARD complex transforms of length n, exactly
+// what a pair of series costs in the xCorrWithX kernels.  The transforms are the Stockham engine's (stk_device.h: natural
+// order in LDS, folded arithmetic), whose output order makes the mirrored element Z[-f] one LDS (n <= 8192) or one scratch
+// (n >= 16384) read away.  Both series enter the shared transform at O(1): exact power-of-two scales near 1 / sigma (or
+// near 1 / rms when not normalized), undone in the one factor the winning value is multiplied by.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <algorithm>
+
+#include "stk_device.h"
+
+namespace muse {
+
+namespace two {
+
+using namespace occ4;
+using namespace stk;
+
+// V[f] = conj(P[f]) * s from Z[f] and Z[-f]
+__device__ __forceinline__ double2 untangle(const double2 z, const double2 zm, const double s)
+{
+    const double re = 0.5 * fma(z.x, zm.y, z.y * zm.x);
+    const double im = 0.25 * (fma(z.x, z.x, z.y * z.y) - fma(zm.x, zm.x, zm.y * zm.y));
+    return make_double2(re * s, -im * s);
+}
+
+// what the statistics of one pair decide (uniform over the pair's threads)
+struct PairScale {
+    double sA, sB, mA, mB; // v = x * s - m at valid positions
+    double fac;            // cc = transform output * fac
+    bool nil, nan;
+};
+// q = {sum dx, sum dx^2, sum dy, sum dy^2} with d = sample - first sample (normalized) or the sample itself (raw)
+__device__ __forceinline__ PairScale pair_scale(const double (&q)[4], const int Nx, const int Ny, const int n, const bool normalize)
+{
+    PairScale s;
+    if (normalize) {
+        bool zA, nA, zB, nB;
+        const double invNx = 1.0 / (double)Nx, invNy = 1.0 / (double)Ny;
+        const double vA0 = variance(Stat{q[0], q[1]}, invNx, 1.0 / (double)(Nx - 1), zA, nA);
+        const double vB0 = variance(Stat{q[2], q[3]}, invNy, 1.0 / (double)(Ny - 1), zB, nB);
+        s.nil = zA || zB; // xcorr.go:110-127: either sigma == 0 -> (nil, 0, 0) (x is checked first; a NaN x with a constant y is nil too)
+        s.nan = !s.nil && (nA || nB);
+        const bool dead = s.nil || s.nan;
+        s.sA = dead ? 1.0 : pow2_inv_sigma(vA0);
+        s.sB = dead ? 1.0 : pow2_inv_sigma(vB0);
+        s.mA = q[0] * invNx * s.sA;
+        s.mB = q[2] * invNy * s.sB;
+        const double vA = vA0 * s.sA * s.sA, vB = vB0 * s.sB * s.sB;
+        double ya = __builtin_amdgcn_rsq(vA), yb = __builtin_amdgcn_rsq(vB);
+        ya = ya * fma(-0.5 * vA * ya, ya, 1.5);
+        ya = ya * fma(-0.5 * vA * ya, ya, 1.5);
+        yb = yb * fma(-0.5 * vB * yb, yb, 1.5);
+        yb = yb * fma(-0.5 * vB * yb, yb, 1.5);
+        s.fac = ya * yb / (double)(n - 1); // xcorr.go:140: 1 / (n (n - 1)); the 1 / n rides in the untangled spectrum
+    } else {
+        const double eA = q[1] / (double)Nx, eB = q[3] / (double)Ny; // mean squares
+        s.nil = false;
+        s.nan = !__builtin_isfinite(eA) || !__builtin_isfinite(eB);
+        s.sA = (s.nan || !(eA > 0.0)) ? 1.0 : pow2_inv_sigma(eA);
+        s.sB = (s.nan || !(eB > 0.0)) ? 1.0 : pow2_inv_sigma(eB);
+        s.mA = s.mB = 0.0;
+        s.fac = (1.0 / s.sA) * (1.0 / s.sB); // exact
+    }
+    return s;
+}
+
+} // namespace two
+
+// n = 512 ... 8192: n/16 threads per pair, the pair's work buffer in LDS (xcorr_fused_stk_lds's geometry)
+template <int LOGN>
+__global__ __launch_bounds__(((1 << LOGN) / 16 > 256 ? (1 << LOGN) / 16 : 256), ((1 << LOGN) / 16 >= 256 ? 1 : 2))
+void xcorr_two_sided_lds(const FusedParams p)
+{
+    using namespace occ4;
+    using namespace stk;
+    using namespace two;
+    constexpr int n = 1 << LOGN;
+    constexpr int S = n / 16;
+    constexpr int G = S >= 256 ? 1 : 256 / S;
+    constexpr int TPB = S * G;
+    constexpr int ROWS = S / 16;
+    constexpr int BUF = n + n / 16;
+    static_assert(LOGN >= 9 && LOGN <= 13, "LDS kernel: n = 512 ... 8192");
+    __shared__ double2 buf[G * BUF];
+    __shared__ double red[(TPB / 16) * 4];
+    __shared__ double arg[(TPB / 16) * 3];
+    const int t = threadIdx.x;
+    const int g = t / S, j = t % S;
+    const int row = t >> 4;
+    double2 *const b = buf + g * BUF;
+    const int Nx = p.Nx, Ny = p.N, padx = n - Nx, pady = n - Ny;
+    const bool normalize = p.normalize_y != 0;
+    const double2 *__restrict__ twm = p.twm;
+    const long long total = p.npairs;
+    const long long ngroups = (total + G - 1) / G;
+    const int rbase = j + (j >> 4); // padpos(j + r S) = rbase + r padk(S)
+
+    for (long long it = blockIdx.x; it < ngroups; it += gridDim.x) {
+        const long long slot = it * G + g;
+        const bool live = slot < total;
+        const long long pair = live ? slot : total - 1; // idle sub-groups shadow the last pair
+        const double *__restrict__ rx = p.xrows + pair * p.xstride;
+        const double *__restrict__ ry = p.rows + pair * p.stride;
+        double2 v[16];
+        const double KA = normalize ? rx[0] : 0.0, KB = normalize ? ry[0] : 0.0;
+        double q[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int ex = j + i * S - padx, ey = j + i * S - pady;
+            double da = __builtin_nontemporal_load(rx + (ex < 0 ? 0 : ex)) - KA;
+            double db = __builtin_nontemporal_load(ry + (ey < 0 ? 0 : ey)) - KB;
+            da = ex >= 0 ? da : 0.0;
+            db = ey >= 0 ? db : 0.0;
+            v[i] = make_double2(da, db);
+            q[0] += da;
+            q[1] = fma(da, da, q[1]);
+            q[2] += db;
+            q[3] = fma(db, db, q[3]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            q[k] = row_sum_dpp(q[k]);
+        if ((t & 15) == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                red[row * 4 + k] = q[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            double s = 0.0;
+            for (int r = 0; r < ROWS; r++)
+                s += red[(g * ROWS + r) * 4 + k];
+            q[k] = s;
+        }
+        const PairScale ps = pair_scale(q, Nx, Ny, n, normalize);
+        const bool dead = ps.nil || ps.nan;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const bool vx = j + i * S - padx >= 0, vy = j + i * S - pady >= 0;
+            v[i].x = (vx && !dead) ? fma(v[i].x, ps.sA, -ps.mA) : 0.0;
+            v[i].y = (vy && !dead) ? fma(v[i].y, ps.sB, -ps.mB) : 0.0;
+        }
+        // Z = FFT(x + i y): Z[j + r S] at v[BR16(r)]
+        lds_forward<LOGN, false>(v, b, twm, j);
+        __syncthreads(); // every thread is past its last read of the buffer
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            b[rbase + r * padk(S)] = v[BR16(r)];
+        __syncthreads();
+        {
+            double2 w[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int fm = (n - (j + r * S)) & (n - 1);
+                w[r] = untangle(v[BR16(r)], b[padpos(fm)], 1.0 / (double)n);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                v[r] = w[r];
+        }
+        // cc = FFT(conj(P) / n): real part at v[BR16(i)] for index j + i S
+        lds_forward<LOGN, true>(v, b, twm, j);
+        double ma = 0.0, sa = 0.0;
+        int ia = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < 16; i++) { // ascending i = ascending index for this thread
+            const double x = v[BR16(i)].x, aa = fabs(x);
+            if (aa > ma) { ma = aa; sa = x; ia = j + i * S; }
+        }
+        if (p.cc_out && live && !dead) {
+            double *const cc = p.cc_out + pair * (long long)n;
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                cc[j + i * S] = v[BR16(i)].x * ps.fac;
+        }
+        {
+            const double rma = row_max_dpp(ma);
+            const int ca = row_min_i_dpp((ma == rma && rma > 0.0) ? ia : 0x7fffffff);
+            if (ca == 0x7fffffff) {
+                if ((t & 15) == 0) {
+                    arg[row * 3 + 0] = 0.0;
+                    arg[row * 3 + 1] = 0.0;
+                    arg[row * 3 + 2] = (double)0x7fffffff;
+                }
+            } else if (ia == ca && ma == rma) {
+                arg[row * 3 + 0] = rma;
+                arg[row * 3 + 1] = sa;
+                arg[row * 3 + 2] = (double)ca;
+            }
+        }
+        if (j == 0) // cc[0], for the "nothing above zero" case (index 0, mv = cc[0])
+            red[g * ROWS * 4] = v[0].x;
+        __syncthreads();
+        if (j == 0 && live) {
+            double best = 0.0, bsv = 0.0, bidx = (double)0x7fffffff;
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) {
+                const double *a = arg + (g * ROWS + r) * 3;
+                if (a[0] > best || (a[0] == best && a[2] < bidx)) {
+                    best = a[0];
+                    bsv = a[1];
+                    bidx = a[2];
+                }
+            }
+            const int idx = (best > 0.0) ? (int)bidx : 0;
+            double mv = ((best > 0.0) ? bsv : red[g * ROWS * 4]) * ps.fac;
+            int lag = idx > n / 2 ? idx - n : idx;
+            if (ps.nil) { mv = 0.0; lag = 0; }                 // xcorr.go:110-127
+            if (ps.nan) { mv = __builtin_nan(""); lag = 0; }   // every cc is NaN: maxAbsIndex keeps index 0
+            p.mv[pair] = mv;
+            p.lag[pair] = lag;
+            if (p.nil_out)
+                p.nil_out[pair] = ps.nil ? 1 : 0;
+        }
+        __syncthreads(); // red / arg / buf free for the next iteration
+    }
+}
+
+// n = 16384 ... 65536: four-step, n = R1 * 4096 (xcorr_fused_stk_4step's geometry), TWO n-element scratch slices per
+// workgroup: Y takes the rows, the first sweep and the row spectra Z (natural order: Z[k1 + R1 k2] at Y[4096 k1 + k2]);
+// the second stage reads Z[f] and Z[-f] (row R1 - k1, column 4095 - k2; row 0: column 4096 - k2), transforms the untangled
+// product row by row into Y2, and the last sweep runs over Y2.
+template <int LOGN>
+__global__ __launch_bounds__(256, 2) void xcorr_two_sided_4step(const FusedParams p)
+{
+    using namespace occ4;
+    using namespace stk;
+    using namespace two;
+    constexpr int n = 1 << LOGN;
+    constexpr int S = n / 16;
+    constexpr int CH = S / 256;
+    constexpr int R1 = n / 4096;
+    constexpr int Q1 = 16 / R1;
+    static_assert(LOGN >= 14 && LOGN <= 16, "four-step kernel: n = 16384 ... 65536");
+    __shared__ double2 buf[4096 + 256];
+    __shared__ double red[64];
+    __shared__ int redi[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    double2 *const Y = p.gscratch + (size_t)(2 * blockIdx.x) * (size_t)n;
+    double2 *const Y2 = Y + n;
+    const int Nx = p.Nx, Ny = p.N, padx = n - Nx, pady = n - Ny;
+    const bool normalize = p.normalize_y != 0;
+    const double2 *__restrict__ twm = p.twm;
+
+    for (long long pair = blockIdx.x; pair < p.npairs; pair += gridDim.x) {
+        const double *__restrict__ rx = p.xrows + pair * p.xstride;
+        const double *__restrict__ ry = p.rows + pair * p.stride;
+        const double KA = normalize ? rx[0] : 0.0, KB = normalize ? ry[0] : 0.0;
+        const auto twiddle_rows = [&](double2 (&v)[16], const int j) __attribute__((always_inline)) {
+#pragma unroll
+            for (int m = 0; m < Q1; m++) {
+                const int m2 = j + m * S;
+#pragma unroll
+                for (int r = 1; r < R1; r++) {
+                    const int e = (m2 * r * (65536 / n)) & 65535;
+                    const double2 w = twm[e & 32767];
+                    const double2 ws = e >= 32768 ? make_double2(-w.x, -w.y) : w;
+                    v[m + r * Q1] = cmul(v[m + r * Q1], ws);
+                }
+            }
+        };
+        // ---- sweep 0: rows -> d (leading zero pads) into the slice, statistics
+        double q[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma clang loop unroll(disable)
+        for (int ch = 0; ch < CH; ch++) {
+            const int j = t + 256 * ch;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int ex = j + i * S - padx, ey = j + i * S - pady;
+                double da = __builtin_nontemporal_load(rx + (ex < 0 ? 0 : ex)) - KA;
+                double db = __builtin_nontemporal_load(ry + (ey < 0 ? 0 : ey)) - KB;
+                da = ex >= 0 ? da : 0.0;
+                db = ey >= 0 ? db : 0.0;
+                Y[j + i * S] = make_double2(da, db);
+                q[0] += da;
+                q[1] = fma(da, da, q[1]);
+                q[2] += db;
+                q[3] = fma(db, db, q[3]);
+            }
+        }
+        block_sum<4>(q, red);
+        const PairScale ps = pair_scale(q, Nx, Ny, n, normalize);
+        const bool dead = ps.nil || ps.nan;
+        // ---- sweep 1: scale / centre, radix R1 over m1, twiddle W_n^(m2 k1), in place
+#pragma clang loop unroll(disable)
+        for (int ch = 0; ch < CH; ch++) {
+            const int j = t + 256 * ch;
+            double2 v[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const bool vx = j + i * S - padx >= 0, vy = j + i * S - pady >= 0;
+                const double2 d = Y[j + i * S];
+                v[i].x = (vx && !dead) ? fma(d.x, ps.sA, -ps.mA) : 0.0;
+                v[i].y = (vy && !dead) ? fma(d.y, ps.sB, -ps.mB) : 0.0;
+            }
+            dft_small<R1>(v);
+            twiddle_rows(v, j);
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                Y[j + i * S] = v[i];
+        }
+        __syncthreads();
+        // ---- rows, first transform: row k1 -> Z[k1 + R1 k2] at Y[4096 k1 + k2]
+#pragma clang loop unroll(disable)
+        for (int k1 = 0; k1 < R1; k1++) {
+            double2 *const row = Y + k1 * 4096;
+            double2 v[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                v[i] = row[t + 256 * i];
+            lds_forward<12, true>(v, buf, twm, t);
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                row[t + 256 * r] = v[BR16(r)];
+        }
+        __syncthreads(); // every row's spectrum is in the slice
+        // ---- rows, second transform: V[f] = conj(X[f] conj(Y[f])) / n from Z[f] and Z[-f], row k1 -> Y2
+#pragma clang loop unroll(disable)
+        for (int k1 = 0; k1 < R1; k1++) {
+            const double2 *const row = Y + k1 * 4096;
+            const double2 *const mrow = Y + ((R1 - k1) & (R1 - 1)) * 4096;
+            double2 v[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int k2 = t + 256 * r;
+                const int m2 = k1 == 0 ? ((4096 - k2) & 4095) : 4095 - k2;
+                v[r] = untangle(row[k2], mrow[m2], 1.0 / (double)n);
+            }
+            lds_forward<12, true>(v, buf, twm, t);
+            double2 *const out = Y2 + k1 * 4096;
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                out[t + 256 * r] = v[BR16(r)];
+        }
+        __syncthreads();
+        // ---- sweep 2: twiddle, radix R1 over k1 -> cc[m1 4096 + m2] at register m + m1 Q1 (real part); argmax
+        double ma = 0.0, sa = 0.0, cc0 = 0.0;
+        int ia = 0x7fffffff;
+#pragma clang loop unroll(disable)
+        for (int ch = 0; ch < CH; ch++) {
+            const int j = t + 256 * ch;
+            double2 v[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                v[i] = Y2[j + i * S];
+            twiddle_rows(v, j);
+            dft_small<R1>(v);
+            if (ch == 0)
+                cc0 = v[0].x;
+            if (p.cc_out && !dead) {
+                double *const cc = p.cc_out + pair * (long long)n;
+#pragma unroll
+                for (int i = 0; i < 16; i++)
+                    cc[j + i * S] = v[i].x * ps.fac;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const double aa = fabs(v[i].x);
+                const int idx = j + i * S;
+                if (aa > ma || (aa == ma && aa > 0.0 && idx < ia)) { ma = aa; sa = v[i].x; ia = idx; }
+            }
+        }
+        {
+            const double wa = wave_max(ma);
+            if (lane == 0)
+                red[32 + wave] = wa;
+            if (t == 0)
+                red[40] = cc0;
+            __syncthreads();
+            const double MA = fmax(fmax(red[32], red[33]), fmax(red[34], red[35]));
+            int ca = (ma == MA && MA > 0.0) ? ia : 0x7fffffff;
+            ca = wave_min_i(ca);
+            if (lane == 0)
+                redi[wave] = ca;
+            __syncthreads();
+            const int IA = min(min(redi[0], redi[1]), min(redi[2], redi[3]));
+            const bool none = IA == 0x7fffffff;
+            const bool owner = none ? (t == 0) : (ia == IA && ma == MA);
+            if (owner) {
+                const int idx = none ? 0 : IA;
+                double mv = (none ? red[40] : sa) * ps.fac;
+                int lag = idx > n / 2 ? idx - n : idx;
+                if (ps.nil) { mv = 0.0; lag = 0; }
+                if (ps.nan) { mv = __builtin_nan(""); lag = 0; }
+                p.mv[pair] = mv;
+                p.lag[pair] = lag;
+                if (p.nil_out)
+                    p.nil_out[pair] = ps.nil ? 1 : 0;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int LOGN>
+static hipError_t launch_two_lds(const FusedParams &p, int num_cus, hipStream_t stream)
+{
+    constexpr int S = (1 << LOGN) / 16;
+    constexpr int G = S >= 256 ? 1 : 256 / S;
+    constexpr int TPB = S * G;
+    constexpr int WPC = S >= 256 ? 1 : 2;
+    const long long ngroups = (p.npairs + G - 1) / G;
+    const long long grid = std::min<long long>(ngroups, (long long)num_cus * WPC * 8);
+    hipLaunchKernelGGL((xcorr_two_sided_lds<LOGN>), dim3((unsigned)grid), dim3(TPB), 0, stream, p);
+    return hipGetLastError();
+}
+
+template <int LOGN>
+static hipError_t launch_two_4step(const FusedParams &p, int num_cus, hipStream_t stream)
+{
+    const long long grid = std::min<long long>(p.npairs, (long long)num_cus * STOCKHAM_GLOBAL_WGS_PER_CU);
+    if (!p.gscratch || 2 * grid > p.gscratch_slices) // two n-element slices per workgroup
+        return hipErrorInvalidValue;
+    hipLaunchKernelGGL((xcorr_two_sided_4step<LOGN>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+// M = p.npairs pairs (x_i = p.xrows + i p.xstride, length p.Nx; y_i = p.rows + i p.stride, length p.N), FFT length
+// p.n = 2^p.logn in 512 ... 65536 (>= both lengths), p.normalize_y = the reference's `normalize`; results in p.mv / p.lag /
+// p.nil_out (optional) / p.cc_out (optional, M x n)
+hipError_t launch_two_sided(const FusedParams &p, int num_cus, hipStream_t stream)
+{
+    if (!p.xrows || !p.rows || !p.twm || !p.mv || !p.lag || p.npairs < 1 || p.Nx < 1 || p.N < 1 || p.Nx > p.n || p.N > p.n ||
+        (p.normalize_y && (p.Nx < 2 || p.N < 2)))
+        return hipErrorInvalidValue;
+    switch (p.logn) {
+    case 9: return launch_two_lds<9>(p, num_cus, stream);
+    case 10: return launch_two_lds<10>(p, num_cus, stream);
+    case 11: return launch_two_lds<11>(p, num_cus, stream);
+    case 12: return launch_two_lds<12>(p, num_cus, stream);
+    case 13: return launch_two_lds<13>(p, num_cus, stream);
+    case 14: return launch_two_4step<14>(p, num_cus, stream);
+    case 15: return launch_two_4step<15>(p, num_cus, stream);
+    case 16: return launch_two_4step<16>(p, num_cus, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+} // namespace muse

@@ -42,8 +42,8 @@ int main(int argc, char** argv)
     CK(hipDeviceSynchronize());
     int cus = 256; { hipDeviceProp_t pr; CK(hipGetDeviceProperties(&pr, 0)); cus = pr.multiProcessorCount; }
     const int grid = cus * 4;
-    const int vars[] = {0, 1, 3, 4, 7, 2};
-    const launch_fn fns[] = {launch<0>, launch<1>, launch<3>, launch<4>, launch<7>, launch<2>};
+    const int vars[] = {0, 7, 8, 15, 2};
+    const launch_fn fns[] = {launch<0>, launch<7>, launch<8>, launch<15>, launch<2>};
     const int NV = sizeof(vars) / sizeof(vars[0]);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     std::vector<double> mv0(M), mv(M);
