@@ -82,6 +82,8 @@ SIGNATURES = {
     "muse_batch_free": (ctypes.c_int, [_vp]),
     "muse_xcorr_with_x": (ctypes.c_int, [_vp, _dp, _dp, _i32, _i32, _dp, _i32p, _dp, _i32p]),
     "muse_xcorr": (ctypes.c_int, [_vp, _dp, _i32, _dp, _i32, _i32, _i32, _dp, _i32p, _dp, _i32p]),
+    "muse_xcorr_groups": (ctypes.c_int, [_vp, _vp, _i32, _i32, _i32p, _dp, _i32p, _dp]),
+    "muse_xcorr_batch": (ctypes.c_int, [_vp, _dp, _dp, _i64, _i32, _i32, _i32, _i32, _i32p, _dp, _i32p, _dp]),
     "muse_next_pow2": (_i64, [_f64]),
 }
 

@@ -271,21 +271,16 @@ __device__ __forceinline__ void issue_row_loads(RawPair &r, const FusedParams &p
 // (v_permlane32_swap, gfx950: 32 VALU per pair), after which lane (m, h) holds COLUMN 64 w + 2 m + h of both rows:
 // r.a[i] = A[256 i + col], r.b[i] = B[256 i + col], i = 0 .. 15 -- the layout pass 1 wants, on a relabelled column.
 __device__ __forceinline__ int wide_column(int t) { return (t & ~63) | ((t & 31) << 1) | ((t >> 5) & 1); }
-template <bool SK>
 __device__ __forceinline__ void issue_row_loads_wide(RawPair &r, const FusedParams &p, long long pair, int t)
 {
     const long long rA = 2 * pair;
     const long long rB = (rA + 1 < p.M) ? rA + 1 : rA;
-    if (SK) { // the rows' first samples through the scalar cache (uniform address): no vector memory instruction
+    // the rows' first samples through the scalar cache (uniform address): no vector memory instruction
 #if defined(__HIP_DEVICE_COMPILE__)
-        typedef const double __attribute__((address_space(4))) *cptr;
-        r.ka = *(cptr)(unsigned long long)(p.rows + rA * p.stride);
-        r.kb = *(cptr)(unsigned long long)(p.rows + rB * p.stride);
+    typedef const double __attribute__((address_space(4))) *cptr;
+    r.ka = *(cptr)(unsigned long long)(p.rows + rA * p.stride);
+    r.kb = *(cptr)(unsigned long long)(p.rows + rB * p.stride);
 #endif
-    } else {
-        r.ka = scalar_ptr(p.rows + rA * p.stride)[0];
-        r.kb = scalar_ptr(p.rows + rB * p.stride)[0];
-    }
     const int lo16 = ((t >> 5) & 1) * 1024 + (t >> 6) * 32 + (t & 31); // in 16-byte units: (2048 h + 64 w + 2 m) / 2
 #pragma unroll
     for (int i = 0; i < 8; i++) { // one scalar base per four 2 KB slices (immediate offsets -4096 .. +2048 B)

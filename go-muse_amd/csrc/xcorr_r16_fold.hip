@@ -30,9 +30,7 @@ namespace muse {
 // PADDED (2048 < N < 4096, leading zero pad): as in xcorr_r16_fast.hip -- the transforms run on d, sum d is read
 // off the DC bin and the 16 values a lane ends with are corrected by -m c1[index] before the argmax.
 // F32: float32-storage group (half the HBM bytes; samples widened exactly on consumption, same float64 arithmetic)
-// VAR (measurement builds, tools/ablate/fold_phases.hip; N == n, float64 rows only): bit 0 = 16-byte row loads, bit 1 = the rows'
-// first samples through the scalar cache, bit 2 = pass-3 factors derived from two table entries
-template <bool TIMING = false, bool PADDED = false, bool F32 = false, int VAR = 0>
+template <bool TIMING = false, bool PADDED = false, bool F32 = false>
 __global__ __launch_bounds__(OCC_THREADS, 4) void xcorr_fused_n4096_fold(const FusedParams p)
 {
     using namespace occ4;
@@ -40,10 +38,7 @@ __global__ __launch_bounds__(OCC_THREADS, 4) void xcorr_fused_n4096_fold(const F
     using namespace foldk;
     __shared__ double2 xbuf[OCC_XBUF];
     __shared__ double2 g2s[128];
-    // records of the pairs in flight: the one being written plus (BATCH) the ones waiting for their results to be
-    // written out together, one series per lane, every BATCH pairs
-    constexpr int BATCH = (VAR & 8) ? 8 : 1, NREC = BATCH + 1;
-    __shared__ double red[NREC * REC];
+    __shared__ double red[2 * REC];
     __shared__ int next_s[2];
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -55,34 +50,20 @@ __global__ __launch_bounds__(OCC_THREADS, 4) void xcorr_fused_n4096_fold(const F
 
     if (t < 128)
         g2s[t] = p.g2[t];
-    if (t < NREC)
-        red[REC * (t) + 34] = -1.0; // no pair yet
+    if (t < 2)
+        red[REC * (t) + 34] = -1.0; // no previous pair yet (either parity)
     __syncthreads();
-    // results of records [first, first + count) (ring slots modulo NREC): lane 2 k + s of wave 0 writes series s of record first + k
-    const auto write_out = [&](int first, int count) __attribute__((always_inline)) {
-        if (wave == 0 && lane < 2 * count) {
-            const double *const r = red + REC * ((first + (lane >> 1)) % NREC);
-            const int series = lane & 1;
-            if (r[34] >= 0.0 && (series == 0 || r[35] != 0.0)) {
-                const long long row = (long long)r[34] + series;
-                if (finalize(r, series, invN, invNm1, p.mv + row, p.lag + row)) {
-                    const int slot = atomicAdd(p.ovf_count, 1);
-                    p.ovf_list[slot] = row >> 1;
-                }
-            }
-        }
-    };
-    int cnt = 0, done = 0; // pairs this workgroup has started / written out
     PhaseClock<TIMING> clk;
     clk.start();
 
     int parity = 0;
     const long long total = p.npairs;
     RawPair raw;
-    constexpr bool WIDE = (VAR & 1) && !PADDED && !F32;
+    // N == n float64 rows: 16-byte requests on relabelled columns (r16_device.h, issue_row_loads_wide): -1.6 % (profiles/r03_fold_variants.txt)
+    constexpr bool WIDE = !PADDED && !F32;
     const auto request_rows = [&](long long pr) __attribute__((always_inline)) {
         if (WIDE)
-            issue_row_loads_wide<(VAR & 2) != 0>(raw, p, pr, t);
+            issue_row_loads_wide(raw, p, pr, t);
         else
             issue_row_loads<PADDED, F32>(raw, p, pr, t, pad);
     };
@@ -92,7 +73,7 @@ __global__ __launch_bounds__(OCC_THREADS, 4) void xcorr_fused_n4096_fold(const F
     for (long long pair = blockIdx.x; pair < total; pair = nextpair) {
         const long long rA = 2 * pair;
         const bool hasB = rA + 1 < p.M;
-        double *const rec = red + REC * (BATCH > 1 ? cnt % NREC : parity);
+        double *const rec = red + REC * parity;
         const double *const prec = red + REC * (parity ^ 1);
         if (t == 0) // the pair after this one: claimed now, read behind this pair's barriers
             next_s[parity] = (int)gridDim.x + atomicAdd(p.work_counter, 1);
@@ -135,13 +116,6 @@ __global__ __launch_bounds__(OCC_THREADS, 4) void xcorr_fused_n4096_fold(const F
         // -> thread (k1 = hi, c = lo), input b at v[b]; the tail barrier frees the wave's private quarter for the
         // wave-local transpose below while the waves are still in step
         exchange_cross<0, 1, true>(v, xbuf, wave, t, WIDE ? wide_column(t) : -1);
-        if (BATCH > 1) {
-            // the records of the pairs before this one are complete and visible: every BATCH pairs their results are written
-            if (cnt - done == BATCH) {
-                write_out(done, BATCH);
-                done += BATCH;
-            }
-        } else
         // the previous pair's record is complete and visible: lane 0 of waves 0 / 1 writes one series' result each
         if (lane == 0 && wave < 2 && prec[34] >= 0.0 && (wave == 0 || prec[35] != 0.0)) {
             const long long row = (long long)prec[34] + wave;
@@ -158,10 +132,7 @@ __global__ __launch_bounds__(OCC_THREADS, 4) void xcorr_fused_n4096_fold(const F
         clk.template stamp<5>();
         // pass 3: generalised DFT over c, delta = (k1 + 16 k2) / 256 (carries W_4096^(c k1) W_256^(c k2));
         // Z[hi + 16 lo + 256 k3] at v[BR16(k3)]
-        if (VAR & 4)
-            gdft16_nr_l2(v, G3Derived(p.g3a, t));
-        else
-            gdft16_nr_l2(v, G3Fetch{p.g3a, t});
+        gdft16_nr_l2(v, G3Derived(p.g3a, t));
         double s1a, s1b;
         {
             // bin 0 (lane 0 of wave 0) = (sum dA, sum dB): kept in SGPRs until the record is written; the centred
@@ -197,10 +168,7 @@ __global__ __launch_bounds__(OCC_THREADS, 4) void xcorr_fused_n4096_fold(const F
         nextpair = __builtin_amdgcn_readfirstlane(next_s[parity]);
         long long nxt = nextpair; // last iteration: pair 0 (L2-resident dummy)
         nxt = nxt < total ? nxt : 0;
-        if (VAR & 4)
-            gdft16_nr_l2(v, G3Derived(p.g3b, t));
-        else
-            gdft16_nr_l2(v, G3Fetch{p.g3b, t});
+        gdft16_nr_l2(v, G3Derived(p.g3b, t));
         if (PADDED) { // cc(d - m 1_valid) = cc(d) - m c1, m = sum d / N
             const auto c1l = [&](int k) __attribute__((always_inline)) {
                 return scalar_ptr_at(p.c1, 256 * ((k + 1) & ~1))[t - 256 * (k & 1)];
@@ -239,13 +207,10 @@ __global__ __launch_bounds__(OCC_THREADS, 4) void xcorr_fused_n4096_fold(const F
             rec[33] = s1b;
         }
         parity ^= 1;
-        cnt++;
         clk.template stamp<12>();
     }
     lds_barrier();
-    if (BATCH > 1) {
-        write_out(done, cnt - done);
-    } else {
+    {
         const double *const prec = red + REC * (parity ^ 1);
         if (t < 2 && prec[34] >= 0.0 && (t == 0 || prec[35] != 0.0)) {
             const long long row = (long long)prec[34] + t;

@@ -113,6 +113,33 @@ class Engine:
         return cc, int(lag.value), float(mv.value)
 
 
+    def xcorr_batch(self, x_rows, y_rows, n, normalize, want_cc=False):
+        """xCorr (xcorr.go:102-153) for M independent pairs in one launch: x_rows is M x lenx, y_rows M x leny.
+        Returns (lag[M], mv[M], is_nil[M]) or, with want_cc, (cc[M, n], lag, mv, is_nil)."""
+        x, y = np.ascontiguousarray(x_rows, dtype=np.float64), np.ascontiguousarray(y_rows, dtype=np.float64)
+        if x.ndim != 2 or y.ndim != 2 or x.shape[0] != y.shape[0]:
+            raise ValueError("x_rows and y_rows must be 2-D with one row per pair")
+        M = x.shape[0]
+        nn = max(int(n), x.shape[1], y.shape[1])
+        lag, mv, nil = np.zeros(M, dtype=np.int32), np.zeros(M), np.zeros(M, dtype=np.int32)
+        cc = np.zeros((M, nn)) if want_cc else None
+        B.check(B.load().muse_xcorr_batch(self._h, B.dptr(x), B.dptr(y), M, x.shape[1], y.shape[1], int(n),
+                                          1 if normalize else 0, B.i32ptr(lag), B.dptr(mv), B.i32ptr(nil),
+                                          B.dptr(cc) if want_cc else None))
+        return (cc, lag, mv, nil) if want_cc else (lag, mv, nil)
+
+
+def xcorr_groups(gx, gy, n, normalize, want_cc=False):
+    """The same over two device-resident groups (row i of gx with row i of gy): nothing is uploaded."""
+    M = gx.M
+    nn = max(int(n), gx.N, gy.N)
+    lag, mv, nil = np.zeros(M, dtype=np.int32), np.zeros(M), np.zeros(M, dtype=np.int32)
+    cc = np.zeros((M, nn)) if want_cc else None
+    B.check(B.load().muse_xcorr_groups(gx._h, gy._h, int(n), 1 if normalize else 0, B.i32ptr(lag), B.dptr(mv),
+                                       B.i32ptr(nil), B.dptr(cc) if want_cc else None))
+    return (cc, lag, mv, nil) if want_cc else (lag, mv, nil)
+
+
 _engines = {}
 
 

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MUSE_HIP_ABI_VERSION 2
+#define MUSE_HIP_ABI_VERSION 3
 
 typedef enum muse_status {
     MUSE_OK = 0,
@@ -249,6 +249,21 @@ int muse_xcorr_with_x(muse_ctx *ctx, const double *ref, const double *y,
 int muse_xcorr(muse_ctx *ctx, const double *x, int32_t lenx, const double *y,
                int32_t leny, int32_t n, int32_t normalize, double *cc,
                int32_t *lag, double *mv, int32_t *is_nil);
+/* xCorr (xcorr.go:102-153) for M independent pairs in ONE launch: pair i = (row i of gx, row i of gy).
+ * The two groups may hold series of different lengths (each is zero-padded on its own, xcorr.go:129-130); n is raised
+ * to max(n, Nx, Ny) (xcorr.go:104-106).  FFT lengths 512 ... 65536 that are powers of two run the batched kernels
+ * (xcorr_two_sided.hip: z = x + i y, one forward transform, X conj(Y) untangled from Z[f] and Z[-f], one more forward
+ * transform, scale 1 / (n (n - 1)) when normalized else 1 / n, exactly as xcorr.go:139-143); any other n (the
+ * reference's n = 5 tables, short series) goes pair by pair through muse_xcorr's path.  The groups are not mutated
+ * (the reference's zNormalize mutates x and y in place).
+ * Outputs (host): lag[M], mv[M]; is_nil[M] (may be NULL) = 1 where the reference returns (nil, 0, 0), i.e. normalize
+ * and sigma(x) == 0 or sigma(y) == 0; cc (may be NULL): M x n correlations (rows of nil pairs are zero). */
+int muse_xcorr_groups(muse_group *gx, muse_group *gy, int32_t n, int32_t normalize,
+                      int32_t *lag, double *mv, int32_t *is_nil, double *cc);
+/* The same from host memory: x_rows is M x lenx, y_rows M x leny, dense row-major; uploads, runs, frees. */
+int muse_xcorr_batch(muse_ctx *ctx, const double *x_rows, const double *y_rows, int64_t M,
+                     int32_t lenx, int32_t leny, int32_t n, int32_t normalize,
+                     int32_t *lag, double *mv, int32_t *is_nil, double *cc);
 /* nextPowOf2 (xcorr.go:19-24), same floating formula. */
 int64_t muse_next_pow2(double val);
 

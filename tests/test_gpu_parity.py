@@ -1551,3 +1551,106 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     assert d["value"] > 0 and d["config"]["rows_per_gpu"] == 20001
     # the planted copy of the reference (synthetic row of rank 0) tops the merged list
     assert abs(d["top_score"] - 1.0) < 1e-9
+
+
+# ------------------------------------------------ batched two-sided xCorr (xcorr.go:102-153)
+def _oracle_xcorr_rows(oracle, X, Y, n, normalize):
+    """oracle.xcorr per pair: cc rows (None where nil), lags, values and the top-two |cc| gap of each pair"""
+    ccs, lags, mvs, gaps = [], [], [], []
+    for x, y in zip(X, Y):
+        cc, lag, mv = oracle.xcorr(x, y, n, normalize)
+        ccs.append(cc)
+        lags.append(lag)
+        mvs.append(mv)
+        if cc is None or not np.all(np.isfinite(cc)):
+            gaps.append(1.0)
+        else:
+            a = np.sort(np.abs(cc))[::-1]
+            gaps.append((a[0] - a[1]) / a[0] if a[0] > 0 else 0.0)
+    return ccs, np.array(lags), np.array(mvs), np.array(gaps)
+
+
+def _check_xcorr_batch(eng, oracle, X, Y, n, normalize):
+    cc, lag, mv, nil = eng.xcorr_batch(X, Y, n, normalize, want_cc=True)
+    occ, olag, omv, gap = _oracle_xcorr_rows(oracle, X, Y, n, normalize)
+    onil = np.array([c is None for c in occ])
+    assert np.array_equal(nil.astype(bool), onil)          # (nil, 0, 0): xcorr.go:110-127
+    assert np.all(lag[onil] == 0) and np.all(mv[onil] == 0.0)
+    live = ~onil
+    # (a constant series that is NOT normalized correlates to the same value at every lag: an exact tie by construction)
+    worst = assert_scores_match(lag[live], mv[live], olag[live], omv[live], gap[live], max_ties=0 if normalize else 2)
+    for i in np.nonzero(live)[0]:
+        if np.all(np.isfinite(occ[i])):
+            scale = max(np.max(np.abs(occ[i])), 1e-300)
+            assert np.max(np.abs(cc[i] - occ[i])) <= 1e-9 * scale + 1e-12, (i, n, normalize)
+        else:
+            assert np.all(np.isnan(cc[i]))
+    # the outputs-only form returns the same lags and values
+    lag2, mv2, nil2 = eng.xcorr_batch(X, Y, n, normalize)
+    assert np.array_equal(lag2, lag) and np.array_equal(nil2, nil)
+    assert np.array_equal(np.isnan(mv2), np.isnan(mv)) and np.array_equal(mv2[~np.isnan(mv)], mv[~np.isnan(mv)])
+    return worst
+
+
+@pytest.mark.parametrize("n", [512, 1024, 2048, 4096, 8192, 16384, 32768, 65536])
+@pytest.mark.parametrize("normalize", [True, False])
+def test_xcorr_batch_matches_oracle(eng, oracle, n, normalize):
+    rng = np.random.default_rng(n + int(normalize))
+    M = 11 if n <= 8192 else 5
+    for N in (n, n - n // 4 - 3):                          # no padding (circular) and leading zero pads
+        X = rng.normal(size=(M, N)) * rng.uniform(0.1, 30.0, size=(M, 1)) + rng.normal(size=(M, 1)) * 5.0
+        Y = rng.normal(size=(M, N)) * rng.uniform(0.1, 30.0, size=(M, 1)) - 2.0
+        Y[1] = np.roll(X[1], 7) * -3.0 + 1.0               # a strong negative peak at a known lag
+        X[2] = 4.25                                        # sigma(x) == 0: nil when normalized, zero-lag ... product otherwise
+        Y[3] = -1.5                                        # sigma(y) == 0
+        X[4] *= 1e9                                        # scales far apart inside one pair
+        Y[4] *= 1e-7
+        if N == n:
+            Y[0, N // 3] = np.nan                          # every cc NaN: lag 0, mv NaN
+        _check_xcorr_batch(eng, oracle, X, Y, n, normalize)
+
+
+def test_xcorr_batch_different_lengths_and_raised_n(eng, oracle):
+    rng = np.random.default_rng(77)
+    M = 9
+    X = rng.normal(size=(M, 700))
+    Y = rng.normal(size=(M, 1000)) + np.linspace(0.0, 3.0, 1000)
+    for normalize in (True, False):
+        _check_xcorr_batch(eng, oracle, X, Y, 1024, normalize)     # each series padded on its own (xcorr.go:129-130)
+        _check_xcorr_batch(eng, oracle, X, Y, 600, normalize)      # n raised to max(n, lenx, leny) = 1000: the direct kernel
+    # the bench workload's shape through the resident-groups entry point
+    muse = pkg()
+    gx = muse.DeviceGroup.from_rows(eng, X[:, :512])
+    gy = muse.DeviceGroup.from_rows(eng, Y[:, :512])
+    lag, mv, nil = muse.xcorr_groups(gx, gy, 512, True)
+    _, olag, omv, gap = _oracle_xcorr_rows(oracle, X[:, :512], Y[:, :512], 512, True)
+    assert_scores_match(lag, mv, olag, omv, gap)
+    with pytest.raises(muse.MuseError):
+        muse.xcorr_groups(gx, muse.DeviceGroup.from_rows(eng, Y[:3, :512]), 512, True)   # row counts differ
+
+
+def test_xcorr_batch_golden_tables(eng, golden):           # xcorr_test.go:86-202 through the batch entry (n = 5: pair by pair)
+    for c in golden["xcorr"]["cases"]:
+        cc, lag, mv, nil = eng.xcorr_batch([c["x"]], [c["y"]], len(c["x"]), c["normalize"], want_cc=True)
+        if c["cc"] is None:
+            assert nil[0] == 1 and lag[0] == 0 and mv[0] == 0.0
+        else:
+            assert nil[0] == 0
+            assert np.max(np.abs(cc[0] - np.array(c["cc"], float))) <= golden["xcorr"]["tol"]
+            assert lag[0] == c["idx"]
+            _check_sign(mv[0], c["sign"])
+
+
+def test_xcorr_batch_many_pairs_4096(eng, oracle):
+    """2 000 pairs of rect + noise series (the bench's extra object at a size the oracle still finishes)"""
+    rng = np.random.default_rng(5)
+    M, N = 2000, 4096
+    t = np.arange(N)
+    c = rng.integers(N // 4, 3 * N // 4, size=(M, 1))
+    X = (np.abs(t - c) <= 5) * 1.5 + 0.1 * rng.normal(size=(M, N))
+    Y = (np.abs(t - c - rng.integers(-40, 40, size=(M, 1))) <= 8) * rng.uniform(-3, 3, size=(M, 1)) + 0.1 * rng.normal(size=(M, N))
+    lag, mv, nil = eng.xcorr_batch(X, Y, N, True)
+    sel = rng.choice(M, 150, replace=False)
+    _, olag, omv, gap = _oracle_xcorr_rows(oracle, X[sel], Y[sel], N, True)
+    assert not nil.any()
+    assert_scores_match(lag[sel], mv[sel], olag, omv, gap)
