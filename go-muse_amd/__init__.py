@@ -15,4 +15,5 @@ from . import dist  # noqa: F401
 from .muse import (Batch, DefaultLabel, DeviceBatch, DeviceGroup, Engine, Group, Labels, Muse, New,  # noqa: F401
                    NewBatch, NewGroup, NewLabels, NewResults, NewSeries, Results, Score, Series,
                    SignFilter_ANY, SignFilter_NEG, SignFilter_POS, get_engine, merge_records, next_pow2,
-                   RunMany, run_many, score_many, scores_many, xcorr_groups)
+                   RunMany, run_many, score_many, scores_many, xcorr_groups, device_count,
+                   merge_group_records)

@@ -43,6 +43,7 @@ SIGNATURES = {
     "muse_last_error": (ctypes.c_char_p, []),
     "muse_status_string": (ctypes.c_char_p, [ctypes.c_int]),
     "muse_ctx_create": (ctypes.c_int, [_i32, ctypes.POINTER(_vp)]),
+    "muse_device_count": (ctypes.c_int, [_i32p]),
     "muse_ctx_destroy": (ctypes.c_int, [_vp]),
     "muse_ctx_synchronize": (ctypes.c_int, [_vp]),
     "muse_ctx_device_info": (ctypes.c_int, [_vp, ctypes.c_char_p, _i32, _i32p, _i64p]),
@@ -68,6 +69,9 @@ SIGNATURES = {
                                       _i64p, _i32p, _dp, _i32p, _dp]),
     "muse_batch_run_shard": (ctypes.c_int, [_vp, _i32p, _i32, _i64, _i32, _i32, _f64, _i32, _i32,
                                             _recp, _i32p]),
+    "muse_batch_run_groups": (ctypes.c_int, [_vp, _i32p, _i32, _i64, _i32, _recp, ctypes.POINTER(ctypes.c_uint8)]),
+    "muse_merge_group_records": (ctypes.c_int, [_recp, ctypes.POINTER(ctypes.c_uint8), _i32, _i32, _i32, _i32, _f64, _i32,
+                                                _i64p, _i32p, _dp, _i32p, _dp]),
     "muse_merge_records": (ctypes.c_int, [_recp, _i64, _i32, _i64p, _i32p, _dp, _i32p, _dp]),
     "muse_batch_score_many": (ctypes.c_int, [ctypes.POINTER(_vp), _i32]),
     "muse_batch_read_scores": (ctypes.c_int, [_vp, _i32p, _dp]),

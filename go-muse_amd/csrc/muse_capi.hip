@@ -348,6 +348,29 @@ extern "C" int muse_ctx_create(int32_t device, muse_ctx **out)
     return MUSE_OK;
 }
 
+extern "C" int muse_device_count(int32_t *count)
+{
+    if (!count)
+        return fail(MUSE_ERR_INVALID, "count is NULL");
+    *count = 0;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(MUSE_ERR_NO_DEVICE, "no HIP device visible (this engine has no CPU fallback)");
+    }
+    int usable = 0;
+    for (int d = 0; d < n; d++) { // device ordinals are HIP's: count the leading run of gfx950 devices
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, d) != hipSuccess || strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            break;
+        usable++;
+    }
+    if (!usable)
+        return fail(MUSE_ERR_NO_DEVICE, "no gfx950 device visible");
+    *count = usable;
+    return MUSE_OK;
+}
+
 static void ctx_release(muse_ctx *ctx)
 {
     if (!ctx || ctx->refs.fetch_sub(1) != 1)
@@ -1849,6 +1872,100 @@ extern "C" int muse_batch_run_shard(muse_batch *b, const int32_t *group_id, int3
     for (size_t i = 0; i < sel.size(); i++)
         out_records[i] = sel[i];
     *out_count = (int32_t)sel.size();
+    return MUSE_OK;
+}
+
+// Sharded Run whose label groups may straddle shards ("... or the per-group partial maxima are merged before
+// top-N"): this shard's winner per label group, unfiltered, plus the group's state on this shard (SelectParams::partial)
+extern "C" int muse_batch_run_groups(muse_batch *b, const int32_t *group_id, int32_t G, int64_t series_offset,
+                                     int32_t abs_scores, muse_record *out_records, uint8_t *out_state)
+{
+    if (!b || !group_id || G < 0 || (G > 0 && (!out_records || !out_state)))
+        return fail(MUSE_ERR_INVALID, "bad arguments (label groups are required: ungrouped Runs shard with muse_batch_run_shard)");
+    muse_ctx *ctx = b->ctx;
+    b->last_path = MUSE_RUN_PATH_FP64;
+    b->last_screened = false;
+    int rc = muse_batch_score(b);
+    if (rc)
+        return rc;
+    const int64_t M = b->g->M;
+    for (int32_t g = 0; g < G; g++) {
+        out_records[g] = muse_record{-1, 0.0, 0, g};
+        out_state[g] = 0;
+    }
+    if (M == 0 || G == 0)
+        return MUSE_OK;
+    rc = ensure_select_ws(b, M, G, true, 1, false);
+    if (rc)
+        return rc;
+    rc = upload_group_ids(b, group_id, M);
+    if (rc)
+        return rc;
+    SelectParams sp{};
+    sp.mv = b->mv;
+    sp.lag = b->lag;
+    sp.M = M;
+    sp.group_id = b->gid_dev;
+    sp.G = G;
+    sp.abs_scores = abs_scores ? 1 : 0;
+    sp.series_offset = series_offset;
+    sp.partial = 1;
+    HIP_TRY(launch_group_reduce(sp, b->gw, b->rec, b->selkey, ctx->stream));
+    std::vector<unsigned long long> st((size_t)G);
+    HIP_TRY(hipMemcpyAsync(out_records, b->rec, (size_t)G * sizeof(muse_record), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(st.data(), b->selkey, (size_t)G * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int32_t g = 0; g < G; g++)
+        out_state[g] = (uint8_t)st[(size_t)g];
+    return MUSE_OK;
+}
+
+// results.go:46-52 on the host (the merge of shards filters AFTER the group maxima are final)
+static bool passed_host(double s, int32_t lag, int32_t max_lag, double threshold, int32_t sign_filter)
+{
+    return std::fabs((double)lag) <= (double)max_lag && std::fabs(s) >= threshold &&
+           (sign_filter == 0 || (s > 0 && sign_filter == 1) || (s < 0 && sign_filter == -1));
+}
+
+extern "C" int muse_merge_group_records(const muse_record *records, const uint8_t *state, int32_t n_shards, int32_t G,
+                                        int32_t max_lag, int32_t top_n, double threshold, int32_t sign_filter,
+                                        int64_t *out_series, int32_t *out_lag, double *out_score, int32_t *out_count,
+                                        double *out_mean_abs)
+{
+    if (n_shards < 0 || G < 0 || ((int64_t)n_shards * G > 0 && (!records || !state)))
+        return fail(MUSE_ERR_INVALID, "bad shard records");
+    if (sign_filter < -1 || sign_filter > 1)
+        return fail(MUSE_ERR_INVALID, "sign_filter must be -1, 0 or 1");
+    std::vector<muse_record> cands;
+    for (int32_t g = 0; g < G; g++) {
+        // shards are listed in ascending row order: the first one with a member holds the group's first member
+        bool seen = false, nan_first = false, have = false;
+        muse_record best{};
+        for (int32_t s = 0; s < n_shards; s++) {
+            const size_t k = (size_t)s * (size_t)G + (size_t)g;
+            if (state[k] == 0)
+                continue;
+            if (!seen) {
+                seen = true;
+                nan_first = state[k] == 2;
+            }
+            const muse_record &r = records[k];
+            if (r.series < 0)
+                continue;
+            // muse_batch.go:87 / muse.go:86: a later series replaces the maximum only if strictly greater (by |score|)
+            if (!have || std::fabs(r.score) > std::fabs(best.score)) {
+                best = r;
+                have = true;
+            }
+        }
+        if (!seen || nan_first || !have) // empty group, or its first member's score is NaN: never passes Results.passed
+            continue;
+        best.group = g;
+        if (passed_host(best.score, best.lag, max_lag, threshold, sign_filter))
+            cands.push_back(best);
+    }
+    std::vector<muse_record> sel = heap_select(std::move(cands), top_n);
+    emit(sel, out_series, out_lag, out_score, out_count, out_mean_abs);
     return MUSE_OK;
 }
 

@@ -99,6 +99,21 @@ __global__ void group_final_kernel(SelectParams sp, GroupWork gw, muse_record *r
             }
             w = gw.win[g];
             const double vf = clamp_score(sp.mv[f], sp.abs_scores);
+            if (sp.partial) { // one shard of the group: the merge over shards decides (muse_merge_group_records)
+                selkey[g] = vf != vf ? 2ull : 1ull;
+                if (w == IDX_NONE) {
+                    rec[g].series = -1;
+                    rec[g].score = 0.0;
+                    rec[g].lag = 0;
+                    rec[g].group = g;
+                } else {
+                    rec[g].series = w + sp.series_offset;
+                    rec[g].score = clamp_score(sp.mv[w], sp.abs_scores);
+                    rec[g].lag = sp.lag[w];
+                    rec[g].group = g;
+                }
+                continue;
+            }
             if (w == IDX_NONE || vf != vf) // first member NaN is never replaced (x > NaN is false)
                 w = f;
         } else {

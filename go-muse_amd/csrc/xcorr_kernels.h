@@ -139,6 +139,12 @@ struct SelectParams {
     int sign_filter;
     long long series_offset;
     const unsigned char *include; // optional: rows that may be selected (filter-and-refine Run); nullptr = all
+    // 1: this device holds ONE SHARD of a group whose label groups may continue on other shards (muse_batch_run_groups):
+    // rec[g] = the winner among the shard's members whose score is a number (series -1 if there is none), nothing is
+    // filtered, and selkey[g] = the group's state on this shard: 0 no member, 1 members and the first one's score is a
+    // number, 2 the first member's score is NaN (if it is the group's first member overall the group's score is NaN:
+    // x > NaN never replaces it, muse_batch.go:87)
+    int partial;
 };
 
 // filter-and-refine Run: what the screening pass left per row, the Run's filters and the error bound of the estimate

@@ -62,6 +62,69 @@ func getEngine() (*engine, error) {
 	return defaultEngine, defaultEngineErr
 }
 
+// The device set a Batch shards its Comparison group over (SURVEY 8e: the goroutine fan-out of
+// muse_batch.go:99-130 becomes one goroutine per GPU, each driving its own muse_ctx).  Default: device 0 only.
+var (
+	engineSet   []*engine
+	engineSetMu sync.Mutex
+)
+
+// SetDevices selects the GPUs every later Batch.Run shards over (one muse_ctx per listed device; a device may be
+// listed more than once).  SetDevices(nil) goes back to the single default engine.  DeviceCount() tells how many
+// the process can see; SetDevices(AllDevices()) is the eight-GPU configuration of one node.
+func SetDevices(ids []int) error {
+	engineSetMu.Lock()
+	defer engineSetMu.Unlock()
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	var set []*engine
+	for _, id := range ids {
+		e := &engine{}
+		if err := hipError(C.muse_ctx_create(C.int32_t(id), &e.ctx)); err != nil {
+			for _, d := range set {
+				C.muse_ctx_destroy(d.ctx)
+			}
+			return err
+		}
+		set = append(set, e)
+	}
+	for _, d := range engineSet {
+		C.muse_ctx_destroy(d.ctx) // (reference-counted: lives until its last group / batch is freed)
+	}
+	engineSet = set
+	return nil
+}
+
+// DeviceCount returns the number of gfx950 devices visible to the process.
+func DeviceCount() (int, error) {
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	var n C.int32_t
+	if err := hipError(C.muse_device_count(&n)); err != nil {
+		return 0, err
+	}
+	return int(n), nil
+}
+
+// AllDevices lists every visible device once.
+func AllDevices() []int {
+	n, _ := DeviceCount()
+	ids := make([]int, n)
+	for i := range ids {
+		ids[i] = i
+	}
+	return ids
+}
+
+func shardEngines() []*engine {
+	engineSetMu.Lock()
+	defer engineSetMu.Unlock()
+	if len(engineSet) < 2 {
+		return nil
+	}
+	return append([]*engine(nil), engineSet...)
+}
+
 // SetScreening switches the filter-and-refine Run of the default engine (include/muse_hip.h:
 // muse_ctx_set_screening; OFF by default -- every series is scored in float64 like the reference --;
 // when on, Runs over large groups screen every series in fp32 and re-evaluate in fp64 only the rows that
@@ -115,6 +178,62 @@ func (g *Group) residentRows(e *engine) (*C.muse_group, error) {
 	return g.dev.g, nil
 }
 
+// groupShard is one contiguous row range of the Group on one device (the shard_bounds rule: equal shares rounded up to
+// an even row count -- the fused kernels pack two series per pass).  The cut is made once, at the first sharded Run;
+// series added later extend the last shard.  Group gains a third field: shards []*groupShard.
+type groupShard struct {
+	e                *engine
+	g                *C.muse_group
+	lo, hi, uploaded int
+}
+
+func (g *Group) residentShards(es []*engine) ([]*groupShard, error) {
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	same := len(g.shards) == len(es)
+	for i := 0; same && i < len(es); i++ {
+		same = g.shards[i].e == es[i]
+	}
+	if !same {
+		g.shards = nil // (the old shards' device groups are released by their finalizers)
+		M, W := len(g.order), len(es)
+		per := (M + W - 1) / W
+		per = (per + 1) / 2 * 2
+		n := g.n
+		if n < 1 {
+			n = 1
+		}
+		for r := 0; r < W; r++ {
+			sh := &groupShard{e: es[r]}
+			sh.lo = r * per
+			if sh.lo > M {
+				sh.lo = M
+			}
+			sh.hi = sh.lo + per
+			if sh.hi > M {
+				sh.hi = M
+			}
+			if err := hipError(C.muse_group_create(es[r].ctx, C.int64_t(sh.hi-sh.lo), C.int32_t(n), &sh.g)); err != nil {
+				return nil, err
+			}
+			runtime.SetFinalizer(sh, func(sh *groupShard) { C.muse_group_free(sh.g) })
+			g.shards = append(g.shards, sh)
+		}
+	}
+	if len(g.shards) > 0 {
+		g.shards[len(g.shards)-1].hi = len(g.order) // series added since the cut
+	}
+	for _, sh := range g.shards {
+		for ; sh.lo+sh.uploaded < sh.hi; sh.uploaded++ {
+			y := g.order[sh.lo+sh.uploaded].y
+			if err := hipError(C.muse_group_append(sh.g, (*C.double)(unsafe.Pointer(&y[0])), 1, C.int64_t(len(y)))); err != nil {
+				return nil, err
+			}
+		}
+	}
+	return g.shards, nil
+}
+
 // Batch keeps the exported fields of muse_batch.go:13-19; x and n are gone
 // (the reference spectrum lives on the device).
 type Batch struct {
@@ -124,6 +243,8 @@ type Batch struct {
 	Concurrency int
 	batch       *C.muse_batch
 	batchGroup  *C.muse_group
+	shardBatch  []*C.muse_batch // sharded Runs (SetDevices): one device batch per shard
+	shardGroup  []*C.muse_group
 }
 
 // NewBatch replaces muse_batch.go:23-52: same length check, same
@@ -162,6 +283,12 @@ func NewBatch(ref *Series, comp *Group, results *Results, cc int) (*Batch, error
 			C.muse_batch_free(b.batch)
 			b.batch = nil
 		}
+		for _, sb := range b.shardBatch {
+			if sb != nil {
+				C.muse_batch_free(sb)
+			}
+		}
+		b.shardBatch = nil
 	})
 	return b, nil
 }
@@ -173,14 +300,6 @@ func (b *Batch) Run(groupByLabels []string) error {
 	labelValuesSet := b.Comparison.indexLabelValues(groupByLabels)
 	if len(labelValuesSet) == 0 {
 		return nil
-	}
-	e, err := getEngine()
-	if err != nil {
-		return err
-	}
-	dg, err := b.Comparison.residentRows(e)
-	if err != nil {
-		return err
 	}
 	// group id of every series, in upload order
 	pos := make(map[string]int, len(b.Comparison.order))
@@ -194,6 +313,17 @@ func (b *Batch) Run(groupByLabels []string) error {
 			gid[pos[uid]] = C.int32_t(gi)
 		}
 		gi++
+	}
+	if es := shardEngines(); es != nil {
+		return b.runSharded(es, gid, len(labelValuesSet))
+	}
+	e, err := getEngine()
+	if err != nil {
+		return err
+	}
+	dg, err := b.Comparison.residentRows(e)
+	if err != nil {
+		return err
 	}
 	runtime.LockOSThread()
 	defer runtime.UnlockOSThread()
@@ -224,6 +354,147 @@ func (b *Batch) Run(groupByLabels []string) error {
 	}
 	// ordered drain (muse_batch.go:124-128): feed Results in group order
 	order := make([]int, int(cnt))
+	for i := range order {
+		order[i] = i
+	}
+	sort.SliceStable(order, func(a, c int) bool { return gid[idx[order[a]]] < gid[idx[order[c]]] })
+	for _, k := range order {
+		b.Results.Update(Score{Labels: b.Comparison.order[idx[k]].Labels(), Lag: int(lag[k]), PercentScore: float64(score[k])})
+	}
+	return nil
+}
+
+// runSharded is Run over several GPUs (SetDevices).  The Comparison group is cut into one contiguous row range per device
+// and every shard is scored at the same time, one goroutine per device.  Label groups that live on ONE shard each
+// (always true when every series is its own group): each shard returns its top-N candidates (muse_batch_run_shard,
+// 24 B x TopN per device) and muse_merge_records selects.  Label groups that straddle shards: each shard returns its
+// winner per group, unfiltered (muse_batch_run_groups), and muse_merge_group_records takes the per-group maximum BEFORE
+// Results.passed and the top-N heap -- what SURVEY 8e requires for exactness.
+func (b *Batch) runSharded(es []*engine, gid []C.int32_t, G int) error {
+	shards, err := b.Comparison.residentShards(es)
+	if err != nil {
+		return err
+	}
+	W := len(shards)
+	if len(b.shardBatch) != W {
+		for _, sb := range b.shardBatch {
+			if sb != nil {
+				C.muse_batch_free(sb)
+			}
+		}
+		b.shardBatch = make([]*C.muse_batch, W)
+		b.shardGroup = make([]*C.muse_group, W)
+	}
+	{
+		runtime.LockOSThread()
+		for r, sh := range shards {
+			if b.shardBatch[r] == nil || b.shardGroup[r] != sh.g {
+				if b.shardBatch[r] != nil {
+					C.muse_batch_free(b.shardBatch[r])
+					b.shardBatch[r] = nil
+				}
+				st := C.muse_batch_create(sh.e.ctx, sh.g, (*C.double)(unsafe.Pointer(&b.ref[0])), C.int32_t(len(b.ref)), &b.shardBatch[r])
+				if err := hipError(st); err != nil {
+					runtime.UnlockOSThread()
+					return err
+				}
+				b.shardGroup[r] = sh.g
+			}
+		}
+		runtime.UnlockOSThread()
+	}
+	// does any label group have members on two shards?
+	straddle := false
+	owner := make([]int, G)
+	for i := range owner {
+		owner[i] = -1
+	}
+	for r, sh := range shards {
+		for i := sh.lo; i < sh.hi && !straddle; i++ {
+			o := owner[gid[i]]
+			if o >= 0 && o != r {
+				straddle = true
+			}
+			owner[gid[i]] = r
+		}
+	}
+	res := b.Results
+	top := res.TopN
+	capN := top
+	if capN < 1 {
+		capN = 1
+	}
+	per := capN
+	if straddle {
+		per = G
+	}
+	// C memory for what the devices write concurrently (muse_record is a plain 24-byte struct)
+	recs := (*C.muse_record)(C.calloc(C.size_t(W*per), C.size_t(unsafe.Sizeof(C.muse_record{}))))
+	defer C.free(unsafe.Pointer(recs))
+	recv := unsafe.Slice(recs, W*per)
+	var state *C.uint8_t
+	if straddle {
+		state = (*C.uint8_t)(C.calloc(C.size_t(W*G), 1))
+		defer C.free(unsafe.Pointer(state))
+	}
+	cnt := make([]C.int32_t, W)
+	errs := make([]error, W)
+	var wg sync.WaitGroup
+	for r, sh := range shards {
+		if sh.lo == sh.hi {
+			continue // an empty shard (fewer rows than devices)
+		}
+		wg.Add(1)
+		go func(r int, sh *groupShard) {
+			defer wg.Done()
+			runtime.LockOSThread() // the cgo call and the muse_last_error that explains it: one OS thread
+			defer runtime.UnlockOSThread()
+			g := &gid[sh.lo]
+			var st C.int
+			if straddle {
+				st = C.muse_batch_run_groups(b.shardBatch[r], g, C.int32_t(G), C.int64_t(sh.lo), 1, &recv[r*per],
+					(*C.uint8_t)(unsafe.Add(unsafe.Pointer(state), r*G)))
+			} else {
+				st = C.muse_batch_run_shard(b.shardBatch[r], g, C.int32_t(G), C.int64_t(sh.lo), C.int32_t(res.MaxLag),
+					C.int32_t(top), C.double(res.Threshold), C.int32_t(res.SignFilter), 1, &recv[r*per], &cnt[r])
+			}
+			errs[r] = hipError(st)
+		}(r, sh)
+	}
+	wg.Wait()
+	for _, e := range errs {
+		if e != nil {
+			return e
+		}
+	}
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	idx := make([]C.int64_t, capN)
+	lag := make([]C.int32_t, capN)
+	score := make([]C.double, capN)
+	var n C.int32_t
+	var mean C.double
+	if straddle {
+		st := C.muse_merge_group_records(recs, state, C.int32_t(W), C.int32_t(G), C.int32_t(res.MaxLag), C.int32_t(top),
+			C.double(res.Threshold), C.int32_t(res.SignFilter), &idx[0], &lag[0], &score[0], &n, &mean)
+		if err := hipError(st); err != nil {
+			return err
+		}
+	} else {
+		// compact the shards' candidate lists (count[r] of capN each) in place, then merge
+		k := 0
+		for r := 0; r < W; r++ {
+			for i := 0; i < int(cnt[r]); i++ {
+				recv[k] = recv[r*per+i]
+				k++
+			}
+		}
+		st := C.muse_merge_records(recs, C.int64_t(k), C.int32_t(top), &idx[0], &lag[0], &score[0], &n, &mean)
+		if err := hipError(st); err != nil {
+			return err
+		}
+	}
+	order := make([]int, int(n))
 	for i := range order {
 		order[i] = i
 	}

@@ -26,6 +26,7 @@
 #include <random>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -131,6 +132,16 @@ public:
         static std::shared_ptr<Engine> e = std::make_shared<Engine>(0);
         return e;
     }
+    // One engine (context, stream, tables) per listed device: the device set a Batch shards its Comparison group over
+    // (the goroutine fan-out of muse_batch.go:99-130 becomes one host thread per device).  A device may be
+    // listed more than once (several contexts on one GPU: what the tests on a one-GPU box do).
+    static std::vector<std::shared_ptr<Engine>> List(const std::vector<int> &devices)
+    {
+        std::vector<std::shared_ptr<Engine>> out;
+        for (int d : devices)
+            out.push_back(std::make_shared<Engine>(d));
+        return out;
+    }
 
 private:
     muse_ctx *ctx_ = nullptr;
@@ -144,6 +155,7 @@ public:
     {
         if (dev_)
             muse_group_free(dev_);
+        free_shards();
     }
     std::string Name;
     int Length() const { return n_; }
@@ -214,6 +226,41 @@ public:
     }
     const std::vector<SeriesPtr> &series() const { return order_; }
 
+    // One contiguous row range per engine (the shard_bounds rule of go-muse_amd/dist.py: equal shares rounded up to an even
+    // row count, the fused kernels pack two series per pass).  Cut once, at the first sharded Run; series added later
+    // extend the last shard.
+    struct Shard {
+        std::shared_ptr<Engine> eng;
+        muse_group *dev = nullptr;
+        size_t lo = 0, hi = 0, uploaded = 0; // rows [lo, hi) of the group; `uploaded` of them are resident
+    };
+    std::vector<Shard> &shards(const std::vector<std::shared_ptr<Engine>> &engs)
+    {
+        bool same = shards_.size() == engs.size();
+        for (size_t i = 0; same && i < engs.size(); i++)
+            same = shards_[i].eng == engs[i];
+        if (!same) {
+            free_shards();
+            const size_t M = order_.size(), W = engs.size();
+            size_t per = (M + W - 1) / W;
+            per = (per + 1) / 2 * 2;
+            for (size_t r = 0; r < W; r++) {
+                Shard sh;
+                sh.eng = engs[r];
+                sh.lo = std::min(r * per, M);
+                sh.hi = std::min(sh.lo + per, M);
+                check(muse_group_create(engs[r]->handle(), (int64_t)(sh.hi - sh.lo), n_ > 0 ? n_ : 1, &sh.dev));
+                shards_.push_back(sh);
+            }
+        }
+        if (!shards_.empty())
+            shards_.back().hi = order_.size(); // series added since the cut
+        for (auto &sh : shards_)
+            for (; sh.lo + sh.uploaded < sh.hi; sh.uploaded++)
+                check(muse_group_append(sh.dev, order_[sh.lo + sh.uploaded]->Values().data(), 1, n_));
+        return shards_;
+    }
+
     // device residency: rows are uploaded once and appended to (muse_group_append)
     muse_group *device(const std::shared_ptr<Engine> &eng)
     {
@@ -231,6 +278,13 @@ public:
     }
 
 private:
+    void free_shards()
+    {
+        for (auto &sh : shards_)
+            if (sh.dev)
+                muse_group_free(sh.dev);
+        shards_.clear();
+    }
     int n_ = 0;
     std::vector<SeriesPtr> order_;
     std::unordered_map<std::string, size_t> registry_;
@@ -238,6 +292,7 @@ private:
     std::shared_ptr<Engine> eng_;
     muse_group *dev_ = nullptr;
     size_t uploaded_ = 0;
+    std::vector<Shard> shards_;
 };
 using GroupPtr = std::shared_ptr<Group>;
 inline GroupPtr NewGroup(std::string name) { return std::make_shared<Group>(std::move(name)); }
@@ -353,6 +408,14 @@ class Batch {
 public:
     // NewBatch (muse_batch.go:23-52): length check against every series of the group,
     // reference spectrum computed right away ("Invalid input query" on sigma == 0).
+    // Over several devices: the Comparison group is cut into one contiguous row range per engine, every Run
+    // scores the shards at the same time (one host thread per device) and merges their candidates on the host.
+    Batch(SeriesPtr ref, GroupPtr comp, ResultsPtr results, int cc, std::vector<std::shared_ptr<Engine>> engines)
+        : Batch(ref, comp, results, cc, engines.empty() ? Engine::Default() : engines[0])
+    {
+        if (engines.size() > 1)
+            engines_ = std::move(engines);
+    }
     Batch(SeriesPtr ref, GroupPtr comp, ResultsPtr results, int cc, std::shared_ptr<Engine> eng = Engine::Default())
         : Comparison(std::move(comp)), Results_(std::move(results)), Concurrency(cc < 1 ? 1 : cc), eng_(std::move(eng)),
           ref_(ref->Values())
@@ -372,7 +435,12 @@ public:
         if (rc)
             throw Error(rc, msg);
     }
-    ~Batch() { muse_batch_free(batch_); }
+    ~Batch()
+    {
+        muse_batch_free(batch_);
+        for (auto &sb : shard_batches_)
+            muse_batch_free(sb.batch);
+    }
     int n = 0;
     GroupPtr Comparison;
     ResultsPtr Results_;
@@ -385,6 +453,10 @@ public:
         auto lvs = Comparison->indexLabelValues(groupByLabels, &gid);
         if (lvs.empty())
             return;
+        if (!engines_.empty()) {
+            run_sharded(gid, (int32_t)lvs.size());
+            return;
+        }
         muse_group *dg = Comparison->device(eng_);
         ensure(dg);
         const int cap = std::max(Results_->TopN, 1);
@@ -455,6 +527,96 @@ public:
     }
 
 private:
+    // The sharded Run.  Label groups that live on ONE shard each (always the case when every series is its own group):
+    // each shard returns its top-N candidates (muse_batch_run_shard) and muse_merge_records selects -- 24 B x TopN per
+    // device cross the host.  Label groups that straddle shards: each shard returns its winner per group, unfiltered
+    // (muse_batch_run_groups), and muse_merge_group_records takes the per-group maximum BEFORE filtering and selecting.
+    void run_sharded(const std::vector<int32_t> &gid, int32_t G)
+    {
+        auto &shards = Comparison->shards(engines_);
+        const size_t W = shards.size();
+        if (shard_batches_.size() != W)
+            shard_batches_.resize(W);
+        for (size_t r = 0; r < W; r++) {
+            auto &sb = shard_batches_[r];
+            if (!sb.batch || sb.group != shards[r].dev) {
+                muse_batch_free(sb.batch);
+                sb.batch = nullptr;
+                check(muse_batch_create(shards[r].eng->handle(), shards[r].dev, ref_.data(), (int32_t)ref_.size(), &sb.batch));
+                sb.group = shards[r].dev;
+            }
+        }
+        // does any label group have members on two shards?
+        bool straddle = false;
+        {
+            std::vector<int32_t> owner((size_t)G, -1);
+            for (size_t r = 0; r < W && !straddle; r++)
+                for (size_t i = shards[r].lo; i < shards[r].hi; i++) {
+                    int32_t &o = owner[(size_t)gid[i]];
+                    if (o >= 0 && o != (int32_t)r) {
+                        straddle = true;
+                        break;
+                    }
+                    o = (int32_t)r;
+                }
+        }
+        const int top = Results_->TopN, cap = std::max(top, 1);
+        std::vector<muse_record> recs(straddle ? W * (size_t)G : W * (size_t)cap);
+        std::vector<uint8_t> state(straddle ? W * (size_t)G : 0);
+        std::vector<int32_t> cnt(W, 0);
+        std::vector<int> status(W, MUSE_OK);
+        std::vector<std::string> message(W);
+        std::vector<std::thread> workers;
+        for (size_t r = 0; r < W; r++) {
+            if (shards[r].lo == shards[r].hi)
+                continue; // an empty shard (fewer rows than devices)
+            workers.emplace_back([&, r]() {
+                const int32_t *g = gid.data() + shards[r].lo;
+                int rc;
+                if (straddle)
+                    rc = muse_batch_run_groups(shard_batches_[r].batch, g, G, (int64_t)shards[r].lo, 1,
+                                               recs.data() + r * (size_t)G, state.data() + r * (size_t)G);
+                else
+                    rc = muse_batch_run_shard(shard_batches_[r].batch, g, G, (int64_t)shards[r].lo, Results_->MaxLag, top,
+                                              Results_->Threshold, (int32_t)Results_->Filter, 1, recs.data() + r * (size_t)cap,
+                                              &cnt[r]);
+                status[r] = rc;
+                if (rc)
+                    message[r] = muse_last_error(); // (thread-local: read it on the thread that failed)
+            });
+        }
+        for (auto &w : workers)
+            w.join();
+        for (size_t r = 0; r < W; r++)
+            if (status[r])
+                throw Error(status[r], message[r]);
+        std::vector<int64_t> idx(cap);
+        std::vector<int32_t> lag(cap);
+        std::vector<double> score(cap);
+        int32_t n_out = 0;
+        double mean = 0;
+        if (straddle) {
+            check(muse_merge_group_records(recs.data(), state.data(), (int32_t)W, G, Results_->MaxLag, top, Results_->Threshold,
+                                           (int32_t)Results_->Filter, idx.data(), lag.data(), score.data(), &n_out, &mean));
+        } else {
+            std::vector<muse_record> all;
+            for (size_t r = 0; r < W; r++)
+                all.insert(all.end(), recs.begin() + r * (size_t)cap, recs.begin() + r * (size_t)cap + cnt[r]);
+            check(muse_merge_records(all.data(), (int64_t)all.size(), top, idx.data(), lag.data(), score.data(), &n_out, &mean));
+        }
+        std::vector<int> order(n_out);
+        for (int i = 0; i < n_out; i++)
+            order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return gid[idx[a]] < gid[idx[b]]; });
+        for (int k : order)
+            Results_->Update(Score{Comparison->series()[idx[k]]->Labels(), lag[k], score[k]});
+    }
+    struct ShardBatch {
+        muse_batch *batch = nullptr;
+        muse_group *group = nullptr;
+    };
+    std::vector<std::shared_ptr<Engine>> engines_; // more than one device: the sharded Run
+    std::vector<ShardBatch> shard_batches_;
     void ensure(muse_group *dg)
     {
         if (!batch_ || batch_group_ != dg) {
@@ -472,6 +634,12 @@ private:
 inline std::shared_ptr<Batch> NewBatch(SeriesPtr ref, GroupPtr comp, ResultsPtr results, int cc)
 {
     return std::make_shared<Batch>(std::move(ref), std::move(comp), std::move(results), cc);
+}
+// the same over a set of devices (Engine::List): one shard of the Comparison group per device
+inline std::shared_ptr<Batch> NewBatch(SeriesPtr ref, GroupPtr comp, ResultsPtr results, int cc,
+                                       std::vector<std::shared_ptr<Engine>> engines)
+{
+    return std::make_shared<Batch>(std::move(ref), std::move(comp), std::move(results), cc, std::move(engines));
 }
 
 // ----------------------------------------------------------------- muse.go

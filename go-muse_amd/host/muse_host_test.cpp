@@ -280,6 +280,161 @@ static void TestFirstUseConcurrent()
     }
 }
 
+
+// ---- the Comparison group sharded over a list of devices behind the same NewBatch / Run (muse_batch.go:99-130).
+// On a one-GPU box the list names device 0 several times: distinct contexts, distinct shards, the same code path.
+static void sameScores(const std::pair<Scores, double> &a, const std::pair<Scores, double> &b, const char *name)
+{
+    EXPECT(a.first.size() == b.first.size(), "%s: %zu vs %zu scores", name, a.first.size(), b.first.size());
+    for (size_t i = 0; i < a.first.size() && i < b.first.size(); i++) {
+        EXPECT(a.first[i].Lag == b.first[i].Lag && a.first[i].Labels->ID() == b.first[i].Labels->ID(), "%s[%zu]: lag %d vs %d, labels %s vs %s", name,
+               i, a.first[i].Lag, b.first[i].Lag, a.first[i].Labels->ID().c_str(), b.first[i].Labels->ID().c_str());
+        EXPECT(a.first[i].PercentScore == b.first[i].PercentScore, "%s[%zu]: score %.17g vs %.17g", name, i, a.first[i].PercentScore,
+               b.first[i].PercentScore);
+    }
+    EXPECT(a.second == b.second || (std::isnan(a.second) && std::isnan(b.second)), "%s: mean %.17g vs %.17g", name, a.second, b.second);
+}
+
+static void TestBatchRunShardedTables() // the reference's two Batch tables, three shards
+{
+    auto engines = Engine::List({0, 0, 0});
+    {
+        auto ref = NewSeries(REF12, NewLabels({{"graph", "graph1"}}));
+        auto g = NewGroup("targets");
+        g->Add({NewSeries({0, 0, 0, 0, 2, 4, 6, 6, 4, 2, 0, 0}, NewLabels({{"graph", "perfectMatch"}})),
+                NewSeries({0, 0, 0, 0, 2, 4, 6, 4, 2, 0, 0, 0}, NewLabels({{"graph", "slightlyLower"}})),
+                NewSeries({0, 0, 0, 2, 4, 2, 0, 0, 0, 0, 0, 0}, NewLabels({{"graph", "evenLower"}})),
+                NewSeries({0, 0, 0, 0, 0, 0, 0, 0, 2, 3, 2, 0}, NewLabels({{"graph", "evenLowerShiftedAhead"}})),
+                NewSeries(std::vector<double>(12, 3.0), NewLabels({{"graph", "zeros"}}))});
+        auto b = NewBatch(ref, g, NewResults(10, 20, 0, SignFilter_ANY), 10, engines);
+        b->Run({"graph"});
+        compareScores(b->Results_->Fetch().first,
+                      {{{{"graph", "perfectMatch"}}, {0}, 1.000},
+                       {{{"graph", "slightlyLower"}}, {0}, 0.929},
+                       {{{"graph", "evenLowerShiftedAhead"}}, {-3, -2}, 0.754},
+                       {{{"graph", "evenLower"}}, {2}, 0.733},
+                       {{{"graph", "zeros"}}, {0}, 0.0}},
+                      "TestBatchRunSimple over 3 shards");
+    }
+    {
+        auto ref = NewSeries({0.0, 0.0, 0.0, 0.0, 0.1, 0.2, 0.3, 0.4}, NewLabels({{"graph", "graph1"}}));
+        auto L = [](const char *g, const char *h) { return NewLabels({{"graph", g}, {"host", h}}); };
+        auto grp = NewGroup("targets");
+        // (graph1's two hosts sit in different shards of two rows each: the straddling-group merge)
+        grp->Add({NewSeries({0.2, 0.1, 0.2, 0.1, 0.2, 0.1, 0.2, 0.1}, L("graph1", "host2")),
+                  NewSeries({0.0, 0.0, 0.0, 0.0, 0.2, 0.4, 0.4, 0.8}, L("graph2", "host1")),
+                  NewSeries({0.2, 0.1, 0.2, 0.1, 0.2, 0.1, 0.22, 0.1}, L("graph3", "host1")),
+                  NewSeries({0.0, 0.0, 0.0, 0.0, 0.1, 0.2, 0.3, 0.4}, L("graph1", "host1")),
+                  NewSeries({0.0, 0.0, 0.0, 0.0, -0.2, -0.4, 0.0, -0.8}, L("graph4", "host1")),
+                  NewSeries({0.0, 0.0, 0.0, -0.2, -0.4, -0.6, 1.0, 0.0}, L("graph5", "host1"))});
+        auto m = NewBatch(ref, grp, NewResults(10, 20, 0, SignFilter_ANY), 10, engines);
+        m->Run({"graph"});
+        compareScores(m->Results_->Fetch().first,
+                      {{{{"graph", "graph1"}, {"host", "host1"}}, {0}, 1.000},
+                       {{{"graph", "graph2"}, {"host", "host1"}}, {0}, 0.976},
+                       {{{"graph", "graph4"}, {"host", "host1"}}, {0}, 0.759},
+                       {{{"graph", "graph5"}, {"host", "host1"}}, {2}, 0.719},
+                       {{{"graph", "graph3"}, {"host", "host1"}}, {1}, 0.248}},
+                      "TestBatchRunMultiDimensional over 3 shards (straddling group)");
+    }
+}
+
+// 1 003 series of 480 samples, 37 graphs x 28 hosts interleaved (every graph straddles every shard), a NaN series first in
+// one graph and a constant one elsewhere: Run(nil), Run(["graph"]), Run(["host"]) and filtered Runs over 2, 3 and
+// (devices visible) shards must return exactly what the one-device Run returns
+static void TestBatchRunShardedEqualsUnsharded()
+{
+    const int N = 480, M = 1003;
+    auto mk = [&](int seed, int shift, double amp) {
+        std::vector<double> v(N);
+        unsigned long long h = 0x9E3779B97F4A7C15ull * (unsigned long long)(seed + 1);
+        for (int i = 0; i < N; i++) {
+            h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+            v[i] = 0.2 * ((double)(h >> 11) * (1.0 / 9007199254740992.0) - 0.5) + ((i + shift) % N >= 200 && (i + shift) % N < 215 ? amp : 0.0);
+        }
+        return v;
+    };
+    auto ref = NewSeries(mk(0, 0, 1.5), NewLabels({{"graph", "ref"}}));
+    auto build = [&]() {
+        auto g = NewGroup("targets");
+        for (int i = 0; i < M; i++) {
+            auto v = mk(1 + i, (i * 7) % 60 - 30, (i % 3 == 0 ? -1.0 : 1.0) * (0.5 + (i % 11)));
+            if (i == 5)
+                v[100] = std::nan(""); // the FIRST member of graph g5: its group's score is NaN whatever follows (muse_batch.go:87)
+            if (i == 8 + 37 * 20)
+                v[7] = std::nan(""); // a LATER member of graph g8, in another shard: skipped, the group keeps its maximum
+            if (i == 11)
+                std::fill(v.begin(), v.end(), 2.5); // sigma == 0: score 0
+            g->Add({NewSeries(v, NewLabels({{"graph", "g" + std::to_string(i % 37)}, {"host", "h" + std::to_string(i / 37)}}))});
+        }
+        return g;
+    };
+    std::vector<std::vector<int>> device_lists = {{0, 0}, {0, 0, 0}, {0, 0, 0, 0, 0}};
+    struct Case { std::vector<std::string> by; int maxLag, topN; double thr; SignFilter sf; };
+    const std::vector<Case> cases = {{{}, N, 20, 0.0, SignFilter_ANY},          {{"graph"}, N, 20, 0.0, SignFilter_ANY},
+                                     {{"host"}, N, 7, 0.0, SignFilter_ANY},     {{"graph"}, 12, 10, 0.3, SignFilter_POS},
+                                     {{"graph", "host"}, 25, 2000, 0.0, SignFilter_ANY}};
+    for (auto &devs : device_lists) {
+        auto engines = Engine::List(devs);
+        auto g1 = build(), gs = build();
+        for (size_t c = 0; c < cases.size(); c++) {
+            auto one = NewBatch(ref, g1, NewResults(cases[c].maxLag, cases[c].topN, cases[c].thr, cases[c].sf), 8);
+            auto sh = NewBatch(ref, gs, NewResults(cases[c].maxLag, cases[c].topN, cases[c].thr, cases[c].sf), 8, engines);
+            one->Run(cases[c].by);
+            sh->Run(cases[c].by);
+            char name[96];
+            snprintf(name, sizeof(name), "sharded x%zu, case %zu", devs.size(), c);
+            auto a = one->Results_->Fetch(), b = sh->Results_->Fetch();
+            EXPECT(!a.first.empty(), "%s: empty result", name);
+            sameScores(a, b, name);
+        }
+        // series added after the cut extend the last shard
+        auto extra = mk(9999, 3, 4.0);
+        g1->Add({NewSeries(extra, NewLabels({{"graph", "g3"}, {"host", "late"}}))});
+        gs->Add({NewSeries(extra, NewLabels({{"graph", "g3"}, {"host", "late"}}))});
+        auto one = NewBatch(ref, g1, NewResults(N, 5, 0, SignFilter_ANY), 8);
+        auto sh = NewBatch(ref, gs, NewResults(N, 5, 0, SignFilter_ANY), 8, engines);
+        one->Run({"graph"});
+        sh->Run({"graph"});
+        sameScores(one->Results_->Fetch(), sh->Results_->Fetch(), "sharded, series added after the cut");
+    }
+}
+
+// every device the process can see, one shard each (on a one-GPU box this is the single-engine path through the list API)
+static void TestBatchRunAllVisibleDevices()
+{
+    int ndev = 0;
+    for (; ndev < 64; ndev++) {
+        muse_ctx *c = nullptr;
+        if (muse_ctx_create(ndev, &c) != MUSE_OK)
+            break;
+        muse_ctx_destroy(c);
+    }
+    EXPECT(ndev >= 1, "no device");
+    std::vector<int> devs;
+    for (int d = 0; d < ndev; d++)
+        devs.push_back(d);
+    auto engines = Engine::List(devs);
+    const int N = 4096, M = 300;
+    auto g = NewGroup("targets");
+    std::vector<double> refv(N);
+    for (int i = 0; i < N; i++)
+        refv[i] = std::sin(0.01 * i) + (i >= 2000 && i < 2010 ? 1.5 : 0.0);
+    for (int i = 0; i < M; i++) {
+        std::vector<double> v(N);
+        for (int k = 0; k < N; k++)
+            v[k] = refv[(k + 3 * i) % N] * (1.0 + 0.01 * i) + 1e-3 * ((k * 2654435761u + i) % 1013);
+        g->Add({NewSeries(v, NewLabels({{"graph", "g" + std::to_string(i % 10)}, {"host", "h" + std::to_string(i)}}))});
+    }
+    auto ref = NewSeries(refv, NewLabels({{"graph", "ref"}}));
+    auto one = NewBatch(ref, g, NewResults(N, 10, 0, SignFilter_ANY), 8);
+    auto all = NewBatch(ref, g, NewResults(N, 10, 0, SignFilter_ANY), 8, engines);
+    one->Run({"graph"});
+    all->Run({"graph"});
+    sameScores(one->Results_->Fetch(), all->Results_->Fetch(), "all visible devices");
+    printf("sharded Run over %d visible device(s)\n", ndev);
+}
+
 int main()
 {
     try {
@@ -292,6 +447,9 @@ int main()
         TestRunNoInput();
         TestRunManyEqualsRuns();
         TestRunConcurrentCallers();
+        TestBatchRunShardedTables();
+        TestBatchRunShardedEqualsUnsharded();
+        TestBatchRunAllVisibleDevices();
     } catch (const Error &e) {
         printf("muse::Error %d: %s\n", e.status, e.what());
         return 2;

@@ -322,6 +322,15 @@ class DeviceBatch:
             B.recptr(rec), ctypes.byref(cnt)))
         return rec[:cnt.value].copy()
 
+    def run_groups(self, group_id, G, series_offset=0, abs_scores=True):
+        """this shard's winner per label group, unfiltered (muse_batch_run_groups): (records[G], state[G])"""
+        rec = np.zeros(max(int(G), 1), dtype=B.RECORD_DTYPE)
+        state = np.zeros(max(int(G), 1), dtype=np.uint8)
+        gid = np.ascontiguousarray(group_id, dtype=np.int32)
+        B.check(B.load().muse_batch_run_groups(self._h, B.i32ptr(gid), int(G), int(series_offset), 1 if abs_scores else 0,
+                                               B.recptr(rec), state.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))))
+        return rec[:int(G)], state[:int(G)]
+
     def close(self):
         if self._h:
             B.load().muse_batch_free(self._h)
@@ -391,6 +400,27 @@ def run_many(batches, group_id=None, G=0, max_lag=10, top_n=20, threshold=0.0, s
         res.append((o_s[r * tn:r * tn + c].copy(), o_l[r * tn:r * tn + c].copy(), o_v[r * tn:r * tn + c].copy(),
                     float(mean[r])))
     return res
+
+
+def device_count():
+    n = ctypes.c_int32(0)
+    B.check(B.load().muse_device_count(ctypes.byref(n)))
+    return int(n.value)
+
+
+def merge_group_records(records, state, max_lag, top_n, threshold, sign_filter):
+    """muse_merge_group_records: records / state are (n_shards, G) arrays, shards in ascending row order"""
+    records = np.ascontiguousarray(records, dtype=B.RECORD_DTYPE)
+    state = np.ascontiguousarray(state, dtype=np.uint8)
+    W, G = records.shape
+    cap = max(int(top_n), 1)
+    o_s, o_l, o_v = np.zeros(cap, dtype=np.int64), np.zeros(cap, dtype=np.int32), np.zeros(cap)
+    cnt, mean = ctypes.c_int32(0), ctypes.c_double(0)
+    B.check(B.load().muse_merge_group_records(B.recptr(records), state.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)), W, G,
+                                              int(max_lag), int(top_n), float(threshold), int(sign_filter),
+                                              B.i64ptr(o_s), B.i32ptr(o_l), B.dptr(o_v), ctypes.byref(cnt), ctypes.byref(mean)))
+    c = cnt.value
+    return o_s[:c].copy(), o_l[:c].copy(), o_v[:c].copy(), float(mean.value)
 
 
 def merge_records(records, top_n):
@@ -533,6 +563,28 @@ class Group:
         return dg
 
 
+    def _device_shards(self, engines):
+        """one contiguous row range per engine (dist.shard_bounds: equal shares rounded up to an even row count), cut once at
+        the first sharded Run; series added later extend the last shard.  Returns [(engine, DeviceGroup, lo, hi)]."""
+        from .dist import shard_bounds
+        ser = self._series_list()
+        sh = getattr(self, "_shards", None)
+        if sh is None or len(sh) != len(engines) or any(s[0] is not e for s, e in zip(sh, engines)):
+            sh = []
+            for r, e in enumerate(engines):
+                lo, hi = shard_bounds(len(ser), len(engines), r)
+                sh.append([e, DeviceGroup(e, self.n, hi - lo), lo, hi, 0])
+            self._shards = sh
+        if sh:
+            sh[-1][3] = len(ser)
+        for s in sh:
+            e, dg, lo, hi, done = s
+            if lo + done < hi:
+                dg.append(np.stack([x.y for x in ser[lo + done:hi]]))
+                s[4] = hi - lo
+        return [(s[0], s[1], s[2], s[3]) for s in sh]
+
+
 def NewGroup(name):
     return Group(name)
 
@@ -628,7 +680,7 @@ def NewResults(maxLag, topN, threshold, signFilter):
 
 # ----------------------------------------------------------- muse_batch.go
 class Batch:
-    def __init__(self, ref, comp, results, cc, engine=None):
+    def __init__(self, ref, comp, results, cc, engine=None, engines=None):
         # muse_batch.go:24-28 (length check over the registry)
         for uid, s in comp.registry.items():
             if ref.Length() != s.Length():
@@ -637,9 +689,13 @@ class Batch:
         self.Concurrency = max(int(cc), 1)       # kept for API compatibility; the GPU is the fan-out
         self.Comparison = comp
         self.Results = results
-        self._engine = engine or get_engine()
+        # engines: a list of Engine objects (one per device; a device may appear more than once) -- the Comparison group is
+        # then sharded over them and every Run scores the shards at the same time, one host thread per device
+        self._engines = list(engines) if engines and len(engines) > 1 else None
+        self._engine = engine or (engines[0] if engines else None) or get_engine()
         self._ref = np.array(ref.Values(), dtype=np.float64)
         self._db = None
+        self._shard_db = None
         self.n = next_pow2(float(ref.Length()))   # muse_batch.go:35
         # NewBatch computes the reference spectrum right away and returns
         # "Invalid input query" on sigma == 0 (muse_batch.go:38-41): probe it.
@@ -667,8 +723,11 @@ class Batch:
             for u in uids:
                 gid[uid_pos[u]] = g
         r = self.Results
-        idx, lag, score, _ = self._batch().run(gid, len(labelValuesSet), r.MaxLag, r.TopN, r.Threshold,
-                                               r.SignFilter, abs_scores=True)
+        if self._engines:
+            idx, lag, score = self._run_sharded(gid, len(labelValuesSet))
+        else:
+            idx, lag, score, _ = self._batch().run(gid, len(labelValuesSet), r.MaxLag, r.TopN, r.Threshold,
+                                                   r.SignFilter, abs_scores=True)
         # feed Results in group order, as the ordered drain does (muse_batch.go:124-128)
         order = np.argsort(gid[idx], kind="stable")
         for k in order:
@@ -676,8 +735,56 @@ class Batch:
         return None
 
 
-def NewBatch(ref, comp, results, cc, engine=None):
-    return Batch(ref, comp, results, cc, engine)
+    def _run_sharded(self, gid, G):
+        """the sharded Run (muse.hpp Batch::run_sharded is the same code): top-N candidates per shard when every label group
+        lives on one shard, per-group winners merged BEFORE filtering when groups straddle shards"""
+        import threading
+        shards = self.Comparison._device_shards(self._engines)
+        if self._shard_db is None or len(self._shard_db) != len(shards) or \
+                any(db.dgroup is not sh[1] for db, sh in zip(self._shard_db, shards)):
+            self._shard_db = [DeviceBatch(e, dg, self._ref) for e, dg, _, _ in shards]
+        owner = np.full(G, -1, dtype=np.int64)
+        straddle = False
+        for k, (_, _, lo, hi) in enumerate(shards):
+            g = np.unique(gid[lo:hi])
+            straddle = straddle or bool(np.any((owner[g] >= 0) & (owner[g] != k)))
+            owner[g] = k
+        r = self.Results
+        out = [None] * len(shards)
+        err = [None] * len(shards)
+
+        def work(k):
+            _, _, lo, hi = shards[k]
+            try:
+                if straddle:
+                    out[k] = self._shard_db[k].run_groups(gid[lo:hi], G, lo, abs_scores=True)
+                else:
+                    out[k] = self._shard_db[k].run_shard(gid[lo:hi], G, lo, r.MaxLag, r.TopN, r.Threshold, r.SignFilter, True)
+            except Exception as e:   # reported by the calling thread
+                err[k] = e
+        threads = [threading.Thread(target=work, args=(k,)) for k, sh in enumerate(shards) if sh[3] > sh[2]]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for e in err:
+            if e is not None:
+                raise e
+        if straddle:
+            empty = (np.zeros(G, dtype=B.RECORD_DTYPE), np.zeros(G, dtype=np.uint8))
+            empty[0]["series"] = -1
+            parts = [o if o is not None else empty for o in out]
+            idx, lag, score, _ = merge_group_records(np.stack([p[0] for p in parts]), np.stack([p[1] for p in parts]),
+                                                     r.MaxLag, r.TopN, r.Threshold, r.SignFilter)
+        else:
+            recs = [o for o in out if o is not None and len(o)]
+            allrec = np.concatenate(recs) if recs else np.zeros(0, dtype=B.RECORD_DTYPE)
+            idx, lag, score, _ = merge_records(allrec, r.TopN)
+        return idx, lag, score
+
+
+def NewBatch(ref, comp, results, cc, engine=None, engines=None):
+    return Batch(ref, comp, results, cc, engine, engines)
 
 
 def RunMany(batches, groupByLabels):

@@ -14,8 +14,12 @@
  *   - no caller pointer is retained after a call returns (cgo rule): uploads
  *     copy.  Caller data is never mutated (the reference's zNormalize mutates
  *     Series values in place, xcorr.go:86,93; this engine does not).
- *   - one context = one GPU (one process per GPU under torch.distributed /
- *     RCCL; a Go host creates one context per device).  A handle may be used
+ *   - one context = one GPU.  Several contexts may live in one process, on
+ *     different devices or on the same one: the host mirrors shard a Group
+ *     over a list of contexts inside ONE process (one host thread per
+ *     context: muse.hpp Engine::List, muse_hip.go SetDevices, muse.py
+ *     Batch(engines=...)); under torch.distributed / RCCL it is one process
+ *     and one context per GPU (go-muse_amd/dist.py).  A handle may be used
  *     from any host thread.  Calls on DIFFERENT group / batch handles of one
  *     context may be in flight at the same time (muse_test.go:203-214 drives
  *     one Muse from many goroutines: every Muse.Run owns its group and batch);
@@ -72,6 +76,9 @@ const char *muse_status_string(int status);
 /* ------------------------------------------------------------ context */
 /* Streams, twiddle tables, scratch.  device = HIP device ordinal.      */
 int muse_ctx_create(int32_t device, muse_ctx **out);
+/* Number of usable (gfx950) devices, ordinals 0 .. count-1: a host that shards a Group over the GPUs of a node
+ *  creates one context per device and one host thread per context. */
+int muse_device_count(int32_t *count);
 int muse_ctx_destroy(muse_ctx *ctx);
 int muse_ctx_synchronize(muse_ctx *ctx);
 /* name: >= 64 bytes.  Any out pointer may be NULL. */
@@ -208,6 +215,25 @@ int muse_batch_run_shard(muse_batch *b, const int32_t *group_id, int32_t G,
 int muse_merge_records(const muse_record *records, int64_t count, int32_t top_n,
                        int64_t *out_series, int32_t *out_lag, double *out_score,
                        int32_t *out_count, double *out_mean_abs);
+/* Sharded Run whose label groups may STRADDLE shards ("... or the per-group partial maxima are merged
+ * before top-N"; e.g. Run(["graph"]) over a Group whose graphs are interleaved, cut into contiguous row ranges): every
+ * shard reports, per label group and unfiltered, its winner among the members whose score is a number
+ * (out_records[g].series = global index, -1 if none) and out_state[g] = 0 no member on this shard / 1 members, the first
+ * one's score is a number / 2 the first member's score is NaN (muse_batch.go:87: x > NaN never replaces it, so a group
+ * whose FIRST member overall scores NaN yields NaN).  G records and states per shard; group ids are global and
+ * required (ungrouped Runs are exact with muse_batch_run_shard). */
+int muse_batch_run_groups(muse_batch *b, const int32_t *group_id, int32_t G,
+                          int64_t series_offset, int32_t abs_scores,
+                          muse_record *out_records, uint8_t *out_state);
+/* Merge of those per-shard records (host only): records / state hold n_shards x G entries, shard-major, shards in
+ * ascending row order.  Per group: the first shard with a member decides the NaN rule, the maximum by |score| wins
+ * (the earlier shard on ties: muse_batch.go:87 keeps the earlier series); then Results.passed, the top-N heap and
+ * Fetch exactly as muse_merge_records. */
+int muse_merge_group_records(const muse_record *records, const uint8_t *state,
+                             int32_t n_shards, int32_t G, int32_t max_lag,
+                             int32_t top_n, double threshold, int32_t sign_filter,
+                             int64_t *out_series, int32_t *out_lag, double *out_score,
+                             int32_t *out_count, double *out_mean_abs);
 /* Many references against one resident group (the
  * README.md:10-13 use case iterates references and groupings over a fixed
  * set of series, i.e. one NewBatch + Run per reference against the same

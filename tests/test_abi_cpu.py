@@ -197,3 +197,32 @@ def test_lane_relabelling_removes_the_modelled_lds_bank_conflicts():
     # the kernel source carries the same map: the XOR terms of column bit 3 and the parity of column bit 4
     src = open(os.path.join(root, "go-muse_amd", "csrc", "xcorr_small.hip")).read()
     assert "((l >> 4) ^ (l >> 3) ^ (l >> 2)) & 1" in src and "(LOGN == 10 || LOGN == 14) ? (l >> 1) : l" in src
+
+
+def test_merge_group_records_semantics(muse):
+    """muse_merge_group_records on hand-made shard records (host only): the first shard with a member decides the NaN rule,
+    ties keep the earlier shard, filters apply to the merged maximum, empty groups are skipped"""
+    G, W = 5, 3
+    rec = np.zeros((W, G), dtype=muse.binding.RECORD_DTYPE)
+    rec["series"] = -1
+    state = np.zeros((W, G), dtype=np.uint8)
+
+    def put(s, g, series, score, lag, st=1):
+        rec[s, g] = (series, score, lag, g)
+        state[s, g] = st
+    put(0, 0, 3, 0.5, 1)
+    put(1, 0, 40, 0.9, 2)                # group 0: later shard strictly greater -> wins
+    put(2, 0, 90, 0.9, 3)                # ... tie with shard 1: the earlier one stays
+    state[0, 1] = 2                      # group 1: its first member (shard 0) scores NaN, no numeric member there
+    put(1, 1, 41, 0.99, 0)               # ... a later shard's number must not replace it
+    put(1, 2, 42, 0.7, 30)               # group 2: only on shard 1; lag filtered below
+    put(0, 3, 5, 0.2, 0)
+    put(2, 3, 91, 0.3, 0, st=2)          # group 3: a LATER shard whose own first member is NaN but has a number: counts
+    # group 4: no member anywhere
+    s, l, v, mean = muse.merge_group_records(rec, state, 10, 10, 0.0, 0)
+    assert list(s) == [40, 91] and list(l) == [2, 0] and list(v) == [0.9, 0.3]
+    assert mean == (0.3 + 0.9) / 2
+    s, l, v, mean = muse.merge_group_records(rec, state, 40, 1, 0.0, 0)
+    assert list(s) == [40]
+    s, l, v, mean = muse.merge_group_records(rec, state, 40, 10, 0.5, 0)
+    assert list(s) == [40, 42]

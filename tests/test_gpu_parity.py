@@ -791,7 +791,10 @@ def test_mixed_unit_group_every_pair_handed_off(muse, eng, oracle):
     # the second pass over the same rows goes to the rescaling kernel directly (automatic selection learnt the
     # hand-off count of the first): same results
     lag2, mv2 = db.scores()
-    assert np.array_equal(lag, lag2) and np.array_equal(mv, mv2)
+    # (the listed pairs are redone by that kernel in the first pass too: identical bits; the last row has no partner, is
+    # never listed and comes from the default kernel in the first pass: equal to rounding)
+    assert np.array_equal(lag, lag2) and np.array_equal(mv[:M - 1], mv2[:M - 1])
+    assert abs(mv[M - 1] - mv2[M - 1]) <= 1e-12 * abs(mv[M - 1])
 
 
 def test_muse_run_concurrent_callers(muse):
@@ -1654,3 +1657,68 @@ def test_xcorr_batch_many_pairs_4096(eng, oracle):
     _, olag, omv, gap = _oracle_xcorr_rows(oracle, X[sel], Y[sel], N, True)
     assert not nil.any()
     assert_scores_match(lag[sel], mv[sel], olag, omv, gap)
+
+
+# ------------------------------------------------ one process, several devices behind Batch.Run
+def _mirror_group(muse, rows, graphs, hosts):
+    g = muse.NewGroup("targets")
+    g.Add(*[muse.NewSeries(rows[i], muse.NewLabels({"graph": "g%d" % graphs[i], "host": "h%d" % hosts[i]}))
+            for i in range(len(rows))])
+    return g
+
+
+def _fetch(batch):
+    scores, mean = batch.Results.Fetch()
+    return [(s.Labels.ID(), s.Lag, s.PercentScore) for s in scores], mean
+
+
+def test_batch_run_sharded_over_engine_list(muse, eng, oracle):
+    """NewBatch(..., engines=[...]).Run shards the Comparison group over the listed contexts (here: device 0 three times,
+    plus every device the box has) and must return exactly the one-device Run's Scores -- for Run(nil) (per-shard top-N),
+    for label groups that straddle every shard (per-group maxima merged before filtering) and under filters; the
+    one-device scores themselves are checked against the oracle's Results."""
+    rng = np.random.default_rng(31)
+    M, N = 2001, 4096
+    ref = rng.standard_normal(N)
+    rows = rng.standard_normal((M, N))
+    rows[::7] += 1.5 * np.roll(ref, 5)[None, :]
+    rows[3::11] -= 2.5 * np.roll(ref, -9)[None, :]
+    rows[4] = 1.25                                         # sigma == 0
+    rows[6, 100] = np.nan                                  # first member of graph 6: that group never passes
+    rows[6 + 50 * 13, 7] = np.nan                          # a later member of graph 6 + ... in another shard
+    graphs = np.arange(M) % 50                             # every graph has members in every shard
+    hosts = np.arange(M) // 50
+    ndev = muse.device_count()
+    lists = [[0, 0, 0], [0, 0], list(range(ndev)) * (1 if ndev > 1 else 4)]
+    cases = [(None, N, 20, 0.0, 0), (["graph"], N, 20, 0.0, 0), (["host"], N, 9, 0.0, 0),
+             (["graph"], 6, 10, 0.02, 1), (["graph", "host"], N, 300, 0.0, 0)]
+    refs = muse.NewSeries(ref, muse.NewLabels({"graph": "ref"}))
+    one_group = _mirror_group(muse, rows, graphs, hosts)
+    expect = []
+    for by, max_lag, top, thr, sf in cases:
+        b = muse.NewBatch(refs, one_group, muse.NewResults(max_lag, top, thr, sf), 8, engine=eng)
+        b.Run(by)
+        expect.append(_fetch(b))
+    # anchor: the grouped one-device Run against the oracle's Results over oracle scores
+    olag, omv, gap = oracle.batch_scores(ref, rows, nthreads=16)
+    oi, ol, osc, omean = oracle.results(olag, omv, graphs.astype(np.int32), 50, True, N, 20, 0.0, 0)
+    got = expect[1][0]
+    assert [g[1] for g in got] == list(ol)
+    assert np.allclose([g[2] for g in got], osc, rtol=SCORE_RTOL, atol=SCORE_ATOL)
+    for devs in lists:
+        engines = [muse.Engine(d) for d in devs]
+        grp = _mirror_group(muse, rows, graphs, hosts)
+        for c, (by, max_lag, top, thr, sf) in enumerate(cases):
+            b = muse.NewBatch(refs, grp, muse.NewResults(max_lag, top, thr, sf), 8, engines=engines)
+            b.Run(by)
+            got, mean = _fetch(b)
+            assert got == expect[c][0], (devs, c)
+            assert mean == expect[c][1] or (math.isnan(mean) and math.isnan(expect[c][1]))
+    # fewer rows than devices (empty shards) and the reference's own table over three shards
+    tiny = _mirror_group(muse, rows[:3], graphs[:3], hosts[:3])
+    b1 = muse.NewBatch(refs, tiny, muse.NewResults(N, 5, 0.0, 0), 1, engine=eng)
+    b3 = muse.NewBatch(refs, _mirror_group(muse, rows[:3], graphs[:3], hosts[:3]), muse.NewResults(N, 5, 0.0, 0), 1,
+                       engines=[muse.Engine(0) for _ in range(5)])
+    b1.Run(None)
+    b3.Run(None)
+    assert _fetch(b1) == _fetch(b3)
