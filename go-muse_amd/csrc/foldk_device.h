@@ -71,6 +71,46 @@ __device__ __forceinline__ void exchange_cross(double2 (&v)[16], double2 *xbuf, 
         lds_barrier();
 }
 
+// The same through a FULL 16 x 272 buffer (69,632 B: kernels that run two workgroups per CU): one round, two barriers.
+// Row k takes output k, the reader with hi reads row hi; the in-row patterns are the half-round ones (conflict-free).
+constexpr int OCC_XBUF_FULL = 16 * 272;
+template <int MODE, int PERM>
+__device__ __forceinline__ void exchange_cross_full(double2 (&v)[16], double2 *xbuf, const int t, const int wcol = -1)
+{
+    const int hi = t >> 4, lo = t & 15;
+    const int wbase = MODE ? 17 * lo + hi : (wcol >= 0 ? wcol : t);
+    const int rbase = 272 * hi + (MODE ? 17 * lo : lo);
+    lds_barrier(); // buffer free: every wave is done with its previous (wave-local or shared) use
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        xbuf[272 * k + wbase] = v[pr<PERM>(k)];
+    lds_barrier();
+#pragma unroll
+    for (int e = 0; e < 16; e++)
+        v[e] = xbuf[rbase + (MODE ? e : 16 * e)];
+}
+// Wave-local transpose among the sixteen lanes that share hi, through the wave's quarter of the full buffer
+// (xw = xbuf + 1088 wave): lane (hl, lo) writes output k to 272 hl + 17 k + lo and reads input e from 272 hl + 17 lo + e.
+// Bank check (MI355X_MICROARCH.md, LDS): a ds_read_b128 group {0-3, 12-15, 20-27} holds (hl, lo) = (0, 0..3), (0, 12..15),
+// (1, 4..11): slots 17 lo + 272 hl = lo + 16 (lo + 17 hl), i.e. sixteen different residues mod 16; a ds_write_b128 group is
+// eight consecutive lanes on eight consecutive slots.  No barrier: a wave's LDS operations execute in order.
+template <int PERM>
+__device__ __forceinline__ void exchange_local_full(double2 (&v)[16], double2 *xw, const int t)
+{
+    const int hl = (t >> 4) & 3, lo = t & 15;
+    const int wbase = 272 * hl + lo;
+    const int rbase = 272 * hl + 17 * lo;
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        xw[17 * k + wbase] = v[pr<PERM>(k)];
+    fence();
+    asm volatile("" ::: "memory"); // (the compiler must not move a lane's reads above its writes: other lanes' data arrives through them)
+    fence();
+#pragma unroll
+    for (int e = 0; e < 16; e++)
+        v[e] = xw[rbase + e];
+}
+
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef __attribute__((address_space(3))) char *lds_ptr;
 #define MUSE_LDS_ADDR(p) ((unsigned)(unsigned long long)(lds_ptr)(p))
@@ -314,6 +354,16 @@ __device__ __forceinline__ void wave_argmax_store(const double2 (&v)[16], const 
         ra_[3] = widxB == 0x7fffffff ? 0.0 : wb;
         ra_[4] = widxB == 0x7fffffff ? cc0b : svB;
         ra_[5] = (double)widxB;
+    }
+}
+
+// the same with all sixteen factors already in registers (xf[j] = xc for k3 = j)
+__device__ __forceinline__ void xc_stage1_pre(double2 (&v)[16], const double2 (&xf)[16])
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        bf_xc(v[BR16(2 * i)], v[BR16(2 * i) + 1], xf[2 * i], xf[2 * i + 8]);
+        bf_xc(v[BR16(2 * i + 1)], v[BR16(2 * i + 1) + 1], xf[2 * i + 1], xf[2 * i + 9]);
     }
 }
 

@@ -231,15 +231,21 @@ __global__ __launch_bounds__(OCC_THREADS, 4) void xcorr_fused_n4096_fold(const F
 // Many references against one resident group in ONE pass over the rows
 // (the README use case iterates references over a fixed set of
 // series).  Each pair of series is read from HBM and forward-transformed once; its
-// spectrum Z (DC bin zeroed) is parked in a 64 KB per-workgroup slice of a global
-// scratch buffer (L2 / Infinity-Cache resident: every lane re-reads exactly the
-// addresses it wrote) and re-loaded for references 1..R-1, each of which costs one
+// spectrum Z (DC bin zeroed) STAYS IN REGISTERS for the R references, each of which costs one
 // spectrum multiply, one transform and one argmax.  Per (series, reference) that is
 // (1 + R) / (2 R) of the single-reference transform work and 1/R of the HBM bytes.
+// (Round 2 parked Z in a 64 KB slice of global scratch per resident workgroup: 67 MB against
+// 4 MB of L2 per XCD, i.e. 9 x the row bytes through the memory side,
+// profiles/r01_many_refs_rocprof_summary.txt; that traffic is gone.)
 //
-// One prefetch buffer serves both kinds of iteration: 16 x (re, im) of Z, or
-// 16 x (row A sample, row B sample) -- the same packing the transform starts from --
-// so every path through the loop defines all of it (no stale live ranges).
+// Two workgroups per CU with 256 registers per lane and 72 KB of LDS each (measured against three at
+// 168 registers with a quarter of Z in LDS: +4 %, profiles/r03_many_references.txt), spent on what
+// hides latency at that occupancy: every transpose goes through a FULL 16 x 272 buffer (two barriers
+// instead of five), the next reference's sixteen spectrum factors are requested one iteration ahead,
+// the eight pass-3 factors travel under the transpose in front of the pass (R = 8, 400 000 x 4096:
+// 1.64 -> 1.70 -> 1.76 -> 1.86e8 series-references/s step by step, profiles/r03_many_references.txt).  The last reference of
+// a pair is peeled out of the reference loop: Z dies in its first stage, and its registers take the
+// next pair's rows, requested in front of the last pass.
 namespace foldk {
 
 constexpr int MSTAT = 12; // per pair: [0,8) sum d^2 partials (2*wave + series), [8,10) sum d, [10] first row, [11] has second row
@@ -288,18 +294,6 @@ __device__ __forceinline__ bool finalize_multi(const double *tr, const double *s
     return redo;
 }
 
-// 16-byte global store through a scalar base (+ element offset `off`) and a lane index
-__device__ __forceinline__ void zstore(double2 *base, long long off, int idx, d2v val)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    unsigned long long u = (unsigned long long)base;
-    asm volatile("" : "+s"(u));
-    u += (unsigned long long)(off * 16);
-    asm volatile("" : "+s"(u));
-    ((d2v __attribute__((address_space(1))) *)u)[idx] = val;
-#endif
-}
-
 // the previous iteration's results, written behind the first barrier of the current one
 // (a free function on purpose: a by-reference lambda with two call sites is not inlined and
 // drags the kernel argument struct into private memory)
@@ -309,12 +303,13 @@ __device__ __forceinline__ void finalize_prev_multi(const double *trip, const do
                                                     long long *ovf_list)
 {
     const double *const tr = trip + MTRIP * (cur_ip ^ 1);
-    if (t < 2 && tr[24] >= 0.0) {
+    const int series = t >> 6; // lane 0 of waves 0 / 1 writes one series' result each
+    if ((t & 63) == 0 && series < 2 && tr[24] >= 0.0) {
         const double *const st = stats + MSTAT * (int)tr[25];
-        if (t == 0 || st[11] != 0.0) {
+        if (series == 0 || st[11] != 0.0) {
             const int r = (int)tr[24];
-            const long long row = (long long)st[10] + t;
-            if (finalize_multi(tr, st, t, invN, invNm1, mv_many[r] + row, lag_many[r] + row) && r == 0) {
+            const long long row = (long long)st[10] + series;
+            if (finalize_multi(tr, st, series, invN, invNm1, mv_many[r] + row, lag_many[r] + row) && r == 0) {
                 const int slot = atomicAdd(ovf_count, 1);
                 ovf_list[slot] = row >> 1;
             }
@@ -324,15 +319,17 @@ __device__ __forceinline__ void finalize_prev_multi(const double *trip, const do
 
 } // namespace foldk
 
-// PADDED (2048 < N < 4096): as in xcorr_fused_n4096_fast -- the parked spectrum keeps its DC bin and every
-// reference's results are corrected by -m c1_r[index] (FusedParams::c1_many) before the argmax.
-template <bool TIMING = false, bool PADDED = false>
-__global__ __launch_bounds__(OCC_THREADS, 4) void xcorr_fused_n4096_fold_multi(const FusedParams p)
+constexpr int MULTI_WGS_PER_CU = 2;
+
+// PADDED (2048 < N < 4096): the spectrum keeps its DC bin and every reference's results are corrected by
+// -m c1_r[index] (FusedParams::c1_many) before the argmax.
+template <bool PADDED = false>
+__global__ __launch_bounds__(OCC_THREADS, MULTI_WGS_PER_CU) void xcorr_fused_n4096_fold_multi(const FusedParams p)
 {
     using namespace occ4;
     using namespace fold;
     using namespace foldk;
-    __shared__ double2 xbuf[OCC_XBUF];
+    __shared__ double2 xbuf[OCC_XBUF_FULL];
     __shared__ double2 g2s[128];
     __shared__ double stats[2 * MSTAT];
     __shared__ double trip[2 * MTRIP];
@@ -340,8 +337,7 @@ __global__ __launch_bounds__(OCC_THREADS, 4) void xcorr_fused_n4096_fold_multi(c
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int hi = t >> 4, lo = t & 15;
-    double2 *const xw = xbuf + XW * wave;
+    double2 *const xw = xbuf + 1088 * wave;
     const int pad = PADDED ? 4096 - p.N : 0;
     const double invN = PADDED ? 1.0 / (double)p.N : 1.0 / 4096.0, invNm1 = PADDED ? 1.0 / (double)(p.N - 1) : 1.0 / 4095.0;
     const int R = p.R;
@@ -351,177 +347,183 @@ __global__ __launch_bounds__(OCC_THREADS, 4) void xcorr_fused_n4096_fold_multi(c
     if (t < 2)
         trip[MTRIP * t + 24] = -1.0;
     __syncthreads();
-    double2 *const zs = p.zscratch + (size_t)blockIdx.x * 4096; // resident grid: one slice per workgroup
 
     int ip = 0, pp = 0;
     const long long total = p.npairs;
-    // prefetch buffer: rows (pre[i] = (A[t + 256 i], B[t + 256 i]), ka/kb = first samples) or Z
-    double2 pre[16];
-    double ka, kb;
-    {
-        RawPair raw;
-        issue_row_loads<PADDED>(raw, p, blockIdx.x < total ? (long long)blockIdx.x : 0ll, t, pad);
+    RawPair raw;
+    constexpr bool WIDE = !PADDED;
+    const auto request_rows = [&](long long pr) __attribute__((always_inline)) {
+        if (WIDE)
+            issue_row_loads_wide(raw, p, pr, t);
+        else
+            issue_row_loads<PADDED>(raw, p, pr, t, pad);
+    };
+    request_rows(blockIdx.x < total ? (long long)blockIdx.x : 0ll);
+    // reference r's sixteen spectrum factors of this thread (lane-ordered table, L2): requested one iteration ahead
+    const auto request_spectrum = [&](double2 (&xf)[16], const int r) __attribute__((always_inline)) {
+        const double2 *xr;
+        { // the table pointer is wave-uniform: keep it in SGPRs
+            const unsigned long long u = (unsigned long long)p.xcp_many[r];
+            const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)u);
+            const unsigned hi32 = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+            xr = (const double2 *)(((unsigned long long)hi32 << 32) | lo32);
+        }
 #pragma unroll
-        for (int i = 0; i < 16; i++)
-            pre[i] = make_double2(raw.a[i], raw.b[i]);
-        ka = raw.ka;
-        kb = raw.kb;
-    }
-    // one flat loop over (pair, reference) iterations: the prefetch buffer is live across
-    // exactly one back-edge
-    double s1a = 0.0, s1b = 0.0;
-    long long nextpair = 0;
-    int r = 0;
-#pragma clang loop unroll(disable)
-    for (long long pair = blockIdx.x; pair < total;) {
-        {
-            const long long rA = 2 * pair;
-            const bool hasB = rA + 1 < p.M;
-            double *const st = stats + MSTAT * pp;
-            double *const tr = trip + MTRIP * ip;
-            double2 v[16];
-            if (r == 0) {
-                // ---------- rows -> Z = FFT(dA + i dB), as in xcorr_fused_n4096_fast
-                if (t == 0) // claim the pair after this one (read at the last reference, many barriers later)
-                    next_s[pp] = (int)gridDim.x + atomicAdd(p.work_counter, 1);
-                {
-                    double qa = 0.0, qb = 0.0;
+        for (int j = 0; j < 16; j++)
+            xf[j] = ldg2(scalar_ptr_at(xr, 256 * ((j + 1) & ~1)), t - 256 * (j & 1));
+    };
+
+    // one reference: V = Z conj(X_r) / n (factors xf, requested earlier), cc = FFT(V), argmax -> trip[ip]; `v` holds Z on entry.
+    // `ahead()` runs in front of the last stage of the last pass: the place to request what the NEXT iteration needs.
+    const auto correlate = [&](double2 (&v)[16], const double2 (&xf)[16], const int r, const double *st, auto ahead) __attribute__((always_inline)) {
+        double *const tr = trip + MTRIP * ip;
+        xc_stage1_pre(v, xf);
+        dft16_rn_s234(v);
+        exchange_local_full<0>(v, xw, t);
+        gdft16_nr(v, G2Fetch{g2s, t & 15});
+        double2 g3[8]; // pass 3's factors travel under the transpose
 #pragma unroll
-                    for (int i = 0; i < 16; i++) {
-                        const double da = pre[i].x - ka, db = pre[i].y - kb;
-                        v[i] = make_double2(da, db);
-                        qa = fma(da, da, qa);
-                        qb = fma(db, db, qb);
-                    }
-                    qa = wave_sum_dpp(qa);
-                    qb = wave_sum_dpp(qb);
-                    if (lane == 0) {
-                        st[2 * wave] = qa;
-                        st[2 * wave + 1] = qb;
-                    }
-                    if (t == 0) {
-                        st[10] = (double)rA;
-                        st[11] = hasB ? 1.0 : 0.0;
-                    }
-                }
-                dft16_nr(v);
-                exchange_cross<0, 1, true>(v, xbuf, wave, t);
-                finalize_prev_multi(trip, stats, ip, t, invN, invNm1, p.mv_many, p.lag_many, p.ovf_count, p.ovf_list);
-                gdft16_nr(v, G2Fetch{g2s, hi});
-                exchange_local<1>(v, xw, t);
-                gdft16_nr(v, G3Fetch{p.g3a, t}); // Z[hi + 16 lo + 256 k3] at v[BR16(k3)]
-                s1a = readlane_f64(v[0].x, 0);
-                s1b = readlane_f64(v[0].y, 0);
-                if (!PADDED) {
-                    v[0].x = (t == 0) ? 0.0 : v[0].x;
-                    v[0].y = (t == 0) ? 0.0 : v[0].y;
-                } else if (wave == 0 && lane == 0) { // every lane needs the means before each argmax of this pair
-                    st[8] = s1a;
-                    st[9] = s1b;
-                }
-                if (R > 1) { // park Z: lane t owns zs[256 k + t] (scalar bases: no hoisted VGPR addresses)
-#pragma unroll
-                    for (int k = 0; k < 16; k++) {
-                        d2v z;
-                        z.x = v[k].x;
-                        z.y = v[k].y;
-                        zstore(zs, 256 * ((k + 1) & ~1), t - 256 * (k & 1), z);
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < 16; k++)
-                    v[k] = pre[k];
-            }
-            // ---------- V = Z * conj(X_r)/n ; cc = FFT(V) ; argmax
+        for (int q = 0; q < 8; q++)
+            g3[q] = G3Fetch{p.g3b, t}(q);
+        fence();
+        exchange_cross_full<1, 1>(v, xbuf, t);
+        if (r > 0) // (r == 0: the previous iteration's results went out behind the forward transform's first barriers)
+            finalize_prev_multi(trip, stats, ip, t, invN, invNm1, p.mv_many, p.lag_many, p.ovf_count, p.ovf_list);
+        gdft16_nr_s12(v, g3[0], g3[1]); // cc index t + 256 m3 at v[BR16(m3)]
+        gdft16_nr_s3(v, g3[2], g3[3]);
+        fence();
+        ahead();
+        fence();
+        gdft16_nr_s4(v, g3[4], g3[5], g3[6], g3[7]);
+        if (PADDED) { // cc(d - m 1_valid) = cc(d) - m c1_r
+            const double *c1r;
             {
-                const double2 *xr;
-                { // the table pointer is wave-uniform: keep it in SGPRs
-                    const unsigned long long u = (unsigned long long)p.xcp_many[r];
-                    const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)u);
-                    const unsigned hi32 = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
-                    xr = (const double2 *)(((unsigned long long)hi32 << 32) | lo32);
-                }
-                xc_stage1(v, [&](int j) __attribute__((always_inline)) {
-                    return ldg2(scalar_ptr_at(xr, 256 * ((j + 1) & ~1)), t - 256 * (j & 1));
-                });
+                const unsigned long long u = (unsigned long long)p.c1_many[r];
+                const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)u);
+                const unsigned hi32 = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+                c1r = (const double *)(((unsigned long long)hi32 << 32) | lo32);
             }
-            dft16_rn_s234(v);
-            exchange_local<0>(v, xw, t);
-            gdft16_nr(v, G2Fetch{g2s, lo});
-            exchange_cross<1, 1, true>(v, xbuf, wave, t); // (tail barrier: the next iteration may start with a wave-local transpose)
-            if (r > 0) // this iteration's first workgroup barriers were the ones above
-                finalize_prev_multi(trip, stats, ip, t, invN, invNm1, p.mv_many, p.lag_many, p.ovf_count, p.ovf_list);
-            gdft16_nr(v, G3Fetch{p.g3b, t}); // cc index t + 256 m3 at v[BR16(m3)]
-            if (PADDED) { // cc(d - m 1_valid) = cc(d) - m c1_r
-                const double *c1r;
-                {
-                    const unsigned long long u = (unsigned long long)p.c1_many[r];
-                    const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)u);
-                    const unsigned hi32 = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
-                    c1r = (const double *)(((unsigned long long)hi32 << 32) | lo32);
-                }
-                const double mA = st[8] * invN, mB = st[9] * invN;
+            const double mA = st[8] * invN, mB = st[9] * invN;
 #pragma unroll
-                for (int k = 0; k < 16; k++) {
-                    const double c = scalar_ptr_at(c1r, 256 * ((k + 1) & ~1))[t - 256 * (k & 1)];
-                    v[BR16(k)] = make_double2(fma(-mA, c, v[BR16(k)].x), fma(-mB, c, v[BR16(k)].y));
+            for (int h = 0; h < 4; h++) {
+                double cq[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    cq[k] = scalar_ptr_at(c1r, 256 * ((4 * h + k + 1) & ~1))[t - 256 * ((4 * h + k) & 1)];
+                fence();
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int q = BR16(4 * h + k);
+                    v[q] = make_double2(fma(-mA, cq[k], v[q].x), fma(-mB, cq[k], v[q].y));
                 }
             }
-            wave_argmax_store(v, wave, lane, tr + 6 * wave);
-            // ---------- request the next iteration's input: Z again, or the next pair's rows
-            fence();
-            if (r + 1 < R) {
-#pragma unroll
-                for (int k = 0; k < 16; k++)
-                    pre[k] = ldg2(scalar_ptr_at((const double2 *)zs, 256 * ((k + 1) & ~1)), t - 256 * (k & 1));
-                ka = 0.0;
-                kb = 0.0;
-            } else {
-                nextpair = __builtin_amdgcn_readfirstlane(next_s[pp]);
-                long long nxt = nextpair < total ? nextpair : 0; // nothing left: pair 0 (L2-resident dummy)
-                RawPair raw;
-                issue_row_loads<PADDED>(raw, p, nxt, t, pad);
-#pragma unroll
-                for (int i = 0; i < 16; i++)
-                    pre[i] = make_double2(raw.a[i], raw.b[i]);
-                ka = raw.ka;
-                kb = raw.kb;
-            }
-            fence();
-            if (wave == 0 && lane == 0) {
-                tr[24] = (double)r;
-                tr[25] = (double)pp;
-                if (r == 0) {
-                    st[8] = s1a;
-                    st[9] = s1b;
-                }
-            }
-            ip ^= 1;
         }
-        if (++r == R) {
-            r = 0;
-            pair = nextpair;
-            pp ^= 1;
+        wave_argmax_store(v, wave, lane, tr + 6 * wave);
+        if (wave == 0 && lane == 0) {
+            tr[24] = (double)r;
+            tr[25] = (double)pp;
         }
+        ip ^= 1;
+    };
+
+    long long nextpair = 0;
+#pragma clang loop unroll(disable)
+    for (long long pair = blockIdx.x; pair < total; pair = nextpair) {
+        const long long rA = 2 * pair;
+        const bool hasB = rA + 1 < p.M;
+        double *const st = stats + MSTAT * pp;
+        if (t == 0) // claim the pair after this one (read at the last reference, many barriers later)
+            next_s[pp] = (int)gridDim.x + atomicAdd(p.work_counter, 1);
+        // ---------- rows -> Z = FFT(dA + i dB), as in xcorr_fused_n4096_fold
+        double2 Z[16];
+        {
+            const double KA = raw.ka, KB = raw.kb;
+            double qa = 0.0, qb = 0.0;
+            if (WIDE)
+                widen_rows(raw);
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const double da = raw.a[i] - KA, db = raw.b[i] - KB;
+                Z[i] = make_double2(da, db);
+                qa = fma(da, da, qa);
+                qb = fma(db, db, qb);
+            }
+            qa = wave_sum_dpp(qa);
+            qb = wave_sum_dpp(qb);
+            if (lane == 0) {
+                st[2 * wave] = qa;
+                st[2 * wave + 1] = qb;
+            }
+            if (t == 0) {
+                st[10] = (double)rA;
+                st[11] = hasB ? 1.0 : 0.0;
+            }
+        }
+        double2 xf[16];
+        fence();
+        request_spectrum(xf, 0); // (the rows' registers are free again: the first reference's factors travel under the forward transform)
+        fence();
+        dft16_nr(Z);
+        exchange_cross_full<0, 1>(Z, xbuf, t, WIDE ? wide_column(t) : -1);
+        finalize_prev_multi(trip, stats, ip, t, invN, invNm1, p.mv_many, p.lag_many, p.ovf_count, p.ovf_list);
+        gdft16_nr(Z, G2Fetch{g2s, t >> 4});
+        {
+            double2 g3[8]; // pass 3's factors travel under the transpose
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+                g3[q] = G3Fetch{p.g3a, t}(q);
+            fence();
+            exchange_local_full<1>(Z, xw, t);
+            gdft16_nr_s12(Z, g3[0], g3[1]); // Z[hi + 16 lo + 256 k3] at Z[BR16(k3)]
+            gdft16_nr_s3(Z, g3[2], g3[3]);
+            gdft16_nr_s4(Z, g3[4], g3[5], g3[6], g3[7]);
+        }
+        {
+            const double s1a = readlane_f64(Z[0].x, 0), s1b = readlane_f64(Z[0].y, 0);
+            if (!PADDED) {
+                Z[0].x = (t == 0) ? 0.0 : Z[0].x;
+                Z[0].y = (t == 0) ? 0.0 : Z[0].y;
+            }
+            if (wave == 0 && lane == 0) { // (PADDED: every lane needs the means before each argmax of this pair: many barriers away)
+                st[8] = s1a;
+                st[9] = s1b;
+            }
+        }
+#pragma clang loop unroll(disable)
+        for (int r = 0; r + 1 < R; r++) {
+            double2 v[16], xn[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                v[k] = Z[k];
+            correlate(v, xf, r, st, [&]() __attribute__((always_inline)) { request_spectrum(xn, r + 1); });
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                xf[k] = xn[k];
+        }
+        {   // the last reference: Z dies in its first stage; the next pair's rows are requested in front of its last pass
+            nextpair = __builtin_amdgcn_readfirstlane(next_s[pp]);
+            const long long nxt = nextpair < total ? nextpair : 0; // nothing left: pair 0 (L2-resident dummy)
+            correlate(Z, xf, R - 1, st, [&]() __attribute__((always_inline)) { request_rows(nxt); });
+        }
+        pp ^= 1;
     }
     lds_barrier();
     finalize_prev_multi(trip, stats, ip, t, invN, invNm1, p.mv_many, p.lag_many, p.ovf_count, p.ovf_list);
 }
 
-// R >= 2 references, n == 4096 (N < 4096: p.c1_many); p.ovf_count and p.work_counter zeroed; a resident grid
-// (pairs are handed out dynamically), one scratch slice per workgroup
+// R >= 1 references, n == 4096 (N < 4096: p.c1_many); p.ovf_count and p.work_counter zeroed; a resident grid
+// (pairs are handed out dynamically)
 hipError_t launch_fused_multi(const FusedParams &p, int num_cus, hipStream_t stream)
 {
-    const long long grid = std::min<long long>(p.npairs, (long long)num_cus * 4);
-    if (p.zslots < grid || !p.zscratch || !p.work_counter || p.R < 1 || !p.g2 || !p.g3a || !p.g3b)
+    const long long grid = std::min<long long>(p.npairs, (long long)num_cus * MULTI_WGS_PER_CU);
+    if (!p.work_counter || p.R < 1 || !p.g2 || !p.g3a || !p.g3b || !p.xcp_many || !p.mv_many || !p.lag_many || p.rows32)
         return hipErrorInvalidValue;
     if (p.N < 4096) {
         if (!p.c1_many)
             return hipErrorInvalidValue;
-        hipLaunchKernelGGL((xcorr_fused_n4096_fold_multi<false, true>), dim3((unsigned)grid), dim3(OCC_THREADS), 0, stream, p);
+        hipLaunchKernelGGL((xcorr_fused_n4096_fold_multi<true>), dim3((unsigned)grid), dim3(OCC_THREADS), 0, stream, p);
     } else {
-        hipLaunchKernelGGL((xcorr_fused_n4096_fold_multi<false, false>), dim3((unsigned)grid), dim3(OCC_THREADS), 0, stream, p);
+        hipLaunchKernelGGL((xcorr_fused_n4096_fold_multi<false>), dim3((unsigned)grid), dim3(OCC_THREADS), 0, stream, p);
     }
     return hipGetLastError();
 }
