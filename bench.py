@@ -25,6 +25,80 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_COPY_GBPS = 6290.0       # MI355X_MICROARCH.md: best measured copy
+
+
+def csrc_sha():
+    """fingerprint of the kernel sources: counters collected from other sources are not attached"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "go-muse_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+class Counters:
+    """profiles/r*_counters.json (tools/profile.sh + tools/profile_summary.py): per kernel instantiation, the rocprofv3 PMC
+    means of one launch on the default bench workload.  Looked up by kernel name AND rows AND length; a miss is reported in
+    the object that asked (never silently a number from another workload), a file collected from other kernel sources too."""
+
+    def __init__(self):
+        import glob
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_counters.json")))
+        self.path, self.data, self.note = (files[-1] if files else None), {}, None
+        if not self.path:
+            self.note = "no profiles/r*_counters.json"
+            return
+        try:
+            j = json.load(open(self.path))
+        except Exception as e:
+            self.note = "unreadable %s: %s" % (os.path.basename(self.path), e)
+            return
+        self.meta = {k: j.get(k) for k in ("collected_at_commit", "csrc_sha", "method")}
+        if j.get("csrc_sha") != csrc_sha():
+            self.note = "%s was collected from other kernel sources (csrc_sha %s, now %s): regenerate with tools/profile.sh" % (
+                os.path.basename(self.path), j.get("csrc_sha"), csrc_sha())
+            return
+        self.data = {k["kernel"]: k for k in j.get("kernels", [])}
+
+    def lookup(self, kernel, rows, length):
+        """-> (record or None, source dict)"""
+        src = {"file": os.path.relpath(self.path, ROOT) if self.path else None}
+        if self.note:
+            src["note"] = self.note
+            return None, src
+        src.update(self.meta)
+        k = self.data.get(kernel)
+        if k is None:
+            src["note"] = "no counters for kernel %s" % kernel
+            return None, src
+        if k.get("rows") != rows or k.get("length") != length:
+            src["note"] = "counters for %s are for %s x %s, this run is %d x %d" % (kernel, k.get("rows"), k.get("length"), rows, length)
+            return None, src
+        return k, src
+
+    def attach(self, obj, kernel, rows, length, algorithmic_bytes):
+        """adds `traffic` (HBM bytes per launch from FETCH_SIZE / WRITE_SIZE), its ratio to the algorithmic bytes and the source"""
+        k, src = self.lookup(kernel, rows, length)
+        obj["traffic"] = k.get("hbm_bytes_per_launch") if k else None
+        if k and algorithmic_bytes:
+            obj["traffic_over_algorithmic"] = k["hbm_bytes_per_launch"] / algorithmic_bytes
+        obj["traffic_source"] = src
+        return k
+
+
+def clock_stats(mhz):
+    import numpy as np
+    mhz = np.asarray(mhz, dtype=float)
+    mhz = mhz[mhz > 0]
+    if not len(mhz):
+        return None
+    return {"median_mhz": float(np.median(mhz)), "min_mhz": float(mhz.min()), "max_mhz": float(mhz.max()), "windows": int(len(mhz)),
+            "method": "one probe wave beside the timed launches: delta s_memtime / delta s_memrealtime x 100 MHz per 1 ms window "
+                      "(muse_test_clock_probe_*)"}
 
 
 def cpu_baseline(dg, ref, N):
@@ -175,8 +249,24 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # the shader clock held under this load (prices the fp64-VALU / LDS ceilings below): a one-wave probe kernel on its own
+    # stream, started ahead of the LAST warm-up step so that it is resident when the timed region begins
+    probing = n_gpus == 1 and not use_dist
+    est_ms = 15.0 * max(1.0, M * N / 4.096e9)
+
+    def start_probe():
+        eng.clock_probe_start(1.0, min(50000.0, est_ms * (args.steps + 2) * 1.3 + 30.0))
+
+    for i in range(args.warmup):
+        if probing and i == args.warmup - 1:
+            start_probe()
+        t0 = time.perf_counter()
         step()
+        if i == 0:
+            fence()
+            est_ms = (time.perf_counter() - t0) * 1e3
+    if probing and args.warmup == 0:
+        start_probe()
     fence()
     eng.kernel_time()                                   # drop warm-up events
     eng.kernel_timing(True)
@@ -187,6 +277,7 @@ def main():
     dt = time.perf_counter() - t0
     eng.kernel_timing(False)
     k_ms, k_cnt = eng.kernel_time()
+    sclk = clock_stats(eng.clock_probe_read()) if probing else None
     if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=tdev if tdev is not None else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -201,15 +292,7 @@ def main():
         bytes_per_launch = float(M) * (8 * N + 16)
         achieved = bytes_per_launch / k_avg_s / 1e9 if k_avg_s > 0 else 0.0
         kname = eng.kernel_name(db) if hasattr(eng, "kernel_name") else "xcorr_fused"
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_fp64.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("rows") == M and tj.get("length") == N and tj.get("kernel", "").split("<")[0] == kname.split("<")[0]:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        counters = Counters()
         line = {
             "metric": "series-pairs XCorr/sec at N=4096, 1M-series batch; achieved HBM GB/s",
             "value": value, "unit": "series-pairs/s", "n_gpus": n_gpus, "steps": args.steps,
@@ -221,12 +304,34 @@ def main():
                        "rows_per_gpu": M, "length": N, "fft_len": db.n, "sharding": "rows x %d" % n_gpus,
                        "device": dev_name},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                          "kernel": kname, "kernel_ms_avg": k_avg_s * 1e3, "launches_timed": k_cnt,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
             "achieved_hbm_gbps_whole_step": value / n_gpus * (8 * N + 16) / 1e9,
             "top_score": float(out[2][0]) if len(out[2]) else None,
         }
+        # HBM bytes of the dominant kernel from the PMC counters (separate rocprofv3 passes, FETCH_SIZE doubled on gfx950:
+        # tools/profile.sh) and the ceilings the kernel shares the chip with: its fp64
+        # arithmetic at one vector instruction per SIMD per 4 cycles and the LDS array, both at the clock measured in THIS run
+        rl = line["roofline"]
+        krec = counters.attach(rl, kname, M, N, bytes_per_launch)
+        co = {"hbm_measured_copy": {"peak": HBM_COPY_GBPS, "unit": "GB/s", "frac": achieved / HBM_COPY_GBPS},
+              "sclk_in_kernel": sclk}
+        if krec and sclk and k_avg_s > 0:
+            hz = sclk["median_mhz"] * 1e6
+            simds = cus * 4
+            valu_ms = krec["SQ_INSTS_VALU"] * 4.0 / simds / hz * 1e3
+            lds_ms = krec["SQ_LDS_IDX_ACTIVE"] / cus / hz * 1e3
+            co["fp64_valu_issue"] = {"vector_insts_per_launch": krec["SQ_INSTS_VALU"], "floor_ms": valu_ms,
+                                     "kernel_over_floor": k_avg_s * 1e3 / valu_ms, "frac": valu_ms / (k_avg_s * 1e3),
+                                     "note": "SQ_INSTS_VALU x 4 cycles / (%d CUs x 4 SIMDs) / measured clock: the time the kernel's "
+                                             "vector instructions (1 330 of ~1 530 per wave and pair are v_*_f64) need at full issue" % cus}
+            co["lds_array"] = {"array_cycles_per_launch": krec["SQ_LDS_IDX_ACTIVE"], "bank_conflict_cycles": krec.get("SQ_LDS_BANK_CONFLICT"),
+                               "floor_ms": lds_ms, "frac": lds_ms / (k_avg_s * 1e3),
+                               "note": "SQ_LDS_IDX_ACTIVE / CUs / measured clock: the time the LDS arrays are busy"}
+        elif not krec:
+            co["note"] = "fp64-VALU / LDS ceilings need the kernel's counters: " + str(rl["traffic_source"].get("note"))
+        rl["co_bounds"] = co
         extras = n_gpus == 1 and not use_dist and not args.no_extras
         if extras and db.n >= 512:
             # opt-in filter-and-refine Run (muse_ctx_set_screening(ctx, 1)): fp32 screening pass over every row + fp64
@@ -275,10 +380,12 @@ def main():
                 b32 = float(M) * (4 * N + 16)
                 line["f32_storage_group"] = {
                     "value": float(M) / dt32, "unit": "series-pairs/s", "ms_per_step": dt32 * 1e3, "dtype": "f64 arithmetic on f32-stored rows",
+                    "kernel": eng.kernel_name(db32), "rows": M, "length": N,
                     "kernel_ms_avg": k32_s * 1e3, "algorithmic_bytes_per_launch": b32,
                     "roofline_frac": b32 / k32_s / 1e9 / HBM_PEAK_GBPS if k32_s > 0 else None,
                     "note": "opt-in muse_group_create_f32: half the HBM bytes; inputs rounded to float32 (scores are the "
                             "reference's on the rounded rows, not within 1e-6 of the float64 inputs' in general)"}
+                counters.attach(line["f32_storage_group"], eng.kernel_name(db32), M, N, b32)
                 db32.close()
                 dg32.close()
             except Exception as e:            # (e.g. not enough HBM next to the float64 group)
@@ -290,16 +397,64 @@ def main():
             bs = [db] + [pkg.DeviceBatch(eng, dg, x) for x in refs[1:]]
             pkg.run_many(bs, None, 0, args.max_lag, args.top_n, 0.0, 0, True)
             eng.synchronize()
+            eng.kernel_time()
+            eng.kernel_timing(True)
             t1 = time.perf_counter()
             reps = 3
             for _ in range(reps):
                 pkg.run_many(bs, None, 0, args.max_lag, args.top_n, 0.0, 0, True)
             eng.synchronize()
             dtm = (time.perf_counter() - t1) / reps
+            eng.kernel_timing(False)
+            km_ms, km_cnt = eng.kernel_time()
+            km_s = km_ms / max(km_cnt, 1) * 1e-3
+            bm = float(M) * (8 * N + 16 * R)                      # every row read once, one result per (row, reference)
+            mk = "xcorr_fused_n4096_fold_multi<false>"
             line["many_references"] = {"references": R, "value": R * float(M) / dtm, "unit": "series-pairs/s",
-                                       "ms_per_run": dtm * 1e3, "dtype": "f64",
-                                       "note": "muse_batch_run_many: one pass over the rows for all references"}
+                                       "ms_per_run": dtm * 1e3, "dtype": "f64", "kernel": mk, "rows": M, "length": N,
+                                       "kernel_ms_avg": km_s * 1e3, "algorithmic_bytes_per_launch": bm,
+                                       "roofline_frac": bm / km_s / 1e9 / HBM_PEAK_GBPS if km_s > 0 else None,
+                                       "vs_single_reference_passes": (R * float(M) / dtm) / value if value > 0 else None,
+                                       "note": "muse_batch_run_many: one pass over the rows for all references; the pairs' spectra stay "
+                                               "in registers, so the pass is bound by its fp64 arithmetic ((1 + R) / 2R of R single passes), "
+                                               "not by HBM"}
+            counters.attach(line["many_references"], mk, M, N, bm)
+            for b in bs[1:]:
+                b.close()
             del bs
+        if extras and N == 4096:
+            # the batched two-sided xCorr (xcorr.go:102-153), 200 000 independent (x, y) pairs resident in HBM;
+            # algorithmic bytes per pair: both rows in, (lag, value, nil flag) out
+            try:
+                P = min(200_000, M)
+                gx, _ = pkg.DeviceGroup.synthetic(eng, P, N, seed=0x78636F72)
+                gy, _ = pkg.DeviceGroup.synthetic(eng, P, N, seed=0x6D757365)
+                pkg.xcorr_groups(gx, gy, N, True)
+                eng.synchronize()
+                eng.kernel_time()
+                eng.kernel_timing(True)
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    pkg.xcorr_groups(gx, gy, N, True)
+                eng.synchronize()
+                dtx = (time.perf_counter() - t1) / 3
+                eng.kernel_timing(False)
+                kx_ms, kx_cnt = eng.kernel_time()
+                kx_s = kx_ms / max(kx_cnt, 1) * 1e-3
+                bx = float(P) * (16 * N + 16)
+                xk = "xcorr_two_sided_lds<12>"
+                line["two_sided_xcorr"] = {"value": P / kx_s if kx_s > 0 else None, "unit": "xCorr pairs/s (kernel)", "pairs": P, "rows": P, "length": N,
+                                           "normalize": True, "dtype": "f64", "kernel": xk, "kernel_ms_avg": kx_s * 1e3,
+                                           "ms_per_call_with_copy_back": dtx * 1e3, "algorithmic_bytes_per_launch": bx,
+                                           "roofline_frac": bx / kx_s / 1e9 / HBM_PEAK_GBPS if kx_s > 0 else None,
+                                           "note": "muse_xcorr_groups: z = x + i y, one forward transform, X conj(Y) untangled, one more; "
+                                                   "Stockham engine (the xCorrWithX path's tuned kernels do not apply: the mirrored spectrum "
+                                                   "element lives in another thread's registers there)"}
+                counters.attach(line["two_sided_xcorr"], xk, P, N, bx)
+                gx.close()
+                gy.close()
+            except Exception as e:
+                line["two_sided_xcorr"] = {"error": str(e)}
         if extras:
             # BASELINE config 5's lengths (N zero-padded to the next power of two), float64: one all-scores pass per length
             # over a ~4 GB group of its own; per length the kernel automatic selection takes and its share of the HBM
@@ -320,9 +475,10 @@ def main():
                     eng.kernel_timing(False)
                     kl_ms, kl_cnt = eng.kernel_time()
                     kl_s = kl_ms / max(kl_cnt, 1) * 1e-3
-                    per_len.append({"N": Nl, "fft_len": dbl.n, "rows": rows_l, "kernel": eng.kernel_name(dbl),
+                    per_len.append({"N": Nl, "fft_len": dbl.n, "rows": rows_l, "length": Nl, "kernel": eng.kernel_name(dbl),
                                     "kernel_ms_avg": kl_s * 1e3, "series_per_s": rows_l / kl_s,
                                     "roofline_frac": rows_l * (8.0 * Nl + 16.0) / kl_s / 1e9 / HBM_PEAK_GBPS})
+                    counters.attach(per_len[-1], eng.kernel_name(dbl), rows_l, Nl, rows_l * (8.0 * Nl + 16.0))
                     dbl.close()
                     dgl.close()
                 except Exception as e:

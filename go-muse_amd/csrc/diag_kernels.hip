@@ -1,0 +1,50 @@
+// diag_kernels.hip -- measurement hook (include/muse_hip_test.h), not on the product path: ONE wave that samples the shader
+// clock while other kernels run.  In-kernel clock = delta s_memtime / delta s_memrealtime x 100 MHz (MI355X_MICROARCH.md,
+// "DVFS give-back" item 6: s_memtime ticks at the shader clock, s_memrealtime at a constant 100 MHz); bench.py starts the
+// probe on its own stream next to the timed launches and prices the fp64-VALU and LDS ceilings of its roofline object at the
+// clock the chip actually held under that load, not at the nominal 2.4 GHz.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "xcorr_kernels.h"
+
+namespace muse {
+
+// windows of ~window_ticks of the 100 MHz clock until total_ticks have passed (or the buffer is full): out[2 w] = shader
+// ticks, out[2 w + 1] = 100 MHz ticks of window w; *count = windows written.  One wave, a handful of registers: it fits
+// next to the resident grids of the product kernels and sleeps between samples.
+__global__ __launch_bounds__(64, 1) void clock_probe_kernel(unsigned long long *out, int *count, int max_windows,
+                                                            unsigned long long window_ticks, unsigned long long total_ticks)
+{
+    if (threadIdx.x != 0)
+        return;
+    const unsigned long long r_begin = __builtin_amdgcn_s_memrealtime();
+    int w = 0;
+    for (; w < max_windows; w++) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+        unsigned long long r1 = r0;
+        while (r1 - r0 < window_ticks) {
+            __builtin_amdgcn_s_sleep(127);
+            r1 = __builtin_amdgcn_s_memrealtime();
+        }
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+        r1 = __builtin_amdgcn_s_memrealtime();
+        out[2 * w] = t1 - t0;
+        out[2 * w + 1] = r1 - r0;
+        if (r1 - r_begin >= total_ticks) {
+            w++;
+            break;
+        }
+    }
+    *count = w;
+}
+
+hipError_t launch_clock_probe(unsigned long long *out, int *count, int max_windows, double window_ms, double total_ms,
+                              hipStream_t stream)
+{
+    const unsigned long long wt = (unsigned long long)(window_ms * 1e5), tt = (unsigned long long)(total_ms * 1e5);
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, stream, out, count, max_windows, wt, tt);
+    return hipGetLastError();
+}
+
+} // namespace muse

@@ -109,6 +109,9 @@ struct muse_ctx {
     int64_t screen_min_rows = 0;
     double screen_e_scale = 1.0;     // test hook (muse_test_set_screen_bound_scale): scales the error bound, to exercise the guard
     int variant = 0;
+    // measurement hook (muse_test_clock_probe_*): a one-wave kernel on its own stream sampling the shader clock
+    hipStream_t probe_stream = nullptr;
+    unsigned long long *probe_buf = nullptr; // pinned host memory: [2 * PROBE_WINDOWS] ticks + the window count behind them
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     double total_ms = 0.0;
@@ -404,6 +407,12 @@ static void ctx_release(muse_ctx *ctx)
         (void)hipHostFree(b);
     (void)hipFree(ctx->many_tab);
     (void)hipFree(ctx->tw2f);
+    if (ctx->probe_stream) {
+        (void)hipStreamSynchronize(ctx->probe_stream);
+        (void)hipStreamDestroy(ctx->probe_stream);
+    }
+    if (ctx->probe_buf)
+        (void)hipHostFree(ctx->probe_buf);
     if (ctx->stream)
         (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -1642,14 +1651,15 @@ extern "C" int muse_batch_kernel_name(muse_batch *b, char *name, int32_t cap)
 {
     if (!b || !name || cap < 1)
         return fail(MUSE_ERR_INVALID, "NULL argument");
-    const char *k = "xcorr_fused_generic";
+    // (the names rocprofv3 prints for the instantiations automatic selection launches: profiles/r*_counters.json is keyed by them)
+    char k[96] = "xcorr_fused_generic";
+    const bool padded = b->N < b->n;
     if (b->n == 4096)
-        k = b->g->f32 ? (b->N == 4096 ? "xcorr_fused_n4096_fold<false, false, true>" : "xcorr_fused_n4096_fold<false, true, true>")
-                      : (b->N == 4096 ? "xcorr_fused_n4096_fold<false, false, false>" : "xcorr_fused_n4096_fold<false, true, false>");
+        snprintf(k, sizeof(k), "xcorr_fused_n4096_fold<false, %s, %s>", padded ? "true" : "false", b->g->f32 ? "true" : "false");
     else if ((b->n >= 512 && b->n <= 2048) || b->n == 8192 || b->n == 16384)
-        k = "xcorr_fused_small";
+        snprintf(k, sizeof(k), "xcorr_fused_small<%d, %s, false>", b->logn, padded ? "true" : "false");
     else if (b->n > 16384)
-        k = "xcorr_fused_long";
+        snprintf(k, sizeof(k), "xcorr_fused_long<%d, %s>", b->logn, padded ? "true" : "false");
     snprintf(name, (size_t)cap, "%s", k);
     return MUSE_OK;
 }
@@ -2582,4 +2592,42 @@ extern "C" int muse_xcorr_batch(muse_ctx *ctx, const double *x_rows, const doubl
     if (rc)
         g_last_error = msg;
     return rc;
+}
+
+// ---- measurement hook: the shader clock held while other kernels of the process run (diag_kernels.hip)
+constexpr int PROBE_WINDOWS = 4096;
+extern "C" int muse_test_clock_probe_start(muse_ctx *ctx, double window_ms, double total_ms)
+{
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    if (!(window_ms >= 0.05) || !(total_ms >= window_ms) || total_ms > 60000.0)
+        return fail(MUSE_ERR_INVALID, "clock probe: window >= 0.05 ms, window <= total <= 60 s");
+    if (!ctx->probe_stream)
+        HIP_TRY(hipStreamCreateWithFlags(&ctx->probe_stream, hipStreamNonBlocking));
+    if (!ctx->probe_buf) // (pinned and device-visible: the probe writes it directly, no copy behind a kernel that is still running)
+        HIP_TRY(hipHostMalloc((void **)&ctx->probe_buf, (2 * PROBE_WINDOWS + 1) * sizeof(unsigned long long), hipHostMallocDefault));
+    HIP_TRY(hipStreamSynchronize(ctx->probe_stream));
+    memset(ctx->probe_buf, 0, (2 * PROBE_WINDOWS + 1) * sizeof(unsigned long long));
+    HIP_TRY(launch_clock_probe(ctx->probe_buf, (int *)(ctx->probe_buf + 2 * PROBE_WINDOWS), PROBE_WINDOWS, window_ms, total_ms,
+                               ctx->probe_stream));
+    return MUSE_OK;
+}
+
+// waits for the probe; mhz[] (capacity cap) receives the clock of every window in order, *windows their number
+extern "C" int muse_test_clock_probe_read(muse_ctx *ctx, double *mhz, int32_t cap, int32_t *windows)
+{
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    if (!ctx->probe_stream || !ctx->probe_buf || !windows)
+        return fail(MUSE_ERR_INVALID, "clock probe was not started");
+    HIP_TRY(hipStreamSynchronize(ctx->probe_stream));
+    const int n = *(const int *)(ctx->probe_buf + 2 * PROBE_WINDOWS);
+    *windows = n;
+    for (int w = 0; w < n && w < cap && mhz; w++) {
+        const double ticks = (double)ctx->probe_buf[2 * w], real = (double)ctx->probe_buf[2 * w + 1];
+        mhz[w] = real > 0.0 ? ticks / real * 100.0 : 0.0;
+    }
+    return MUSE_OK;
 }

@@ -117,6 +117,10 @@ hipError_t launch_synth_f32(float *rows, long long stride, long long first, long
                             int N, unsigned long long seed, unsigned flags, hipStream_t stream);
 hipError_t launch_synth_ref(double *ref, int N, unsigned long long seed, hipStream_t stream);
 
+// measurement hook (diag_kernels.hip): one wave sampling delta s_memtime / delta s_memrealtime in windows of window_ms for total_ms
+hipError_t launch_clock_probe(unsigned long long *out, int *count, int max_windows, double window_ms, double total_ms,
+                              hipStream_t stream);
+
 // ---- group max / filter / top-N (reduce_kernels.hip)
 constexpr int TOPN_CHUNK = 4096;    // groups per workgroup in the selection pass
 constexpr int TOPN_DEVICE_MAX = 256; // larger top_n: winners are copied to the host instead

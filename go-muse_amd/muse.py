@@ -72,6 +72,17 @@ class Engine:
         """test hook (include/muse_hip_test.h): scales the error bound the filter-and-refine Run assumes"""
         B.check(B.load().muse_test_set_screen_bound_scale(self._h, float(scale)))
 
+    def clock_probe_start(self, window_ms=1.0, total_ms=1000.0):
+        """measurement hook: a one-wave kernel samples the shader clock for total_ms while the caller's kernels run"""
+        B.check(B.load().muse_test_clock_probe_start(self._h, float(window_ms), float(total_ms)))
+
+    def clock_probe_read(self):
+        """waits for the probe; the clock of every window in MHz"""
+        mhz = np.zeros(4096)
+        n = ctypes.c_int32(0)
+        B.check(B.load().muse_test_clock_probe_read(self._h, B.dptr(mhz), len(mhz), ctypes.byref(n)))
+        return mhz[:int(n.value)].copy()
+
     def kernel_name(self, dbatch):
         """name of the kernel automatic selection takes for this batch's all-scores pass"""
         name = ctypes.create_string_buffer(128)

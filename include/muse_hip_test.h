@@ -29,6 +29,12 @@ int muse_test_screen_bound(int32_t n, double xmax, double *Es);
  * |estimate - exact score|.  Any out pointer may be NULL. */
 int muse_batch_screen_estimates(muse_batch *b, int32_t max_lag, double *estimate, uint32_t *flags, double *E);
 
+/* Shader clock held under load (bench.py's roofline.co_bounds): starts a one-wave kernel on a stream of its own that, for
+ * total_ms, samples delta s_memtime / delta s_memrealtime x 100 MHz (MI355X_MICROARCH.md) in windows of window_ms while
+ * the caller launches its kernels; _read waits for it and returns the clock of every window (MHz) in order. */
+int muse_test_clock_probe_start(muse_ctx *ctx, double window_ms, double total_ms);
+int muse_test_clock_probe_read(muse_ctx *ctx, double *mhz, int32_t cap, int32_t *windows);
+
 #ifdef __cplusplus
 }
 #endif

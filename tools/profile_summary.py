@@ -1,64 +1,113 @@
 #!/usr/bin/env python3
-"""Condenses rocprofv3 CSV output (kernel trace stats + PMC passes) into a small text summary."""
+"""Condenses rocprofv3 CSV output (kernel trace stats + PMC passes of tools/profile.sh) into a text summary and
+counters.json: per kernel instantiation the means over its launches, keyed the way bench.py names kernels, with the
+workload (rows, length) bench.py itself printed for that kernel in the traced run."""
 import csv
 import glob
+import hashlib
+import json
 import os
+import re
 import sys
 from collections import defaultdict
 
 out = sys.argv[1]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def find(sub, pat):
     return sorted(glob.glob(os.path.join(out, sub, "**", pat), recursive=True))
 
 
+def short(name):
+    """'void muse::xcorr_fused_small<9, false, false>(muse::FusedParams)' -> 'xcorr_fused_small<9, false, false>'"""
+    name = name.strip()
+    depth, cut = 0, len(name)
+    for i, ch in enumerate(name):          # cut the argument list: the first '(' outside template brackets
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            cut = i
+            break
+    name = name[:cut]
+    return re.sub(r"^void\s+", "", name).replace("muse::", "").strip()
+
+
+def csrc_sha():
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "go-muse_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def ours(k):
+    return k.startswith("xcorr_")
+
+
 print("# rocprofv3 summary for", out)
+kern = defaultdict(dict)
 for f in find("trace", "*kernel_stats.csv"):
     print("\n## kernel stats (%s)" % os.path.relpath(f, out))
     rows = list(csv.DictReader(open(f)))
-    for r in rows[:12]:
-        print("  %-60s calls=%s total_ns=%s avg_ns=%s pct=%s" % (
-            r.get("Name", "")[:60], r.get("Calls"), r.get("TotalDurationNs"), r.get("AverageNs"), r.get("Percentage")))
+    for r in rows:
+        k = short(r.get("Name", ""))
+        if ours(k):
+            kern[k]["calls"] = int(float(r.get("Calls", 0)))
+            kern[k]["avg_ns"] = float(r.get("AverageNs", 0))
+    for r in rows[:24]:
+        print("  %-64s calls=%s total_ns=%s avg_ns=%s pct=%s" % (
+            short(r.get("Name", ""))[:64], r.get("Calls"), r.get("TotalDurationNs"), r.get("AverageNs"), r.get("Percentage")))
 for sub in ("pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2"):
     for f in find(sub, "*counter_collection.csv"):
         acc = defaultdict(lambda: defaultdict(list))
         for r in csv.DictReader(open(f)):
-            acc[r.get("Kernel_Name", "")][r.get("Counter_Name", "")].append(float(r.get("Counter_Value", 0)))
+            acc[short(r.get("Kernel_Name", ""))][r.get("Counter_Name", "")].append(float(r.get("Counter_Value", 0)))
         print("\n## %s (%s)" % (sub, os.path.relpath(f, out)))
-        for k, cs in acc.items():
-            if "xcorr_fused" not in k and "xcorr_screen" not in k:
+        for k, cs in sorted(acc.items()):
+            if not ours(k):
                 continue
             for c, vals in sorted(cs.items()):
-                print("  %-40s %-28s n=%d mean=%.6g" % (k[:40], c, len(vals), sum(vals) / len(vals)))
+                kern[k][c] = sum(vals) / len(vals)
+                print("  %-56s %-24s n=%d mean=%.6g" % (k[:56], c, len(vals), kern[k][c]))
 
-# HBM traffic per launch of the fused kernel, as MI355X_MICROARCH.md (HBM) prescribes for gfx950:
-# FETCH_SIZE (KB) reads exactly half of a wide coalesced stream -> x2; WRITE_SIZE (KB) as is.
-import json
+# the workload of every kernel, from the line bench.py printed in the traced run
+workload = {}
+try:
+    for ln in open(os.path.join(out, "trace.log")):
+        ln = ln.strip()
+        if ln.startswith("{") and '"metric"' in ln:
+            j = json.loads(ln)
+            workload[j["roofline"]["kernel"]] = (j["config"]["rows_per_gpu"], j["config"]["length"])
+            for key in ("f32_storage_group", "many_references", "two_sided_xcorr"):
+                o = j.get(key) or {}
+                if "kernel" in o:
+                    workload[o["kernel"]] = (o["rows"], o["length"])
+            for o in j.get("config5_lengths", []):
+                if "kernel" in o:
+                    workload[o["kernel"]] = (o["rows"], o["length"])
+except Exception as e:
+    print("\n(no bench line in trace.log: %s)" % e)
 
-
-def _mean(sub, counter):
-    """mean over launches of the DOMINANT fused kernel (the NaN-pair fallback launch that follows the
-    default kernel moves a few KB and must not be averaged in)"""
-    per = defaultdict(list)
-    for f in find(sub, "*counter_collection.csv"):
-        for r in csv.DictReader(open(f)):
-            name = r.get("Kernel_Name", "")
-            if ("xcorr_fused" in name or "xcorr_screen" in name) and r.get("Counter_Name") == counter:
-                per[name].append(float(r.get("Counter_Value", 0)))
-    if not per:
-        return None, None
-    name, best = max(per.items(), key=lambda kv: sum(kv[1]) / len(kv[1]))
-    return sum(best) / len(best), name
-
-
-(fetch, kname), (write, _) = _mean("pmc_fetch", "FETCH_SIZE"), _mean("pmc_write", "WRITE_SIZE")
-if fetch is not None and write is not None:
-    traffic = (2.0 * fetch + write) * 1024.0
-    print("\n## HBM traffic per fused launch: 2*FETCH_SIZE + WRITE_SIZE = %.4g B (FETCH_SIZE %.4g KB, WRITE_SIZE %.4g KB)"
-          % (traffic, fetch, write))
-    json.dump({"rows": int(os.environ.get("PROFILE_ROWS", "1000000")), "length": 4096,
-               "kernel": kname.split("(")[0].replace("void ", "").replace("muse::", "").strip(),
-               "hbm_bytes_per_launch": traffic, "fetch_size_kb": fetch, "write_size_kb": write,
-               "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE doubled (gfx950)"},
-              open(os.path.join(out, "traffic.json"), "w"))
+print("\n## HBM bytes per launch = 2 * FETCH_SIZE + WRITE_SIZE (KB -> B; FETCH_SIZE doubled: gfx950 counts a wide streaming read at half)")
+recs = []
+for k, c in sorted(kern.items()):
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        c["hbm_bytes_per_launch"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+    rec = {"kernel": k}
+    if k in workload:
+        rec["rows"], rec["length"] = workload[k]
+    rec.update(c)
+    recs.append(rec)
+    if "hbm_bytes_per_launch" in c and k in workload:
+        rows, length = workload[k]
+        print("  %-56s %8d x %-6d %.4g B  (8 N + 16 per row: %.4g B)" % (k[:56], rows, length, c["hbm_bytes_per_launch"], rows * (8.0 * length + 16)))
+json.dump({"collected_at_commit": os.environ.get("PROFILE_COMMIT"), "csrc_sha": csrc_sha(),
+           "method": "rocprofv3 --kernel-trace --stats, then --pmc FETCH_SIZE / WRITE_SIZE / two SQ sets in separate runs of `bench.py --steps 4 "
+                     "--warmup 1 --no-cpu-baseline` (tools/profile.sh); means over each kernel's launches; hbm_bytes_per_launch = "
+                     "(2 FETCH_SIZE + WRITE_SIZE) KB (MI355X_MICROARCH.md, HBM: gfx950 FETCH_SIZE counts wide streaming reads at half)",
+           "kernels": recs}, open(os.path.join(out, "counters.json"), "w"), indent=1)
