@@ -541,13 +541,20 @@ __global__ __launch_bounds__((LOGN >= 11 ? (1 << LOGN) / 16 : 256), 4) void xcor
         asm volatile("" : "+v"(jr)); // (offsets derived per request, not hoisted)
         jr &= S - 1;                 // (the range the compiler no longer sees: keeps global offsets 32-bit, saddr + voffset loads)
         const double *ra = p.rows + rA * p.stride, *rb = p.rows + (hasB ? rA + 1 : rA) * p.stride;
+        // PADDED: the elements i S .. (i + 1) S - 1 of the padded series are all pad when (i + 1) S <= pad (a wave-uniform
+        // test; pad < n / 2, so only i < 8 can be).  Such a request would fetch the end of the previous row from HBM only to be
+        // masked (N = 5000 -> n = 8192: six of the sixteen requests, N = 480 -> 512: one): it is pointed at the row's own
+        // first S samples instead -- the same unconditional load instruction (a branch around it parks the row registers in
+        // scratch), an L2 hit instead of HBM bytes.
+        const auto all_pad = [&](int i) __attribute__((always_inline)) { return PADDED && i < 8 && (i + 1) * S <= pad; };
         if (S >= 64) { // the wave works on one pair: scalar bases + the shared VGPR offset 8 j
             KA = scalar_ptr(ra)[0];
             KB = scalar_ptr(rb)[0];
 #pragma unroll
             for (int i = 0; i < 16; i++) {
-                xa[i] = __builtin_nontemporal_load(scalar_ptr_at(ra - pad, i * S) + (unsigned)jr);
-                xb[i] = __builtin_nontemporal_load(scalar_ptr_at(rb - pad, i * S) + (unsigned)jr);
+                const long long off = all_pad(i) ? 0ll : (long long)i * S - pad;
+                xa[i] = __builtin_nontemporal_load(scalar_ptr_at(ra, off) + (unsigned)jr);
+                xb[i] = __builtin_nontemporal_load(scalar_ptr_at(rb, off) + (unsigned)jr);
             }
         } else { // two pairs per wave: one 64-bit base per lane and row, immediate offsets 256 i bytes
             KA = ra[0];
@@ -555,8 +562,8 @@ __global__ __launch_bounds__((LOGN >= 11 ? (1 << LOGN) / 16 : 256), 4) void xcor
             const double *la = ra - pad + jr, *lb = rb - pad + jr;
 #pragma unroll
             for (int i = 0; i < 16; i++) {
-                xa[i] = __builtin_nontemporal_load(la + i * S);
-                xb[i] = __builtin_nontemporal_load(lb + i * S);
+                xa[i] = __builtin_nontemporal_load(all_pad(i) ? ra + jr : la + i * S);
+                xb[i] = __builtin_nontemporal_load(all_pad(i) ? rb + jr : lb + i * S);
             }
         }
     };
