@@ -36,8 +36,14 @@ __device__ __forceinline__ void exchange_cross(double2 (&v)[16], double2 *xbuf, 
 {
     const int t = t_;
     const int hi = t >> 4, lo = t & 15;
-    const int wbase = MODE ? 17 * lo + hi : (wcol >= 0 ? wcol : t);
-    const int rbase = 272 * (hi & 7) + (MODE ? 17 * lo : lo);
+    // relabelled writers (wcol >= 0: lanes 0-31 of a wave hold the even columns, lanes 32-63 the odd ones) would put the eight
+    // lanes of a ds_write_b128 group on every second 16-byte slot (2-way conflicts: SQ_LDS_BANK_CONFLICT 11 % of the LDS
+    // cycles); the image then keeps column c of a row at slot (c & ~15) | rot4(c & 15), rot4 = the low four bits rotated right
+    // by one: eight consecutive even (or odd) columns land on eight consecutive slots, and a reader's sixteen lanes (distinct
+    // lo) still hit sixteen different slots modulo 16
+    const auto rot4 = [](int c) { return (c & ~15) | ((c & 15) >> 1) | ((c & 1) << 3); };
+    const int wbase = MODE ? 17 * lo + hi : (wcol >= 0 ? rot4(wcol) : t);
+    const int rbase = 272 * (hi & 7) + (MODE ? 17 * lo : (wcol >= 0 ? rot4(lo) : lo));
     const bool early = wave < 2;
     lds_barrier(); // buffer free: every wave is done with its previous (wave-local or shared) use
 #pragma unroll
@@ -78,8 +84,9 @@ template <int MODE, int PERM>
 __device__ __forceinline__ void exchange_cross_full(double2 (&v)[16], double2 *xbuf, const int t, const int wcol = -1)
 {
     const int hi = t >> 4, lo = t & 15;
-    const int wbase = MODE ? 17 * lo + hi : (wcol >= 0 ? wcol : t);
-    const int rbase = 272 * hi + (MODE ? 17 * lo : lo);
+    const auto rot4 = [](int c) { return (c & ~15) | ((c & 15) >> 1) | ((c & 1) << 3); }; // (see exchange_cross)
+    const int wbase = MODE ? 17 * lo + hi : (wcol >= 0 ? rot4(wcol) : t);
+    const int rbase = 272 * hi + (MODE ? 17 * lo : (wcol >= 0 ? rot4(lo) : lo));
     lds_barrier(); // buffer free: every wave is done with its previous (wave-local or shared) use
 #pragma unroll
     for (int k = 0; k < 16; k++)

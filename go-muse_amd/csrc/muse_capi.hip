@@ -507,8 +507,9 @@ extern "C" int muse_group_create(muse_ctx *ctx, int64_t capacity_rows, int32_t N
 }
 extern "C" int muse_group_create_f32(muse_ctx *ctx, int64_t capacity_rows, int32_t N, muse_group **out)
 {
-    if (N <= 2048 || N > 4096) // (the float32-row loaders are built into the n = 4096 kernels)
-        return fail(MUSE_ERR_UNSUPPORTED, "float32-storage groups are built for series of length 2049 .. 4096 (got %d)", N);
+    // (the float32-row loaders are built into the kernels automatic selection takes for FFT lengths 512 ... 16384)
+    if (N <= 256 || N > 16384)
+        return fail(MUSE_ERR_UNSUPPORTED, "float32-storage groups are built for series of length 257 .. 16384 (got %d)", N);
     return group_create(ctx, capacity_rows, N, true, out);
 }
 static int group_create(muse_ctx *ctx, int64_t capacity_rows, int32_t N, bool f32, muse_group **out)
@@ -1145,6 +1146,8 @@ extern "C" int muse_batch_score(muse_batch *b)
         if (variant == KERNEL_R16_FOLD && ctx->variant == 0 && b->handoff_host && b->handoff_M == M &&
             (long long)*(volatile int *)b->handoff_host * 8 > p.npairs)
             variant = KERNEL_R16_OCC3;
+    } else if (b->g->f32 && !(((b->n >= 512 && b->n <= 2048) || b->n == 8192 || b->n == 16384) && (ctx->variant == 0 || ctx->variant == 12))) {
+        return fail(MUSE_ERR_UNSUPPORTED, "float32-storage groups run on the default kernels only (FFT lengths 512 ... 16384)");
     } else if (b->xcp && p.twl && (b->N == b->n || b->c1) && ((b->n >= 32768 && ctx->variant == 0) || (b->n >= 16384 && ctx->variant == 13))) {
         variant = KERNEL_LONG; // four-step, 4096-point rows on the n = 4096 kernel's transforms (xcorr_long.hip)
     } else if (((b->n >= 512 && b->n <= 2048) || b->n == 8192 || b->n == 16384) && (ctx->variant == 0 || ctx->variant == 12)) {
@@ -1657,7 +1660,7 @@ extern "C" int muse_batch_kernel_name(muse_batch *b, char *name, int32_t cap)
     if (b->n == 4096)
         snprintf(k, sizeof(k), "xcorr_fused_n4096_fold<false, %s, %s>", padded ? "true" : "false", b->g->f32 ? "true" : "false");
     else if ((b->n >= 512 && b->n <= 2048) || b->n == 8192 || b->n == 16384)
-        snprintf(k, sizeof(k), "xcorr_fused_small<%d, %s, false>", b->logn, padded ? "true" : "false");
+        snprintf(k, sizeof(k), "xcorr_fused_small<%d, %s, false%s>", b->logn, padded ? "true" : "false", b->g->f32 ? ", true" : ", false");
     else if (b->n > 16384)
         snprintf(k, sizeof(k), "xcorr_fused_long<%d, %s>", b->logn, padded ? "true" : "false");
     snprintf(name, (size_t)cap, "%s", k);

@@ -488,7 +488,9 @@ __device__ __forceinline__ T *uniform_ptr(T *ptr)
 // MULTI: R references against the group in one pass (muse_batch_score_many): rows are loaded, reduced and transformed
 // once; the pair's spectrum is parked lane-ordered in the workgroup's slice of p.zscratch (L2 / MALL resident, every
 // thread re-reads only what it wrote) and every reference takes product, second transform and argmax from there.
-template <int LOGN, bool PADDED, bool MULTI>
+// F32: float32-storage group (muse_group_create_f32, opt-in): the rows are float32 in HBM, widened exactly as they are
+// consumed; the arithmetic is the float64 arithmetic of the float64 groups.
+template <int LOGN, bool PADDED, bool MULTI, bool F32 = false>
 __global__ __launch_bounds__((LOGN >= 11 ? (1 << LOGN) / 16 : 256), 4) void xcorr_fused_small(const FusedParams p)
 {
     using namespace occ4;
@@ -540,6 +542,30 @@ __global__ __launch_bounds__((LOGN >= 11 ? (1 << LOGN) / 16 : 256), 4) void xcor
         int jr = j;
         asm volatile("" : "+v"(jr)); // (offsets derived per request, not hoisted)
         jr &= S - 1;                 // (the range the compiler no longer sees: keeps global offsets 32-bit, saddr + voffset loads)
+        if (F32) { // the same requests on float32 rows (half the bytes per request)
+            const float *ra = p.rows32 + rA * p.stride, *rb = p.rows32 + (hasB ? rA + 1 : rA) * p.stride;
+            const auto all_pad = [&](int i) __attribute__((always_inline)) { return PADDED && i < 8 && (i + 1) * S <= pad; };
+            if (S >= 64) {
+                KA = (double)scalar_ptr(ra)[0];
+                KB = (double)scalar_ptr(rb)[0];
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const long long off = all_pad(i) ? 0ll : (long long)i * S - pad;
+                    xa[i] = (double)__builtin_nontemporal_load(scalar_ptr_at(ra, off) + (unsigned)jr);
+                    xb[i] = (double)__builtin_nontemporal_load(scalar_ptr_at(rb, off) + (unsigned)jr);
+                }
+            } else {
+                KA = (double)ra[0];
+                KB = (double)rb[0];
+                const float *la = ra - pad + jr, *lb = rb - pad + jr;
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    xa[i] = (double)__builtin_nontemporal_load(all_pad(i) ? ra + jr : la + i * S);
+                    xb[i] = (double)__builtin_nontemporal_load(all_pad(i) ? rb + jr : lb + i * S);
+                }
+            }
+            return;
+        }
         const double *ra = p.rows + rA * p.stride, *rb = p.rows + (hasB ? rA + 1 : rA) * p.stride;
         // PADDED: the elements i S .. (i + 1) S - 1 of the padded series are all pad when (i + 1) S <= pad (a wave-uniform
         // test; pad < n / 2, so only i < 8 can be).  Such a request would fetch the end of the previous row from HBM only to be
@@ -760,7 +786,12 @@ static hipError_t launch_small_n(const FusedParams &p, int num_cus, hipStream_t 
         return hipGetLastError();
     }
     const long long grid = std::min<long long>(ngroups, (long long)num_cus * (1024 / TPB) * 8);
-    if (p.N < (1 << LOGN))
+    if (p.rows32) {
+        if (p.N < (1 << LOGN))
+            hipLaunchKernelGGL((xcorr_fused_small<LOGN, true, false, true>), dim3((unsigned)grid), dim3(TPB), 0, stream, p);
+        else
+            hipLaunchKernelGGL((xcorr_fused_small<LOGN, false, false, true>), dim3((unsigned)grid), dim3(TPB), 0, stream, p);
+    } else if (p.N < (1 << LOGN))
         hipLaunchKernelGGL((xcorr_fused_small<LOGN, true, false>), dim3((unsigned)grid), dim3(TPB), 0, stream, p);
     else
         hipLaunchKernelGGL((xcorr_fused_small<LOGN, false, false>), dim3((unsigned)grid), dim3(TPB), 0, stream, p);
@@ -773,7 +804,7 @@ static hipError_t launch_small_n(const FusedParams &p, int num_cus, hipStream_t 
 hipError_t launch_fused_small(const FusedParams &p, int num_cus, hipStream_t stream)
 {
     static_assert((1 << 14) <= SMALL_MAX_N, "the largest length built below");
-    if (!p.rows || !p.twm || (!p.xc && p.R <= 1) || !p.gsmall)
+    if ((!p.rows && !p.rows32) || !p.twm || (!p.xc && p.R <= 1) || !p.gsmall || (p.rows32 && p.R > 1))
         return hipErrorInvalidValue;
     switch (p.logn) {
     case 9: return launch_small_n<9>(p, num_cus, stream);

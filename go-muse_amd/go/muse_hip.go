@@ -145,6 +145,40 @@ func SetScreening(enable bool, minRows int) error {
 	return hipError(C.muse_ctx_set_screening(e.ctx, v))
 }
 
+// appendSeries uploads series (all of length n) to a device group in slabs of up to 32 MB packed in C memory: one cgo
+// call per slab instead of one per Series (a million calls for a million-series Group), and no Go pointer crosses.
+func appendSeries(g *C.muse_group, series []*Series, n int) error {
+	if len(series) == 0 {
+		return nil
+	}
+	rowsPerSlab := (32 << 20) / (8 * n)
+	if rowsPerSlab < 1 {
+		rowsPerSlab = 1
+	}
+	if rowsPerSlab > len(series) {
+		rowsPerSlab = len(series)
+	}
+	buf := (*C.double)(C.malloc(C.size_t(rowsPerSlab) * C.size_t(n) * 8))
+	if buf == nil {
+		return errors.New("out of memory staging series for upload")
+	}
+	defer C.free(unsafe.Pointer(buf))
+	slab := unsafe.Slice((*float64)(unsafe.Pointer(buf)), rowsPerSlab*n)
+	for i := 0; i < len(series); i += rowsPerSlab {
+		k := rowsPerSlab
+		if k > len(series)-i {
+			k = len(series) - i
+		}
+		for r := 0; r < k; r++ {
+			copy(slab[r*n:(r+1)*n], series[i+r].y)
+		}
+		if err := hipError(C.muse_group_append(g, buf, C.int64_t(k), C.int64_t(n))); err != nil {
+			return err
+		}
+	}
+	return nil
+}
+
 // deviceGroup mirrors Group's rows on the GPU; rows are appended once.
 type deviceGroup struct {
 	g        *C.muse_group
@@ -168,12 +202,11 @@ func (g *Group) residentRows(e *engine) (*C.muse_group, error) {
 		runtime.SetFinalizer(d, func(d *deviceGroup) { C.muse_group_free(d.g) })
 		g.dev = d
 	}
-	for ; g.dev.uploaded < len(g.order); g.dev.uploaded++ {
-		y := g.order[g.dev.uploaded].y
-		st := C.muse_group_append(g.dev.g, (*C.double)(unsafe.Pointer(&y[0])), 1, C.int64_t(len(y)))
-		if err := hipError(st); err != nil {
+	if g.dev.uploaded < len(g.order) {
+		if err := appendSeries(g.dev.g, g.order[g.dev.uploaded:], g.n); err != nil {
 			return nil, err
 		}
+		g.dev.uploaded = len(g.order)
 	}
 	return g.dev.g, nil
 }
@@ -224,11 +257,11 @@ func (g *Group) residentShards(es []*engine) ([]*groupShard, error) {
 		g.shards[len(g.shards)-1].hi = len(g.order) // series added since the cut
 	}
 	for _, sh := range g.shards {
-		for ; sh.lo+sh.uploaded < sh.hi; sh.uploaded++ {
-			y := g.order[sh.lo+sh.uploaded].y
-			if err := hipError(C.muse_group_append(sh.g, (*C.double)(unsafe.Pointer(&y[0])), 1, C.int64_t(len(y)))); err != nil {
+		if sh.lo+sh.uploaded < sh.hi {
+			if err := appendSeries(sh.g, g.order[sh.lo+sh.uploaded:sh.hi], g.n); err != nil {
 				return nil, err
 			}
+			sh.uploaded = sh.hi - sh.lo
 		}
 	}
 	return g.shards, nil

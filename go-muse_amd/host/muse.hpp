@@ -255,9 +255,10 @@ public:
         }
         if (!shards_.empty())
             shards_.back().hi = order_.size(); // series added since the cut
-        for (auto &sh : shards_)
-            for (; sh.lo + sh.uploaded < sh.hi; sh.uploaded++)
-                check(muse_group_append(sh.dev, order_[sh.lo + sh.uploaded]->Values().data(), 1, n_));
+        for (auto &sh : shards_) {
+            append_rows(sh.dev, sh.lo + sh.uploaded, sh.hi);
+            sh.uploaded = sh.hi - sh.lo;
+        }
         return shards_;
     }
 
@@ -272,12 +273,26 @@ public:
             uploaded_ = 0;
             check(muse_group_create(eng->handle(), (int64_t)order_.size(), n_ > 0 ? n_ : 1, &dev_));
         }
-        for (; uploaded_ < order_.size(); uploaded_++)
-            check(muse_group_append(dev_, order_[uploaded_]->Values().data(), 1, n_));
+        append_rows(dev_, uploaded_, order_.size());
+        uploaded_ = order_.size();
         return dev_;
     }
 
 private:
+    // series [first, last) to a device group in slabs of up to 32 MB: one C-ABI call per slab, not per Series
+    void append_rows(muse_group *dev, size_t first, size_t last)
+    {
+        if (first >= last)
+            return;
+        const size_t per = std::max<size_t>(1, std::min<size_t>(last - first, ((size_t)32 << 20) / (8 * (size_t)n_)));
+        std::vector<double> slab(per * (size_t)n_);
+        for (size_t i = first; i < last; i += per) {
+            const size_t k = std::min(per, last - i);
+            for (size_t r = 0; r < k; r++)
+                std::copy(order_[i + r]->Values().begin(), order_[i + r]->Values().end(), slab.begin() + r * (size_t)n_);
+            check(muse_group_append(dev, slab.data(), (int64_t)k, n_));
+        }
+    }
     void free_shards()
     {
         for (auto &sh : shards_)

@@ -124,9 +124,10 @@ int muse_group_create(muse_ctx *ctx, int64_t capacity_rows, int32_t N,
  * muse_group_append narrows the caller's float64 samples (round to nearest) on the way in, so scores are those of
  * the reference applied to the ROUNDED inputs, not to the caller's: they no longer match the float64 reference to
  * 1e-6 in general (relative input perturbation 6e-8 per sample), which is why this is never the default.
- * Built for series of length 2049 .. 4096 (FFT length 4096); MUSE_ERR_UNSUPPORTED otherwise.  Such a group works
- * with muse_batch_create / _score(s) / _run / _run_shard / _score_many (one pass per reference); the opt-in
- * filter-and-refine Run does not apply to it.  muse_group_read returns the stored values widened to float64. */
+ * Built for series of length 257 .. 16384 (FFT lengths 512 ... 16384: the float32-row loaders live in the kernels
+ * automatic selection takes for them); MUSE_ERR_UNSUPPORTED otherwise.  Such a group works with muse_batch_create /
+ * _score(s) / _run / _run_shard / _run_groups / _score_many (one pass per reference); the opt-in filter-and-refine
+ * Run and the two-sided xCorr do not apply to it.  muse_group_read returns the stored values widened to float64. */
 int muse_group_create_f32(muse_ctx *ctx, int64_t capacity_rows, int32_t N,
                           muse_group **out);
 /* Appends count rows read from host memory (row_stride in doubles, >= N).

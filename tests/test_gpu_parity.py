@@ -1437,7 +1437,7 @@ def test_screened_run_soak_1m_rows(muse, eng):
         db.close()
 
 
-@pytest.mark.parametrize("N", [4096, 3000])
+@pytest.mark.parametrize("N", [4096, 3000, 512, 480, 1000, 2048, 1500, 5000, 8192, 16384, 10000])
 def test_f32_storage_group_matches_oracle_on_rounded_rows(muse, eng, oracle, N):
     """SURVEY 8f-3, opt-in float32-STORAGE group: rows are rounded to float32 on the way in and widened exactly when the
     kernels consume them; arithmetic stays float64.  So the scores equal the oracle's on the ROUNDED rows (read back
@@ -1445,7 +1445,7 @@ def test_f32_storage_group_matches_oracle_on_rounded_rows(muse, eng, oracle, N):
     pairs with sigmas far apart (hand-off kernel reading float32 rows too), an odd row count, appends in several
     pieces -- and differ from the float64 group's scores only by the input rounding."""
     rng = np.random.default_rng(909 + N)
-    M = 515
+    M = 515 if N <= 4096 else 131
     ref = rng.standard_normal(N)
     rows = rng.standard_normal((M, N))
     rows[::4] += rng.uniform(-3, 3, size=(len(rows[::4]), 1)) * np.roll(ref, 5)
@@ -1478,7 +1478,9 @@ def test_f32_storage_group_matches_oracle_on_rounded_rows(muse, eng, oracle, N):
     assert np.array_equal(lag[ok], lag64[ok])
     assert np.nanmax(np.abs(mv[ok] - mv64[ok])) < 1e-5
     with pytest.raises(muse.MuseError):
-        muse.DeviceGroup(eng, 1000, 0, f32=True)       # built for 2049 .. 4096 only
+        muse.DeviceGroup(eng, 200, 0, f32=True)        # built for 257 .. 16384 only (FFT lengths 512 ... 16384)
+    with pytest.raises(muse.MuseError):
+        muse.DeviceGroup(eng, 20000, 0, f32=True)
     db.close()
     d64.close()
 
