@@ -91,20 +91,18 @@ class Counters:
 
 
 def clock_stats(mhz):
-    """the probe runs a little longer than the timed launches: windows at the idle clock (before the first / after the last
-    launch) are told apart from the ones under load by the clock itself (tools/clock_trace.py: 2.4 GHz idle, ~1.8 GHz within
-    30 ms of the first launch of the fp64 kernel) when the two differ by more than 5 %"""
+    """the probe runs from just before the first timed launch to just behind the last one: every window is a sample of the
+    clock the chip held over the timed region (tools/clock_trace.py: 2.4 GHz idle, down to ~1.3 GHz within 5 ms of the first
+    launch of the fp64 kernel, ~1.8 GHz from 30 ms on, short boosts in the gaps between launches)"""
     import numpy as np
     mhz = np.asarray(mhz, dtype=float)
     mhz = mhz[mhz > 0]
     if not len(mhz):
         return None
-    lo, hi = np.percentile(mhz, 10), np.percentile(mhz, 90)
-    load = mhz[mhz < 0.5 * (lo + hi)] if hi > 1.05 * lo else mhz
-    return {"median_mhz": float(np.median(load)), "p10_mhz": float(np.percentile(load, 10)), "p90_mhz": float(np.percentile(load, 90)),
-            "windows_under_load": int(len(load)), "windows": int(len(mhz)), "idle_mhz": float(mhz.max()),
-            "method": "one probe wave beside the timed launches: delta s_memtime / delta s_memrealtime x 100 MHz per 1 ms window "
-                      "(muse_test_clock_probe_*); median over the windows under load"}
+    return {"median_mhz": float(np.median(mhz)), "mean_mhz": float(mhz.mean()), "p10_mhz": float(np.percentile(mhz, 10)),
+            "p90_mhz": float(np.percentile(mhz, 90)), "windows": int(len(mhz)),
+            "method": "one probe wave resident beside the timed launches: delta s_memtime / delta s_memrealtime x 100 MHz per 0.5 ms "
+                      "window (muse_test_clock_probe_*), all windows of the timed region"}
 
 
 def cpu_baseline(dg, ref, N):
@@ -256,34 +254,35 @@ def main():
             torch.cuda.synchronize()
 
     # the shader clock held under this load (prices the fp64-VALU / LDS ceilings below): a one-wave probe kernel on its own
-    # stream, started ahead of the LAST warm-up step so that it is resident when the timed region begins
+    # stream, started BEHIND the synchronisation that opens the timed region (a device-wide synchronize would wait for it) and
+    # resident before the first timed launch; stopped by a host flag in front of the synchronisation that closes the region
     probing = n_gpus == 1 and not use_dist
     est_ms = 15.0 * max(1.0, M * N / 4.096e9)
-
-    def start_probe():
-        eng.clock_probe_start(1.0, min(50000.0, est_ms * (args.steps + 2) * 1.3 + 30.0))
-
     for i in range(args.warmup):
-        if probing and i == args.warmup - 1:
-            start_probe()
         t0 = time.perf_counter()
         step()
         if i == 0:
             fence()
             est_ms = (time.perf_counter() - t0) * 1e3
-    if probing and args.warmup == 0:
-        start_probe()
     fence()
     eng.kernel_time()                                   # drop warm-up events
     eng.kernel_timing(True)
+    if probing:
+        eng.clock_probe_start(0.5, min(50000.0, est_ms * (args.steps + 2) * 1.5 + 30.0))   # returns once the probe is resident
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
+    if probing:
+        eng.clock_probe_stop()                          # (a host flag: the device-wide synchronize below must not wait for the probe)
     fence()
     dt = time.perf_counter() - t0
     eng.kernel_timing(False)
     k_ms, k_cnt = eng.kernel_time()
-    sclk = clock_stats(eng.clock_probe_read()) if probing else None
+    raw_mhz = eng.clock_probe_read() if probing else None
+    if probing and os.environ.get("MUSE_BENCH_DUMP_CLOCK"):
+        import numpy as np
+        np.savetxt(os.environ["MUSE_BENCH_DUMP_CLOCK"], raw_mhz, fmt="%.0f")
+    sclk = clock_stats(raw_mhz) if probing else None
     if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=tdev if tdev is not None else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

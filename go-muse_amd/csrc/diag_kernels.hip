@@ -13,17 +13,20 @@ namespace muse {
 // windows of ~window_ticks of the 100 MHz clock until total_ticks have passed (or the buffer is full): out[2 w] = shader
 // ticks, out[2 w + 1] = 100 MHz ticks of window w; *count = windows written.  One wave, a handful of registers: it fits
 // next to the resident grids of the product kernels and sleeps between samples.
+// count[1] is a stop flag the host may set (pinned memory): the probe then ends within one sleep (~4 us), so that a
+// device-wide synchronisation behind the measured launches does not wait out the rest of total_ticks.
 __global__ __launch_bounds__(64, 1) void clock_probe_kernel(unsigned long long *out, int *count, int max_windows,
                                                             unsigned long long window_ticks, unsigned long long total_ticks)
 {
     if (threadIdx.x != 0)
         return;
     const unsigned long long r_begin = __builtin_amdgcn_s_memrealtime();
+    const volatile int *stop = count + 1;
     int w = 0;
-    for (; w < max_windows; w++) {
+    for (; w < max_windows && !*stop; w++) {
         const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
         unsigned long long r1 = r0;
-        while (r1 - r0 < window_ticks) {
+        while (r1 - r0 < window_ticks && !*stop) {
             __builtin_amdgcn_s_sleep(127);
             r1 = __builtin_amdgcn_s_memrealtime();
         }
@@ -31,12 +34,15 @@ __global__ __launch_bounds__(64, 1) void clock_probe_kernel(unsigned long long *
         r1 = __builtin_amdgcn_s_memrealtime();
         out[2 * w] = t1 - t0;
         out[2 * w + 1] = r1 - r0;
+        __threadfence_system();
+        *(volatile int *)count = w + 1; // (the host polls this to know the probe is resident before it starts its launches)
         if (r1 - r_begin >= total_ticks) {
             w++;
             break;
         }
     }
-    *count = w;
+    __threadfence_system();
+    *(volatile int *)count = w;
 }
 
 hipError_t launch_clock_probe(unsigned long long *out, int *count, int max_windows, double window_ms, double total_ms,

@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <limits>
 #include <new>
 #include <string>
@@ -2599,6 +2600,16 @@ extern "C" int muse_xcorr_batch(muse_ctx *ctx, const double *x_rows, const doubl
 
 // ---- measurement hook: the shader clock held while other kernels of the process run (diag_kernels.hip)
 constexpr int PROBE_WINDOWS = 4096;
+// ends a running probe early (host flag in the pinned buffer: no GPU call)
+extern "C" int muse_test_clock_probe_stop(muse_ctx *ctx)
+{
+    if (!ctx)
+        return fail(MUSE_ERR_INVALID, "NULL context");
+    if (ctx->probe_buf)
+        *((volatile int *)(ctx->probe_buf + 2 * PROBE_WINDOWS) + 1) = 1;
+    return MUSE_OK;
+}
+
 extern "C" int muse_test_clock_probe_start(muse_ctx *ctx, double window_ms, double total_ms)
 {
     int rc = use_device(ctx);
@@ -2614,6 +2625,15 @@ extern "C" int muse_test_clock_probe_start(muse_ctx *ctx, double window_ms, doub
     memset(ctx->probe_buf, 0, (2 * PROBE_WINDOWS + 1) * sizeof(unsigned long long));
     HIP_TRY(launch_clock_probe(ctx->probe_buf, (int *)(ctx->probe_buf + 2 * PROBE_WINDOWS), PROBE_WINDOWS, window_ms, total_ms,
                                ctx->probe_stream));
+    // return once the probe is RESIDENT (its first window has landed in the pinned buffer): launched behind a grid that fills
+    // the chip it would only start when that grid has drained, and sample an idle GPU
+    volatile int *cnt = (volatile int *)(ctx->probe_buf + 2 * PROBE_WINDOWS);
+    for (int spin = 0; *cnt == 0 && spin < 20000; spin++) { // <= ~2 s
+        struct timespec ts = {0, 100000};
+        nanosleep(&ts, nullptr);
+    }
+    if (*cnt == 0)
+        return fail(MUSE_ERR_HIP, "clock probe did not start");
     return MUSE_OK;
 }
 

@@ -76,6 +76,9 @@ class Engine:
         """measurement hook: a one-wave kernel samples the shader clock for total_ms while the caller's kernels run"""
         B.check(B.load().muse_test_clock_probe_start(self._h, float(window_ms), float(total_ms)))
 
+    def clock_probe_stop(self):
+        B.check(B.load().muse_test_clock_probe_stop(self._h))
+
     def clock_probe_read(self):
         """waits for the probe; the clock of every window in MHz"""
         mhz = np.zeros(4096)

@@ -31,8 +31,11 @@ int muse_batch_screen_estimates(muse_batch *b, int32_t max_lag, double *estimate
 
 /* Shader clock held under load (bench.py's roofline.co_bounds): starts a one-wave kernel on a stream of its own that, for
  * total_ms, samples delta s_memtime / delta s_memrealtime x 100 MHz (MI355X_MICROARCH.md) in windows of window_ms while
- * the caller launches its kernels; _read waits for it and returns the clock of every window (MHz) in order. */
+ * the caller launches its kernels; _read waits for it and returns the clock of every window (MHz) in order.
+ * _start returns once the probe is resident; _stop ends it within microseconds (a host flag), so that a device-wide
+ * synchronisation behind the measured launches does not wait out the rest of total_ms. */
 int muse_test_clock_probe_start(muse_ctx *ctx, double window_ms, double total_ms);
+int muse_test_clock_probe_stop(muse_ctx *ctx);
 int muse_test_clock_probe_read(muse_ctx *ctx, double *mhz, int32_t cap, int32_t *windows);
 
 #ifdef __cplusplus
