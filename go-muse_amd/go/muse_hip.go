@@ -8,6 +8,7 @@
 // xcorr.go's hot loop.  Every cgo call copies its inputs (no Go pointer is
 // retained by C after the call returns), as the cgo pointer rules require.
 //
+// Needs Go >= 1.17 (unsafe.Slice / unsafe.Add over C memory; the reference's go.mod says 1.13).
 // Build: CGO_CFLAGS="-I${REPO}/include" CGO_LDFLAGS="-L${REPO}/go-muse_amd/lib -lmuse_hip"
 package muse
 
