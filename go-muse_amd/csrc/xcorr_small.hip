@@ -465,8 +465,11 @@ template <int LOGN>
 __device__ __forceinline__ int column_of_lane(const int l)
 {
     const int rg = ((l >> 4) ^ (l >> 3) ^ (l >> 2)) & 1;
-    if (LOGN == 9) // (measured: no gain at n = 512, where the relabelled half-round writers of transpose B spread over all write groups)
-        return l;
+    if (LOGN == 9) // n = 512: the register trade of transpose B (level()) pairs lane l with lane l + 16 as columns c and c + 16, so
+                   // column bit 4 must stay lane bit 4 and the read groups keep their pad-slot conflict;
+                   // column bit 3 ^= lane bit 2 still spreads the stride-2 writes of transpose A over all eight slots
+                   // (tools/lds_bank_sim.py: 16 -> 8 LDS cycles per store) and leaves transpose B's stores conflict-free
+        return (l & ~8) | ((((l >> 3) ^ (l >> 2)) & 1) << 3);
     const int b3 = ((l >> 3) ^ ((LOGN == 10 || LOGN == 14) ? (l >> 1) : l)) & 1;
     return (l & ~0x18) | (b3 << 3) | (rg << 4);
 }

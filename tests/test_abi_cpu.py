@@ -194,9 +194,14 @@ def test_lane_relabelling_removes_the_modelled_lds_bank_conflicts():
         rd, wa, wbs = sim.cycles(logn)
         assert (rd0, wa0) == (8, 16.0) and (rd, wa) == (4, 8.0)
         assert wbs[0] <= 8.0
-    # the kernel source carries the same map: the XOR terms of column bit 3 and the parity of column bit 4
+    # n = 512: column bit 4 must stay lane bit 4 (register trade of transpose B), so only the transpose-A stores are fixed
+    assert sorted(sim.column_of_lane(9, l) for l in range(32)) == list(range(32))
+    assert all(sim.column_of_lane(9, l + 16) == sim.column_of_lane(9, l) + 16 for l in range(16))
+    assert sim.cycles(9, identity=True)[:2] == (8, 16.0) and sim.cycles(9)[:2] == (8, 8.0)
+    # the kernel source carries the same maps: the XOR terms of column bit 3 and the parity of column bit 4
     src = open(os.path.join(root, "go-muse_amd", "csrc", "xcorr_small.hip")).read()
     assert "((l >> 4) ^ (l >> 3) ^ (l >> 2)) & 1" in src and "(LOGN == 10 || LOGN == 14) ? (l >> 1) : l" in src
+    assert "(l & ~8) | ((((l >> 3) ^ (l >> 2)) & 1) << 3)" in src
 
 
 def test_merge_group_records_semantics(muse):

@@ -41,9 +41,9 @@ def shape(logn):
 
 def column_of_lane(logn, lane):
     """xcorr_small.hip, column_of_lane<LOGN>()"""
-    if logn == 9:
-        return lane
     b = lambda k: (lane >> k) & 1
+    if logn == 9:
+        return (lane & ~8) | ((b(3) ^ b(2)) << 3)
     rg = b(4) ^ b(3) ^ b(2)
     b3 = b(3) ^ (b(1) if logn in (10, 14) else b(0))
     return (lane & ~0x18) | (b3 << 3) | (rg << 4)
