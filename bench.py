@@ -330,7 +330,7 @@ def main():
             co["fp64_valu_issue"] = {"vector_insts_per_launch": krec["SQ_INSTS_VALU"], "floor_ms": valu_ms,
                                      "kernel_over_floor": k_avg_s * 1e3 / valu_ms, "frac": valu_ms / (k_avg_s * 1e3),
                                      "note": "SQ_INSTS_VALU x 4 cycles / (%d CUs x 4 SIMDs) / measured clock: the time the kernel's "
-                                             "vector instructions (1 330 of ~1 530 per wave and pair are v_*_f64) need at full issue" % cus}
+                                             "vector instructions (~1 380 of ~1 610 per wave and pair are v_*_f64) need at full issue" % cus}
             co["lds_array"] = {"array_cycles_per_launch": krec["SQ_LDS_IDX_ACTIVE"], "bank_conflict_cycles": krec.get("SQ_LDS_BANK_CONFLICT"),
                                "floor_ms": lds_ms, "frac": lds_ms / (k_avg_s * 1e3),
                                "note": "SQ_LDS_IDX_ACTIVE / CUs / measured clock: the time the LDS arrays are busy"}
