@@ -461,6 +461,60 @@ def main():
             except Exception as e:
                 line["two_sided_xcorr"] = {"error": str(e)}
         if extras:
+            # SURVEY 8e inside ONE process (what NewBatch over a device list does: INTEGRATION.md): the same logical group cut into
+            # one contiguous row range per context, every shard scored at the same time from its own host thread, per-shard top-N
+            # records merged on the host.  With one GPU visible the contexts share it (device 0 listed twice): this exercises the
+            # path and prices its host side; it is NOT a scaling number.
+            try:
+                import threading
+                ndev = pkg.device_count()
+                devs = list(range(ndev)) if ndev > 1 else [0, 0]
+                per = 200_000
+                engs = [pkg.Engine(d) for d in devs]
+                parts = [pkg.DeviceGroup.synthetic(e, per, N, seed=0x6D757365, global_first=k * per) for k, e in enumerate(engs)]
+                sb = [pkg.DeviceBatch(e, g, ref) for e, (g, _) in zip(engs, parts)]
+                whole, _ = pkg.DeviceGroup.synthetic(eng, per * len(devs), N, seed=0x6D757365)
+                wb = pkg.DeviceBatch(eng, whole, ref)
+
+                def sharded():
+                    recs = [None] * len(sb)
+
+                    def work(k):
+                        recs[k] = sb[k].run_shard(None, 0, k * per, args.max_lag, args.top_n, 0.0, 0, True)
+                    th = [threading.Thread(target=work, args=(k,)) for k in range(len(sb))]
+                    for x in th:
+                        x.start()
+                    for x in th:
+                        x.join()
+                    return pkg.merge_records(np.concatenate(recs), args.top_n)
+
+                a = sharded()
+                b = wb.run(None, 0, args.max_lag, args.top_n, 0.0, 0, True)
+                same = a[0].tolist() == b[0].tolist() and a[1].tolist() == b[1].tolist() and np.array_equal(a[2], b[2])
+                reps = 5
+                t1 = time.perf_counter()
+                for _ in range(reps):
+                    sharded()
+                dsh = (time.perf_counter() - t1) / reps
+                t1 = time.perf_counter()
+                for _ in range(reps):
+                    wb.run(None, 0, args.max_lag, args.top_n, 0.0, 0, True)
+                dwh = (time.perf_counter() - t1) / reps
+                line["in_process_shards"] = {
+                    "devices": devs, "distinct_devices": ndev, "rows_per_shard": per, "length": N,
+                    "ms_per_run_sharded": dsh * 1e3, "ms_per_run_one_context_same_rows": dwh * 1e3,
+                    "value": per * len(devs) / dsh, "unit": "series-pairs/s", "records_identical_to_one_context": bool(same),
+                    "note": "one process, one muse_ctx + host thread per listed device, muse_batch_run_shard + muse_merge_records"
+                            + ("" if ndev > 1 else "; ONE GPU visible: both contexts share it -- a check of the path and of its host-side cost, not a scaling number")}
+                for x in sb:
+                    x.close()
+                wb.close()
+                whole.close()
+                for g, _ in parts:
+                    g.close()
+            except Exception as e:
+                line["in_process_shards"] = {"error": str(e)}
+        if extras:
             # BASELINE config 5's lengths (N zero-padded to the next power of two), float64: one all-scores pass per length
             # over a ~4 GB group of its own; per length the kernel automatic selection takes and its share of the HBM
             # roofline on 8 N + 16 algorithmic bytes per series.  Parity per length: tests/test_gpu_parity.py.

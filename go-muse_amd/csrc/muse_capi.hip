@@ -238,6 +238,45 @@ static int use_device(muse_ctx *ctx)
     return MUSE_OK;
 }
 
+// HIP-event bracket of ONE kernel launch on the context's stream (muse_ctx_kernel_timing): begin() right in front of the
+// launch, end() right behind it; a bracket that never reaches end() (an error return in between) destroys its events.
+struct LaunchTimer {
+    muse_ctx *ctx;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    explicit LaunchTimer(muse_ctx *c) : ctx(c) {}
+    LaunchTimer(const LaunchTimer &) = delete;
+    LaunchTimer &operator=(const LaunchTimer &) = delete;
+    hipError_t begin()
+    {
+        if (!ctx->timing)
+            return hipSuccess;
+        hipError_t e = hipEventCreate(&e0);
+        if (e == hipSuccess)
+            e = hipEventCreate(&e1);
+        if (e == hipSuccess)
+            e = hipEventRecord(e0, ctx->stream);
+        return e;
+    }
+    hipError_t end()
+    {
+        if (!e0 || !e1)
+            return hipSuccess;
+        const hipError_t e = hipEventRecord(e1, ctx->stream);
+        if (e == hipSuccess) {
+            ctx->events.emplace_back(e0, e1);
+            e0 = e1 = nullptr;
+        }
+        return e;
+    }
+    ~LaunchTimer()
+    {
+        if (e0)
+            (void)hipEventDestroy(e0);
+        if (e1)
+            (void)hipEventDestroy(e1);
+    }
+};
+
 // ----------------------------------------------------------------- context
 static void fill_twiddle(std::vector<double2> &v, size_t i, long long num, long long den)
 {
@@ -1158,12 +1197,7 @@ extern "C" int muse_batch_score(muse_batch *b)
     }
     if (variant == KERNEL_GENERIC && b->n <= GENERIC_LDS_MAX_N)
         p.gscratch = nullptr; // the generic kernel takes a non-NULL scratch pointer as "work in global memory"
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (ctx->timing) {
-        HIP_TRY(hipEventCreate(&e0));
-        HIP_TRY(hipEventCreate(&e1));
-        HIP_TRY(hipEventRecord(e0, ctx->stream));
-    }
+    LaunchTimer timer(ctx); // (brackets the fused launch alone: not the counter reset in front of it, not the redo launch behind it)
     if (variant == KERNEL_R16_FOLD) {
         // pairs with a NaN/Inf series or with sigmas too far apart for one shared transform are listed by the kernel
         // (once per such series: 2 entries per pair) and redone by the rescaling kernel right behind it (no host round
@@ -1179,7 +1213,9 @@ extern "C" int muse_batch_score(muse_batch *b)
         p.work_counter = b->ovf_count + 1;
         p.ovf_list = b->ovf_list;
         HIP_TRY(hipMemsetAsync(b->ovf_count, 0, 2 * sizeof(int), ctx->stream));
+        HIP_TRY(timer.begin());
         HIP_TRY(launch_fused(p, variant, ctx->num_cus, ctx->stream));
+        HIP_TRY(timer.end());
         FusedParams q = p;
         q.pair_list = b->ovf_list;
         q.pair_count = b->ovf_count;
@@ -1207,18 +1243,18 @@ extern "C" int muse_batch_score(muse_batch *b)
         p.ovf_count = b->ovf_count;
         p.ovf_list = b->ovf_list;
         HIP_TRY(hipMemsetAsync(b->ovf_count, 0, 2 * sizeof(int), ctx->stream));
+        HIP_TRY(timer.begin());
         HIP_TRY(launch_fused(p, variant, ctx->num_cus, ctx->stream));
+        HIP_TRY(timer.end());
         FusedParams q = p;
         q.pair_list = b->ovf_list;
         q.pair_count = b->ovf_count;
         q.npairs = std::min<long long>(p.npairs, (long long)ctx->num_cus * STOCKHAM_GLOBAL_WGS_PER_CU);
         HIP_TRY(launch_fused(q, KERNEL_STOCKHAM, ctx->num_cus, ctx->stream));
     } else {
+        HIP_TRY(timer.begin());
         HIP_TRY(launch_fused(p, variant, ctx->num_cus, ctx->stream));
-    }
-    if (ctx->timing) {
-        HIP_TRY(hipEventRecord(e1, ctx->stream));
-        ctx->events.emplace_back(e0, e1);
+        HIP_TRY(timer.end());
     }
     return MUSE_OK;
 }
@@ -1608,17 +1644,10 @@ static int score_screened(muse_batch *b, int32_t max_lag, int32_t top_n, double 
         scratch_lock.lock();
     // (Batch.Run filters the sign of |score|, Muse.Run that of the signed score: only the latter needs the pass's sign flags)
     const FusedParams p = screen_pass_params(b, max_lag, plan, sign_filter != 0 && !abs_scores);
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (ctx->timing) {
-        HIP_TRY(hipEventCreate(&e0));
-        HIP_TRY(hipEventCreate(&e1));
-        HIP_TRY(hipEventRecord(e0, ctx->stream));
-    }
+    LaunchTimer timer(ctx);
+    HIP_TRY(timer.begin());
     HIP_TRY(b->n == 4096 ? launch_screen_pass(p, ctx->num_cus, ctx->stream) : launch_screen_pass_stk(p, ctx->num_cus, ctx->stream));
-    if (ctx->timing) {
-        HIP_TRY(hipEventRecord(e1, ctx->stream));
-        ctx->events.emplace_back(e0, e1);
-    }
+    HIP_TRY(timer.end());
     return screen_finish(b, top_n, threshold, sign_filter, abs_scores, gid_dev, G, plan);
 }
 
@@ -2093,19 +2122,16 @@ extern "C" int muse_batch_score_many(muse_batch *const *bs, int32_t R)
     p.ovf_count = b0->ovf_count;
     p.work_counter = b0->ovf_count + 1;
     p.ovf_list = b0->ovf_list;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (ctx->timing) {
-        HIP_TRY(hipEventCreate(&e0));
-        HIP_TRY(hipEventCreate(&e1));
-        HIP_TRY(hipEventRecord(e0, ctx->stream));
-    }
+    LaunchTimer timer(ctx);
     HIP_TRY(hipMemsetAsync(b0->ovf_count, 0, 2 * sizeof(int), ctx->stream));
+    HIP_TRY(timer.begin());
     if (small_n) { // (this kernel isolates dead series itself: nothing is handed on)
         HIP_TRY(launch_fused_small(p, ctx->num_cus, ctx->stream));
         for (int r = 0; r < R; r++)
             bs[r]->scores_exact = true;
     } else
         HIP_TRY(launch_fused_multi(p, ctx->num_cus, ctx->stream));
+    HIP_TRY(timer.end());
     // pairs holding a NaN/Inf series (listed once, by reference 0): redone per reference by the
     // kernel that isolates the dead series before the shared transform
     for (int r = 0; r < R && !small_n; r++) {
@@ -2115,10 +2141,6 @@ extern "C" int muse_batch_score_many(muse_batch *const *bs, int32_t R)
         q.npairs = std::min<long long>(q.npairs, (long long)ctx->num_cus * 3);
         HIP_TRY(launch_fused(q, KERNEL_R16_OCC3, ctx->num_cus, ctx->stream));
         bs[r]->scores_exact = true; // mv / lag of every batch now hold fp64 results for every row
-    }
-    if (ctx->timing) {
-        HIP_TRY(hipEventRecord(e1, ctx->stream));
-        ctx->events.emplace_back(e0, e1);
     }
     return MUSE_OK;
 }
@@ -2205,17 +2227,10 @@ static int screen_many(muse_batch *const *bs, int32_t R, const int32_t *group_id
     p.var_many = (double *const *)((void **)ctx->many_tab + 4 * R);
     p.zscratch = ctx->zscratch;
     p.zslots = ctx->zslots;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (ctx->timing) {
-        HIP_TRY(hipEventCreate(&e0));
-        HIP_TRY(hipEventCreate(&e1));
-        HIP_TRY(hipEventRecord(e0, ctx->stream));
-    }
+    LaunchTimer timer(ctx);
+    HIP_TRY(timer.begin());
     HIP_TRY(launch_screen_pass_many(p, ctx->num_cus, ctx->stream));
-    if (ctx->timing) {
-        HIP_TRY(hipEventRecord(e1, ctx->stream));
-        ctx->events.emplace_back(e0, e1);
-    }
+    HIP_TRY(timer.end());
     for (int r = 0; r < R; r++) {
         rc = screen_finish(bs[r], top_n, threshold, sign_filter, abs_scores, group_id ? bs[r]->gid_dev : nullptr, G,
                            plan[(size_t)r]);
@@ -2538,21 +2553,12 @@ extern "C" int muse_xcorr_groups(muse_group *gx, muse_group *gy, int32_t n, int3
         p.lag = dlag;
         p.nil_out = dnil;
         p.cc_out = dcc;
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (ctx->timing) {
-            e = hipEventCreate(&e0);
-            if (e == hipSuccess)
-                e = hipEventCreate(&e1);
-            if (e == hipSuccess)
-                e = hipEventRecord(e0, ctx->stream);
-        }
+        LaunchTimer timer(ctx);
+        e = timer.begin();
         if (e == hipSuccess)
             e = launch_two_sided(p, ctx->num_cus, ctx->stream);
-        if (e == hipSuccess && ctx->timing) {
-            e = hipEventRecord(e1, ctx->stream);
-            if (e == hipSuccess)
-                ctx->events.emplace_back(e0, e1);
-        }
+        if (e == hipSuccess)
+            e = timer.end();
     }
     std::vector<int> nil((size_t)M);
     if (e == hipSuccess)
