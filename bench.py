@@ -414,7 +414,7 @@ def main():
             km_ms, km_cnt = eng.kernel_time()
             km_s = km_ms / max(km_cnt, 1) * 1e-3
             bm = float(M) * (8 * N + 16 * R)                      # every row read once, one result per (row, reference)
-            mk = "xcorr_fused_n4096_fold_multi<false>"
+            mk = "xcorr_fused_n4096_fold_multi<false, false>"
             line["many_references"] = {"references": R, "value": R * float(M) / dtm, "unit": "series-pairs/s",
                                        "ms_per_run": dtm * 1e3, "dtype": "f64", "kernel": mk, "rows": M, "length": N,
                                        "kernel_ms_avg": km_s * 1e3, "algorithmic_bytes_per_launch": bm,

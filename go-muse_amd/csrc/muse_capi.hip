@@ -2056,8 +2056,10 @@ extern "C" int muse_batch_score_many(muse_batch *const *bs, int32_t R)
     // the one-pass kernel is built for N == n == 4096 (and is only taken under automatic kernel
     // selection); everything else scores the batches one after the other
     const bool small_n = (b0->n >= 512 && b0->n <= 2048) || b0->n == 8192 || b0->n == 16384; // xcorr_small.hip's lengths
-    bool one_pass = R > 1 && !b0->g->f32 &&
-                    ((b0->n == 4096 && (ctx->variant == 0 || ctx->variant == 10)) || (small_n && (ctx->variant == 0 || ctx->variant == 12)));
+    // (float32-storage groups: the n = 4096 one-pass kernel reads them; the other lengths' one-pass builds do not)
+    bool one_pass = R > 1 &&
+                    ((b0->n == 4096 && (ctx->variant == 0 || ctx->variant == 10)) ||
+                     (small_n && !b0->g->f32 && (ctx->variant == 0 || ctx->variant == 12)));
     for (int r = 0; r < R && one_pass; r++)
         one_pass = bs[r]->N == b0->N && (small_n || b0->N == 4096 || bs[r]->c1 != nullptr);
     if (!one_pass) {

@@ -323,7 +323,8 @@ constexpr int MULTI_WGS_PER_CU = 2;
 
 // PADDED (2048 < N < 4096): the spectrum keeps its DC bin and every reference's results are corrected by
 // -m c1_r[index] (FusedParams::c1_many) before the argmax.
-template <bool PADDED = false>
+// F32: float32-storage group (rows widened as they are consumed, float64 arithmetic)
+template <bool PADDED = false, bool F32 = false>
 __global__ __launch_bounds__(OCC_THREADS, MULTI_WGS_PER_CU) void xcorr_fused_n4096_fold_multi(const FusedParams p)
 {
     using namespace occ4;
@@ -351,12 +352,12 @@ __global__ __launch_bounds__(OCC_THREADS, MULTI_WGS_PER_CU) void xcorr_fused_n40
     int ip = 0, pp = 0;
     const long long total = p.npairs;
     RawPair raw;
-    constexpr bool WIDE = !PADDED;
+    constexpr bool WIDE = !PADDED && !F32;
     const auto request_rows = [&](long long pr) __attribute__((always_inline)) {
         if (WIDE)
             issue_row_loads_wide(raw, p, pr, t);
         else
-            issue_row_loads<PADDED>(raw, p, pr, t, pad);
+            issue_row_loads<PADDED, F32>(raw, p, pr, t, pad);
     };
     request_rows(blockIdx.x < total ? (long long)blockIdx.x : 0ll);
     // reference r's sixteen spectrum factors of this thread (lane-ordered table, L2): requested one iteration ahead
@@ -516,14 +517,20 @@ __global__ __launch_bounds__(OCC_THREADS, MULTI_WGS_PER_CU) void xcorr_fused_n40
 hipError_t launch_fused_multi(const FusedParams &p, int num_cus, hipStream_t stream)
 {
     const long long grid = std::min<long long>(p.npairs, (long long)num_cus * MULTI_WGS_PER_CU);
-    if (!p.work_counter || p.R < 1 || !p.g2 || !p.g3a || !p.g3b || !p.xcp_many || !p.mv_many || !p.lag_many || p.rows32)
+    if (!p.work_counter || p.R < 1 || !p.g2 || !p.g3a || !p.g3b || !p.xcp_many || !p.mv_many || !p.lag_many)
         return hipErrorInvalidValue;
+    const dim3 g((unsigned)grid), b(OCC_THREADS);
     if (p.N < 4096) {
         if (!p.c1_many)
             return hipErrorInvalidValue;
-        hipLaunchKernelGGL((xcorr_fused_n4096_fold_multi<true>), dim3((unsigned)grid), dim3(OCC_THREADS), 0, stream, p);
+        if (p.rows32)
+            hipLaunchKernelGGL((xcorr_fused_n4096_fold_multi<true, true>), g, b, 0, stream, p);
+        else
+            hipLaunchKernelGGL((xcorr_fused_n4096_fold_multi<true, false>), g, b, 0, stream, p);
+    } else if (p.rows32) {
+        hipLaunchKernelGGL((xcorr_fused_n4096_fold_multi<false, true>), g, b, 0, stream, p);
     } else {
-        hipLaunchKernelGGL((xcorr_fused_n4096_fold_multi<false>), dim3((unsigned)grid), dim3(OCC_THREADS), 0, stream, p);
+        hipLaunchKernelGGL((xcorr_fused_n4096_fold_multi<false, false>), g, b, 0, stream, p);
     }
     return hipGetLastError();
 }

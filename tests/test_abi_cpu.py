@@ -57,6 +57,18 @@ def test_no_gpu_fails_loudly(muse):
     with pytest.raises(muse.MuseError) as e:
         muse.Engine(0)
     assert e.value.status == muse.binding.MUSE_ERR_NO_DEVICE
+    with pytest.raises(muse.MuseError) as e:          # the device set of a sharded Batch starts here: no device, no count
+        muse.device_count()
+    assert e.value.status == muse.binding.MUSE_ERR_NO_DEVICE
+    # the host entry points that need no device still answer (merges of shard records run on the host)
+    s, l, v, mean = muse.merge_records(np.zeros(0, dtype=muse.binding.RECORD_DTYPE), 5)
+    assert len(s) == 0 and math.isnan(mean)
+    x = np.zeros((2, 512))
+    import ctypes
+    lag, mv, nil = np.zeros(2, dtype=np.int32), np.zeros(2), np.zeros(2, dtype=np.int32)
+    rc = muse.binding.load().muse_xcorr_batch(None, muse.binding.dptr(x), muse.binding.dptr(x), 2, 512, 512, 512, 1,
+                                              muse.binding.i32ptr(lag), muse.binding.dptr(mv), muse.binding.i32ptr(nil), None)
+    assert rc == muse.binding.MUSE_ERR_INVALID        # NULL context: an error, never a CPU computation
 
 
 def test_product_never_imports_oracle():

@@ -1558,6 +1558,31 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     assert abs(d["top_score"] - 1.0) < 1e-9
 
 
+def test_many_references_on_a_float32_storage_group(muse, eng, oracle):
+    """muse_batch_score_many over an opt-in float32-storage group at n = 4096 (N = 4096 and a padded length): one pass over the
+    float32 rows for all references; per reference the scores of the oracle on the ROUNDED rows, and what single passes give"""
+    for N in (4096, 3500):
+        rng = np.random.default_rng(4242 + N)
+        M, R = 301, 3
+        rows = rng.standard_normal((M, N))
+        refs = [rng.standard_normal(N) for _ in range(R)]
+        rows[::3] += 2.0 * np.roll(refs[1], 11)
+        rows[7, 3] = np.nan
+        rows[9] = -2.0
+        dg = muse.DeviceGroup.from_rows(eng, rows, f32=True)
+        back = dg.read(0, M)
+        bs = [muse.DeviceBatch(eng, dg, r) for r in refs]
+        out = muse.scores_many(bs)
+        for r in range(R):
+            olag, omv, gap = oracle.batch_scores(refs[r], back)
+            assert_scores_match(out[r][0], out[r][1], olag, omv, gap)
+            lag1, mv1 = bs[r].scores()
+            assert np.array_equal(lag1, out[r][0]) and np.allclose(mv1, out[r][1], rtol=1e-12, atol=1e-15, equal_nan=True)
+        for b in bs:
+            b.close()
+        dg.close()
+
+
 # ------------------------------------------------ batched two-sided xCorr (xcorr.go:102-153; SURVEY 8f-4)
 def _oracle_xcorr_rows(oracle, X, Y, n, normalize):
     """oracle.xcorr per pair: cc rows (None where nil), lags, values and the top-two |cc| gap of each pair"""
