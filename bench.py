@@ -184,6 +184,9 @@ def main():
     ap.add_argument("--many-refs", type=int, default=8,
                     help="also time muse_batch_run_many with this many references (N=1 only; 0 = skip); "
                          "reported as an extra object, never as `value`")
+    ap.add_argument("--skip-extra", action="append", default=[],
+                    help="leave one extra object out (tools/profile.sh: in_process_shards re-launches the headline kernel on other "
+                         "row counts, which would blur that kernel's per-launch counter means)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the extra objects (filter_and_refine_run, f32_storage_group, many_references, config5_lengths)")
     ap.add_argument("--force-dist", action="store_true",
@@ -460,7 +463,7 @@ def main():
                 gy.close()
             except Exception as e:
                 line["two_sided_xcorr"] = {"error": str(e)}
-        if extras:
+        if extras and "in_process_shards" not in args.skip_extra:
             # SURVEY 8e inside ONE process (what NewBatch over a device list does: INTEGRATION.md): the same logical group cut into
             # one contiguous row range per context, every shard scored at the same time from its own host thread, per-shard top-N
             # records merged on the host.  With one GPU visible the contexts share it (device 0 listed twice): this exercises the

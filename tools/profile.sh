@@ -15,7 +15,7 @@ OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-ARGS="bench.py --steps $STEPS --warmup 1 --no-cpu-baseline"
+ARGS="bench.py --steps $STEPS --warmup 1 --no-cpu-baseline --skip-extra in_process_shards"
 run() { # name, rocprofv3 options...
     local name=$1; shift
     echo "== $name: rocprofv3 $*" >&2
