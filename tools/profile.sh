@@ -21,7 +21,10 @@ run() { # name, rocprofv3 options...
     echo "== $name: rocprofv3 $*" >&2
     rocprofv3 "$@" --output-format csv -d $OUT/$name -- python3 $ARGS > $OUT/$name.log 2>&1 || { tail -5 $OUT/$name.log; exit 1; }
 }
-run trace --kernel-trace --stats
+ARGS_PMC=$ARGS
+ARGS="bench.py --steps 16 --warmup 3 --no-cpu-baseline --skip-extra in_process_shards"   # (the trace pass: enough launches for its
+run trace --kernel-trace --stats                                                       #  average to sit behind the 30 ms clock ramp)
+ARGS=$ARGS_PMC
 run pmc_fetch --pmc FETCH_SIZE
 run pmc_write --pmc WRITE_SIZE
 run pmc_sq1 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
