@@ -74,6 +74,7 @@ extern "C" int64_t muse_next_pow2(double val)
 }
 
 // ----------------------------------------------------------------- handles
+constexpr int PROBE_WINDOWS = 4096; // clock probe (muse_test_clock_probe_*): windows its pinned buffer holds; the window count and the stop flag sit behind them
 struct muse_ctx {
     int device = 0;
     hipStream_t stream = nullptr;      // every kernel of the context
@@ -448,6 +449,8 @@ static void ctx_release(muse_ctx *ctx)
     (void)hipFree(ctx->many_tab);
     (void)hipFree(ctx->tw2f);
     if (ctx->probe_stream) {
+        if (ctx->probe_buf) // (a probe still running ends within microseconds of its stop flag)
+            *((volatile int *)(ctx->probe_buf + 2 * PROBE_WINDOWS) + 1) = 1;
         (void)hipStreamSynchronize(ctx->probe_stream);
         (void)hipStreamDestroy(ctx->probe_stream);
     }
