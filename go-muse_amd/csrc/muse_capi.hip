@@ -2610,7 +2610,6 @@ extern "C" int muse_xcorr_batch(muse_ctx *ctx, const double *x_rows, const doubl
 }
 
 // ---- measurement hook: the shader clock held while other kernels of the process run (diag_kernels.hip)
-constexpr int PROBE_WINDOWS = 4096;
 // ends a running probe early (host flag in the pinned buffer: no GPU call)
 extern "C" int muse_test_clock_probe_stop(muse_ctx *ctx)
 {
