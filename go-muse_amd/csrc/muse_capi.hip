@@ -2087,7 +2087,7 @@ extern "C" int muse_batch_score_many(muse_batch *const *bs, int32_t R)
         if (rc)
             return rc;
     }
-    if (!ctx->zscratch) {
+    if (b0->n == 16384 && !ctx->zscratch) { // (every other length keeps the spectra in registers: no scratch)
         const int slots = ctx->num_cus * 4; // one 64 KB slice per resident workgroup
         HIP_TRY(hipMalloc(&ctx->zscratch, (size_t)slots * 4096 * sizeof(double2)));
         ctx->zslots = slots;

@@ -26,8 +26,9 @@
 //   * Tables: pass 2's 8 x R1 factors from an LDS copy (a broadcast read; gathered per lane out of the W_65536 table they
 //     were the longest stall of the kernel), the later passes' from lane-ordered per-length tables (coalesced).
 //   * Lanes are relabelled to columns so that LDS read groups and write groups meet no bank conflicts (column_of_lane()).
-//   * MULTI: R references in one pass (muse_batch_score_many): the pair's spectrum is parked per workgroup and every
-//     reference takes product, second transform and argmax from there.
+//   * MULTI: R references in one pass (muse_batch_score_many): the pair's spectrum stays in registers (n <= 8192: 256 VGPRs, half
+//     the resident waves; round 2 parked it in global scratch: x 1.4 per reference at R = 8, now x 1.5 - 1.8) or is parked per
+//     workgroup (n = 16384), and every reference takes product, second transform and argmax from there.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -493,8 +494,10 @@ __device__ __forceinline__ T *uniform_ptr(T *ptr)
 // thread re-reads only what it wrote) and every reference takes product, second transform and argmax from there.
 // F32: float32-storage group (muse_group_create_f32, opt-in): the rows are float32 in HBM, widened exactly as they are
 // consumed; the arithmetic is the float64 arithmetic of the float64 groups.
+// ZREG (MULTI, n <= 8192): the pair's spectrum stays in REGISTERS over the references (256 VGPRs: half the resident waves)
+// instead of being parked in the workgroup's slice of global scratch (n = 16384: 1024 threads per pair cap a lane at 128).
 template <int LOGN, bool PADDED, bool MULTI, bool F32 = false>
-__global__ __launch_bounds__((LOGN >= 11 ? (1 << LOGN) / 16 : 256), 4) void xcorr_fused_small(const FusedParams p)
+__global__ __launch_bounds__((LOGN >= 11 ? (1 << LOGN) / 16 : 256), ((MULTI && LOGN <= 13) ? 2 : 4)) void xcorr_fused_small(const FusedParams p)
 {
     using namespace occ4;
     using namespace fold;
@@ -658,20 +661,31 @@ __global__ __launch_bounds__((LOGN >= 11 ? (1 << LOGN) / 16 : 256), 4) void xcor
             gt &= TPB - 1;
             return (d2v __attribute__((address_space(1))) *)scalar_ptr_at(p.zscratch, i * ZT + (long long)blockIdx.x * TPB) + (unsigned)gt;
         };
+        constexpr bool ZREG = MULTI && LOGN <= 13;
+        double2 Z[16];
         if (MULTI) {
 #pragma unroll
-            for (int i = 0; i < 16; i++)
-                *zslot(i) = d2v{v[i].x, v[i].y};
+            for (int i = 0; i < 16; i++) {
+                if (ZREG)
+                    Z[i] = v[i];
+                else
+                    *zslot(i) = d2v{v[i].x, v[i].y};
+            }
         }
         const int R = MULTI ? p.R : 1;
+#pragma clang loop unroll(disable)
         for (int ref = 0; ref < R; ref++) {
         const double2 *__restrict__ xcr = MULTI ? uniform_ptr(p.xcp_many[ref]) : p.xc;
         if (MULTI) {
             fence();
 #pragma unroll
             for (int i = 0; i < 16; i++) {
-                const d2v z = *zslot(i);
-                v[i] = make_double2(z.x, z.y);
+                if (ZREG) {
+                    v[i] = Z[i];
+                } else {
+                    const d2v z = *zslot(i);
+                    v[i] = make_double2(z.x, z.y);
+                }
             }
         }
         { // V = Z conj(X)/n in place, the factors in four batches of four (two in flight: 32 registers), then the
@@ -776,11 +790,12 @@ static hipError_t launch_small_n(const FusedParams &p, int num_cus, hipStream_t 
     constexpr int TPB = LOGN >= 11 ? (1 << LOGN) / 16 : 256;
     constexpr int G = TPB / ((1 << LOGN) / 16);
     const long long ngroups = (p.npairs + G - 1) / G;
-    if (p.R > 1) { // one pass for R references: exactly the resident workgroups, each with its slice of the spectrum scratch
-        if (!p.xcp_many || !p.mv_many || !p.lag_many || !p.zscratch)
+    if (p.R > 1) { // one pass for R references: exactly the resident workgroups (n = 16384: each with its slice of the spectrum scratch)
+        constexpr bool ZREG = LOGN <= 13;
+        if (!p.xcp_many || !p.mv_many || !p.lag_many || (!ZREG && !p.zscratch))
             return hipErrorInvalidValue;
-        const long long grid = std::min<long long>(ngroups, (long long)num_cus * (1024 / TPB));
-        if ((size_t)grid * TPB * 16 > (size_t)p.zslots * 4096)
+        const long long grid = std::min<long long>(ngroups, (long long)num_cus * (ZREG ? std::max(1, 512 / TPB) : 1024 / TPB));
+        if (!ZREG && (size_t)grid * TPB * 16 > (size_t)p.zslots * 4096)
             return hipErrorInvalidValue;
         if (p.N < (1 << LOGN))
             hipLaunchKernelGGL((xcorr_fused_small<LOGN, true, true>), dim3((unsigned)grid), dim3(TPB), 0, stream, p);
