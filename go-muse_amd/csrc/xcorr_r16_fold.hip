@@ -245,7 +245,7 @@ __global__ __launch_bounds__(OCC_THREADS, 4) void xcorr_fused_n4096_fold(const F
 // the eight pass-3 factors travel under the transpose in front of the pass (R = 8, 400 000 x 4096:
 // 1.64 -> 1.70 -> 1.76 -> 1.86e8 series-references/s step by step, profiles/r03_many_references.txt).  The last reference of
 // a pair is peeled out of the reference loop: Z dies in its first stage, and its registers take the
-// next pair's rows, requested in front of the last pass.
+// next pair's rows, requested right behind that stage.
 namespace foldk {
 
 constexpr int MSTAT = 12; // per pair: [0,8) sum d^2 partials (2*wave + series), [8,10) sum d, [10] first row, [11] has second row
@@ -376,9 +376,13 @@ __global__ __launch_bounds__(OCC_THREADS, MULTI_WGS_PER_CU) void xcorr_fused_n40
 
     // one reference: V = Z conj(X_r) / n (factors xf, requested earlier), cc = FFT(V), argmax -> trip[ip]; `v` holds Z on entry.
     // `ahead()` runs in front of the last stage of the last pass: the place to request what the NEXT iteration needs.
-    const auto correlate = [&](double2 (&v)[16], const double2 (&xf)[16], const int r, const double *st, auto ahead) __attribute__((always_inline)) {
+    // `early()` runs right behind the spectrum multiply (the last reference: Z is dead there, its registers can take the next pair's rows).
+    const auto correlate = [&](double2 (&v)[16], const double2 (&xf)[16], const int r, const double *st, auto early, auto ahead) __attribute__((always_inline)) {
         double *const tr = trip + MTRIP * ip;
         xc_stage1_pre(v, xf);
+        fence();
+        early();
+        fence();
         dft16_rn_s234(v);
         exchange_local_full<0>(v, xw, t);
         gdft16_nr(v, G2Fetch{g2s, t & 15});
@@ -496,15 +500,16 @@ __global__ __launch_bounds__(OCC_THREADS, MULTI_WGS_PER_CU) void xcorr_fused_n40
 #pragma unroll
             for (int k = 0; k < 16; k++)
                 v[k] = Z[k];
-            correlate(v, xf, r, st, [&]() __attribute__((always_inline)) { request_spectrum(xn, r + 1); });
+            correlate(v, xf, r, st, [&]() __attribute__((always_inline)) {}, [&]() __attribute__((always_inline)) { request_spectrum(xn, r + 1); });
 #pragma unroll
             for (int k = 0; k < 16; k++)
                 xf[k] = xn[k];
         }
-        {   // the last reference: Z dies in its first stage; the next pair's rows are requested in front of its last pass
+        {   // the last reference: Z dies in its first stage and the next pair's rows are requested right behind it -- a whole
+            // reference iteration (~ 5 us) ahead of their use
             nextpair = __builtin_amdgcn_readfirstlane(next_s[pp]);
             const long long nxt = nextpair < total ? nextpair : 0; // nothing left: pair 0 (L2-resident dummy)
-            correlate(Z, xf, R - 1, st, [&]() __attribute__((always_inline)) { request_rows(nxt); });
+            correlate(Z, xf, R - 1, st, [&]() __attribute__((always_inline)) { request_rows(nxt); }, [&]() __attribute__((always_inline)) {});
         }
         pp ^= 1;
     }
