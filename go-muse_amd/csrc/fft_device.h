@@ -170,6 +170,28 @@ __device__ __forceinline__ double wave_max_dpp(double v)
     v = fmax(v, dpp_f64<0x140>(v));
     return fmax(fmax(readlane_f64(v, 0), readlane_f64(v, 16)), fmax(readlane_f64(v, 32), readlane_f64(v, 48)));
 }
+// Wave maximum of NON-NEGATIVE doubles: their bit patterns order like the values, so the maximum is an unsigned maximum of
+// the high words followed by one of the low words among the lanes that hold the winning high word -- v_max_u32 takes the
+// DPP operand itself (one instruction per step instead of two moves and a v_max_f64 behind a canonicalising copy), and
+// row_bcast:15 / :31 (gfx9 DPP) carry the rows' results to lane 63.  A NaN anywhere wins (its pattern is above Inf's);
+// callers only use the result of such a series to flag it.
+__device__ __forceinline__ unsigned wave_max_u32_dpp(unsigned v)
+{
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true));  // quad_perm [1,0,3,2]
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true));  // quad_perm [2,3,0,1]
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true)); // row_half_mirror
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, true)); // row_mirror
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false)); // row_bcast:15 into rows 1, 3 (0 = identity elsewhere)
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false)); // row_bcast:31 into rows 2, 3
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ double wave_max_nonneg(double x)
+{
+    const unsigned hi = (unsigned)__double2hiint(x), lo = (unsigned)__double2loint(x);
+    const unsigned mh = wave_max_u32_dpp(hi);
+    const unsigned ml = wave_max_u32_dpp(hi == mh ? lo : 0u);
+    return __hiloint2double((int)mh, (int)ml);
+}
 __device__ __forceinline__ int wave_min_i_dpp(int v)
 {
     v = min(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true));

@@ -315,6 +315,41 @@ __device__ __forceinline__ bool finalize(const double *r, const int series, cons
 
 // maxAbsIndex (xcorr.go:39-50) over the wave's 16 x 64 values of both series; value of lag index t + 256 m sits in
 // register BR16(m).  Writes the wave's {max |cc|, signed value (cc[0] when nothing is above 0), index} per series.
+// Few instructions of ANY kind: a wave issues at most one instruction every four cycles, scalar ones included, so the
+// locate step keeps its bookkeeping in the vector carry (v_cmp_eq + v_addc shift "|v| == max" into a per-lane 16-bit mask)
+// instead of a scalar select chain per register.
+#define MUSE_HIWORD_CASE(m) case m: h = __builtin_amdgcn_readlane(__double2hiint(S == 0 ? v[BR16(m)].x : v[BR16(m)].y), l); break;
+template <int S>
+__device__ __forceinline__ int hiword_at(const double2 (&v)[16], const int m, const int l) // m, l wave-uniform
+{
+    int h = 0;
+    switch (m) {
+        MUSE_HIWORD_CASE(0) MUSE_HIWORD_CASE(1) MUSE_HIWORD_CASE(2) MUSE_HIWORD_CASE(3)
+        MUSE_HIWORD_CASE(4) MUSE_HIWORD_CASE(5) MUSE_HIWORD_CASE(6) MUSE_HIWORD_CASE(7)
+        MUSE_HIWORD_CASE(8) MUSE_HIWORD_CASE(9) MUSE_HIWORD_CASE(10) MUSE_HIWORD_CASE(11)
+        MUSE_HIWORD_CASE(12) MUSE_HIWORD_CASE(13) MUSE_HIWORD_CASE(14) MUSE_HIWORD_CASE(15)
+    }
+    return h;
+}
+#undef MUSE_HIWORD_CASE
+// lowest index among the lanes whose mask is non-zero (bit m of a lane's mask: its value of register BR16(m) is the
+// maximum): lowest m first, then the lowest lane.  One trip unless several lanes hold exactly the maximum.
+__device__ __forceinline__ void lowest_hit(const unsigned acc, int &m_out, int &l_out)
+{
+    unsigned long long c = __ballot(acc != 0u);
+    int bm = 16, bl = 0;
+    while (c != 0ull) {
+        const int l = __ffsll((long long)c) - 1;
+        const int m = __ffs((int)__builtin_amdgcn_readlane((int)acc, l)) - 1;
+        if (m < bm) {
+            bm = m;
+            bl = l;
+        }
+        c &= c - 1ull;
+    }
+    m_out = bm;
+    l_out = bl;
+}
 __device__ __forceinline__ void wave_argmax_store(const double2 (&v)[16], const int wave, const int lane, double *ra_)
 {
     double ma = 0.0, mb = 0.0;
@@ -323,34 +358,30 @@ __device__ __forceinline__ void wave_argmax_store(const double2 (&v)[16], const 
         ma = fmax(ma, fabs(v[k].x));
         mb = fmax(mb, fabs(v[k].y));
     }
-    const double wa = wave_max_dpp(ma), wb = wave_max_dpp(mb);
+    const double wa = wave_max_nonneg(ma), wb = wave_max_nonneg(mb);
+    unsigned accA = 0u, accB = 0u;
+#pragma unroll
+    for (int m = 15; m >= 0; m--) { // acc = 2 acc + (|v| == w): register BR16(m) ends up at bit m
+        const int k = BR16(m);
+        asm("v_cmp_eq_f64 vcc, |%1|, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(accA) : "v"(v[k].x), "s"(wa) : "vcc");
+        asm("v_cmp_eq_f64 vcc, |%1|, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(accB) : "v"(v[k].y), "s"(wb) : "vcc");
+    }
     int widxA = 0x7fffffff, widxB = 0x7fffffff;
     double svA = 0.0, svB = 0.0;
-    {
-        unsigned long long selA = 0ull, selB = 0ull;
-        int kA = 0, kB = 0, hiA = 0, hiB = 0;
-#pragma unroll
-        for (int m = 15; m >= 0; m--) { // descending index: the lowest is selected last
-            const int k = BR16(m);
-            const unsigned long long mA_ = __ballot(fabs(v[k].x) == wa);
-            const unsigned long long mB_ = __ballot(fabs(v[k].y) == wb);
-            const bool hA = mA_ != 0ull, hB = mB_ != 0ull; // wave-uniform
-            selA = hA ? mA_ : selA;
-            kA = hA ? m : kA;
-            hiA = hA ? __double2hiint(v[k].x) : hiA;
-            selB = hB ? mB_ : selB;
-            kB = hB ? m : kB;
-            hiB = hB ? __double2hiint(v[k].y) : hiB;
+    if (__double_as_longlong(wa) != 0ll) { // (wa >= 0 or NaN: nothing equals a NaN, the masks are empty then)
+        int m, l;
+        lowest_hit(accA, m, l);
+        if (m < 16) {
+            widxA = wave * 64 + l + 256 * m;
+            svA = (hiword_at<0>(v, m, l) < 0) ? -wa : wa;
         }
-        if (wa > 0.0 && selA != 0ull) {
-            const int l = __ffsll((long long)selA) - 1;
-            widxA = wave * 64 + l + 256 * kA;
-            svA = (__builtin_amdgcn_readlane(hiA, l) < 0) ? -wa : wa;
-        }
-        if (wb > 0.0 && selB != 0ull) {
-            const int l = __ffsll((long long)selB) - 1;
-            widxB = wave * 64 + l + 256 * kB;
-            svB = (__builtin_amdgcn_readlane(hiB, l) < 0) ? -wb : wb;
+    }
+    if (__double_as_longlong(wb) != 0ll) {
+        int m, l;
+        lowest_hit(accB, m, l);
+        if (m < 16) {
+            widxB = wave * 64 + l + 256 * m;
+            svB = (hiword_at<1>(v, m, l) < 0) ? -wb : wb;
         }
     }
     const double cc0a = v[0].x, cc0b = v[0].y; // index t + 256 * 0 (BR16(0) = 0): cc[0] in wave 0 lane 0

@@ -21,6 +21,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <type_traits>
 
 #include "foldk_device.h"
 
@@ -324,8 +325,9 @@ constexpr int MULTI_WGS_PER_CU = 2;
 // PADDED (2048 < N < 4096): the spectrum keeps its DC bin and every reference's results are corrected by
 // -m c1_r[index] (FusedParams::c1_many) before the argmax.
 // F32: float32-storage group (rows widened as they are consumed, float64 arithmetic)
-template <bool PADDED = false, bool F32 = false>
-__global__ __launch_bounds__(OCC_THREADS, MULTI_WGS_PER_CU) void xcorr_fused_n4096_fold_multi(const FusedParams p)
+// TIMING: the phase-stamped build of tools/ablate/multi_phases.hip (FusedParams::dbg); the product kernel below is <.., false>.
+template <bool PADDED, bool F32, bool TIMING>
+__device__ __forceinline__ void fold_multi_body(const FusedParams &p)
 {
     using namespace occ4;
     using namespace fold;
@@ -342,12 +344,14 @@ __global__ __launch_bounds__(OCC_THREADS, MULTI_WGS_PER_CU) void xcorr_fused_n40
     const int pad = PADDED ? 4096 - p.N : 0;
     const double invN = PADDED ? 1.0 / (double)p.N : 1.0 / 4096.0, invNm1 = PADDED ? 1.0 / (double)(p.N - 1) : 1.0 / 4095.0;
     const int R = p.R;
+    PhaseClock<TIMING> clk;
 
     if (t < 128)
         g2s[t] = p.g2[t];
     if (t < 2)
         trip[MTRIP * t + 24] = -1.0;
     __syncthreads();
+    clk.start();
 
     int ip = 0, pp = 0;
     const long long total = p.npairs;
@@ -377,23 +381,39 @@ __global__ __launch_bounds__(OCC_THREADS, MULTI_WGS_PER_CU) void xcorr_fused_n40
     // one reference: V = Z conj(X_r) / n (factors xf, requested earlier), cc = FFT(V), argmax -> trip[ip]; `v` holds Z on entry.
     // `ahead()` runs in front of the last stage of the last pass: the place to request what the NEXT iteration needs.
     // `early()` runs right behind the spectrum multiply (the last reference: Z is dead there, its registers can take the next pair's rows).
-    const auto correlate = [&](double2 (&v)[16], const double2 (&xf)[16], const int r, const double *st, auto early, auto ahead) __attribute__((always_inline)) {
+    // `g3_first`: pass 3's factors are requested IN FRONT of early() -- loads return in order, so a factor requested behind the
+    // next pair's rows could only be used once those rows (HBM latency) have arrived.
+    const auto correlate = [&](double2 (&v)[16], const double2 (&xf)[16], const int r, const double *st, auto g3_first, auto early, auto ahead) __attribute__((always_inline)) {
         double *const tr = trip + MTRIP * ip;
+        clk.template stamp<13>();
         xc_stage1_pre(v, xf);
         fence();
+        double2 g3[8];
+        if (decltype(g3_first)::value) {
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+                g3[q] = G3Fetch{p.g3b, t}(q);
+            fence();
+        }
         early();
         fence();
+        clk.template stamp<6>();
         dft16_rn_s234(v);
+        clk.template stamp<7>();
         exchange_local_full<0>(v, xw, t);
+        clk.template stamp<8>();
         gdft16_nr(v, G2Fetch{g2s, t & 15});
-        double2 g3[8]; // pass 3's factors travel under the transpose
+        if (!decltype(g3_first)::value) { // pass 3's factors travel under the transpose
 #pragma unroll
-        for (int q = 0; q < 8; q++)
-            g3[q] = G3Fetch{p.g3b, t}(q);
+            for (int q = 0; q < 8; q++)
+                g3[q] = G3Fetch{p.g3b, t}(q);
+        }
         fence();
+        clk.template stamp<9>();
         exchange_cross_full<1, 1>(v, xbuf, t);
         if (r > 0) // (r == 0: the previous iteration's results went out behind the forward transform's first barriers)
             finalize_prev_multi(trip, stats, ip, t, invN, invNm1, p.mv_many, p.lag_many, p.ovf_count, p.ovf_list);
+        clk.template stamp<10>();
         gdft16_nr_s12(v, g3[0], g3[1]); // cc index t + 256 m3 at v[BR16(m3)]
         gdft16_nr_s3(v, g3[2], g3[3]);
         fence();
@@ -423,12 +443,14 @@ __global__ __launch_bounds__(OCC_THREADS, MULTI_WGS_PER_CU) void xcorr_fused_n40
                 }
             }
         }
+        clk.template stamp<11>();
         wave_argmax_store(v, wave, lane, tr + 6 * wave);
         if (wave == 0 && lane == 0) {
             tr[24] = (double)r;
             tr[25] = (double)pp;
         }
         ip ^= 1;
+        clk.template stamp<12>();
     };
 
     long long nextpair = 0;
@@ -466,11 +488,14 @@ __global__ __launch_bounds__(OCC_THREADS, MULTI_WGS_PER_CU) void xcorr_fused_n40
         }
         double2 xf[16];
         fence();
+        clk.template stamp<0>();
         request_spectrum(xf, 0); // (the rows' registers are free again: the first reference's factors travel under the forward transform)
         fence();
         dft16_nr(Z);
+        clk.template stamp<1>();
         exchange_cross_full<0, 1>(Z, xbuf, t, WIDE ? wide_column(t) : -1);
         finalize_prev_multi(trip, stats, ip, t, invN, invNm1, p.mv_many, p.lag_many, p.ovf_count, p.ovf_list);
+        clk.template stamp<2>();
         gdft16_nr(Z, G2Fetch{g2s, t >> 4});
         {
             double2 g3[8]; // pass 3's factors travel under the transpose
@@ -478,7 +503,9 @@ __global__ __launch_bounds__(OCC_THREADS, MULTI_WGS_PER_CU) void xcorr_fused_n40
             for (int q = 0; q < 8; q++)
                 g3[q] = G3Fetch{p.g3a, t}(q);
             fence();
+            clk.template stamp<3>();
             exchange_local_full<1>(Z, xw, t);
+            clk.template stamp<4>();
             gdft16_nr_s12(Z, g3[0], g3[1]); // Z[hi + 16 lo + 256 k3] at Z[BR16(k3)]
             gdft16_nr_s3(Z, g3[2], g3[3]);
             gdft16_nr_s4(Z, g3[4], g3[5], g3[6], g3[7]);
@@ -494,13 +521,14 @@ __global__ __launch_bounds__(OCC_THREADS, MULTI_WGS_PER_CU) void xcorr_fused_n40
                 st[9] = s1b;
             }
         }
+        clk.template stamp<5>();
 #pragma clang loop unroll(disable)
         for (int r = 0; r + 1 < R; r++) {
             double2 v[16], xn[16];
 #pragma unroll
             for (int k = 0; k < 16; k++)
                 v[k] = Z[k];
-            correlate(v, xf, r, st, [&]() __attribute__((always_inline)) {}, [&]() __attribute__((always_inline)) { request_spectrum(xn, r + 1); });
+            correlate(v, xf, r, st, std::false_type{}, [&]() __attribute__((always_inline)) {}, [&]() __attribute__((always_inline)) { request_spectrum(xn, r + 1); });
 #pragma unroll
             for (int k = 0; k < 16; k++)
                 xf[k] = xn[k];
@@ -509,12 +537,23 @@ __global__ __launch_bounds__(OCC_THREADS, MULTI_WGS_PER_CU) void xcorr_fused_n40
             // reference iteration (~ 5 us) ahead of their use
             nextpair = __builtin_amdgcn_readfirstlane(next_s[pp]);
             const long long nxt = nextpair < total ? nextpair : 0; // nothing left: pair 0 (L2-resident dummy)
-            correlate(Z, xf, R - 1, st, [&]() __attribute__((always_inline)) { request_rows(nxt); }, [&]() __attribute__((always_inline)) {});
+            correlate(Z, xf, R - 1, st, std::true_type{}, [&]() __attribute__((always_inline)) { request_rows(nxt); }, [&]() __attribute__((always_inline)) {});
         }
         pp ^= 1;
     }
     lds_barrier();
     finalize_prev_multi(trip, stats, ip, t, invN, invNm1, p.mv_many, p.lag_many, p.ovf_count, p.ovf_list);
+    if (TIMING && p.dbg && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < NPHASE; i++)
+            p.dbg[((long long)blockIdx.x * 4 + wave) * NPHASE + i] = clk.acc[i];
+    }
+}
+
+template <bool PADDED = false, bool F32 = false>
+__global__ __launch_bounds__(OCC_THREADS, MULTI_WGS_PER_CU) void xcorr_fused_n4096_fold_multi(const FusedParams p)
+{
+    fold_multi_body<PADDED, F32, false>(p);
 }
 
 // R >= 1 references, n == 4096 (N < 4096: p.c1_many); p.ovf_count and p.work_counter zeroed; a resident grid

@@ -101,7 +101,7 @@ __device__ __forceinline__ double pair_max(double v, double *red, const int wave
         rows_side_by_side(v, e, o);
         return fmax(e, o);
     }
-    v = wave_max_dpp(v);
+    v = wave_max_nonneg(v); // (|cc| maxima: never negative)
     if (S > 64) {
         lds_barrier();
         red[wave] = v;
@@ -180,7 +180,7 @@ __device__ __forceinline__ void pair_max2(double &a, double &b, double *red, con
         return;
     }
     constexpr int NW = S / 64;
-    const double wa = wave_max_dpp(a), wb = wave_max_dpp(b);
+    const double wa = wave_max_nonneg(a), wb = wave_max_nonneg(b);
     red[64 + wave] = wa;
     red[80 + wave] = wb;
     lds_barrier();
