@@ -7,8 +7,36 @@
 #include <stdint.h>
 
 #include "xcorr_kernels.h"
+#include "foldk_device.h"
 
 namespace muse {
+
+// Unit-test hook (muse_test_wave_argmax): one 256-thread workgroup holds 2 x 4096 given values exactly as the n = 4096
+// kernels hold a pair's correlations behind their last pass -- lag index t + 256 m of series A / B in v[BR16(m)].x / .y of
+// thread t -- and runs foldk::wave_argmax_store on them: out[6 w ... 6 w + 5] = wave w's {max |cc|, signed value, index}
+// of A, then of B.  The tie rules (lowest index among equal |values|, across registers, lanes and waves) are what the
+// parity test feeds it.
+__global__ __launch_bounds__(256) void wave_argmax_probe_kernel(const double *ccA, const double *ccB, double *out)
+{
+    using namespace fold;
+    __shared__ double rec[24];
+    const int t = threadIdx.x;
+    double2 v[16];
+#pragma unroll
+    for (int m = 0; m < 16; m++)
+        v[BR16(m)] = make_double2(ccA[t + 256 * m], ccB[t + 256 * m]);
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    foldk::wave_argmax_store(v, wave, t & 63, rec + 6 * wave);
+    __syncthreads();
+    if (t < 24)
+        out[t] = rec[t];
+}
+
+hipError_t launch_wave_argmax_probe(const double *ccA, const double *ccB, double *out24, hipStream_t stream)
+{
+    hipLaunchKernelGGL(wave_argmax_probe_kernel, dim3(1), dim3(256), 0, stream, ccA, ccB, out24);
+    return hipGetLastError();
+}
 
 // windows of ~window_ticks of the 100 MHz clock until total_ticks have passed (or the buffer is full): out[2 w] = shader
 // ticks, out[2 w + 1] = 100 MHz ticks of window w; *count = windows written.  One wave, a handful of registers: it fits

@@ -2620,6 +2620,28 @@ extern "C" int muse_test_clock_probe_stop(muse_ctx *ctx)
     return MUSE_OK;
 }
 
+extern "C" int muse_test_wave_argmax(muse_ctx *ctx, const double *ccA, const double *ccB, double *out24)
+{
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    if (!ccA || !ccB || !out24)
+        return fail(MUSE_ERR_INVALID, "wave argmax probe: null pointer");
+    double *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, (2 * 4096 + 24) * sizeof(double)));
+    hipError_t e = hipMemcpy(d, ccA, 4096 * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = hipMemcpy(d + 4096, ccB, 4096 * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        e = launch_wave_argmax_probe(d, d + 4096, d + 8192, nullptr);
+    if (e == hipSuccess)
+        e = hipMemcpy(out24, d + 8192, 24 * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess)
+        return fail(MUSE_ERR_HIP, hipGetErrorString(e));
+    return MUSE_OK;
+}
+
 extern "C" int muse_test_clock_probe_start(muse_ctx *ctx, double window_ms, double total_ms)
 {
     int rc = use_device(ctx);

@@ -120,6 +120,8 @@ hipError_t launch_synth_ref(double *ref, int N, unsigned long long seed, hipStre
 // measurement hook (diag_kernels.hip): one wave sampling delta s_memtime / delta s_memrealtime in windows of window_ms for total_ms
 hipError_t launch_clock_probe(unsigned long long *out, int *count, int max_windows, double window_ms, double total_ms,
                               hipStream_t stream);
+// unit-test hook: foldk::wave_argmax_store on 2 x 4096 given values (diag_kernels.hip); out24 = 4 waves x {max, value, index} x 2 series
+hipError_t launch_wave_argmax_probe(const double *ccA, const double *ccB, double *out24, hipStream_t stream);
 
 // ---- group max / filter / top-N (reduce_kernels.hip)
 constexpr int TOPN_CHUNK = 4096;    // groups per workgroup in the selection pass

@@ -72,6 +72,17 @@ class Engine:
         """test hook (include/muse_hip_test.h): scales the error bound the filter-and-refine Run assumes"""
         B.check(B.load().muse_test_set_screen_bound_scale(self._h, float(scale)))
 
+    def wave_argmax(self, cc_a, cc_b):
+        """test hook: the n = 4096 kernels' per-wave argmax step on 2 x 4096 given values; (4, 2, 3) array of
+        {max |cc|, signed value, index} per wave and series"""
+        a = np.ascontiguousarray(cc_a, dtype=np.float64)
+        b = np.ascontiguousarray(cc_b, dtype=np.float64)
+        if a.shape != (4096,) or b.shape != (4096,):
+            raise ValueError("wave_argmax: two vectors of 4096 values")
+        out = np.zeros(24)
+        B.check(B.load().muse_test_wave_argmax(self._h, B.dptr(a), B.dptr(b), B.dptr(out)))
+        return out.reshape(4, 2, 3)
+
     def clock_probe_start(self, window_ms=1.0, total_ms=1000.0):
         """measurement hook: a one-wave kernel samples the shader clock for total_ms while the caller's kernels run"""
         B.check(B.load().muse_test_clock_probe_start(self._h, float(window_ms), float(total_ms)))

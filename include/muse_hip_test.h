@@ -38,6 +38,12 @@ int muse_test_clock_probe_start(muse_ctx *ctx, double window_ms, double total_ms
 int muse_test_clock_probe_stop(muse_ctx *ctx);
 int muse_test_clock_probe_read(muse_ctx *ctx, double *mhz, int32_t cap, int32_t *windows);
 
+/* Device unit test of the n = 4096 kernels' argmax step (foldk_device.h, wave_argmax_store; maxAbsIndex of
+ * xcorr.go:39-50): ccA / ccB are 4096 host doubles each, laid out in registers as the kernels hold a pair's correlations;
+ * out24 receives, per wave w = 0..3, {max |cc|, signed value at the winning index (cc[0] of the wave's first lane when
+ * nothing is above 0), winning index (2147483647 when nothing is above 0)} of series A, then of series B. */
+int muse_test_wave_argmax(muse_ctx *ctx, const double *ccA, const double *ccB, double *out24);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1749,3 +1749,58 @@ def test_batch_run_sharded_over_engine_list(muse, eng, oracle):
     b1.Run(None)
     b3.Run(None)
     assert _fetch(b1) == _fetch(b3)
+
+
+# ------------------------------------------------ device unit test: the argmax step of the n = 4096 kernels
+def _wave_argmax_expected(cc, wave):
+    """maxAbsIndex (xcorr.go:39-50) over the lag indices a wave owns (t + 256 m, t in the wave's 64 lanes): the first index
+    whose |value| is the largest, only values above 0 count."""
+    idx = (np.arange(64)[None, :] + 64 * wave + 256 * np.arange(16)[:, None]).ravel()
+    idx.sort()
+    a = np.abs(cc[idx])
+    if not (a.max() > 0):
+        return 0.0, cc[64 * wave], 2147483647
+    k = int(idx[np.argmax(a)])  # argmax returns the first maximum of the ascending indices
+    return float(a.max()), float(cc[k]), k
+
+
+def test_wave_argmax_tie_rules(eng):                   # foldk_device.h wave_argmax_store
+    rng = np.random.default_rng(77)
+    cases = []
+    base = rng.standard_normal((2, 4096))
+    cases.append(base.copy())                              # no ties
+    c = base.copy()                                        # the same maximum in several registers of one lane, both signs
+    c[0, [5 + 256 * 9, 5 + 256 * 3, 5 + 256 * 12]] = [7.5, -7.5, 7.5]
+    c[1, [200 + 256 * 15, 200]] = [-9.25, 9.25]
+    cases.append(c)
+    c = base.copy()                                        # the same maximum in several lanes of a wave and in several waves
+    c[0, [70 + 256 * 4, 100 + 256 * 2, 127 + 256 * 2, 3 + 256 * 2, 250 + 256]] = [8.0, -8.0, 8.0, 8.0, -8.0]
+    c[1, [64 * w + 63 + 256 * 15 for w in range(4)]] = 6.0
+    c[1, 64 + 256 * 15] = -6.0
+    cases.append(c)
+    c = np.zeros((2, 4096))                                # nothing above 0 / a single non-zero value in the last place
+    c[1, 4095] = -1e-300
+    cases.append(c)
+    c = np.full((2, 4096), 3.0)                            # every value ties
+    c[1] = -3.0
+    cases.append(c)
+    c = base.copy()                                        # maxima that differ in the last bit only (low word decides)
+    c[0, 1000] = 11.0
+    c[0, 17] = np.nextafter(11.0, 12.0)
+    c[0, 3000] = -np.nextafter(11.0, 12.0)
+    c[1, 2047] = -np.nextafter(11.0, 0.0)
+    c[1, 2048] = 11.0
+    cases.append(c)
+    c = base.copy()                                        # denormals and huge values
+    c[0] *= 1e-310
+    c[1] *= 1e300
+    cases.append(c)
+    for ci, c in enumerate(cases):
+        out = eng.wave_argmax(c[0], c[1])
+        for w in range(4):
+            for s in range(2):
+                m, sv, k = _wave_argmax_expected(c[s], w)
+                got = out[w, s]
+                assert got[0] == m and int(got[2]) == k, (ci, w, s, got, (m, sv, k))
+                if k != 2147483647 or w == 0:              # (nothing above 0: the kernels only use wave 0's cc[0])
+                    assert got[1] == sv, (ci, w, s, got, (m, sv, k))
