@@ -283,14 +283,19 @@ __device__ __forceinline__ void issue_row_loads_wide(RawPair &r, const FusedPara
 #endif
     const int lo16 = ((t >> 5) & 1) * 1024 + (t >> 6) * 32 + (t & 31); // in 16-byte units: (2048 h + 64 w + 2 m) / 2
 #pragma unroll
-    for (int i = 0; i < 8; i++) { // one scalar base per four 2 KB slices (immediate offsets -4096 .. +2048 B)
-        const int c = (i & ~3) * 256 + 512;
-        const d2v xa = __builtin_nontemporal_load((gptr<d2v>)scalar_ptr_at(p.rows + rA * p.stride, c) + (128 * i - c / 2) + lo16);
-        const d2v xb = __builtin_nontemporal_load((gptr<d2v>)scalar_ptr_at(p.rows + rB * p.stride, c) + (128 * i - c / 2) + lo16);
-        r.a[i] = xa.x;
-        r.a[i + 8] = xa.y;
-        r.b[i] = xb.x;
-        r.b[i + 8] = xb.y;
+    for (int h = 0; h < 2; h++) { // one scalar base per row and four 2 KB slices (immediate offsets -4096 .. +2048 B), formed ONCE
+        const int c = 1024 * h + 512;
+        const gptr<d2v> ba = (gptr<d2v>)scalar_ptr_at(p.rows + rA * p.stride, c);
+        const gptr<d2v> bb = (gptr<d2v>)scalar_ptr_at(p.rows + rB * p.stride, c);
+#pragma unroll
+        for (int i = 4 * h; i < 4 * h + 4; i++) {
+            const d2v xa = __builtin_nontemporal_load(ba + (128 * i - c / 2) + lo16);
+            const d2v xb = __builtin_nontemporal_load(bb + (128 * i - c / 2) + lo16);
+            r.a[i] = xa.x;
+            r.a[i + 8] = xa.y;
+            r.b[i] = xb.x;
+            r.b[i + 8] = xb.y;
+        }
     }
 }
 __device__ __forceinline__ void swap_halves(double &first, double &second)
