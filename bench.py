@@ -450,14 +450,14 @@ def main():
                 kx_ms, kx_cnt = eng.kernel_time()
                 kx_s = kx_ms / max(kx_cnt, 1) * 1e-3
                 bx = float(P) * (16 * N + 16)
-                xk = "xcorr_two_sided_lds<12>"
+                xk = "xcorr_two_sided_fold<false>"
                 line["two_sided_xcorr"] = {"value": P / kx_s if kx_s > 0 else None, "unit": "xCorr pairs/s (kernel)", "pairs": P, "rows": P, "length": N,
                                            "normalize": True, "dtype": "f64", "kernel": xk, "kernel_ms_avg": kx_s * 1e3,
                                            "ms_per_call_with_copy_back": dtx * 1e3, "algorithmic_bytes_per_launch": bx,
                                            "roofline_frac": bx / kx_s / 1e9 / HBM_PEAK_GBPS if kx_s > 0 else None,
-                                           "note": "muse_xcorr_groups: z = x + i y, one forward transform, X conj(Y) untangled, one more; "
-                                                   "Stockham engine (the xCorrWithX path's tuned kernels do not apply: the mirrored spectrum "
-                                                   "element lives in another thread's registers there)"}
+                                           "note": "muse_xcorr_groups: z = (x read backwards) + i y, one forward transform, cc = Im FFT(Z^2) / 2n on the "
+                                                   "xCorrWithX kernel's transforms (no spectrum table, no mirrored element); statistics first, "
+                                                   "one extra workgroup barrier per pair"}
                 counters.attach(line["two_sided_xcorr"], xk, P, N, bx)
                 gx.close()
                 gy.close()

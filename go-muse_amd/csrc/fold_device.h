@@ -186,6 +186,15 @@ __device__ __forceinline__ void bf_xc(double2 &a, double2 &b, const double2 xa, 
     b = make_double2(fma_(2.0, px, -ox), fma_(2.0, py, -oy));
     a = make_double2(ox, oy);
 }
+// the same first stage on the element-wise SQUARE of the input (two-sided xCorr, xcorr_two_sided.hip):
+//   p = z_b^2 (4), o1 = p + z_(b+8)^2 (4), o2 = 2 p - o1 (2)
+__device__ __forceinline__ void bf_sq(double2 &a, double2 &b)
+{
+    const double px = fma_(-a.y, a.y, a.x * a.x), py = (a.x + a.x) * a.y;
+    const double ox = fma_(b.x, b.x, fma_(-b.y, b.y, px)), oy = fma_(b.x + b.x, b.y, py);
+    b = make_double2(fma_(2.0, px, -ox), fma_(2.0, py, -oy));
+    a = make_double2(ox, oy);
+}
 // stages 2..4 of the RN order: strides 2, 4, 8; the stage-L butterfly at sub-index m uses W_L^m
 __device__ __forceinline__ void dft16_rn_s234(double2 (&v)[16])
 {

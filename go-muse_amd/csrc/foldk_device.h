@@ -395,6 +395,39 @@ __device__ __forceinline__ void wave_argmax_store(const double2 (&v)[16], const 
     }
 }
 
+// One series only (S = 0: the .x components, S = 1: the .y components); out3 = {max |cc|, signed value, index}.
+template <int S>
+__device__ __forceinline__ void wave_argmax_store_one(const double2 (&v)[16], const int wave, const int lane, double *out3)
+{
+    double ma = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        ma = fmax(ma, fabs(S == 0 ? v[k].x : v[k].y));
+    const double wa = wave_max_nonneg(ma);
+    unsigned acc = 0u;
+#pragma unroll
+    for (int m = 15; m >= 0; m--) {
+        const int k = BR16(m);
+        asm("v_cmp_eq_f64 vcc, |%1|, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(S == 0 ? v[k].x : v[k].y), "s"(wa) : "vcc");
+    }
+    int widx = 0x7fffffff;
+    double sv = 0.0;
+    if (__double_as_longlong(wa) != 0ll) {
+        int m, l;
+        lowest_hit(acc, m, l);
+        if (m < 16) {
+            widx = wave * 64 + l + 256 * m;
+            sv = (hiword_at<S>(v, m, l) < 0) ? -wa : wa;
+        }
+    }
+    const double cc0 = S == 0 ? v[0].x : v[0].y;
+    if (lane == 0) {
+        out3[0] = widx == 0x7fffffff ? 0.0 : wa;
+        out3[1] = widx == 0x7fffffff ? cc0 : sv;
+        out3[2] = (double)widx;
+    }
+}
+
 // the same with all sixteen factors already in registers (xf[j] = xc for k3 = j)
 __device__ __forceinline__ void xc_stage1_pre(double2 (&v)[16], const double2 (&xf)[16])
 {

@@ -2552,6 +2552,9 @@ extern "C" int muse_xcorr_groups(muse_group *gx, muse_group *gy, int32_t n, int3
         p.logn = ilog2(n);
         p.normalize_y = normalize ? 1 : 0;
         p.twm = ctx->twm;
+        p.g2 = ctx->g2;
+        p.g3a = ctx->g3a;
+        p.g3b = ctx->g3b;
         p.gscratch = ctx->gscratch;
         p.gscratch_slices = (long long)(ctx->gscratch_elems / (size_t)n);
         p.mv = dmv;

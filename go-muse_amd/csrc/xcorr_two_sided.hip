@@ -19,6 +19,7 @@
 #include <algorithm>
 
 #include "stk_device.h"
+#include "foldk_device.h"
 
 namespace muse {
 
@@ -42,14 +43,22 @@ struct PairScale {
     bool nil, nan;
 };
 // q = {sum dx, sum dx^2, sum dy, sum dy^2} with d = sample - first sample (normalized) or the sample itself (raw)
-__device__ __forceinline__ PairScale pair_scale(const double (&q)[4], const int Nx, const int Ny, const int n, const bool normalize)
+// the launch's reciprocals (uniform)
+struct PairInv {
+    double invNx, invNxm1, invNy, invNym1, invnm1;
+};
+__host__ __device__ __forceinline__ PairInv pair_inv(const int Nx, const int Ny, const int n)
+{
+    return PairInv{1.0 / (double)Nx, 1.0 / (double)(Nx - 1), 1.0 / (double)Ny, 1.0 / (double)(Ny - 1), 1.0 / (double)(n - 1)};
+}
+__device__ __forceinline__ PairScale pair_scale(const double (&q)[4], const PairInv &iv, const bool normalize)
 {
     PairScale s;
     if (normalize) {
         bool zA, nA, zB, nB;
-        const double invNx = 1.0 / (double)Nx, invNy = 1.0 / (double)Ny;
-        const double vA0 = variance(Stat{q[0], q[1]}, invNx, 1.0 / (double)(Nx - 1), zA, nA);
-        const double vB0 = variance(Stat{q[2], q[3]}, invNy, 1.0 / (double)(Ny - 1), zB, nB);
+        const double invNx = iv.invNx, invNy = iv.invNy;
+        const double vA0 = variance(Stat{q[0], q[1]}, invNx, iv.invNxm1, zA, nA);
+        const double vB0 = variance(Stat{q[2], q[3]}, invNy, iv.invNym1, zB, nB);
         s.nil = zA || zB; // xcorr.go:110-127: either sigma == 0 -> (nil, 0, 0) (x is checked first; a NaN x with a constant y is nil too)
         s.nan = !s.nil && (nA || nB);
         const bool dead = s.nil || s.nan;
@@ -63,9 +72,9 @@ __device__ __forceinline__ PairScale pair_scale(const double (&q)[4], const int 
         ya = ya * fma(-0.5 * vA * ya, ya, 1.5);
         yb = yb * fma(-0.5 * vB * yb, yb, 1.5);
         yb = yb * fma(-0.5 * vB * yb, yb, 1.5);
-        s.fac = ya * yb / (double)(n - 1); // xcorr.go:140: 1 / (n (n - 1)); the 1 / n rides in the untangled spectrum
+        s.fac = ya * yb * iv.invnm1; // xcorr.go:140: 1 / (n (n - 1)); the 1 / n rides in the untangled spectrum
     } else {
-        const double eA = q[1] / (double)Nx, eB = q[3] / (double)Ny; // mean squares
+        const double eA = q[1] * iv.invNx, eB = q[3] * iv.invNy; // mean squares (only their binary exponents are used)
         s.nil = false;
         s.nan = !__builtin_isfinite(eA) || !__builtin_isfinite(eB);
         s.sA = (s.nan || !(eA > 0.0)) ? 1.0 : pow2_inv_sigma(eA);
@@ -74,6 +83,10 @@ __device__ __forceinline__ PairScale pair_scale(const double (&q)[4], const int 
         s.fac = (1.0 / s.sA) * (1.0 / s.sB); // exact
     }
     return s;
+}
+__device__ __forceinline__ PairScale pair_scale(const double (&q)[4], const int Nx, const int Ny, const int n, const bool normalize)
+{
+    return pair_scale(q, pair_inv(Nx, Ny, n), normalize);
 }
 
 } // namespace two
@@ -227,6 +240,179 @@ void xcorr_two_sided_lds(const FusedParams p)
         }
         __syncthreads(); // red / arg / buf free for the next iteration
     }
+}
+
+// n = 4096 on the xCorrWithX kernel's machinery (foldk_device.h: three radix-16 passes per transform with the twiddles
+// folded into the butterflies, half-round LDS transposes, 128 registers -> four workgroups per CU) WITHOUT the mirrored
+// element: with xr[j] = x[-j mod n] (x read backwards -- an address pattern, not an instruction) conj(X) = FFT(xr), so
+//     cc = FFT(conj(X) Y) / n = FFT(FFT(xr) FFT(y)) / n,      and with z = xr + i y,  Z = FFT(z) = Xr + i Y:
+//     Z^2 = (Xr^2 - Y^2) + 2 i Xr Y        ->        cc = Im FFT(Z^2) / (2 n)
+// (Xr^2, Y^2 and Xr Y are spectra of real sequences, so their forward transforms are real).  A pair costs the same two
+// forward transforms as in the kernels above, but no spectrum table, no Z[-f] and no exchange to fetch it: the square
+// rides in the first butterfly stage of the second transform (fold_device.h, bf_sq).  The real part, xr * xr - y * y,
+// is computed and dropped.  Statistics first (one workgroup barrier), as in the kernels above: both series enter the shared
+// transform centred and at O(1).  The previous pair's four wave records are combined behind the next pair's statistics
+// barrier (no barrier of its own).
+// PADDED = false: Nx == Ny == n (every position valid: shared lane offsets + immediates, no masks).
+// iv: the launch's reciprocals, formed on the host (IEEE division both sides) so that they arrive in scalar registers.
+template <bool PADDED>
+__global__ __launch_bounds__(256, 4) void xcorr_two_sided_fold(const FusedParams p, const two::PairInv iv)
+{
+    using namespace occ4;
+    using namespace fold;
+    using namespace foldk;
+    using namespace two;
+    constexpr int n = 4096;
+    __shared__ double2 xbuf[OCC_XBUF];
+    __shared__ double2 g2s[128];
+    __shared__ double red[16];
+    __shared__ double arg[2][16]; // per parity: four waves x {max, value, index}, [12] = cc[0], [13] = factor, [14] = nil, [15] = NaN
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    double2 *const xw = xbuf + XW * wave;
+    const int Nx = p.Nx, Ny = p.N, padx = n - Nx, pady = n - Ny;
+    const bool normalize = p.normalize_y != 0;
+    if (t < 128)
+        g2s[t] = p.g2[t];
+    __syncthreads();
+    int parity = 0;
+    // the pair before `pair` (this workgroup's previous one): its four wave records, cc[0], factor and flags sit in LDS -- no
+    // register lives across the transforms for it
+    const auto finish_prev = [&](const long long prev_pair) __attribute__((always_inline)) {
+        if (t == 0 && prev_pair >= 0) {
+            const double *a = arg[parity ^ 1];
+            double best = 0.0, bsv = 0.0, bidx = (double)0x7fffffff;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                if (a[3 * w] > best || (a[3 * w] == best && a[3 * w + 2] < bidx)) {
+                    best = a[3 * w];
+                    bsv = a[3 * w + 1];
+                    bidx = a[3 * w + 2];
+                }
+            }
+            const int idx = (best > 0.0) ? (int)bidx : 0;
+            double mv = ((best > 0.0) ? bsv : a[12]) * a[13];
+            int lag = idx > n / 2 ? idx - n : idx;
+            const bool nil = a[14] != 0.0, nan = a[15] != 0.0;
+            if (nil) { mv = 0.0; lag = 0; }                 // xcorr.go:110-127
+            if (nan) { mv = __builtin_nan(""); lag = 0; }   // every cc is NaN: maxAbsIndex keeps index 0
+            p.mv[prev_pair] = mv;
+            p.lag[prev_pair] = lag;
+            if (p.nil_out)
+                p.nil_out[prev_pair] = nil ? 1 : 0;
+        }
+    };
+
+    long long pair = blockIdx.x;
+    for (; pair < p.npairs; pair += gridDim.x) {
+        double2 v[16];
+        {
+            const double *const rx = p.xrows + pair * p.xstride, *const ry = p.rows + pair * p.stride;
+            typedef const double __attribute__((address_space(4))) *cptr; // the shift constants through the scalar cache
+            const double KA = normalize ? *(cptr)(unsigned long long)rx : 0.0, KB = normalize ? *(cptr)(unsigned long long)ry : 0.0;
+            double q[4] = {0.0, 0.0, 0.0, 0.0};
+            // position e = t + 256 i of the padded arrays holds y[e - pady] and x[(-e mod n) - padx] (leading zero pads,
+            // xcorr.go:129-130); four batches of four positions bound the registers in flight
+#pragma unroll
+            for (int h = 0; h < 4; h++) {
+                double xa[4], yb[4];
+                int tb = t;
+                if (PADDED)
+                    asm volatile("" : "+v"(tb)); // (a batch's offsets and masks are formed in the batch, not hoisted in front of all four)
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int i = 4 * h + k;
+                    if (PADDED) {
+                        const int e = tb + 256 * i;
+                        const int ex = ((n - e) & (n - 1)) - padx, ey = e - pady;
+                        xa[k] = __builtin_nontemporal_load(scalar_ptr(rx) + (unsigned)(ex < 0 ? 0 : ex));
+                        yb[k] = __builtin_nontemporal_load(scalar_ptr(ry) + (unsigned)(ey < 0 ? 0 : ey));
+                    } else {
+                        // y[t + 256 i]; x[4096 - 256 i - t] = x[256 (15 - i) + (256 - t)] for i >= 1; position 0 reads x[0]
+                        if (i == 0)
+                            xa[k] = __builtin_nontemporal_load(scalar_ptr(rx) + (t == 0 ? 0u : (unsigned)(4096 - t)));
+                        else
+                            xa[k] = __builtin_nontemporal_load(scalar_ptr_at(rx, 256 * (15 - i)) + (unsigned)(256 - t));
+                        yb[k] = __builtin_nontemporal_load(scalar_ptr_at(ry, 256 * i) + (unsigned)t);
+                    }
+                }
+                fence();
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int i = 4 * h + k;
+                    double da = xa[k] - KA, db = yb[k] - KB;
+                    if (PADDED) {
+                        const int e = tb + 256 * i;
+                        da = ((n - e) & (n - 1)) - padx >= 0 ? da : 0.0;
+                        db = e - pady >= 0 ? db : 0.0;
+                    }
+                    v[i] = make_double2(da, db);
+                    q[0] += da;
+                    q[1] = fma(da, da, q[1]);
+                    q[2] += db;
+                    q[3] = fma(db, db, q[3]);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                q[k] = wave_sum_dpp(q[k]);
+            if (lane == 0) {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    red[4 * wave + k] = q[k];
+            }
+            lds_barrier();
+            finish_prev(pair - gridDim.x); // (its records were complete before this barrier)
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                q[k] = (red[k] + red[4 + k]) + (red[8 + k] + red[12 + k]);
+            const PairScale ps = pair_scale(q, iv, normalize);
+            const bool dead = ps.nil || ps.nan;
+            if (t == 0) {
+                arg[parity][13] = ps.fac * (1.0 / (2.0 * n)); // (pair_scale's factor assumes a spectrum already divided by n; 1 / 2n is exact)
+                arg[parity][14] = ps.nil ? 1.0 : 0.0;
+                arg[parity][15] = ps.nan ? 1.0 : 0.0;
+            }
+            const double sA = dead ? 0.0 : ps.sA, sB = dead ? 0.0 : ps.sB, mA = dead ? 0.0 : ps.mA, mB = dead ? 0.0 : ps.mB;
+            int tt = t;
+            asm volatile("" : "+v"(tt)); // (the validity masks are recomputed here, not kept in 32 register pairs across the statistics)
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int e = tt + 256 * i;
+                const bool vx = !PADDED || ((n - e) & (n - 1)) - padx >= 0, vy = !PADDED || e - pady >= 0;
+                v[i].x = vx ? fma(v[i].x, sA, -mA) : 0.0;
+                v[i].y = vy ? fma(v[i].y, sB, -mB) : 0.0;
+            }
+        }
+        // ---- Z = FFT(xr + i y): Z[hi + 16 lo + 256 k3] at v[BR16(k3)] (as xcorr_fused_n4096_fold)
+        dft16_nr(v);
+        exchange_cross<0, 1, true>(v, xbuf, wave, t);
+        gdft16_nr(v, G2Fetch{g2s, t >> 4});
+        exchange_local<1>(v, xw, t);
+        gdft16_nr_l2(v, G3Derived(p.g3a, t));
+        // ---- FFT(Z^2): the square in the first stage of the plain pass
+#pragma unroll
+        for (int r = 0; r < 16; r += 2)
+            bf_sq(v[r], v[r + 1]);
+        dft16_rn_s234(v);
+        exchange_local<0>(v, xw, t);
+        gdft16_nr(v, G2Fetch{g2s, t & 15});
+        exchange_cross<1, 1>(v, xbuf, wave, t); // (the factor and flags written before the transforms are visible behind these barriers)
+        gdft16_nr_l2(v, G3Derived(p.g3b, t)); // 2 n cc[t + 256 m] = v[BR16(m)].y
+        if (p.cc_out && arg[parity][14] == 0.0 && arg[parity][15] == 0.0) {
+            const double fac = arg[parity][13];
+            double *const cc = p.cc_out + pair * (long long)n;
+#pragma unroll
+            for (int m = 0; m < 16; m++)
+                cc[t + 256 * m] = v[BR16(m)].y * fac;
+        }
+        wave_argmax_store_one<1>(v, wave, lane, arg[parity] + 3 * wave);
+        if (t == 0)
+            arg[parity][12] = v[0].y;
+        parity ^= 1;
+    }
+    lds_barrier();
+    finish_prev(pair - gridDim.x);
 }
 
 // n = 16384 ... 65536: four-step, n = R1 * 4096 (xcorr_fused_stk_4step's geometry), TWO n-element scratch slices per
@@ -440,7 +626,17 @@ hipError_t launch_two_sided(const FusedParams &p, int num_cus, hipStream_t strea
     case 9: return launch_two_lds<9>(p, num_cus, stream);
     case 10: return launch_two_lds<10>(p, num_cus, stream);
     case 11: return launch_two_lds<11>(p, num_cus, stream);
-    case 12: return launch_two_lds<12>(p, num_cus, stream);
+    case 12: {
+        if (!p.g2 || !p.g3a || !p.g3b)
+            return hipErrorInvalidValue;
+        const long long grid = std::min<long long>(p.npairs, (long long)num_cus * 4);
+        const two::PairInv iv = two::pair_inv(p.Nx, p.N, 4096);
+        if (p.Nx == 4096 && p.N == 4096)
+            hipLaunchKernelGGL(xcorr_two_sided_fold<false>, dim3((unsigned)grid), dim3(256), 0, stream, p, iv);
+        else
+            hipLaunchKernelGGL(xcorr_two_sided_fold<true>, dim3((unsigned)grid), dim3(256), 0, stream, p, iv);
+        return hipGetLastError();
+    }
     case 13: return launch_two_lds<13>(p, num_cus, stream);
     case 14: return launch_two_4step<14>(p, num_cus, stream);
     case 15: return launch_two_4step<15>(p, num_cus, stream);

@@ -1659,6 +1659,20 @@ def test_xcorr_batch_different_lengths_and_raised_n(eng, oracle):
         muse.xcorr_groups(gx, muse.DeviceGroup.from_rows(eng, Y[:3, :512]), 512, True)   # row counts differ
 
 
+@pytest.mark.parametrize("lens", [(700, 3000), (4096, 10), (2, 4096), (4095, 4096), (4096, 4096)])
+def test_xcorr_batch_4096_lengths(eng, oracle, lens):
+    """n = 4096 runs on the xCorrWithX machinery (x read backwards, the spectrum squared): every pad geometry"""
+    rng = np.random.default_rng(lens[0] * 7 + lens[1])
+    M = 13
+    X = rng.normal(size=(M, lens[0])) * rng.uniform(0.5, 4.0, size=(M, 1)) + 3.0
+    Y = rng.normal(size=(M, lens[1])) - np.linspace(0.0, 1.0, lens[1])
+    k = min(lens)
+    Y[5, :k] = X[5, :k][::-1] * 2.0                         # a mirrored copy: the peak of a convolution, not of the correlation
+    Y[6, :k] = -X[6, :k]
+    for normalize in (True, False):
+        _check_xcorr_batch(eng, oracle, X, Y, 4096, normalize)
+
+
 def test_xcorr_batch_golden_tables(eng, golden):           # xcorr_test.go:86-202 through the batch entry (n = 5: pair by pair)
     for c in golden["xcorr"]["cases"]:
         cc, lag, mv, nil = eng.xcorr_batch([c["x"]], [c["y"]], len(c["x"]), c["normalize"], want_cc=True)
