@@ -2555,6 +2555,7 @@ extern "C" int muse_xcorr_groups(muse_group *gx, muse_group *gy, int32_t n, int3
         p.g2 = ctx->g2;
         p.g3a = ctx->g3a;
         p.g3b = ctx->g3b;
+        p.gsmall = (p.logn >= 9 && p.logn <= 11) ? ctx->gsmall[p.logn - 9] : (p.logn == 13 || p.logn == 14) ? ctx->gsmall[p.logn - 10] : nullptr;
         p.gscratch = ctx->gscratch;
         p.gscratch_slices = (long long)(ctx->gscratch_elems / (size_t)n);
         p.mv = dmv;

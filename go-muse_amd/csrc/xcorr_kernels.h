@@ -85,7 +85,9 @@ hipError_t launch_fused_multi(const FusedParams &p, int num_cus, hipStream_t str
 hipError_t launch_fused_small(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_small.hip (n = 512, 1024, 2048: default)
 hipError_t launch_fused_stockham(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_stockham.hip (n = 512 .. 2048, 8192 .. 65536)
 hipError_t launch_fused_long(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_long.hip (n = 32768, 65536: default; 16384)
-hipError_t launch_two_sided(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_two_sided.hip (xCorr, n = 512 .. 65536)
+hipError_t launch_two_sided(const FusedParams &p, int num_cus, hipStream_t stream);
+// the same for n = 512 ... 2048, 8192, 16384 on xcorr_small.hip's transforms (called by launch_two_sided)
+hipError_t launch_two_sided_small(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_two_sided.hip (xCorr, n = 512 .. 65536)
 // out[4096 k1 + 256 k + t] = in[k1 + R1 (256 k + (t >> 4) + 16 (t & 15))]: the spectrum rows of the long-series kernel in lane order
 hipError_t launch_lane_order_rows(const double2 *in, double2 *out, int R1, hipStream_t stream);
 // out[256 k + t] = in[256 k + (t >> 4) + 16 (t & 15)], k < 16: a 4096-entry table in the lane order of xcorr_r16_fold.hip

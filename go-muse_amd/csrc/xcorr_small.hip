@@ -36,6 +36,7 @@
 
 #include "fold_device.h"
 #include "r16_device.h"
+#include "two_device.h"
 
 namespace muse {
 
@@ -781,6 +782,187 @@ __global__ __launch_bounds__((LOGN >= 11 ? (1 << LOGN) / 16 : 256), ((MULTI && L
             fence();
             request(it + gridDim.x);
         }
+    }
+}
+
+// The batched two-sided xCorr (xcorr.go:102-153) on the same transforms: pair i = (x_i, y_i), each zero-padded
+// in front on its own (any Nx, Ny <= n).  With xr[j] = x[-j mod n] (the row read backwards: an address pattern) and
+// z = xr + i y:  conj(X) = FFT(xr), Z = FFT(z) = Xr + i Y, Z^2 = (Xr^2 - Y^2) + 2 i Xr Y, so
+//     cc = FFT(conj(X) Y) / n = Im FFT(Z^2) / (2 n)
+// -- two forward transforms per pair as above, the spectrum product a square of what the thread already holds: no
+// table, no mirrored element Z[-f] (round 3's first version fetched it through the Stockham engine's natural-order LDS image).
+// Statistics first (xcorr.go:108-128: either sigma == 0 -> nil), both series centred and scaled to O(1) by exact powers of
+// two (two_device.h).  Rows are requested where they are used: the kernel is bound by its arithmetic.
+template <int LOGN, bool PADDED>
+__global__ __launch_bounds__((LOGN >= 11 ? (1 << LOGN) / 16 : 256), 4) void xcorr_two_sided_small(const FusedParams p, const two::PairInv iv)
+{
+    using namespace occ4;
+    using namespace fold;
+    using namespace small;
+    constexpr int n = 1 << LOGN;
+    constexpr int S = n / 16;
+    constexpr int TPB = LOGN >= 11 ? S : 256;
+    constexpr int G = TPB / S;
+    static_assert((LOGN >= 9 && LOGN <= 11) || LOGN == 13 || LOGN == 14, "n = 512, 1024, 2048, 8192, 16384");
+    __shared__ double red[112];
+    constexpr int NP_ = (LOGN + 3) / 4, R1_ = n >> (4 * (NP_ - 1));
+    __shared__ double2 g2l[8 * R1_];
+    __shared__ double2 xbuf[(TPB / 64) * 544];
+    const int t = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int g = S >= 64 ? __builtin_amdgcn_readfirstlane(t / S) : t / S;
+    const int j = column_of_lane<LOGN>(t % S);
+    double2 *const b = xbuf + g * (8 * S + S / 2);
+    const int padx = PADDED ? n - p.Nx : 0, pady = PADDED ? n - p.N : 0;
+    const bool normalize = p.normalize_y != 0;
+    const double2 *__restrict__ twm = p.twm;
+    const double2 *__restrict__ gs = p.gsmall;
+    if (t < 8 * R1_)
+        g2l[t] = tw_factor<R1_>(twm, t % R1_, t / R1_);
+    __syncthreads();
+    const long long total = p.npairs;
+    const long long ngroups = (total + G - 1) / G;
+    for (long long it = blockIdx.x; it < ngroups; it += gridDim.x) {
+        const long long slot = it * G + g;
+        const bool live = slot < total;
+        const long long pair = live ? slot : total - 1; // idle sub-groups shadow the last pair
+        const double *const rx = p.xrows + pair * p.xstride, *const ry = p.rows + pair * p.stride;
+        double2 v[16];
+        double q[4] = {0.0, 0.0, 0.0, 0.0};
+        {
+            const double KA = normalize ? rx[0] : 0.0, KB = normalize ? ry[0] : 0.0;
+            // position e = j + i S of the padded arrays holds y[e - pady] and x[(-e mod n) - padx]; four batches of four
+#pragma unroll
+            for (int h = 0; h < 4; h++) {
+                double xa[4], yb[4];
+                int jb = j;
+                asm volatile("" : "+v"(jb)); // (a batch's offsets and masks are formed in the batch)
+                jb &= S - 1;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int e = jb + (4 * h + k) * S;
+                    const int ex = ((n - e) & (n - 1)) - padx, ey = e - pady;
+                    if (S >= 64) { // the wave works on one pair: scalar bases + 32-bit lane offsets
+                        xa[k] = __builtin_nontemporal_load(scalar_ptr(rx) + (unsigned)(PADDED && ex < 0 ? 0 : ex));
+                        yb[k] = __builtin_nontemporal_load(scalar_ptr(ry) + (unsigned)(PADDED && ey < 0 ? 0 : ey));
+                    } else {
+                        xa[k] = __builtin_nontemporal_load(rx + (PADDED && ex < 0 ? 0 : ex));
+                        yb[k] = __builtin_nontemporal_load(ry + (PADDED && ey < 0 ? 0 : ey));
+                    }
+                }
+                fence();
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int e = jb + (4 * h + k) * S;
+                    double da = xa[k] - KA, db = yb[k] - KB;
+                    if (PADDED) {
+                        da = ((n - e) & (n - 1)) - padx >= 0 ? da : 0.0;
+                        db = e - pady >= 0 ? db : 0.0;
+                    }
+                    v[4 * h + k] = make_double2(da, db);
+                    q[0] += da;
+                    q[1] = fma(da, da, q[1]);
+                    q[2] += db;
+                    q[3] = fma(db, db, q[3]);
+                }
+            }
+        }
+        pair_sum4<S>(q[0], q[1], q[2], q[3], red, wave);
+        const two::PairScale ps = two::pair_scale(q, iv, normalize);
+        const bool dead = ps.nil || ps.nan;
+        const double fac = ps.fac * (1.0 / (2.0 * n)); // (pair_scale's factor assumes a spectrum already divided by n; 1 / 2n is exact)
+        {
+            const double sA = dead ? 0.0 : ps.sA, sB = dead ? 0.0 : ps.sB, mA = dead ? 0.0 : ps.mA, mB = dead ? 0.0 : ps.mB;
+            int jb = j;
+            asm volatile("" : "+v"(jb)); // (the validity masks are recomputed, not kept across the statistics)
+            jb &= S - 1;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int e = jb + i * S;
+                const bool vx = !PADDED || ((n - e) & (n - 1)) - padx >= 0, vy = !PADDED || e - pady >= 0;
+                v[i].x = vx ? fma(v[i].x, sA, -mA) : 0.0;
+                v[i].y = vy ? fma(v[i].y, sB, -mB) : 0.0;
+            }
+        }
+        forward<LOGN>(v, b, g2l, gs, j); // Z[j + r S] at v[BR16(r)]
+        {
+            double2 w[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) { // the square, renamed to natural order
+                const double2 z = v[BR16(r)];
+                w[r] = make_double2(fma(z.x, z.x, -(z.y * z.y)), (z.x + z.x) * z.y);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                v[r] = w[r];
+        }
+        forward<LOGN>(v, b, g2l, gs, j); // 2 n cc[j + r S] at v[BR16(r)].y
+        if (p.cc_out && live && !dead) {
+            double *const cc = p.cc_out + pair * (long long)n;
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                cc[j + r * S] = v[BR16(r)].y * fac;
+        }
+        // ---- maxAbsIndex (xcorr.go:39-50): ascending r = ascending index for this thread
+        double sa = 0.0;
+        int ra_ = 0;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const double x = v[BR16(r)].y;
+            const bool ga = fabs(x) > fabs(sa);
+            sa = ga ? x : sa;
+            ra_ = ga ? r : ra_;
+        }
+        const double ma = fabs(sa);
+        const int ia = j + ra_ * S;
+        const double cc0 = v[0].y; // (lane with j == 0: cc[0], reported when nothing is above 0)
+        const double pa = pair_max<S>(ma, red, wave);
+        const int ca = pair_min_i<S>((ma == pa && pa > 0.0) ? ia : 0x7fffffff, red + 96, wave);
+        if (live) {
+            const bool own = ca == 0x7fffffff ? j == 0 : (ia == ca && ma == pa);
+            if (own) {
+                const int idx = ca == 0x7fffffff ? 0 : ca;
+                double mv = (ca == 0x7fffffff ? cc0 : sa) * fac;
+                int lag = idx > n / 2 ? idx - n : idx;
+                if (ps.nil) { mv = 0.0; lag = 0; }               // xcorr.go:110-127
+                if (ps.nan) { mv = __builtin_nan(""); lag = 0; } // every cc is NaN: maxAbsIndex keeps index 0
+                p.mv[pair] = mv;
+                p.lag[pair] = lag;
+                if (p.nil_out)
+                    p.nil_out[pair] = ps.nil ? 1 : 0;
+            }
+        }
+        if (S > 64)
+            lds_barrier(); // (red is reused by the next pair's statistics)
+    }
+}
+
+template <int LOGN>
+static hipError_t launch_two_small_n(const FusedParams &p, int num_cus, hipStream_t stream)
+{
+    constexpr int TPB = LOGN >= 11 ? (1 << LOGN) / 16 : 256;
+    constexpr int G = TPB / ((1 << LOGN) / 16);
+    const long long ngroups = (p.npairs + G - 1) / G;
+    const long long grid = std::min<long long>(ngroups, (long long)num_cus * (1024 / TPB) * 8);
+    const two::PairInv iv = two::pair_inv(p.Nx, p.N, 1 << LOGN);
+    if (p.Nx < (1 << LOGN) || p.N < (1 << LOGN))
+        hipLaunchKernelGGL((xcorr_two_sided_small<LOGN, true>), dim3((unsigned)grid), dim3(TPB), 0, stream, p, iv);
+    else
+        hipLaunchKernelGGL((xcorr_two_sided_small<LOGN, false>), dim3((unsigned)grid), dim3(TPB), 0, stream, p, iv);
+    return hipGetLastError();
+}
+// two-sided xCorr, n = 512, 1024, 2048, 8192, 16384 (launch_two_sided's argument checks apply)
+hipError_t launch_two_sided_small(const FusedParams &p, int num_cus, hipStream_t stream)
+{
+    if (!p.xrows || !p.rows || !p.twm || !p.gsmall || !p.mv || !p.lag)
+        return hipErrorInvalidValue;
+    switch (p.logn) {
+    case 9: return launch_two_small_n<9>(p, num_cus, stream);
+    case 10: return launch_two_small_n<10>(p, num_cus, stream);
+    case 11: return launch_two_small_n<11>(p, num_cus, stream);
+    case 13: return launch_two_small_n<13>(p, num_cus, stream);
+    case 14: return launch_two_small_n<14>(p, num_cus, stream);
+    default: return hipErrorInvalidValue;
     }
 }
 

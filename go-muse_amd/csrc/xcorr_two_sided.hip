@@ -20,6 +20,7 @@
 
 #include "stk_device.h"
 #include "foldk_device.h"
+#include "two_device.h"
 
 namespace muse {
 
@@ -36,211 +37,7 @@ __device__ __forceinline__ double2 untangle(const double2 z, const double2 zm, c
     return make_double2(re * s, -im * s);
 }
 
-// what the statistics of one pair decide (uniform over the pair's threads)
-struct PairScale {
-    double sA, sB, mA, mB; // v = x * s - m at valid positions
-    double fac;            // cc = transform output * fac
-    bool nil, nan;
-};
-// q = {sum dx, sum dx^2, sum dy, sum dy^2} with d = sample - first sample (normalized) or the sample itself (raw)
-// the launch's reciprocals (uniform)
-struct PairInv {
-    double invNx, invNxm1, invNy, invNym1, invnm1;
-};
-__host__ __device__ __forceinline__ PairInv pair_inv(const int Nx, const int Ny, const int n)
-{
-    return PairInv{1.0 / (double)Nx, 1.0 / (double)(Nx - 1), 1.0 / (double)Ny, 1.0 / (double)(Ny - 1), 1.0 / (double)(n - 1)};
-}
-__device__ __forceinline__ PairScale pair_scale(const double (&q)[4], const PairInv &iv, const bool normalize)
-{
-    PairScale s;
-    if (normalize) {
-        bool zA, nA, zB, nB;
-        const double invNx = iv.invNx, invNy = iv.invNy;
-        const double vA0 = variance(Stat{q[0], q[1]}, invNx, iv.invNxm1, zA, nA);
-        const double vB0 = variance(Stat{q[2], q[3]}, invNy, iv.invNym1, zB, nB);
-        s.nil = zA || zB; // xcorr.go:110-127: either sigma == 0 -> (nil, 0, 0) (x is checked first; a NaN x with a constant y is nil too)
-        s.nan = !s.nil && (nA || nB);
-        const bool dead = s.nil || s.nan;
-        s.sA = dead ? 1.0 : pow2_inv_sigma(vA0);
-        s.sB = dead ? 1.0 : pow2_inv_sigma(vB0);
-        s.mA = q[0] * invNx * s.sA;
-        s.mB = q[2] * invNy * s.sB;
-        const double vA = vA0 * s.sA * s.sA, vB = vB0 * s.sB * s.sB;
-        double ya = __builtin_amdgcn_rsq(vA), yb = __builtin_amdgcn_rsq(vB);
-        ya = ya * fma(-0.5 * vA * ya, ya, 1.5);
-        ya = ya * fma(-0.5 * vA * ya, ya, 1.5);
-        yb = yb * fma(-0.5 * vB * yb, yb, 1.5);
-        yb = yb * fma(-0.5 * vB * yb, yb, 1.5);
-        s.fac = ya * yb * iv.invnm1; // xcorr.go:140: 1 / (n (n - 1)); the 1 / n rides in the untangled spectrum
-    } else {
-        const double eA = q[1] * iv.invNx, eB = q[3] * iv.invNy; // mean squares (only their binary exponents are used)
-        s.nil = false;
-        s.nan = !__builtin_isfinite(eA) || !__builtin_isfinite(eB);
-        s.sA = (s.nan || !(eA > 0.0)) ? 1.0 : pow2_inv_sigma(eA);
-        s.sB = (s.nan || !(eB > 0.0)) ? 1.0 : pow2_inv_sigma(eB);
-        s.mA = s.mB = 0.0;
-        s.fac = (1.0 / s.sA) * (1.0 / s.sB); // exact
-    }
-    return s;
-}
-__device__ __forceinline__ PairScale pair_scale(const double (&q)[4], const int Nx, const int Ny, const int n, const bool normalize)
-{
-    return pair_scale(q, pair_inv(Nx, Ny, n), normalize);
-}
-
 } // namespace two
-
-// n = 512 ... 8192: n/16 threads per pair, the pair's work buffer in LDS (xcorr_fused_stk_lds's geometry)
-template <int LOGN>
-__global__ __launch_bounds__(((1 << LOGN) / 16 > 256 ? (1 << LOGN) / 16 : 256), ((1 << LOGN) / 16 >= 256 ? 1 : 2))
-void xcorr_two_sided_lds(const FusedParams p)
-{
-    using namespace occ4;
-    using namespace stk;
-    using namespace two;
-    constexpr int n = 1 << LOGN;
-    constexpr int S = n / 16;
-    constexpr int G = S >= 256 ? 1 : 256 / S;
-    constexpr int TPB = S * G;
-    constexpr int ROWS = S / 16;
-    constexpr int BUF = n + n / 16;
-    static_assert(LOGN >= 9 && LOGN <= 13, "LDS kernel: n = 512 ... 8192");
-    __shared__ double2 buf[G * BUF];
-    __shared__ double red[(TPB / 16) * 4];
-    __shared__ double arg[(TPB / 16) * 3];
-    const int t = threadIdx.x;
-    const int g = t / S, j = t % S;
-    const int row = t >> 4;
-    double2 *const b = buf + g * BUF;
-    const int Nx = p.Nx, Ny = p.N, padx = n - Nx, pady = n - Ny;
-    const bool normalize = p.normalize_y != 0;
-    const double2 *__restrict__ twm = p.twm;
-    const long long total = p.npairs;
-    const long long ngroups = (total + G - 1) / G;
-    const int rbase = j + (j >> 4); // padpos(j + r S) = rbase + r padk(S)
-
-    for (long long it = blockIdx.x; it < ngroups; it += gridDim.x) {
-        const long long slot = it * G + g;
-        const bool live = slot < total;
-        const long long pair = live ? slot : total - 1; // idle sub-groups shadow the last pair
-        const double *__restrict__ rx = p.xrows + pair * p.xstride;
-        const double *__restrict__ ry = p.rows + pair * p.stride;
-        double2 v[16];
-        const double KA = normalize ? rx[0] : 0.0, KB = normalize ? ry[0] : 0.0;
-        double q[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const int ex = j + i * S - padx, ey = j + i * S - pady;
-            double da = __builtin_nontemporal_load(rx + (ex < 0 ? 0 : ex)) - KA;
-            double db = __builtin_nontemporal_load(ry + (ey < 0 ? 0 : ey)) - KB;
-            da = ex >= 0 ? da : 0.0;
-            db = ey >= 0 ? db : 0.0;
-            v[i] = make_double2(da, db);
-            q[0] += da;
-            q[1] = fma(da, da, q[1]);
-            q[2] += db;
-            q[3] = fma(db, db, q[3]);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            q[k] = row_sum_dpp(q[k]);
-        if ((t & 15) == 0) {
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                red[row * 4 + k] = q[k];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            double s = 0.0;
-            for (int r = 0; r < ROWS; r++)
-                s += red[(g * ROWS + r) * 4 + k];
-            q[k] = s;
-        }
-        const PairScale ps = pair_scale(q, Nx, Ny, n, normalize);
-        const bool dead = ps.nil || ps.nan;
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const bool vx = j + i * S - padx >= 0, vy = j + i * S - pady >= 0;
-            v[i].x = (vx && !dead) ? fma(v[i].x, ps.sA, -ps.mA) : 0.0;
-            v[i].y = (vy && !dead) ? fma(v[i].y, ps.sB, -ps.mB) : 0.0;
-        }
-        // Z = FFT(x + i y): Z[j + r S] at v[BR16(r)]
-        lds_forward<LOGN, false>(v, b, twm, j);
-        __syncthreads(); // every thread is past its last read of the buffer
-#pragma unroll
-        for (int r = 0; r < 16; r++)
-            b[rbase + r * padk(S)] = v[BR16(r)];
-        __syncthreads();
-        {
-            double2 w[16];
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int fm = (n - (j + r * S)) & (n - 1);
-                w[r] = untangle(v[BR16(r)], b[padpos(fm)], 1.0 / (double)n);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-                v[r] = w[r];
-        }
-        // cc = FFT(conj(P) / n): real part at v[BR16(i)] for index j + i S
-        lds_forward<LOGN, true>(v, b, twm, j);
-        double ma = 0.0, sa = 0.0;
-        int ia = 0x7fffffff;
-#pragma unroll
-        for (int i = 0; i < 16; i++) { // ascending i = ascending index for this thread
-            const double x = v[BR16(i)].x, aa = fabs(x);
-            if (aa > ma) { ma = aa; sa = x; ia = j + i * S; }
-        }
-        if (p.cc_out && live && !dead) {
-            double *const cc = p.cc_out + pair * (long long)n;
-#pragma unroll
-            for (int i = 0; i < 16; i++)
-                cc[j + i * S] = v[BR16(i)].x * ps.fac;
-        }
-        {
-            const double rma = row_max_dpp(ma);
-            const int ca = row_min_i_dpp((ma == rma && rma > 0.0) ? ia : 0x7fffffff);
-            if (ca == 0x7fffffff) {
-                if ((t & 15) == 0) {
-                    arg[row * 3 + 0] = 0.0;
-                    arg[row * 3 + 1] = 0.0;
-                    arg[row * 3 + 2] = (double)0x7fffffff;
-                }
-            } else if (ia == ca && ma == rma) {
-                arg[row * 3 + 0] = rma;
-                arg[row * 3 + 1] = sa;
-                arg[row * 3 + 2] = (double)ca;
-            }
-        }
-        if (j == 0) // cc[0], for the "nothing above zero" case (index 0, mv = cc[0])
-            red[g * ROWS * 4] = v[0].x;
-        __syncthreads();
-        if (j == 0 && live) {
-            double best = 0.0, bsv = 0.0, bidx = (double)0x7fffffff;
-#pragma unroll
-            for (int r = 0; r < ROWS; r++) {
-                const double *a = arg + (g * ROWS + r) * 3;
-                if (a[0] > best || (a[0] == best && a[2] < bidx)) {
-                    best = a[0];
-                    bsv = a[1];
-                    bidx = a[2];
-                }
-            }
-            const int idx = (best > 0.0) ? (int)bidx : 0;
-            double mv = ((best > 0.0) ? bsv : red[g * ROWS * 4]) * ps.fac;
-            int lag = idx > n / 2 ? idx - n : idx;
-            if (ps.nil) { mv = 0.0; lag = 0; }                 // xcorr.go:110-127
-            if (ps.nan) { mv = __builtin_nan(""); lag = 0; }   // every cc is NaN: maxAbsIndex keeps index 0
-            p.mv[pair] = mv;
-            p.lag[pair] = lag;
-            if (p.nil_out)
-                p.nil_out[pair] = ps.nil ? 1 : 0;
-        }
-        __syncthreads(); // red / arg / buf free for the next iteration
-    }
-}
 
 // n = 4096 on the xCorrWithX kernel's machinery (foldk_device.h: three radix-16 passes per transform with the twiddles
 // folded into the butterflies, half-round LDS transposes, 128 registers -> four workgroups per CU) WITHOUT the mirrored
@@ -430,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void xcorr_two_sided_4step(const FusedParam
     constexpr int CH = S / 256;
     constexpr int R1 = n / 4096;
     constexpr int Q1 = 16 / R1;
-    static_assert(LOGN >= 14 && LOGN <= 16, "four-step kernel: n = 16384 ... 65536");
+    static_assert(LOGN >= 15 && LOGN <= 16, "four-step kernel: n = 32768, 65536");
     __shared__ double2 buf[4096 + 256];
     __shared__ double red[64];
     __shared__ int redi[16];
@@ -592,19 +389,6 @@ __global__ __launch_bounds__(256, 2) void xcorr_two_sided_4step(const FusedParam
 }
 
 template <int LOGN>
-static hipError_t launch_two_lds(const FusedParams &p, int num_cus, hipStream_t stream)
-{
-    constexpr int S = (1 << LOGN) / 16;
-    constexpr int G = S >= 256 ? 1 : 256 / S;
-    constexpr int TPB = S * G;
-    constexpr int WPC = S >= 256 ? 1 : 2;
-    const long long ngroups = (p.npairs + G - 1) / G;
-    const long long grid = std::min<long long>(ngroups, (long long)num_cus * WPC * 8);
-    hipLaunchKernelGGL((xcorr_two_sided_lds<LOGN>), dim3((unsigned)grid), dim3(TPB), 0, stream, p);
-    return hipGetLastError();
-}
-
-template <int LOGN>
 static hipError_t launch_two_4step(const FusedParams &p, int num_cus, hipStream_t stream)
 {
     const long long grid = std::min<long long>(p.npairs, (long long)num_cus * STOCKHAM_GLOBAL_WGS_PER_CU);
@@ -623,9 +407,12 @@ hipError_t launch_two_sided(const FusedParams &p, int num_cus, hipStream_t strea
         (p.normalize_y && (p.Nx < 2 || p.N < 2)))
         return hipErrorInvalidValue;
     switch (p.logn) {
-    case 9: return launch_two_lds<9>(p, num_cus, stream);
-    case 10: return launch_two_lds<10>(p, num_cus, stream);
-    case 11: return launch_two_lds<11>(p, num_cus, stream);
+    case 9:
+    case 10:
+    case 11:
+    case 13:
+    case 14:
+        return launch_two_sided_small(p, num_cus, stream);
     case 12: {
         if (!p.g2 || !p.g3a || !p.g3b)
             return hipErrorInvalidValue;
@@ -637,8 +424,6 @@ hipError_t launch_two_sided(const FusedParams &p, int num_cus, hipStream_t strea
             hipLaunchKernelGGL(xcorr_two_sided_fold<true>, dim3((unsigned)grid), dim3(256), 0, stream, p, iv);
         return hipGetLastError();
     }
-    case 13: return launch_two_lds<13>(p, num_cus, stream);
-    case 14: return launch_two_4step<14>(p, num_cus, stream);
     case 15: return launch_two_4step<15>(p, num_cus, stream);
     case 16: return launch_two_4step<16>(p, num_cus, stream);
     default: return hipErrorInvalidValue;

@@ -1659,18 +1659,22 @@ def test_xcorr_batch_different_lengths_and_raised_n(eng, oracle):
         muse.xcorr_groups(gx, muse.DeviceGroup.from_rows(eng, Y[:3, :512]), 512, True)   # row counts differ
 
 
-@pytest.mark.parametrize("lens", [(700, 3000), (4096, 10), (2, 4096), (4095, 4096), (4096, 4096)])
-def test_xcorr_batch_4096_lengths(eng, oracle, lens):
-    """n = 4096 runs on the xCorrWithX machinery (x read backwards, the spectrum squared): every pad geometry"""
+@pytest.mark.parametrize("n", [512, 1024, 2048, 4096, 8192, 16384])
+@pytest.mark.parametrize("geom", ["short_long", "full_tiny", "two_full", "minus_one", "full_full"])
+def test_xcorr_batch_pad_geometries(eng, oracle, n, geom):
+    """n <= 16384 runs on the xCorrWithX transforms (x read backwards, the spectrum squared): every pad geometry, each
+    series padded on its own (xcorr.go:129-130)"""
+    lens = {"short_long": (n // 6 + 17, 3 * n // 4 - 1), "full_tiny": (n, 10), "two_full": (2, n), "minus_one": (n - 1, n),
+            "full_full": (n, n)}[geom]
     rng = np.random.default_rng(lens[0] * 7 + lens[1])
-    M = 13
+    M = 13 if n <= 4096 else 5
     X = rng.normal(size=(M, lens[0])) * rng.uniform(0.5, 4.0, size=(M, 1)) + 3.0
     Y = rng.normal(size=(M, lens[1])) - np.linspace(0.0, 1.0, lens[1])
     k = min(lens)
-    Y[5, :k] = X[5, :k][::-1] * 2.0                         # a mirrored copy: the peak of a convolution, not of the correlation
-    Y[6, :k] = -X[6, :k]
+    Y[3, :k] = X[3, :k][::-1] * 2.0                         # a mirrored copy: the peak of a convolution, not of the correlation
+    Y[4, :k] = -X[4, :k]
     for normalize in (True, False):
-        _check_xcorr_batch(eng, oracle, X, Y, 4096, normalize)
+        _check_xcorr_batch(eng, oracle, X, Y, n, normalize)
 
 
 def test_xcorr_batch_golden_tables(eng, golden):           # xcorr_test.go:86-202 through the batch entry (n = 5: pair by pair)
