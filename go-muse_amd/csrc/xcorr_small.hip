@@ -580,7 +580,24 @@ __global__ __launch_bounds__((LOGN >= 11 ? (1 << LOGN) / 16 : 256), ((MULTI && L
         // first S samples instead -- the same unconditional load instruction (a branch around it parks the row registers in
         // scratch), an L2 hit instead of HBM bytes.
         const auto all_pad = [&](int i) __attribute__((always_inline)) { return PADDED && i < 8 && (i + 1) * S <= pad; };
-        if (S >= 64) { // the wave works on one pair: scalar bases + the shared VGPR offset 8 j
+        if (S >= 64 && !PADDED) { // the wave works on one pair: scalar bases + the shared VGPR offset 8 j; ONE base per row serves
+                                  // every request whose immediate offset (-4096 ... 4095 bytes) reaches it
+            KA = scalar_ptr(ra)[0];
+            KB = scalar_ptr(rb)[0];
+            constexpr int PER = S <= 64 ? 8 : S <= 128 ? 4 : S <= 512 ? 2 : 1;
+#pragma unroll
+            for (int gq = 0; gq < 16 / PER; gq++) {
+                constexpr int HALF = PER / 2;
+                const int c = (gq * PER + HALF) * S;
+                const gptr<double> ba = scalar_ptr_at(ra, c), bb = scalar_ptr_at(rb, c);
+#pragma unroll
+                for (int k = 0; k < PER; k++) {
+                    const int i = gq * PER + k;
+                    xa[i] = __builtin_nontemporal_load(ba + (i * S - c) + (unsigned)jr);
+                    xb[i] = __builtin_nontemporal_load(bb + (i * S - c) + (unsigned)jr);
+                }
+            }
+        } else if (S >= 64) {
             KA = scalar_ptr(ra)[0];
             KB = scalar_ptr(rb)[0];
 #pragma unroll
@@ -600,9 +617,16 @@ __global__ __launch_bounds__((LOGN >= 11 ? (1 << LOGN) / 16 : 256), ((MULTI && L
             }
         }
     };
-    if (blockIdx.x < ngroups)
+    // n <= 1024 (a wave holds one or two whole pairs, no workgroup barrier anywhere): the rows are requested where they are
+    // consumed -- the sixteen waves of a CU hide the latency, and the 64 registers a prefetch would hold across the argmax
+    // and the write-out are worth more (n = 512: 0.543 -> 0.453 ms per 400 000 series, 37.9 -> 45.4 % of the roofline;
+    // n = 1024: +2 %; from n = 2048 the prefetch wins, at n = 16384 by 7 %).
+    constexpr bool PREFETCH = MULTI || LOGN >= 11;
+    if (PREFETCH && blockIdx.x < ngroups)
         request(blockIdx.x);
     for (long long it = blockIdx.x; it < ngroups; it += gridDim.x) {
+        if (!PREFETCH)
+            request(it);
         const long long slot = it * G + g;
         const bool live = slot < total;
         const long long sl = live ? slot : total - 1; // idle sub-groups shadow the last pair
@@ -694,8 +718,14 @@ __global__ __launch_bounds__((LOGN >= 11 ? (1 << LOGN) / 16 : 256), ((MULTI && L
             int jx = j;
             asm volatile("" : "+v"(jx)); // (the table offsets are derived here, not hoisted out of the pair loop)
             jx &= S - 1;
+            // one scalar base per PERX table rows (16 S bytes apart; immediate offsets -4096 ... 4095 bytes), formed once
+            constexpr int PERX = S <= 32 ? 16 : S <= 64 ? 8 : S <= 128 ? 4 : S <= 256 ? 2 : 1;
+            gptr<double2> xbase[16 / PERX];
+#pragma unroll
+            for (int gq = 0; gq < 16 / PERX; gq++)
+                xbase[gq] = scalar_ptr_at(xcr, (gq * PERX + PERX / 2) * S);
             const auto xcl = [&](int r) __attribute__((always_inline)) {
-                return ldg2u(scalar_ptr_at(xcr, r * S), (unsigned)jx);
+                return ldg2u(xbase[r / PERX] + (r * S - ((r / PERX) * PERX + PERX / 2) * S), (unsigned)jx);
             };
             double2 xq[2][4];
 #pragma unroll
@@ -741,7 +771,7 @@ __global__ __launch_bounds__((LOGN >= 11 ? (1 << LOGN) / 16 : 256), ((MULTI && L
         const int ia = j + ra_ * S, ib = j + rb_ * S;
         const double cc0a = v[0].x, cc0b = v[0].y; // (lane 0: cc[0], reported when nothing is above 0)
         fence();
-        if (!MULTI)
+        if (!MULTI && PREFETCH)
             request(it + gridDim.x); // the next iteration's rows: in flight during the reductions and the result write-out
         fence();
         double pa = ma, pb = mb;
