@@ -5,14 +5,16 @@
 // cc = IFFT(X conj(Y)) (134-138), scale 1 / (n (n - 1)) when normalized, else 1 / n (139-143) -- n - 1 of the FFT length,
 // not of the series length --, global first-strict argmax of |cc| and lag unwrap (145-150).
 //
-// One complex transform serves both series of a pair: z = x + i y, Z = FFT(z).  With Zm[f] = Z[-f mod n]
+// n <= 16384: the squared-spectrum form (xcorr_two_sided_fold below for n = 4096, xcorr_small.hip for the other lengths).
+// n >= 32768 (four-step kernel at the end of this file): one complex transform serves both series of a pair:
+// z = x + i y, Z = FFT(z).  With Zm[f] = Z[-f mod n]
 //     X[f] = (Z[f] + conj(Zm[f])) / 2,   Y[f] = (Z[f] - conj(Zm[f])) / 2i
 //     P[f] = X[f] conj(Y[f]):   Re P = Im(Z[f] Zm[f]) / 2,   Im P = (|Z[f]|^2 - |Zm[f]|^2) / 4
 // and cc = IFFT(P) is real, so FFT(conj(P) / n) = cc: a pair costs two FORWARD complex transforms of length n, exactly
 // what a pair of series costs in the xCorrWithX kernels.  The transforms are the Stockham engine's (stk_device.h: natural
-// order in LDS, folded arithmetic), whose output order makes the mirrored element Z[-f] one LDS (n <= 8192) or one scratch
-// (n >= 16384) read away.  Both series enter the shared transform at O(1): exact power-of-two scales near 1 / sigma (or
-// near 1 / rms when not normalized), undone in the one factor the winning value is multiplied by.
+// order, folded arithmetic), whose output order makes the mirrored element Z[-f] one scratch read away.  Both series enter
+// the shared transform at O(1): exact power-of-two scales near 1 / sigma (or near 1 / rms when not normalized), undone in
+// the one factor the winning value is multiplied by (two_device.h).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>

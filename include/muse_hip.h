@@ -279,8 +279,9 @@ int muse_xcorr(muse_ctx *ctx, const double *x, int32_t lenx, const double *y,
 /* xCorr (xcorr.go:102-153) for M independent pairs in ONE launch: pair i = (row i of gx, row i of gy).
  * The two groups may hold series of different lengths (each is zero-padded on its own, xcorr.go:129-130); n is raised
  * to max(n, Nx, Ny) (xcorr.go:104-106).  FFT lengths 512 ... 65536 that are powers of two run the batched kernels
- * (xcorr_two_sided.hip: z = x + i y, one forward transform, X conj(Y) untangled from Z[f] and Z[-f], one more forward
- * transform, scale 1 / (n (n - 1)) when normalized else 1 / n, exactly as xcorr.go:139-143); any other n (the
+ * (n <= 16384: z = (x read backwards) + i y, one forward transform, cc = Im FFT(Z^2) / 2n on the xCorrWithX kernels'
+ * transforms -- xcorr_two_sided.hip, xcorr_small.hip; n >= 32768: z = x + i y, X conj(Y) untangled from Z[f] and Z[-f],
+ * one more forward transform; scale 1 / (n (n - 1)) when normalized else 1 / n, exactly as xcorr.go:139-143); any other n (the
  * reference's n = 5 tables, short series) goes pair by pair through muse_xcorr's path.  The groups are not mutated
  * (the reference's zNormalize mutates x and y in place).
  * Outputs (host): lag[M], mv[M]; is_nil[M] (may be NULL) = 1 where the reference returns (nil, 0, 0), i.e. normalize
