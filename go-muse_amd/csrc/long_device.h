@@ -89,6 +89,37 @@ __device__ __forceinline__ void row_transforms(double2 (&v)[16], double2 *xbuf, 
     gdft16_nr_l2(v, G3Fetch{g3b, t});
 }
 
+// the two halves on their own (many references in one pass, xcorr_fused_long<.., MULTI>): the row's spectrum is stored in
+// REGISTER order (register r of thread t at element t + 256 r -- every thread re-reads only what it wrote) and taken from
+// there once per reference
+__device__ __forceinline__ void row_forward(double2 (&v)[16], double2 *xbuf, double2 *xw, const double2 *g2s,
+                                            const double2 *__restrict__ g3a, const int t, const int wave, const bool zero0)
+{
+    dft16_nr(v);
+    exchange_cross<0, 1, true>(v, xbuf, wave, t);
+    gdft16_nr(v, G2Fetch{g2s, t >> 4});
+    exchange_local<1>(v, xw, t);
+    gdft16_nr_l2(v, G3Fetch{g3a, t});
+    if (zero0) {
+        v[0].x = (t == 0) ? 0.0 : v[0].x;
+        v[0].y = (t == 0) ? 0.0 : v[0].y;
+    }
+}
+__device__ __forceinline__ void row_second(double2 (&v)[16], double2 *xbuf, double2 *xw, const double2 *g2s,
+                                           const double2 *__restrict__ g3b, const double2 *__restrict__ xrow, const int t,
+                                           const int wave)
+{
+    const auto xcl = [&](int j) __attribute__((always_inline)) {
+        return ldg2(scalar_ptr_at(xrow, 256 * ((j + 1) & ~1)), t - 256 * (j & 1));
+    };
+    xc_stage1(v, xcl);
+    dft16_rn_s234(v);
+    exchange_local<0>(v, xw, t);
+    gdft16_nr(v, G2Fetch{g2s, t & 15});
+    exchange_cross<1, 1>(v, xbuf, wave, t);
+    gdft16_nr_l2(v, G3Fetch{g3b, t});
+}
+
 } // namespace lng
 
 } // namespace muse

@@ -894,11 +894,11 @@ static int build_spectrum(muse_ctx *ctx, const double *ref_host, int N, int n, i
     return MUSE_OK;
 }
 
-static hipError_t ensure_gscratch(muse_ctx *ctx, int64_t n)
+static hipError_t ensure_gscratch(muse_ctx *ctx, int64_t n, int slices_per_cu = GSCRATCH_SLICES_PER_CU)
 {
     if (n < GENERIC_LDS_MAX_N) // generic kernel above 8192: one slice per workgroup; Stockham from 8192: up to two
         return hipSuccess;
-    const size_t need = (size_t)ctx->num_cus * GSCRATCH_SLICES_PER_CU * (size_t)n;
+    const size_t need = (size_t)ctx->num_cus * (size_t)slices_per_cu * (size_t)n;
     std::lock_guard<std::mutex> lock(ctx->stage_mu); // launches that use the buffer hold the same lock (muse_batch_score)
     if (need <= ctx->gscratch_elems)
         return hipSuccess;
@@ -2060,11 +2060,13 @@ extern "C" int muse_batch_score_many(muse_batch *const *bs, int32_t R)
     // selection); everything else scores the batches one after the other
     const bool small_n = (b0->n >= 512 && b0->n <= 2048) || b0->n == 8192 || b0->n == 16384; // xcorr_small.hip's lengths
     // (float32-storage groups: the n = 4096 one-pass kernel reads them; the other lengths' one-pass builds do not)
+    // long series (xcorr_long.hip, MULTI): 3 + 3 R slice crossings per pair against 4 R -- from three references on
+    const bool long_n = (b0->n == 32768 || b0->n == 65536) && R >= 3 && !b0->g->f32 && ctx->variant == 0 && b0->logn >= 14 && ctx->twl[b0->logn - 14];
     bool one_pass = R > 1 &&
                     ((b0->n == 4096 && (ctx->variant == 0 || ctx->variant == 10)) ||
-                     (small_n && !b0->g->f32 && (ctx->variant == 0 || ctx->variant == 12)));
+                     (small_n && !b0->g->f32 && (ctx->variant == 0 || ctx->variant == 12)) || long_n);
     for (int r = 0; r < R && one_pass; r++)
-        one_pass = bs[r]->N == b0->N && (small_n || b0->N == 4096 || bs[r]->c1 != nullptr);
+        one_pass = bs[r]->N == b0->N && (small_n || b0->N == b0->n || bs[r]->c1 != nullptr) && (!long_n || bs[r]->xcp != nullptr);
     if (!one_pass) {
         for (int r = 0; r < R; r++) {
             int rc = muse_batch_score(bs[r]);
@@ -2087,6 +2089,8 @@ extern "C" int muse_batch_score_many(muse_batch *const *bs, int32_t R)
         if (rc)
             return rc;
     }
+    if (long_n) // two n-element slices per resident workgroup
+        HIP_TRY(ensure_gscratch(ctx, b0->n, 2 * LONG_WGS_PER_CU));
     if (b0->n == 16384 && !ctx->zscratch) { // (every other length keeps the spectra in registers: no scratch)
         const int slots = ctx->num_cus * 4; // one 64 KB slice per resident workgroup
         HIP_TRY(hipMalloc(&ctx->zscratch, (size_t)slots * 4096 * sizeof(double2)));
@@ -2127,6 +2131,13 @@ extern "C" int muse_batch_score_many(muse_batch *const *bs, int32_t R)
     p.ovf_count = b0->ovf_count;
     p.work_counter = b0->ovf_count + 1;
     p.ovf_list = b0->ovf_list;
+    // (the long-series kernel works in the context's scratch buffer: its pointer must not be swapped between reading it and the launch)
+    std::unique_lock<std::mutex> scratch_lock(ctx->stage_mu, std::defer_lock);
+    if (long_n) {
+        scratch_lock.lock();
+        p.gscratch = ctx->gscratch;
+        p.gscratch_slices = (long long)(ctx->gscratch_elems / (size_t)b0->n);
+    }
     LaunchTimer timer(ctx);
     HIP_TRY(hipMemsetAsync(b0->ovf_count, 0, 2 * sizeof(int), ctx->stream));
     HIP_TRY(timer.begin());
@@ -2134,7 +2145,9 @@ extern "C" int muse_batch_score_many(muse_batch *const *bs, int32_t R)
         HIP_TRY(launch_fused_small(p, ctx->num_cus, ctx->stream));
         for (int r = 0; r < R; r++)
             bs[r]->scores_exact = true;
-    } else
+    } else if (long_n)
+        HIP_TRY(launch_fused_long(p, ctx->num_cus, ctx->stream));
+    else
         HIP_TRY(launch_fused_multi(p, ctx->num_cus, ctx->stream));
     HIP_TRY(timer.end());
     // pairs holding a NaN/Inf series (listed once, by reference 0): redone per reference by the
@@ -2143,8 +2156,13 @@ extern "C" int muse_batch_score_many(muse_batch *const *bs, int32_t R)
         FusedParams q = base_params(bs[r]);
         q.pair_list = b0->ovf_list;
         q.pair_count = b0->ovf_count;
-        q.npairs = std::min<long long>(q.npairs, (long long)ctx->num_cus * 3);
-        HIP_TRY(launch_fused(q, KERNEL_R16_OCC3, ctx->num_cus, ctx->stream));
+        if (long_n) { // (the four-step kernel that isolates and rescales first, as behind a single long-series pass)
+            q.npairs = std::min<long long>(q.npairs, (long long)ctx->num_cus * STOCKHAM_GLOBAL_WGS_PER_CU);
+            HIP_TRY(launch_fused(q, KERNEL_STOCKHAM, ctx->num_cus, ctx->stream));
+        } else {
+            q.npairs = std::min<long long>(q.npairs, (long long)ctx->num_cus * 3);
+            HIP_TRY(launch_fused(q, KERNEL_R16_OCC3, ctx->num_cus, ctx->stream));
+        }
         bs[r]->scores_exact = true; // mv / lag of every batch now hold fp64 results for every row
     }
     return MUSE_OK;

@@ -62,6 +62,15 @@ __device__ __forceinline__ gptr<T> scalar_ptr_at(const T *p, long long off)
     asm volatile("" : "+s"(u));
     return (gptr<T>)u;
 }
+// a wave-uniform pointer fetched from a device table, forced into SGPRs (the compiler cannot prove uniformity)
+template <typename T>
+__device__ __forceinline__ T *uniform_ptr(T *ptr)
+{
+    const unsigned long long u = (unsigned long long)ptr;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return (T *)(((unsigned long long)hi << 32) | lo);
+}
+
 // 16-byte global load of one complex value (native vector type: HIP's double2
 // struct cannot be copied out of an address_space(1) reference)
 __device__ __forceinline__ double2 ldg2(gptr<double2> p, int i)

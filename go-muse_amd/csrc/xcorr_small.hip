@@ -476,15 +476,6 @@ __device__ __forceinline__ int column_of_lane(const int l)
     return (l & ~0x18) | (b3 << 3) | (rg << 4);
 }
 
-// a wave-uniform pointer fetched from a device table, forced into SGPRs (the compiler cannot prove uniformity)
-template <typename T>
-__device__ __forceinline__ T *uniform_ptr(T *ptr)
-{
-    const unsigned long long u = (unsigned long long)ptr;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
-    return (T *)(((unsigned long long)hi << 32) | lo);
-}
-
 } // namespace small
 
 // PADDED: N < n (leading zero pad); N == n needs no per-sample validity masks

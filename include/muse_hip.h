@@ -242,9 +242,11 @@ int muse_merge_group_records(const muse_record *records, const uint8_t *state,
  * scored exactly as muse_batch_score would, but in ONE pass over the rows:
  * every pair of series is read and forward-transformed once and correlated
  * against all R reference spectra (FFT lengths 512 ... 16384, i.e.
- * 256 < N <= 16384; float32-storage groups: FFT length 4096; shorter and
- * longer series and forced kernel variants score the batches one after the
- * other).  Results land in each
+ * 256 < N <= 16384, from two references on; FFT lengths 32768 and 65536 from
+ * three references on: the row spectra stay in the workgroup's scratch slice
+ * and every reference takes product, second transform and argmax from there;
+ * float32-storage groups: FFT length 4096; shorter series and forced kernel
+ * variants score the batches one after the other).  Results land in each
  * batch's own buffers (muse_batch_scores / _run on a batch re-score it). */
 int muse_batch_score_many(muse_batch *const *batches, int32_t R);
 /* Copies back the (lag, signed mv) of the last scoring pass WITHOUT re-scoring
