@@ -1695,7 +1695,7 @@ extern "C" int muse_batch_kernel_name(muse_batch *b, char *name, int32_t cap)
     else if ((b->n >= 512 && b->n <= 2048) || b->n == 8192 || b->n == 16384)
         snprintf(k, sizeof(k), "xcorr_fused_small<%d, %s, false%s>", b->logn, padded ? "true" : "false", b->g->f32 ? ", true" : ", false");
     else if (b->n > 16384)
-        snprintf(k, sizeof(k), "xcorr_fused_long<%d, %s>", b->logn, padded ? "true" : "false");
+        snprintf(k, sizeof(k), "xcorr_fused_long<%d, %s, false>", b->logn, padded ? "true" : "false");
     snprintf(name, (size_t)cap, "%s", k);
     return MUSE_OK;
 }
