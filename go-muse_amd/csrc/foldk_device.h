@@ -48,17 +48,17 @@ __device__ __forceinline__ void exchange_cross(double2 (&v)[16], double2 *xbuf, 
     lds_barrier(); // buffer free: every wave is done with its previous (wave-local or shared) use
 #pragma unroll
     for (int k = 0; k < 8; k++)
-        xbuf[272 * k + wbase] = v[pr<PERM>(k)];
+        lds_st2(xbuf + 272 * k + wbase, v[pr<PERM>(k)]);
     lds_barrier();
     if (early) {
         double2 w[16];
 #pragma unroll
         for (int e = 0; e < 16; e++)
-            w[e] = xbuf[rbase + (MODE ? e : 16 * e)];
+            w[e] = lds_ld2(xbuf + rbase + (MODE ? e : 16 * e));
         lds_barrier();
 #pragma unroll
         for (int k = 0; k < 8; k++)
-            xbuf[272 * k + wbase] = v[pr<PERM>(8 + k)];
+            lds_st2(xbuf + 272 * k + wbase, v[pr<PERM>(8 + k)]);
         lds_barrier();
 #pragma unroll
         for (int e = 0; e < 16; e++)
@@ -67,11 +67,11 @@ __device__ __forceinline__ void exchange_cross(double2 (&v)[16], double2 *xbuf, 
         lds_barrier();
 #pragma unroll
         for (int k = 0; k < 8; k++)
-            xbuf[272 * k + wbase] = v[pr<PERM>(8 + k)];
+            lds_st2(xbuf + 272 * k + wbase, v[pr<PERM>(8 + k)]);
         lds_barrier();
 #pragma unroll
         for (int e = 0; e < 16; e++)
-            v[e] = xbuf[rbase + (MODE ? e : 16 * e)];
+            v[e] = lds_ld2(xbuf + rbase + (MODE ? e : 16 * e));
     }
     if (TAILBAR)
         lds_barrier();
@@ -90,11 +90,11 @@ __device__ __forceinline__ void exchange_cross_full(double2 (&v)[16], double2 *x
     lds_barrier(); // buffer free: every wave is done with its previous (wave-local or shared) use
 #pragma unroll
     for (int k = 0; k < 16; k++)
-        xbuf[272 * k + wbase] = v[pr<PERM>(k)];
+        lds_st2(xbuf + 272 * k + wbase, v[pr<PERM>(k)]);
     lds_barrier();
 #pragma unroll
     for (int e = 0; e < 16; e++)
-        v[e] = xbuf[rbase + (MODE ? e : 16 * e)];
+        v[e] = lds_ld2(xbuf + rbase + (MODE ? e : 16 * e));
 }
 // Wave-local transpose among the sixteen lanes that share hi, through the wave's quarter of the full buffer
 // (xw = xbuf + 1088 wave): lane (hl, lo) writes output k to 272 hl + 17 k + lo and reads input e from 272 hl + 17 lo + e.
@@ -109,13 +109,13 @@ __device__ __forceinline__ void exchange_local_full(double2 (&v)[16], double2 *x
     const int rbase = 272 * hl + 17 * lo;
 #pragma unroll
     for (int k = 0; k < 16; k++)
-        xw[17 * k + wbase] = v[pr<PERM>(k)];
+        lds_st2(xw + 17 * k + wbase, v[pr<PERM>(k)]);
     fence();
     asm volatile("" ::: "memory"); // (the compiler must not move a lane's reads above its writes: other lanes' data arrives through them)
     fence();
 #pragma unroll
     for (int e = 0; e < 16; e++)
-        v[e] = xw[rbase + e];
+        v[e] = lds_ld2(xw + rbase + e);
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -134,7 +134,7 @@ __device__ __forceinline__ void exchange_local(double2 (&v)[16], double2 *xw, co
     const int rbase = 68 * (lo & 7) + 17 * hl;
 #pragma unroll
     for (int k = 0; k < 8; k++)
-        xw[68 * k + wbase] = v[pr<PERM>(k)];
+        lds_st2(xw + 68 * k + wbase, v[pr<PERM>(k)]);
     const unsigned waddr = MUSE_LDS_ADDR(xw + wbase), raddr = MUSE_LDS_ADDR(xw + rbase);
     const unsigned long long first = __ballot(lo < 8); // lanes that read in round 0
     d2v w[16], d[8];

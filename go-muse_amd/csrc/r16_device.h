@@ -71,6 +71,18 @@ __device__ __forceinline__ T *uniform_ptr(T *ptr)
     return (T *)(((unsigned long long)hi << 32) | lo);
 }
 
+// 16-byte LDS accesses as ONE native vector access: a double2 struct copy is scalarised and re-paired by the compiler, which
+// may then pair neighbours across element boundaries (ds_read2_b64 at offset 8: xcorr_two_sided_fold's second workgroup-wide
+// transpose did -- SQ_LDS_BANK_CONFLICT 10 % of its LDS cycles on a layout that is conflict-free for ds_read_b128)
+__device__ __forceinline__ double2 lds_ld2(const double2 *p)
+{
+    const d2v x = *reinterpret_cast<const d2v *>(p);
+    return make_double2(x.x, x.y);
+}
+__device__ __forceinline__ void lds_st2(double2 *p, const double2 v)
+{
+    *reinterpret_cast<d2v *>(p) = d2v{v.x, v.y};
+}
 // 16-byte global load of one complex value (native vector type: HIP's double2
 // struct cannot be copied out of an address_space(1) reference)
 __device__ __forceinline__ double2 ldg2(gptr<double2> p, int i)

@@ -162,9 +162,16 @@ __global__ __launch_bounds__(256, 4) void xcorr_two_sided_fold(const FusedParams
             }
             lds_barrier();
             finish_prev(pair - gridDim.x); // (its records were complete before this barrier)
+            {   // the four waves' partial sums: ONE LDS read (lane l takes red[l & 15]: sixteen different addresses per read group --
+                // 64 lanes on one address are not a free broadcast: SQ_LDS_BANK_CONFLICT was 10 % of this kernel's LDS cycles),
+                // lanes k + 4 w added up inside each 16-lane row by two DPP shifts, lanes 0 - 3 read into scalar registers
+                double r = red[lane & 15];
+                r += dpp_f64<0x108>(r); // row_shl:8 (zero fill): lane i += lane i + 8
+                r += dpp_f64<0x104>(r); // row_shl:4:             lane i += lane i + 4
 #pragma unroll
-            for (int k = 0; k < 4; k++)
-                q[k] = (red[k] + red[4 + k]) + (red[8 + k] + red[12 + k]);
+                for (int k = 0; k < 4; k++)
+                    q[k] = readlane_f64(r, k);
+            }
             const PairScale ps = pair_scale(q, iv, normalize);
             const bool dead = ps.nil || ps.nan;
             if (t == 0) {
