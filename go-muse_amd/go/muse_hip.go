@@ -636,6 +636,64 @@ func RunMany(batches []*Batch, groupByLabels []string) error {
 	return nil
 }
 
+// xCorrBatch is xCorr (xcorr.go:102-153) for many independent (x, y) pairs in ONE launch (muse_xcorr_batch; SURVEY 8f-4):
+// xs[i] and ys[i] are pair i, every x of one length and every y of one length (each zero-padded on its own, xcorr.go:129-130),
+// n raised to max(n, lenx, leny) as in xcorr.go:104-106.  Returns per pair the lag, the signed value and whether the
+// reference would have returned (nil, 0, 0).  Unexported like xCorr itself: the package's tests are its callers
+// (xcorr_test.go:86-202).  The rows are packed into C memory (no Go pointer crosses); inputs are not mutated (the reference's
+// zNormalize mutates x and y in place).
+func xCorrBatch(xs, ys [][]float64, n int, normalize bool) (lags []int, mvs []float64, isNil []bool, err error) {
+	m := len(xs)
+	if m == 0 || len(ys) != m {
+		return nil, nil, nil, errors.New("xCorrBatch: xs and ys must hold the same, non-zero number of series")
+	}
+	lenx, leny := len(xs[0]), len(ys[0])
+	for i := 0; i < m; i++ {
+		if len(xs[i]) != lenx || len(ys[i]) != leny {
+			return nil, nil, nil, errors.New("xCorrBatch: every x (and every y) must have one length")
+		}
+	}
+	e, err := getEngine()
+	if err != nil {
+		return nil, nil, nil, err
+	}
+	bx := (*C.double)(C.malloc(C.size_t(m) * C.size_t(lenx) * 8))
+	by := (*C.double)(C.malloc(C.size_t(m) * C.size_t(leny) * 8))
+	clag := (*C.int32_t)(C.malloc(C.size_t(m) * 4))
+	cnil := (*C.int32_t)(C.malloc(C.size_t(m) * 4))
+	cmv := (*C.double)(C.malloc(C.size_t(m) * 8))
+	defer C.free(unsafe.Pointer(bx))
+	defer C.free(unsafe.Pointer(by))
+	defer C.free(unsafe.Pointer(clag))
+	defer C.free(unsafe.Pointer(cnil))
+	defer C.free(unsafe.Pointer(cmv))
+	if bx == nil || by == nil || clag == nil || cnil == nil || cmv == nil {
+		return nil, nil, nil, errors.New("out of memory staging series for xCorrBatch")
+	}
+	sx := unsafe.Slice((*float64)(unsafe.Pointer(bx)), m*lenx)
+	sy := unsafe.Slice((*float64)(unsafe.Pointer(by)), m*leny)
+	for i := 0; i < m; i++ {
+		copy(sx[i*lenx:(i+1)*lenx], xs[i])
+		copy(sy[i*leny:(i+1)*leny], ys[i])
+	}
+	norm := C.int32_t(0)
+	if normalize {
+		norm = 1
+	}
+	if err := hipError(C.muse_xcorr_batch(e.ctx, bx, by, C.int64_t(m), C.int32_t(lenx), C.int32_t(leny), C.int32_t(n), norm,
+		clag, cmv, cnil, nil)); err != nil {
+		return nil, nil, nil, err
+	}
+	lags, mvs, isNil = make([]int, m), make([]float64, m), make([]bool, m)
+	gl := unsafe.Slice((*int32)(unsafe.Pointer(clag)), m)
+	gn := unsafe.Slice((*int32)(unsafe.Pointer(cnil)), m)
+	gv := unsafe.Slice((*float64)(unsafe.Pointer(cmv)), m)
+	for i := 0; i < m; i++ {
+		lags[i], mvs[i], isNil[i] = int(gl[i]), gv[i], gn[i] != 0
+	}
+	return lags, mvs, isNil, nil
+}
+
 // Muse keeps the exported fields of muse.go:13-17; x and n are gone (the
 // reference spectrum lives on the device, owned by the template batch).
 type Muse struct {

@@ -143,6 +143,30 @@ public:
         return out;
     }
 
+    // xCorr (xcorr.go:102-153) for M independent (x, y) pairs in one launch: x_rows is M x lenx, y_rows M x leny,
+    // dense row-major; n is raised to max(n, lenx, leny).  nil[i] != 0 where the reference returns (nil, 0, 0).
+    struct XCorrResult {
+        std::vector<int32_t> lag, nil;
+        std::vector<double> mv, cc; // cc: M x n when asked for
+        int32_t n = 0;
+    };
+    XCorrResult XCorrBatch(const std::vector<double> &x_rows, const std::vector<double> &y_rows, int64_t M, int32_t lenx,
+                           int32_t leny, int32_t n, bool normalize, bool want_cc = false) const
+    {
+        if (M < 0 || (int64_t)x_rows.size() != M * lenx || (int64_t)y_rows.size() != M * leny)
+            throw Error(MUSE_ERR_INVALID, "XCorrBatch: row counts and lengths do not match the data");
+        XCorrResult r;
+        r.n = std::max(n, std::max(lenx, leny));
+        r.lag.assign((size_t)M, 0);
+        r.nil.assign((size_t)M, 0);
+        r.mv.assign((size_t)M, 0.0);
+        if (want_cc)
+            r.cc.assign((size_t)M * (size_t)r.n, 0.0);
+        check(muse_xcorr_batch(ctx_, x_rows.data(), y_rows.data(), M, lenx, leny, n, normalize ? 1 : 0, r.lag.data(), r.mv.data(),
+                               r.nil.data(), want_cc ? r.cc.data() : nullptr));
+        return r;
+    }
+
 private:
     muse_ctx *ctx_ = nullptr;
 };

@@ -435,6 +435,44 @@ static void TestBatchRunAllVisibleDevices()
     printf("sharded Run over %d visible device(s)\n", ndev);
 }
 
+static void TestXCorrBatchEqualsSinglePairs() // xcorr_test.go:86-202 exercises xCorr pair by pair; the batch entry must agree
+{
+    const int M = 37, lenx = 3000, leny = 4096, n = 4096;
+    std::vector<double> X((size_t)M * lenx), Y((size_t)M * leny);
+    for (int i = 0; i < M; i++) {
+        for (int k = 0; k < lenx; k++)
+            X[(size_t)i * lenx + k] = std::sin(0.013 * k * (1 + i % 5)) * (1.0 + i) + ((k * 2654435761u + i) % 997) * 1e-3;
+        for (int k = 0; k < leny; k++)
+            Y[(size_t)i * leny + k] = std::cos(0.011 * k + i) - 0.25 * ((k * 40503u + 7 * i) % 1009) * 1e-3;
+    }
+    for (int k = 0; k < lenx; k++)
+        X[(size_t)5 * lenx + k] = 2.5; // sigma(x) == 0: (nil, 0, 0) when normalized
+    auto eng = Engine::Default();
+    for (int normalize = 0; normalize < 2; normalize++) {
+        const auto r = eng->XCorrBatch(X, Y, M, lenx, leny, n, normalize != 0, true);
+        EXPECT(r.n == 4096 && (int)r.lag.size() == M, "XCorrBatch sizes");
+        for (int i = 0; i < M; i++) {
+            std::vector<double> cc((size_t)n);
+            int32_t lag = 0, nil = 0;
+            double mv = 0.0;
+            check(muse_xcorr(eng->handle(), X.data() + (size_t)i * lenx, lenx, Y.data() + (size_t)i * leny, leny, n, normalize, cc.data(),
+                             &lag, &mv, &nil));
+            EXPECT(nil == r.nil[i], "XCorrBatch nil flag");
+            if (nil)
+                continue;
+            EXPECT(lag == r.lag[i], "XCorrBatch lag");
+            EXPECT(std::fabs(mv - r.mv[i]) <= 1e-9 * std::fabs(mv) + 1e-12, "XCorrBatch value");
+            double worst = 0.0, scale = 0.0;
+            for (int k = 0; k < n; k++) {
+                worst = std::max(worst, std::fabs(cc[k] - r.cc[(size_t)i * n + k]));
+                scale = std::max(scale, std::fabs(cc[k]));
+            }
+            EXPECT(worst <= 1e-9 * scale + 1e-12, "XCorrBatch cc");
+        }
+        EXPECT(normalize == 0 || r.nil[5] == 1, "XCorrBatch: constant x is nil when normalized");
+    }
+}
+
 int main()
 {
     try {
@@ -450,6 +488,7 @@ int main()
         TestBatchRunShardedTables();
         TestBatchRunShardedEqualsUnsharded();
         TestBatchRunAllVisibleDevices();
+        TestXCorrBatchEqualsSinglePairs();
     } catch (const Error &e) {
         printf("muse::Error %d: %s\n", e.status, e.what());
         return 2;
