@@ -1679,6 +1679,17 @@ def test_xcorr_batch_pad_geometries(eng, oracle, n, geom):
         _check_xcorr_batch(eng, oracle, X, Y, n, normalize)
 
 
+@pytest.mark.parametrize("M", [1, 2, 3, 257])
+def test_xcorr_batch_few_and_many_pairs(eng, oracle, M):
+    """pair counts below one workgroup's share (n = 512: eight pairs per workgroup iteration), odd counts, more pairs than one
+    resident set of sub-groups handles at once"""
+    rng = np.random.default_rng(M)
+    for n in (512, 1024, 4096):
+        X = rng.normal(size=(M, n - 7))
+        Y = rng.normal(size=(M, n)) * 3.0 + 1.0
+        _check_xcorr_batch(eng, oracle, X, Y, n, True)
+
+
 def test_xcorr_batch_golden_tables(eng, golden):           # xcorr_test.go:86-202 through the batch entry (n = 5: pair by pair)
     for c in golden["xcorr"]["cases"]:
         cc, lag, mv, nil = eng.xcorr_batch([c["x"]], [c["y"]], len(c["x"]), c["normalize"], want_cc=True)
