@@ -22,9 +22,6 @@
 #include <stdlib.h>
 #include <algorithm>
 #include <type_traits>
-#ifndef EXP_STAGGER
-#define EXP_STAGGER 0
-#endif
 
 #include "foldk_device.h"
 
@@ -59,20 +56,6 @@ __global__ __launch_bounds__(OCC_THREADS, 4) void xcorr_fused_n4096_fold(const F
     __syncthreads();
     PhaseClock<TIMING> clk;
     clk.start();
-#if EXP_STAGGER
-    if (p.dbg && !TIMING) { // experiment: the workgroups of one CU start a quarter of a pair period apart
-        int rank = 0;
-        if (t == 0) {
-            const unsigned hw = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
-            const unsigned xcc = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11));  // HW_REG_XCC_ID[3:0]
-            const unsigned cu = ((xcc & 15) << 8) | ((hw >> 8) & 0xff);
-            rank = (int)(atomicAdd((unsigned long long *)p.dbg + cu, 1ull) & 3ull);
-            for (int k = 0; k < rank * EXP_STAGGER; k++)
-                __builtin_amdgcn_s_sleep(127);
-        }
-        __syncthreads();
-    }
-#endif
 
     int parity = 0;
     const long long total = p.npairs;

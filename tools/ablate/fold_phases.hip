@@ -50,14 +50,10 @@ int main(int argc, char** argv)
     const int wpc = getenv("WPC") ? atoi(getenv("WPC")) : 4;
     const int grid = cus * wpc;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    unsigned long long* stag = nullptr;
-    if (getenv("STAGGER")) { CK(hipMalloc(&stag, 4096 * 8)); p.dbg = stag; }
-    if (stag) CK(hipMemset(stag, 0, 4096 * 8));
-    launch<false>(p, grid); if (stag) CK(hipMemset(stag, 0, 4096 * 8)); launch<false>(p, grid); CK(hipDeviceSynchronize());
+    launch<false>(p, grid); launch<false>(p, grid); CK(hipDeviceSynchronize());
     std::vector<float> ts;
     for (int r = 0; r < reps; r++) {
         CK(hipMemsetAsync(p.ovf_count, 0, 8));
-        if (stag) CK(hipMemsetAsync(stag, 0, 4096 * 8));
         CK(hipEventRecord(e0));
         hipLaunchKernelGGL((xcorr_fused_n4096_fold<false, false, HARNESS_F32 != 0>), dim3(grid), dim3(256), 0, 0, p);
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
