@@ -61,6 +61,43 @@ __device__ __forceinline__ void sweep_dft(double2 (&v)[16])
     }
 }
 
+__device__ __forceinline__ double2 csqr(const double2 a)
+{
+    return make_double2(fma(a.x, a.x, -a.y * a.y), (a.x + a.x) * a.y);
+}
+// The sweeps' factors W_n^(m2 k), k = 1 .. R-1, of one element from ONE table entry w = W_n^(m2): powers formed where they are
+// consumed, every one a product of at most two of {w, w^2, w^3} and {w^4, w^8, w^12} (at most four multiplications deep:
+// a few 1e-16 of rounding on a unit-modulus factor).  Round 3 loaded all R - 1 from an [R][4096] table: fifteen 16-byte L2 requests
+// per thread and chunk at n = 65536, two batches of four in flight beside the chunk's 64 data registers -- 32-49 registers per lane
+// ended up in scratch, and the 1 MB table competed with the slices for the XCD's L2.  f(k, w^k) is called for k = 1 .. R-1 in order.
+template <int R, typename F>
+__device__ __forceinline__ void twiddle_powers(const double2 w, F f)
+{
+    const double2 w2 = csqr(w), w3 = cmul(w2, w);
+    f(1, w);
+    f(2, w2);
+    f(3, w3);
+    if (R > 4) {
+        const double2 w4 = csqr(w2);
+        f(4, w4);
+        f(5, cmul(w4, w));
+        f(6, cmul(w4, w2));
+        f(7, cmul(w4, w3));
+        if (R > 8) {
+            const double2 w8 = csqr(w4);
+            f(8, w8);
+            f(9, cmul(w8, w));
+            f(10, cmul(w8, w2));
+            f(11, cmul(w8, w3));
+            const double2 w12 = cmul(w8, w4);
+            f(12, w12);
+            f(13, cmul(w12, w));
+            f(14, cmul(w12, w2));
+            f(15, cmul(w12, w3));
+        }
+    }
+}
+
 // the n = 4096 kernel's pair of transforms on one row (xcorr_r16_fold.hip, default scheduling): x[t + 256 i] at v[i] ->
 // FFT, times the lane-ordered spectrum row `xrow`, FFT -> element t + 256 m at v[BR16(m)].  zero0: bin 0 is zeroed.
 __device__ __forceinline__ void row_transforms(double2 (&v)[16], double2 *xbuf, double2 *xw, const double2 *g2s,

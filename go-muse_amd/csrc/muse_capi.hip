@@ -84,7 +84,7 @@ struct muse_ctx {
     char name[64] = {0};
     double2 *tw1 = nullptr, *tw2 = nullptr, *twm = nullptr;
     double2 *g2 = nullptr, *g3a = nullptr, *g3b = nullptr; // folded-twiddle tables (xcorr_r16_fold.hip)
-    double2 *twl[3] = {nullptr, nullptr, nullptr};          // xcorr_long.hip (n = 16384, 32768, 65536): [n/4096][4096] W_n^(m2 k1), built on first use
+    double2 *twl[3] = {nullptr, nullptr, nullptr};          // xcorr_long.hip (n = 16384, 32768, 65536): [4096] W_n^(m2), built on first use
     double2 *gsmall[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // the same for xcorr_small.hip: n = 512, 1024, 2048: [8][n/16]; n = 8192: [8][32] + [8][512]; n = 16384: [8][64] + [8][1024]
     float2 *tw1f = nullptr, *tw2f = nullptr, *twmf = nullptr; // fp32 copies for the screening kernels
     // many-reference pass (muse_batch_score_many): parked spectra + device pointer tables
@@ -1003,10 +1003,9 @@ extern "C" int muse_batch_create(muse_ctx *ctx, muse_group *g, const double *ref
         { // (first use per length: rare, so always under the lock -- no unlocked read of the pointer another thread may be storing)
             std::lock_guard<std::mutex> lock(ctx->stage_mu);
             if (!ctx->twl[li]) {
-                std::vector<double2> tl((size_t)n);
-                for (int k1 = 0; k1 < R1; k1++)
-                    for (int m2 = 0; m2 < 4096; m2++)
-                        fill_twiddle(tl, (size_t)k1 * 4096 + m2, (long long)k1 * m2, n);
+                std::vector<double2> tl(4096);
+                for (int m2 = 0; m2 < 4096; m2++)
+                    fill_twiddle(tl, (size_t)m2, (long long)m2, n);
                 double2 *d = nullptr;
                 e = hipMalloc(&d, tl.size() * sizeof(double2));
                 if (e == hipSuccess)

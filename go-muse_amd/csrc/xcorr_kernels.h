@@ -29,7 +29,7 @@ struct FusedParams {
     const double2 *g3a;  // [8][256] first transform, pass 3: u = (t >> 4) + 16 (t & 15)
     const double2 *g3b;  // [8][256] second transform, pass 3: u = t
     const double2 *gsmall; // [8][n/16] xcorr_small.hip (n = 512, 1024, 2048): last-pass factors, delta = j / (n/16), lane-ordered
-    const double2 *twl;  // [n/4096][4096] W_n^(m2 k1): the sweeps' twiddles of the long-series kernel (xcorr_long.hip)
+    const double2 *twl;  // [4096] W_n^(m2): the base of the sweeps' twiddles W_n^(m2 k1) of the long-series kernel (xcorr_long.hip forms the powers)
     const double *c1;    // [n] (n = 4096 and the long-series kernel) N < n: correlation of the valid-sample indicator with the reference (xcorr_r16_fold.hip)
     // many references in one pass (xcorr_fused_n4096_multi): device arrays of R pointers
     int R;

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256, 4) void xcorr_fused_long(const FusedParams p)
     double2 *const Y2 = MULTI ? Y + n : Y; // where the second transforms land and sweep 2 reads
     const int N = PADDED ? p.N : n, pad = n - N;
     const double invN = 1.0 / (double)N, invNm1 = 1.0 / (double)(N - 1);
-    const double2 *__restrict__ twl = p.twl; // [R1][4096] W_n^(m2 k1)
+    const double2 *__restrict__ twl = p.twl; // [4096] W_n^(m2)
     // addresses: a scalar base formed where it is used plus one 32-bit lane offset (nothing 64-bit per lane, nothing
     // hoisted out of the loops into registers the transforms need)
     typedef d2v __attribute__((address_space(1))) *gd2;
@@ -72,11 +72,8 @@ __global__ __launch_bounds__(256, 4) void xcorr_fused_long(const FusedParams p)
         asm volatile("" : "+v"(x));
         return x;
     };
-    constexpr int T = Q1 * (R1 - 1), NB = (T + 3) / 4; // twiddle factors per thread and chunk: (m, k1 >= 1) at f = m (R1 - 1) + k1 - 1
-    const auto tw_load = [&](int f, unsigned jj) __attribute__((always_inline)) {
-        const int m = f / (R1 - 1), k1 = 1 + f % (R1 - 1);
-        return ldg2u(scalar_ptr_at(twl, k1 * 4096 + m * S), jj);
-    };
+    // the sweeps' factors W_n^(m2 k1): one table entry W_n^(m2) per element, its powers formed in registers (long_device.h)
+    const auto tw_base = [&](int m, unsigned jj) __attribute__((always_inline)) { return ldg2u(scalar_ptr_at(twl, m * S), jj); };
     if (t < 128)
         g2s[t] = p.g2[t];
     __syncthreads();
@@ -95,7 +92,7 @@ __global__ __launch_bounds__(256, 4) void xcorr_fused_long(const FusedParams p)
             double2 v[16];
             // all 32 requests first (a request behind a consumer would wait for it: the address asm statements keep program
             // order), then the values in request order
-            double xa[16], xb[16];
+            double xa[16], xb[16], c[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int i = 0; i < 16; i++) {
                 if (PADDED && i >= 8) { // (pad < n / 2: always inside the row -- scalar base, no clamp)
@@ -121,19 +118,24 @@ __global__ __launch_bounds__(256, 4) void xcorr_fused_long(const FusedParams p)
                     db = valid ? db : 0.0;
                 }
                 v[i] = make_double2(da, db);
-                q[0] += da;
-                q[1] = fma(da, da, q[1]);
-                q[2] += db;
-                q[3] = fma(db, db, q[3]);
+                c[0] += da;
+                c[1] = fma(da, da, c[1]);
+                c[2] += db;
+                c[3] = fma(db, db, c[3]);
             }
-            // the sweep's twiddles W_n^(m2 k1), k1 >= 1: T factors per thread and chunk in batches of four, two batches in
-            // flight; the first one travels behind the row requests
-            double2 wq[2][4];
+            // the chunk's sums leave the vector registers before the butterflies: reduced over the wave and added to the wave's
+            // running sums in SGPRs (as per-lane accumulators across the chunks they were what the allocator parked in scratch
+            // around every chunk's transform)
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                q[k] = uniform(q[k] + wave_sum_dpp(c[k]));
+            // the sweep's twiddles W_n^(m2 k1): the Q1 base entries travel behind the row requests
+            double2 wb[Q1];
             {
                 const unsigned jw = (unsigned)(opaque(t + 256 * ch) & (S - 1));
 #pragma unroll
-                for (int f = 0; f < 4 && f < T; f++)
-                    wq[0][f] = tw_load(f, jw);
+                for (int m = 0; m < Q1; m++)
+                    wb[m] = tw_base(m, jw);
             }
             fence();
             sweep_dft<R1>(v);
@@ -143,28 +145,18 @@ __global__ __launch_bounds__(256, 4) void xcorr_fused_long(const FusedParams p)
                 SLICE_ST(yat((long long)m * S) + js, (d2v{v[m].x, v[m].y}));
             }
 #pragma unroll
-            for (int bt = 0; bt < NB; bt++) {
-                fence();
-                if (bt + 1 < NB) {
-#pragma unroll
-                    for (int f = 4 * (bt + 1); f < 4 * (bt + 2) && f < T; f++)
-                        wq[(bt + 1) & 1][f & 3] = tw_load(f, js);
-                }
-                fence();
-#pragma unroll
-                for (int f = 4 * bt; f < 4 * (bt + 1) && f < T; f++) {
-                    // element m2 = j + m S of row k1: register m + brev(k1) Q1, position j + (m + k1 Q1) S
-                    const int m = f / (R1 - 1), k1 = 1 + f % (R1 - 1);
-                    const double2 z = cmul(v[m + brev<R1>(k1) * Q1], wq[bt & 1][f & 3]);
+            for (int m = 0; m < Q1; m++) {
+                // element m2 = j + m S of row k1: register m + brev(k1) Q1, position j + (m + k1 Q1) S
+                twiddle_powers<R1>(wb[m], [&](const int k1, const double2 w) __attribute__((always_inline)) {
+                    const double2 z = cmul(v[m + brev<R1>(k1) * Q1], w);
                     SLICE_ST(yat((long long)(m + k1 * Q1) * S) + js, (d2v{z.x, z.y}));
-                }
+                });
             }
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const double w = wave_sum_dpp(q[k]);
             if (lane == 0)
-                red[4 * wave + k] = w;
+                red[4 * wave + k] = q[k];
         }
         __syncthreads();
 #pragma unroll
@@ -249,25 +241,16 @@ __global__ __launch_bounds__(256, 4) void xcorr_fused_long(const FusedParams p)
                 v[i] = make_double2(z.x, z.y);
             }
             {
-                double2 wq[2][4];
+                double2 wb[Q1];
 #pragma unroll
-                for (int f = 0; f < 4 && f < T; f++)
-                    wq[0][f] = tw_load(f, (unsigned)j);
+                for (int m = 0; m < Q1; m++)
+                    wb[m] = tw_base(m, (unsigned)j);
+                fence();
 #pragma unroll
-                for (int bt = 0; bt < NB; bt++) {
-                    fence();
-                    if (bt + 1 < NB) {
-#pragma unroll
-                        for (int f = 4 * (bt + 1); f < 4 * (bt + 2) && f < T; f++)
-                            wq[(bt + 1) & 1][f & 3] = tw_load(f, (unsigned)j);
-                    }
-                    fence();
-#pragma unroll
-                    for (int f = 4 * bt; f < 4 * (bt + 1) && f < T; f++) {
-                        const int m = f / (R1 - 1), k1 = 1 + f % (R1 - 1);
-                        v[m + k1 * Q1] = cmul(v[m + k1 * Q1], wq[bt & 1][f & 3]);
-                    }
-                }
+                for (int m = 0; m < Q1; m++)
+                    twiddle_powers<R1>(wb[m], [&](const int k1, const double2 w) __attribute__((always_inline)) {
+                        v[m + k1 * Q1] = cmul(v[m + k1 * Q1], w);
+                    });
             }
             sweep_dft<R1>(v);
             // the chunk's first maximum per lane (ascending i = ascending lag index: strictly greater keeps the first) ...

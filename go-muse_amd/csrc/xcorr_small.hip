@@ -164,12 +164,23 @@ __device__ __forceinline__ void pair_sum4(double &q0, double &q1, double &q2, do
     q1 = red[16];
     q2 = red[32];
     q3 = red[48];
+    // the partials in batches of four waves, each batch read and added before the next is requested: left to the compiler the
+    // 4 x NW partials stay live far into the statistics -- at n = 16384 (NW = 16) up to 128 registers beside the 64 the pair's
+    // samples occupy, and the kernel parked 28-49 registers per lane in scratch around this barrier (1.5 GB of scratch writes
+    // per launch)
 #pragma unroll
-    for (int w = 1; w < NW; w++) {
-        q0 += red[w];
-        q1 += red[16 + w];
-        q2 += red[32 + w];
-        q3 += red[48 + w];
+    for (int w0 = 1; w0 < NW; w0 += 4) {
+        fence();
+#pragma unroll
+        for (int w = w0; w < w0 + 4 && w < NW; w++) {
+            q0 += red[w];
+            q1 += red[16 + w];
+            q2 += red[32 + w];
+            q3 += red[48 + w];
+        }
+        asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3)); // (the sums are formed HERE: left alone, the adds of the second
+                                                                   // series sink below the first one's variance, their partials live)
+        fence();
     }
 }
 template <int S>
