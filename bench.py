@@ -150,9 +150,11 @@ def cpu_baseline(dg, ref, N):
 
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start N rank processes (one per GPU) BEFORE this
-    process makes any GPU call, relay their output and exit with the worst return code.  (Never re-exec
-    a process that has initialised the GPU.)"""
+    process makes any GPU call and exit with the worst return code.  (Never re-exec a process that has
+    initialised the GPU.)  stdout of this process carries exactly what a launcher run would: rank 0's one
+    JSON line; whatever else the ranks print goes to stderr, prefixed with the rank."""
     import subprocess
+    import threading
     n = args.gpus
     port = int(os.environ.get("MASTER_PORT", "0")) or (29500 + (os.getpid() % 2000))
     procs = []
@@ -161,14 +163,39 @@ def spawn_ranks(args):
         env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1",
                     "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
                     "MUSE_BENCH_CHILD": "1"})
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE, text=True))
+
+    def relay(r, pr):
+        for ln in pr.stdout:
+            if r == 0 and ln.startswith("{"):
+                sys.stdout.write(ln)
+                sys.stdout.flush()
+            else:
+                sys.stderr.write("[rank %d] %s" % (r, ln))
+    th = [threading.Thread(target=relay, args=(r, pr)) for r, pr in enumerate(procs)]
+    for x in th:
+        x.start()
     rc = 0
     for r, pr in enumerate(procs):
         c = pr.wait()
         if c != 0:
             print("bench.py: rank %d exited with code %d" % (r, c), file=sys.stderr, flush=True)
             rc = rc or c
+    for x in th:
+        x.join()
     sys.exit(rc)
+
+
+def workload_name(M, N, n_gpus, max_lag, top_n):
+    """BASELINE.json's configs by shape: [2] = 1 ref x 1 M series on one GPU, [3] = 8 M series sharded over 8 GPUs (1 M rows each)"""
+    tail = "N=%d float64 rect+noise, Run(nil), MaxLag=%d TopN=%d" % (N, max_lag, top_n)
+    if n_gpus == 1:
+        tag = "configs[2]" if (M, N) == (1_000_000, 4096) else "configs[2]-shaped"
+        return "%s: 1 ref x %d series on 1 GPU, %s" % (tag, M, tail)
+    tag = "configs[3]" if (M * n_gpus, N, n_gpus) == (8_000_000, 4096, 8) else "configs[3]-shaped"
+    return "%s: 1 ref x %d series, Group sharded by rows over %d GPUs (%d rows each, weak scaling), RCCL all_gather of per-shard top-N records, %s" % (
+        tag, M * n_gpus, n_gpus, M, tail)
 
 
 def main():
@@ -181,6 +208,14 @@ def main():
     ap.add_argument("--top-n", type=int, default=20)
     ap.add_argument("--max-lag", type=int, default=15)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--clock-probe", action="store_true",
+                    help="keep the one-wave shader-clock probe resident INSIDE the timed region (default: the clock that prices "
+                         "roofline.co_bounds is measured in a separate, untimed pass of the same steps behind it)")
+    ap.add_argument("--in-process-devices", default="auto",
+                    help="devices of the in_process_shards extra object (one process, one context + host thread per device, "
+                         "SURVEY 8e / INTEGRATION.md): 'all' = every visible GPU, a number k = the first k, 'auto' = all when "
+                         "more than one is visible, else device 0 twice (a check of the path, not a scaling number)")
+    ap.add_argument("--in-process-rows", type=int, default=200_000, help="rows per shard of in_process_shards")
     ap.add_argument("--many-refs", type=int, default=8,
                     help="also time muse_batch_run_many with this many references (N=1 only; 0 = skip); "
                          "reported as an extra object, never as `value`")
@@ -256,10 +291,30 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # the shader clock held under this load (prices the fp64-VALU / LDS ceilings below): a one-wave probe kernel on its own
-    # stream, started BEHIND the synchronisation that opens the timed region (a device-wide synchronize would wait for it) and
-    # resident before the first timed launch; stopped by a host flag in front of the synchronisation that closes the region
-    probing = n_gpus == 1 and not use_dist
+    def probed(fn, est_total_ms):
+        """runs fn() with the one-wave shader-clock probe resident beside it; -> (clock_stats or None, note).  The probe is a
+        measurement hook: whatever goes wrong with it, the benchmark goes on without a clock (sclk = None)."""
+        try:
+            eng.clock_probe_start(0.5, min(50000.0, est_total_ms * 1.5 + 30.0))   # returns once the probe is resident
+        except Exception as e:
+            fn()
+            return None, "clock probe did not start: %s" % e
+        try:
+            fn()
+        finally:
+            try:
+                eng.clock_probe_stop()                      # (a host flag: a device-wide synchronize must not wait for the probe)
+            except Exception:
+                pass
+        try:
+            eng.synchronize()
+            raw = eng.clock_probe_read()
+            if os.environ.get("MUSE_BENCH_DUMP_CLOCK"):
+                np.savetxt(os.environ["MUSE_BENCH_DUMP_CLOCK"], raw, fmt="%.0f")
+            return clock_stats(raw), None
+        except Exception as e:
+            return None, "clock probe could not be read: %s" % e
+
     est_ms = 15.0 * max(1.0, M * N / 4.096e9)
     for i in range(args.warmup):
         t0 = time.perf_counter()
@@ -269,34 +324,53 @@ def main():
             est_ms = (time.perf_counter() - t0) * 1e3
     fence()
     eng.kernel_time()                                   # drop warm-up events
+    eng.redo_time()
     eng.kernel_timing(True)
-    if probing:
-        eng.clock_probe_start(0.5, min(50000.0, est_ms * (args.steps + 2) * 1.5 + 30.0))   # returns once the probe is resident
+    out = [None]
+
+    def timed_steps():
+        for _ in range(args.steps):
+            out[0] = step()
+
+    # ---- the timed region: exactly `steps` Runs between two fences.  By default NOTHING else runs on the GPU in it; with
+    # --clock-probe the one-wave probe kernel sits on its own stream beside the Runs (said on the line: clock_probe_in_timed_region)
+    sclk = sclk_note = None
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    if probing:
-        eng.clock_probe_stop()                          # (a host flag: the device-wide synchronize below must not wait for the probe)
+    if args.clock_probe:
+        sclk, sclk_note = probed(timed_steps, est_ms * (args.steps + 2))
+    else:
+        timed_steps()
     fence()
     dt = time.perf_counter() - t0
     eng.kernel_timing(False)
+    out = out[0]
     k_ms, k_cnt = eng.kernel_time()
-    raw_mhz = eng.clock_probe_read() if probing else None
-    if probing and os.environ.get("MUSE_BENCH_DUMP_CLOCK"):
-        import numpy as np
-        np.savetxt(os.environ["MUSE_BENCH_DUMP_CLOCK"], raw_mhz, fmt="%.0f")
-    sclk = clock_stats(raw_mhz) if probing else None
+    r_ms, r_cnt = eng.redo_time()
     if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=tdev if tdev is not None else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    # every rank reports its own GPU: kernel time by HIP events on its stream, device name and PCI bus id -- the line's proof
+    # that N ranks ran on N distinct devices, and what makes a slow GPU visible
+    mine = {"rank": rank, "local_rank": local_rank, "device": dev_name, "pci_bus_id": eng.pci_bus_id(), "rows": M,
+            "kernel_ms_avg": k_ms / max(k_cnt, 1), "launches_timed": k_cnt, "redo_ms_avg": r_ms / max(r_cnt, 1)}
+    per_rank = [mine]
+    if use_dist:
+        per_rank = [None] * n_gpus
+        dist.all_gather_object(per_rank, mine)
+    # the clock that prices the co-bounds (rank 0): by default from an UNTIMED repeat of the same steps behind the timed region
+    if rank == 0 and not args.clock_probe and not args.no_extras:
+        reps = max(3, min(args.steps, 10))
+        sclk, sclk_note = probed(lambda: [db.run(None, 0, args.max_lag, args.top_n, 0.0, 0, True) for _ in range(reps)], est_ms * (reps + 2))
+        eng.synchronize()
 
     screened, refined_pairs = db.last_run_info()
     assert not screened, "the headline Run must not take the fp32 filter-and-refine path"
     if rank == 0:
         total_pairs = float(M) * n_gpus * args.steps
         value = total_pairs / dt
-        k_avg_s = (k_ms / max(k_cnt, 1)) * 1e-3
+        kms = [r["kernel_ms_avg"] for r in per_rank]
+        k_avg_s = max(kms) * 1e-3                       # the SLOWEST rank's kernel: roofline.frac is per GPU and conservative
         bytes_per_launch = float(M) * (8 * N + 16)
         achieved = bytes_per_launch / k_avg_s / 1e9 if k_avg_s > 0 else 0.0
         kname = eng.kernel_name(db) if hasattr(eng, "kernel_name") else "xcorr_fused"
@@ -307,14 +381,25 @@ def main():
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "rehearsal": bool(args.rehearse_on_one_gpu),
-            "config": {"workload": "configs[2]: 1 ref x %d series/GPU, N=%d float64 rect+noise, Run(nil), "
-                                   "MaxLag=%d TopN=%d" % (M, N, args.max_lag, args.top_n),
-                       "rows_per_gpu": M, "length": N, "fft_len": db.n, "sharding": "rows x %d" % n_gpus,
+            "config": {"workload": workload_name(M, N, n_gpus, args.max_lag, args.top_n),
+                       "rows_per_gpu": M, "rows_total": M * n_gpus, "length": N, "fft_len": db.n, "sharding": "rows x %d" % n_gpus,
                        "device": dev_name},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "kernel": kname, "kernel_ms_avg": k_avg_s * 1e3, "launches_timed": k_cnt,
-                         "algorithmic_bytes_per_launch": bytes_per_launch},
+                         "kernel": kname, "kernel_ms_avg": k_avg_s * 1e3, "launches_timed": min(r["launches_timed"] for r in per_rank),
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "per_gpu": True,
+                         "per_rank": {"kernel_ms_avg": {"min": min(kms), "max": max(kms), "mean": sum(kms) / len(kms)},
+                                      "frac": {"min": bytes_per_launch / (max(kms) * 1e-3) / 1e9 / HBM_PEAK_GBPS if max(kms) > 0 else None,
+                                               "max": bytes_per_launch / (min(kms) * 1e-3) / 1e9 / HBM_PEAK_GBPS if min(kms) > 0 else None},
+                                      "note": "HIP events on each rank's own stream around the fused launch alone; frac / achieved / "
+                                              "kernel_ms_avg above are the SLOWEST rank's"},
+                         "redo_ms_avg": max(r["redo_ms_avg"] for r in per_rank),
+                         "redo_note": "the launch behind the fused one that redoes listed pairs (NaN / Inf series, sigma spread): outside "
+                                      "kernel_ms_avg, inside ms_per_step"},
+            "ranks": per_rank,
+            "distinct_devices": len({r["pci_bus_id"] for r in per_rank}),
+            "clock_probe_in_timed_region": bool(args.clock_probe),
             "achieved_hbm_gbps_whole_step": value / n_gpus * (8 * N + 16) / 1e9,
             "top_score": float(out[2][0]) if len(out[2]) else None,
         }
@@ -324,7 +409,11 @@ def main():
         rl = line["roofline"]
         krec = counters.attach(rl, kname, M, N, bytes_per_launch)
         co = {"hbm_measured_copy": {"peak": HBM_COPY_GBPS, "unit": "GB/s", "frac": achieved / HBM_COPY_GBPS},
-              "sclk_in_kernel": sclk}
+              "sclk_in_kernel": sclk,
+              "sclk_measured_in": "the timed region (--clock-probe)" if args.clock_probe else
+                                  "an untimed repeat of the same Runs on rank 0 behind the timed region (the probe wave is not resident while `value` is timed)"}
+        if sclk_note:
+            co["sclk_note"] = sclk_note
         if krec and sclk and k_avg_s > 0:
             hz = sclk["median_mhz"] * 1e6
             simds = cus * 4
@@ -471,8 +560,16 @@ def main():
             try:
                 import threading
                 ndev = pkg.device_count()
-                devs = list(range(ndev)) if ndev > 1 else [0, 0]
-                per = 200_000
+                sel = args.in_process_devices
+                if sel == "all":
+                    devs = list(range(ndev))
+                elif sel == "auto":
+                    devs = list(range(ndev)) if ndev > 1 else [0, 0]
+                else:
+                    devs = list(range(min(int(sel), ndev)))
+                    if len(devs) < 2:
+                        devs = [0, 0]
+                per = args.in_process_rows
                 engs = [pkg.Engine(d) for d in devs]
                 # (without the planted exact copies of the reference: among exactly tied scores the ORDER Fetch returns depends on
                 # the heap's history, results.go:55-87, and a pre-selected merge has another history than one long feed)
@@ -506,11 +603,12 @@ def main():
                     wb.run(None, 0, args.max_lag, args.top_n, 0.0, 0, True)
                 dwh = (time.perf_counter() - t1) / reps
                 line["in_process_shards"] = {
-                    "devices": devs, "distinct_devices": ndev, "rows_per_shard": per, "length": N,
+                    "devices": devs, "distinct_devices": len({e.pci_bus_id() for e in engs}), "pci_bus_ids": [e.pci_bus_id() for e in engs],
+                    "rows_per_shard": per, "length": N,
                     "ms_per_run_sharded": dsh * 1e3, "ms_per_run_one_context_same_rows": dwh * 1e3,
                     "value": per * len(devs) / dsh, "unit": "series-pairs/s", "records_identical_to_one_context": bool(same),
                     "note": "one process, one muse_ctx + host thread per listed device, muse_batch_run_shard + muse_merge_records"
-                            + ("" if ndev > 1 else "; ONE GPU visible: both contexts share it -- a check of the path and of its host-side cost, not a scaling number")}
+                            + ("" if len(set(devs)) > 1 else "; ONE GPU: the contexts share it -- a check of the path and of its host-side cost, not a scaling number")}
                 for x in sb:
                     x.close()
                 wb.close()
@@ -548,7 +646,8 @@ def main():
                 except Exception as e:
                     per_len.append({"N": Nl, "error": str(e)})
             line["config5_lengths"] = per_len
-        if n_gpus == 1 and not use_dist and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:
+            # (at every N, on rank 0's host cores over a sample of rank 0's shard: the other ranks wait at the closing barrier)
             line["cpu_baseline"] = cpu_baseline(dg, ref, N)
         print(json.dumps(line), flush=True)
     if use_dist:

@@ -51,6 +51,8 @@ SIGNATURES = {
     "muse_ctx_set_screening": (ctypes.c_int, [_vp, _i32]),
     "muse_ctx_kernel_timing": (ctypes.c_int, [_vp, _i32]),
     "muse_ctx_kernel_time": (ctypes.c_int, [_vp, _dp, _i64p]),
+    "muse_ctx_redo_time": (ctypes.c_int, [_vp, _dp, _i64p]),
+    "muse_ctx_device_pci_bus_id": (ctypes.c_int, [_vp, ctypes.c_char_p, _i32]),
     "muse_group_create": (ctypes.c_int, [_vp, _i64, _i32, ctypes.POINTER(_vp)]),
     "muse_group_create_f32": (ctypes.c_int, [_vp, _i64, _i32, ctypes.POINTER(_vp)]),
     "muse_group_append": (ctypes.c_int, [_vp, _dp, _i64, _i64]),

@@ -115,9 +115,10 @@ struct muse_ctx {
     hipStream_t probe_stream = nullptr;
     unsigned long long *probe_buf = nullptr; // pinned host memory: [2 * PROBE_WINDOWS] ticks + the window count behind them
     bool timing = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
-    double total_ms = 0.0;
-    int64_t launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events, redo_events;
+    double total_ms = 0.0, redo_ms = 0.0;
+    int64_t launches = 0, redo_launches = 0;
+    char pci[32] = {0}; // PCI bus id of the device ("0000:05:00.0"): tells two contexts on one GPU from two GPUs
     // Handles may be released in any order (Go finalizers, Python GC): the
     // context lives until it is destroyed AND its last group/batch is freed.
     std::atomic<int> refs{1};
@@ -244,7 +245,8 @@ static int use_device(muse_ctx *ctx)
 struct LaunchTimer {
     muse_ctx *ctx;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    explicit LaunchTimer(muse_ctx *c) : ctx(c) {}
+    bool redo; // the bracket of the launches that redo listed pairs behind a fused launch (muse_ctx_redo_time)
+    explicit LaunchTimer(muse_ctx *c, bool redo_ = false) : ctx(c), redo(redo_) {}
     LaunchTimer(const LaunchTimer &) = delete;
     LaunchTimer &operator=(const LaunchTimer &) = delete;
     hipError_t begin()
@@ -264,7 +266,7 @@ struct LaunchTimer {
             return hipSuccess;
         const hipError_t e = hipEventRecord(e1, ctx->stream);
         if (e == hipSuccess) {
-            ctx->events.emplace_back(e0, e1);
+            (redo ? ctx->redo_events : ctx->events).emplace_back(e0, e1);
             e0 = e1 = nullptr;
         }
         return e;
@@ -311,6 +313,8 @@ extern "C" int muse_ctx_create(int32_t device, muse_ctx **out)
     ctx->num_cus = prop.multiProcessorCount;
     ctx->hbm = (int64_t)prop.totalGlobalMem;
     snprintf(ctx->name, sizeof(ctx->name), "%s (%s)", prop.name, prop.gcnArchName);
+    if (hipDeviceGetPCIBusId(ctx->pci, (int)sizeof(ctx->pci), device) != hipSuccess)
+        snprintf(ctx->pci, sizeof(ctx->pci), "%04x:%02x:%02x.0", prop.pciDomainID, prop.pciBusID, prop.pciDeviceID);
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     HIP_TRY(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
@@ -426,10 +430,11 @@ static void ctx_release(muse_ctx *ctx)
         (void)hipStreamSynchronize(ctx->copy_stream);
         (void)hipStreamDestroy(ctx->copy_stream);
     }
-    for (auto &e : ctx->events) {
-        (void)hipEventDestroy(e.first);
-        (void)hipEventDestroy(e.second);
-    }
+    for (auto *ev : {&ctx->events, &ctx->redo_events})
+        for (auto &e : *ev) {
+            (void)hipEventDestroy(e.first);
+            (void)hipEventDestroy(e.second);
+        }
     (void)hipFree(ctx->tw1);
     (void)hipFree(ctx->tw2);
     (void)hipFree(ctx->twm);
@@ -514,27 +519,60 @@ extern "C" int muse_ctx_kernel_timing(muse_ctx *ctx, int32_t enable)
     return MUSE_OK;
 }
 
+static int drain_events(std::vector<std::pair<hipEvent_t, hipEvent_t>> &ev, double &ms_sum, int64_t &count)
+{
+    for (auto &e : ev) {
+        HIP_TRY(hipEventSynchronize(e.second));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, e.first, e.second));
+        ms_sum += (double)ms;
+        count += 1;
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    ev.clear();
+    return MUSE_OK;
+}
+
 extern "C" int muse_ctx_kernel_time(muse_ctx *ctx, double *total_ms, int64_t *launches)
 {
     int rc = use_device(ctx);
     if (rc)
         return rc;
-    for (auto &e : ctx->events) {
-        HIP_TRY(hipEventSynchronize(e.second));
-        float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, e.first, e.second));
-        ctx->total_ms += (double)ms;
-        ctx->launches += 1;
-        (void)hipEventDestroy(e.first);
-        (void)hipEventDestroy(e.second);
-    }
-    ctx->events.clear();
+    rc = drain_events(ctx->events, ctx->total_ms, ctx->launches);
+    if (rc)
+        return rc;
     if (total_ms)
         *total_ms = ctx->total_ms;
     if (launches)
         *launches = ctx->launches;
     ctx->total_ms = 0.0;
     ctx->launches = 0;
+    return MUSE_OK;
+}
+
+extern "C" int muse_ctx_redo_time(muse_ctx *ctx, double *total_ms, int64_t *brackets)
+{
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    rc = drain_events(ctx->redo_events, ctx->redo_ms, ctx->redo_launches);
+    if (rc)
+        return rc;
+    if (total_ms)
+        *total_ms = ctx->redo_ms;
+    if (brackets)
+        *brackets = ctx->redo_launches;
+    ctx->redo_ms = 0.0;
+    ctx->redo_launches = 0;
+    return MUSE_OK;
+}
+
+extern "C" int muse_ctx_device_pci_bus_id(muse_ctx *ctx, char *out, int32_t cap)
+{
+    if (!ctx || !out || cap < 16)
+        return fail(MUSE_ERR_INVALID, "muse_ctx_device_pci_bus_id: NULL argument or a buffer under 16 bytes");
+    snprintf(out, (size_t)cap, "%s", ctx->pci);
     return MUSE_OK;
 }
 
@@ -1200,6 +1238,7 @@ extern "C" int muse_batch_score(muse_batch *b)
     if (variant == KERNEL_GENERIC && b->n <= GENERIC_LDS_MAX_N)
         p.gscratch = nullptr; // the generic kernel takes a non-NULL scratch pointer as "work in global memory"
     LaunchTimer timer(ctx); // (brackets the fused launch alone: not the counter reset in front of it, not the redo launch behind it)
+    LaunchTimer redo_timer(ctx, true); // the launch that redoes the listed pairs: its own sum (muse_ctx_redo_time)
     if (variant == KERNEL_R16_FOLD) {
         // pairs with a NaN/Inf series or with sigmas too far apart for one shared transform are listed by the kernel
         // (once per such series: 2 entries per pair) and redone by the rescaling kernel right behind it (no host round
@@ -1221,10 +1260,15 @@ extern "C" int muse_batch_score(muse_batch *b)
         FusedParams q = p;
         q.pair_list = b->ovf_list;
         q.pair_count = b->ovf_count;
+        // a dense list (the same threshold as the hand-off rule above) makes the redo kernel redo EVERY pair: the results of a
+        // mixed-unit group then come from kernel 7 in this pass exactly as in the later ones that go there directly
+        q.dense_total = ctx->variant == 0 ? p.npairs : 0;
         // grid size only (the loop bound is *pair_count): one resident set, so a group with MANY listed pairs
         // (mixed-unit metrics: sigmas far apart) is redone at full width; an empty list costs a few microseconds
         q.npairs = std::min<long long>(p.npairs, (long long)ctx->num_cus * 3);
+        HIP_TRY(redo_timer.begin());
         HIP_TRY(launch_fused(q, KERNEL_R16_OCC3, ctx->num_cus, ctx->stream));
+        HIP_TRY(redo_timer.end());
         if (p.npairs >= 1024) { // (small groups: a pinned allocation costs more than it can save)
             if (!b->handoff_host)
                 HIP_TRY(hipHostMalloc((void **)&b->handoff_host, sizeof(int), hipHostMallocDefault));
@@ -1252,7 +1296,9 @@ extern "C" int muse_batch_score(muse_batch *b)
         q.pair_list = b->ovf_list;
         q.pair_count = b->ovf_count;
         q.npairs = std::min<long long>(p.npairs, (long long)ctx->num_cus * STOCKHAM_GLOBAL_WGS_PER_CU);
+        HIP_TRY(redo_timer.begin());
         HIP_TRY(launch_fused(q, KERNEL_STOCKHAM, ctx->num_cus, ctx->stream));
+        HIP_TRY(redo_timer.end());
     } else {
         HIP_TRY(timer.begin());
         HIP_TRY(launch_fused(p, variant, ctx->num_cus, ctx->stream));
@@ -2151,6 +2197,9 @@ extern "C" int muse_batch_score_many(muse_batch *const *bs, int32_t R)
     HIP_TRY(timer.end());
     // pairs holding a NaN/Inf series (listed once, by reference 0): redone per reference by the
     // kernel that isolates the dead series before the shared transform
+    LaunchTimer redo_timer(ctx, true); // (one bracket around the R redo launches)
+    if (!small_n)
+        HIP_TRY(redo_timer.begin());
     for (int r = 0; r < R && !small_n; r++) {
         FusedParams q = base_params(bs[r]);
         q.pair_list = b0->ovf_list;
@@ -2164,6 +2213,7 @@ extern "C" int muse_batch_score_many(muse_batch *const *bs, int32_t R)
         }
         bs[r]->scores_exact = true; // mv / lag of every batch now hold fp64 results for every row
     }
+    HIP_TRY(redo_timer.end());
     return MUSE_OK;
 }
 

@@ -66,6 +66,7 @@ struct FusedParams {
     // optional indirection for the fp64 kernels: process pair_list[0 .. *pair_count)
     const long long *pair_list;
     const int *pair_count;
+    long long dense_total; // xcorr_r16_occ4.hip behind the default n = 4096 kernel: > 0 and *pair_count * 8 > dense_total -> redo ALL dense_total pairs
     long long gscratch_slices; // n-element slices `gscratch` holds: a kernel that works in it launches no more workgroups than fit
     // two-sided xCorr (xcorr_two_sided.hip): pair i = (x_i = xrows + i xstride, length Nx; y_i = rows + i stride, length N)
     const double *xrows;

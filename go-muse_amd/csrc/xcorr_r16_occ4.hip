@@ -165,17 +165,25 @@ __global__ __launch_bounds__(OCC_THREADS, WPS) void xcorr_fused_n4096_occ4(const
 
     // optional indirection: process pair_list[0 .. *pair_count) (overflow pairs of the
     // fp32 screening kernel); otherwise pairs 0 .. npairs
-    const long long total = p.pair_count ? (long long)*p.pair_count : p.npairs;
+    // A DENSE list (more than an eighth of the group's pairs listed: a group of mixed-unit series) is not followed: the
+    // kernel redoes EVERY pair, so that all results of such a group come from this kernel in every pass -- the first one, which
+    // found the list, and the later ones, which the host sends here directly (muse_capi.hip): Run(); Run() is bit-identical.
+    long long total = p.pair_count ? (long long)*p.pair_count : p.npairs;
+    const long long *__restrict__ plist = p.pair_list;
+    if (p.pair_count && p.dense_total > 0 && total * 8 > p.dense_total) {
+        total = p.dense_total;
+        plist = nullptr;
+    }
     RawPair raw;
     {
         long long first = 0;
         if (blockIdx.x < total)
-            first = p.pair_list ? p.pair_list[blockIdx.x] : (long long)blockIdx.x;
+            first = plist ? plist[blockIdx.x] : (long long)blockIdx.x;
         issue_row_loads<PADDED, F32>(raw, p, first, t, pad);
     }
 
     for (long long it = blockIdx.x; it < total; it += gridDim.x) {
-        const long long pair = p.pair_list ? p.pair_list[it] : it;
+        const long long pair = plist ? plist[it] : it;
         const long long rA = 2 * pair, rB = rA + 1;
         const bool hasB = rB < p.M;
         // ---- consume the prefetched rows (element t + 256 i of the zero-padded rows)
@@ -263,7 +271,7 @@ __global__ __launch_bounds__(OCC_THREADS, WPS) void xcorr_fused_n4096_occ4(const
         long long nxt = 0; // last iteration: an unconditional dummy prefetch of pair 0, whose 64 KB every
                            // workgroup re-reads (L2-resident) -- re-reading the own pair cost 2.4 % HBM traffic
         if (it + gridDim.x < total)
-            nxt = p.pair_list ? p.pair_list[it + gridDim.x] : it + gridDim.x;
+            nxt = plist ? plist[it + gridDim.x] : it + gridDim.x;
         fft4096<2, true, PADDED, TIMING, F32>(v, xbuf, tw2s, p.tw1, p.xc, dc, t, wave, clk, raw, p, nxt, pad);
         clk.template stamp<7>();
         // ---- ccA + i ccB = FFT(V)   (unscaled by 1/sigma)

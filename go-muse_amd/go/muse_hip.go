@@ -49,6 +49,15 @@ var (
 // use (muse_test.go:203-214 drives one Muse from many goroutines).  A failed creation is remembered:
 // there is no CPU fallback to retry into.
 func getEngine() (*engine, error) {
+	// SetDevices([]int{k}): ONE engine selected -- every unsharded path (Batch, Muse, xCorr) runs on that device, as the
+	// Python and C++ mirrors do with engines[0]; the default context on device 0 is not created for it
+	engineSetMu.Lock()
+	if len(engineSet) == 1 {
+		e := engineSet[0]
+		engineSetMu.Unlock()
+		return e, nil
+	}
+	engineSetMu.Unlock()
 	defaultEngineOne.Do(func() {
 		e := &engine{}
 		// a cgo call and the muse_last_error that explains it must run on one OS thread
@@ -71,7 +80,8 @@ var (
 )
 
 // SetDevices selects the GPUs every later Batch.Run shards over (one muse_ctx per listed device; a device may be
-// listed more than once).  SetDevices(nil) goes back to the single default engine.  DeviceCount() tells how many
+// listed more than once).  A single id selects that device for the unsharded path.  SetDevices(nil) goes back to the
+// single default engine (device 0).  DeviceCount() tells how many
 // the process can see; SetDevices(AllDevices()) is the eight-GPU configuration of one node.
 func SetDevices(ids []int) error {
 	engineSetMu.Lock()

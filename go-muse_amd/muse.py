@@ -111,6 +111,17 @@ class Engine:
         B.check(B.load().muse_ctx_kernel_time(self._h, ctypes.byref(ms), ctypes.byref(cnt)))
         return float(ms.value), int(cnt.value)
 
+    def redo_time(self):
+        """(ms, brackets) of the launches that redo listed pairs behind a fused launch: what kernel_time() leaves out"""
+        ms, cnt = ctypes.c_double(0), ctypes.c_int64(0)
+        B.check(B.load().muse_ctx_redo_time(self._h, ctypes.byref(ms), ctypes.byref(cnt)))
+        return float(ms.value), int(cnt.value)
+
+    def pci_bus_id(self):
+        buf = ctypes.create_string_buffer(32)
+        B.check(B.load().muse_ctx_device_pci_bus_id(self._h, buf, 32))
+        return buf.value.decode()
+
     # single-pair entry points (xcorr_test.go-style known-answer access)
     def xcorr_with_x(self, ref, y, n=None):
         ref, y = B.as_f64(ref), B.as_f64(y)

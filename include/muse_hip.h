@@ -84,6 +84,9 @@ int muse_ctx_synchronize(muse_ctx *ctx);
 /* name: >= 64 bytes.  Any out pointer may be NULL. */
 int muse_ctx_device_info(muse_ctx *ctx, char *name, int32_t name_cap,
                          int32_t *compute_units, int64_t *hbm_bytes);
+/* PCI bus id of the context's device ("0000:05:00.0"; cap >= 16): what tells N contexts on N GPUs from N contexts on one
+ * (the sharded Runs of SURVEY 8e report it per shard; bench.py prints it per rank). */
+int muse_ctx_device_pci_bus_id(muse_ctx *ctx, char *out, int32_t cap);
 /* Filter-and-refine Run: OPT-IN (off by default: every Run scores every series with the float64 kernel, the
  * arithmetic of the reference, xcorr.go:160-197).  enable = 1: Runs over groups of >= 32768 * 4096 samples after
  * padding, where it starts to pay; enable = n > 1: Runs over >= n series; 0: off.  When enabled, a muse_batch_run /
@@ -110,6 +113,11 @@ int muse_batch_last_run_path(muse_batch *b, int32_t *path);
  * enable, run, then read (sum of launch durations in ms, launch count). */
 int muse_ctx_kernel_timing(muse_ctx *ctx, int32_t enable);
 int muse_ctx_kernel_time(muse_ctx *ctx, double *total_ms, int64_t *launches);
+/* The same for what muse_ctx_kernel_time leaves out: the launches that REDO the pairs a fused launch listed (a NaN / Inf
+ * series, sigmas too far apart for one shared transform) with the kernel that isolates and rescales first -- one bracket per
+ * pass (many references: one around the R redo launches).  Microseconds for an empty list, a second pass for a group of
+ * mixed-unit series. */
+int muse_ctx_redo_time(muse_ctx *ctx, double *total_ms, int64_t *brackets);
 /* Name of the kernel automatic selection takes for this batch's all-scores pass (name: >= 64 bytes). */
 int muse_batch_kernel_name(muse_batch *b, char *name, int32_t name_cap);
 

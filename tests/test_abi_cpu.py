@@ -40,6 +40,78 @@ def test_header_symbols_all_exported(muse):
     assert exported == declared, exported ^ declared
 
 
+def _split_top_level(args):
+    """splits an argument list at its top-level commas (nested parentheses, brackets and braces stay together)"""
+    parts, depth, cur = [], 0, ""
+    for ch in args:
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            parts.append(cur)
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        parts.append(cur)
+    return parts
+
+
+def _call_args(text, start):
+    """text[start] is the '(' of a call: -> the text between it and its matching ')'"""
+    depth = 0
+    for k in range(start, len(text)):
+        if text[k] == "(":
+            depth += 1
+        elif text[k] == ")":
+            depth -= 1
+            if depth == 0:
+                return text[start + 1:k]
+    raise AssertionError("unbalanced call at %d" % start)
+
+
+def test_go_shim_calls_match_the_header():
+    """go-muse_amd/go/muse_hip.go is written blind (no Go toolchain in this image): every C.muse_*( call it makes must name a
+    function include/muse_hip.h declares -- the product header, not the test hooks -- with the declared number of arguments,
+    the C enum constants it uses must exist, and the record struct it reads must have the fields the header gives it."""
+    hdr = open(os.path.join(ROOT, "include", "muse_hip.h")).read()
+    hdr_nc = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = {}
+    for m in re.finditer(r"\b(?:int|int64_t|const char \*)\s*(muse_[a-z0-9_]+)\s*\(", hdr_nc):
+        params = _call_args(hdr_nc, m.end() - 1).strip()
+        declared[m.group(1)] = 0 if params in ("", "void") else len(_split_top_level(params))
+    assert len(declared) >= 40
+    go = open(os.path.join(ROOT, "go-muse_amd", "go", "muse_hip.go")).read()
+    go_nc = re.sub(r"//[^\n]*", "", go)
+    cgo_preamble = go[:go.index('import "C"')]
+    assert '#include "muse_hip.h"' in cgo_preamble and "muse_hip_test.h" not in go
+    calls = list(re.finditer(r"\bC\.(muse_[a-z0-9_]+)\(", go_nc))
+    assert len(calls) >= 40
+    used = set()
+    for m in calls:
+        name = m.group(1)
+        assert name in declared, "muse_hip.go calls C.%s, which include/muse_hip.h does not declare" % name
+        nargs = len(_split_top_level(_call_args(go_nc, m.end() - 1)))
+        assert nargs == declared[name], "C.%s called with %d arguments, the header declares %d" % (name, nargs, declared[name])
+        used.add(name)
+    # the calls a drop-in Batch / Muse / sharded Run cannot do without
+    for need in ("muse_ctx_create", "muse_group_create", "muse_group_append", "muse_batch_create", "muse_batch_run",
+                 "muse_batch_run_shard", "muse_batch_run_groups", "muse_merge_records", "muse_merge_group_records",
+                 "muse_batch_create_like", "muse_last_error", "muse_device_count"):
+        assert need in used, need
+    # constants and types taken from the header by name
+    for const in set(re.findall(r"\bC\.(MUSE_[A-Z0-9_]+)\b", go_nc)):
+        assert re.search(r"\b%s\b" % const, hdr_nc), "muse_hip.go uses C.%s, which the header does not define" % const
+    for typ in set(re.findall(r"\bC\.(muse_[a-z_]+)\b(?!\()", go_nc)) - set(declared):
+        assert re.search(r"\b%s\b" % typ, hdr_nc), "muse_hip.go uses the type C.%s, which the header does not define" % typ
+    rec = re.search(r"typedef struct muse_record \{(.*?)\} muse_record;", hdr_nc, flags=re.S)
+    assert rec
+    fields = set(re.findall(r"\b(\w+);", rec.group(1)))
+    for f in set(re.findall(r"\brecs?\[[^\]]*\]\.(\w+)\b", go_nc)):
+        assert f in fields, "muse_hip.go reads muse_record.%s; the header has %s" % (f, sorted(fields))
+
+
 def test_record_layout(muse):
     assert ctypes.sizeof(muse.binding.MuseRecord) == 24 == muse.binding.RECORD_DTYPE.itemsize
 

@@ -793,10 +793,27 @@ def test_mixed_unit_group_every_pair_handed_off(muse, eng, oracle):
     # the second pass over the same rows goes to the rescaling kernel directly (automatic selection learnt the
     # hand-off count of the first): same results
     lag2, mv2 = db.scores()
-    # (the listed pairs are redone by that kernel in the first pass too: identical bits; the last row has no partner, is
-    # never listed and comes from the default kernel in the first pass: equal to rounding)
-    assert np.array_equal(lag, lag2) and np.array_equal(mv[:M - 1], mv2[:M - 1])
-    assert abs(mv[M - 1] - mv2[M - 1]) <= 1e-12 * abs(mv[M - 1])
+    # Run(); Run() is bit-identical (the tie rules of muse_batch.go:87 are "first wins": a last-bit difference between two passes
+    # could reorder a Fetch): a dense list makes the FIRST pass redo every pair with the rescaling kernel too -- the un-paired last
+    # row, which is never listed, included
+    assert np.array_equal(lag, lag2) and np.array_equal(mv, mv2)
+    lag3, mv3 = db.scores()
+    assert np.array_equal(lag, lag3) and np.array_equal(mv, mv3)
+    db.close()
+    dg.close()
+    # a SPARSE list (one pair in sixteen: below the hand-off threshold) is followed in every pass: identical bits again
+    rows = rng.standard_normal((M, N))
+    rows[1::32] *= 1e30
+    dg = muse.DeviceGroup.from_rows(eng, rows)
+    db = muse.DeviceBatch(eng, dg, ref)
+    lag, mv = db.scores()
+    olag, omv, gap = oracle.batch_scores(ref, rows, nthreads=16)
+    assert_scores_match(lag, mv, olag, omv, gap, max_ties=1)
+    for _ in range(2):
+        lag2, mv2 = db.scores()
+        assert np.array_equal(lag, lag2) and np.array_equal(mv, mv2)
+    db.close()
+    dg.close()
 
 
 def test_muse_run_concurrent_callers(muse):
@@ -1549,15 +1566,30 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
     env["MASTER_PORT"] = "29641"
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rows", "20001", "--steps", "2", "--warmup", "1",
-                        "--no-cpu-baseline", "--no-extras", "--rehearse-on-one-gpu"], capture_output=True, text=True, timeout=600, env=env)
+                        "--no-extras", "--rehearse-on-one-gpu"], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
-    d = json.loads(lines[0])
+    assert r.stdout.count("\n") == 1 and r.stdout.startswith("{"), r.stdout[-2000:]   # stdout = rank 0's ONE line, nothing else
+    d = json.loads(r.stdout)
     assert d["n_gpus"] == 2 and d["rehearsal"] is True and d["dtype"] == "f64" and d["scaling"] == "weak"
-    assert d["value"] > 0 and d["config"]["rows_per_gpu"] == 20001
+    assert d["value"] > 0 and d["config"]["rows_per_gpu"] == 20001 and d["config"]["rows_total"] == 40002
+    assert d["config"]["workload"].startswith("configs[3]-shaped") and "2 GPUs" in d["config"]["workload"]
     # the planted copy of the reference (synthetic row of rank 0) tops the merged list
     assert abs(d["top_score"] - 1.0) < 1e-9
+    # what makes an N-rank line a measurement: every rank's own kernel time, device and PCI bus id; the roofline fraction is the
+    # slowest rank's; the CPU baseline beside it at every N; no probe kernel inside the timed region
+    assert [x["rank"] for x in d["ranks"]] == [0, 1]
+    for x in d["ranks"]:
+        assert x["kernel_ms_avg"] > 0 and x["launches_timed"] == 2 and x["rows"] == 20001
+        assert x["pci_bus_id"].count(":") == 2 and "gfx950" in x["device"]
+    assert d["distinct_devices"] == 1                      # (the rehearsal puts both ranks on GPU 0, and the line says so)
+    rl = d["roofline"]
+    kms = [x["kernel_ms_avg"] for x in d["ranks"]]
+    assert rl["per_rank"]["kernel_ms_avg"]["max"] == max(kms) and rl["per_rank"]["kernel_ms_avg"]["min"] == min(kms)
+    assert abs(rl["kernel_ms_avg"] - max(kms)) < 1e-12 and abs(rl["frac"] - rl["per_rank"]["frac"]["min"]) < 1e-12
+    assert rl["per_gpu"] is True and rl["redo_ms_avg"] >= 0
+    assert d["clock_probe_in_timed_region"] is False
+    cb = d["cpu_baseline"]
+    assert cb["value"] > 0 and cb["kind"] == "port" and cb["cores"] >= 1 and cb["single_thread"]["value"] > 0
 
 
 def test_many_references_on_a_float32_storage_group(muse, eng, oracle):
