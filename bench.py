@@ -618,34 +618,69 @@ def main():
             except Exception as e:
                 line["in_process_shards"] = {"error": str(e)}
         if extras:
-            # BASELINE config 5's lengths (N zero-padded to the next power of two), float64: one all-scores pass per length
-            # over a ~4 GB group of its own; per length the kernel automatic selection takes and its share of the HBM
-            # roofline on 8 N + 16 algorithmic bytes per series.  Parity per length: tests/test_gpu_parity.py.
-            per_len = []
-            for Nl in (512, 1000, 5000, 16384, 65536):
+            # BASELINE configs[4] as ONE workload (single-GPU half): a mixed-length Group is six (ref, Group) pairs, one per length
+            # (group.go:45-51 and muse_batch.go:24-28 allow one length per Group), each ~4 GB resident, label groups of 50 series
+            # ("graph"), every Batch Run(["graph"]) into ONE shared Results (results.go:55-72) and one Fetch at the end.  Timed per
+            # length: the whole Run (fused kernel + group max + filter + top-N + copy-back + the host feed of the shared heap) and,
+            # by HIP events, its fused kernel alone (-> share of the HBM roofline on 8 N + 16 bytes per series, with the measured
+            # traffic of that kernel beside it).  Parity of exactly this flow: tests/test_gpu_parity.py,
+            # test_config5_mixed_lengths_one_shared_results.
+            per_len, shared, carry = [], pkg.NewResults(args.max_lag, args.top_n, 0.0, 0), []
+            run_s_total, rows_total = 0.0, 0
+            for Nl in (512, 1000, 4096, 5000, 16384, 65536):
                 try:
                     rows_l = max(2048, min(400_000, (1 << 32) // (8 * Nl)))
-                    dgl, refl = pkg.DeviceGroup.synthetic(eng, rows_l, Nl, seed=0x6D757365)
+                    # (without the planted exact copies of the reference: the shared top-N is then a field of distinct scores from
+                    # all six lengths, not twenty 1.0s from the first)
+                    dgl, refl = pkg.DeviceGroup.synthetic(eng, rows_l, Nl, seed=0x6D757365, copies=False)
                     dbl = pkg.DeviceBatch(eng, dgl, refl)
-                    dbl.score()
+                    Gl = (rows_l + 49) // 50
+                    gidl = (np.arange(rows_l, dtype=np.int64) // 50).astype(np.int32)
+
+                    def run_len():
+                        idx, lg, sc, _ = dbl.run(gidl, Gl, args.max_lag, args.top_n, 0.0, 0, True)
+                        for k in np.argsort(gidl[idx], kind="stable"):          # the ordered drain, muse_batch.go:124-128
+                            shared.Update(pkg.Score(pkg.NewLabels({"len": str(Nl), "graph": "g%d" % int(gidl[idx[k]]), "row": str(int(idx[k]))}),
+                                                    int(lg[k]), float(sc[k])))
+                    run_len()
                     eng.synchronize()
                     eng.kernel_time()
                     eng.kernel_timing(True)
-                    for _ in range(3):
-                        dbl.score()
+                    reps = 3
+                    t1 = time.perf_counter()
+                    for r_ in range(reps):
+                        shared.Fetch()                                          # every repeat starts from what the EARLIER lengths left
+                        for sc_ in carry:
+                            shared.Update(sc_)
+                        run_len()
                     eng.synchronize()
+                    dtl = (time.perf_counter() - t1) / reps
                     eng.kernel_timing(False)
                     kl_ms, kl_cnt = eng.kernel_time()
                     kl_s = kl_ms / max(kl_cnt, 1) * 1e-3
-                    per_len.append({"N": Nl, "fft_len": dbl.n, "rows": rows_l, "length": Nl, "kernel": eng.kernel_name(dbl),
-                                    "kernel_ms_avg": kl_s * 1e3, "series_per_s": rows_l / kl_s,
+                    carry = shared.Fetch()[0]                                   # (Fetch drains, results.go:75-87: put it back)
+                    for sc_ in carry:
+                        shared.Update(sc_)
+                    per_len.append({"N": Nl, "fft_len": dbl.n, "rows": rows_l, "length": Nl, "label_groups": Gl, "kernel": eng.kernel_name(dbl),
+                                    "run_ms": dtl * 1e3, "kernel_ms_avg": kl_s * 1e3, "series_per_s": rows_l / dtl,
+                                    "series_per_s_kernel": rows_l / kl_s,
                                     "roofline_frac": rows_l * (8.0 * Nl + 16.0) / kl_s / 1e9 / HBM_PEAK_GBPS})
                     counters.attach(per_len[-1], eng.kernel_name(dbl), rows_l, Nl, rows_l * (8.0 * Nl + 16.0))
+                    run_s_total += dtl
+                    rows_total += rows_l
                     dbl.close()
                     dgl.close()
                 except Exception as e:
                     per_len.append({"N": Nl, "error": str(e)})
             line["config5_lengths"] = per_len
+            top, mean_abs = shared.Fetch()
+            line["config5_mixed_run"] = {
+                "value": rows_total / run_s_total if run_s_total > 0 else None, "unit": "series/s", "series_total": rows_total,
+                "ms_total": run_s_total * 1e3, "lengths": [e_["N"] for e_ in per_len if "error" not in e_],
+                "shared_results": {"top_n": args.top_n, "fetched": len(top), "mean_abs_score": mean_abs,
+                                   "lengths_in_top_n": sorted({s_.Labels.labels["len"] for s_ in top}, key=int)},
+                "note": "configs[4], single-GPU half: six (ref, Group) pairs, Run([\"graph\"]) each (muse_batch_run with 50-series label groups) "
+                        "into ONE Results, one Fetch; per-length Run and kernel times in config5_lengths"}
         if not args.no_cpu_baseline:
             # (at every N, on rank 0's host cores over a sample of rank 0's shard: the other ranks wait at the closing barrier)
             line["cpu_baseline"] = cpu_baseline(dg, ref, N)

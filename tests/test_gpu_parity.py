@@ -497,6 +497,74 @@ def test_config5_mixed_lengths_label_grouped(muse, eng, oracle, N):
     assert got[0].Labels.labels == {"graph": "g07", "host": "h3"} and abs(got[0].PercentScore - 1.0) < 1e-9
 
 
+@pytest.mark.parametrize("sharded", [False, True])
+def test_config5_mixed_lengths_one_shared_results(muse, eng, oracle, sharded):
+    """BASELINE configs[4] as ONE workload: a mixed-length Group is realised the way the reference must realise it (one length per
+    Group: group.go:45-51, muse_batch.go:24-28) -- six (ref, Group) pairs, N in {512, 1000, 4096, 5000, 16384, 65536},
+    2 000 series each in 200 graphs x 10 hosts, every Batch Run(["graph"]) into ONE shared Results (results.go:55-72 keeps one
+    top-N heap across Runs: example_test.go:53-80 reuses one Results for three Runs), ONE Fetch at the end.  Checked against the
+    oracle's Results over the union of all six Groups' oracle scores, fed in the same order (batch by batch, group by group):
+    descending order, lags, scores, labels, mean |score|.  sharded: every Group cut over a list of contexts (device 0
+    twice plus every other device of the box), the same Scores."""
+    lengths = (512, 1000, 4096, 5000, 16384, 65536)
+    graphs, hosts = 200, 10
+    res = muse.NewResults(15, 20, 0.0, muse.SignFilter_ANY)
+    engines = None
+    if sharded:
+        ndev = muse.device_count()
+        engines = [muse.Engine(d) for d in ([0, 0] + list(range(1, ndev)))]
+    all_lag, all_mv, all_gid, all_labels, batches = [], [], [], [], []
+    for k, N in enumerate(lengths):
+        rng = np.random.default_rng(1000 + N)
+        t = np.arange(N)
+        ref_y = 1.5 * (np.abs(t - N // 2) <= 5) + 0.1 * rng.standard_normal(N)
+        M = graphs * hosts
+        shift = rng.integers(-20, 21, size=(M, 1))
+        width = rng.integers(2, 12, size=(M, 1))
+        amp = rng.uniform(-3, 3, size=(M, 1))
+        # (the noise grows with the length so that the best scores of all six lengths interleave in one top-20)
+        rows = amp * (np.abs(t[None, :] - N // 2 - shift) <= width) + (0.1 + 0.02 * k) * rng.standard_normal((M, N))
+        rows[1000 + 17 * k + 3] = (2.0 + k) * ref_y - 1.0   # a perfect match in every Group: six ties at 1.0 across Runs
+        rows[10 * (3 + k):10 * (4 + k)] = 0.5               # a whole graph of constant lines (sigma == 0: score 0, lag 0)
+        labels = [{"len": str(N), "graph": "g%03d" % (i // hosts), "host": "h%d" % (i % hosts)} for i in range(M)]
+        comp = muse.NewGroup("comparison-%d" % N)
+        comp.Add(*[muse.NewSeries(rows[i], muse.NewLabels(labels[i])) for i in range(M)])
+        ref = muse.NewSeries(ref_y, muse.NewLabels({"len": str(N), "graph": "ref"}))
+        b = muse.NewBatch(ref, comp, res, 8, engine=eng, engines=engines)
+        assert b.n == oracle.next_pow2(N)
+        b.Run(["graph"])                                     # every Batch into the ONE Results
+        batches.append(b)
+        olag, omv, gap = oracle.batch_scores(ref_y, rows, nthreads=16)
+        all_lag.append(olag)
+        all_mv.append(omv)
+        all_gid.append(np.arange(M, dtype=np.int32) // hosts + k * graphs)
+        all_labels += labels
+    got, mean = res.Fetch()                                  # ONE Fetch over all six Runs
+    oi, ol, osc, omean = oracle.results(np.concatenate(all_lag), np.concatenate(all_mv), np.concatenate(all_gid),
+                                        graphs * len(lengths), True, 15, 20, 0.0, 0)
+    assert len(got) == 20 == len(oi)
+    assert [s.Lag for s in got] == ol.tolist()
+    assert np.allclose([s.PercentScore for s in got], osc, rtol=SCORE_RTOL, atol=SCORE_ATOL)
+    # labels in Fetch order; among equal scores (the six planted 1.0s, equal to rounding) the order Fetch returns is the heap's own history
+    # (results.go:55-87) -- in the reference that history follows Go's map iteration order (group.go:83: unspecified), here the
+    # per-Batch candidates are fed in group order: compared as a set inside a run of equal scores, in order everywhere else
+    want = [all_labels[i] for i in oi]
+    have = [s.Labels.labels for s in got]
+    k = 0
+    while k < 20:
+        e = k
+        while e + 1 < 20 and abs(osc[e + 1] - osc[e]) <= 1e-12:   # (equal to rounding: 1.0 against 1 - 2e-16 is a tie too)
+            e += 1
+        key = lambda d: sorted(d.items())
+        assert sorted(have[k:e + 1], key=key) == sorted(want[k:e + 1], key=key), (k, e)
+        k = e + 1
+    assert abs(mean - omean) < 1e-9
+    assert len({s.Labels.labels["len"] for s in got}) >= 4                   # the top-20 really mixes the lengths
+    assert sorted(s.Labels.labels["len"] for s in got[:6]) == sorted(str(N) for N in lengths)   # the six planted matches lead
+    second, mean2 = res.Fetch()                              # Fetch drains (results.go:75-87)
+    assert second == [] and math.isnan(mean2)
+
+
 def test_group_append_staging_paths(muse, eng, oracle):
     """Group.Add-style ingestion: one muse_group_append per Series (pinned double-buffered
     staging, asynchronous upload), mixed with slab appends and growth re-allocations; the
