@@ -80,7 +80,6 @@ SIGNATURES = {
     "muse_batch_last_run_info": (ctypes.c_int, [_vp, _i32p, _i64p]),
     "muse_batch_last_run_path": (ctypes.c_int, [_vp, _i32p]),
     "muse_batch_kernel_name": (ctypes.c_int, [_vp, ctypes.c_char_p, _i32]),
-    "muse_test_long_team_config": (ctypes.c_int, [_vp, _i32, _i32, _i32]),
     "muse_test_set_screen_bound_scale": (ctypes.c_int, [_vp, _f64]),
     "muse_test_screen_bound": (ctypes.c_int, [_i32, _f64, _dp]),
     "muse_test_wave_argmax": (ctypes.c_int, [_vp, _dp, _dp, _dp]),

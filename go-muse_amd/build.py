@@ -13,7 +13,7 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libmuse_hip.so")
-SOURCES = ["xcorr_kernels.hip", "xcorr_r16_fold.hip", "xcorr_r16_occ4.hip", "xcorr_stockham.hip", "xcorr_two_sided.hip", "xcorr_small.hip", "xcorr_long.hip", "xcorr_long_team.hip", "xcorr_r16_screen.hip", "xcorr_screen_stk.hip", "reduce_kernels.hip", "diag_kernels.hip", "muse_capi.hip"]
+SOURCES = ["xcorr_kernels.hip", "xcorr_r16_fold.hip", "xcorr_r16_occ4.hip", "xcorr_stockham.hip", "xcorr_two_sided.hip", "xcorr_small.hip", "xcorr_long.hip", "xcorr_r16_screen.hip", "xcorr_screen_stk.hip", "reduce_kernels.hip", "diag_kernels.hip", "muse_capi.hip"]
 HEADERS = [os.path.join(CSRC, "xcorr_kernels.h"), os.path.join(CSRC, "fft_device.h"), os.path.join(CSRC, "r16_device.h"), os.path.join(CSRC, "fold_device.h"), os.path.join(CSRC, "foldk_device.h"), os.path.join(CSRC, "long_device.h"), os.path.join(CSRC, "stk_device.h"), os.path.join(CSRC, "two_device.h"), os.path.join(ROOT, "include", "muse_hip.h"), os.path.join(ROOT, "include", "muse_hip_test.h")]
 
 

@@ -118,10 +118,6 @@ struct muse_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events, redo_events;
     double total_ms = 0.0, redo_ms = 0.0;
     int64_t launches = 0, redo_launches = 0;
-    // kernel variant 14 (xcorr_long_team.hip): control block (device), its error word (pinned host copy), geometry
-    void *team_ctl = nullptr;
-    unsigned *team_err = nullptr;
-    int team_wgs = 2, team_slots = 4, team_dist = 1;
     char pci[32] = {0}; // PCI bus id of the device ("0000:05:00.0"): tells two contexts on one GPU from two GPUs
     // Handles may be released in any order (Go finalizers, Python GC): the
     // context lives until it is destroyed AND its last group/batch is freed.
@@ -439,9 +435,6 @@ static void ctx_release(muse_ctx *ctx)
             (void)hipEventDestroy(e.first);
             (void)hipEventDestroy(e.second);
         }
-    (void)hipFree(ctx->team_ctl);
-    if (ctx->team_err)
-        (void)hipHostFree(ctx->team_err);
     (void)hipFree(ctx->tw1);
     (void)hipFree(ctx->tw2);
     (void)hipFree(ctx->twm);
@@ -503,19 +496,9 @@ extern "C" int muse_ctx_device_info(muse_ctx *ctx, char *name, int32_t name_cap,
 
 extern "C" int muse_ctx_set_kernel(muse_ctx *ctx, int32_t variant)
 {
-    if (!ctx || !(variant == 0 || variant == 1 || variant == 7 || variant == 10 || variant == 11 || variant == 12 || variant == 13 || variant == 14))
-        return fail(MUSE_ERR_INVALID, "bad kernel variant (0 auto, 1 generic, 7 rescaling n=4096, 10 default n=4096, 11 Stockham, 12 half-round, 13 long series, 14 long series in XCD teams)");
+    if (!ctx || !(variant == 0 || variant == 1 || variant == 7 || variant == 10 || variant == 11 || variant == 12 || variant == 13))
+        return fail(MUSE_ERR_INVALID, "bad kernel variant (0 auto, 1 generic, 7 rescaling n=4096, 10 default n=4096, 11 Stockham, 12 half-round, 13 long series)");
     ctx->variant = variant;
-    return MUSE_OK;
-}
-
-extern "C" int muse_test_long_team_config(muse_ctx *ctx, int32_t wgs_per_cu, int32_t slices_per_xcd, int32_t distance)
-{
-    if (!ctx || wgs_per_cu < 1 || wgs_per_cu > 4 || distance < 1 || slices_per_xcd < 2 * distance + 1 || slices_per_xcd > 8)
-        return fail(MUSE_ERR_INVALID, "muse_test_long_team_config: 1 .. 4 workgroups per CU, distance >= 1, 2 distance + 1 .. 8 slices per XCD");
-    ctx->team_wgs = wgs_per_cu;
-    ctx->team_slots = slices_per_xcd;
-    ctx->team_dist = distance;
     return MUSE_OK;
 }
 
@@ -1245,8 +1228,6 @@ extern "C" int muse_batch_score(muse_batch *b)
             variant = KERNEL_R16_OCC3;
     } else if (b->g->f32 && !(((b->n >= 512 && b->n <= 2048) || b->n == 8192 || b->n == 16384) && (ctx->variant == 0 || ctx->variant == 12))) {
         return fail(MUSE_ERR_UNSUPPORTED, "float32-storage groups run on the default kernels only (FFT lengths 512 ... 16384)");
-    } else if (b->xcp && p.twl && (b->N == b->n || b->c1) && b->n >= 32768 && ctx->variant == 14) {
-        variant = KERNEL_LONG_TEAM; // the same transform as tasks of XCD-local teams (xcorr_long_team.hip)
     } else if (b->xcp && p.twl && (b->N == b->n || b->c1) && ((b->n >= 32768 && ctx->variant == 0) || (b->n >= 16384 && ctx->variant == 13))) {
         variant = KERNEL_LONG; // four-step, 4096-point rows on the n = 4096 kernel's transforms (xcorr_long.hip)
     } else if (((b->n >= 512 && b->n <= 2048) || b->n == 8192 || b->n == 16384) && (ctx->variant == 0 || ctx->variant == 12)) {
@@ -1295,42 +1276,6 @@ extern "C" int muse_batch_score(muse_batch *b)
             b->handoff_M = M;
             HIP_TRY(hipMemcpyAsync(b->handoff_host, b->ovf_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         }
-    } else if (variant == KERNEL_LONG_TEAM) {
-        if (2 * p.npairs > b->ovf_cap) {
-            (void)hipFree(b->ovf_list);
-            b->ovf_list = nullptr;
-            b->ovf_cap = 0;
-            HIP_TRY(hipMalloc(&b->ovf_list, (size_t)(2 * p.npairs) * sizeof(long long)));
-            b->ovf_cap = 2 * p.npairs;
-        }
-        if (!ctx->team_ctl) {
-            HIP_TRY(hipMalloc(&ctx->team_ctl, long_team_ctl_bytes()));
-            HIP_TRY(hipHostMalloc((void **)&ctx->team_err, sizeof(unsigned), hipHostMallocDefault));
-        }
-        p.ovf_count = b->ovf_count;
-        p.ovf_list = b->ovf_list;
-        p.team_ctl = ctx->team_ctl;
-        p.team_slots = ctx->team_slots;
-        p.team_dist = ctx->team_dist;
-        HIP_TRY(hipMemsetAsync(b->ovf_count, 0, 2 * sizeof(int), ctx->stream));
-        HIP_TRY(hipMemsetAsync(ctx->team_ctl, 0, long_team_ctl_bytes(), ctx->stream));
-        HIP_TRY(timer.begin());
-        HIP_TRY(launch_long_team(p, ctx->num_cus, ctx->team_wgs, ctx->stream));
-        HIP_TRY(timer.end());
-        FusedParams q = p;
-        q.pair_list = b->ovf_list;
-        q.pair_count = b->ovf_count;
-        q.npairs = std::min<long long>(p.npairs, (long long)ctx->num_cus * STOCKHAM_GLOBAL_WGS_PER_CU);
-        HIP_TRY(redo_timer.begin());
-        HIP_TRY(launch_fused(q, KERNEL_STOCKHAM, ctx->num_cus, ctx->stream));
-        HIP_TRY(redo_timer.end());
-        // (a test-hook variant: its error word is checked right away; a wait that timed out or an unexpected XCC id)
-        *ctx->team_err = 0;
-        HIP_TRY(hipMemcpyAsync(ctx->team_err, (const char *)ctx->team_ctl + long_team_error_offset(), sizeof(unsigned),
-                               hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-        if (*ctx->team_err)
-            return fail(MUSE_ERR_HIP, "xcorr_long_team reported error %u (1: a hand-off wait timed out, 2: an XCC id outside 0..7)", *ctx->team_err);
     } else if (variant == KERNEL_LONG) {
         // as above: NaN / Inf and sigma-spread pairs are listed (one entry per pair) and redone by the four-step kernel that
         // isolates and rescales the series first

@@ -8,7 +8,7 @@
 
 namespace muse {
 
-enum { KERNEL_GENERIC = 0, KERNEL_R16_OCC3 = 6, KERNEL_STOCKHAM = 10, KERNEL_R16_FOLD = 11, KERNEL_SMALL = 12, KERNEL_LONG = 13, KERNEL_LONG_TEAM = 14 };
+enum { KERNEL_GENERIC = 0, KERNEL_R16_OCC3 = 6, KERNEL_STOCKHAM = 10, KERNEL_R16_FOLD = 11, KERNEL_SMALL = 12, KERNEL_LONG = 13 };
 
 struct FusedParams {
     const double *rows; // M x N row-major, row stride `stride` elements (float64 groups)
@@ -68,10 +68,6 @@ struct FusedParams {
     const int *pair_count;
     long long dense_total; // xcorr_r16_occ4.hip behind the default n = 4096 kernel: > 0 and *pair_count * 8 > dense_total -> redo ALL dense_total pairs
     long long gscratch_slices; // n-element slices `gscratch` holds: a kernel that works in it launches no more workgroups than fit
-    // xcorr_long_team.hip: the zeroed control block and the slices per XCD the kernel may use in gscratch
-    void *team_ctl;
-    int team_slots;
-    int team_dist; // rounds between the phases of one pair (>= 1; team_slots >= 2 team_dist + 1)
     // two-sided xCorr (xcorr_two_sided.hip): pair i = (x_i = xrows + i xstride, length Nx; y_i = rows + i stride, length N)
     const double *xrows;
     long long xstride;
@@ -90,10 +86,6 @@ hipError_t launch_fused_multi(const FusedParams &p, int num_cus, hipStream_t str
 hipError_t launch_fused_small(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_small.hip (n = 512, 1024, 2048: default)
 hipError_t launch_fused_stockham(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_stockham.hip (n = 512 .. 2048, 8192 .. 65536)
 hipError_t launch_fused_long(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_long.hip (n = 32768, 65536: default; 16384)
-// xcorr_long_team.hip (n = 32768, 65536): tasks of one pair stay on one XCD, the slices in its L2
-hipError_t launch_long_team(const FusedParams &p, int num_cus, int wgs_per_cu, hipStream_t stream);
-size_t long_team_ctl_bytes();
-size_t long_team_error_offset();
 hipError_t launch_two_sided(const FusedParams &p, int num_cus, hipStream_t stream);
 // the same for n = 512 ... 2048, 8192, 16384 on xcorr_small.hip's transforms (called by launch_two_sided)
 hipError_t launch_two_sided_small(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_two_sided.hip (xCorr, n = 512 .. 65536)

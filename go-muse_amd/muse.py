@@ -64,10 +64,6 @@ class Engine:
     def set_kernel(self, variant):
         B.check(B.load().muse_ctx_set_kernel(self._h, int(variant)))
 
-    def long_team_config(self, wgs_per_cu, slices_per_xcd, distance=1):
-        """test hook: geometry of kernel variant 14 (xcorr_long_team.hip)"""
-        B.check(B.load().muse_test_long_team_config(self._h, int(wgs_per_cu), int(slices_per_xcd), int(distance)))
-
     def set_screening(self, enable, min_rows=None):
         """OPT-IN filter-and-refine Run (include/muse_hip.h: muse_ctx_set_screening); min_rows: smallest group it is used for"""
         B.check(B.load().muse_ctx_set_screening(self._h, (int(min_rows) if min_rows and min_rows > 1 else 1) if enable else 0))

@@ -16,11 +16,6 @@ extern "C" {
  * target of the default kernel), 10 = the default n = 4096 kernel, 11 = round-1 radix-16 Stockham / four-step kernels
  * (n = 512 .. 2048, 8192 .. 65536; what auto takes from 8192), 12 = the n = 512 .. 2048 kernels auto takes.  The parity tests run every kernel on the same inputs. */
 int muse_ctx_set_kernel(muse_ctx *ctx, int32_t variant);
-/* Variant 14 (n = 32768, 65536; xcorr_long_team.hip): the four-step kernel whose tasks of one pair stay on one XCD and whose
- * slices stay in that XCD's L2.  This call sets how many workgroups per CU draw tasks (1 .. 4) and how many slices an XCD
- * cycles through (2 distance + 1 .. 8: the pairs it has in flight), and how many rounds of tickets lie between the three phases of one
- * pair (distance >= 1). */
-int muse_test_long_team_config(muse_ctx *ctx, int32_t wgs_per_cu, int32_t slices_per_xcd, int32_t distance);
 /* Scales the error bound the filter-and-refine Run assumes for its fp32 estimates (1.0 = the derived bound): the
  * guard test shrinks it a million-fold to force the fp64 re-run. */
 int muse_test_set_screen_bound_scale(muse_ctx *ctx, double scale);
