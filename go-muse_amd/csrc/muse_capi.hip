@@ -952,6 +952,30 @@ static hipError_t ensure_gscratch(muse_ctx *ctx, int64_t n, int slices_per_cu = 
     return e;
 }
 
+// the base table of the long-series sweeps' twiddles, [4096] W_n^(m2) (n = 16384, 32768, 65536): built on first use per length
+// (rare, so always under the lock -- no unlocked read of the pointer another thread may be storing)
+static hipError_t ensure_twl(muse_ctx *ctx, int64_t n)
+{
+    const int li = ilog2(n) - 14;
+    if (li < 0 || li > 2)
+        return hipErrorInvalidValue;
+    std::lock_guard<std::mutex> lock(ctx->stage_mu);
+    if (ctx->twl[li])
+        return hipSuccess;
+    std::vector<double2> tl(4096);
+    for (int m2 = 0; m2 < 4096; m2++)
+        fill_twiddle(tl, (size_t)m2, (long long)m2, n);
+    double2 *d = nullptr;
+    hipError_t e = hipMalloc(&d, tl.size() * sizeof(double2));
+    if (e == hipSuccess)
+        e = hipMemcpy(d, tl.data(), tl.size() * sizeof(double2), hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+        ctx->twl[li] = d;
+    else
+        (void)hipFree(d);
+    return e;
+}
+
 static void adopt_spectrum(muse_batch *b)
 {
     b->X = b->sp->X;
@@ -1037,23 +1061,8 @@ extern "C" int muse_batch_create(muse_ctx *ctx, muse_group *g, const double *ref
         }
     }
     if (long_n) {
-        const int li = ilog2(n) - 14, R1 = (int)(n / 4096);
-        { // (first use per length: rare, so always under the lock -- no unlocked read of the pointer another thread may be storing)
-            std::lock_guard<std::mutex> lock(ctx->stage_mu);
-            if (!ctx->twl[li]) {
-                std::vector<double2> tl(4096);
-                for (int m2 = 0; m2 < 4096; m2++)
-                    fill_twiddle(tl, (size_t)m2, (long long)m2, n);
-                double2 *d = nullptr;
-                e = hipMalloc(&d, tl.size() * sizeof(double2));
-                if (e == hipSuccess)
-                    e = hipMemcpy(d, tl.data(), tl.size() * sizeof(double2), hipMemcpyHostToDevice);
-                if (e == hipSuccess)
-                    ctx->twl[li] = d;
-                else
-                    (void)hipFree(d);
-            }
-        }
+        const int R1 = (int)(n / 4096);
+        e = ensure_twl(ctx, n);
         if (e == hipSuccess)
             e = launch_lane_order_rows(b->xc, b->xcp, R1, ctx->stream);
         if (e == hipSuccess && b->c1)
@@ -2583,6 +2592,8 @@ extern "C" int muse_xcorr_groups(muse_group *gx, muse_group *gy, int32_t n, int3
         return MUSE_OK;
     }
     hipError_t e = ensure_gscratch(ctx, n);
+    if (e == hipSuccess && n >= 32768)
+        e = ensure_twl(ctx, n);
     if (e != hipSuccess)
         return fail(MUSE_ERR_NOMEM, "scratch: %s", hipGetErrorString(e));
     double *dmv = nullptr, *dcc = nullptr;
@@ -2625,6 +2636,7 @@ extern "C" int muse_xcorr_groups(muse_group *gx, muse_group *gy, int32_t n, int3
         p.gsmall = (p.logn >= 9 && p.logn <= 11) ? ctx->gsmall[p.logn - 9] : (p.logn == 13 || p.logn == 14) ? ctx->gsmall[p.logn - 10] : nullptr;
         p.gscratch = ctx->gscratch;
         p.gscratch_slices = (long long)(ctx->gscratch_elems / (size_t)n);
+        p.twl = (p.logn >= 14 && p.logn <= 16) ? ctx->twl[p.logn - 14] : nullptr;
         p.mv = dmv;
         p.lag = dlag;
         p.nil_out = dnil;

@@ -5,41 +5,22 @@
 // cc = IFFT(X conj(Y)) (134-138), scale 1 / (n (n - 1)) when normalized, else 1 / n (139-143) -- n - 1 of the FFT length,
 // not of the series length --, global first-strict argmax of |cc| and lag unwrap (145-150).
 //
-// n <= 16384: the squared-spectrum form (xcorr_two_sided_fold below for n = 4096, xcorr_small.hip for the other lengths).
-// n >= 32768 (four-step kernel at the end of this file): one complex transform serves both series of a pair:
-// z = x + i y, Z = FFT(z).  With Zm[f] = Z[-f mod n]
-//     X[f] = (Z[f] + conj(Zm[f])) / 2,   Y[f] = (Z[f] - conj(Zm[f])) / 2i
-//     P[f] = X[f] conj(Y[f]):   Re P = Im(Z[f] Zm[f]) / 2,   Im P = (|Z[f]|^2 - |Zm[f]|^2) / 4
-// and cc = IFFT(P) is real, so FFT(conj(P) / n) = cc: a pair costs two FORWARD complex transforms of length n, exactly
-// what a pair of series costs in the xCorrWithX kernels.  The transforms are the Stockham engine's (stk_device.h: natural
-// order, folded arithmetic), whose output order makes the mirrored element Z[-f] one scratch read away.  Both series enter
-// the shared transform at O(1): exact power-of-two scales near 1 / sigma (or near 1 / rms when not normalized), undone in
-// the one factor the winning value is multiplied by (two_device.h).
+// Every batched length runs the squared-spectrum form: with xr[j] = x[-j mod n] (x read backwards: an address pattern) and
+// z = xr + i y, Z = FFT(z) = Xr + i Y and cc = Im FFT(Z^2) / 2n -- two FORWARD complex transforms of length n per pair, exactly
+// what a pair of series costs in the xCorrWithX kernels, no spectrum table and no mirrored element Z[-f]: n = 4096 on
+// xcorr_two_sided_fold below, n = 512 ... 2048, 8192, 16384 on xcorr_small.hip's transforms, n = 32768, 65536 on the long-series
+// kernel's four-step transform (xcorr_two_sided_long at the end of this file).  Both series enter the shared transform centred and
+// at O(1): exact power-of-two scales near 1 / sigma (or near 1 / rms when not normalized), undone in the one factor the winning
+// value is multiplied by (two_device.h).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <algorithm>
 
-#include "stk_device.h"
-#include "foldk_device.h"
+#include "long_device.h"
 #include "two_device.h"
 
 namespace muse {
-
-namespace two {
-
-using namespace occ4;
-using namespace stk;
-
-// V[f] = conj(P[f]) * s from Z[f] and Z[-f]
-__device__ __forceinline__ double2 untangle(const double2 z, const double2 zm, const double s)
-{
-    const double re = 0.5 * fma(z.x, zm.y, z.y * zm.x);
-    const double im = 0.25 * (fma(z.x, z.x, z.y * z.y) - fma(zm.x, zm.x, zm.y * zm.y));
-    return make_double2(re * s, -im * s);
-}
-
-} // namespace two
 
 // n = 4096 on the xCorrWithX kernel's machinery (foldk_device.h: three radix-16 passes per transform with the twiddles
 // folded into the butterflies, half-round LDS transposes, 128 registers -> four workgroups per CU) WITHOUT the mirrored
@@ -221,172 +202,259 @@ __global__ __launch_bounds__(256, 4) void xcorr_two_sided_fold(const FusedParams
     finish_prev(pair - gridDim.x);
 }
 
-// n = 16384 ... 65536: four-step, n = R1 * 4096 (xcorr_fused_stk_4step's geometry), TWO n-element scratch slices per
-// workgroup: Y takes the rows, the first sweep and the row spectra Z (natural order: Z[k1 + R1 k2] at Y[4096 k1 + k2]);
-// the second stage reads Z[f] and Z[-f] (row R1 - k1, column 4095 - k2; row 0: column 4096 - k2), transforms the untangled
-// product row by row into Y2, and the last sweep runs over Y2.
-template <int LOGN>
-__global__ __launch_bounds__(256, 2) void xcorr_two_sided_4step(const FusedParams p)
+// n = 32768, 65536: the squared-spectrum form on the long-series kernel's four-step transform (xcorr_long.hip: n = R1 * 4096,
+// sweeps of radix R1 in registers with their twiddles formed as powers of one table entry, 4096-point rows on the n = 4096
+// kernel's folded transforms at 16 waves per CU, ONE n-element scratch slice per workgroup):
+//   pass 0  the pair's statistics (both rows read once; xcorr.go:108-128) -> exact power-of-two scales, means, the result factor;
+//   sweep 1 the rows again, x backwards: z[e] = (x[-e mod n] s_x - m_x) + i (y[e] s_y - m_y) (leading zero pads of either series
+//           masked), radix R1 over m1, twiddle -> the slice;
+//   rows    first transform, the element-wise SQUARE in the first stage of the second transform (bf_sq), second transform, in place;
+//   sweep 2 twiddle, radix R1 over k1: 2 n cc = the IMAGINARY part; argmax.
+// Round 3 ran these lengths on the Stockham four-step with the mirrored element Z[-f] (two slices per workgroup, nine crossings of a
+// slice per pair, 8 waves per CU): 0.06 of the roofline; this form crosses the slice four times and reads the rows twice.
+template <int LOGN, bool PADDED>
+__global__ __launch_bounds__(256, 4) void xcorr_two_sided_long(const FusedParams p, const two::PairInv iv)
 {
     using namespace occ4;
-    using namespace stk;
+    using namespace fold;
+    using namespace foldk;
+    using namespace lng;
     using namespace two;
     constexpr int n = 1 << LOGN;
     constexpr int S = n / 16;
     constexpr int CH = S / 256;
     constexpr int R1 = n / 4096;
     constexpr int Q1 = 16 / R1;
-    static_assert(LOGN >= 15 && LOGN <= 16, "four-step kernel: n = 32768, 65536");
-    __shared__ double2 buf[4096 + 256];
-    __shared__ double red[64];
-    __shared__ int redi[16];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    double2 *const Y = p.gscratch + (size_t)(2 * blockIdx.x) * (size_t)n;
-    double2 *const Y2 = Y + n;
-    const int Nx = p.Nx, Ny = p.N, padx = n - Nx, pady = n - Ny;
+    constexpr int NW = 4;
+    static_assert(LOGN >= 15 && LOGN <= 16, "n = 32768, 65536");
+    __shared__ double2 xbuf[OCC_XBUF];
+    __shared__ double2 g2s[128];
+    __shared__ double red[4 * NW + NW + 2];
+    __shared__ int redi[NW];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    double2 *const xw = xbuf + XW * wave;
+    double2 *const Y = p.gscratch + (size_t)blockIdx.x * (size_t)n;
+    const int Nx = PADDED ? p.Nx : n, Ny = PADDED ? p.N : n, padx = n - Nx, pady = n - Ny;
     const bool normalize = p.normalize_y != 0;
-    const double2 *__restrict__ twm = p.twm;
+    const double2 *__restrict__ twl = p.twl; // [4096] W_n^(m2)
+    typedef d2v __attribute__((address_space(1))) *gd2;
+    const auto yat = [&](long long off) __attribute__((always_inline)) { return (gd2)scalar_ptr_at(Y, off); };
+    const auto opaque = [](int x) __attribute__((always_inline)) {
+        asm volatile("" : "+v"(x));
+        return x;
+    };
+    const auto tw_base = [&](int m, unsigned jj) __attribute__((always_inline)) { return ldg2u(scalar_ptr_at(twl, m * S), jj); };
+    if (t < 128)
+        g2s[t] = p.g2[t];
+    __syncthreads();
 
     for (long long pair = blockIdx.x; pair < p.npairs; pair += gridDim.x) {
         const double *__restrict__ rx = p.xrows + pair * p.xstride;
         const double *__restrict__ ry = p.rows + pair * p.stride;
         const double KA = normalize ? rx[0] : 0.0, KB = normalize ? ry[0] : 0.0;
-        const auto twiddle_rows = [&](double2 (&v)[16], const int j) __attribute__((always_inline)) {
+        // position e of the padded arrays holds y[e - pady] and x[(-e mod n) - padx] (leading zero pads, xcorr.go:129-130)
+        const auto load_chunk = [&](const int j, double (&xa)[16], double (&yb)[16]) __attribute__((always_inline)) {
 #pragma unroll
-            for (int m = 0; m < Q1; m++) {
-                const int m2 = j + m * S;
-#pragma unroll
-                for (int r = 1; r < R1; r++) {
-                    const int e = (m2 * r * (65536 / n)) & 65535;
-                    const double2 w = twm[e & 32767];
-                    const double2 ws = e >= 32768 ? make_double2(-w.x, -w.y) : w;
-                    v[m + r * Q1] = cmul(v[m + r * Q1], ws);
-                }
+            for (int i = 0; i < 16; i++) {
+                const int e = j + i * S;
+                const int ex = ((n - e) & (n - 1)) - padx, ey = e - pady;
+                xa[i] = __builtin_nontemporal_load(scalar_ptr(rx) + (unsigned)(PADDED && ex < 0 ? 0 : ex));
+                if (PADDED)
+                    yb[i] = __builtin_nontemporal_load(scalar_ptr(ry) + (unsigned)(ey < 0 ? 0 : ey));
+                else
+                    yb[i] = __builtin_nontemporal_load(scalar_ptr_at(ry, i * S) + (unsigned)j);
             }
         };
-        // ---- sweep 0: rows -> d (leading zero pads) into the slice, statistics
+        // ---------------- pass 0: statistics (the wave's running sums in SGPRs)
         double q[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma clang loop unroll(disable)
         for (int ch = 0; ch < CH; ch++) {
-            const int j = t + 256 * ch;
+            const int j = opaque(t + 256 * ch) & (S - 1);
+            double xa[16], yb[16], c[4] = {0.0, 0.0, 0.0, 0.0};
+            load_chunk(j, xa, yb);
+            fence();
 #pragma unroll
             for (int i = 0; i < 16; i++) {
-                const int ex = j + i * S - padx, ey = j + i * S - pady;
-                double da = __builtin_nontemporal_load(rx + (ex < 0 ? 0 : ex)) - KA;
-                double db = __builtin_nontemporal_load(ry + (ey < 0 ? 0 : ey)) - KB;
-                da = ex >= 0 ? da : 0.0;
-                db = ey >= 0 ? db : 0.0;
-                Y[j + i * S] = make_double2(da, db);
-                q[0] += da;
-                q[1] = fma(da, da, q[1]);
-                q[2] += db;
-                q[3] = fma(db, db, q[3]);
+                double da = xa[i] - KA, db = yb[i] - KB;
+                if (PADDED) {
+                    const int e = j + i * S;
+                    da = ((n - e) & (n - 1)) - padx >= 0 ? da : 0.0;
+                    db = e - pady >= 0 ? db : 0.0;
+                }
+                c[0] += da;
+                c[1] = fma(da, da, c[1]);
+                c[2] += db;
+                c[3] = fma(db, db, c[3]);
             }
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                q[k] = uniform(q[k] + wave_sum_dpp(c[k]));
         }
-        block_sum<4>(q, red);
-        const PairScale ps = pair_scale(q, Nx, Ny, n, normalize);
-        const bool dead = ps.nil || ps.nan;
-        // ---- sweep 1: scale / centre, radix R1 over m1, twiddle W_n^(m2 k1), in place
-#pragma clang loop unroll(disable)
-        for (int ch = 0; ch < CH; ch++) {
-            const int j = t + 256 * ch;
-            double2 v[16];
+        if (lane == 0) {
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const bool vx = j + i * S - padx >= 0, vy = j + i * S - pady >= 0;
-                const double2 d = Y[j + i * S];
-                v[i].x = (vx && !dead) ? fma(d.x, ps.sA, -ps.mA) : 0.0;
-                v[i].y = (vy && !dead) ? fma(d.y, ps.sB, -ps.mB) : 0.0;
-            }
-            dft_small<R1>(v);
-            twiddle_rows(v, j);
-#pragma unroll
-            for (int i = 0; i < 16; i++)
-                Y[j + i * S] = v[i];
+            for (int k = 0; k < 4; k++)
+                red[4 * wave + k] = q[k];
         }
         __syncthreads();
-        // ---- rows, first transform: row k1 -> Z[k1 + R1 k2] at Y[4096 k1 + k2]
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            q[k] = uniform((red[k] + red[4 + k]) + (red[8 + k] + red[12 + k]));
+        const PairScale ps = pair_scale(q, iv, normalize);
+        const bool dead = ps.nil || ps.nan;
+        const double sA = dead ? 0.0 : ps.sA, sB = dead ? 0.0 : ps.sB, mA = dead ? 0.0 : ps.mA, mB = dead ? 0.0 : ps.mB;
+        const double fac = ps.fac * (1.0 / (2.0 * n)); // (pair_scale's factor assumes a spectrum already divided by n; 1 / 2n is exact)
+        // ---------------- sweep 1: the rows again, scaled and centred, radix R1 over m1, twiddle -> the slice
+#pragma clang loop unroll(disable)
+        for (int ch = 0; ch < CH; ch++) {
+            const int j = opaque(t + 256 * ch) & (S - 1);
+            double2 v[16];
+            double xa[16], yb[16];
+            load_chunk(j, xa, yb);
+            double2 wb[Q1];
+            {
+                const unsigned jw = (unsigned)(opaque(t + 256 * ch) & (S - 1));
+#pragma unroll
+                for (int m = 0; m < Q1; m++)
+                    wb[m] = tw_base(m, jw);
+            }
+            fence();
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int e = j + i * S;
+                const bool vx = !PADDED || ((n - e) & (n - 1)) - padx >= 0, vy = !PADDED || e - pady >= 0;
+                v[i].x = vx ? fma(xa[i] - KA, sA, -mA) : 0.0;
+                v[i].y = vy ? fma(yb[i] - KB, sB, -mB) : 0.0;
+            }
+            sweep_dft<R1>(v);
+            const unsigned js = (unsigned)(opaque(t + 256 * ch) & (S - 1));
+#pragma unroll
+            for (int m = 0; m < Q1; m++)
+                *(yat((long long)m * S) + js) = d2v{v[m].x, v[m].y};
+#pragma unroll
+            for (int m = 0; m < Q1; m++) {
+                twiddle_powers<R1>(wb[m], [&](const int k1, const double2 w) __attribute__((always_inline)) {
+                    const double2 z = cmul(v[m + brev<R1>(k1) * Q1], w);
+                    *(yat((long long)(m + k1 * Q1) * S) + js) = d2v{z.x, z.y};
+                });
+            }
+        }
+        __syncthreads(); // the slice is complete
+        // ---------------- rows: Z = FFT(row), FFT(Z^2), in place
 #pragma clang loop unroll(disable)
         for (int k1 = 0; k1 < R1; k1++) {
             double2 *const row = Y + k1 * 4096;
             double2 v[16];
+            {
+                const unsigned tl = (unsigned)(opaque(t) & 255);
 #pragma unroll
-            for (int i = 0; i < 16; i++)
-                v[i] = row[t + 256 * i];
-            lds_forward<12, true>(v, buf, twm, t);
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-                row[t + 256 * r] = v[BR16(r)];
-        }
-        __syncthreads(); // every row's spectrum is in the slice
-        // ---- rows, second transform: V[f] = conj(X[f] conj(Y[f])) / n from Z[f] and Z[-f], row k1 -> Y2
-#pragma clang loop unroll(disable)
-        for (int k1 = 0; k1 < R1; k1++) {
-            const double2 *const row = Y + k1 * 4096;
-            const double2 *const mrow = Y + ((R1 - k1) & (R1 - 1)) * 4096;
-            double2 v[16];
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int k2 = t + 256 * r;
-                const int m2 = k1 == 0 ? ((4096 - k2) & 4095) : 4095 - k2;
-                v[r] = untangle(row[k2], mrow[m2], 1.0 / (double)n);
+                for (int i = 0; i < 16; i++) {
+                    const d2v z = __builtin_nontemporal_load((gd2)scalar_ptr_at(row, 256 * i) + tl);
+                    v[i] = make_double2(z.x, z.y);
+                }
             }
-            lds_forward<12, true>(v, buf, twm, t);
-            double2 *const out = Y2 + k1 * 4096;
+            dft16_nr(v);
+            exchange_cross<0, 1, true>(v, xbuf, wave, t);
+            gdft16_nr(v, G2Fetch{g2s, t >> 4});
+            exchange_local<1>(v, xw, t);
+            gdft16_nr_l2(v, G3Fetch{p.g3a, t});
 #pragma unroll
-            for (int r = 0; r < 16; r++)
-                out[t + 256 * r] = v[BR16(r)];
+            for (int r = 0; r < 16; r += 2)
+                bf_sq(v[r], v[r + 1]);
+            dft16_rn_s234(v);
+            exchange_local<0>(v, xw, t);
+            gdft16_nr(v, G2Fetch{g2s, t & 15});
+            exchange_cross<1, 1>(v, xbuf, wave, t);
+            gdft16_nr_l2(v, G3Fetch{p.g3b, t});
+            {
+                const unsigned tl = (unsigned)(opaque(t) & 255);
+#pragma unroll
+                for (int m = 0; m < 16; m++)
+                    *((gd2)scalar_ptr_at(row, 256 * m) + tl) = d2v{v[BR16(m)].x, v[BR16(m)].y};
+            }
         }
         __syncthreads();
-        // ---- sweep 2: twiddle, radix R1 over k1 -> cc[m1 4096 + m2] at register m + m1 Q1 (real part); argmax
+        // ---------------- sweep 2: twiddle, radix R1 over k1; 2 n cc[j + i S] = Im; running argmax (maxAbsIndex, xcorr.go:39-50)
         double ma = 0.0, sa = 0.0, cc0 = 0.0;
         int ia = 0x7fffffff;
 #pragma clang loop unroll(disable)
         for (int ch = 0; ch < CH; ch++) {
-            const int j = t + 256 * ch;
+            const int j = opaque(t + 256 * ch) & (S - 1);
             double2 v[16];
 #pragma unroll
-            for (int i = 0; i < 16; i++)
-                v[i] = Y2[j + i * S];
-            twiddle_rows(v, j);
-            dft_small<R1>(v);
-            if (ch == 0)
-                cc0 = v[0].x;
+            for (int i = 0; i < 16; i++) {
+                const d2v z = __builtin_nontemporal_load(yat((long long)i * S) + (unsigned)j);
+                v[i] = make_double2(z.x, z.y);
+            }
+            {
+                double2 wb[Q1];
+#pragma unroll
+                for (int m = 0; m < Q1; m++)
+                    wb[m] = tw_base(m, (unsigned)j);
+                fence();
+#pragma unroll
+                for (int m = 0; m < Q1; m++)
+                    twiddle_powers<R1>(wb[m], [&](const int k1, const double2 w) __attribute__((always_inline)) {
+                        v[m + k1 * Q1] = cmul(v[m + k1 * Q1], w);
+                    });
+            }
+            sweep_dft<R1>(v);
+            double cs = 0.0;
+            int ci = 0;
+            const int jc = opaque(t + 256 * ch) & (S - 1);
             if (p.cc_out && !dead) {
                 double *const cc = p.cc_out + pair * (long long)n;
 #pragma unroll
                 for (int i = 0; i < 16; i++)
-                    cc[j + i * S] = v[i].x * ps.fac;
+                    cc[jc + i * S] = v[i % Q1 + brev<R1>(i / Q1) * Q1].y * fac;
             }
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const double aa = fabs(v[i].x);
-                const int idx = j + i * S;
-                if (aa > ma || (aa == ma && aa > 0.0 && idx < ia)) { ma = aa; sa = v[i].x; ia = idx; }
+            for (int i = 0; i < 16; i++) { // i = m + l1 Q1: lag index j + i S
+                const double c = v[i % Q1 + brev<R1>(i / Q1) * Q1].y;
+                if (i == 0)
+                    cc0 = ch == 0 ? c : cc0; // (lane 0 of chunk 0: cc[0], the value reported when nothing is above 0)
+                const bool g = fabs(c) > fabs(cs);
+                cs = g ? c : cs;
+                ci = g ? i : ci;
+            }
+            {   // merged into the lane's running maximum (chunks are not in index order: ties go to the lower index)
+                const int xi = jc + ci * S;
+                const double ca = fabs(cs);
+                const bool tk = (ca > ma) | ((ca == ma) & (ca > 0.0) & (xi < ia));
+                ma = tk ? ca : ma;
+                sa = tk ? cs : sa;
+                ia = tk ? xi : ia;
             }
         }
         {
+            constexpr int RM = 4 * NW;
             const double wa = wave_max(ma);
             if (lane == 0)
-                red[32 + wave] = wa;
+                red[RM + wave] = wa;
             if (t == 0)
-                red[40] = cc0;
+                red[RM + NW] = cc0;
             __syncthreads();
-            const double MA = fmax(fmax(red[32], red[33]), fmax(red[34], red[35]));
+            double MA = red[RM];
+#pragma unroll
+            for (int x = 1; x < NW; x++)
+                MA = fmax(MA, red[RM + x]);
             int ca = (ma == MA && MA > 0.0) ? ia : 0x7fffffff;
             ca = wave_min_i(ca);
             if (lane == 0)
                 redi[wave] = ca;
             __syncthreads();
-            const int IA = min(min(redi[0], redi[1]), min(redi[2], redi[3]));
+            int IA = redi[0];
+#pragma unroll
+            for (int x = 1; x < NW; x++)
+                IA = min(IA, redi[x]);
             const bool none = IA == 0x7fffffff;
             const bool owner = none ? (t == 0) : (ia == IA && ma == MA);
             if (owner) {
                 const int idx = none ? 0 : IA;
-                double mv = (none ? red[40] : sa) * ps.fac;
+                double mv = (none ? red[RM + NW] : sa) * fac;
                 int lag = idx > n / 2 ? idx - n : idx;
-                if (ps.nil) { mv = 0.0; lag = 0; }
-                if (ps.nan) { mv = __builtin_nan(""); lag = 0; }
+                if (ps.nil) { mv = 0.0; lag = 0; }               // xcorr.go:110-127
+                if (ps.nan) { mv = __builtin_nan(""); lag = 0; } // every cc is NaN: maxAbsIndex keeps index 0
                 p.mv[pair] = mv;
                 p.lag[pair] = lag;
                 if (p.nil_out)
@@ -398,12 +466,16 @@ __global__ __launch_bounds__(256, 2) void xcorr_two_sided_4step(const FusedParam
 }
 
 template <int LOGN>
-static hipError_t launch_two_4step(const FusedParams &p, int num_cus, hipStream_t stream)
+static hipError_t launch_two_long(const FusedParams &p, int num_cus, hipStream_t stream)
 {
-    const long long grid = std::min<long long>(p.npairs, (long long)num_cus * STOCKHAM_GLOBAL_WGS_PER_CU);
-    if (!p.gscratch || 2 * grid > p.gscratch_slices) // two n-element slices per workgroup
+    const long long grid = std::min<long long>(p.npairs, (long long)num_cus * LONG_WGS_PER_CU);
+    if (!p.gscratch || grid > p.gscratch_slices || !p.twl || !p.g2 || !p.g3a || !p.g3b) // one n-element slice per workgroup
         return hipErrorInvalidValue;
-    hipLaunchKernelGGL((xcorr_two_sided_4step<LOGN>), dim3((unsigned)grid), dim3(256), 0, stream, p);
+    const two::PairInv iv = two::pair_inv(p.Nx, p.N, 1 << LOGN);
+    if (p.Nx == (1 << LOGN) && p.N == (1 << LOGN))
+        hipLaunchKernelGGL((xcorr_two_sided_long<LOGN, false>), dim3((unsigned)grid), dim3(256), 0, stream, p, iv);
+    else
+        hipLaunchKernelGGL((xcorr_two_sided_long<LOGN, true>), dim3((unsigned)grid), dim3(256), 0, stream, p, iv);
     return hipGetLastError();
 }
 
@@ -433,8 +505,8 @@ hipError_t launch_two_sided(const FusedParams &p, int num_cus, hipStream_t strea
             hipLaunchKernelGGL(xcorr_two_sided_fold<true>, dim3((unsigned)grid), dim3(256), 0, stream, p, iv);
         return hipGetLastError();
     }
-    case 15: return launch_two_4step<15>(p, num_cus, stream);
-    case 16: return launch_two_4step<16>(p, num_cus, stream);
+    case 15: return launch_two_long<15>(p, num_cus, stream);
+    case 16: return launch_two_long<16>(p, num_cus, stream);
     default: return hipErrorInvalidValue;
     }
 }

@@ -1761,11 +1761,11 @@ def test_xcorr_batch_different_lengths_and_raised_n(eng, oracle):
         muse.xcorr_groups(gx, muse.DeviceGroup.from_rows(eng, Y[:3, :512]), 512, True)   # row counts differ
 
 
-@pytest.mark.parametrize("n", [512, 1024, 2048, 4096, 8192, 16384])
+@pytest.mark.parametrize("n", [512, 1024, 2048, 4096, 8192, 16384, 32768, 65536])
 @pytest.mark.parametrize("geom", ["short_long", "full_tiny", "two_full", "minus_one", "full_full"])
 def test_xcorr_batch_pad_geometries(eng, oracle, n, geom):
-    """n <= 16384 runs on the xCorrWithX transforms (x read backwards, the spectrum squared): every pad geometry, each
-    series padded on its own (xcorr.go:129-130)"""
+    """every batched length runs on the xCorrWithX transforms (x read backwards, the spectrum squared; n >= 32768: on the
+    long-series kernel's four-step transform): every pad geometry, each series padded on its own (xcorr.go:129-130)"""
     lens = {"short_long": (n // 6 + 17, 3 * n // 4 - 1), "full_tiny": (n, 10), "two_full": (2, n), "minus_one": (n - 1, n),
             "full_full": (n, n)}[geom]
     rng = np.random.default_rng(lens[0] * 7 + lens[1])
