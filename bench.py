@@ -34,7 +34,7 @@ def csrc_sha():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "go-muse_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".h")) and f != "muse_capi.hip":   # (the host side of the library launches kernels, it holds none)
+        if f.endswith((".hip", ".h")) and not f.startswith("capi_"):   # (the host side of the library launches kernels, it holds none)
             h.update(f.encode())
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]

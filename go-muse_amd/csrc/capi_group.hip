@@ -1,0 +1,326 @@
+// capi_group.hip -- the resident comparison Group (Group.Add, group.go:31-56): staging, uploads, reads
+// Part of the implementation of the C ABI declared in include/muse_hip.h (capi_internal.h: the handles and the helpers the
+// parts share).  Host-side orchestration only; there is no CPU compute fallback anywhere: without a gfx950 device every
+// compute entry point returns MUSE_ERR_NO_DEVICE.
+#include "capi_internal.h"
+
+using namespace muse;
+
+
+// ------------------------------------------------------------------- group
+// Every group allocation starts with GROUP_GUARD readable (zeroed) elements in front of row 0: the kernels for zero-padded
+// series (xcorr_small.hip) read up to n - N samples in front of a row without clamping and mask them afterwards.
+constexpr size_t GROUP_GUARD = 8192;
+static_assert(GROUP_GUARD >= (size_t)SMALL_MAX_N / 2, "xcorr_small.hip reads up to n - N < n / 2 samples in front of row 0");
+static int group_create(muse_ctx *ctx, int64_t capacity_rows, int32_t N, bool f32, muse_group **out);
+extern "C" int muse_group_create(muse_ctx *ctx, int64_t capacity_rows, int32_t N, muse_group **out)
+{
+    return group_create(ctx, capacity_rows, N, false, out);
+}
+extern "C" int muse_group_create_f32(muse_ctx *ctx, int64_t capacity_rows, int32_t N, muse_group **out)
+{
+    // (the float32-row loaders are built into the kernels automatic selection takes for FFT lengths 512 ... 16384)
+    if (N <= 256 || N > 16384)
+        return fail(MUSE_ERR_UNSUPPORTED, "float32-storage groups are built for series of length 257 .. 16384 (got %d)", N);
+    return group_create(ctx, capacity_rows, N, true, out);
+}
+static int group_create(muse_ctx *ctx, int64_t capacity_rows, int32_t N, bool f32, muse_group **out)
+{
+    if (!out)
+        return fail(MUSE_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    if (N < 1 || capacity_rows < 0)
+        return fail(MUSE_ERR_INVALID, "bad group shape (%lld x %d)", (long long)capacity_rows, N);
+    muse_group *g = new (std::nothrow) muse_group();
+    if (!g)
+        return fail(MUSE_ERR_NOMEM, "host allocation failed");
+    g->ctx = ctx;
+    g->N = N;
+    g->stride = N;
+    g->cap = capacity_rows;
+    g->f32 = f32;
+    if (hipEventCreateWithFlags(&g->uploaded, hipEventDisableTiming) != hipSuccess) {
+        delete g;
+        return fail(MUSE_ERR_HIP, "hipEventCreate failed");
+    }
+    if (capacity_rows > 0) {
+        void *mem = nullptr;
+        hipError_t e = hipMalloc(&mem, ((size_t)capacity_rows * (size_t)N + GROUP_GUARD) * g->elem());
+        if (e == hipSuccess)
+            e = hipMemset(mem, 0, GROUP_GUARD * g->elem());
+        if (e != hipSuccess) {
+            (void)hipFree(mem);
+            delete g;
+            return fail(MUSE_ERR_NOMEM, "hipMalloc of %lld x %d samples failed: %s", (long long)capacity_rows, N,
+                        hipGetErrorString(e));
+        }
+        mem = (char *)mem + GROUP_GUARD * g->elem();
+        (f32 ? (void *&)g->rows32 : (void *&)g->rows) = mem;
+    }
+    ctx->refs.fetch_add(1);
+    *out = g;
+    return MUSE_OK;
+}
+
+static int group_reserve(muse_group *g, int64_t rows)
+{
+    if (rows <= g->cap)
+        return MUSE_OK;
+    int64_t ncap = std::max<int64_t>(rows, g->cap * 2);
+    void *nr = nullptr;
+    hipError_t e = hipMalloc(&nr, ((size_t)ncap * (size_t)g->N + GROUP_GUARD) * g->elem());
+    if (e == hipSuccess)
+        e = hipMemset(nr, 0, GROUP_GUARD * g->elem());
+    if (e != hipSuccess) {
+        (void)hipFree(nr);
+        return fail(MUSE_ERR_NOMEM, "hipMalloc of %lld rows failed: %s", (long long)ncap, hipGetErrorString(e));
+    }
+    nr = (char *)nr + GROUP_GUARD * g->elem();
+    HIP_TRY(hipStreamSynchronize(g->ctx->copy_stream)); // uploads into the old allocation have landed
+    HIP_TRY(hipStreamSynchronize(g->ctx->stream));      // no kernel is still reading it
+    if (g->M > 0) {
+        HIP_TRY(hipMemcpyAsync(nr, g->base(), (size_t)g->M * (size_t)g->N * g->elem(), hipMemcpyDeviceToDevice,
+                               g->ctx->stream));
+        HIP_TRY(hipStreamSynchronize(g->ctx->stream));
+    }
+    if (g->base())
+        (void)hipFree((char *)g->base() - GROUP_GUARD * g->elem());
+    (g->f32 ? (void *&)g->rows32 : (void *&)g->rows) = nr;
+    g->cap = ncap;
+    return MUSE_OK;
+}
+
+// enqueue the staged rows' upload (asynchronous); the buffer is reusable after stage_done
+static int group_flush(muse_group *g)
+{
+    if (!g->staged)
+        return MUSE_OK;
+    const int64_t first = g->M - g->staged;
+    HIP_TRY(hipMemcpyAsync((char *)g->base() + (size_t)(first * g->stride) * g->elem(), g->stage[g->cur],
+                           (size_t)g->staged * (size_t)g->N * g->elem(), hipMemcpyHostToDevice, g->ctx->copy_stream));
+    HIP_TRY(hipEventRecord(g->stage_done[g->cur], g->ctx->copy_stream));
+    HIP_TRY(hipEventRecord(g->uploaded, g->ctx->copy_stream));
+    g->upload_pending = true;
+    g->staged = 0;
+    g->cur ^= 1;
+    HIP_TRY(hipEventSynchronize(g->stage_done[g->cur])); // the other buffer's last upload has landed
+    return MUSE_OK;
+}
+
+// staged rows enqueued for upload, and the compute stream ordered behind every upload enqueued so far: call before
+// anything on the compute stream reads the rows
+int group_ready(muse_group *g)
+{
+    int rc = group_flush(g);
+    if (rc)
+        return rc;
+    if (g->upload_pending) {
+        HIP_TRY(hipStreamWaitEvent(g->ctx->stream, g->uploaded, 0));
+        g->upload_pending = false;
+    }
+    return MUSE_OK;
+}
+
+extern "C" int muse_group_append(muse_group *g, const double *rows, int64_t count, int64_t row_stride)
+{
+    if (!g || (!rows && count > 0) || count < 0)
+        return fail(MUSE_ERR_INVALID, "bad append arguments");
+    if (count == 0)
+        return MUSE_OK;
+    if (row_stride < g->N) // group.go:45-51: one length per group
+        return fail(MUSE_ERR_LENGTH, "Timeseries has length %lld, but current group has length %d",
+                    (long long)row_stride, g->N);
+    int rc = use_device(g->ctx);
+    if (rc)
+        return rc;
+    const size_t row_bytes = (size_t)g->N * sizeof(double);
+    constexpr size_t STAGE_BYTES = 32u << 20;
+    // small appends are staged from the SECOND one on: a group that is uploaded in one call (Muse.Run builds one
+    // per call) never needs the staging pair
+    bool small = (size_t)count * row_bytes < STAGE_BYTES / 4 && row_bytes <= STAGE_BYTES;
+    if (small && !g->stage[0] && g->small_appends++ == 0)
+        small = false;
+    if (g->f32) // float32 storage: every append is narrowed on the host into the pinned staging pair (half the PCIe bytes too)
+        small = true;
+    if (small && !g->stage[0]) { // borrow the staging pair from the context's pool
+        g->stage_rows = std::max<int64_t>(1, (int64_t)(STAGE_BYTES / ((size_t)g->N * g->elem())));
+        for (int i = 0; i < 2; i++) {
+            double *buf = nullptr;
+            {
+                std::lock_guard<std::mutex> lock(g->ctx->stage_mu);
+                if (!g->ctx->stage_pool.empty()) {
+                    buf = g->ctx->stage_pool.back();
+                    g->ctx->stage_pool.pop_back();
+                }
+            }
+            if (!buf)
+                HIP_TRY(hipHostMalloc((void **)&buf, STAGE_BYTES, hipHostMallocDefault));
+            g->stage[i] = buf;
+            HIP_TRY(hipEventCreateWithFlags(&g->stage_done[i], hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(g->stage_done[i], g->ctx->copy_stream));
+        }
+    }
+    if (!small) { // a slab: upload it directly (synchronously: the caller's memory is not retained)
+        rc = group_flush(g);
+        if (rc)
+            return rc;
+        rc = group_reserve(g, g->M + count);
+        if (rc)
+            return rc;
+        // (on the copy stream: the caller's memory is not retained, so the call waits for the copy -- but not for a score
+        // pass that may be running on the compute stream over the rows uploaded earlier)
+        HIP_TRY(hipMemcpy2DAsync(g->rows + g->M * g->stride, (size_t)g->stride * sizeof(double), rows,
+                                 (size_t)row_stride * sizeof(double), row_bytes, (size_t)count, hipMemcpyHostToDevice,
+                                 g->ctx->copy_stream));
+        HIP_TRY(hipStreamSynchronize(g->ctx->copy_stream));
+        g->M += count;
+        return MUSE_OK;
+    }
+    for (int64_t r = 0; r < count; r++) {
+        if (g->staged == g->stage_rows) {
+            rc = group_flush(g);
+            if (rc)
+                return rc;
+        }
+        if (g->M + 1 > g->cap) {
+            // growing re-allocates and copies on the stream; staged rows are uploaded first
+            rc = group_flush(g);
+            if (!rc)
+                rc = group_reserve(g, g->M + 1);
+            if (rc)
+                return rc;
+        }
+        if (g->f32) {
+            float *dst = (float *)g->stage[g->cur] + g->staged * g->N;
+            const double *src = rows + r * row_stride;
+            for (int32_t j = 0; j < g->N; j++)
+                dst[j] = (float)src[j];
+        } else {
+            memcpy(g->stage[g->cur] + g->staged * g->N, rows + r * row_stride, row_bytes);
+        }
+        g->staged++;
+        g->M++;
+    }
+    return MUSE_OK;
+}
+
+extern "C" int muse_group_upload(muse_ctx *ctx, const double *rows, int64_t M, int32_t N, int64_t row_stride,
+                                 muse_group **out)
+{
+    int rc = muse_group_create(ctx, M, N, out);
+    if (rc)
+        return rc;
+    rc = muse_group_append(*out, rows, M, row_stride);
+    if (rc) {
+        muse_group_free(*out);
+        *out = nullptr;
+    }
+    return rc;
+}
+
+extern "C" int muse_group_fill_synthetic(muse_group *g, int64_t first, int64_t count, int64_t global_first,
+                                         uint64_t seed, uint32_t flags, double *ref_out)
+{
+    if (!g || first < 0 || count < 0 || first > g->M)
+        return fail(MUSE_ERR_INVALID, "bad synthetic fill range");
+    int rc = use_device(g->ctx);
+    if (rc)
+        return rc;
+    rc = group_ready(g);
+    if (rc)
+        return rc;
+    rc = group_reserve(g, first + count);
+    if (rc)
+        return rc;
+    if (g->f32)
+        HIP_TRY(launch_synth_f32(g->rows32, g->stride, first, count, global_first, g->N, seed, flags, g->ctx->stream));
+    else
+        HIP_TRY(launch_synth(g->rows, g->stride, first, count, global_first, g->N, seed, flags, g->ctx->stream));
+    g->M = std::max(g->M, first + count);
+    if (ref_out) {
+        double *d = nullptr;
+        HIP_TRY(hipMalloc(&d, (size_t)g->N * sizeof(double)));
+        hipError_t e = launch_synth_ref(d, g->N, seed, g->ctx->stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(ref_out, d, (size_t)g->N * sizeof(double), hipMemcpyDeviceToHost, g->ctx->stream);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(g->ctx->stream);
+        (void)hipFree(d);
+        HIP_TRY(e);
+    }
+    HIP_TRY(hipStreamSynchronize(g->ctx->stream));
+    return MUSE_OK;
+}
+
+extern "C" int muse_group_shape(muse_group *g, int64_t *M, int32_t *N)
+{
+    if (!g)
+        return fail(MUSE_ERR_INVALID, "NULL group");
+    if (M)
+        *M = g->M;
+    if (N)
+        *N = g->N;
+    return MUSE_OK;
+}
+
+extern "C" int muse_group_read(muse_group *g, int64_t first, int64_t count, double *out)
+{
+    if (!g || !out || first < 0 || count < 0 || first + count > g->M)
+        return fail(MUSE_ERR_INVALID, "bad read range");
+    if (count == 0)
+        return MUSE_OK;
+    int rc = use_device(g->ctx);
+    if (rc)
+        return rc;
+    rc = group_ready(g);
+    if (rc)
+        return rc;
+    HIP_TRY(hipStreamSynchronize(g->ctx->copy_stream));
+    HIP_TRY(hipStreamSynchronize(g->ctx->stream));
+    if (g->f32) { // widened exactly: the checker sees the values the kernels see
+        std::vector<float> tmp((size_t)count * (size_t)g->N);
+        HIP_TRY(hipMemcpy2D(tmp.data(), (size_t)g->N * sizeof(float), g->rows32 + first * g->stride,
+                            (size_t)g->stride * sizeof(float), (size_t)g->N * sizeof(float), (size_t)count,
+                            hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < tmp.size(); i++)
+            out[i] = (double)tmp[i];
+        return MUSE_OK;
+    }
+    HIP_TRY(hipMemcpy2D(out, (size_t)g->N * sizeof(double), g->rows + first * g->stride,
+                        (size_t)g->stride * sizeof(double), (size_t)g->N * sizeof(double), (size_t)count,
+                        hipMemcpyDeviceToHost));
+    return MUSE_OK;
+}
+
+void group_release(muse_group *g)
+{
+    if (!g || g->refs.fetch_sub(1) != 1)
+        return;
+    (void)hipSetDevice(g->ctx->device);
+    (void)hipStreamSynchronize(g->ctx->copy_stream);
+    (void)hipStreamSynchronize(g->ctx->stream);
+    if (g->uploaded)
+        (void)hipEventDestroy(g->uploaded);
+    if (g->base())
+        (void)hipFree((char *)g->base() - GROUP_GUARD * g->elem());
+    for (int i = 0; i < 2; i++) {
+        if (g->stage[i]) { // back to the context's pool (the stream is idle: no upload reads it any more)
+            std::lock_guard<std::mutex> lock(g->ctx->stage_mu);
+            g->ctx->stage_pool.push_back(g->stage[i]);
+        }
+        if (g->stage_done[i])
+            (void)hipEventDestroy(g->stage_done[i]);
+    }
+    muse_ctx *ctx = g->ctx;
+    delete g;
+    ctx_release(ctx);
+}
+
+extern "C" int muse_group_free(muse_group *g)
+{
+    group_release(g);
+    return MUSE_OK;
+}

@@ -1,0 +1,411 @@
+// capi_run.hip -- Batch.Run / Results (muse_batch.go:99-130, results.go:46-87): group max, filter, top-N, the merges of sharded Runs
+// Part of the implementation of the C ABI declared in include/muse_hip.h (capi_internal.h: the handles and the helpers the
+// parts share).  Host-side orchestration only; there is no CPU compute fallback anywhere: without a gfx950 device every
+// compute entry point returns MUSE_ERR_NO_DEVICE.
+#include "capi_internal.h"
+
+using namespace muse;
+
+
+// ---- Results: Go container/heap on |score| (scores.go:25-27, results.go)
+namespace {
+struct GoHeap {
+    std::vector<muse_record> h;
+    static bool less(const muse_record &a, const muse_record &b) { return std::fabs(a.score) < std::fabs(b.score); }
+    void up(size_t j)
+    {
+        for (;;) {
+            if (j == 0)
+                break;
+            size_t i = (j - 1) / 2;
+            if (!less(h[j], h[i]))
+                break;
+            std::swap(h[i], h[j]);
+            j = i;
+        }
+    }
+    void down(size_t i0, size_t n)
+    {
+        size_t i = i0;
+        for (;;) {
+            size_t j1 = 2 * i + 1;
+            if (j1 >= n)
+                break;
+            size_t j = j1, j2 = j1 + 1;
+            if (j2 < n && less(h[j2], h[j1]))
+                j = j2;
+            if (!less(h[j], h[i]))
+                break;
+            std::swap(h[i], h[j]);
+            i = j;
+        }
+    }
+    void push(const muse_record &r)
+    {
+        h.push_back(r);
+        up(h.size() - 1);
+    }
+    muse_record pop()
+    {
+        size_t n = h.size() - 1;
+        std::swap(h[0], h[n]);
+        down(0, n);
+        muse_record r = h.back();
+        h.pop_back();
+        return r;
+    }
+};
+
+// Results.Update over `cands` (already filtered by passed()) in group order,
+// then Results.Fetch: descending |score|.
+std::vector<muse_record> heap_select(std::vector<muse_record> cands, int64_t top_n)
+{
+    std::stable_sort(cands.begin(), cands.end(), [](const muse_record &a, const muse_record &b) {
+        if (a.group != b.group)
+            return a.group < b.group;
+        return a.series < b.series;
+    });
+    GoHeap hp;
+    if (top_n > 0) {
+        for (const auto &r : cands) {
+            if ((int64_t)hp.h.size() == top_n) { // results.go:62-66
+                if (std::fabs(r.score) > std::fabs(hp.h[0].score)) {
+                    hp.pop();
+                    hp.push(r);
+                }
+            } else {
+                hp.push(r);
+            }
+        }
+    }
+    std::vector<muse_record> out(hp.h.size());
+    for (size_t i = out.size(); i-- > 0;) // results.go:81-85
+        out[i] = hp.pop();
+    return out;
+}
+} // namespace
+
+int ensure_select_ws(muse_batch *b, int64_t M, int64_t G, bool with_gid, int K, bool on_device)
+{
+    if (with_gid && M > b->gid_cap) {
+        (void)hipFree(b->gid_dev);
+        b->gid_dev = nullptr;
+        b->gid_cap = 0;
+        b->gid_valid = false;
+        HIP_TRY(hipMalloc(&b->gid_dev, (size_t)M * sizeof(int)));
+        b->gid_cap = M;
+    }
+    if (G > b->grp_cap) {
+        (void)hipFree(b->gw.key);
+        (void)hipFree(b->gw.first);
+        (void)hipFree(b->gw.win);
+        (void)hipFree(b->rec);
+        (void)hipFree(b->selkey);
+        b->gw = GroupWork{nullptr, nullptr, nullptr};
+        b->rec = nullptr;
+        b->selkey = nullptr;
+        b->grp_cap = 0;
+        HIP_TRY(hipMalloc(&b->gw.key, (size_t)G * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc(&b->gw.first, (size_t)G * sizeof(long long)));
+        HIP_TRY(hipMalloc(&b->gw.win, (size_t)G * sizeof(long long)));
+        HIP_TRY(hipMalloc(&b->rec, (size_t)G * sizeof(muse_record)));
+        HIP_TRY(hipMalloc(&b->selkey, (size_t)G * sizeof(unsigned long long)));
+        b->grp_cap = G;
+    }
+    const int64_t nb = (G + TOPN_CHUNK - 1) / TOPN_CHUNK;
+    if (nb > b->cnt_cap) {
+        (void)hipFree(b->cnt);
+        b->cnt = nullptr;
+        b->cnt_cap = 0;
+        HIP_TRY(hipMalloc(&b->cnt, (size_t)nb * sizeof(int)));
+        b->cnt_cap = nb;
+    }
+    if (nb * K > b->cand_cap) {
+        (void)hipFree(b->cand);
+        b->cand = nullptr;
+        b->cand_cap = 0;
+        HIP_TRY(hipMalloc(&b->cand, (size_t)(nb * K) * sizeof(muse_record)));
+        b->cand_cap = nb * K;
+    }
+    if (on_device && nb > b->cnt_host_cap) { // (small selections copy the group records instead: no pinned memory)
+        if (b->cnt_host)
+            (void)hipHostFree(b->cnt_host); // (hipHostFree(NULL) leaves a sticky error behind)
+        b->cnt_host = nullptr;
+        b->cnt_host_cap = 0;
+        HIP_TRY(hipHostMalloc((void **)&b->cnt_host, (size_t)nb * sizeof(int), hipHostMallocDefault));
+        b->cnt_host_cap = nb;
+    }
+    if (on_device && nb * K > b->cand_host_cap) {
+        if (b->cand_host)
+            (void)hipHostFree(b->cand_host);
+        b->cand_host = nullptr;
+        b->cand_host_cap = 0;
+        HIP_TRY(hipHostMalloc((void **)&b->cand_host, (size_t)(nb * K) * sizeof(muse_record), hipHostMallocDefault));
+        b->cand_host_cap = nb * K;
+    }
+    return MUSE_OK;
+}
+
+// the label-group map of a Run on the device (re-sent only when it changed)
+int upload_group_ids(muse_batch *b, const int32_t *group_id, int64_t M)
+{
+    if (!group_id)
+        return MUSE_OK;
+    const bool same = b->gid_valid && (int64_t)b->gid_host.size() == M &&
+                      memcmp(b->gid_host.data(), group_id, (size_t)M * sizeof(int32_t)) == 0;
+    if (!same) {
+        b->gid_host.assign(group_id, group_id + M);
+        HIP_TRY(hipMemcpyAsync(b->gid_dev, b->gid_host.data(), (size_t)M * sizeof(int), hipMemcpyHostToDevice,
+                               b->ctx->stream));
+        b->gid_valid = true;
+    }
+    return MUSE_OK;
+}
+
+int run_select(muse_batch *b, const int32_t *group_id, int32_t G_in, int64_t series_offset, int32_t max_lag,
+                      int32_t top_n, double threshold, int32_t sign_filter, int32_t abs_scores,
+                      std::vector<muse_record> &out, bool already_scored, bool prescreened)
+{
+    out.clear();
+    muse_ctx *ctx = b->ctx;
+    const int64_t M = b->g->M;
+    if (sign_filter < -1 || sign_filter > 1)
+        return fail(MUSE_ERR_INVALID, "sign_filter must be -1, 0 or 1");
+    if (group_id && G_in < 0)
+        return fail(MUSE_ERR_INVALID, "negative group count");
+    // Batch.Run re-scores on every call (muse_batch.go:116-122)
+    // (prescreened: muse_batch_run_many has run the screening pass for several batches at once and finished this one)
+    const muse_batch::RunKey rkey = run_key(b, group_id, group_id ? (int64_t)G_in : 0, max_lag, top_n, threshold, sign_filter, abs_scores);
+    const int32_t path = prescreened ? MUSE_RUN_PATH_SCREENED : screen_path(b, rkey, already_scored);
+    const bool screened = path == MUSE_RUN_PATH_SCREENED;
+    b->last_path = path;
+    int rc = (already_scored || screened) ? MUSE_OK : muse_batch_score(b);
+    if (rc)
+        return rc;
+    const int64_t G = group_id ? (int64_t)G_in : M;
+    if (M == 0 || G == 0 || top_n <= 0)
+        return MUSE_OK;
+    if (G > 0x7fffffffLL)
+        return fail(MUSE_ERR_UNSUPPORTED, "more than 2^31-1 groups on one device");
+    const bool on_device = top_n <= TOPN_DEVICE_MAX && G > TOPN_CHUNK / 4;
+    const int K = on_device ? top_n : 1;
+    rc = ensure_select_ws(b, M, G, group_id != nullptr, K, on_device);
+    if (rc)
+        return rc;
+    rc = upload_group_ids(b, group_id, M);
+    if (rc)
+        return rc;
+    b->last_screened = screened;
+    if (screened && !prescreened) { // fp32 screening pass, then fp64 for the rows that can reach the top-N (needs the selection workspace)
+        rc = score_screened(b, max_lag, top_n, threshold, sign_filter, abs_scores, group_id ? b->gid_dev : nullptr, G);
+        if (rc)
+            return rc;
+    }
+    SelectParams sp{};
+    sp.mv = b->mv;
+    sp.lag = b->lag;
+    sp.M = M;
+    sp.group_id = group_id ? b->gid_dev : nullptr;
+    sp.G = (int)G;
+    sp.abs_scores = abs_scores ? 1 : 0;
+    sp.max_lag = max_lag;
+    sp.threshold = threshold;
+    sp.sign_filter = sign_filter;
+    sp.series_offset = series_offset;
+    sp.include = screened ? b->include : nullptr;
+    HIP_TRY(launch_group_reduce(sp, b->gw, b->rec, b->selkey, ctx->stream));
+    std::vector<muse_record> cands;
+    if (on_device) {
+        const int64_t nb = (G + TOPN_CHUNK - 1) / TOPN_CHUNK;
+        HIP_TRY(launch_topn(b->rec, b->selkey, (int)G, K, b->cand, b->cnt, ctx->stream));
+        const int *cnt = b->cnt_host;
+        const muse_record *cand = b->cand_host;
+        HIP_TRY(hipMemcpyAsync(b->cnt_host, b->cnt, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(b->cand_host, b->cand, (size_t)(nb * K) * sizeof(muse_record), hipMemcpyDeviceToHost,
+                               ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        for (int64_t blk = 0; blk < nb; blk++)
+            for (int r = 0; r < cnt[(size_t)blk]; r++)
+                cands.push_back(cand[(size_t)(blk * K + r)]);
+        // a screened Run that had to re-evaluate a large part of the rows (few rows certainly pass the filters, or the
+        // scores crowd around the cut) costs more than the plain fp64 pass: not again for this (immutable) set of rows
+        if (screened && (int64_t)*b->refine_host * 4 > (M + 1) / 2)
+            b->costly_key = rkey;
+        if (screened && screen_guard_tripped(b)) // an estimate left its bound: this Run is redone entirely in fp64
+            return run_select(b, group_id, G_in, series_offset, max_lag, top_n, threshold, sign_filter, abs_scores, out, false);
+    } else {
+        std::vector<muse_record> rec((size_t)G);
+        std::vector<unsigned long long> key((size_t)G);
+        HIP_TRY(hipMemcpyAsync(rec.data(), b->rec, (size_t)G * sizeof(muse_record), hipMemcpyDeviceToHost,
+                               ctx->stream));
+        HIP_TRY(hipMemcpyAsync(key.data(), b->selkey, (size_t)G * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                               ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        for (int64_t g = 0; g < G; g++)
+            if (key[(size_t)g] != 0ull)
+                cands.push_back(rec[(size_t)g]);
+        if (screened && (int64_t)*b->refine_host * 4 > (M + 1) / 2)
+            b->costly_key = rkey;
+        if (screened && screen_guard_tripped(b))
+            return run_select(b, group_id, G_in, series_offset, max_lag, top_n, threshold, sign_filter, abs_scores, out, false);
+    }
+    if (!group_id) // ungrouped: global order of the groups is the global series index
+        for (auto &r : cands)
+            r.group = (int32_t)std::min<int64_t>(r.series, 0x7fffffffLL);
+    out = heap_select(std::move(cands), top_n);
+    return MUSE_OK;
+}
+
+void emit(const std::vector<muse_record> &sel, int64_t *out_series, int32_t *out_lag, double *out_score,
+                 int32_t *out_count, double *out_mean_abs)
+{
+    double sum = 0.0;
+    for (size_t i = sel.size(); i-- > 0;) { // results.go:81-85 sums in pop order (ascending |score|)
+        if (out_series)
+            out_series[i] = sel[i].series;
+        if (out_lag)
+            out_lag[i] = sel[i].lag;
+        if (out_score)
+            out_score[i] = sel[i].score;
+        sum += std::fabs(sel[i].score);
+    }
+    if (out_count)
+        *out_count = (int32_t)sel.size();
+    if (out_mean_abs) // results.go:86 (0/0 = NaN when empty)
+        *out_mean_abs = sel.empty() ? std::numeric_limits<double>::quiet_NaN() : sum / (double)sel.size();
+}
+
+extern "C" int muse_batch_run(muse_batch *b, const int32_t *group_id, int32_t G, int32_t max_lag, int32_t top_n,
+                              double threshold, int32_t sign_filter, int32_t abs_scores, int64_t *out_series,
+                              int32_t *out_lag, double *out_score, int32_t *out_count, double *out_mean_abs)
+{
+    if (!b)
+        return fail(MUSE_ERR_INVALID, "NULL batch");
+    std::vector<muse_record> sel;
+    int rc = run_select(b, group_id, G, 0, max_lag, top_n, threshold, sign_filter, abs_scores, sel);
+    if (rc)
+        return rc;
+    emit(sel, out_series, out_lag, out_score, out_count, out_mean_abs);
+    return MUSE_OK;
+}
+
+extern "C" int muse_batch_run_shard(muse_batch *b, const int32_t *group_id, int32_t G, int64_t series_offset,
+                                    int32_t max_lag, int32_t top_n, double threshold, int32_t sign_filter,
+                                    int32_t abs_scores, muse_record *out_records, int32_t *out_count)
+{
+    if (!b || !out_count || (top_n > 0 && !out_records))
+        return fail(MUSE_ERR_INVALID, "NULL argument");
+    std::vector<muse_record> sel;
+    int rc = run_select(b, group_id, G, series_offset, max_lag, top_n, threshold, sign_filter, abs_scores, sel);
+    if (rc)
+        return rc;
+    for (size_t i = 0; i < sel.size(); i++)
+        out_records[i] = sel[i];
+    *out_count = (int32_t)sel.size();
+    return MUSE_OK;
+}
+
+// Sharded Run whose label groups may straddle shards ("... or the per-group partial maxima are merged before
+// top-N"): this shard's winner per label group, unfiltered, plus the group's state on this shard (SelectParams::partial)
+extern "C" int muse_batch_run_groups(muse_batch *b, const int32_t *group_id, int32_t G, int64_t series_offset,
+                                     int32_t abs_scores, muse_record *out_records, uint8_t *out_state)
+{
+    if (!b || !group_id || G < 0 || (G > 0 && (!out_records || !out_state)))
+        return fail(MUSE_ERR_INVALID, "bad arguments (label groups are required: ungrouped Runs shard with muse_batch_run_shard)");
+    muse_ctx *ctx = b->ctx;
+    b->last_path = MUSE_RUN_PATH_FP64;
+    b->last_screened = false;
+    int rc = muse_batch_score(b);
+    if (rc)
+        return rc;
+    const int64_t M = b->g->M;
+    for (int32_t g = 0; g < G; g++) {
+        out_records[g] = muse_record{-1, 0.0, 0, g};
+        out_state[g] = 0;
+    }
+    if (M == 0 || G == 0)
+        return MUSE_OK;
+    rc = ensure_select_ws(b, M, G, true, 1, false);
+    if (rc)
+        return rc;
+    rc = upload_group_ids(b, group_id, M);
+    if (rc)
+        return rc;
+    SelectParams sp{};
+    sp.mv = b->mv;
+    sp.lag = b->lag;
+    sp.M = M;
+    sp.group_id = b->gid_dev;
+    sp.G = G;
+    sp.abs_scores = abs_scores ? 1 : 0;
+    sp.series_offset = series_offset;
+    sp.partial = 1;
+    HIP_TRY(launch_group_reduce(sp, b->gw, b->rec, b->selkey, ctx->stream));
+    std::vector<unsigned long long> st((size_t)G);
+    HIP_TRY(hipMemcpyAsync(out_records, b->rec, (size_t)G * sizeof(muse_record), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(st.data(), b->selkey, (size_t)G * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int32_t g = 0; g < G; g++)
+        out_state[g] = (uint8_t)st[(size_t)g];
+    return MUSE_OK;
+}
+
+// results.go:46-52 on the host (the merge of shards filters AFTER the group maxima are final)
+static bool passed_host(double s, int32_t lag, int32_t max_lag, double threshold, int32_t sign_filter)
+{
+    return std::fabs((double)lag) <= (double)max_lag && std::fabs(s) >= threshold &&
+           (sign_filter == 0 || (s > 0 && sign_filter == 1) || (s < 0 && sign_filter == -1));
+}
+
+extern "C" int muse_merge_group_records(const muse_record *records, const uint8_t *state, int32_t n_shards, int32_t G,
+                                        int32_t max_lag, int32_t top_n, double threshold, int32_t sign_filter,
+                                        int64_t *out_series, int32_t *out_lag, double *out_score, int32_t *out_count,
+                                        double *out_mean_abs)
+{
+    if (n_shards < 0 || G < 0 || ((int64_t)n_shards * G > 0 && (!records || !state)))
+        return fail(MUSE_ERR_INVALID, "bad shard records");
+    if (sign_filter < -1 || sign_filter > 1)
+        return fail(MUSE_ERR_INVALID, "sign_filter must be -1, 0 or 1");
+    std::vector<muse_record> cands;
+    for (int32_t g = 0; g < G; g++) {
+        // shards are listed in ascending row order: the first one with a member holds the group's first member
+        bool seen = false, nan_first = false, have = false;
+        muse_record best{};
+        for (int32_t s = 0; s < n_shards; s++) {
+            const size_t k = (size_t)s * (size_t)G + (size_t)g;
+            if (state[k] == 0)
+                continue;
+            if (!seen) {
+                seen = true;
+                nan_first = state[k] == 2;
+            }
+            const muse_record &r = records[k];
+            if (r.series < 0)
+                continue;
+            // muse_batch.go:87 / muse.go:86: a later series replaces the maximum only if strictly greater (by |score|)
+            if (!have || std::fabs(r.score) > std::fabs(best.score)) {
+                best = r;
+                have = true;
+            }
+        }
+        if (!seen || nan_first || !have) // empty group, or its first member's score is NaN: never passes Results.passed
+            continue;
+        best.group = g;
+        if (passed_host(best.score, best.lag, max_lag, threshold, sign_filter))
+            cands.push_back(best);
+    }
+    std::vector<muse_record> sel = heap_select(std::move(cands), top_n);
+    emit(sel, out_series, out_lag, out_score, out_count, out_mean_abs);
+    return MUSE_OK;
+}
+
+extern "C" int muse_merge_records(const muse_record *records, int64_t count, int32_t top_n, int64_t *out_series,
+                                  int32_t *out_lag, double *out_score, int32_t *out_count, double *out_mean_abs)
+{
+    if (count < 0 || (count > 0 && !records))
+        return fail(MUSE_ERR_INVALID, "bad records");
+    std::vector<muse_record> c(records, records + count);
+    std::vector<muse_record> sel = heap_select(std::move(c), top_n);
+    emit(sel, out_series, out_lag, out_score, out_count, out_mean_abs);
+    return MUSE_OK;
+}

@@ -1,0 +1,286 @@
+// capi_xcorr.hip -- single-pair entry points (xcorr_test.go-style access) and the batched two-sided xCorr (xcorr.go:102-153)
+// Part of the implementation of the C ABI declared in include/muse_hip.h (capi_internal.h: the handles and the helpers the
+// parts share).  Host-side orchestration only; there is no CPU compute fallback anywhere: without a gfx950 device every
+// compute entry point returns MUSE_ERR_NO_DEVICE.
+#include "capi_internal.h"
+
+using namespace muse;
+
+
+// ------------------------------------------------- single-pair entry points
+static bool is_pow2(int64_t n) { return n > 0 && (n & (n - 1)) == 0; }
+
+// shared tail: x (len lenx) vs y (len leny) at FFT length n
+static int single_pair(muse_ctx *ctx, const double *x, int lenx, const double *y, int leny, int n, int normalize_x,
+                       int normalize_y, double x_scale, double cc_scale, double *cc, int32_t *lag, double *mv,
+                       int32_t *is_nil)
+{
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    if (!x || !y || lenx < 1 || leny < 1 || n < lenx || n < leny || !lag || !mv)
+        return fail(MUSE_ERR_INVALID, "bad single-pair arguments");
+    if ((normalize_x && lenx < 2) || (normalize_y && leny < 2))
+        return fail(MUSE_ERR_INVALID, "series length 1 has no sample standard deviation");
+    if (n > GENERIC_MAX_N || (!is_pow2(n) && n > 8192))
+        return fail(MUSE_ERR_UNSUPPORTED, "FFT length %d is not built (powers of two up to %d, any n up to 8192)", n,
+                    GENERIC_MAX_N);
+    double *dx = nullptr, *dy = nullptr, *dcc = nullptr, *dmv = nullptr;
+    int *dlag = nullptr, *dstat = nullptr;
+    double2 *dX = nullptr, *dxc = nullptr, *dscr = nullptr;
+    int nil = 0, lg = 0;
+    double val = 0.0;
+    hipError_t e = hipSuccess;
+    auto cleanup = [&]() {
+        (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dcc); (void)hipFree(dmv);
+        (void)hipFree(dlag); (void)hipFree(dstat); (void)hipFree(dX); (void)hipFree(dxc); (void)hipFree(dscr);
+    };
+#define SP_TRY(expr)                                                                                        \
+    do {                                                                                                    \
+        e = (expr);                                                                                         \
+        if (e != hipSuccess) {                                                                              \
+            cleanup();                                                                                      \
+            return fail(MUSE_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e));                        \
+        }                                                                                                   \
+    } while (0)
+    SP_TRY(hipMalloc(&dy, (size_t)leny * sizeof(double)));
+    SP_TRY(hipMalloc(&dcc, (size_t)n * sizeof(double)));
+    SP_TRY(hipMalloc(&dmv, sizeof(double)));
+    SP_TRY(hipMalloc(&dlag, sizeof(int)));
+    SP_TRY(hipMalloc(&dstat, sizeof(int)));
+    SP_TRY(hipMemcpyAsync(dy, y, (size_t)leny * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if (is_pow2(n) && n >= 2) {
+        // FFT path: the same device code the batch uses (generic kernel)
+        SP_TRY(hipMalloc(&dX, (size_t)(n / 2 + 1) * sizeof(double2)));
+        SP_TRY(hipMalloc(&dxc, (size_t)n * sizeof(double2)));
+        int zero = 0;
+        rc = build_spectrum(ctx, x, lenx, n, normalize_x, x_scale, cc_scale, dX, dxc, nullptr, nullptr, &zero);
+        if (rc) {
+            cleanup();
+            return rc;
+        }
+        FusedParams p{};
+        p.rows = dy;
+        p.M = 1;
+        p.stride = leny;
+        p.npairs = 1;
+        p.N = leny;
+        p.n = n;
+        p.logn = ilog2(n);
+        p.normalize_y = normalize_y;
+        p.xc = dxc;
+        p.tw1 = ctx->tw1;
+        p.tw2 = ctx->tw2;
+        p.twm = ctx->twm;
+        p.mv = dmv;
+        p.lag = dlag;
+        p.cc_out = dcc;
+        p.nil_out = dstat;
+        if (n > GENERIC_LDS_MAX_N) {
+            SP_TRY(hipMalloc(&dscr, (size_t)n * sizeof(double2)));
+            p.gscratch = dscr;
+            p.gscratch_slices = 1;
+        }
+        SP_TRY(launch_fused(p, KERNEL_GENERIC, ctx->num_cus, ctx->stream));
+        SP_TRY(hipMemcpyAsync(&lg, dlag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        SP_TRY(hipMemcpyAsync(&val, dmv, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        SP_TRY(hipMemcpyAsync(&nil, dstat, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        SP_TRY(hipStreamSynchronize(ctx->stream));
+        nil = (nil || zero) ? 1 : 0; // sigma(y) == 0 or sigma(x) == 0 -> (nil, 0, 0)
+    } else {
+        SP_TRY(hipMalloc(&dx, (size_t)lenx * sizeof(double)));
+        SP_TRY(hipMemcpyAsync(dx, x, (size_t)lenx * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        SP_TRY(launch_direct(dx, lenx, dy, leny, n, normalize_x, normalize_y, x_scale, cc_scale * (double)n, dcc,
+                             dlag, dmv, dstat, ctx->stream));
+        SP_TRY(hipMemcpyAsync(&lg, dlag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        SP_TRY(hipMemcpyAsync(&val, dmv, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        SP_TRY(hipMemcpyAsync(&nil, dstat, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        SP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    if (cc && !nil)
+        SP_TRY(hipMemcpy(cc, dcc, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+#undef SP_TRY
+    cleanup();
+    *lag = nil ? 0 : lg;
+    *mv = nil ? 0.0 : val;
+    if (is_nil)
+        *is_nil = nil;
+    return MUSE_OK;
+}
+
+extern "C" int muse_xcorr_with_x(muse_ctx *ctx, const double *ref, const double *y, int32_t N, int32_t n, double *cc,
+                                 int32_t *lag, double *mv, int32_t *is_nil)
+{
+    if (N < 2)
+        return fail(MUSE_ERR_INVALID, "N must be >= 2");
+    // reference side: zNormalize(ref)/(N-1) (xcorr_test.go:259-266 == muse_batch.go:38-47);
+    // sigma(ref) == 0 is the caller's "Invalid input query" error.
+    int32_t nil = 0;
+    // probe sigma(ref) through the same path: build with normalize and check flag
+    int rc = single_pair(ctx, ref, N, y, N, n, 1, 1, 1.0 / (double)(N - 1), 1.0 / (double)n, cc, lag, mv, &nil);
+    if (rc)
+        return rc;
+    if (is_nil)
+        *is_nil = nil;
+    return MUSE_OK;
+}
+
+extern "C" int muse_xcorr(muse_ctx *ctx, const double *x, int32_t lenx, const double *y, int32_t leny, int32_t n,
+                          int32_t normalize, double *cc, int32_t *lag, double *mv, int32_t *is_nil)
+{
+    const int32_t minn = std::max(lenx, leny); // xcorr.go:104-106
+    if (n < minn)
+        n = minn;
+    // xcorr.go:139-143: 1/(n(n-1)) when normalized, else 1/n
+    const double cc_scale = normalize ? 1.0 / ((double)n * (double)(n - 1)) : 1.0 / (double)n;
+    return single_pair(ctx, x, lenx, y, leny, n, normalize, normalize, 1.0, cc_scale, cc, lag, mv, is_nil);
+}
+
+// ---- batched two-sided xCorr (xcorr.go:102-153)
+extern "C" int muse_xcorr_groups(muse_group *gx, muse_group *gy, int32_t n, int32_t normalize, int32_t *lag, double *mv,
+                                 int32_t *is_nil, double *cc)
+{
+    if (!gx || !gy || gx->ctx != gy->ctx)
+        return fail(MUSE_ERR_INVALID, "the two groups must share a context");
+    if (gx->f32 || gy->f32)
+        return fail(MUSE_ERR_UNSUPPORTED, "xCorr is not built for float32-storage groups");
+    muse_ctx *ctx = gx->ctx;
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    if (gx->M != gy->M)
+        return fail(MUSE_ERR_LENGTH, "xCorr pairs row i of x with row i of y: %lld vs %lld rows", (long long)gx->M, (long long)gy->M);
+    const int64_t M = gx->M;
+    if (M == 0)
+        return MUSE_OK;
+    if (!lag || !mv)
+        return fail(MUSE_ERR_INVALID, "NULL output");
+    const int32_t Nx = gx->N, Ny = gy->N;
+    n = std::max(n, std::max(Nx, Ny)); // xcorr.go:104-106
+    if (normalize && (Nx < 2 || Ny < 2))
+        return fail(MUSE_ERR_INVALID, "series length 1 has no sample standard deviation");
+    rc = group_ready(gx);
+    if (!rc)
+        rc = group_ready(gy);
+    if (rc)
+        return rc;
+    if (!is_pow2(n) || n < 512 || n > GENERIC_MAX_N) {
+        // FFT lengths without a batched kernel (the reference's n = 5 tables, short series): pair by pair through the
+        // single-pair path (generic radix-2 kernel, or the direct kernel for n that is not a power of two)
+        std::vector<double> x((size_t)Nx), y((size_t)Ny);
+        HIP_TRY(hipStreamSynchronize(ctx->copy_stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        for (int64_t i = 0; i < M; i++) {
+            HIP_TRY(hipMemcpy(x.data(), gx->rows + i * gx->stride, (size_t)Nx * sizeof(double), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(y.data(), gy->rows + i * gy->stride, (size_t)Ny * sizeof(double), hipMemcpyDeviceToHost));
+            int32_t nil = 0;
+            rc = muse_xcorr(ctx, x.data(), Nx, y.data(), Ny, n, normalize, cc ? cc + (size_t)i * (size_t)n : nullptr, lag + i, mv + i, &nil);
+            if (rc)
+                return rc;
+            if (cc && nil)
+                std::fill(cc + (size_t)i * (size_t)n, cc + (size_t)(i + 1) * (size_t)n, 0.0);
+            if (is_nil)
+                is_nil[i] = nil;
+        }
+        return MUSE_OK;
+    }
+    hipError_t e = ensure_gscratch(ctx, n);
+    if (e == hipSuccess && n >= 32768)
+        e = ensure_twl(ctx, n);
+    if (e != hipSuccess)
+        return fail(MUSE_ERR_NOMEM, "scratch: %s", hipGetErrorString(e));
+    double *dmv = nullptr, *dcc = nullptr;
+    int *dlag = nullptr, *dnil = nullptr;
+    auto cleanup = [&]() { (void)hipFree(dmv); (void)hipFree(dcc); (void)hipFree(dlag); (void)hipFree(dnil); };
+    e = hipMalloc(&dmv, (size_t)M * sizeof(double));
+    if (e == hipSuccess)
+        e = hipMalloc(&dlag, (size_t)M * sizeof(int));
+    if (e == hipSuccess)
+        e = hipMalloc(&dnil, (size_t)M * sizeof(int));
+    if (e == hipSuccess && cc)
+        e = hipMalloc(&dcc, (size_t)M * (size_t)n * sizeof(double));
+    if (e == hipSuccess && cc)
+        e = hipMemsetAsync(dcc, 0, (size_t)M * (size_t)n * sizeof(double), ctx->stream);
+    if (e != hipSuccess) {
+        cleanup();
+        return fail(MUSE_ERR_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e));
+    }
+    {
+        // long series work in the context's scratch buffer: its pointer must not be swapped between reading it and the launch
+        std::unique_lock<std::mutex> scratch_lock(ctx->stage_mu, std::defer_lock);
+        if (n >= GENERIC_LDS_MAX_N)
+            scratch_lock.lock();
+        FusedParams p{};
+        p.rows = gy->rows;
+        p.stride = gy->stride;
+        p.N = Ny;
+        p.xrows = gx->rows;
+        p.xstride = gx->stride;
+        p.Nx = Nx;
+        p.M = M;
+        p.npairs = M;
+        p.n = n;
+        p.logn = ilog2(n);
+        p.normalize_y = normalize ? 1 : 0;
+        p.twm = ctx->twm;
+        p.g2 = ctx->g2;
+        p.g3a = ctx->g3a;
+        p.g3b = ctx->g3b;
+        p.gsmall = (p.logn >= 9 && p.logn <= 11) ? ctx->gsmall[p.logn - 9] : (p.logn == 13 || p.logn == 14) ? ctx->gsmall[p.logn - 10] : nullptr;
+        p.gscratch = ctx->gscratch;
+        p.gscratch_slices = (long long)(ctx->gscratch_elems / (size_t)n);
+        p.twl = (p.logn >= 14 && p.logn <= 16) ? ctx->twl[p.logn - 14] : nullptr;
+        p.mv = dmv;
+        p.lag = dlag;
+        p.nil_out = dnil;
+        p.cc_out = dcc;
+        LaunchTimer timer(ctx);
+        e = timer.begin();
+        if (e == hipSuccess)
+            e = launch_two_sided(p, ctx->num_cus, ctx->stream);
+        if (e == hipSuccess)
+            e = timer.end();
+    }
+    std::vector<int> nil((size_t)M);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(lag, dlag, (size_t)M * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(mv, dmv, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(nil.data(), dnil, (size_t)M * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && cc)
+        e = hipMemcpyAsync(cc, dcc, (size_t)M * (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(ctx->stream);
+    cleanup();
+    if (e != hipSuccess)
+        return fail(MUSE_ERR_HIP, "two-sided xCorr: %s", hipGetErrorString(e));
+    for (int64_t i = 0; i < M; i++) {
+        if (is_nil)
+            is_nil[i] = nil[(size_t)i];
+        if (cc && !nil[(size_t)i] && mv[i] != mv[i]) // NaN / Inf statistics: the reference's cc is NaN throughout
+            std::fill(cc + (size_t)i * (size_t)n, cc + (size_t)(i + 1) * (size_t)n, std::numeric_limits<double>::quiet_NaN());
+    }
+    return MUSE_OK;
+}
+
+extern "C" int muse_xcorr_batch(muse_ctx *ctx, const double *x_rows, const double *y_rows, int64_t M, int32_t lenx, int32_t leny,
+                                int32_t n, int32_t normalize, int32_t *lag, double *mv, int32_t *is_nil, double *cc)
+{
+    if (!ctx || M < 0 || lenx < 1 || leny < 1 || (M > 0 && (!x_rows || !y_rows)))
+        return fail(MUSE_ERR_INVALID, "bad xCorr batch arguments");
+    if (M == 0)
+        return MUSE_OK;
+    muse_group *gx = nullptr, *gy = nullptr;
+    int rc = muse_group_upload(ctx, x_rows, M, lenx, lenx, &gx);
+    if (!rc)
+        rc = muse_group_upload(ctx, y_rows, M, leny, leny, &gy);
+    if (!rc)
+        rc = muse_xcorr_groups(gx, gy, n, normalize, lag, mv, is_nil, cc);
+    const std::string msg = rc ? g_last_error : std::string();
+    muse_group_free(gx);
+    muse_group_free(gy);
+    if (rc)
+        g_last_error = msg;
+    return rc;
+}

@@ -99,13 +99,13 @@ hipError_t launch_ref_spectrum(const double *ref_dev, int N, int n, int logn, in
                                double xc_scale, const double2 *twm, double2 *X, double2 *xc, float2 *xcf, double *xs,
                                double2 *gscratch, int *status, hipStream_t stream);
 constexpr int SMALL_MAX_N = 16384;       // largest FFT length of xcorr_small.hip (it reads n - N samples in front of a row unclamped:
-                                         // FusedParams::rows must carry that many readable elements in front of row 0, muse_capi.hip GROUP_GUARD)
+                                         // FusedParams::rows must carry that many readable elements in front of row 0, capi_group.hip GROUP_GUARD)
 constexpr int GENERIC_LDS_MAX_N = 8192;  // larger n: the radix-2 passes run in gscratch
 constexpr int GENERIC_MAX_N = 65536;
 constexpr int GENERIC_GLOBAL_WGS_PER_CU = 2;
 constexpr int STOCKHAM_GLOBAL_WGS_PER_CU = 2; // xcorr_fused_stk_4step: resident workgroups per CU, one n-element slice each (two for the two-sided xCorr)
 constexpr int LONG_WGS_PER_CU = 4;            // xcorr_long.hip: resident workgroups per CU, one n-element slice each
-// n-element complex slices of the context's scratch buffer per CU (muse_capi.hip, ensure_gscratch): every kernel that works in it
+// n-element complex slices of the context's scratch buffer per CU (capi_batch.hip, ensure_gscratch): every kernel that works in it
 // launches at most this many workgroups per CU times the slices each of them uses, and checks FusedParams::gscratch_slices
 constexpr int GSCRATCH_SLICES_PER_CU = 4;
 static_assert(LONG_WGS_PER_CU <= GSCRATCH_SLICES_PER_CU && GENERIC_GLOBAL_WGS_PER_CU <= GSCRATCH_SLICES_PER_CU &&

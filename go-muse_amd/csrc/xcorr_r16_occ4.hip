@@ -167,7 +167,7 @@ __global__ __launch_bounds__(OCC_THREADS, WPS) void xcorr_fused_n4096_occ4(const
     // fp32 screening kernel); otherwise pairs 0 .. npairs
     // A DENSE list (more than an eighth of the group's pairs listed: a group of mixed-unit series) is not followed: the
     // kernel redoes EVERY pair, so that all results of such a group come from this kernel in every pass -- the first one, which
-    // found the list, and the later ones, which the host sends here directly (muse_capi.hip): Run(); Run() is bit-identical.
+    // found the list, and the later ones, which the host sends here directly (capi_batch.hip): Run(); Run() is bit-identical.
     long long total = p.pair_count ? (long long)*p.pair_count : p.npairs;
     const long long *__restrict__ plist = p.pair_list;
     if (p.pair_count && p.dense_total > 0 && total * 8 > p.dense_total) {

@@ -6,7 +6,7 @@
 // power-of-two-scaled fp32 copy of the centred samples, and per series an ESTIMATE of the score plus FLAGS that
 // describe every lag whose fp32 |cc| lies within the error bound of the fp32 maximum (kernel comment below).
 // Nothing the library returns is computed here: rows that can reach the top-N are re-evaluated by the fp64
-// kernels and only those are selected (muse_capi.hip, screen_finish).
+// kernels and only those are selected (capi_screen.hip, screen_finish).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -149,7 +149,7 @@ __device__ __forceinline__ void reduce_series(const double (&r)[16], const doubl
 
 
 // ---------------------------------------------------------------------------------------------
-// The screening PASS of the filter-and-refine Run (muse_capi.hip: run_select): fp32 only, no
+// The screening PASS of the filter-and-refine Run (capi_run.hip: run_select): fp32 only, no
 // re-evaluation.  Per series it writes
 //   mv[row]   sigma times the fp32 estimate of the signed score at the fp32 argmax (the fp32 value with its exact
 //             power-of-two scale, as a double) and scr_var[row] = sigma^2: score estimate = mv / sqrt(var), with

@@ -537,7 +537,7 @@ __global__ __launch_bounds__((LOGN >= 11 ? (1 << LOGN) / 16 : 256), ((MULTI && L
     // The rows of the NEXT iteration are requested behind the per-lane argmax of the current one (the transform registers
     // are free then) and consumed at the top of the loop: element j + i S of the padded series is sample j + i S - pad; a pad
     // position reads up to `pad` samples IN FRONT of the row (the end of the previous row, or the guard the group
-    // allocation keeps in front of row 0: muse_capi.hip, GROUP_GUARD) and is masked -- no clamp, so every load is one
+    // allocation keeps in front of row 0: capi_group.hip, GROUP_GUARD) and is masked -- no clamp, so every load is one
     // base plus a compile-time offset.
     double xa[16], xb[16], KA, KB;
     const auto request = [&](long long it2) __attribute__((always_inline)) {
@@ -1032,7 +1032,7 @@ static hipError_t launch_small_n(const FusedParams &p, int num_cus, hipStream_t 
 
 // n = 512, 1024, 2048, 8192, 16384 (float64 rows); any N in (n/2, n]
 // p.rows must carry n - N < n / 2 readable elements in front of row 0 (zero-padded rows are read unclamped and masked;
-// muse_capi.hip allocates every group with GROUP_GUARD >= SMALL_MAX_N / 2 such elements)
+// capi_group.hip allocates every group with GROUP_GUARD >= SMALL_MAX_N / 2 such elements)
 hipError_t launch_fused_small(const FusedParams &p, int num_cus, hipStream_t stream)
 {
     static_assert((1 << 14) <= SMALL_MAX_N, "the largest length built below");
