@@ -16,4 +16,4 @@ from .muse import (Batch, DefaultLabel, DeviceBatch, DeviceGroup, Engine, Group,
                    NewBatch, NewGroup, NewLabels, NewResults, NewSeries, Results, Score, Series,
                    SignFilter_ANY, SignFilter_NEG, SignFilter_POS, get_engine, merge_records, next_pow2,
                    RunMany, run_many, score_many, scores_many, xcorr_groups, device_count,
-                   merge_group_records)
+                   merge_group_records, merge_group_winners)

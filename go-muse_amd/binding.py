@@ -74,6 +74,7 @@ SIGNATURES = {
     "muse_batch_run_groups": (ctypes.c_int, [_vp, _i32p, _i32, _i64, _i32, _recp, ctypes.POINTER(ctypes.c_uint8)]),
     "muse_merge_group_records": (ctypes.c_int, [_recp, ctypes.POINTER(ctypes.c_uint8), _i32, _i32, _i32, _i32, _f64, _i32,
                                                 _i64p, _i32p, _dp, _i32p, _dp]),
+    "muse_merge_group_winners": (ctypes.c_int, [_recp, ctypes.POINTER(ctypes.c_uint8), _i32, _i32, _recp, ctypes.POINTER(ctypes.c_uint8)]),
     "muse_merge_records": (ctypes.c_int, [_recp, _i64, _i32, _i64p, _i32p, _dp, _i32p, _dp]),
     "muse_batch_score_many": (ctypes.c_int, [ctypes.POINTER(_vp), _i32]),
     "muse_batch_read_scores": (ctypes.c_int, [_vp, _i32p, _dp]),

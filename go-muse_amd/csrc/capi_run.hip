@@ -357,20 +357,16 @@ static bool passed_host(double s, int32_t lag, int32_t max_lag, double threshold
            (sign_filter == 0 || (s > 0 && sign_filter == 1) || (s < 0 && sign_filter == -1));
 }
 
-extern "C" int muse_merge_group_records(const muse_record *records, const uint8_t *state, int32_t n_shards, int32_t G,
-                                        int32_t max_lag, int32_t top_n, double threshold, int32_t sign_filter,
-                                        int64_t *out_series, int32_t *out_lag, double *out_score, int32_t *out_count,
-                                        double *out_mean_abs)
+// per label group: what the shards' records and states amount to (the group's winner; out_state 0 = no member anywhere,
+// 1 = out_records[g] is the group's Score, 2 = the group's first member scores NaN, so the group's score is NaN)
+static void merge_group_winners(const muse_record *records, const uint8_t *state, int32_t n_shards, int32_t G,
+                                muse_record *out_records, uint8_t *out_state)
 {
-    if (n_shards < 0 || G < 0 || ((int64_t)n_shards * G > 0 && (!records || !state)))
-        return fail(MUSE_ERR_INVALID, "bad shard records");
-    if (sign_filter < -1 || sign_filter > 1)
-        return fail(MUSE_ERR_INVALID, "sign_filter must be -1, 0 or 1");
-    std::vector<muse_record> cands;
     for (int32_t g = 0; g < G; g++) {
         // shards are listed in ascending row order: the first one with a member holds the group's first member
         bool seen = false, nan_first = false, have = false;
         muse_record best{};
+        best.series = -1;
         for (int32_t s = 0; s < n_shards; s++) {
             const size_t k = (size_t)s * (size_t)G + (size_t)g;
             if (state[k] == 0)
@@ -388,12 +384,36 @@ extern "C" int muse_merge_group_records(const muse_record *records, const uint8_
                 have = true;
             }
         }
-        if (!seen || nan_first || !have) // empty group, or its first member's score is NaN: never passes Results.passed
-            continue;
         best.group = g;
-        if (passed_host(best.score, best.lag, max_lag, threshold, sign_filter))
-            cands.push_back(best);
+        out_records[g] = best;
+        out_state[g] = !seen ? 0 : (nan_first || !have) ? 2 : 1;
     }
+}
+
+extern "C" int muse_merge_group_winners(const muse_record *records, const uint8_t *state, int32_t n_shards, int32_t G,
+                                        muse_record *out_records, uint8_t *out_state)
+{
+    if (n_shards < 0 || G < 0 || ((int64_t)n_shards * G > 0 && (!records || !state)) || (G > 0 && (!out_records || !out_state)))
+        return fail(MUSE_ERR_INVALID, "bad shard records");
+    merge_group_winners(records, state, n_shards, G, out_records, out_state);
+    return MUSE_OK;
+}
+
+extern "C" int muse_merge_group_records(const muse_record *records, const uint8_t *state, int32_t n_shards, int32_t G,
+                                        int32_t max_lag, int32_t top_n, double threshold, int32_t sign_filter,
+                                        int64_t *out_series, int32_t *out_lag, double *out_score, int32_t *out_count,
+                                        double *out_mean_abs)
+{
+    if (n_shards < 0 || G < 0 || ((int64_t)n_shards * G > 0 && (!records || !state)))
+        return fail(MUSE_ERR_INVALID, "bad shard records");
+    if (sign_filter < -1 || sign_filter > 1)
+        return fail(MUSE_ERR_INVALID, "sign_filter must be -1, 0 or 1");
+    std::vector<muse_record> win((size_t)G), cands;
+    std::vector<uint8_t> st((size_t)G);
+    merge_group_winners(records, state, n_shards, G, win.data(), st.data());
+    for (int32_t g = 0; g < G; g++) // (an empty group, or one whose first member scores NaN, never passes Results.passed)
+        if (st[(size_t)g] == 1 && passed_host(win[(size_t)g].score, win[(size_t)g].lag, max_lag, threshold, sign_filter))
+            cands.push_back(win[(size_t)g]);
     std::vector<muse_record> sel = heap_select(std::move(cands), top_n);
     emit(sel, out_series, out_lag, out_score, out_count, out_mean_abs);
     return MUSE_OK;

@@ -358,8 +358,15 @@ func (b *Batch) Run(groupByLabels []string) error {
 		}
 		gi++
 	}
+	// Up to exactFeedMaxGroups label groups Results is fed the reference's own sequence: ONE Score per label group, in group
+	// order, through the unchanged Results.Update (muse_batch.go:124-128) -- the heap's history, and with it the order Fetch
+	// returns exactly tied scores in and which of them survives at the TopN boundary, also into a Results that earlier Runs
+	// have filled (results.go:55-72), on one device or sharded.  Beyond it (Run(nil) over a million series) the device
+	// pre-selects the TopN candidates and 24 B x TopN cross the host.
+	G := len(labelValuesSet)
+	exact := G <= exactFeedMaxGroups
 	if es := shardEngines(); es != nil {
-		return b.runSharded(es, gid, len(labelValuesSet))
+		return b.runSharded(es, gid, G, exact)
 	}
 	e, err := getEngine()
 	if err != nil {
@@ -380,6 +387,16 @@ func (b *Batch) Run(groupByLabels []string) error {
 			return err
 		}
 		b.batchGroup = dg
+	}
+	if exact {
+		recs := (*C.muse_record)(C.calloc(C.size_t(G), C.size_t(unsafe.Sizeof(C.muse_record{}))))
+		defer C.free(unsafe.Pointer(recs))
+		state := (*C.uint8_t)(C.calloc(C.size_t(G), 1))
+		defer C.free(unsafe.Pointer(state))
+		if err := hipError(C.muse_batch_run_groups(b.batch, &gid[0], C.int32_t(G), 0, 1, recs, state)); err != nil {
+			return err
+		}
+		return b.feedGroupWinners(recs, state, 1, G)
 	}
 	r := b.Results
 	top := r.TopN
@@ -408,13 +425,38 @@ func (b *Batch) Run(groupByLabels []string) error {
 	return nil
 }
 
+const exactFeedMaxGroups = 65536
+
+// feedGroupWinners merges the shards' per-group records (muse_merge_group_winners: the first shard with a member decides the NaN
+// rule, the maximum by |score| wins, the earlier shard on ties) and pushes one Score per label group through Results.Update in
+// group order.  recs / state: nShards x G entries in C memory, shard-major.  Call with the OS thread locked.
+func (b *Batch) feedGroupWinners(recs *C.muse_record, state *C.uint8_t, nShards, G int) error {
+	win := (*C.muse_record)(C.calloc(C.size_t(G), C.size_t(unsafe.Sizeof(C.muse_record{}))))
+	defer C.free(unsafe.Pointer(win))
+	wst := (*C.uint8_t)(C.calloc(C.size_t(G), 1))
+	defer C.free(unsafe.Pointer(wst))
+	if err := hipError(C.muse_merge_group_winners(recs, state, C.int32_t(nShards), C.int32_t(G), win, wst)); err != nil {
+		return err
+	}
+	winv := unsafe.Slice(win, G)
+	wstv := unsafe.Slice(wst, G)
+	for g := 0; g < G; g++ {
+		if wstv[g] != 1 { // 0: no member; 2: the group's score is NaN, which never passes Results.passed
+			continue
+		}
+		w := winv[g]
+		b.Results.Update(Score{Labels: b.Comparison.order[int(w.series)].Labels(), Lag: int(w.lag), PercentScore: float64(w.score)})
+	}
+	return nil
+}
+
 // runSharded is Run over several GPUs (SetDevices).  The Comparison group is cut into one contiguous row range per device
 // and every shard is scored at the same time, one goroutine per device.  Label groups that live on ONE shard each
 // (always true when every series is its own group): each shard returns its top-N candidates (muse_batch_run_shard,
 // 24 B x TopN per device) and muse_merge_records selects.  Label groups that straddle shards: each shard returns its
 // winner per group, unfiltered (muse_batch_run_groups), and muse_merge_group_records takes the per-group maximum BEFORE
 // Results.passed and the top-N heap -- what SURVEY 8e requires for exactness.
-func (b *Batch) runSharded(es []*engine, gid []C.int32_t, G int) error {
+func (b *Batch) runSharded(es []*engine, gid []C.int32_t, G int, exact bool) error {
 	shards, err := b.Comparison.residentShards(es)
 	if err != nil {
 		return err
@@ -447,13 +489,16 @@ func (b *Batch) runSharded(es []*engine, gid []C.int32_t, G int) error {
 		}
 		runtime.UnlockOSThread()
 	}
-	// does any label group have members on two shards?
-	straddle := false
+	// does any label group have members on two shards?  (exact: every shard reports per group anyway)
+	straddle := exact
 	owner := make([]int, G)
 	for i := range owner {
 		owner[i] = -1
 	}
 	for r, sh := range shards {
+		if exact {
+			break
+		}
 		for i := sh.lo; i < sh.hi && !straddle; i++ {
 			o := owner[gid[i]]
 			if o >= 0 && o != r {
@@ -513,6 +558,9 @@ func (b *Batch) runSharded(es []*engine, gid []C.int32_t, G int) error {
 	}
 	runtime.LockOSThread()
 	defer runtime.UnlockOSThread()
+	if exact {
+		return b.feedGroupWinners(recs, state, W, G)
+	}
 	idx := make([]C.int64_t, capN)
 	lag := make([]C.int32_t, capN)
 	score := make([]C.double, capN)

@@ -492,6 +492,12 @@ public:
         auto lvs = Comparison->indexLabelValues(groupByLabels, &gid);
         if (lvs.empty())
             return;
+        if ((int64_t)lvs.size() <= EXACT_FEED_MAX_GROUPS) {
+            feed_groups(gid, (int32_t)lvs.size());
+            return;
+        }
+        // very many label groups (Run(nil) over a million series): the device pre-selects the TopN candidates, 24 B x TopN cross
+        // the host; among EXACTLY tied scores the order / the survivor at the boundary may then differ from a full feed
         if (!engines_.empty()) {
             run_sharded(gid, (int32_t)lvs.size());
             return;
@@ -565,14 +571,61 @@ public:
         }
     }
 
+    // Batch.Run feeds Results one Score per label group (the reference's feed) up to this many groups
+    static constexpr int64_t EXACT_FEED_MAX_GROUPS = 65536;
+
 private:
-    // The sharded Run.  Label groups that live on ONE shard each (always the case when every series is its own group):
-    // each shard returns its top-N candidates (muse_batch_run_shard) and muse_merge_records selects -- 24 B x TopN per
-    // device cross the host.  Label groups that straddle shards: each shard returns its winner per group, unfiltered
-    // (muse_batch_run_groups), and muse_merge_group_records takes the per-group maximum BEFORE filtering and selecting.
-    void run_sharded(const std::vector<int32_t> &gid, int32_t G)
+    // The reference's own feed (muse_batch.go:124-128): ONE Score per label group, in group order, through Results.Update --
+    // the heap's history, and with it the order Fetch returns exactly tied scores in and which of them survives at the TopN
+    // boundary, is the reference's (for insertion-ordered groups), also when the Results already holds the Scores of earlier
+    // Runs (results.go:55-72) and whether the Group sits on one device or is cut over several: every shard returns its winner
+    // per group, unfiltered (muse_batch_run_groups), muse_merge_group_winners takes the per-group maximum.
+    void feed_groups(const std::vector<int32_t> &gid, int32_t G)
     {
-        auto &shards = Comparison->shards(engines_);
+        size_t W = 1;
+        std::vector<muse_record> recs;
+        std::vector<uint8_t> state;
+        if (engines_.empty()) {
+            muse_group *dg = Comparison->device(eng_);
+            ensure(dg);
+            recs.resize((size_t)G);
+            state.resize((size_t)G);
+            check(muse_batch_run_groups(batch_, gid.data(), G, 0, 1, recs.data(), state.data()));
+        } else {
+            auto &shards = Comparison->shards(engines_);
+            ensure_shard_batches(shards);
+            W = shards.size();
+            recs.assign(W * (size_t)G, muse_record{-1, 0.0, 0, 0});
+            state.assign(W * (size_t)G, 0);
+            std::vector<int> status(W, MUSE_OK);
+            std::vector<std::string> message(W);
+            std::vector<std::thread> workers;
+            for (size_t r = 0; r < W; r++) {
+                if (shards[r].lo == shards[r].hi)
+                    continue; // an empty shard (fewer rows than devices)
+                workers.emplace_back([&, r]() {
+                    status[r] = muse_batch_run_groups(shard_batches_[r].batch, gid.data() + shards[r].lo, G, (int64_t)shards[r].lo, 1,
+                                                      recs.data() + r * (size_t)G, state.data() + r * (size_t)G);
+                    if (status[r])
+                        message[r] = muse_last_error(); // (thread-local: read it on the thread that failed)
+                });
+            }
+            for (auto &w : workers)
+                w.join();
+            for (size_t r = 0; r < W; r++)
+                if (status[r])
+                    throw Error(status[r], message[r]);
+        }
+        std::vector<muse_record> win((size_t)G);
+        std::vector<uint8_t> st((size_t)G);
+        check(muse_merge_group_winners(recs.data(), state.data(), (int32_t)W, G, win.data(), st.data()));
+        for (int32_t g = 0; g < G; g++)
+            if (st[(size_t)g] == 1) // (0: no member; 2: the group's score is NaN, which never passes Results.passed)
+                Results_->Update(Score{Comparison->series()[(size_t)win[(size_t)g].series]->Labels(), win[(size_t)g].lag, win[(size_t)g].score});
+    }
+    template <typename Shards>
+    void ensure_shard_batches(Shards &shards)
+    {
         const size_t W = shards.size();
         if (shard_batches_.size() != W)
             shard_batches_.resize(W);
@@ -585,6 +638,16 @@ private:
                 sb.group = shards[r].dev;
             }
         }
+    }
+    // The sharded Run over very many label groups.  Label groups that live on ONE shard each (always the case when every series is its own group):
+    // each shard returns its top-N candidates (muse_batch_run_shard) and muse_merge_records selects -- 24 B x TopN per
+    // device cross the host.  Label groups that straddle shards: each shard returns its winner per group, unfiltered
+    // (muse_batch_run_groups), and muse_merge_group_records takes the per-group maximum BEFORE filtering and selecting.
+    void run_sharded(const std::vector<int32_t> &gid, int32_t G)
+    {
+        auto &shards = Comparison->shards(engines_);
+        const size_t W = shards.size();
+        ensure_shard_batches(shards);
         // does any label group have members on two shards?
         bool straddle = false;
         {

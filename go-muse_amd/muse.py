@@ -459,6 +459,18 @@ def merge_group_records(records, state, max_lag, top_n, threshold, sign_filter):
     return o_s[:c].copy(), o_l[:c].copy(), o_v[:c].copy(), float(mean.value)
 
 
+def merge_group_winners(records, state):
+    """muse_merge_group_winners: (n_shards, G) records / states -> the G label groups' winners and states (0 no member, 1 a
+    Score, 2 the group's score is NaN): what Batch.Run feeds through Results.Update in group order"""
+    records = np.ascontiguousarray(records, dtype=B.RECORD_DTYPE)
+    state = np.ascontiguousarray(state, dtype=np.uint8)
+    W, G = records.shape
+    out, ost = np.zeros(max(G, 1), dtype=B.RECORD_DTYPE), np.zeros(max(G, 1), dtype=np.uint8)
+    u8 = ctypes.POINTER(ctypes.c_uint8)
+    B.check(B.load().muse_merge_group_winners(B.recptr(records), state.ctypes.data_as(u8), W, G, B.recptr(out), ost.ctypes.data_as(u8)))
+    return out[:G], ost[:G]
+
+
 def merge_records(records, top_n):
     """Results.Update/Fetch over gathered shard candidates (host only)."""
     records = np.ascontiguousarray(records, dtype=B.RECORD_DTYPE)
@@ -715,6 +727,11 @@ def NewResults(maxLag, topN, threshold, signFilter):
 
 
 # ----------------------------------------------------------- muse_batch.go
+# Batch.Run feeds Results one Score per label group (the reference's feed) up to this many groups; beyond it the device
+# pre-selects the TopN candidates
+EXACT_FEED_MAX_GROUPS = 65536
+
+
 class Batch:
     def __init__(self, ref, comp, results, cc, engine=None, engines=None):
         # muse_batch.go:24-28 (length check over the registry)
@@ -759,26 +776,74 @@ class Batch:
             for u in uids:
                 gid[uid_pos[u]] = g
         r = self.Results
+        G = len(labelValuesSet)
+        if G <= EXACT_FEED_MAX_GROUPS:
+            # the reference's own feed (muse_batch.go:124-128): ONE Score per label group, in group order, through Results.Update --
+            # the heap's history, and with it the order Fetch returns exactly tied scores in and which of them survives at the
+            # top-N boundary, is the reference's (for insertion-ordered groups), also when the Results already holds the Scores of
+            # earlier Runs (results.go:55-72) and whether the Group sits on one device or is cut over several
+            if self._engines:
+                rec, state = self._group_winners_sharded(gid, G)
+            else:
+                rec, state = merge_group_winners(*[a[None, :] for a in self._batch().run_groups(gid, G, 0, abs_scores=True)])
+            live = (state == 1) & (np.abs(rec["lag"].astype(np.int64)) <= r.MaxLag) & (np.abs(rec["score"]) >= r.Threshold)
+            if r.SignFilter == SignFilter_POS:
+                live &= rec["score"] > 0
+            elif r.SignFilter == SignFilter_NEG:
+                live &= rec["score"] < 0
+            for g in np.nonzero(live)[0]:      # (a Score that fails Results.passed leaves the heap untouched: not constructed)
+                r.Update(Score(series[int(rec["series"][g])].Labels(), int(rec["lag"][g]), float(rec["score"][g])))
+            return None
+        # very many label groups (Run(nil) over a million series): the device pre-selects the TopN candidates, 24 B x TopN cross
+        # the host; among EXACTLY tied scores the order / the survivor at the boundary may then differ from a full feed
         if self._engines:
-            idx, lag, score = self._run_sharded(gid, len(labelValuesSet))
+            idx, lag, score = self._run_sharded(gid, G)
         else:
-            idx, lag, score, _ = self._batch().run(gid, len(labelValuesSet), r.MaxLag, r.TopN, r.Threshold,
-                                                   r.SignFilter, abs_scores=True)
+            idx, lag, score, _ = self._batch().run(gid, G, r.MaxLag, r.TopN, r.Threshold, r.SignFilter, abs_scores=True)
         # feed Results in group order, as the ordered drain does (muse_batch.go:124-128)
         order = np.argsort(gid[idx], kind="stable")
         for k in order:
             r.Update(Score(series[int(idx[k])].Labels(), int(lag[k]), float(score[k])))
         return None
 
+    def _shard_batches(self):
+        shards = self.Comparison._device_shards(self._engines)
+        if self._shard_db is None or len(self._shard_db) != len(shards) or \
+                any(db.dgroup is not sh[1] for db, sh in zip(self._shard_db, shards)):
+            self._shard_db = [DeviceBatch(e, dg, self._ref) for e, dg, _, _ in shards]
+        return shards
+
+    def _group_winners_sharded(self, gid, G):
+        """every shard's winner per label group at the same time (one host thread per device), merged per group"""
+        import threading
+        shards = self._shard_batches()
+        out, err = [None] * len(shards), [None] * len(shards)
+
+        def work(k):
+            _, _, lo, hi = shards[k]
+            try:
+                out[k] = self._shard_db[k].run_groups(gid[lo:hi], G, lo, abs_scores=True)
+            except Exception as e:   # reported by the calling thread
+                err[k] = e
+        threads = [threading.Thread(target=work, args=(k,)) for k, sh in enumerate(shards) if sh[3] > sh[2]]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        for e in err:
+            if e is not None:
+                raise e
+        empty = (np.zeros(G, dtype=B.RECORD_DTYPE), np.zeros(G, dtype=np.uint8))
+        empty[0]["series"] = -1
+        parts = [o if o is not None else empty for o in out]
+        return merge_group_winners(np.stack([p[0] for p in parts]), np.stack([p[1] for p in parts]))
+
 
     def _run_sharded(self, gid, G):
         """the sharded Run (muse.hpp Batch::run_sharded is the same code): top-N candidates per shard when every label group
         lives on one shard, per-group winners merged BEFORE filtering when groups straddle shards"""
         import threading
-        shards = self.Comparison._device_shards(self._engines)
-        if self._shard_db is None or len(self._shard_db) != len(shards) or \
-                any(db.dgroup is not sh[1] for db, sh in zip(self._shard_db, shards)):
-            self._shard_db = [DeviceBatch(e, dg, self._ref) for e, dg, _, _ in shards]
+        shards = self._shard_batches()
         owner = np.full(G, -1, dtype=np.int64)
         straddle = False
         for k, (_, _, lo, hi) in enumerate(shards):

@@ -234,6 +234,16 @@ int muse_merge_records(const muse_record *records, int64_t count, int32_t top_n,
 int muse_batch_run_groups(muse_batch *b, const int32_t *group_id, int32_t G,
                           int64_t series_offset, int32_t abs_scores,
                           muse_record *out_records, uint8_t *out_state);
+/* The per-group part of that merge alone (host only): records / state hold n_shards x G entries, shard-major, shards in
+ * ascending row order; out_records[g] = the group's winner (the first shard with a member decides the NaN rule, the maximum by
+ * |score| wins, the earlier shard on ties: muse_batch.go:87), out_state[g] = 0 the group has no member / 1 out_records[g] is its
+ * Score / 2 its first member scores NaN, so its score is NaN.  This is what a host feeds through Results.Update, one Score per
+ * label group in group order (muse_batch.go:124-128), to reproduce the reference's heap HISTORY and with it the order among
+ * exactly tied scores -- also into a Results that earlier Runs have filled (results.go:55-72).  n_shards = 1 turns one
+ * muse_batch_run_groups result into that feed. */
+int muse_merge_group_winners(const muse_record *records, const uint8_t *state,
+                             int32_t n_shards, int32_t G,
+                             muse_record *out_records, uint8_t *out_state);
 /* Merge of those per-shard records (host only): records / state hold n_shards x G entries, shard-major, shards in
  * ascending row order.  Per group: the first shard with a member decides the NaN rule, the maximum by |score| wins
  * (the earlier shard on ties: muse_batch.go:87 keeps the earlier series); then Results.passed, the top-N heap and

@@ -565,6 +565,63 @@ def test_config5_mixed_lengths_one_shared_results(muse, eng, oracle, sharded):
     assert second == [] and math.isnan(mean2)
 
 
+def test_exactly_tied_scores_follow_the_reference_feed(muse, eng, oracle):
+    """Results.Update keeps a full heap's minimum unless the new Score is STRICTLY greater (results.go:63), so among exactly
+    tied scores what survives at the TopN boundary and the order Fetch returns are the heap's history: Batch.Run must feed one
+    Score per label group in group order (muse_batch.go:124-128), not a pre-selected subset.  Thirteen label groups hold
+    bit-identical pairs of series (identical pairs share one complex transform: identical bits on the GPU too) that tie at the
+    top of a TopN = 8 Results; a second Batch then Runs into the SAME Results.  One device and a Group cut over three contexts
+    must both return exactly what the reference's feed gives over the same per-series scores (oracle.results on the GPU's own
+    scores: the heap semantics in isolation), which in turn match the oracle's scores."""
+    rng = np.random.default_rng(2024)
+    N, M = 512, 400
+    t = np.arange(N)
+    ref_y = 1.5 * (np.abs(t - N // 2) <= 5) + 0.1 * rng.standard_normal(N)
+
+    def make_rows(seed):
+        r = np.random.default_rng(seed)
+        rows = r.uniform(-2, 2, size=(M, 1)) * (np.abs(t[None, :] - N // 2 - r.integers(-20, 21, size=(M, 1))) <= 6) + 0.3 * r.standard_normal((M, N))
+        rows[0] = 1.2 * ref_y + 0.05 * r.standard_normal(N)       # a strong match and its pair partner ...
+        for k in (7, 20, 33, 61, 62, 90, 121, 133, 150, 170, 188, 199):
+            rows[2 * k:2 * k + 2] = rows[0:2]                      # ... copied bit for bit into twelve more label groups
+        return rows
+    rows1, rows2 = make_rows(1), make_rows(2)
+    gid = (np.arange(M) // 2).astype(np.int32)                     # label groups = the pairs
+    G = M // 2
+
+    def group_of(rows, tag):
+        g = muse.NewGroup("g" + tag)
+        g.Add(*[muse.NewSeries(rows[i], muse.NewLabels({"batch": tag, "graph": "g%03d" % (i // 2), "host": "h%d" % (i % 2)})) for i in range(M)])
+        return g
+    ref = muse.NewSeries(ref_y, muse.NewLabels({"graph": "ref"}))
+    want = None
+    for engines in (None, [muse.Engine(0) for _ in range(3)]):
+        res = muse.NewResults(N, 8, 0.0, muse.SignFilter_ANY)
+        per_series = []
+        for tag, rows in (("1", rows1), ("2", rows2)):
+            b = muse.NewBatch(ref, group_of(rows, tag), res, 4, engine=eng, engines=engines)
+            b.Run(["graph"])                                       # both Batches into ONE Results
+            dg = muse.DeviceGroup.from_rows(eng, rows)
+            db = muse.DeviceBatch(eng, dg, ref_y)
+            per_series.append(db.scores())
+            olag, omv, gap = oracle.batch_scores(ref_y, rows)
+            assert_scores_match(per_series[-1][0], per_series[-1][1], olag, omv, gap)
+            db.close()
+            dg.close()
+        got, mean = res.Fetch()
+        lag = np.concatenate([p[0] for p in per_series])
+        mv = np.concatenate([p[1] for p in per_series])
+        oi, ol, osc, omean = oracle.results(lag, mv, np.concatenate([gid, gid + G]), 2 * G, True, N, 8, 0.0, 0)
+        have = [(s.Labels.labels["batch"], s.Labels.labels["graph"], s.Labels.labels["host"], s.Lag, s.PercentScore) for s in got]
+        expect = [("1" if i < M else "2", "g%03d" % ((i % M) // 2), "h%d" % (i % 2), int(l), float(v)) for i, l, v in zip(oi, ol, osc)]
+        assert have == expect                                      # order, survivors at the boundary, lags, scores: bit for bit
+        assert len({h[4] for h in have}) <= 2 and len(have) == 8   # (the eight really are ties: at most the two batches' values)
+        assert mean == omean
+        if want is None:
+            want = have
+        assert have == want                                        # the sharded Group returns what one device returns
+
+
 def test_group_append_staging_paths(muse, eng, oracle):
     """Group.Add-style ingestion: one muse_group_append per Series (pinned double-buffered
     staging, asynchronous upload), mixed with slab appends and growth re-allocations; the
