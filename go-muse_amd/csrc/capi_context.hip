@@ -394,7 +394,10 @@ extern "C" int muse_test_clock_probe_start(muse_ctx *ctx, double window_ms, doub
     if (!ctx->probe_stream)
         HIP_TRY(hipStreamCreateWithFlags(&ctx->probe_stream, hipStreamNonBlocking));
     if (!ctx->probe_buf) // (pinned and device-visible: the probe writes it directly, no copy behind a kernel that is still running)
-        HIP_TRY(hipHostMalloc((void **)&ctx->probe_buf, (2 * PROBE_WINDOWS + 1) * sizeof(unsigned long long), hipHostMallocDefault));
+        // (coherent: the host's stop flag must reach a kernel that is already running, and the kernel's window count the host,
+        // whatever HIP_HOST_COHERENT says)
+        HIP_TRY(hipHostMalloc((void **)&ctx->probe_buf, (2 * PROBE_WINDOWS + 1) * sizeof(unsigned long long),
+                              hipHostMallocCoherent | hipHostMallocMapped));
     HIP_TRY(hipStreamSynchronize(ctx->probe_stream));
     memset(ctx->probe_buf, 0, (2 * PROBE_WINDOWS + 1) * sizeof(unsigned long long));
     HIP_TRY(launch_clock_probe(ctx->probe_buf, (int *)(ctx->probe_buf + 2 * PROBE_WINDOWS), PROBE_WINDOWS, window_ms, total_ms,
@@ -406,8 +409,10 @@ extern "C" int muse_test_clock_probe_start(muse_ctx *ctx, double window_ms, doub
         struct timespec ts = {0, 100000};
         nanosleep(&ts, nullptr);
     }
-    if (*cnt == 0)
+    if (*cnt == 0) {
+        *(cnt + 1) = 1; // the stop flag: a probe that becomes resident later ends at once instead of sampling for total_ms
         return fail(MUSE_ERR_HIP, "clock probe did not start");
+    }
     return MUSE_OK;
 }
 
