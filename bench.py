@@ -619,7 +619,8 @@ def main():
                 line["in_process_shards"] = {"error": str(e)}
         if extras:
             # BASELINE configs[4] as ONE workload (single-GPU half): a mixed-length Group is six (ref, Group) pairs, one per length
-            # (group.go:45-51 and muse_batch.go:24-28 allow one length per Group), each ~4 GB resident, label groups of 50 series
+            # (group.go:45-51 and muse_batch.go:24-28 allow one length per Group), each ~4 GB resident (the headline's length: as
+            # many rows as the headline), label groups of 50 series
             # ("graph"), every Batch Run(["graph"]) into ONE shared Results (results.go:55-72) and one Fetch at the end.  Timed per
             # length: the whole Run (fused kernel + group max + filter + top-N + copy-back + the host feed of the shared heap) and,
             # by HIP events, its fused kernel alone (-> share of the HBM roofline on 8 N + 16 bytes per series, with the measured
@@ -629,7 +630,9 @@ def main():
             run_s_total, rows_total = 0.0, 0
             for Nl in (512, 1000, 4096, 5000, 16384, 65536):
                 try:
-                    rows_l = max(2048, min(400_000, (1 << 32) // (8 * Nl)))
+                    # (the leg of the headline's own length runs on as many rows as the headline: every launch of that kernel
+                    # instantiation in this process then has ONE workload, and its rocprofv3 averages mean what they say)
+                    rows_l = M if Nl == N else max(2048, min(400_000, (1 << 32) // (8 * Nl)))
                     # (without the planted exact copies of the reference: the shared top-N is then a field of distinct scores from
                     # all six lengths, not twenty 1.0s from the first)
                     dgl, refl = pkg.DeviceGroup.synthetic(eng, rows_l, Nl, seed=0x6D757365, copies=False)

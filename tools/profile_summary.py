@@ -62,6 +62,27 @@ for f in find("trace", "*kernel_stats.csv"):
     for r in rows[:24]:
         print("  %-64s calls=%s total_ns=%s avg_ns=%s pct=%s" % (
             short(r.get("Name", ""))[:64], r.get("Calls"), r.get("TotalDurationNs"), r.get("AverageNs"), r.get("Percentage")))
+# the headline kernel dispatch by dispatch: the traced command launches it `warmup` times, then `steps` times inside the timed region
+# (what bench.py's kernel_ms_avg and `value` are measured on), then again outside it (the untimed clock-probe repeat, the mixed
+# run's leg of the same length): the average over ALL launches (kernel_stats.csv) and the one over the timed region's, side by side
+try:
+    bench = None
+    for ln in open(os.path.join(out, "trace.log")):
+        if ln.startswith("{") and '"metric"' in ln:
+            bench = json.loads(ln)
+    hk = bench["roofline"]["kernel"]
+    for f in find("trace", "*kernel_trace.csv"):
+        dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6 for r in csv.DictReader(open(f)) if short(r.get("Kernel_Name", "")) == hk]
+        w, k = bench["warmup"], bench["steps"]
+        timed = dur[w:w + k]
+        print("\n## %s, per dispatch (%s): %d launches" % (hk, os.path.relpath(f, out), len(dur)))
+        print("  all launches:            avg %.4f ms  (min %.4f, max %.4f)" % (sum(dur) / len(dur), min(dur), max(dur)))
+        print("  launches %d..%d (the timed region: %d steps behind %d warm-up): avg %.4f ms  (min %.4f, max %.4f); bench.py's HIP events "
+              "in the same run: kernel_ms_avg %.4f ms" % (w + 1, w + k, k, w, sum(timed) / len(timed), min(timed), max(timed), bench["roofline"]["kernel_ms_avg"]))
+        kern[hk]["timed_region_avg_ns"] = sum(timed) / len(timed) * 1e6
+        kern[hk]["timed_region_launches"] = len(timed)
+except Exception as e:
+    print("\n(no per-dispatch section: %s)" % e)
 REF_COUNTERS = ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_INSTS_SALU")  # deterministic per workload: one per pass
 for sub in ("pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2"):
     for f in find(sub, "*counter_collection.csv"):
@@ -102,7 +123,7 @@ try:
                     workload[o["kernel"]] = (o["rows"], o["length"])
             for o in j.get("config5_lengths", []):
                 if "kernel" in o:
-                    workload[o["kernel"]] = (o["rows"], o["length"])
+                    workload.setdefault(o["kernel"], (o["rows"], o["length"]))
 except Exception as e:
     print("\n(no bench line in trace.log: %s)" % e)
 
