@@ -660,7 +660,9 @@ __global__ __launch_bounds__((LOGN >= 11 ? (1 << LOGN) / 16 : 256), ((MULTI && L
         // both series go into the shared transform at O(1): exact power-of-two scales close to 1/sigma
         // (fft_device.h, pow2_inv_sigma), folded into the mean removal; the variances scale along exactly
         const double sA = deadA ? 1.0 : pow2_inv_sigma(varA0), sB = deadB ? 1.0 : pow2_inv_sigma(varB0);
-        const double varA = varA0 * sA * sA, varB = varB0 * sB * sB;
+        // (a pair that fills its wave(s): the scaled variances wait for the result write-out in SGPRs, not in four registers the
+        // allocator parks in scratch across the transforms)
+        const double varA = S >= 64 ? uniform(varA0 * sA * sA) : varA0 * sA * sA, varB = S >= 64 ? uniform(varB0 * sB * sB) : varB0 * sB * sB;
         const double mA = q0 * invN * sA, mB = q2 * invN * sB;
         asm volatile("" : "+v"(js));
         js &= S - 1;
