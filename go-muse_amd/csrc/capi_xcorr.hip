@@ -190,9 +190,17 @@ extern "C" int muse_xcorr_groups(muse_group *gx, muse_group *gy, int32_t n, int3
     if (e != hipSuccess)
         return fail(MUSE_ERR_NOMEM, "scratch: %s", hipGetErrorString(e));
     double *dmv = nullptr, *dcc = nullptr;
-    int *dlag = nullptr, *dnil = nullptr;
-    auto cleanup = [&]() { (void)hipFree(dmv); (void)hipFree(dcc); (void)hipFree(dlag); (void)hipFree(dnil); };
+    int *dlag = nullptr, *dnil = nullptr, *dcount = nullptr;
+    long long *dlist = nullptr; // n >= 32768, no padding: the pairs the single-read launch hands to the launch that scales first
+    auto cleanup = [&]() { (void)hipFree(dmv); (void)hipFree(dcc); (void)hipFree(dlag); (void)hipFree(dnil); (void)hipFree(dlist); (void)hipFree(dcount); };
+    const bool listing = n >= 32768 && Nx == n && Ny == n;
     e = hipMalloc(&dmv, (size_t)M * sizeof(double));
+    if (e == hipSuccess && listing)
+        e = hipMalloc(&dlist, (size_t)M * sizeof(long long));
+    if (e == hipSuccess && listing)
+        e = hipMalloc(&dcount, 2 * sizeof(int));
+    if (e == hipSuccess && listing)
+        e = hipMemsetAsync(dcount, 0, 2 * sizeof(int), ctx->stream);
     if (e == hipSuccess)
         e = hipMalloc(&dlag, (size_t)M * sizeof(int));
     if (e == hipSuccess)
@@ -234,6 +242,8 @@ extern "C" int muse_xcorr_groups(muse_group *gx, muse_group *gy, int32_t n, int3
         p.lag = dlag;
         p.nil_out = dnil;
         p.cc_out = dcc;
+        p.ovf_list = dlist;
+        p.ovf_count = dcount;
         LaunchTimer timer(ctx);
         e = timer.begin();
         if (e == hipSuccess)

@@ -212,9 +212,16 @@ __global__ __launch_bounds__(256, 4) void xcorr_two_sided_fold(const FusedParams
 //   sweep 2 twiddle, radix R1 over k1: 2 n cc = the IMAGINARY part; argmax.
 // Round 3 ran these lengths on the Stockham four-step with the mirrored element Z[-f] (two slices per workgroup, nine crossings of a
 // slice per pair, 8 waves per CU): 0.06 of the roofline; this form crosses the slice four times and reads the rows twice.
-template <int LOGN, bool PADDED>
+// PRE = true: as described (any pad geometry; also the kernel that redoes a listed pair).  PRE = false (Nx = Ny = n): the rows
+// are read ONCE -- sweep 1 takes d = sample - first sample unscaled and the statistics beside it, the means go with bin 0 of the
+// spectrum (Z[0] = sum dx + i sum dy: zeroed behind the first transform of row 0; N = n: no pad to keep at zero), the scale
+// 1 / (sigma_x sigma_y) comes out of Z^2 as one factor -- and a pair whose two series differ too much in scale for one unscaled square
+// (or whose magnitudes are extreme) is LISTED and redone by the PRE kernel in a second launch bounded by the on-device count, as the
+// xCorrWithX kernels do with their sigma-spread pairs: 5 instead of 6 crossings of 16 n bytes per pair.
+template <int LOGN, bool PADDED, bool PRE>
 __global__ __launch_bounds__(256, 4) void xcorr_two_sided_long(const FusedParams p, const two::PairInv iv)
 {
+    static_assert(PRE || !PADDED, "the single-read form needs N = n");
     using namespace occ4;
     using namespace fold;
     using namespace foldk;
@@ -249,7 +256,10 @@ __global__ __launch_bounds__(256, 4) void xcorr_two_sided_long(const FusedParams
         g2s[t] = p.g2[t];
     __syncthreads();
 
-    for (long long pair = blockIdx.x; pair < p.npairs; pair += gridDim.x) {
+    // optional indirection (PRE): the pairs the single-read launch listed
+    const long long total = p.pair_list ? (long long)*p.pair_count : p.npairs;
+    for (long long it = blockIdx.x; it < total; it += gridDim.x) {
+        const long long pair = p.pair_list ? p.pair_list[it] : it;
         const double *__restrict__ rx = p.xrows + pair * p.xstride;
         const double *__restrict__ ry = p.rows + pair * p.stride;
         const double KA = normalize ? rx[0] : 0.0, KB = normalize ? ry[0] : 0.0;
@@ -266,10 +276,10 @@ __global__ __launch_bounds__(256, 4) void xcorr_two_sided_long(const FusedParams
                     yb[i] = __builtin_nontemporal_load(scalar_ptr_at(ry, i * S) + (unsigned)j);
             }
         };
-        // ---------------- pass 0: statistics (the wave's running sums in SGPRs)
+        // ---------------- pass 0 (PRE): statistics (the wave's running sums in SGPRs)
         double q[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma clang loop unroll(disable)
-        for (int ch = 0; ch < CH; ch++) {
+        for (int ch = 0; PRE && ch < CH; ch++) {
             const int j = opaque(t + 256 * ch) & (S - 1);
             double xa[16], yb[16], c[4] = {0.0, 0.0, 0.0, 0.0};
             load_chunk(j, xa, yb);
@@ -291,19 +301,26 @@ __global__ __launch_bounds__(256, 4) void xcorr_two_sided_long(const FusedParams
             for (int k = 0; k < 4; k++)
                 q[k] = uniform(q[k] + wave_sum_dpp(c[k]));
         }
-        if (lane == 0) {
+        // the block's sums -> what the statistics decide
+        const auto block_stats = [&]() __attribute__((always_inline)) {
+            if (lane == 0) {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    red[4 * wave + k] = q[k];
+            }
+            __syncthreads();
 #pragma unroll
             for (int k = 0; k < 4; k++)
-                red[4 * wave + k] = q[k];
+                q[k] = uniform((red[k] + red[4 + k]) + (red[8 + k] + red[12 + k]));
+        };
+        PairScale ps{1.0, 1.0, 0.0, 0.0, 1.0, false, false};
+        if (PRE) {
+            block_stats();
+            ps = pair_scale(q, iv, normalize);
         }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            q[k] = uniform((red[k] + red[4 + k]) + (red[8 + k] + red[12 + k]));
-        const PairScale ps = pair_scale(q, iv, normalize);
-        const bool dead = ps.nil || ps.nan;
+        bool dead = ps.nil || ps.nan, redo = false;
         const double sA = dead ? 0.0 : ps.sA, sB = dead ? 0.0 : ps.sB, mA = dead ? 0.0 : ps.mA, mB = dead ? 0.0 : ps.mB;
-        const double fac = ps.fac * (1.0 / (2.0 * n)); // (pair_scale's factor assumes a spectrum already divided by n; 1 / 2n is exact)
+        double fac = ps.fac * (1.0 / (2.0 * n)); // (pair_scale's factor assumes a spectrum already divided by n; 1 / 2n is exact)
         // ---------------- sweep 1: the rows again, scaled and centred, radix R1 over m1, twiddle -> the slice
 #pragma clang loop unroll(disable)
         for (int ch = 0; ch < CH; ch++) {
@@ -319,12 +336,28 @@ __global__ __launch_bounds__(256, 4) void xcorr_two_sided_long(const FusedParams
                     wb[m] = tw_base(m, jw);
             }
             fence();
+            if (PRE) {
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const int e = j + i * S;
-                const bool vx = !PADDED || ((n - e) & (n - 1)) - padx >= 0, vy = !PADDED || e - pady >= 0;
-                v[i].x = vx ? fma(xa[i] - KA, sA, -mA) : 0.0;
-                v[i].y = vy ? fma(yb[i] - KB, sB, -mB) : 0.0;
+                for (int i = 0; i < 16; i++) {
+                    const int e = j + i * S;
+                    const bool vx = !PADDED || ((n - e) & (n - 1)) - padx >= 0, vy = !PADDED || e - pady >= 0;
+                    v[i].x = vx ? fma(xa[i] - KA, sA, -mA) : 0.0;
+                    v[i].y = vy ? fma(yb[i] - KB, sB, -mB) : 0.0;
+                }
+            } else {
+                double c[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const double da = xa[i] - KA, db = yb[i] - KB;
+                    v[i] = make_double2(da, db);
+                    c[0] += da;
+                    c[1] = fma(da, da, c[1]);
+                    c[2] += db;
+                    c[3] = fma(db, db, c[3]);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    q[k] = uniform(q[k] + wave_sum_dpp(c[k]));
             }
             sweep_dft<R1>(v);
             const unsigned js = (unsigned)(opaque(t + 256 * ch) & (S - 1));
@@ -337,6 +370,36 @@ __global__ __launch_bounds__(256, 4) void xcorr_two_sided_long(const FusedParams
                     const double2 z = cmul(v[m + brev<R1>(k1) * Q1], w);
                     *(yat((long long)(m + k1 * Q1) * S) + js) = d2v{z.x, z.y};
                 });
+            }
+        }
+        if (!PRE) { // the statistics of the single read: nil / NaN, the one factor, or the pair is listed for the kernel that scales first
+            block_stats();
+            if (normalize) {
+                bool zA, nA, zB, nB;
+                const double vA = variance(Stat{q[0], q[1]}, iv.invNx, iv.invNxm1, zA, nA), vB = variance(Stat{q[2], q[3]}, iv.invNy, iv.invNym1, zB, nB);
+                ps.nil = zA || zB; // xcorr.go:110-127
+                ps.nan = !ps.nil && (nA || nB);
+                dead = ps.nil || ps.nan;
+                const int eA = var_exp(vA), eB = var_exp(vB);
+                redo = !dead && (sigma_spread_too_wide(vA, vB) || eA > 400 || eA < -400 || eB > 400 || eB < -400);
+                double ya = __builtin_amdgcn_rsq(vA), yb = __builtin_amdgcn_rsq(vB);
+                ya = ya * fma(-0.5 * vA * ya, ya, 1.5);
+                ya = ya * fma(-0.5 * vA * ya, ya, 1.5);
+                yb = yb * fma(-0.5 * vB * yb, yb, 1.5);
+                yb = yb * fma(-0.5 * vB * yb, yb, 1.5);
+                fac = ya * yb * iv.invnm1 * (1.0 / (2.0 * n)); // xcorr.go:140: 1 / (n (n - 1)), the 1 / n with the 1 / 2 of Im Z^2
+            } else {
+                const double mA2 = q[1] * iv.invNx, mB2 = q[3] * iv.invNy; // mean squares: only their exponents matter
+                ps.nil = false;
+                ps.nan = !__builtin_isfinite(mA2) || !__builtin_isfinite(mB2);
+                dead = ps.nan;
+                const int eA = var_exp(mA2), eB = var_exp(mB2);
+                redo = !dead && mA2 > 0.0 && mB2 > 0.0 && (sigma_spread_too_wide(mA2, mB2) || eA > 400 || eA < -400 || eB > 400 || eB < -400);
+                fac = 1.0 / (2.0 * n);
+            }
+            if (redo && t == 0) {
+                const int slot = atomicAdd(p.ovf_count, 1);
+                p.ovf_list[slot] = pair;
             }
         }
         __syncthreads(); // the slice is complete
@@ -358,6 +421,10 @@ __global__ __launch_bounds__(256, 4) void xcorr_two_sided_long(const FusedParams
             gdft16_nr(v, G2Fetch{g2s, t >> 4});
             exchange_local<1>(v, xw, t);
             gdft16_nr_l2(v, G3Fetch{p.g3a, t});
+            if (!PRE && normalize && k1 == 0) { // bin 0 = sum dx + i sum dy: both means leave with it
+                v[0].x = (t == 0) ? 0.0 : v[0].x;
+                v[0].y = (t == 0) ? 0.0 : v[0].y;
+            }
 #pragma unroll
             for (int r = 0; r < 16; r += 2)
                 bf_sq(v[r], v[r + 1]);
@@ -402,7 +469,7 @@ __global__ __launch_bounds__(256, 4) void xcorr_two_sided_long(const FusedParams
             double cs = 0.0;
             int ci = 0;
             const int jc = opaque(t + 256 * ch) & (S - 1);
-            if (p.cc_out && !dead) {
+            if (p.cc_out && !dead && !redo) {
                 double *const cc = p.cc_out + pair * (long long)n;
 #pragma unroll
                 for (int i = 0; i < 16; i++)
@@ -448,7 +515,7 @@ __global__ __launch_bounds__(256, 4) void xcorr_two_sided_long(const FusedParams
             for (int x = 1; x < NW; x++)
                 IA = min(IA, redi[x]);
             const bool none = IA == 0x7fffffff;
-            const bool owner = none ? (t == 0) : (ia == IA && ma == MA);
+            const bool owner = (none ? (t == 0) : (ia == IA && ma == MA)) && !redo; // (a listed pair is written by its second pass)
             if (owner) {
                 const int idx = none ? 0 : IA;
                 double mv = (none ? red[RM + NW] : sa) * fac;
@@ -472,10 +539,17 @@ static hipError_t launch_two_long(const FusedParams &p, int num_cus, hipStream_t
     if (!p.gscratch || grid > p.gscratch_slices || !p.twl || !p.g2 || !p.g3a || !p.g3b) // one n-element slice per workgroup
         return hipErrorInvalidValue;
     const two::PairInv iv = two::pair_inv(p.Nx, p.N, 1 << LOGN);
-    if (p.Nx == (1 << LOGN) && p.N == (1 << LOGN))
-        hipLaunchKernelGGL((xcorr_two_sided_long<LOGN, false>), dim3((unsigned)grid), dim3(256), 0, stream, p, iv);
-    else
-        hipLaunchKernelGGL((xcorr_two_sided_long<LOGN, true>), dim3((unsigned)grid), dim3(256), 0, stream, p, iv);
+    if (p.Nx == (1 << LOGN) && p.N == (1 << LOGN)) {
+        if (!p.ovf_list || !p.ovf_count || p.pair_list) // (the caller zeroes *ovf_count in front of this launch)
+            return hipErrorInvalidValue;
+        hipLaunchKernelGGL((xcorr_two_sided_long<LOGN, false, false>), dim3((unsigned)grid), dim3(256), 0, stream, p, iv);
+        FusedParams q = p; // the listed pairs again, statistics first (grid size only: the loop is bounded by the count on the device)
+        q.pair_list = p.ovf_list;
+        q.pair_count = p.ovf_count;
+        const long long g2 = std::min<long long>(grid, (long long)num_cus);
+        hipLaunchKernelGGL((xcorr_two_sided_long<LOGN, false, true>), dim3((unsigned)g2), dim3(256), 0, stream, q, iv);
+    } else
+        hipLaunchKernelGGL((xcorr_two_sided_long<LOGN, true, true>), dim3((unsigned)grid), dim3(256), 0, stream, p, iv);
     return hipGetLastError();
 }
 
