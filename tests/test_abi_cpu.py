@@ -315,3 +315,21 @@ def test_merge_group_records_semantics(muse):
     assert list(s) == [40]
     s, l, v, mean = muse.merge_group_records(rec, state, 40, 10, 0.5, 0)
     assert list(s) == [40, 42]
+
+
+def test_bench_names_the_workload_it_runs():
+    """bench.py's config.workload: BASELINE configs[2] on one GPU, configs[3] when 8 x 1 M rows of 4096 samples run, and a -shaped
+    label for every other size -- an N-rank line must not call itself configs[2]"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.workload_name(1_000_000, 4096, 1, 15, 20).startswith("configs[2]: 1 ref x 1000000 series on 1 GPU")
+    assert bench.workload_name(20_001, 4096, 1, 15, 20).startswith("configs[2]-shaped")
+    w8 = bench.workload_name(1_000_000, 4096, 8, 15, 20)
+    assert w8.startswith("configs[3]: 1 ref x 8000000 series") and "over 8 GPUs" in w8 and "RCCL" in w8
+    assert bench.workload_name(1_000_000, 4096, 4, 15, 20).startswith("configs[3]-shaped: 1 ref x 4000000 series")
+    assert bench.workload_name(1_000_000, 512, 8, 15, 20).startswith("configs[3]-shaped")
+    # the fingerprint bench.py refuses stale counters by covers the kernel sources, not the host side of the library
+    sha = bench.csrc_sha()
+    assert len(sha) == 16 and sha == bench.csrc_sha()
