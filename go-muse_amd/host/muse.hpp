@@ -572,7 +572,8 @@ public:
     }
 
     // Batch.Run feeds Results one Score per label group (the reference's feed) up to this many groups
-    static constexpr int64_t EXACT_FEED_MAX_GROUPS = 65536;
+    // (settable: the tests also drive the pre-selecting path, which is otherwise only taken above this many groups)
+    static inline int64_t EXACT_FEED_MAX_GROUPS = 65536;
 
 private:
     // The reference's own feed (muse_batch.go:124-128): ONE Score per label group, in group order, through Results.Update --

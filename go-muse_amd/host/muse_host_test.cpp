@@ -488,6 +488,15 @@ int main()
         TestBatchRunShardedTables();
         TestBatchRunShardedEqualsUnsharded();
         TestBatchRunAllVisibleDevices();
+        // the same Batch tests through the pre-selecting paths a Run over more than EXACT_FEED_MAX_GROUPS label groups takes
+        // (muse_batch_run / _run_shard + muse_merge_records, _run_groups + muse_merge_group_records)
+        Batch::EXACT_FEED_MAX_GROUPS = 0;
+        TestBatchRunSimple();
+        TestBatchRunMultiDimensional();
+        TestBatchRunShardedTables();
+        TestBatchRunShardedEqualsUnsharded();
+        TestBatchRunAllVisibleDevices();
+        Batch::EXACT_FEED_MAX_GROUPS = 65536;
         TestXCorrBatchEqualsSinglePairs();
     } catch (const Error &e) {
         printf("muse::Error %d: %s\n", e.status, e.what());

@@ -1923,12 +1923,17 @@ def test_batch_run_sharded_over_engine_list(muse, eng, oracle):
     for devs in lists:
         engines = [muse.Engine(d) for d in devs]
         grp = _mirror_group(muse, rows, graphs, hosts)
-        for c, (by, max_lag, top, thr, sf) in enumerate(cases):
-            b = muse.NewBatch(refs, grp, muse.NewResults(max_lag, top, thr, sf), 8, engines=engines)
-            b.Run(by)
-            got, mean = _fetch(b)
-            assert got == expect[c][0], (devs, c)
-            assert mean == expect[c][1] or (math.isnan(mean) and math.isnan(expect[c][1]))
+        for limit in (muse.muse.EXACT_FEED_MAX_GROUPS, 0):   # the reference's feed, and the pre-selecting paths of very large Runs
+            saved, muse.muse.EXACT_FEED_MAX_GROUPS = muse.muse.EXACT_FEED_MAX_GROUPS, limit
+            try:
+                for c, (by, max_lag, top, thr, sf) in enumerate(cases):
+                    b = muse.NewBatch(refs, grp, muse.NewResults(max_lag, top, thr, sf), 8, engines=engines)
+                    b.Run(by)
+                    got, mean = _fetch(b)
+                    assert got == expect[c][0], (devs, c, limit)
+                    assert mean == expect[c][1] or (math.isnan(mean) and math.isnan(expect[c][1]))
+            finally:
+                muse.muse.EXACT_FEED_MAX_GROUPS = saved
     # fewer rows than devices (empty shards) and the reference's own table over three shards
     tiny = _mirror_group(muse, rows[:3], graphs[:3], hosts[:3])
     b1 = muse.NewBatch(refs, tiny, muse.NewResults(N, 5, 0.0, 0), 1, engine=eng)

@@ -50,8 +50,9 @@ class StubShardBatch:
         return rec, state
 
 
+@pytest.mark.parametrize("exact_feed", [True, False])
 @pytest.mark.parametrize("n_shards", [2, 3, 5])
-def test_in_process_sharded_run_equals_results_over_all_rows(monkeypatch, n_shards):
+def test_in_process_sharded_run_equals_results_over_all_rows(monkeypatch, n_shards, exact_feed):
     muse = pkg()
     from oracle import oracle_py as oracle
     rng = np.random.default_rng(17 + n_shards)
@@ -78,6 +79,9 @@ def test_in_process_sharded_run_equals_results_over_all_rows(monkeypatch, n_shar
             out.append((e, ("rows", lo, hi), lo, hi))
         return out
     monkeypatch.setattr(muse.Group, "_device_shards", fake_shards)
+    # exact_feed: one Score per label group through Results.Update (what a Run over up to 65 536 groups does); otherwise the
+    # pre-selecting paths a Run over more groups takes (per-shard top-N / per-group records + muse_merge_*)
+    monkeypatch.setattr(muse.muse, "EXACT_FEED_MAX_GROUPS", 65536 if exact_feed else 0)
     monkeypatch.setattr(muse.muse, "DeviceBatch",
                         lambda e, dg, r: StubShardBatch(muse, oracle, lag[dg[1]:dg[2]], mv[dg[1]:dg[2]], dg))
 
