@@ -1799,6 +1799,28 @@ def test_xcorr_batch_matches_oracle(eng, oracle, n, normalize):
         _check_xcorr_batch(eng, oracle, X, Y, n, normalize)
 
 
+@pytest.mark.parametrize("n", [32768, 65536])
+def test_xcorr_batch_long_series_single_read_and_its_redo_list(eng, oracle, n):
+    """n >= 32768 with N = n reads the rows once and squares the spectrum UNSCALED; pairs whose series differ by more than 2^16 in
+    sigma, or whose magnitudes are extreme (variance exponents beyond +-400: the square would leave the float64 range), are listed
+    and redone by the launch that takes the statistics first and scales by exact powers of two.  Every kind of pair in one batch,
+    more listed pairs than one workgroup takes, against the oracle (full cc vectors)."""
+    rng = np.random.default_rng(n)
+    M = 9
+    X = rng.normal(size=(M, n)) * 3.0 + 1.0
+    Y = rng.normal(size=(M, n)) - 0.5
+    Y[0] = np.roll(X[0], -11) * 2.0                        # an ordinary pair with a clear peak
+    X[1] *= 1e130; Y[1] *= 1e130                           # extreme magnitudes, equal scale: listed
+    X[2] *= 1e-130; Y[2] *= 1e-130                         # tiny magnitudes: listed
+    X[3] *= 1e12                                           # scales 10^12 apart: listed
+    Y[4] *= 1e-9                                           # listed
+    X[5] = -7.0                                            # sigma(x) == 0
+    Y[6, 5] = np.inf                                       # every cc NaN
+    X[7] *= 3e4                                            # 2^15 apart in sigma: NOT listed (inside the spread the square tolerates)
+    for normalize in (True, False):
+        _check_xcorr_batch(eng, oracle, X, Y, n, normalize)
+
+
 def test_xcorr_batch_different_lengths_and_raised_n(eng, oracle):
     rng = np.random.default_rng(77)
     M = 9
