@@ -291,14 +291,18 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def probed(fn, est_total_ms):
-        """runs fn() with the one-wave shader-clock probe resident beside it; -> (clock_stats or None, note).  The probe is a
-        measurement hook: whatever goes wrong with it, the benchmark goes on without a clock (sclk = None)."""
+    def probed(fn, est_total_ms, after=lambda: None):
+        """runs fn() with the one-wave shader-clock probe resident beside it, then after() (the caller's closing fence and clock
+        reading) BEFORE the probe's windows are collected; -> (clock_stats or None, note, the time fn() began).
+        The probe is a measurement hook: whatever goes wrong with it, the benchmark goes on without a clock (sclk = None)."""
         try:
             eng.clock_probe_start(0.5, min(50000.0, est_total_ms * 1.5 + 30.0))   # returns once the probe is resident
         except Exception as e:
+            t_begin = time.perf_counter()
             fn()
-            return None, "clock probe did not start: %s" % e
+            after()
+            return None, "clock probe did not start: %s" % e, t_begin
+        t_begin = time.perf_counter()
         try:
             fn()
         finally:
@@ -306,14 +310,15 @@ def main():
                 eng.clock_probe_stop()                      # (a host flag: a device-wide synchronize must not wait for the probe)
             except Exception:
                 pass
+        after()
         try:
             eng.synchronize()
             raw = eng.clock_probe_read()
             if os.environ.get("MUSE_BENCH_DUMP_CLOCK"):
                 np.savetxt(os.environ["MUSE_BENCH_DUMP_CLOCK"], raw, fmt="%.0f")
-            return clock_stats(raw), None
+            return clock_stats(raw), None, t_begin
         except Exception as e:
-            return None, "clock probe could not be read: %s" % e
+            return None, "clock probe could not be read: %s" % e, t_begin
 
     est_ms = 15.0 * max(1.0, M * N / 4.096e9)
     for i in range(args.warmup):
@@ -335,13 +340,18 @@ def main():
     # ---- the timed region: exactly `steps` Runs between two fences.  By default NOTHING else runs on the GPU in it; with
     # --clock-probe the one-wave probe kernel sits on its own stream beside the Runs (said on the line: clock_probe_in_timed_region)
     sclk = sclk_note = None
+    t_end = [None]
+
+    def close_region():
+        fence()
+        t_end[0] = time.perf_counter()
     t0 = time.perf_counter()
     if args.clock_probe:
-        sclk, sclk_note = probed(timed_steps, est_ms * (args.steps + 2))
+        sclk, sclk_note, t0 = probed(timed_steps, est_ms * (args.steps + 2), close_region)   # (t0: behind the probe's start-up)
     else:
         timed_steps()
-    fence()
-    dt = time.perf_counter() - t0
+        close_region()
+    dt = t_end[0] - t0
     eng.kernel_timing(False)
     out = out[0]
     k_ms, k_cnt = eng.kernel_time()
@@ -361,7 +371,7 @@ def main():
     # the clock that prices the co-bounds (rank 0): by default from an UNTIMED repeat of the same steps behind the timed region
     if rank == 0 and not args.clock_probe and not args.no_extras:
         reps = max(3, min(args.steps, 10))
-        sclk, sclk_note = probed(lambda: [db.run(None, 0, args.max_lag, args.top_n, 0.0, 0, True) for _ in range(reps)], est_ms * (reps + 2))
+        sclk, sclk_note, _ = probed(lambda: [db.run(None, 0, args.max_lag, args.top_n, 0.0, 0, True) for _ in range(reps)], est_ms * (reps + 2))
         eng.synchronize()
 
     screened, refined_pairs = db.last_run_info()
