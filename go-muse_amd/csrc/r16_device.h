@@ -240,6 +240,12 @@ __device__ __forceinline__ void issue_row_loads(RawPair &r, const FusedParams &p
 {
     const long long rA = 2 * pair;
     const long long rB = (rA + 1 < p.M) ? rA + 1 : rA;
+    // PADDED: the clamped per-lane offsets of the lower half (i < 8) are formed HERE, per call -- left visible to the compiler they
+    // are loop-invariant, get hoisted out of the pair loop into sixteen registers, are parked in scratch, and every row request then
+    // waits (vmcnt(0): scratch reloads share the counter) for the HBM request in front of it: sixteen serialised round trips per
+    // pair.  The upper half (always data: pad < 2048) needs no clamp: one scalar base per request + the shared lane offset.
+    if (PADDED)
+        asm volatile("" : "+v"(t));
     if (F32) {
         const gptr<float> ra = scalar_ptr(p.rows32 + rA * p.stride);
         const gptr<float> rb = scalar_ptr(p.rows32 + rB * p.stride);
@@ -247,10 +253,12 @@ __device__ __forceinline__ void issue_row_loads(RawPair &r, const FusedParams &p
         r.kb = (double)rb[0];
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-            if (PADDED) {
+            if (PADDED && i >= 8) {
+                r.a[i] = (double)__builtin_nontemporal_load(scalar_ptr_at(p.rows32 + rA * p.stride, 256 * i - pad) + (unsigned)(t & 255));
+                r.b[i] = (double)__builtin_nontemporal_load(scalar_ptr_at(p.rows32 + rB * p.stride, 256 * i - pad) + (unsigned)(t & 255));
+            } else if (PADDED) {
                 int j = t + 256 * i - pad;
-                if (i < 8)
-                    j = j < 0 ? 0 : j;
+                j = j < 0 ? 0 : j;
                 const unsigned ju = (unsigned)j & 4095u;
                 r.a[i] = (double)__builtin_nontemporal_load(ra + ju);
                 r.b[i] = (double)__builtin_nontemporal_load(rb + ju);
@@ -268,10 +276,12 @@ __device__ __forceinline__ void issue_row_loads(RawPair &r, const FusedParams &p
     r.kb = rb[0];
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-        if (PADDED) {
+        if (PADDED && i >= 8) { // pad < 2048 (n = nextPowOf2(N)): elements 2048.. are always data
+            r.a[i] = __builtin_nontemporal_load(scalar_ptr_at(p.rows + rA * p.stride, 256 * i - pad) + (unsigned)(t & 255));
+            r.b[i] = __builtin_nontemporal_load(scalar_ptr_at(p.rows + rB * p.stride, 256 * i - pad) + (unsigned)(t & 255));
+        } else if (PADDED) {
             int j = t + 256 * i - pad;
-            if (i < 8)             // pad < 2048 (n = nextPowOf2(N)): elements 2048.. are always valid
-                j = j < 0 ? 0 : j; // clamped: always load, the value is masked later
+            j = j < 0 ? 0 : j; // clamped: a pad position loads the row's first sample K, so d = x - K = 0 there without a mask
             // an UNSIGNED 12-bit index: saddr + 32-bit voffset addressing, no 64-bit sign extension per load
             const unsigned ju = (unsigned)j & 4095u;
             r.a[i] = __builtin_nontemporal_load(ra + ju);
