@@ -15,11 +15,14 @@ CSRC = os.path.join(ROOT, "go-muse_amd", "csrc")
 
 
 def demangle(names):
-    try:
-        out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"], input="\n".join(names), capture_output=True, text=True).stdout
-        return out.splitlines()
-    except Exception:
-        return names
+    for tool in ("/opt/rocm/lib/llvm/bin/llvm-cxxfilt", "c++filt"):
+        try:
+            out = subprocess.run([tool], input="\n".join(names), capture_output=True, text=True).stdout.splitlines()
+            if len(out) == len(names):
+                return out
+        except Exception:
+            pass
+    return names
 
 
 def resources(src, extra=()):
