@@ -315,6 +315,24 @@ def test_merge_group_records_semantics(muse):
     assert list(s) == [40]
     s, l, v, mean = muse.merge_group_records(rec, state, 40, 10, 0.5, 0)
     assert list(s) == [40, 42]
+    # the per-group part alone (muse_merge_group_winners): what Batch.Run feeds through Results.Update, one Score per label group
+    win, st = muse.merge_group_winners(rec, state)
+    assert list(st) == [1, 2, 1, 1, 0]                       # winner / the group's score is NaN / winner / winner / no member
+    assert [int(win[g]["series"]) for g in (0, 2, 3)] == [40, 42, 91]
+    assert [float(win[g]["score"]) for g in (0, 2, 3)] == [0.9, 0.7, 0.3] and [int(win[g]["lag"]) for g in (0, 2, 3)] == [2, 30, 0]
+    assert list(win["group"]) == [0, 1, 2, 3, 4]
+    # feeding those winners through the mirror's Results in group order is exactly what the filtering merge returns
+    for max_lag, top, thr in ((10, 10, 0.0), (40, 1, 0.0), (40, 10, 0.5)):
+        r = muse.NewResults(max_lag, top, thr, muse.SignFilter_ANY)
+        for g in range(G):
+            if st[g] == 1:
+                r.Update(muse.Score(muse.NewLabels({"g": str(g)}), int(win[g]["lag"]), float(win[g]["score"])))
+        got, mean_fed = r.Fetch()
+        s, l, v, mean = muse.merge_group_records(rec, state, max_lag, top, thr, 0)
+        assert [x.PercentScore for x in got] == list(v) and [x.Lag for x in got] == list(l) and mean_fed == mean
+    # one shard: the records pass through, the NaN-first state becomes "the group's score is NaN"
+    w1, s1 = muse.merge_group_winners(rec[:1], state[:1])
+    assert list(s1) == [1, 2, 0, 1, 0] and int(w1[0]["series"]) == 3 and int(w1[3]["series"]) == 5
 
 
 def test_bench_names_the_workload_it_runs():
