@@ -732,6 +732,24 @@ def NewResults(maxLag, topN, threshold, signFilter):
 EXACT_FEED_MAX_GROUPS = 65536
 
 
+def feed_group_winners(results, winners, state, labels_of):
+    """Batch.Run's ordered drain (muse_batch.go:124-128): ONE Score per label group, in group order, through the unchanged
+    Results.Update -- the reference's heap history.  winners / state: what muse_merge_group_winners returns (state 1 = the
+    group's Score; 0 no member; 2 the group's score is NaN, which never passes).  labels_of(series index, group id) -> Labels.
+    Returns the number of Scores fed."""
+    r = results
+    live = (state == 1) & (np.abs(winners["lag"].astype(np.int64)) <= r.MaxLag) & (np.abs(winners["score"]) >= r.Threshold)
+    if r.SignFilter == SignFilter_POS:
+        live &= winners["score"] > 0
+    elif r.SignFilter == SignFilter_NEG:
+        live &= winners["score"] < 0
+    fed = 0
+    for g in np.nonzero(live)[0]:      # (a Score that fails Results.passed leaves the heap untouched: not constructed)
+        r.Update(Score(labels_of(int(winners["series"][g]), int(g)), int(winners["lag"][g]), float(winners["score"][g])))
+        fed += 1
+    return fed
+
+
 class Batch:
     def __init__(self, ref, comp, results, cc, engine=None, engines=None):
         # muse_batch.go:24-28 (length check over the registry)
@@ -786,13 +804,7 @@ class Batch:
                 rec, state = self._group_winners_sharded(gid, G)
             else:
                 rec, state = merge_group_winners(*[a[None, :] for a in self._batch().run_groups(gid, G, 0, abs_scores=True)])
-            live = (state == 1) & (np.abs(rec["lag"].astype(np.int64)) <= r.MaxLag) & (np.abs(rec["score"]) >= r.Threshold)
-            if r.SignFilter == SignFilter_POS:
-                live &= rec["score"] > 0
-            elif r.SignFilter == SignFilter_NEG:
-                live &= rec["score"] < 0
-            for g in np.nonzero(live)[0]:      # (a Score that fails Results.passed leaves the heap untouched: not constructed)
-                r.Update(Score(series[int(rec["series"][g])].Labels(), int(rec["lag"][g]), float(rec["score"][g])))
+            feed_group_winners(r, rec, state, lambda i, g: series[i].Labels())
             return None
         # very many label groups (Run(nil) over a million series): the device pre-selects the TopN candidates, 24 B x TopN cross
         # the host; among EXACTLY tied scores the order / the survivor at the boundary may then differ from a full feed

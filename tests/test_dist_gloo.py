@@ -159,3 +159,143 @@ def test_shard_bounds_grouped_cuts_on_group_boundaries():
             assert max(h - l for l, h in per) <= M / world + 40      # near-even split
     with pytest.raises(ValueError):
         dist_mod.shard_bounds_grouped(np.array([0, 1, 0]), 2, 0)
+
+
+# ---------------------------------------------------------------- label groups that straddle ranks (second branch)
+def _clamp(mv, abs_scores):
+    return np.minimum(np.abs(mv), 1.0) if abs_scores else np.clip(mv, -1.0, 1.0)
+
+
+class StubGroupsBatch:
+    """DeviceBatch stand-in with muse_batch_run_groups' contract (per label group, unfiltered: this shard's winner among the
+    members whose score is a number + the group's state on this shard), scores from the CPU checker."""
+
+    def __init__(self, muse, lag, mv):
+        self.muse, self.lag, self.mv, self.calls = muse, lag, mv, 0
+
+    def run_groups(self, group_id, G, series_offset=0, abs_scores=True):
+        import math
+        self.calls += 1
+        rec = np.zeros(G, dtype=self.muse.binding.RECORD_DTYPE)
+        rec["series"] = -1
+        rec["group"] = np.arange(G)
+        state = np.zeros(G, dtype=np.uint8)
+        s = _clamp(self.mv, abs_scores)
+        for i, g in enumerate(np.asarray(group_id)):
+            if state[g] == 0:
+                state[g] = 2 if math.isnan(s[i]) else 1
+            if math.isnan(s[i]):
+                continue
+            if rec[g]["series"] < 0 or abs(s[i]) > abs(rec[g]["score"]):     # strictly greater replaces: the first wins ties
+                rec[g] = (i + series_offset, s[i], self.lag[i], g)
+        return rec, state
+
+
+def _grouped_workload():
+    """two (ref, Group) pairs of different lengths (BASELINE configs[4] in small): graphs INTERLEAVED over the rows so that
+    every label group has members on every rank, planted bit-identical series in different graphs (exact ties at the top),
+    a graph whose first member scores NaN, a constant series"""
+    out = []
+    for k, (M, N, graphs) in enumerate(((603, 64, 41), (410, 48, 29))):
+        rng = np.random.default_rng(77 + k)
+        ref = rng.standard_normal(N)
+        rows = rng.standard_normal((M, N))
+        rows[::5] += 1.3 * np.roll(ref, 2)
+        strong = 1.7 * ref + 0.05 * rng.standard_normal(N)
+        for i in (3, 100, 101, 222, 345, 346, 347, 401):       # bit-identical series in eight different graphs (i % graphs differ)
+            rows[i] = strong
+        rows[7, 5] = np.nan                                     # series 7 is the FIRST member of graph 7: the group scores NaN
+        rows[7 + 3 * graphs, 1] = np.nan                        # a later NaN member of the same graph (another rank)
+        rows[11] = 0.25                                         # sigma == 0
+        gid = (np.arange(M) % graphs).astype(np.int32)          # interleaved: graph g = rows g, g + graphs, g + 2 graphs, ...
+        out.append((ref, rows, gid, graphs))
+    return out
+
+
+def _grouped_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        muse = pkg()
+        from oracle import oracle_py
+        D = muse.dist
+        work = _grouped_workload()
+        scores = [oracle_py.batch_scores(ref, rows)[:2] for ref, rows, _, _ in work]
+        ok = {}
+        # (a) one Batch, fresh Results, four filter settings, both exchange paths (the all_gather + exact feed, and the
+        #     all_to_all slices a Run over more than EXACT_FEED_MAX_GROUPS label groups takes -- forced by limit 0)
+        ref, rows, gid, G = work[0]
+        lag, mv = scores[0]
+        lo, hi = D.shard_bounds(len(rows), world, rank)
+        for max_lag, top, thr, sf in ((64, 6, 0.0, 0), (64, 50, 0.0, 0), (4, 5, 0.05, 1), (64, 3, 0.2, -1)):
+            want = oracle_py.results(lag, mv, gid, G, True, max_lag, top, thr, sf)
+            for limit in (None, 0):
+                stub = StubGroupsBatch(muse, lag[lo:hi], mv[lo:hi])
+                got = D.run_grouped_sharded(stub, lo, gid[lo:hi], G, max_lag, top, thr, sf, True, exact_feed_max_groups=limit,
+                                            with_groups=True)
+                same = (got[1].tolist() == want[1].tolist() and got[2].tolist() == want[2].tolist()
+                        and (got[3] == want[3] or (np.isnan(got[3]) and np.isnan(want[3])))
+                        and got[4].tolist() == gid[got[0]].tolist() and stub.calls == 1)
+                if limit is None:      # the exact feed: the very series the reference's feed keeps, tie for tie
+                    same = same and got[0].tolist() == want[0].tolist()
+                else:                  # pre-selected slices: equal scores may swap; the multiset of (score, lag) is the reference's
+                    same = same and sorted(zip(np.abs(mv[got[0]]).clip(max=1).tolist(), lag[got[0]].tolist())) == \
+                        sorted(zip(want[2].tolist(), want[1].tolist()))
+                ok["run %s limit %s" % ((max_lag, top, thr, sf), limit)] = bool(same)
+        # (b) configs[4]'s flow: two Batches of different lengths Run(["graph"]) into ONE shared Results through ShardedBatch,
+        #     one Fetch: what the reference's feed gives over the union (batch by batch, group by group)
+        shared = muse.NewResults(64, 7, 0.0, muse.SignFilter_ANY)
+        all_lag, all_mv, all_gid, base = [], [], [], 0
+        for k, ((ref, rows, gid, G), (lag, mv)) in enumerate(zip(work, scores)):
+            lo, hi = D.shard_bounds(len(rows), world, rank)
+            sb = D.ShardedBatch(StubGroupsBatch(muse, lag[lo:hi], mv[lo:hi]), lo, shared,
+                                lambda i, g, k=k: muse.NewLabels({"batch": str(k), "row": str(i), "graph": "g%d" % g}))
+            sb.Run(gid[lo:hi], G)
+            all_lag.append(lag)
+            all_mv.append(mv)
+            all_gid.append(gid + base)
+            base += G
+        got, mean = shared.Fetch()
+        oi, ol, osc, omean = oracle_py.results(np.concatenate(all_lag), np.concatenate(all_mv), np.concatenate(all_gid), base,
+                                               True, 64, 7, 0.0, 0)
+        M0 = len(work[0][1])
+        expect = [("0" if i < M0 else "1", str(i if i < M0 else i - M0), int(l), float(v)) for i, l, v in zip(oi, ol, osc)]
+        have = [(s.Labels.labels["batch"], s.Labels.labels["row"], s.Lag, s.PercentScore) for s in got]
+        ok["shared Results"] = have == expect and mean == omean
+        ok["ties at the top"] = len({h[3] for h in have[:5]}) == 1           # (the planted copies really tie)
+        q.put((rank, ok, [h[:2] for h in have]))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_grouped_world(world):
+    muse = pkg()
+    muse.build.build()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grouped_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_grouped_run_with_straddling_label_groups_gloo(world):
+    """Batch.Run(["graph"]) over a Group sharded by rows with one process per GPU, graphs interleaved over all ranks, exact
+    ties planted: every rank ends with the reference's Results over ALL rows (oracle.results = muse_batch.go:56-93,
+    results.go:46-87 restated), through both exchange paths and through a Results shared by two Batches (configs[4])."""
+    res = _run_grouped_world(world)
+    firsts = None
+    for rank, ok, have in res:
+        for name, good in ok.items():
+            assert good, (rank, name)
+        firsts = firsts or have
+        assert have == firsts                                       # every rank holds the same Results
