@@ -198,6 +198,106 @@ def workload_name(M, N, n_gpus, max_lag, top_n):
         tag, M * n_gpus, n_gpus, M, tail)
 
 
+CONFIG5_LENGTHS = (512, 1000, 4096, 5000, 16384, 65536)
+
+
+def config5_leg(pkg, eng, args, rank, n_gpus, use_dist, tdev, M, N, counters):
+    """BASELINE configs[4] as ONE workload, at any number of ranks: a mixed-length Group is six (ref, Group) pairs, one per
+    length (group.go:45-51 and muse_batch.go:24-28 allow one length per Group), each sharded by rows over the ranks (~4 GB per
+    GPU; the headline's length: as many rows per GPU as the headline), label groups of 50 series ("graph") INTERLEAVED over the
+    rows -- graph g = global rows g, g + G, g + 2G, ... -- so that every label group has members on every rank; every Batch
+    Run(["graph"]) into ONE shared Results (results.go:55-72), one Fetch at the end.  Timed per length: the whole Run as the
+    public API pays it (dist.ShardedBatch.Run: fused kernel + per-group maxima + G x 25 B copy-back + exchange of the ranks'
+    per-group records + merge + the host feed of the shared heap, one Score per label group in group order up to 65 536 groups)
+    between two barriers, the maximum over the ranks; and, by HIP events on each rank's own stream, the fused kernel alone
+    (the SLOWEST rank's -> share of the HBM roofline on 8 N + 16 bytes per series).  ALL ranks call this (it holds collectives);
+    every rank returns the objects, rank 0 prints them.  Parity of exactly this flow: tests/test_dist_gloo.py
+    (test_grouped_run_with_straddling_label_groups_gloo) and tests/test_gpu_parity.py
+    (test_config5_mixed_lengths_one_shared_results, test_sharded_batch_run_on_one_rank_equals_batch_run)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    D = pkg.dist
+    per_len, shared, carry = [], pkg.NewResults(args.max_lag, args.top_n, 0.0, 0), []
+    run_s_total, rows_total = 0.0, 0
+
+    def fence():
+        eng.synchronize()
+        if use_dist:
+            dist.barrier()
+
+    for Nl in CONFIG5_LENGTHS:
+        try:
+            # (the leg of the headline's own length runs on as many rows as the headline: every launch of that kernel
+            # instantiation in this process then has ONE workload, and its rocprofv3 averages mean what they say)
+            rows_l = M if Nl == N else max(2048, min(400_000, (1 << 32) // (8 * Nl)))
+            if args.config5_rows:
+                rows_l = min(rows_l, args.config5_rows)
+            rows_all = rows_l * n_gpus
+            # (without the planted exact copies of the reference: the shared top-N is then a field of distinct scores from
+            # all six lengths, not twenty 1.0s from the first)
+            dgl, refl = pkg.DeviceGroup.synthetic(eng, rows_l, Nl, seed=0x6D757365, global_first=rank * rows_l, copies=False)
+            dbl = pkg.DeviceBatch(eng, dgl, refl)
+            Gl = max(1, rows_all // 50)
+            gidl = ((rank * rows_l + np.arange(rows_l, dtype=np.int64)) % Gl).astype(np.int32)
+            sb = D.ShardedBatch(dbl, rank * rows_l, shared,
+                                lambda i, g, Nl=Nl: pkg.NewLabels({"len": str(Nl), "graph": "g%d" % g, "row": str(i)}), device=tdev)
+            sb.Run(gidl, Gl)
+            fence()
+            eng.kernel_time()
+            eng.kernel_timing(True)
+            reps = 3
+            t1 = time.perf_counter()
+            for r_ in range(reps):
+                shared.Fetch()                                          # every repeat starts from what the EARLIER lengths left
+                for sc_ in carry:
+                    shared.Update(sc_)
+                sb.Run(gidl, Gl)
+            fence()
+            dtl = (time.perf_counter() - t1) / reps
+            eng.kernel_timing(False)
+            kl_ms, kl_cnt = eng.kernel_time()
+            mine = {"run_s": dtl, "kernel_ms_avg": kl_ms / max(kl_cnt, 1)}
+            allr = [mine]
+            if use_dist:
+                allr = [None] * n_gpus
+                dist.all_gather_object(allr, mine)
+            dtl = max(x["run_s"] for x in allr)
+            kms = [x["kernel_ms_avg"] for x in allr]
+            kl_s = max(kms) * 1e-3
+            carry = shared.Fetch()[0]                                   # (Fetch drains, results.go:75-87: put it back)
+            for sc_ in carry:
+                shared.Update(sc_)
+            exact = Gl <= pkg.muse.EXACT_FEED_MAX_GROUPS
+            e_ = {"N": Nl, "fft_len": dbl.n, "rows": rows_l, "rows_total": rows_all, "length": Nl, "label_groups": Gl,
+                  "exchange": ("all_gather of G x 25 B per rank + one Score per label group through Results.Update (the reference's feed)"
+                               if exact else "all_to_all of G/W-group slices + per-slice top-N + gather of top_n x 24 B"),
+                  "kernel": eng.kernel_name(dbl), "run_ms": dtl * 1e3, "kernel_ms_avg": kl_s * 1e3,
+                  "kernel_ms_per_rank": {"min": min(kms), "max": max(kms)},
+                  "series_per_s": rows_all / dtl, "series_per_s_kernel": rows_all / kl_s if kl_s > 0 else None,
+                  "roofline_frac": rows_l * (8.0 * Nl + 16.0) / kl_s / 1e9 / HBM_PEAK_GBPS if kl_s > 0 else None}
+            counters.attach(e_, eng.kernel_name(dbl), rows_l, Nl, rows_l * (8.0 * Nl + 16.0))
+            per_len.append(e_)
+            run_s_total += dtl
+            rows_total += rows_all
+            dbl.close()
+            dgl.close()
+        except Exception as e:
+            if use_dist:
+                raise                                                   # (a rank that drops out of a collective hangs the others)
+            per_len.append({"N": Nl, "error": str(e)})
+    top, mean_abs = shared.Fetch()
+    tag = "configs[4]" if n_gpus == 8 else ("configs[4], single-GPU half" if n_gpus == 1 else "configs[4]-shaped")
+    mixed = {"value": rows_total / run_s_total if run_s_total > 0 else None, "unit": "series/s", "series_total": rows_total,
+             "n_gpus": n_gpus, "ms_total": run_s_total * 1e3, "lengths": [e_["N"] for e_ in per_len if "error" not in e_],
+             "shared_results": {"top_n": args.top_n, "fetched": len(top), "mean_abs_score": mean_abs,
+                                "lengths_in_top_n": sorted({s_.Labels.labels["len"] for s_ in top}, key=int)},
+             "note": "%s: six (ref, Group) pairs, every Group sharded by rows over %d rank(s) with its 50-series label groups interleaved "
+                     "over ALL ranks, Run([\"graph\"]) each through dist.ShardedBatch (muse_batch_run_groups + exchange + muse_merge_group_winners "
+                     "+ host feed) into ONE Results, one Fetch; per-length Run and kernel times in config5_lengths" % (tag, n_gpus)}
+    return per_len, mixed
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -224,6 +324,8 @@ def main():
                          "row counts, which would blur that kernel's per-launch counter means)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the extra objects (filter_and_refine_run, f32_storage_group, many_references, config5_lengths)")
+    ap.add_argument("--with-config5", action="store_true", help="run the config5 leg even with --no-extras")
+    ap.add_argument("--config5-rows", type=int, default=0, help="cap the rows per GPU and length of the config5 leg (tests)")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the RCCL gather path even with one rank (rehearsal on a 1-GPU box)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -376,6 +478,10 @@ def main():
 
     screened, refined_pairs = db.last_run_info()
     assert not screened, "the headline Run must not take the fp32 filter-and-refine path"
+    # BASELINE configs[4] (mixed lengths, label-grouped, one shared Results): every rank takes part, rank 0 reports
+    c5 = None
+    if (not args.no_extras or args.with_config5) and "config5" not in args.skip_extra:
+        c5 = config5_leg(pkg, eng, args, rank, n_gpus, use_dist, tdev, M, N, Counters())
     if rank == 0:
         total_pairs = float(M) * n_gpus * args.steps
         value = total_pairs / dt
@@ -627,73 +733,8 @@ def main():
                     g.close()
             except Exception as e:
                 line["in_process_shards"] = {"error": str(e)}
-        if extras:
-            # BASELINE configs[4] as ONE workload (single-GPU half): a mixed-length Group is six (ref, Group) pairs, one per length
-            # (group.go:45-51 and muse_batch.go:24-28 allow one length per Group), each ~4 GB resident (the headline's length: as
-            # many rows as the headline), label groups of 50 series
-            # ("graph"), every Batch Run(["graph"]) into ONE shared Results (results.go:55-72) and one Fetch at the end.  Timed per
-            # length: the whole Run (fused kernel + group max + filter + top-N + copy-back + the host feed of the shared heap) and,
-            # by HIP events, its fused kernel alone (-> share of the HBM roofline on 8 N + 16 bytes per series, with the measured
-            # traffic of that kernel beside it).  Parity of exactly this flow: tests/test_gpu_parity.py,
-            # test_config5_mixed_lengths_one_shared_results.
-            per_len, shared, carry = [], pkg.NewResults(args.max_lag, args.top_n, 0.0, 0), []
-            run_s_total, rows_total = 0.0, 0
-            for Nl in (512, 1000, 4096, 5000, 16384, 65536):
-                try:
-                    # (the leg of the headline's own length runs on as many rows as the headline: every launch of that kernel
-                    # instantiation in this process then has ONE workload, and its rocprofv3 averages mean what they say)
-                    rows_l = M if Nl == N else max(2048, min(400_000, (1 << 32) // (8 * Nl)))
-                    # (without the planted exact copies of the reference: the shared top-N is then a field of distinct scores from
-                    # all six lengths, not twenty 1.0s from the first)
-                    dgl, refl = pkg.DeviceGroup.synthetic(eng, rows_l, Nl, seed=0x6D757365, copies=False)
-                    dbl = pkg.DeviceBatch(eng, dgl, refl)
-                    Gl = (rows_l + 49) // 50
-                    gidl = (np.arange(rows_l, dtype=np.int64) // 50).astype(np.int32)
-
-                    def run_len():
-                        idx, lg, sc, _ = dbl.run(gidl, Gl, args.max_lag, args.top_n, 0.0, 0, True)
-                        for k in np.argsort(gidl[idx], kind="stable"):          # the ordered drain, muse_batch.go:124-128
-                            shared.Update(pkg.Score(pkg.NewLabels({"len": str(Nl), "graph": "g%d" % int(gidl[idx[k]]), "row": str(int(idx[k]))}),
-                                                    int(lg[k]), float(sc[k])))
-                    run_len()
-                    eng.synchronize()
-                    eng.kernel_time()
-                    eng.kernel_timing(True)
-                    reps = 3
-                    t1 = time.perf_counter()
-                    for r_ in range(reps):
-                        shared.Fetch()                                          # every repeat starts from what the EARLIER lengths left
-                        for sc_ in carry:
-                            shared.Update(sc_)
-                        run_len()
-                    eng.synchronize()
-                    dtl = (time.perf_counter() - t1) / reps
-                    eng.kernel_timing(False)
-                    kl_ms, kl_cnt = eng.kernel_time()
-                    kl_s = kl_ms / max(kl_cnt, 1) * 1e-3
-                    carry = shared.Fetch()[0]                                   # (Fetch drains, results.go:75-87: put it back)
-                    for sc_ in carry:
-                        shared.Update(sc_)
-                    per_len.append({"N": Nl, "fft_len": dbl.n, "rows": rows_l, "length": Nl, "label_groups": Gl, "kernel": eng.kernel_name(dbl),
-                                    "run_ms": dtl * 1e3, "kernel_ms_avg": kl_s * 1e3, "series_per_s": rows_l / dtl,
-                                    "series_per_s_kernel": rows_l / kl_s,
-                                    "roofline_frac": rows_l * (8.0 * Nl + 16.0) / kl_s / 1e9 / HBM_PEAK_GBPS})
-                    counters.attach(per_len[-1], eng.kernel_name(dbl), rows_l, Nl, rows_l * (8.0 * Nl + 16.0))
-                    run_s_total += dtl
-                    rows_total += rows_l
-                    dbl.close()
-                    dgl.close()
-                except Exception as e:
-                    per_len.append({"N": Nl, "error": str(e)})
-            line["config5_lengths"] = per_len
-            top, mean_abs = shared.Fetch()
-            line["config5_mixed_run"] = {
-                "value": rows_total / run_s_total if run_s_total > 0 else None, "unit": "series/s", "series_total": rows_total,
-                "ms_total": run_s_total * 1e3, "lengths": [e_["N"] for e_ in per_len if "error" not in e_],
-                "shared_results": {"top_n": args.top_n, "fetched": len(top), "mean_abs_score": mean_abs,
-                                   "lengths_in_top_n": sorted({s_.Labels.labels["len"] for s_ in top}, key=int)},
-                "note": "configs[4], single-GPU half: six (ref, Group) pairs, Run([\"graph\"]) each (muse_batch_run with 50-series label groups) "
-                        "into ONE Results, one Fetch; per-length Run and kernel times in config5_lengths"}
+        if c5 is not None:
+            line["config5_lengths"], line["config5_mixed_run"] = c5
         if not args.no_cpu_baseline:
             # (at every N, on rank 0's host cores over a sample of rank 0's shard: the other ranks wait at the closing barrier)
             line["cpu_baseline"] = cpu_baseline(dg, ref, N)

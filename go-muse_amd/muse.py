@@ -743,10 +743,26 @@ def feed_group_winners(results, winners, state, labels_of):
         live &= winners["score"] > 0
     elif r.SignFilter == SignFilter_NEG:
         live &= winners["score"] < 0
-    fed = 0
-    for g in np.nonzero(live)[0]:      # (a Score that fails Results.passed leaves the heap untouched: not constructed)
+    # A Score that fails Results.passed leaves the heap untouched, and so does one that is not STRICTLY greater than the minimum
+    # of a full heap (results.go:62-66) -- a minimum that only rises during a feed.  Neither is constructed: the Scores that do
+    # reach Update arrive in group order, so the heap's history (and with it the order among exact ties) is the full feed's.
+    cand = np.nonzero(live)[0]
+    mag = np.abs(winners["score"][cand])
+    fed, k, CH = 0, 0, 8192
+    while k < len(cand):
+        if len(r.scores) == r.TopN:
+            if r.TopN <= 0:
+                break                  # (TopN = 0: Update never pushes)
+            floor = abs(r.scores[0].PercentScore)
+            hit = np.nonzero(mag[k:k + CH] > floor)[0]
+            if len(hit) == 0:
+                k += CH
+                continue
+            k += int(hit[0])
+        g = cand[k]
         r.Update(Score(labels_of(int(winners["series"][g]), int(g)), int(winners["lag"][g]), float(winners["score"][g])))
         fed += 1
+        k += 1
     return fed
 
 

@@ -1398,9 +1398,62 @@ def test_run_sharded_over_rccl_world_size_1(muse, eng, oracle):
             assert (got[0] - off).tolist() == exp[0].tolist() and got[1].tolist() == exp[1].tolist()
             np.testing.assert_allclose(got[2], exp[2], rtol=1e-12, atol=0)
             assert got[3] == exp[3]
+        # label groups on any rank (second branch): the all_gather + exact-feed path and the all_to_all slices of a
+        # Run over more than 65 536 label groups (forced), both over RCCL with device tensors; interleaved graphs, an offset
+        gid2 = (np.arange(40000) % 800).astype(np.int32)
+        exp = oracle.results(lag, mv, gid2, 800, True, 15, 20, 0.0, 0)
+        for limit in (None, 0):
+            got = muse.dist.run_grouped_sharded(db, 5000, gid2, 800, 15, 20, 0.0, 0, True, device=torch.device("cuda", 0),
+                                                exact_feed_max_groups=limit, with_groups=True)
+            assert (got[0] - 5000).tolist() == exp[0].tolist() and got[1].tolist() == exp[1].tolist()
+            np.testing.assert_allclose(got[2], exp[2], rtol=1e-12, atol=0)
+            assert got[3] == exp[3] and got[4].tolist() == gid2[exp[0]].tolist()
         db.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_sharded_batch_run_on_one_rank_equals_batch_run(muse, eng, oracle):
+    """dist.ShardedBatch (what bench.py's config5 leg and a one-process-per-GPU host run) against the mirror's Batch.Run over the
+    same series: two Batches of different lengths into ONE shared Results each way, interleaved graphs, bit-identical planted
+    series in different graphs (exact ties at the top), a NaN-first graph -- the same Scores in the same order, and the
+    oracle's Results over the union."""
+    shared_a, shared_b = muse.NewResults(30, 9, 0.0, muse.SignFilter_ANY), muse.NewResults(30, 9, 0.0, muse.SignFilter_ANY)
+    all_lag, all_mv, all_gid, base, labels = [], [], [], 0, []
+    for k, (M, N, graphs) in enumerate(((900, 1000, 45), (600, 512, 30))):
+        rng = np.random.default_rng(300 + k)
+        t = np.arange(N)
+        ref_y = 1.5 * (np.abs(t - N // 2) <= 5) + 0.1 * rng.standard_normal(N)
+        rows = rng.uniform(-2, 2, size=(M, 1)) * (np.abs(t[None, :] - N // 2 - rng.integers(-20, 21, size=(M, 1))) <= 6) + 0.3 * rng.standard_normal((M, N))
+        strong = 1.2 * ref_y + 0.05 * rng.standard_normal(N)
+        for i in (2, 3, 100, 101, 250, 251, 444, 445, 598, 599):
+            rows[i] = strong                                   # bit-identical series (pairs share one transform: identical bits)
+        rows[7, 5] = np.nan                                    # first member of graph 7
+        gid = (np.arange(M) % graphs).astype(np.int32)
+        labs = [{"b": str(k), "graph": "g%02d" % (i % graphs), "host": "h%d" % (i // graphs)} for i in range(M)]
+        comp = muse.NewGroup("c%d" % k)
+        comp.Add(*[muse.NewSeries(rows[i], muse.NewLabels(labs[i])) for i in range(M)])
+        muse.NewBatch(muse.NewSeries(ref_y, muse.NewLabels({"graph": "ref"})), comp, shared_a, 4, engine=eng).Run(["graph"])
+        dg = muse.DeviceGroup.from_rows(eng, rows)
+        db = muse.DeviceBatch(eng, dg, ref_y)
+        muse.dist.ShardedBatch(db, 0, shared_b, lambda i, g, labs=labs: muse.NewLabels(labs[i])).Run(gid, graphs)
+        lag, mv = db.scores()
+        olag, omv, gap = oracle.batch_scores(ref_y, rows)
+        assert_scores_match(lag, mv, olag, omv, gap)
+        all_lag.append(lag)
+        all_mv.append(mv)
+        all_gid.append(gid + base)
+        base += graphs
+        labels += labs
+        db.close()
+        dg.close()
+    ga, ma = shared_a.Fetch()
+    gb, mb = shared_b.Fetch()
+    key = lambda sc: [(s.Labels.labels, s.Lag, s.PercentScore) for s in sc]
+    assert key(ga) == key(gb) and ma == mb and len(ga) == 9
+    oi, ol, osc, omean = oracle.results(np.concatenate(all_lag), np.concatenate(all_mv), np.concatenate(all_gid), base, True, 30, 9, 0.0, 0)
+    assert key(gb) == [(labels[i], int(l), float(v)) for i, l, v in zip(oi, ol, osc)] and mb == omean
+    assert len({s.PercentScore for s in gb[:5]}) <= 2              # (the planted copies tie)
 
 
 def test_costly_filters_switch_off_only_themselves(muse, eng, oracle):
@@ -1691,7 +1744,8 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
     env["MASTER_PORT"] = "29641"
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rows", "20001", "--steps", "2", "--warmup", "1",
-                        "--no-extras", "--rehearse-on-one-gpu"], capture_output=True, text=True, timeout=600, env=env)
+                        "--no-extras", "--with-config5", "--config5-rows", "3001", "--rehearse-on-one-gpu"],
+                       capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     assert r.stdout.count("\n") == 1 and r.stdout.startswith("{"), r.stdout[-2000:]   # stdout = rank 0's ONE line, nothing else
     d = json.loads(r.stdout)
@@ -1715,6 +1769,15 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     assert d["clock_probe_in_timed_region"] is False
     cb = d["cpu_baseline"]
     assert cb["value"] > 0 and cb["kind"] == "port" and cb["cores"] >= 1 and cb["single_thread"]["value"] > 0
+    # BASELINE configs[4] at N ranks: six lengths, every Group sharded over both ranks with its label groups on both, one shared Results
+    c5, legs = d["config5_mixed_run"], d["config5_lengths"]
+    assert c5["n_gpus"] == 2 and c5["lengths"] == [512, 1000, 4096, 5000, 16384, 65536] and c5["value"] > 0
+    assert c5["shared_results"]["fetched"] == 20 and len(c5["shared_results"]["lengths_in_top_n"]) >= 2
+    for e in legs:
+        assert "error" not in e, e
+        assert e["rows_total"] == 2 * e["rows"] and e["label_groups"] == e["rows_total"] // 50
+        assert abs(e["kernel_ms_avg"] - e["kernel_ms_per_rank"]["max"]) < 1e-9 and e["kernel_ms_avg"] > 0 and e["run_ms"] > 0
+        assert e["exchange"].startswith("all_gather")
 
 
 def test_many_references_on_a_float32_storage_group(muse, eng, oracle):

@@ -104,3 +104,33 @@ def test_in_process_sharded_run_equals_results_over_all_rows(monkeypatch, n_shar
         assert [s.Labels.ID() for s in got] == [series[int(i)].Labels().ID() for i in oi]
         assert mean == omean or (math.isnan(mean) and math.isnan(omean))
         assert all(s.Labels.Get("graph")[0] != "g5" for s in got) or by != ["graph"]   # NaN-first group never passes
+
+
+def test_feed_group_winners_skips_only_no_op_updates():
+    """feed_group_winners never constructs a Score that Results.Update would ignore (fails passed(), or not strictly above a full
+    heap's rising minimum): the heap it leaves must be the plain loop's -- order among exact ties included -- for fresh and
+    pre-filled Results, heavy ties, every filter."""
+    muse = pkg()
+    rng = np.random.default_rng(5)
+    for trial in range(40):
+        G = int(rng.integers(1, 30000 if trial % 8 == 0 else 400))
+        win = np.zeros(G, dtype=muse.binding.RECORD_DTYPE)
+        win["series"] = rng.permutation(G)
+        win["score"] = rng.choice([1.0, 0.5, 0.25, -0.5, 0.0], size=G) if trial % 2 else np.round(rng.uniform(-1, 1, G), 2)
+        win["lag"] = rng.integers(-20, 21, size=G)
+        win["group"] = np.arange(G)
+        state = rng.choice([0, 1, 1, 1, 2], size=G).astype(np.uint8)
+        top, max_lag, thr, sf = int(rng.integers(0, 25)), int(rng.integers(0, 25)), float(rng.choice([0.0, 0.3])), int(rng.integers(-1, 2))
+        a, b = muse.NewResults(max_lag, top, thr, sf), muse.NewResults(max_lag, top, thr, sf)
+        for k in range(int(rng.integers(0, 30))):              # history from an earlier Run
+            a.Update(muse.Score(muse.NewLabels({"pre": str(k)}), 0, [0.5, 1.0, 0.75][k % 3]))
+        b.scores = [muse.Score(s.Labels, s.Lag, s.PercentScore) for s in a.scores]   # identical starting heaps, slot for slot
+        lab = lambda i, g: muse.NewLabels({"row": str(i), "g": str(g)})
+        muse.muse.feed_group_winners(a, win, state, lab)
+        for g in range(G):                                     # the plain feed: every group's Score through Update
+            if state[g] == 1:
+                b.Update(muse.Score(lab(int(win["series"][g]), g), int(win["lag"][g]), float(win["score"][g])))
+        ga, ma = a.Fetch()
+        gb, mb = b.Fetch()
+        assert [(s.Labels.labels, s.Lag, s.PercentScore) for s in ga] == [(s.Labels.labels, s.Lag, s.PercentScore) for s in gb]
+        assert ma == mb or (math.isnan(ma) and math.isnan(mb))
