@@ -63,6 +63,7 @@ SIGNATURES = {
     "muse_group_free": (ctypes.c_int, [_vp]),
     "muse_batch_create": (ctypes.c_int, [_vp, _vp, _dp, _i32, ctypes.POINTER(_vp)]),
     "muse_batch_create_like": (ctypes.c_int, [_vp, _vp, ctypes.POINTER(_vp)]),
+    "muse_batch_run_rows": (ctypes.c_int, [_vp, _dp, _i64, _i64, _i32, _recp, ctypes.POINTER(ctypes.c_uint8)]),
     "muse_batch_fft_len": (ctypes.c_int, [_vp, _i32p]),
     "muse_batch_spectrum": (ctypes.c_int, [_vp, _dp]),
     "muse_batch_score": (ctypes.c_int, [_vp]),

@@ -89,7 +89,7 @@ hipError_t ensure_twl(muse_ctx *ctx, int64_t n)
     return e;
 }
 
-static void adopt_spectrum(muse_batch *b)
+void adopt_spectrum(muse_batch *b)
 {
     b->X = b->sp->X;
     b->xc = b->sp->xc;
@@ -495,6 +495,10 @@ extern "C" int muse_batch_free(muse_batch *b)
         (void)hipHostFree(b->cand_host);
     if (b->cnt_host)
         (void)hipHostFree(b->cnt_host);
+    if (b->rec_host)
+        (void)hipHostFree(b->rec_host);
+    if (b->key_host)
+        (void)hipHostFree(b->key_host);
     (void)hipFree(b->cnt);
     (void)hipFree(b->scr_flags);
     (void)hipFree(b->scr_var);

@@ -205,6 +205,7 @@ void ctx_release(muse_ctx *ctx)
         (void)hipStreamSynchronize(ctx->copy_stream);
         (void)hipStreamDestroy(ctx->copy_stream);
     }
+    rows_slots_free(ctx);
     for (auto *ev : {&ctx->events, &ctx->redo_events})
         for (auto &e : *ev) {
             (void)hipEventDestroy(e.first);

@@ -81,6 +81,10 @@ struct muse_ctx {
     double total_ms = 0.0, redo_ms = 0.0;
     int64_t launches = 0, redo_launches = 0;
     char pci[32] = {0}; // PCI bus id of the device ("0000:05:00.0"): tells two contexts on one GPU from two GPUs
+    // muse_batch_run_rows (capi_rows.hip): idle slots (RowsSlot *) -- pinned staging, device rows, score buffers, a pinned
+    // result record and an event each -- so that a Muse.Run allocates nothing in steady state
+    std::vector<void *> rows_slots;
+    std::mutex rows_mu;
     // Handles may be released in any order (Go finalizers, Python GC): the
     // context lives until it is destroyed AND its last group/batch is freed.
     std::atomic<int> refs{1};
@@ -159,6 +163,10 @@ struct muse_batch {
     muse_record *cand_host = nullptr;
     int *cnt_host = nullptr;
     int64_t cand_host_cap = 0, cnt_host_cap = 0;
+    // pinned host images of rec / selkey: a Run over up to EXACT_FEED_MAX_GROUPS groups feeds the heap one Score per group
+    muse_record *rec_host = nullptr;
+    unsigned long long *key_host = nullptr;
+    int64_t rec_host_cap = 0;
     // filter-and-refine Run
     unsigned *scr_flags = nullptr;      // [M] SCR_* bits of the screening pass
     double *scr_var = nullptr;          // [M] sample variances from the screening pass
@@ -241,7 +249,9 @@ void fill_twiddle(std::vector<double2> &v, size_t i, long long num, long long de
 void ctx_release(muse_ctx *ctx);                       // capi_context.hip: drops one reference, frees the context with the last
 int group_ready(muse_group *g);                        // capi_group.hip: staged rows uploaded, the compute stream behind the copies
 void group_release(muse_group *g);
+void rows_slots_free(muse_ctx *ctx);                   // capi_rows.hip: the idle slots of muse_batch_run_rows (streams idle)
 int ilog2(int64_t n);                                  // capi_batch.hip
+void adopt_spectrum(muse_batch *b);                    // the batch's table pointers from its muse_spectrum
 int build_spectrum(muse_ctx *ctx, const double *ref_host, int N, int n, int normalize, double x_scale,
                           double xc_scale, double2 *X, double2 *xc, float2 *xcf, double *xs, int *zero_std);
 hipError_t ensure_gscratch(muse_ctx *ctx, int64_t n, int slices_per_cu = muse::GSCRATCH_SLICES_PER_CU);
@@ -249,6 +259,8 @@ hipError_t ensure_twl(muse_ctx *ctx, int64_t n);
 int ensure_scores(muse_batch *b);
 muse::FusedParams base_params(muse_batch *b);
 int ensure_select_ws(muse_batch *b, int64_t M, int64_t G, bool with_gid, int K, bool on_device);
+// the selection of a Run happens on the device (each chunk's best top_n) only beyond EXACT_FEED_MAX_GROUPS groups: capi_run.hip, run_select
+inline bool select_on_device(int32_t top_n, int64_t G) { return top_n <= TOPN_DEVICE_MAX && G > EXACT_FEED_MAX_GROUPS; }
 muse_batch::RunKey run_key(const muse_batch *b, const int32_t *group_id, int64_t G, int32_t max_lag, int32_t top_n,
                                   double threshold, int32_t sign_filter, int32_t abs_scores);
 int32_t screen_path(const muse_batch *b, const muse_batch::RunKey &key, bool already_scored);

@@ -1,0 +1,238 @@
+// capi_rows.hip -- Muse.Run (muse.go:46-92) as ONE call: the rows of one small label group from host memory against a
+// template batch's reference, the group's winner back.
+// Part of the implementation of the C ABI declared in include/muse_hip.h (capi_internal.h: the handles and the helpers the
+// parts share).  Host-side orchestration only; there is no CPU compute fallback anywhere: without a gfx950 device every
+// compute entry point returns MUSE_ERR_NO_DEVICE.
+//
+// Why it exists: muse_group_upload + muse_batch_create_like + muse_batch_run + two frees cost a dozen hipMalloc / hipFree
+// (each a device-wide synchronisation) and three stream synchronisations per Muse.Run -- 110 us for 5 x 480 samples, all of it
+// host side.  Here a context keeps a small pool of SLOTS (pinned staging, device rows behind the usual guard, score buffers,
+// a pinned result record, an event); a call takes a slot, copies the rows into the staging buffer, and enqueues exactly
+//     one host -> HBM copy, the fused kernel automatic selection takes for the length, one single-workgroup kernel that
+//     reduces the group (reduce_kernels.hip, single_group_kernel) and writes the winner straight into pinned host memory,
+//     one event
+// on the context's stream, waits for the event alone (not for other callers' work on the stream) and returns the slot.
+// Steady state: no allocation, no hipFree, no device-wide synchronisation.  Many goroutines may drive one Muse
+// (muse_test.go:203-214): every call in flight owns its slot.
+#include "capi_internal.h"
+
+using namespace muse;
+
+namespace {
+constexpr size_t ROWS_GUARD = 8192;            // = capi_group.hip's GROUP_GUARD: padded series read in front of row 0
+constexpr size_t ROWS_SLOT_MIN_ELEMS = 1u << 16;   // 512 KB: 5 ... 50 series of 480 ... 1000 samples without ever growing
+constexpr size_t ROWS_SLOT_MAX_ELEMS = 1u << 24;   // 128 MB: larger groups take the general path (the copies dominate there)
+constexpr int ROWS_SLOTS_KEPT = 16;            // slots kept per context when idle (more callers in flight: created and freed)
+} // namespace
+
+struct RowsSlot {
+    muse_group g;            // rows = the slot's device buffer; N / stride / M set per call
+    muse_batch b;            // spectrum tables rebound per call (the template's)
+    double *dev = nullptr;   // allocation base (guard in front of g.rows)
+    double *host = nullptr;  // pinned staging
+    size_t cap_elems = 0;
+    SingleGroupOut *out = nullptr; // pinned: the winner record, written by the device
+    hipEvent_t done = nullptr;
+};
+
+static void slot_destroy(RowsSlot *s)
+{
+    if (!s)
+        return;
+    (void)hipFree(s->dev);
+    if (s->host)
+        (void)hipHostFree(s->host);
+    if (s->out)
+        (void)hipHostFree(s->out);
+    if (s->done)
+        (void)hipEventDestroy(s->done);
+    (void)hipFree(s->b.mv);
+    (void)hipFree(s->b.lag);
+    (void)hipFree(s->b.ovf_count);
+    (void)hipFree(s->b.ovf_list);
+    if (s->b.handoff_host)
+        (void)hipHostFree(s->b.handoff_host);
+    delete s;
+}
+
+// called by ctx_release with the context's streams idle
+void rows_slots_free(muse_ctx *ctx)
+{
+    for (void *p : ctx->rows_slots)
+        slot_destroy((RowsSlot *)p);
+    ctx->rows_slots.clear();
+}
+
+static int slot_reserve(RowsSlot *s, size_t elems)
+{
+    if (elems <= s->cap_elems)
+        return MUSE_OK;
+    size_t cap = ROWS_SLOT_MIN_ELEMS;
+    while (cap < elems)
+        cap *= 2;
+    (void)hipFree(s->dev);
+    if (s->host)
+        (void)hipHostFree(s->host);
+    s->dev = nullptr;
+    s->host = nullptr;
+    s->cap_elems = 0;
+    s->g.rows = nullptr;
+    HIP_TRY(hipMalloc(&s->dev, (cap + ROWS_GUARD) * sizeof(double)));
+    HIP_TRY(hipMemset(s->dev, 0, ROWS_GUARD * sizeof(double)));
+    HIP_TRY(hipHostMalloc((void **)&s->host, cap * sizeof(double), hipHostMallocDefault));
+    s->g.rows = s->dev + ROWS_GUARD;
+    s->cap_elems = cap;
+    return MUSE_OK;
+}
+
+static int slot_acquire(muse_ctx *ctx, size_t elems, RowsSlot **out)
+{
+    RowsSlot *s = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(ctx->rows_mu);
+        if (!ctx->rows_slots.empty()) {
+            s = (RowsSlot *)ctx->rows_slots.back();
+            ctx->rows_slots.pop_back();
+        }
+    }
+    if (!s) {
+        s = new (std::nothrow) RowsSlot();
+        if (!s)
+            return fail(MUSE_ERR_NOMEM, "host allocation failed");
+        s->g.ctx = ctx;
+        s->b.ctx = ctx;
+        s->b.g = &s->g;
+        hipError_t e = hipHostMalloc((void **)&s->out, sizeof(SingleGroupOut), hipHostMallocDefault);
+        if (e == hipSuccess)
+            e = hipEventCreateWithFlags(&s->done, hipEventDisableTiming);
+        if (e == hipSuccess)
+            e = hipMalloc(&s->b.ovf_count, 2 * sizeof(int));
+        if (e != hipSuccess) {
+            slot_destroy(s);
+            return fail(MUSE_ERR_HIP, "slot set-up failed: %s", hipGetErrorString(e));
+        }
+    }
+    int rc = slot_reserve(s, elems);
+    if (rc) {
+        slot_destroy(s);
+        return rc;
+    }
+    *out = s;
+    return MUSE_OK;
+}
+
+static void slot_return(muse_ctx *ctx, RowsSlot *s)
+{
+    {
+        std::lock_guard<std::mutex> lock(ctx->rows_mu);
+        if ((int)ctx->rows_slots.size() < ROWS_SLOTS_KEPT) {
+            ctx->rows_slots.push_back(s);
+            return;
+        }
+    }
+    slot_destroy(s); // (the slot's work has completed: its event was waited for)
+}
+
+// the general path for groups too large for a slot: what the host mirrors did per Muse.Run before this entry point existed
+static int run_rows_general(muse_batch *tmpl, const double *rows, int64_t M, int64_t row_stride, int32_t abs_scores,
+                            muse_record *out_winner, uint8_t *out_state)
+{
+    muse_group *g = nullptr;
+    muse_batch *b = nullptr;
+    int rc = muse_group_upload(tmpl->ctx, rows, M, tmpl->N, row_stride, &g);
+    if (rc)
+        return rc;
+    rc = muse_batch_create_like(tmpl, g, &b);
+    if (!rc) {
+        std::vector<int32_t> gid((size_t)M, 0);
+        rc = muse_batch_run_groups(b, gid.data(), 1, 0, abs_scores, out_winner, out_state);
+    }
+    muse_batch_free(b);
+    muse_group_free(g);
+    return rc;
+}
+
+extern "C" int muse_batch_run_rows(muse_batch *tmpl, const double *rows, int64_t M, int64_t row_stride, int32_t abs_scores,
+                                   muse_record *out_winner, uint8_t *out_state)
+{
+    if (!tmpl || !out_winner || !out_state || M < 0 || (M > 0 && !rows))
+        return fail(MUSE_ERR_INVALID, "bad arguments");
+    *out_winner = muse_record{-1, 0.0, 0, 0};
+    *out_state = 0;
+    if (M == 0) // muse.go:47-50: nothing to compare
+        return MUSE_OK;
+    const int32_t N = tmpl->N;
+    if (row_stride < N) // muse.go:68-70
+        return fail(MUSE_ERR_LENGTH, "Encountered a comparison graph with differing length than the reference (%lld vs %d)",
+                    (long long)row_stride, N);
+    muse_ctx *ctx = tmpl->ctx;
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    const size_t elems = (size_t)M * (size_t)N;
+    if (elems > ROWS_SLOT_MAX_ELEMS)
+        return run_rows_general(tmpl, rows, M, row_stride, abs_scores, out_winner, out_state);
+    RowsSlot *s = nullptr;
+    rc = slot_acquire(ctx, elems, &s);
+    if (rc)
+        return rc;
+    // the slot's group and batch take this call's shape and the template's reference
+    s->g.N = N;
+    s->g.stride = N;
+    s->g.M = M;
+    s->g.cap = M;
+    s->b.N = tmpl->N;
+    s->b.n = tmpl->n;
+    s->b.logn = tmpl->logn;
+    s->b.sp = tmpl->sp;
+    adopt_spectrum(&s->b);
+    s->b.handoff_M = -1; // (no kernel-selection memory across unrelated groups)
+    if (M > s->b.score_cap) { // (grown in steps that small groups never reach twice)
+        (void)hipFree(s->b.mv);
+        (void)hipFree(s->b.lag);
+        s->b.mv = nullptr;
+        s->b.lag = nullptr;
+        s->b.score_cap = 0;
+        const int64_t cap = std::max<int64_t>(M, 4096);
+        hipError_t ea = hipMalloc(&s->b.mv, (size_t)cap * sizeof(double));
+        if (ea == hipSuccess)
+            ea = hipMalloc(&s->b.lag, (size_t)cap * sizeof(int));
+        if (ea != hipSuccess) {
+            slot_destroy(s);
+            return fail(MUSE_ERR_NOMEM, "hipMalloc failed: %s", hipGetErrorString(ea));
+        }
+        s->b.score_cap = cap;
+    }
+    if (row_stride == N) {
+        memcpy(s->host, rows, elems * sizeof(double));
+    } else {
+        for (int64_t r = 0; r < M; r++)
+            memcpy(s->host + (size_t)r * (size_t)N, rows + (size_t)r * (size_t)row_stride, (size_t)N * sizeof(double));
+    }
+    s->out->state = ~0ull;
+    hipError_t e = hipMemcpyAsync(s->g.rows, s->host, elems * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        rc = muse_batch_score(&s->b); // the fused kernel automatic selection takes for this length (and its redo launch, if any)
+        if (!rc)
+            e = launch_single_group(s->b.mv, s->b.lag, M, abs_scores ? 1 : 0, 0, s->out, ctx->stream);
+    }
+    if (e == hipSuccess && !rc)
+        e = hipEventRecord(s->done, ctx->stream);
+    if (e != hipSuccess || rc) {
+        (void)hipStreamSynchronize(ctx->stream); // nothing of this call may still be using the slot
+        slot_return(ctx, s);
+        return rc ? rc : fail(MUSE_ERR_HIP, "muse_batch_run_rows: %s", hipGetErrorString(e));
+    }
+    e = hipEventSynchronize(s->done);
+    if (e != hipSuccess) {
+        slot_destroy(s);
+        return fail(MUSE_ERR_HIP, "muse_batch_run_rows: %s", hipGetErrorString(e));
+    }
+    const unsigned long long st = *(volatile unsigned long long *)&s->out->state;
+    *out_winner = s->out->rec;
+    slot_return(ctx, s);
+    if (st > 2ull)
+        return fail(MUSE_ERR_HIP, "muse_batch_run_rows: the result record did not arrive");
+    *out_state = (uint8_t)st;
+    return MUSE_OK;
+}

@@ -127,7 +127,20 @@ int ensure_select_ws(muse_batch *b, int64_t M, int64_t G, bool with_gid, int K, 
         HIP_TRY(hipMalloc(&b->cand, (size_t)(nb * K) * sizeof(muse_record)));
         b->cand_cap = nb * K;
     }
-    if (on_device && nb > b->cnt_host_cap) { // (small selections copy the group records instead: no pinned memory)
+    if (!on_device && G > b->rec_host_cap) { // the exact feed: every group's record and selection key through pinned memory
+        if (b->rec_host)
+            (void)hipHostFree(b->rec_host);
+        if (b->key_host)
+            (void)hipHostFree(b->key_host);
+        b->rec_host = nullptr;
+        b->key_host = nullptr;
+        b->rec_host_cap = 0;
+        const int64_t cap = std::max<int64_t>(G, 64);
+        HIP_TRY(hipHostMalloc((void **)&b->rec_host, (size_t)cap * sizeof(muse_record), hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void **)&b->key_host, (size_t)cap * sizeof(unsigned long long), hipHostMallocDefault));
+        b->rec_host_cap = cap;
+    }
+    if (on_device && nb > b->cnt_host_cap) {
         if (b->cnt_host)
             (void)hipHostFree(b->cnt_host); // (hipHostFree(NULL) leaves a sticky error behind)
         b->cnt_host = nullptr;
@@ -187,7 +200,12 @@ int run_select(muse_batch *b, const int32_t *group_id, int32_t G_in, int64_t ser
         return MUSE_OK;
     if (G > 0x7fffffffLL)
         return fail(MUSE_ERR_UNSUPPORTED, "more than 2^31-1 groups on one device");
-    const bool on_device = top_n <= TOPN_DEVICE_MAX && G > TOPN_CHUNK / 4;
+    // Up to EXACT_FEED_MAX_GROUPS groups every group's record comes back (G x 32 B through pinned memory) and the heap below is
+    // fed ONE Score per group in group order: the reference's own feed (muse_batch.go:124-128, results.go:55-72), so exactly tied
+    // scores -- every series that clamps to 1.0 ties -- survive at the TopN boundary and come back from Fetch as they do there,
+    // for every binding of this entry point.  Beyond that the device pre-selects each chunk's best top_n (ties at the boundary
+    // then go to the lower group id: DESIGN 8.3).
+    const bool on_device = select_on_device(top_n, G);
     const int K = on_device ? top_n : 1;
     rc = ensure_select_ws(b, M, G, group_id != nullptr, K, on_device);
     if (rc)
@@ -234,11 +252,10 @@ int run_select(muse_batch *b, const int32_t *group_id, int32_t G_in, int64_t ser
         if (screened && screen_guard_tripped(b)) // an estimate left its bound: this Run is redone entirely in fp64
             return run_select(b, group_id, G_in, series_offset, max_lag, top_n, threshold, sign_filter, abs_scores, out, false);
     } else {
-        std::vector<muse_record> rec((size_t)G);
-        std::vector<unsigned long long> key((size_t)G);
-        HIP_TRY(hipMemcpyAsync(rec.data(), b->rec, (size_t)G * sizeof(muse_record), hipMemcpyDeviceToHost,
-                               ctx->stream));
-        HIP_TRY(hipMemcpyAsync(key.data(), b->selkey, (size_t)G * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+        const muse_record *rec = b->rec_host;
+        const unsigned long long *key = b->key_host;
+        HIP_TRY(hipMemcpyAsync(b->rec_host, b->rec, (size_t)G * sizeof(muse_record), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(b->key_host, b->selkey, (size_t)G * sizeof(unsigned long long), hipMemcpyDeviceToHost,
                                ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         for (int64_t g = 0; g < G; g++)

@@ -366,7 +366,7 @@ int screen_many(muse_batch *const *bs, int32_t R, const int32_t *group_id, int32
     int rc = use_device(ctx);
     if (rc)
         return rc;
-    const bool on_device = top_n <= TOPN_DEVICE_MAX && G > TOPN_CHUNK / 4;
+    const bool on_device = select_on_device(top_n, G);
     const int K = on_device ? top_n : 1;
     std::vector<ScreenPlan> plan((size_t)R);
     double Es_max = 0.0;

@@ -591,6 +591,78 @@ hipError_t launch_screen_select(const ScreenSelect &q, int top_n, unsigned long 
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------- one label group in one workgroup (Muse.Run, muse.go:52-90)
+// The whole of a small group's post-processing in ONE launch: the winner among the members whose score is a number
+// (maximum of |clamped score|, the lowest index on ties -- "strictly greater replaces", muse.go:86) and the group's state
+// (1: the first member's score is a number, 2: it is NaN and never replaced; 0: no member), with the meaning of
+// SelectParams::partial.  `out` may be pinned host memory: the record is written once, by one lane.
+__global__ __launch_bounds__(256) void single_group_kernel(const double *__restrict__ mv, const int *__restrict__ lag,
+                                                           long long M, int abs_scores, long long series_offset,
+                                                           SingleGroupOut *out)
+{
+    __shared__ unsigned long long s_key[4];
+    __shared__ long long s_win[4];
+    const int t = threadIdx.x, w = t >> 6;
+    unsigned long long key = 0ull;
+    long long win = IDX_NONE;
+    for (long long i = t; i < M; i += 256) {      // ascending i per lane: the first index attaining the lane's maximum is kept
+        const double v = clamp_score(mv[i], abs_scores);
+        if (v == v) {
+            const unsigned long long k = abs_bits(v) + 1ull;   // (+1: a score of exactly 0 still beats "no member")
+            if (k > key) {
+                key = k;
+                win = i;
+            }
+        }
+    }
+    const unsigned long long wk = wave_max_u64(key);
+    long long cand = key == wk && key != 0ull ? win : IDX_NONE;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const long long u = __shfl_xor(cand, o, 64);
+        cand = u < cand ? u : cand;
+    }
+    if ((t & 63) == 0) {
+        s_key[w] = wk;
+        s_win[w] = cand;
+    }
+    __syncthreads();
+    if (t == 0) {
+        unsigned long long bk = 0ull;
+        long long bw = IDX_NONE;
+        for (int q = 0; q < 4; q++)
+            if (s_key[q] > bk || (s_key[q] == bk && bk != 0ull && s_win[q] < bw)) {
+                bk = s_key[q];
+                bw = s_win[q];
+            }
+        muse_record r;
+        r.series = -1;
+        r.score = 0.0;
+        r.lag = 0;
+        r.group = 0;
+        unsigned long long state = 0ull;
+        if (M > 0) {
+            const double vf = clamp_score(mv[0], abs_scores);
+            state = vf != vf ? 2ull : 1ull;
+            if (bw != IDX_NONE) {
+                r.series = bw + series_offset;
+                r.score = clamp_score(mv[bw], abs_scores);
+                r.lag = lag[bw];
+            }
+        }
+        out->rec = r;
+        __threadfence_system();
+        out->state = state;
+    }
+}
+
+hipError_t launch_single_group(const double *mv, const int *lag, long long M, int abs_scores, long long series_offset,
+                               SingleGroupOut *out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(single_group_kernel, dim3(1), dim3(256), 0, stream, mv, lag, M, abs_scores, series_offset, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_topn(const muse_record *rec, const unsigned long long *selkey, int G, int K, muse_record *cand,
                        int *cnt, hipStream_t stream)
 {

@@ -129,6 +129,7 @@ hipError_t launch_wave_argmax_probe(const double *ccA, const double *ccB, double
 // ---- group max / filter / top-N (reduce_kernels.hip)
 constexpr int TOPN_CHUNK = 4096;    // groups per workgroup in the selection pass
 constexpr int TOPN_DEVICE_MAX = 256; // larger top_n: winners are copied to the host instead
+constexpr int EXACT_FEED_MAX_GROUPS = 65536; // up to this many groups a Run feeds the top-N heap one Score per group in group order (the reference's feed)
 
 struct GroupWork {
     unsigned long long *key; // [G] max of bits(|score|) over members (atomicMax)
@@ -194,6 +195,13 @@ hipError_t launch_screen_select(const ScreenSelect &q, int top_n, unsigned long 
 // per-group winners -> rec[G] (+ selection keys selkey[G]: 0 = filtered out)
 hipError_t launch_group_reduce(const SelectParams &sp, const GroupWork &gw, muse_record *rec,
                                unsigned long long *selkey, hipStream_t stream);
+// one label group in one launch (Muse.Run): the winner record and the group's state (reduce_kernels.hip)
+struct SingleGroupOut {
+    muse_record rec;
+    unsigned long long state;
+};
+hipError_t launch_single_group(const double *mv, const int *lag, long long M, int abs_scores, long long series_offset,
+                               SingleGroupOut *out, hipStream_t stream);
 // per-chunk top-K extraction: cand[nblocks*K], cnt[nblocks]
 hipError_t launch_topn(const muse_record *rec, const unsigned long long *selkey, int G, int K, muse_record *cand,
                        int *cnt, hipStream_t stream);

@@ -805,35 +805,21 @@ func (m *Muse) Run(compGraphs []*Series) error {
 		}
 		rows = append(rows, s.Values()...)
 	}
-	e, err := getEngine()
-	if err != nil {
+	if _, err := getEngine(); err != nil {
 		return err
 	}
 	runtime.LockOSThread()
 	defer runtime.UnlockOSThread()
-	var g *C.muse_group
-	st := C.muse_group_upload(e.ctx, (*C.double)(unsafe.Pointer(&rows[0])), C.int64_t(len(compGraphs)), C.int32_t(N), C.int64_t(N), &g)
+	// one ABI call: upload, fused kernel, group maximum, record back; signed scores (muse.go:72-76).  The rows are
+	// copied before the call returns (cgo rule); Results.Update applies passed() as the reference does.
+	var win C.muse_record
+	var state C.uint8_t
+	st := C.muse_batch_run_rows(m.template, (*C.double)(unsafe.Pointer(&rows[0])), C.int64_t(len(compGraphs)), C.int64_t(N), 0, &win, &state)
 	if err := hipError(st); err != nil {
 		return err
 	}
-	defer C.muse_group_free(g)
-	var b *C.muse_batch
-	if err := hipError(C.muse_batch_create_like(m.template, g, &b)); err != nil {
-		return err
-	}
-	defer C.muse_batch_free(b)
-	gid := make([]C.int32_t, len(compGraphs)) // all zero: one group
-	var idx C.int64_t
-	var lag, cnt C.int32_t
-	var score, mean C.double
-	r := m.Results
-	st = C.muse_batch_run(b, &gid[0], 1, C.int32_t(r.MaxLag), 1, C.double(r.Threshold), C.int32_t(r.SignFilter),
-		0 /* signed scores: muse.go:72-76 */, &idx, &lag, &score, &cnt, &mean)
-	if err := hipError(st); err != nil {
-		return err
-	}
-	if cnt == 1 {
-		r.Update(Score{Labels: compGraphs[idx].Labels(), Lag: int(lag), PercentScore: float64(score)})
+	if state == 1 && win.series >= 0 {
+		m.Results.Update(Score{Labels: compGraphs[win.series].Labels(), Lag: int(win.lag), PercentScore: float64(win.score)})
 	}
 	return nil
 }

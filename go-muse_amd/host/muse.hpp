@@ -754,7 +754,7 @@ public:
         if (ref->Length() < 1) // muse.go:24-26
             throw Error(MUSE_ERR_EMPTY, "Reference series length must be greater than zero");
         refN_ = ref->Length();
-        // the reference spectrum is computed once (muse.go:29-39); every Run shares it (muse_batch_create_like)
+        // the reference spectrum is computed once (muse.go:29-39); every Run shares it (muse_batch_run_rows)
         check(muse_group_create(eng_->handle(), 0, refN_, &probe_));
         int rc = muse_batch_create(eng_->handle(), probe_, ref_.data(), refN_, &template_);
         if (rc) {
@@ -782,24 +782,13 @@ public:
                 throw Error(MUSE_ERR_LENGTH, "Encountered a comparison graph with differing length than the reference");
             rows.insert(rows.end(), s->Values().begin(), s->Values().end());
         }
-        muse_group *g = nullptr;
-        check(muse_group_upload(eng_->handle(), rows.data(), (int64_t)compGraphs.size(), refN_, refN_, &g));
-        muse_batch *b = nullptr;
-        int rc = muse_batch_create_like(template_, g, &b);
-        std::vector<int32_t> gid(compGraphs.size(), 0);
-        int64_t idx = 0;
-        int32_t lag = 0, cnt = 0;
-        double score = 0, mean = 0;
-        if (!rc)
-            rc = muse_batch_run(b, gid.data(), 1, Results_->MaxLag, 1, Results_->Threshold, (int32_t)Results_->Filter,
-                                0 /* signed scores: muse.go:72-76 */, &idx, &lag, &score, &cnt, &mean);
-        std::string msg = rc ? muse_last_error() : "";
-        muse_batch_free(b);
-        muse_group_free(g);
-        if (rc)
-            throw Error(rc, msg);
-        if (cnt == 1)
-            Results_->Update(Score{compGraphs[idx]->Labels(), lag, score});
+        // one ABI call: upload, fused kernel, group maximum, record back (muse_batch_run_rows; signed scores: muse.go:72-76).
+        // Results.Update applies passed() to the group's Score exactly as the reference does (results.go:55-72).
+        muse_record win{};
+        uint8_t state = 0;
+        check(muse_batch_run_rows(template_, rows.data(), (int64_t)compGraphs.size(), refN_, 0, &win, &state));
+        if (state == 1 && win.series >= 0)
+            Results_->Update(Score{compGraphs[(size_t)win.series]->Labels(), win.lag, win.score});
     }
 
 private:

@@ -358,6 +358,21 @@ class DeviceBatch:
             B.recptr(rec), ctypes.byref(cnt)))
         return rec[:cnt.value].copy()
 
+    def run_rows(self, rows, abs_scores=False):
+        """muse_batch_run_rows: Muse.Run (muse.go:46-92) in one call -- `rows` (M x N, host) form ONE label group scored against
+        this batch's reference (the batch's own group is not touched); -> (winner record, state) as run_groups reports them"""
+        rows = np.asarray(rows, dtype=np.float64)
+        if rows.ndim != 2:
+            raise ValueError("rows must be 2-D")
+        if rows.shape[0] and rows.strides[1] != 8:
+            rows = np.ascontiguousarray(rows)
+        stride = rows.strides[0] // 8 if rows.shape[0] > 1 else rows.shape[1]
+        rec = np.zeros(1, dtype=B.RECORD_DTYPE)
+        state = ctypes.c_uint8(0)
+        B.check(B.load().muse_batch_run_rows(self._h, rows.ctypes.data_as(B._dp), rows.shape[0], stride,
+                                             1 if abs_scores else 0, B.recptr(rec), ctypes.byref(state)))
+        return rec[0], int(state.value)
+
     def run_groups(self, group_id, G, series_offset=0, abs_scores=True):
         """this shard's winner per label group, unfiltered (muse_batch_run_groups): (records[G], state[G])"""
         rec = np.zeros(max(int(G), 1), dtype=B.RECORD_DTYPE)
@@ -963,7 +978,7 @@ class Muse:
         self._engine = engine or get_engine()
         self._ref = np.array(ref.Values(), dtype=np.float64)
         # the reference spectrum is computed once, as New does (muse.go:29-39: sigma(ref) == 0 is an error here);
-        # every Run shares it through muse_batch_create_like
+        # every Run shares it through muse_batch_run_rows
         self._probe = DeviceGroup(self._engine, self.refN, 0)
         try:
             self._template = DeviceBatch(self._engine, self._probe, self._ref)
@@ -978,18 +993,11 @@ class Muse:
             if s.Length() != self.refN:
                 raise MuseError(B.MUSE_ERR_LENGTH, "Encountered a comparison graph with differing length "
                                 "than the reference, %r" % (s.Labels(),))
-        dg = DeviceGroup.from_rows(self._engine, np.stack([s.y for s in compGraphs]))
-        db = DeviceBatch.like(self._template, dg)
-        try:
-            r = self.Results
-            gid = np.zeros(len(compGraphs), dtype=np.int32)
-            idx, lag, score, _ = db.run(gid, 1, r.MaxLag, max(r.TopN, 1), r.Threshold, r.SignFilter,
-                                        abs_scores=False)
-            for k in range(len(idx)):
-                r.Update(Score(compGraphs[int(idx[k])].Labels(), int(lag[k]), float(score[k])))
-        finally:
-            db.close()
-            dg.close()
+        rows = np.stack([s.y for s in compGraphs])
+        win, state = self._template.run_rows(rows, abs_scores=False)      # one ABI call (muse_batch_run_rows)
+        if state == 1 and win["series"] >= 0:
+            # the group's Score through the unchanged Update, which applies passed() as the reference does (results.go:55-72)
+            self.Results.Update(Score(compGraphs[int(win["series"])].Labels(), int(win["lag"]), float(win["score"])))
         return None
 
 

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MUSE_HIP_ABI_VERSION 3
+#define MUSE_HIP_ABI_VERSION 4
 
 typedef enum muse_status {
     MUSE_OK = 0,
@@ -182,6 +182,20 @@ int muse_batch_create(muse_ctx *ctx, muse_group *g, const double *ref,
  * then one _create_like + _run + _free per call.  MUSE_ERR_LENGTH when the
  * group's length differs from the reference's (muse.go:68-70). */
 int muse_batch_create_like(muse_batch *src, muse_group *g, muse_batch **out);
+/* Muse.Run (muse.go:46-92) in ONE call: the M rows of one label group, read from host memory (row_stride in doubles,
+ * >= the reference's length: MUSE_ERR_LENGTH otherwise, muse.go:68-70), are scored against tmpl's reference -- tmpl is the
+ * batch New made once (muse_batch_create over an empty group); its own group is not touched -- and the group's winner comes
+ * back as muse_batch_run_groups reports it for G = 1: *out_winner = the member with the largest |clamped score| among the
+ * members whose score is a number (series = its row index, -1 if none; the first one on ties, muse.go:86), *out_state = 1
+ * the first member's score is a number (out_winner is the Score Muse.Run passes to Results.Update), 2 the first member
+ * scores NaN (x > NaN never replaces it: the group's score is NaN and never passes Results.passed), 0 for M = 0
+ * (muse.go:47-50).  abs_scores = 0: signed score clamped to [-1, 1] (Muse.Run); 1: |score| clamped to 1 (a Batch of one
+ * label group).  rows are copied before the call returns and never mutated.
+ * One host -> HBM copy, the fused kernel of the length, one reduction kernel that writes the record into pinned host
+ * memory, one event: no allocation, no free and no device-wide synchronisation in steady state (a pool of slots per
+ * context); any number of host threads may call it on one tmpl at the same time (muse_test.go:203-214). */
+int muse_batch_run_rows(muse_batch *tmpl, const double *rows, int64_t M, int64_t row_stride,
+                        int32_t abs_scores, muse_record *out_winner, uint8_t *out_state);
 int muse_batch_fft_len(muse_batch *b, int32_t *n);
 /* The batch's x (muse_batch.go:47): n/2+1 complex128, interleaved re,im. */
 int muse_batch_spectrum(muse_batch *b, double *out);

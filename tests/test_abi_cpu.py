@@ -32,7 +32,7 @@ def test_header_symbols_all_exported(muse):
     for name in sorted(declared):
         assert hasattr(lib, name), "libmuse_hip.so does not export %s" % name
     assert declared == set(muse.binding.SIGNATURES), "binding.py and the headers disagree"
-    assert muse.binding.load().muse_abi_version() == 3
+    assert muse.binding.load().muse_abi_version() == 4
     # nothing is exported that no header declares
     import subprocess
     out = subprocess.check_output(["nm", "-D", "--defined-only", muse.build.LIB], text=True)
@@ -98,7 +98,7 @@ def test_go_shim_calls_match_the_header():
     # the calls a drop-in Batch / Muse / sharded Run cannot do without
     for need in ("muse_ctx_create", "muse_group_create", "muse_group_append", "muse_batch_create", "muse_batch_run",
                  "muse_batch_run_shard", "muse_batch_run_groups", "muse_merge_records", "muse_merge_group_records",
-                 "muse_batch_create_like", "muse_last_error", "muse_device_count"):
+                 "muse_batch_run_rows", "muse_last_error", "muse_device_count"):
         assert need in used, need
     # constants and types taken from the header by name
     for const in set(re.findall(r"\bC\.(MUSE_[A-Z0-9_]+)\b", go_nc)):

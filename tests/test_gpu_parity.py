@@ -315,9 +315,15 @@ def test_config2_10000x4096_full_parity(muse, eng, oracle):
         distinct = len(set(np.round(exp[2], 9))) == len(exp[2])
         if distinct:
             assert got[0].tolist() == exp[0].tolist()
+        # exact ties included (the planted copies all clamp to 1.0): muse_batch_run feeds its heap one Score per group in group
+        # order, so the winners and their order are what the reference's feed (results.go:55-72) gives over the SAME scores
+        own = oracle.results(lag, mv, gid, M // 50, absf, max_lag, top_n, thr, sign)
+        assert got[0].tolist() == own[0].tolist() and got[1].tolist() == own[1].tolist() and got[2].tolist() == own[2].tolist()
     got = db.run(None, 0, 15, 20, 0.0, 0, True)               # Run(nil): each series its own group
     exp = oracle.results(olag, omv, None, 0, True, 15, 20, 0.0, 0)
     assert np.allclose(got[2], exp[2], rtol=1e-6, atol=1e-12) and got[1].tolist() == exp[1].tolist()
+    own = oracle.results(lag, mv, None, 0, True, 15, 20, 0.0, 0)   # 10 000 groups of one: the planted copies tie at the top
+    assert got[0].tolist() == own[0].tolist() and got[2].tolist() == own[2].tolist() and int(copies.sum()) >= 3
 
 
 def test_group_semantics_edge_cases(muse, eng, oracle):
@@ -354,8 +360,9 @@ def test_group_semantics_edge_cases(muse, eng, oracle):
 
 
 def test_device_topn_path_large_group_count(muse, eng, oracle):
-    """G > 1024 exercises the on-device top-N pre-selection kernel."""
-    M, N = 6000, 64
+    """more than 65 536 groups (EXACT_FEED_MAX_GROUPS) exercise the on-device top-N pre-selection kernel; fewer take the
+    per-group feed (3 000 interleaved groups)."""
+    M, N = 140000, 64
     rng = np.random.default_rng(9)
     ref = rng.standard_normal(N)
     rows = rng.standard_normal((M, N))
@@ -366,7 +373,8 @@ def test_device_topn_path_large_group_count(muse, eng, oracle):
     olag, omv, gap = oracle.batch_scores(ref, rows, nthreads=4)
     assert_scores_match(lag, mv, olag, omv, gap)
     gid = (np.arange(M) % 3000).astype(np.int32)          # interleaved groups
-    for args in ((None, 0), (gid, 3000)):
+    gid2 = (np.arange(M) % 70000).astype(np.int32)        # ... and more of them than the per-group feed takes
+    for args in ((None, 0), (gid, 3000), (gid2, 70000)):
         for top_n in (1, 20, 256):
             got = db.run(args[0], args[1], 5, top_n, 0.1, 0, True)
             exp = oracle.results(olag, omv, args[0], args[1], True, 5, top_n, 0.1, 0)
@@ -937,6 +945,72 @@ def test_mixed_unit_group_every_pair_handed_off(muse, eng, oracle):
     for _ in range(2):
         lag2, mv2 = db.scores()
         assert np.array_equal(lag, lag2) and np.array_equal(mv, mv2)
+    db.close()
+    dg.close()
+
+
+@pytest.mark.parametrize("N", [8, 12, 480, 1000, 4096, 5000, 20000])
+def test_run_rows_one_call_equals_run_groups(muse, eng, oracle, N):
+    """muse_batch_run_rows (Muse.Run, muse.go:46-92, as one ABI call through a pooled slot) against muse_batch_run_groups over
+    an uploaded group of the same rows, and against the reference loop over the oracle's scores: signed and abs scores, one to
+    1 001 series, a NaN first member (never replaced), a NaN later member, a constant series, exact ties (the first wins), a
+    row stride wider than N, groups of different sizes and lengths alternating on the same slots, an empty group."""
+    rng = np.random.default_rng(400 + N)
+    ref_y = rng.standard_normal(N)
+    probe = muse.DeviceGroup(eng, N, 0)
+    tmpl = muse.DeviceBatch(eng, probe, ref_y)
+    X, n = oracle.ref_spectrum(ref_y)
+    for case, M in enumerate((1, 2, 5, 50, 1001 if N <= 4096 else 65, 3)):
+        wide = np.zeros((M, N + 5))
+        rows = wide[:, :N] if case % 2 else np.zeros((M, N))         # (odd cases: row_stride = N + 5)
+        rows[:] = rng.standard_normal((M, N))
+        rows[::3] += np.roll(ref_y, 1) * rng.uniform(-3, 3, (len(rows[::3]), 1))
+        if M >= 5:
+            rows[3] = rows[1]                                          # exact tie: the earlier series keeps the group
+            rows[4] = 0.5                                              # sigma == 0: score 0
+        if case == 3:
+            rows[0, N // 2] = np.nan                                   # the FIRST member scores NaN: the group's score is NaN
+        if case == 4:
+            rows[2, 1] = np.nan                                        # a later NaN member is skipped
+        dg = muse.DeviceGroup.from_rows(eng, np.ascontiguousarray(rows))
+        db = muse.DeviceBatch.like(tmpl, dg)
+        olag, omv, gap = oracle.batch_scores(ref_y, np.ascontiguousarray(rows)) if not np.isnan(rows).any() else (None, None, None)
+        for abs_scores in (False, True):
+            win, st = tmpl.run_rows(rows, abs_scores=abs_scores)
+            rec, state = db.run_groups(np.zeros(M, dtype=np.int32), 1, 0, abs_scores=abs_scores)
+            assert st == int(state[0]) and win.tolist() == rec[0].tolist(), (N, M, abs_scores)
+            assert st == (2 if case == 3 else 1)
+            if olag is not None:                                       # the reference loop (muse.go:64-88) over the oracle's scores
+                sc = np.minimum(np.abs(omv), 1.0) if abs_scores else np.clip(omv, -1.0, 1.0)
+                best = 0
+                for i in range(1, M):
+                    if abs(sc[i]) > abs(sc[best]) + (1e-9 if abs(abs(sc[i]) - abs(sc[best])) < 1e-9 else 0.0):
+                        best = i
+                assert abs(win["score"] - sc[best]) <= SCORE_RTOL * abs(sc[best]) + SCORE_ATOL
+                if gap[int(win["series"])] >= TIE_GAP and int(win["series"]) == best:
+                    assert int(win["lag"]) == int(olag[best])
+                if M >= 5:
+                    assert int(win["series"]) != 3                     # (series 3 repeats series 1 bit for bit and never wins)
+        db.close()
+        dg.close()
+    win, st = tmpl.run_rows(np.zeros((0, N)))
+    assert st == 0 and int(win["series"]) == -1
+    with pytest.raises(muse.MuseError) as ei:
+        tmpl.run_rows(np.zeros((2, max(N - 1, 1))))
+    assert ei.value.status == muse.binding.MUSE_ERR_LENGTH
+    tmpl.close()
+    probe.close()
+
+
+def test_run_rows_large_group_takes_the_general_path(muse, eng):
+    """more than 2^24 samples do not fit a slot: the same entry point uploads a group and runs it (same record)"""
+    N, M = 4096, 4100
+    dg, ref = muse.DeviceGroup.synthetic(eng, M, N, seed=99, copies=False)
+    rows = dg.read(0, M)
+    db = muse.DeviceBatch(eng, dg, ref)
+    rec, state = db.run_groups(np.zeros(M, dtype=np.int32), 1, 0, abs_scores=False)
+    win, st = db.run_rows(rows, abs_scores=False)
+    assert st == 1 == int(state[0]) and win.tolist() == rec[0].tolist()
     db.close()
     dg.close()
 
