@@ -298,6 +298,51 @@ def config5_leg(pkg, eng, args, rank, n_gpus, use_dist, tdev, M, N, counters):
     return per_len, mixed
 
 
+def reference_bench_shapes(pkg):
+    """The reference's own published benchmark shapes (README.md:98-108): go-muse_amd/host/muse_ref_bench.cpp
+    restates the loop bodies of muse_test.go:144-215, muse_batch_test.go:104-162 and xcorr_test.go:322-348 over the C++ host
+    mirror and is run here as a CHILD process (its own context on the same GPU, while this process is idle); beside each the
+    README's laptop figure and this box's CPU port (oracle/muse_cpu_fast.c, `kind: port`) timed on the same shape."""
+    import subprocess
+    import numpy as np
+    exe = pkg.build.build_ref_bench()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    if r.returncode != 0:
+        return {"error": "muse_ref_bench exited with %d: %s" % (r.returncode, r.stderr[-400:])}
+    obj = json.loads(r.stdout)
+    # the CPU port on the same shapes (not Go / gonum; the README's numbers are a 2018 laptop's)
+    from oracle import oracle_py
+    oracle_py.build_fast()
+    rng = np.random.default_rng(20200419)
+    threads = max(1, min(os.cpu_count() or 1, 64))
+
+    def cpu_ns(ref, rows, nthreads, min_s=0.2):
+        oracle_py.fast_batch_scores(ref, rows, nthreads=nthreads)
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            oracle_py.fast_batch_scores(ref, rows, nthreads=nthreads)
+            reps += 1
+            el = time.perf_counter() - t0
+            if el >= min_s and reps >= 3:
+                return el / reps * 1e9
+    ref480, rows480 = 0.1 * rng.standard_normal(480), 0.1 * rng.standard_normal((5000, 480))
+    for name in ("BenchmarkMuseRunLarge", "BenchmarkMuseBatchRunLarge"):
+        obj[name]["cpu_port_ns_per_op"] = {"all_cores": cpu_ns(ref480, rows480, threads), "cores": threads, "one_thread": cpu_ns(ref480, rows480, 1)}
+    x, y = rng.uniform(size=16385), rng.uniform(size=(1, 16385))
+    obj["BenchmarkXCorrWithX"]["cpu_port_ns_per_op"] = {"one_thread": cpu_ns(x, y, 1), "cores": 1}
+    ref8 = np.array([0.0, 0.0, 0.0, 0.0, 0.1, 0.2, 0.3, 0.4])
+    rows8 = np.array([[0.0, 0.0, 0.0, 0.0, 0.1, 0.2, 0.3, 0.4], [0.2, 0.1, 0.2, 0.1, 0.2, 0.1, 0.2, 0.1], [0.0, 0.0, 0.0, 0.0, 0.2, 0.4, 0.5, 0.8],
+                      [0.2, 0.1, 0.2, 0.1, 0.2, 0.1, 0.22, 0.1], [0.0, 0.0, 0.0, 0.0, -0.2, -0.4, 0.0, -0.8], [0.0, 0.0, 0.0, -0.2, -0.4, -0.6, 1.0, 0.0]])
+    for name in ("BenchmarkMuseRun", "BenchmarkMuseBatchRun"):
+        obj[name]["cpu_port_ns_per_op"] = {"one_thread": cpu_ns(ref8, rows8, 1, 0.05), "cores": 1, "note": "the six xCorrWithX alone (no Results, no labels)"}
+    obj["note"] = ("ns_per_op: this engine through the C++ host mirror, comparison data resident in HBM where the reference's loop keeps it in RAM "
+                   "(Muse.Run uploads its group in every call by design: muse_batch_run_rows); ns_per_op_cold: upload included; "
+                   "readme_ns_per_op: README.md:98-108 (2018 MacBook Air, 1.6 GHz i5, 4 logical CPUs; Go + gonum); cpu_port_ns_per_op: "
+                   "oracle/muse_cpu_fast.c on this box's host cores.  The 8-sample shapes are launch latency, not throughput: a GPU call "
+                   "cannot be cheaper than one kernel launch and one completion wait")
+    return obj
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -735,6 +780,12 @@ def main():
                 line["in_process_shards"] = {"error": str(e)}
         if c5 is not None:
             line["config5_lengths"], line["config5_mixed_run"] = c5
+        if extras and "reference_bench_shapes" not in args.skip_extra:
+            try:
+                eng.synchronize()
+                line["reference_bench_shapes"] = reference_bench_shapes(pkg)
+            except Exception as e:
+                line["reference_bench_shapes"] = {"error": str(e)}
         if not args.no_cpu_baseline:
             # (at every N, on rank 0's host cores over a sample of rank 0's shard: the other ranks wait at the closing barrier)
             line["cpu_baseline"] = cpu_baseline(dg, ref, N)

@@ -85,6 +85,7 @@ SIGNATURES = {
     "muse_test_set_screen_bound_scale": (ctypes.c_int, [_vp, _f64]),
     "muse_test_screen_bound": (ctypes.c_int, [_i32, _f64, _dp]),
     "muse_test_wave_argmax": (ctypes.c_int, [_vp, _dp, _dp, _dp]),
+    "muse_test_rows_always_copy": (ctypes.c_int, [_vp, _i32]),
     "muse_test_clock_probe_start": (ctypes.c_int, [_vp, _f64, _f64]),
     "muse_test_clock_probe_stop": (ctypes.c_int, [_vp]),
     "muse_test_clock_probe_read": (ctypes.c_int, [_vp, _dp, _i32, _i32p]),

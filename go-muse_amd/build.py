@@ -80,3 +80,20 @@ def build_host_test(force=False):
                            "-I" + os.path.join(PKG, "host"), src, "-o", HOST_TEST,
                            "-L" + LIBDIR, "-lmuse_hip", "-pthread", "-Wl,-rpath," + LIBDIR])
     return HOST_TEST
+
+
+REF_BENCH = os.path.join(LIBDIR, "muse_ref_bench")
+
+
+def build_ref_bench(force=False):
+    """g++ build of the reference's own benchmark shapes over the C++ host mirror (host/muse_ref_bench.cpp; bench.py runs it)."""
+    src = os.path.join(PKG, "host", "muse_ref_bench.cpp")
+    hdr = os.path.join(PKG, "host", "muse.hpp")
+    build()
+    if (not force and os.path.exists(REF_BENCH)
+            and os.path.getmtime(REF_BENCH) >= max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(LIB))):
+        return REF_BENCH
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"),
+                           "-I" + os.path.join(PKG, "host"), src, "-o", REF_BENCH,
+                           "-L" + LIBDIR, "-lmuse_hip", "-pthread", "-Wl,-rpath," + LIBDIR])
+    return REF_BENCH

@@ -83,6 +83,7 @@ struct muse_ctx {
     char pci[32] = {0}; // PCI bus id of the device ("0000:05:00.0"): tells two contexts on one GPU from two GPUs
     // muse_batch_run_rows (capi_rows.hip): idle slots (RowsSlot *) -- pinned staging, device rows, score buffers, a pinned
     // result record and an event each -- so that a Muse.Run allocates nothing in steady state
+    bool rows_always_copy = false; // test hook (muse_test_rows_always_copy): never let a kernel read the pinned staging buffer
     std::vector<void *> rows_slots;
     std::mutex rows_mu;
     // Handles may be released in any order (Go finalizers, Python GC): the

@@ -22,6 +22,7 @@ namespace {
 constexpr size_t ROWS_GUARD = 8192;            // = capi_group.hip's GROUP_GUARD: padded series read in front of row 0
 constexpr size_t ROWS_SLOT_MIN_ELEMS = 1u << 16;   // 512 KB: 5 ... 50 series of 480 ... 1000 samples without ever growing
 constexpr size_t ROWS_SLOT_MAX_ELEMS = 1u << 24;   // 128 MB: larger groups take the general path (the copies dominate there)
+constexpr size_t ROWS_ZERO_COPY_BYTES = 256u << 10; // up to here the kernel reads the pinned staging buffer itself
 constexpr int ROWS_SLOTS_KEPT = 16;            // slots kept per context when idle (more callers in flight: created and freed)
 } // namespace
 
@@ -29,7 +30,8 @@ struct RowsSlot {
     muse_group g;            // rows = the slot's device buffer; N / stride / M set per call
     muse_batch b;            // spectrum tables rebound per call (the template's)
     double *dev = nullptr;   // allocation base (guard in front of g.rows)
-    double *host = nullptr;  // pinned staging
+    double *host = nullptr;  // pinned staging (ROWS_GUARD zeroed elements in front of it)
+    double *host_dev = nullptr; // the same memory as the device addresses it
     size_t cap_elems = 0;
     SingleGroupOut *out = nullptr; // pinned: the winner record, written by the device
     hipEvent_t done = nullptr;
@@ -41,7 +43,7 @@ static void slot_destroy(RowsSlot *s)
         return;
     (void)hipFree(s->dev);
     if (s->host)
-        (void)hipHostFree(s->host);
+        (void)hipHostFree(s->host - ROWS_GUARD);
     if (s->out)
         (void)hipHostFree(s->out);
     if (s->done)
@@ -72,14 +74,22 @@ static int slot_reserve(RowsSlot *s, size_t elems)
         cap *= 2;
     (void)hipFree(s->dev);
     if (s->host)
-        (void)hipHostFree(s->host);
+        (void)hipHostFree(s->host - ROWS_GUARD);
     s->dev = nullptr;
     s->host = nullptr;
     s->cap_elems = 0;
     s->g.rows = nullptr;
     HIP_TRY(hipMalloc(&s->dev, (cap + ROWS_GUARD) * sizeof(double)));
     HIP_TRY(hipMemset(s->dev, 0, ROWS_GUARD * sizeof(double)));
-    HIP_TRY(hipHostMalloc((void **)&s->host, cap * sizeof(double), hipHostMallocDefault));
+    // (the staging buffer carries the same zeroed guard: the smallest groups are read by the kernel straight out of it)
+    double *hbase = nullptr;
+    HIP_TRY(hipHostMalloc((void **)&hbase, (cap + ROWS_GUARD) * sizeof(double), hipHostMallocDefault));
+    memset(hbase, 0, ROWS_GUARD * sizeof(double));
+    s->host = hbase + ROWS_GUARD;
+    s->host_dev = nullptr;
+    void *dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, hbase, 0) == hipSuccess && dp)
+        s->host_dev = (double *)dp + ROWS_GUARD;
     s->g.rows = s->dev + ROWS_GUARD;
     s->cap_elems = cap;
     return MUSE_OK;
@@ -210,7 +220,15 @@ extern "C" int muse_batch_run_rows(muse_batch *tmpl, const double *rows, int64_t
             memcpy(s->host + (size_t)r * (size_t)N, rows + (size_t)r * (size_t)row_stride, (size_t)N * sizeof(double));
     }
     s->out->state = ~0ull;
-    hipError_t e = hipMemcpyAsync(s->g.rows, s->host, elems * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    // The smallest groups are not copied at all: the fused kernel reads its rows once, so it reads them straight from the
+    // pinned staging buffer over PCIe (a copy command in front of the kernel costs more than its 19 KB take to cross)
+    hipError_t e = hipSuccess;
+    if (s->host_dev && elems * sizeof(double) <= ROWS_ZERO_COPY_BYTES && !ctx->rows_always_copy) {
+        s->g.rows = s->host_dev;
+    } else {
+        s->g.rows = s->dev + ROWS_GUARD;
+        e = hipMemcpyAsync(s->g.rows, s->host, elems * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    }
     if (e == hipSuccess) {
         rc = muse_batch_score(&s->b); // the fused kernel automatic selection takes for this length (and its redo launch, if any)
         if (!rc)
@@ -234,5 +252,13 @@ extern "C" int muse_batch_run_rows(muse_batch *tmpl, const double *rows, int64_t
     if (st > 2ull)
         return fail(MUSE_ERR_HIP, "muse_batch_run_rows: the result record did not arrive");
     *out_state = (uint8_t)st;
+    return MUSE_OK;
+}
+
+extern "C" int muse_test_rows_always_copy(muse_ctx *ctx, int32_t always_copy)
+{
+    if (!ctx)
+        return fail(MUSE_ERR_INVALID, "NULL context");
+    ctx->rows_always_copy = always_copy != 0;
     return MUSE_OK;
 }

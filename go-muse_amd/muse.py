@@ -72,6 +72,10 @@ class Engine:
         """test hook (include/muse_hip_test.h): scales the error bound the filter-and-refine Run assumes"""
         B.check(B.load().muse_test_set_screen_bound_scale(self._h, float(scale)))
 
+    def rows_always_copy(self, on):
+        """test hook: muse_batch_run_rows copies even the smallest groups to HBM instead of letting the kernel read the pinned buffer"""
+        B.check(B.load().muse_test_rows_always_copy(self._h, 1 if on else 0))
+
     def wave_argmax(self, cc_a, cc_b):
         """test hook: the n = 4096 kernels' per-wave argmax step on 2 x 4096 given values; (4, 2, 3) array of
         {max |cc|, signed value, index} per wave and series"""

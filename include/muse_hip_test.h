@@ -44,6 +44,11 @@ int muse_test_clock_probe_read(muse_ctx *ctx, double *mhz, int32_t cap, int32_t 
  * nothing is above 0), winning index (2147483647 when nothing is above 0)} of series A, then of series B. */
 int muse_test_wave_argmax(muse_ctx *ctx, const double *ccA, const double *ccB, double *out24);
 
+/* muse_batch_run_rows lets the fused kernel read groups of up to 256 KB straight out of the pinned staging buffer (no copy
+ * command); always_copy = 1 sends every group through the host -> HBM copy instead (A/B of the two, and the parity suite
+ * runs both). */
+int muse_test_rows_always_copy(muse_ctx *ctx, int32_t always_copy);
+
 #ifdef __cplusplus
 }
 #endif

@@ -976,7 +976,11 @@ def test_run_rows_one_call_equals_run_groups(muse, eng, oracle, N):
         db = muse.DeviceBatch.like(tmpl, dg)
         olag, omv, gap = oracle.batch_scores(ref_y, np.ascontiguousarray(rows)) if not np.isnan(rows).any() else (None, None, None)
         for abs_scores in (False, True):
+            eng.rows_always_copy(True)                                 # both ways in: through the copy ...
+            copied = tmpl.run_rows(rows, abs_scores=abs_scores)
+            eng.rows_always_copy(False)                                # ... and (up to 256 KB) read by the kernel from pinned memory
             win, st = tmpl.run_rows(rows, abs_scores=abs_scores)
+            assert copied[1] == st and copied[0].tolist() == win.tolist()
             rec, state = db.run_groups(np.zeros(M, dtype=np.int32), 1, 0, abs_scores=abs_scores)
             assert st == int(state[0]) and win.tolist() == rec[0].tolist(), (N, M, abs_scores)
             assert st == (2 if case == 3 else 1)

@@ -22,4 +22,11 @@ for N, K in ((8, 2), (12, 1), (480, 5), (480, 50), (4096, 5), (4096, 200), (3276
     for _ in range(reps):
         m._template.run_rows(rows, abs_scores=False)
     da = (time.perf_counter() - t0) / reps
-    print("N=%6d, %3d series per call: %6.1f us per Muse.Run (mirror), %6.1f us per muse_batch_run_rows" % (N, K, dt * 1e6, da * 1e6), flush=True)
+    muse.get_engine().rows_always_copy(True)
+    m._template.run_rows(rows, abs_scores=False)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        m._template.run_rows(rows, abs_scores=False)
+    dc = (time.perf_counter() - t0) / reps
+    muse.get_engine().rows_always_copy(False)
+    print("N=%6d, %3d series per call: %6.1f us per Muse.Run (mirror), %6.1f us per muse_batch_run_rows, %6.1f us with the copy forced" % (N, K, dt * 1e6, da * 1e6, dc * 1e6), flush=True)
