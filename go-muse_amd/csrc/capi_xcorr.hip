@@ -137,8 +137,121 @@ extern "C" int muse_xcorr(muse_ctx *ctx, const double *x, int32_t lenx, const do
 }
 
 // ---- batched two-sided xCorr (xcorr.go:102-153)
+static int xcorr_groups_impl(muse_group *gx, muse_group *gy, int32_t n, int32_t normalize, int32_t *lag, double *mv,
+                             int32_t *is_nil, double *cc, bool rescue);
+
+// Pairs that came back NaN although the reference may still return numbers: FINITE samples whose squares leave the float64
+// range (|x| >~ 1e154; the batched kernels take sum d^2 for their power-of-two scales).  A device kernel looks at each such
+// pair again (xcorr_kernels.hip, two_sided_rescue_kernel): NaN stands (a NaN / Inf sample, or the reference's own arithmetic
+// overflows), every cc is zero (normalized with sigma = +Inf; raw with an all-zero series), or the pair is recomputed by the same
+// batched kernels on copies scaled by exact powers of two that leave the result unchanged.
+static int rescue_overflowed_pairs(muse_group *gx, muse_group *gy, int32_t n, int32_t normalize, int32_t *lag, double *mv,
+                                   const std::vector<int> &nil, double *cc)
+{
+    muse_ctx *ctx = gx->ctx;
+    const int64_t M = gx->M;
+    std::vector<long long> list;
+    for (int64_t i = 0; i < M; i++)
+        if (!nil[(size_t)i] && mv[i] != mv[i])
+            list.push_back(i);
+    if (list.empty())
+        return MUSE_OK;
+    const int K = (int)std::min<size_t>(list.size(), 0x7fffffff);
+    long long *dlist = nullptr;
+    int *dcode = nullptr;
+    double2 *dscale = nullptr;
+    muse_group *sx = nullptr, *sy = nullptr;
+    auto cleanup = [&]() {
+        (void)hipFree(dlist); (void)hipFree(dcode); (void)hipFree(dscale);
+        muse_group_free(sx);
+        muse_group_free(sy);
+    };
+    std::vector<int> code((size_t)K);
+    hipError_t e = hipMalloc(&dlist, (size_t)K * sizeof(long long));
+    if (e == hipSuccess)
+        e = hipMalloc(&dcode, (size_t)K * sizeof(int));
+    if (e == hipSuccess)
+        e = hipMalloc(&dscale, (size_t)K * sizeof(double2));
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(dlist, list.data(), (size_t)K * sizeof(long long), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess)
+        e = launch_two_sided_rescue(gx->rows, gx->stride, gx->N, gy->rows, gy->stride, gy->N, n, normalize, dlist, K, dcode, dscale,
+                                    ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(code.data(), dcode, (size_t)K * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        cleanup();
+        return fail(MUSE_ERR_HIP, "two-sided xCorr (overflowed statistics): %s", hipGetErrorString(e));
+    }
+    std::vector<long long> again; // positions in `list` of the pairs to recompute
+    for (int k = 0; k < K; k++) {
+        const int64_t i = list[(size_t)k];
+        if (code[(size_t)k] == 1) { // every cc is zero: maxAbsIndex keeps index 0
+            mv[i] = 0.0;
+            lag[i] = 0;
+            if (cc)
+                std::fill(cc + (size_t)i * (size_t)n, cc + (size_t)(i + 1) * (size_t)n, 0.0);
+        } else if (code[(size_t)k] == 2) {
+            again.push_back(k);
+        }
+    }
+    if (again.empty()) {
+        cleanup();
+        return MUSE_OK;
+    }
+    // the pairs to recompute, compacted: list entries and scales in the order of `again`
+    const int K2 = (int)again.size();
+    std::vector<long long> list2((size_t)K2);
+    std::vector<double2> scale((size_t)K), scale2((size_t)K2);
+    e = hipMemcpy(scale.data(), dscale, (size_t)K * sizeof(double2), hipMemcpyDeviceToHost);
+    for (int k = 0; k < K2; k++) {
+        list2[(size_t)k] = list[(size_t)again[(size_t)k]];
+        scale2[(size_t)k] = scale[(size_t)again[(size_t)k]];
+    }
+    int rc = MUSE_OK;
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(dlist, list2.data(), (size_t)K2 * sizeof(long long), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(dscale, scale2.data(), (size_t)K2 * sizeof(double2), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess)
+        rc = muse_group_create(ctx, K2, gx->N, &sx);
+    if (e == hipSuccess && !rc)
+        rc = muse_group_create(ctx, K2, gy->N, &sy);
+    if (e == hipSuccess && !rc)
+        e = launch_scale_listed_rows(gx->rows, gx->stride, gx->N, dlist, dscale, 0, K2, sx->rows, ctx->stream);
+    if (e == hipSuccess && !rc)
+        e = launch_scale_listed_rows(gy->rows, gy->stride, gy->N, dlist, dscale, 1, K2, sy->rows, ctx->stream);
+    if (e != hipSuccess || rc) {
+        cleanup();
+        return rc ? rc : fail(MUSE_ERR_HIP, "two-sided xCorr (overflowed statistics): %s", hipGetErrorString(e));
+    }
+    sx->M = K2;
+    sy->M = K2;
+    std::vector<int32_t> lag2((size_t)K2), nil2((size_t)K2);
+    std::vector<double> mv2((size_t)K2), cc2(cc ? (size_t)K2 * (size_t)n : 0);
+    rc = xcorr_groups_impl(sx, sy, n, normalize, lag2.data(), mv2.data(), nil2.data(), cc ? cc2.data() : nullptr, false);
+    if (!rc)
+        for (int k = 0; k < K2; k++) {
+            const int64_t i = list2[(size_t)k];
+            lag[i] = lag2[(size_t)k];
+            mv[i] = mv2[(size_t)k];
+            if (cc)
+                std::copy(cc2.begin() + (size_t)k * (size_t)n, cc2.begin() + (size_t)(k + 1) * (size_t)n, cc + (size_t)i * (size_t)n);
+        }
+    cleanup();
+    return rc;
+}
+
 extern "C" int muse_xcorr_groups(muse_group *gx, muse_group *gy, int32_t n, int32_t normalize, int32_t *lag, double *mv,
                                  int32_t *is_nil, double *cc)
+{
+    return xcorr_groups_impl(gx, gy, n, normalize, lag, mv, is_nil, cc, true);
+}
+
+static int xcorr_groups_impl(muse_group *gx, muse_group *gy, int32_t n, int32_t normalize, int32_t *lag, double *mv,
+                             int32_t *is_nil, double *cc, bool rescue)
 {
     if (!gx || !gy || gx->ctx != gy->ctx)
         return fail(MUSE_ERR_INVALID, "the two groups must share a context");
@@ -271,7 +384,8 @@ extern "C" int muse_xcorr_groups(muse_group *gx, muse_group *gy, int32_t n, int3
         if (cc && !nil[(size_t)i] && mv[i] != mv[i]) // NaN / Inf statistics: the reference's cc is NaN throughout
             std::fill(cc + (size_t)i * (size_t)n, cc + (size_t)(i + 1) * (size_t)n, std::numeric_limits<double>::quiet_NaN());
     }
-    return MUSE_OK;
+    // ... unless the samples are finite and only their squares overflowed
+    return rescue ? rescue_overflowed_pairs(gx, gy, n, normalize, lag, mv, nil, cc) : MUSE_OK;
 }
 
 extern "C" int muse_xcorr_batch(muse_ctx *ctx, const double *x_rows, const double *y_rows, int64_t M, int32_t lenx, int32_t leny,

@@ -103,8 +103,8 @@ constexpr int SMALL_MAX_N = 16384;       // largest FFT length of xcorr_small.hi
 constexpr int GENERIC_LDS_MAX_N = 8192;  // larger n: the radix-2 passes run in gscratch
 constexpr int GENERIC_MAX_N = 65536;
 constexpr int GENERIC_GLOBAL_WGS_PER_CU = 2;
-constexpr int STOCKHAM_GLOBAL_WGS_PER_CU = 2; // xcorr_fused_stk_4step: resident workgroups per CU, one n-element slice each (two for the two-sided xCorr)
-constexpr int LONG_WGS_PER_CU = 4;            // xcorr_long.hip: resident workgroups per CU, one n-element slice each
+constexpr int STOCKHAM_GLOBAL_WGS_PER_CU = 2; // xcorr_fused_stk_4step (the long series' redo kernel): resident workgroups per CU, one n-element slice each
+constexpr int LONG_WGS_PER_CU = 4;            // xcorr_long.hip and xcorr_two_sided_long: resident workgroups per CU, one n-element slice each
 // n-element complex slices of the context's scratch buffer per CU (capi_batch.hip, ensure_gscratch): every kernel that works in it
 // launches at most this many workgroups per CU times the slices each of them uses, and checks FusedParams::gscratch_slices
 constexpr int GSCRATCH_SLICES_PER_CU = 4;
@@ -114,6 +114,13 @@ static_assert(LONG_WGS_PER_CU <= GSCRATCH_SLICES_PER_CU && GENERIC_GLOBAL_WGS_PE
 hipError_t launch_direct(const double *x, int lenx, const double *y, int leny, int n, int normalize_x,
                          int normalize_y, double x_scale, double cc_scale, double *cc, int *lag, double *mv,
                          int *status, hipStream_t stream);
+// two-sided xCorr, pairs whose statistics overflowed (xcorr_kernels.hip): what the reference's arithmetic gives for each listed
+// pair (code 0 NaN stands / 1 every cc zero / 2 recompute on copies scaled by (scale.x, scale.y)), and those copies
+hipError_t launch_two_sided_rescue(const double *xrows, long long xstride, int Nx, const double *yrows, long long ystride, int Ny,
+                                   int n, int normalize, const long long *list, int count, int *code, double2 *scale,
+                                   hipStream_t stream);
+hipError_t launch_scale_listed_rows(const double *src, long long stride, int N, const long long *list, const double2 *g, int which,
+                                    int count, double *dst, hipStream_t stream);
 hipError_t launch_synth(double *rows, long long stride, long long first, long long count, long long global_first,
                         int N, unsigned long long seed, unsigned flags, hipStream_t stream);
 hipError_t launch_synth_f32(float *rows, long long stride, long long first, long long count, long long global_first,

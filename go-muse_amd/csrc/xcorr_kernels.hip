@@ -532,6 +532,141 @@ hipError_t launch_direct(const double *x, int lenx, const double *y, int leny, i
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------- two-sided xCorr: pairs whose statistics left the float64 range
+// The batched xCorr kernels take sum d^2 for their exact power-of-two scales; for FINITE samples with |x| >~ 1e154 that sum is
+// Inf and the pair comes back like a NaN pair, where the reference (xcorr.go:108-143) still returns numbers: raw, cc is
+// finite whenever the products X conj(Y) are; normalized, gonum's StdDev overflows to +Inf and the series becomes all zeros
+// (x / Inf), or -- when even (sum d)^2 overflows -- NaN.  This kernel looks at such a pair again, one workgroup per listed
+// pair, and decides (code) what the reference's arithmetic gives:
+//   0  NaN stands: a NaN / Inf sample, a NaN variance, or products that overflow float64 in the reference too;
+//   1  every cc is zero (lag 0, value 0): a series scaled by 1 / Inf, or a raw pair with an all-zero series;
+//   2  recompute on copies scaled by exact powers of two, (gx, gy): normalized -- each series to magnitude 1 (z-normalisation
+//      cancels any scale); raw -- x 2^-k and y 2^+k, which leaves x[i] y[j] and with it every cc unchanged (bilinear) while
+//      both series meet at the geometric mean of their magnitudes.
+// The variance is the corrected two-pass of stat.StdDev as oracle/muse_oracle.c restates it: (sum d^2 - (sum d)^2 / N) / (N - 1).
+struct SeriesLook {
+    bool finite;   // every sample is a number
+    double maxabs; // max |x|
+    double var;    // normalized: the reference's variance (may be +Inf or NaN)
+};
+__device__ SeriesLook look_at_series(const double *__restrict__ x, const int N, const bool normalize, double *red)
+{
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const auto block_sum = [&](double v) {
+        v = wave_sum_dpp(v);
+        __syncthreads();
+        if (lane == 0)
+            red[wave] = v;
+        __syncthreads();
+        return (red[0] + red[1]) + (red[2] + red[3]);
+    };
+    const auto block_max = [&](double v) {
+        v = wave_max(v);
+        __syncthreads();
+        if (lane == 0)
+            red[wave] = v;
+        __syncthreads();
+        return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    };
+    double bad = 0.0, mx = 0.0, sum = 0.0;
+    for (int i = t; i < N; i += 256) {
+        const double v = x[i];
+        bad = __builtin_isfinite(v) ? bad : 1.0;
+        mx = fmax(mx, fabs(v)); // (fmax drops a NaN operand: `bad` carries it)
+        sum += v;
+    }
+    SeriesLook s;
+    s.finite = block_max(bad) == 0.0;
+    s.maxabs = block_max(mx);
+    s.var = 0.0;
+    if (normalize) {
+        const double mean = block_sum(sum) / (double)N;
+        double ss = 0.0, comp = 0.0;
+        for (int i = t; i < N; i += 256) {
+            const double d = x[i] - mean;
+            ss = fma(d, d, ss);
+            comp += d;
+        }
+        ss = block_sum(ss);
+        comp = block_sum(comp);
+        s.var = (ss - comp * comp / (double)N) / (double)(N - 1);
+    }
+    return s;
+}
+__device__ __forceinline__ int exp_of(double v) { return (int)((__double_as_longlong(v) >> 52) & 0x7ff) - 1023; }
+__device__ __forceinline__ double pow2(int e) { return __longlong_as_double((long long)(e + 1023) << 52); } // -1022 <= e <= 1023
+
+__global__ __launch_bounds__(256) void two_sided_rescue_kernel(const double *__restrict__ xrows, long long xstride, int Nx,
+                                                               const double *__restrict__ yrows, long long ystride, int Ny,
+                                                               int n, int normalize, const long long *__restrict__ list,
+                                                               int *__restrict__ code, double2 *__restrict__ scale)
+{
+    __shared__ double red[4];
+    const long long pair = list[blockIdx.x];
+    const SeriesLook a = look_at_series(xrows + pair * xstride, Nx, normalize != 0, red);
+    const SeriesLook b = look_at_series(yrows + pair * ystride, Ny, normalize != 0, red);
+    if (threadIdx.x != 0)
+        return;
+    int c = 0;
+    double gx = 1.0, gy = 1.0;
+    if (a.finite && b.finite) {
+        if (normalize) {
+            const bool nanv = a.var != a.var || b.var != b.var;
+            if (!nanv && (__builtin_isinf(a.var) || __builtin_isinf(b.var)))
+                c = 1; // x / sigma with sigma = +Inf: the series is all zeros, and so is every cc
+            else if (!nanv && a.maxabs > 0.0 && b.maxabs > 0.0) {
+                c = 2;
+                gx = pow2(-max(-1022, min(1022, exp_of(a.maxabs))));
+                gy = pow2(-max(-1022, min(1022, exp_of(b.maxabs))));
+            }
+        } else if (a.maxabs == 0.0 || b.maxabs == 0.0) {
+            c = 1;
+        } else {
+            const int ex = exp_of(a.maxabs), ey = exp_of(b.maxabs);
+            // after balancing both magnitudes sit at 2^((ex + ey) / 2): the squares of the shared transform (and the reference's
+            // own products X conj(Y), up to n max|x| max|y|) must stay inside the float64 range
+            if (ex + ey + 2 * (32 - __clz(n)) < 1000) {
+                const int k = max(-1022, min(1022, (ex - ey) / 2));
+                c = 2;
+                gx = pow2(-k);
+                gy = pow2(k);
+            }
+        }
+    }
+    code[blockIdx.x] = c;
+    scale[blockIdx.x] = make_double2(gx, gy);
+}
+// dst row k = src row list[k] * g[k].x (which = 0) or * g[k].y (which = 1): exact (powers of two)
+__global__ __launch_bounds__(256) void scale_listed_rows_kernel(const double *__restrict__ src, long long stride, int N,
+                                                                const long long *__restrict__ list, const double2 *__restrict__ g,
+                                                                int which, double *__restrict__ dst)
+{
+    const long long pair = list[blockIdx.x];
+    const double f = which ? g[blockIdx.x].y : g[blockIdx.x].x;
+    const double *s = src + pair * stride;
+    double *d = dst + (long long)blockIdx.x * N;
+    for (int i = threadIdx.x; i < N; i += 256)
+        d[i] = s[i] * f;
+}
+hipError_t launch_two_sided_rescue(const double *xrows, long long xstride, int Nx, const double *yrows, long long ystride, int Ny,
+                                   int n, int normalize, const long long *list, int count, int *code, double2 *scale,
+                                   hipStream_t stream)
+{
+    if (count <= 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(two_sided_rescue_kernel, dim3((unsigned)count), dim3(256), 0, stream, xrows, xstride, Nx, yrows, ystride, Ny,
+                       n, normalize, list, code, scale);
+    return hipGetLastError();
+}
+hipError_t launch_scale_listed_rows(const double *src, long long stride, int N, const long long *list, const double2 *g, int which,
+                                    int count, double *dst, hipStream_t stream)
+{
+    if (count <= 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(scale_listed_rows_kernel, dim3((unsigned)count), dim3(256), 0, stream, src, stride, N, list, g, which, dst);
+    return hipGetLastError();
+}
+
 hipError_t launch_synth(double *rows, long long stride, long long first, long long count, long long global_first,
                         int N, unsigned long long seed, unsigned flags, hipStream_t stream)
 {

@@ -394,7 +394,11 @@ __global__ __launch_bounds__(256, 4) void xcorr_two_sided_long(const FusedParams
                 ps.nan = !__builtin_isfinite(mA2) || !__builtin_isfinite(mB2);
                 dead = ps.nan;
                 const int eA = var_exp(mA2), eB = var_exp(mB2);
-                redo = !dead && mA2 > 0.0 && mB2 > 0.0 && (sigma_spread_too_wide(mA2, mB2) || eA > 400 || eA < -400 || eB > 400 || eB < -400);
+                // (each series on its own: an all-zero x -- or one whose squares underflow -- beside a y of magnitude 1e150 overflows the
+                // unscaled square just the same; the kernel that scales first handles it: sA = 1, y rescaled)
+                const bool hasA = mA2 > 0.0, hasB = mB2 > 0.0;
+                redo = !dead && ((hasA && hasB && sigma_spread_too_wide(mA2, mB2)) || (hasA && (eA > 400 || eA < -400)) ||
+                                 (hasB && (eB > 400 || eB < -400)) || (hasA != hasB));
                 fac = 1.0 / (2.0 * n);
             }
             if (redo && t == 0) {

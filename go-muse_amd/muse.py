@@ -595,9 +595,15 @@ class Group:
         return [self.registry[u] for u in self.index.get(guid, [])]
 
     def indexLabelValues(self, groupByLabels):    # group.go:76-104
+        groupByLabels = list(groupByLabels) if groupByLabels else []
+        # the partition depends on the label names and the series alone, and series are only ever added: a repeated Run with the
+        # same grouping over the same series reuses it (and the group ids derived from it: _group_ids)
+        key = (len(self.registry), tuple(groupByLabels))
+        if getattr(self, "_index_key", None) == key and self.registry:
+            return self._index_distinct
         distinct = []
         self.index = {}
-        groupByLabels = list(groupByLabels) if groupByLabels else []
+        self._gid_cache = None
         for uid, s in self.registry.items():
             if len(groupByLabels) != 0:
                 guid = s.labels.ID(groupByLabels)
@@ -613,7 +619,19 @@ class Group:
                 distinct.append(NewLabels(lv))
                 self.index[guid] = []
             self.index[guid].append(uid)
+        self._index_key, self._index_distinct = key, distinct
         return distinct
+
+    def _group_ids(self):
+        """int32 group id of every series (insertion order) for the partition indexLabelValues built last"""
+        if getattr(self, "_gid_cache", None) is None:
+            uid_pos = {uid: i for i, uid in enumerate(self.registry)}
+            gid = np.zeros(len(uid_pos), dtype=np.int32)
+            for g, uids in enumerate(self.index.values()):   # same order as the distinct label values
+                for u in uids:
+                    gid[uid_pos[u]] = g
+            self._gid_cache = gid
+        return self._gid_cache
 
     # --- device residency: the matrix is uploaded once and appended to
     def _series_list(self):
@@ -823,11 +841,7 @@ class Batch:
         if not labelValuesSet:
             return None
         series = comp._series_list()
-        uid_pos = {uid: i for i, uid in enumerate(comp.registry)}
-        gid = np.zeros(len(series), dtype=np.int32)
-        for g, uids in enumerate(comp.index.values()):   # same order as labelValuesSet
-            for u in uids:
-                gid[uid_pos[u]] = g
+        gid = comp._group_ids()
         r = self.Results
         G = len(labelValuesSet)
         if G <= EXACT_FEED_MAX_GROUPS:
@@ -957,11 +971,7 @@ def RunMany(batches, groupByLabels):
     if not labelValuesSet:
         return None
     series = comp._series_list()
-    uid_pos = {uid: i for i, uid in enumerate(comp.registry)}
-    gid = np.zeros(len(series), dtype=np.int32)
-    for g, uids in enumerate(comp.index.values()):
-        for u in uids:
-            gid[uid_pos[u]] = g
+    gid = comp._group_ids()
     res = run_many([b._batch() for b in batches], gid, len(labelValuesSet), r0.MaxLag, r0.TopN, r0.Threshold,
                    r0.SignFilter, abs_scores=True)
     for b, (idx, lag, score, _) in zip(batches, res):

@@ -95,7 +95,11 @@ int muse_ctx_device_pci_bus_id(muse_ctx *ctx, char *out, int32_t cap);
  * spectrum), re-evaluates in fp64 exactly those rows whose optimistic selection key reaches the top_n-th best
  * pessimistic key, and selects among the re-evaluated rows only: the records returned are the ones the all-fp64 Run
  * returns (a run-time guard re-does the Run in fp64 if an estimate is found outside the bound).
- * muse_batch_read_scores after such a Run re-scores every row in fp64 first. */
+ * muse_batch_read_scores after such a Run re-scores every row in fp64 first.
+ * Not every Run can take it: muse_batch_run_groups and muse_batch_run_rows always score in float64, and the host mirrors'
+ * Batch.Run goes through muse_batch_run_groups whenever it has at most 65 536 label groups (it feeds Results one Score per
+ * group, the reference's own order among exactly tied scores) -- so with the mirrors screening only ever applies to Runs
+ * over more label groups than that (Run(nil) over a large Group). */
 int muse_ctx_set_screening(muse_ctx *ctx, int32_t enable);
 /* Which path the last muse_batch_run / muse_batch_run_shard on this batch took: *screened = 1 for filter-and-refine,
  * *refined_pairs = pairs of series it re-evaluated in fp64.  Any out pointer may be NULL. */
@@ -312,12 +316,16 @@ int muse_xcorr(muse_ctx *ctx, const double *x, int32_t lenx, const double *y,
                int32_t *lag, double *mv, int32_t *is_nil);
 /* xCorr (xcorr.go:102-153) for M independent pairs in ONE launch: pair i = (row i of gx, row i of gy).
  * The two groups may hold series of different lengths (each is zero-padded on its own, xcorr.go:129-130); n is raised
- * to max(n, Nx, Ny) (xcorr.go:104-106).  FFT lengths 512 ... 65536 that are powers of two run the batched kernels
- * (n <= 16384: z = (x read backwards) + i y, one forward transform, cc = Im FFT(Z^2) / 2n on the xCorrWithX kernels'
- * transforms -- xcorr_two_sided.hip, xcorr_small.hip; n >= 32768: z = x + i y, X conj(Y) untangled from Z[f] and Z[-f],
- * one more forward transform; scale 1 / (n (n - 1)) when normalized else 1 / n, exactly as xcorr.go:139-143); any other n (the
- * reference's n = 5 tables, short series) goes pair by pair through muse_xcorr's path.  The groups are not mutated
- * (the reference's zNormalize mutates x and y in place).
+ * to max(n, Nx, Ny) (xcorr.go:104-106).  FFT lengths 512 ... 65536 that are powers of two run the batched kernels, all in
+ * one form: z = (x read backwards) + i y, one forward transform, cc = Im FFT(Z^2) / 2n on the xCorrWithX kernels' transforms
+ * (xcorr_two_sided.hip: n = 4096 and, on the four-step transform with one scratch slice per workgroup, n = 32768 / 65536;
+ * xcorr_small.hip: the other lengths); scale 1 / (n (n - 1)) when normalized else 1 / n, exactly as xcorr.go:139-143.  For
+ * n >= 32768 with Nx = Ny = n the rows are read once and the spectrum squared unscaled; pairs whose series differ by more than
+ * 2^16 in scale (or whose magnitudes are extreme) are listed on the device and redone by a second launch that takes the
+ * statistics first.  Finite samples whose SQUARES leave the float64 range (|x| >~ 1e154) are looked at again by a device
+ * kernel and give what the reference's arithmetic gives: finite correlations (raw), all zeros (normalized, sigma = +Inf) or
+ * NaN (the reference's own sums overflow).  Any other n (the reference's n = 5 tables, short series) goes pair by pair
+ * through muse_xcorr's path.  The groups are not mutated (the reference's zNormalize mutates x and y in place).
  * Outputs (host): lag[M], mv[M]; is_nil[M] (may be NULL) = 1 where the reference returns (nil, 0, 0), i.e. normalize
  * and sigma(x) == 0 or sigma(y) == 0; cc (may be NULL): M x n correlations (rows of nil pairs are zero). */
 int muse_xcorr_groups(muse_group *gx, muse_group *gy, int32_t n, int32_t normalize,

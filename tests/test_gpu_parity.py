@@ -1926,7 +1926,7 @@ def _check_xcorr_batch(eng, oracle, X, Y, n, normalize):
 @pytest.mark.parametrize("normalize", [True, False])
 def test_xcorr_batch_matches_oracle(eng, oracle, n, normalize):
     rng = np.random.default_rng(n + int(normalize))
-    M = 11 if n <= 8192 else 5
+    M = 11 if n <= 8192 else 7
     for N in (n, n - n // 4 - 3):                          # no padding (circular) and leading zero pads
         X = rng.normal(size=(M, N)) * rng.uniform(0.1, 30.0, size=(M, 1)) + rng.normal(size=(M, 1)) * 5.0
         Y = rng.normal(size=(M, N)) * rng.uniform(0.1, 30.0, size=(M, 1)) - 2.0
@@ -1937,6 +1937,11 @@ def test_xcorr_batch_matches_oracle(eng, oracle, n, normalize):
         Y[4] *= 1e-7
         if N == n:
             Y[0, N // 3] = np.nan                          # every cc NaN: lag 0, mv NaN
+        # finite samples whose SQUARES leave the float64 range (xcorr.go:108-143 still returns numbers): raw -- finite cc of
+        # magnitude 1e200; normalized -- gonum's sigma is +Inf and the series all zeros (1e160), or (sum d)^2 overflows too and
+        # everything is NaN (1e200)
+        X[5] *= 1e200
+        Y[6] *= 1e160
         _check_xcorr_batch(eng, oracle, X, Y, n, normalize)
 
 
@@ -1947,9 +1952,13 @@ def test_xcorr_batch_long_series_single_read_and_its_redo_list(eng, oracle, n):
     and redone by the launch that takes the statistics first and scales by exact powers of two.  Every kind of pair in one batch,
     more listed pairs than one workgroup takes, against the oracle (full cc vectors)."""
     rng = np.random.default_rng(n)
-    M = 9
+    M = 11
     X = rng.normal(size=(M, n)) * 3.0 + 1.0
     Y = rng.normal(size=(M, n)) - 0.5
+    X[8] = 0.0                                             # an all-zero series beside one of magnitude 1e150: listed (raw: the
+    Y[8] *= 1e150                                          # unscaled square of y alone would overflow), nil when normalized
+    X[9] *= 1e-170                                         # squares underflow to zero beside 1e148: listed
+    Y[9] *= 1e148
     Y[0] = np.roll(X[0], -11) * 2.0                        # an ordinary pair with a clear peak
     X[1] *= 1e130; Y[1] *= 1e130                           # extreme magnitudes, equal scale: listed
     X[2] *= 1e-130; Y[2] *= 1e-130                         # tiny magnitudes: listed
