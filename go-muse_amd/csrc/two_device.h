@@ -48,9 +48,14 @@ __device__ __forceinline__ PairScale pair_scale(const double (&q)[4], const Pair
     } else {
         const double eA = q[1] * iv.invNx, eB = q[3] * iv.invNy; // mean squares (only their binary exponents are used)
         s.nil = false;
-        s.nan = !__builtin_isfinite(eA) || !__builtin_isfinite(eB);
-        s.sA = (s.nan || !(eA > 0.0)) ? 1.0 : pow2_inv_sigma(eA);
-        s.sB = (s.nan || !(eB > 0.0)) ? 1.0 : pow2_inv_sigma(eB);
+        // A mean square that is not a positive number gives no scale: Inf / NaN (a NaN or Inf sample, or finite samples whose
+        // squares overflow), or 0 (an all-zero series, or samples whose squares underflow) -- beside a series of any magnitude the
+        // cross term of Z^2 would drown in the rounding of the other series' square.  Such a pair leaves as a NaN pair; the
+        // host has every NaN pair looked at again (capi_xcorr.hip, rescue_overflowed_pairs): all-zero series -> every cc is 0,
+        // finite samples -> recomputed on copies balanced by exact powers of two, NaN / Inf samples -> NaN stands.
+        s.nan = !__builtin_isfinite(eA) || !__builtin_isfinite(eB) || !(eA > 0.0) || !(eB > 0.0);
+        s.sA = s.nan ? 1.0 : pow2_inv_sigma(eA);
+        s.sB = s.nan ? 1.0 : pow2_inv_sigma(eB);
         s.mA = s.mB = 0.0;
         s.fac = (1.0 / s.sA) * (1.0 / s.sB); // exact
     }

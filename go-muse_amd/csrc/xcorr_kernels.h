@@ -72,7 +72,17 @@ struct FusedParams {
     const double *xrows;
     long long xstride;
     int Nx;
+    // 1 / N and 1 / (N - 1), formed on the host by the launchers (with_reciprocals): as kernel arguments they live in scalar
+    // registers; formed by the kernel (N is a run-time value in the builds for zero-padded series) they come out of the vector
+    // divider, and wave-uniform values in vector registers were what those builds parked in scratch
+    double invN, invNm1;
 };
+inline FusedParams with_reciprocals(FusedParams p)
+{
+    p.invN = 1.0 / (double)p.N;
+    p.invNm1 = 1.0 / (double)(p.N - 1);
+    return p;
+}
 
 hipError_t launch_fused(const FusedParams &p, int variant, int num_cus, hipStream_t stream);
 hipError_t launch_fused_occ4(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_r16_occ4.hip (rescaling / pair-list kernel)

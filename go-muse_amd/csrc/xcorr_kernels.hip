@@ -624,8 +624,11 @@ __global__ __launch_bounds__(256) void two_sided_rescue_kernel(const double *__r
         } else {
             const int ex = exp_of(a.maxabs), ey = exp_of(b.maxabs);
             // after balancing both magnitudes sit at 2^((ex + ey) / 2): the squares of the shared transform (and the reference's
-            // own products X conj(Y), up to n max|x| max|y|) must stay inside the float64 range
-            if (ex + ey + 2 * (32 - __clz(n)) < 1000) {
+            // own products X conj(Y), up to n max|x| max|y|) must stay inside the float64 range -- above it the reference
+            // overflows too (NaN stands), below it every product underflows there as well (every cc is zero)
+            if (ex + ey < -1000) {
+                c = 1;
+            } else if (ex + ey + 2 * (32 - __clz(n)) < 1000) {
                 const int k = max(-1022, min(1022, (ex - ey) / 2));
                 c = 2;
                 gx = pow2(-k);

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256, 4) void xcorr_fused_long(const FusedParams p)
     double2 *const Y = p.gscratch + (size_t)blockIdx.x * (size_t)n * (MULTI ? 2 : 1); // the workgroup's slice (MULTI: two)
     double2 *const Y2 = MULTI ? Y + n : Y; // where the second transforms land and sweep 2 reads
     const int N = PADDED ? p.N : n, pad = n - N;
-    const double invN = 1.0 / (double)N, invNm1 = 1.0 / (double)(N - 1);
+    const double invN = PADDED ? p.invN : 1.0 / (double)n, invNm1 = PADDED ? p.invNm1 : 1.0 / (double)(n - 1); // (the launcher's quotients: scalar registers)
     const double2 *__restrict__ twl = p.twl; // [4096] W_n^(m2)
     // addresses: a scalar base formed where it is used plus one 32-bit lane offset (nothing 64-bit per lane, nothing
     // hoisted out of the loops into registers the transforms need)
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256, 4) void xcorr_fused_long(const FusedParams p)
                     const d2v z = SLICE_LD((gd2)scalar_ptr_at(row, 256 * i) + tl);
                     v[i] = make_double2(z.x, z.y);
                 }
-                row_forward(v, xbuf, xw, g2s, p.g3a, t, wave, !PADDED && k1 == 0);
+                row_forward(v, xbuf, xw, g2s, p.g3a, opaque(t), wave, !PADDED && k1 == 0);
                 const unsigned ts = (unsigned)(opaque(t) & 255);
 #pragma unroll
                 for (int r = 0; r < 16; r++)
@@ -217,9 +217,9 @@ __global__ __launch_bounds__(256, 4) void xcorr_fused_long(const FusedParams p)
                 }
             }
             if (MULTI)
-                row_second(v, xbuf, xw, g2s, p.g3b, xcp + k1 * 4096, t, wave);
+                row_second(v, xbuf, xw, g2s, p.g3b, xcp + k1 * 4096, opaque(t), wave);
             else
-                row_transforms(v, xbuf, xw, g2s, p.g3a, p.g3b, xcp + k1 * 4096, t, wave, !PADDED && k1 == 0);
+                row_transforms(v, xbuf, xw, g2s, p.g3a, p.g3b, xcp + k1 * 4096, opaque(t), wave, !PADDED && k1 == 0);
             {
                 const unsigned tl = (unsigned)(opaque(t) & 255);
 #pragma unroll
@@ -380,8 +380,9 @@ static hipError_t launch_long_n(const FusedParams &p, int num_cus, hipStream_t s
 }
 
 // n = 16384, 32768, 65536 (float64 rows, every pair: no pair list); N in (n/2, n], N < n needs p.c1
-hipError_t launch_fused_long(const FusedParams &p, int num_cus, hipStream_t stream)
+hipError_t launch_fused_long(const FusedParams &p_in, int num_cus, hipStream_t stream)
 {
+    const FusedParams p = with_reciprocals(p_in);
     if (!p.rows || !p.gscratch || !p.twl || (!p.xcp && p.R <= 1) || !p.g2 || !p.g3a || !p.g3b || !p.ovf_list || !p.ovf_count || p.pair_list ||
         (p.N < p.n && !p.c1 && p.R <= 1))
         return hipErrorInvalidValue;

@@ -47,7 +47,9 @@ __global__ __launch_bounds__(OCC_THREADS, 4) void xcorr_fused_n4096_fold(const F
     const int hi = t >> 4, lo = t & 15;
     double2 *const xw = xbuf + XW * wave;
     const int pad = PADDED ? 4096 - p.N : 0;
-    const double invN = PADDED ? 1.0 / (double)p.N : 1.0 / 4096.0, invNm1 = PADDED ? 1.0 / (double)(p.N - 1) : 1.0 / 4095.0;
+    // (PADDED: the launcher's quotients, kernel arguments in scalar registers -- formed here they came out of the vector divider and
+    // were parked in scratch across the whole pair loop)
+    const double invN = PADDED ? p.invN : 1.0 / 4096.0, invNm1 = PADDED ? p.invNm1 : 1.0 / 4095.0;
 
     if (t < 128)
         g2s[t] = p.g2[t];
@@ -56,6 +58,14 @@ __global__ __launch_bounds__(OCC_THREADS, 4) void xcorr_fused_n4096_fold(const F
     __syncthreads();
     PhaseClock<TIMING> clk;
     clk.start();
+    // (PADDED: the wave-local transposes' LDS addresses are formed where they are used -- hoisted out of the pair loop they were
+    // parked in scratch and reloaded behind an s_waitcnt vmcnt(0) in the middle of every pair)
+    const auto tl = [&]() __attribute__((always_inline)) {
+        int x = t;
+        if (PADDED)
+            asm volatile("" : "+v"(x));
+        return x;
+    };
 
     int parity = 0;
     const long long total = p.npairs;
@@ -129,7 +139,7 @@ __global__ __launch_bounds__(OCC_THREADS, 4) void xcorr_fused_n4096_fold(const F
         // pass 2: generalised DFT over b, delta = k1 / 16 (carries W_256^(b k1))
         gdft16_nr(v, G2Fetch{g2s, t >> 4});
         clk.template stamp<4>();
-        exchange_local<1>(v, xw, t); // -> thread (k1 = hi, k2 = lo), input c at v[c]
+        exchange_local<1>(v, xw, tl()); // -> thread (k1 = hi, k2 = lo), input c at v[c]
         clk.template stamp<5>();
         // pass 3: generalised DFT over c, delta = (k1 + 16 k2) / 256 (carries W_4096^(c k1) W_256^(c k2));
         // Z[hi + 16 lo + 256 k3] at v[BR16(k3)]
@@ -154,7 +164,7 @@ __global__ __launch_bounds__(OCC_THREADS, 4) void xcorr_fused_n4096_fold(const F
         });
         dft16_rn_s234(v);
         clk.template stamp<7>();
-        exchange_local<0>(v, xw, t); // (c' = hi, b' = lo) -> (c' = hi, m1 = lo), input b' at v[b']: same wave
+        exchange_local<0>(v, xw, tl()); // (c' = hi, b' = lo) -> (c' = hi, m1 = lo), input b' at v[b']: same wave
         if (PADDED && wave == 0 && lane == 0) { // every lane needs the means before its argmax: visible behind
             rec[32] = s1a;                      // the four barriers of the transpose below
             rec[33] = s1b;
@@ -342,7 +352,7 @@ __device__ __forceinline__ void fold_multi_body(const FusedParams &p)
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     double2 *const xw = xbuf + 1088 * wave;
     const int pad = PADDED ? 4096 - p.N : 0;
-    const double invN = PADDED ? 1.0 / (double)p.N : 1.0 / 4096.0, invNm1 = PADDED ? 1.0 / (double)(p.N - 1) : 1.0 / 4095.0;
+    const double invN = PADDED ? p.invN : 1.0 / 4096.0, invNm1 = PADDED ? p.invNm1 : 1.0 / 4095.0; // (the launcher's quotients: scalar registers)
     const int R = p.R;
     PhaseClock<TIMING> clk;
 
@@ -558,8 +568,9 @@ __global__ __launch_bounds__(OCC_THREADS, MULTI_WGS_PER_CU) void xcorr_fused_n40
 
 // R >= 1 references, n == 4096 (N < 4096: p.c1_many); p.ovf_count and p.work_counter zeroed; a resident grid
 // (pairs are handed out dynamically)
-hipError_t launch_fused_multi(const FusedParams &p, int num_cus, hipStream_t stream)
+hipError_t launch_fused_multi(const FusedParams &p_in, int num_cus, hipStream_t stream)
 {
+    const FusedParams p = with_reciprocals(p_in);
     const long long grid = std::min<long long>(p.npairs, (long long)num_cus * MULTI_WGS_PER_CU);
     if (!p.work_counter || p.R < 1 || !p.g2 || !p.g3a || !p.g3b || !p.xcp_many || !p.mv_many || !p.lag_many)
         return hipErrorInvalidValue;
@@ -581,8 +592,9 @@ hipError_t launch_fused_multi(const FusedParams &p, int num_cus, hipStream_t str
 
 // n == 4096 (N < 4096: p.c1 required); p.ovf_count / work_counter must be zeroed and p.ovf_list hold 2*npairs entries;
 // a resident grid, pairs handed out by the atomic counter
-hipError_t launch_fused_fold(const FusedParams &p, int num_cus, hipStream_t stream)
+hipError_t launch_fused_fold(const FusedParams &p_in, int num_cus, hipStream_t stream)
 {
+    const FusedParams p = with_reciprocals(p_in);
     if (!p.work_counter || !p.g2 || !p.g3a || !p.g3b || !p.xcp)
         return hipErrorInvalidValue;
     const long long grid = std::min<long long>(p.npairs, (long long)num_cus * 4);

@@ -145,22 +145,24 @@ __global__ __launch_bounds__(OCC_THREADS, WPS) void xcorr_fused_n4096_occ4(const
     __shared__ double2 xbuf[OCC_XBUF];
     __shared__ double2 tw2s[256];
     __shared__ double red[16 + 2 * 24]; // [0,16): z-norm partials; then 2 parities x 4 waves x 2 series x 3
+    // the previous pair's state per parity and series: {sum d, sum d^2, row (-1: none)} -- in LDS, not in registers carried across
+    // the transforms by threads 0 / 1 (those six registers were parked in scratch: stored and reloaded every pair)
+    __shared__ double pst[2][2][3];
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6); // wave-uniform by construction
     const int N = p.N;
     const int pad = 4096 - N;
-    const double invN = 1.0 / (double)N, invNm1 = 1.0 / (double)(N - 1);
+    const double invN = p.invN, invNm1 = p.invNm1; // (the launcher's quotients: kernel arguments in scalar registers)
 
     tw2s[t] = p.tw2[t];
-    __syncthreads();
     PhaseClock<TIMING> clk;
-    clk.start();
 
-    // state of the previous pair, kept by threads 0 (series A) and 1 (series B)
-    // until its cross-wave argmax combine runs behind this pair's first barrier
-    long long prev_row = -1;
-    Stat prev_stat{0.0, 0.0};
+    // (the previous pair's cross-wave argmax combine runs behind this pair's first barrier: threads 0 / 1, from pst)
+    if (t < 4)
+        pst[t >> 1][t & 1][2] = -1.0;
+    __syncthreads();
+    clk.start();
     int parity = 0;
 
     // optional indirection: process pair_list[0 .. *pair_count) (overflow pairs of the
@@ -222,9 +224,13 @@ __global__ __launch_bounds__(OCC_THREADS, WPS) void xcorr_fused_n4096_occ4(const
         for (int k = 0; k < 4; k++) // block totals: identical in every lane -> SGPRs
             q[k] = uniform((red[k] + red[4 + k]) + (red[8 + k] + red[12 + k]));
         // the previous pair's argmax triples are visible now: finish that pair
-        if (t < 2 && prev_row >= 0)
-            finalize(red + 16 + 24 * (parity ^ 1) + 3 * t, prev_stat, invN, invNm1, p.mv + prev_row,
-                     p.lag + prev_row);
+        if (t < 2) {
+            const double *const ps = pst[parity ^ 1][t];
+            if (ps[2] >= 0.0) {
+                const long long prev_row = (long long)ps[2];
+                finalize(red + 16 + 24 * (parity ^ 1) + 3 * t, Stat{ps[0], ps[1]}, invN, invNm1, p.mv + prev_row, p.lag + prev_row);
+            }
+        }
         Stat stA{q[0], q[1]}, stB{q[2], q[3]};
         bool zeroA, nanA, zeroB, nanB;
         const double varA0 = variance(stA, invN, invNm1, zeroA, nanA);
@@ -263,6 +269,14 @@ __global__ __launch_bounds__(OCC_THREADS, WPS) void xcorr_fused_n4096_occ4(const
             stB.s2 *= sB * sB;
             mA *= sA;
             mB *= sB;
+        }
+        if (t == 0) { // this pair's state for the combine behind the NEXT pair's first barrier (the buffer's last reader was two pairs ago)
+            pst[parity][0][0] = stA.s1;
+            pst[parity][0][1] = stA.s2;
+            pst[parity][0][2] = (double)rA;
+            pst[parity][1][0] = stB.s1;
+            pst[parity][1][1] = stB.s2;
+            pst[parity][1][2] = hasB ? (double)rB : -1.0;
         }
         const double2 dc = PADDED ? make_double2(0.0, 0.0)
                                   : make_double2(uniform(deadA ? 0.0 : 4096.0 * mA), uniform(deadB ? 0.0 : 4096.0 * mB));
@@ -330,19 +344,17 @@ __global__ __launch_bounds__(OCC_THREADS, WPS) void xcorr_fused_n4096_occ4(const
             ra_[5] = (double)widxB;
         }
         // no barrier here: the triples are combined behind the next pair's first one
-        if (t == 0) {
-            prev_row = rA;
-            prev_stat = stA;
-        } else if (t == 1) {
-            prev_row = hasB ? rB : -1;
-            prev_stat = stB;
-        }
         parity ^= 1;
         clk.template stamp<13>();
     }
     lds_barrier();
-    if (t < 2 && prev_row >= 0)
-        finalize(red + 16 + 24 * (parity ^ 1) + 3 * t, prev_stat, invN, invNm1, p.mv + prev_row, p.lag + prev_row);
+    if (t < 2) {
+        const double *const ps = pst[parity ^ 1][t];
+        if (ps[2] >= 0.0) {
+            const long long prev_row = (long long)ps[2];
+            finalize(red + 16 + 24 * (parity ^ 1) + 3 * t, Stat{ps[0], ps[1]}, invN, invNm1, p.mv + prev_row, p.lag + prev_row);
+        }
+    }
     if (TIMING && p.dbg && lane == 0) {
 #pragma unroll
         for (int i = 0; i < NPHASE; i++)
@@ -350,8 +362,9 @@ __global__ __launch_bounds__(OCC_THREADS, WPS) void xcorr_fused_n4096_occ4(const
     }
 }
 
-hipError_t launch_fused_occ4(const FusedParams &p, int num_cus, hipStream_t stream)
+hipError_t launch_fused_occ4(const FusedParams &p_in, int num_cus, hipStream_t stream)
 {
+    const FusedParams p = with_reciprocals(p_in);
     long long grid = p.npairs;
     // 16x the resident set (each workgroup still loops over ~40 pairs): workgroups that
     // start as others retire keep the CUs' phases decorrelated and balance CU speed

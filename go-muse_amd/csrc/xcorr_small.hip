@@ -524,7 +524,7 @@ __global__ __launch_bounds__((LOGN >= 11 ? (1 << LOGN) / 16 : 256), ((MULTI && L
     const int j = column_of_lane<LOGN>(t % S);
     double2 *const b = xbuf + g * (8 * S + S / 2);
     const int N = PADDED ? p.N : n, pad = PADDED ? n - N : 0;
-    const double invN = 1.0 / (double)N, invNm1 = 1.0 / (double)(N - 1);
+    const double invN = PADDED ? p.invN : 1.0 / (double)n, invNm1 = PADDED ? p.invNm1 : 1.0 / (double)(n - 1); // (the launcher's quotients: scalar registers)
     const double2 *__restrict__ twm = p.twm;
     const double2 *__restrict__ gs = p.gsmall;
     if (t < 8 * R1_)
@@ -1035,8 +1035,9 @@ static hipError_t launch_small_n(const FusedParams &p, int num_cus, hipStream_t 
 // n = 512, 1024, 2048, 8192, 16384 (float64 rows); any N in (n/2, n]
 // p.rows must carry n - N < n / 2 readable elements in front of row 0 (zero-padded rows are read unclamped and masked;
 // capi_group.hip allocates every group with GROUP_GUARD >= SMALL_MAX_N / 2 such elements)
-hipError_t launch_fused_small(const FusedParams &p, int num_cus, hipStream_t stream)
+hipError_t launch_fused_small(const FusedParams &p_in, int num_cus, hipStream_t stream)
 {
+    const FusedParams p = with_reciprocals(p_in);
     static_assert((1 << 14) <= SMALL_MAX_N, "the largest length built below");
     if ((!p.rows && !p.rows32) || !p.twm || (!p.xc && p.R <= 1) || !p.gsmall || (p.rows32 && p.R > 1))
         return hipErrorInvalidValue;

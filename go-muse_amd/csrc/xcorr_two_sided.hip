@@ -391,14 +391,11 @@ __global__ __launch_bounds__(256, 4) void xcorr_two_sided_long(const FusedParams
             } else {
                 const double mA2 = q[1] * iv.invNx, mB2 = q[3] * iv.invNy; // mean squares: only their exponents matter
                 ps.nil = false;
-                ps.nan = !__builtin_isfinite(mA2) || !__builtin_isfinite(mB2);
+                // (a mean square of 0 -- an all-zero series, or squares that underflow -- gives no scale either: two_device.h, pair_scale)
+                ps.nan = !__builtin_isfinite(mA2) || !__builtin_isfinite(mB2) || !(mA2 > 0.0) || !(mB2 > 0.0);
                 dead = ps.nan;
                 const int eA = var_exp(mA2), eB = var_exp(mB2);
-                // (each series on its own: an all-zero x -- or one whose squares underflow -- beside a y of magnitude 1e150 overflows the
-                // unscaled square just the same; the kernel that scales first handles it: sA = 1, y rescaled)
-                const bool hasA = mA2 > 0.0, hasB = mB2 > 0.0;
-                redo = !dead && ((hasA && hasB && sigma_spread_too_wide(mA2, mB2)) || (hasA && (eA > 400 || eA < -400)) ||
-                                 (hasB && (eB > 400 || eB < -400)) || (hasA != hasB));
+                redo = !dead && (sigma_spread_too_wide(mA2, mB2) || eA > 400 || eA < -400 || eB > 400 || eB < -400);
                 fac = 1.0 / (2.0 * n);
             }
             if (redo && t == 0) {
