@@ -350,6 +350,9 @@ extern "C" int muse_batch_score(muse_batch *b)
             variant = KERNEL_R16_OCC3;
     } else if (b->g->f32 && !(((b->n >= 512 && b->n <= 2048) || b->n == 8192 || b->n == 16384) && (ctx->variant == 0 || ctx->variant == 12))) {
         return fail(MUSE_ERR_UNSUPPORTED, "float32-storage groups run on the default kernels only (FFT lengths 512 ... 16384)");
+    } else if (b->n == 32768 && !b->g->f32 && ctx->variant == 14 && ctx->gsmall[4]) {
+        variant = KERNEL_REAL; // one real series per 1024-thread workgroup on the 16384-point complex transform (xcorr_real.hip): no scratch slice
+        p.gsmall = ctx->gsmall[4];
     } else if (b->xcp && p.twl && (b->N == b->n || b->c1) && ((b->n >= 32768 && ctx->variant == 0) || (b->n >= 16384 && ctx->variant == 13))) {
         variant = KERNEL_LONG; // four-step, 4096-point rows on the n = 4096 kernel's transforms (xcorr_long.hip)
     } else if (((b->n >= 512 && b->n <= 2048) || b->n == 8192 || b->n == 16384) && (ctx->variant == 0 || ctx->variant == 12)) {

@@ -272,8 +272,8 @@ extern "C" int muse_ctx_device_info(muse_ctx *ctx, char *name, int32_t name_cap,
 
 extern "C" int muse_ctx_set_kernel(muse_ctx *ctx, int32_t variant)
 {
-    if (!ctx || !(variant == 0 || variant == 1 || variant == 7 || variant == 10 || variant == 11 || variant == 12 || variant == 13))
-        return fail(MUSE_ERR_INVALID, "bad kernel variant (0 auto, 1 generic, 7 rescaling n=4096, 10 default n=4096, 11 Stockham, 12 half-round, 13 long series)");
+    if (!ctx || !(variant == 0 || variant == 1 || variant == 7 || variant == 10 || variant == 11 || variant == 12 || variant == 13 || variant == 14))
+        return fail(MUSE_ERR_INVALID, "bad kernel variant (0 auto, 1 generic, 7 rescaling n=4096, 10 default n=4096, 11 Stockham, 12 half-round, 13 long series, 14 real transform n=32768)");
     ctx->variant = variant;
     return MUSE_OK;
 }

@@ -8,7 +8,7 @@
 
 namespace muse {
 
-enum { KERNEL_GENERIC = 0, KERNEL_R16_OCC3 = 6, KERNEL_STOCKHAM = 10, KERNEL_R16_FOLD = 11, KERNEL_SMALL = 12, KERNEL_LONG = 13 };
+enum { KERNEL_GENERIC = 0, KERNEL_R16_OCC3 = 6, KERNEL_STOCKHAM = 10, KERNEL_R16_FOLD = 11, KERNEL_SMALL = 12, KERNEL_LONG = 13, KERNEL_REAL = 14 };
 
 struct FusedParams {
     const double *rows; // M x N row-major, row stride `stride` elements (float64 groups)
@@ -95,7 +95,8 @@ hipError_t launch_fused_fold(const FusedParams &p, int num_cus, hipStream_t stre
 hipError_t launch_fused_multi(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_r16_fold.hip (R references)
 hipError_t launch_fused_small(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_small.hip (n = 512, 1024, 2048: default)
 hipError_t launch_fused_stockham(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_stockham.hip (n = 512 .. 2048, 8192 .. 65536)
-hipError_t launch_fused_long(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_long.hip (n = 32768, 65536: default; 16384)
+hipError_t launch_fused_long(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_long.hip (n = 65536: default; 16384, 32768)
+hipError_t launch_fused_real(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_real.hip (n = 32768: one real series per workgroup on the 16384-point transform)
 hipError_t launch_two_sided(const FusedParams &p, int num_cus, hipStream_t stream);
 // the same for n = 512 ... 2048, 8192, 16384 on xcorr_small.hip's transforms (called by launch_two_sided)
 hipError_t launch_two_sided_small(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_two_sided.hip (xCorr, n = 512 .. 65536)

@@ -1,0 +1,278 @@
+// xcorr_real.hip -- n = 32768 WITHOUT a trip through memory: ONE real series per 1024-thread workgroup as a real transform on the
+// 16384-point complex machinery of xcorr_small.hip (round 5).
+//
+// Mathematics: xCorrWithX, /root/reference/xcorr.go:160-197 (z-normalise, leading zero pad, forward real transform,
+// multiply by the conjugate reference spectrum, inverse real transform, 1/n, first greatest |cc|, lag unwrap), for n = 2 M,
+// M = 16384.  The long-series kernel (xcorr_long.hip) packs two series into one complex transform of n points, which fits
+// neither the LDS nor the registers of a CU: a four-step transform whose slice crosses memory four times per transform pair
+// (5 x the algorithmic bytes, the memory side saturated at 5.8 TB/s: profiles/r04_counters.json).  Here the two halves of
+// ONE series share a complex transform of M points, which does fit (the n = 16384 kernel's geometry: 1024 threads x 16
+// points, every transpose in two half rounds through 139 KB of LDS):
+//
+//   z[m] = d[2m] + i d[2m+1]                      (d = the centred, scaled, zero-padded series; one 16-byte request per point)
+//   Z = FFT_M(z)                                  (small::forward<14>)
+//   E = (Z[k] + conj Z[M-k]) / 2,  O = (Z[k] - conj Z[M-k]) / 2i      (spectra of the even / odd samples)
+//   Y[k] = E + W O,   Y[M-k] = conj(E - W O),     W = W_n^k            (the series' spectrum, bins 0 .. M)
+//   P[k] = Y[k] xc[k],   P[M-k] = Y[M-k] xc[M-k],   xc = conj(X) / n   (FusedParams::xc, all n bins)
+//   A = P[k] + conj P[M-k],   B = (P[k] - conj P[M-k]) W                (cc = FFT_n(P) split into even / odd lags:
+//   C[k] = A + i B,   C[M-k] = conj A + i conj B                         cc[2m] + i cc[2m+1] = FFT_M(C)[m])
+//   c = FFT_M(C):   cc[2m] = Re c[m],  cc[2m+1] = Im c[m]               (small::forward<14> again)
+//
+// A thread holds Z[j + r S] (S = 1024, r = 0 .. 15); bin k's partner M - k = (S - j) + (15 - r) S lives in the thread of column
+// S - j.  The pair (k, M - k) shares E, O, W O and both products, so the threads of columns j and S - j split the sixteen pairs
+// between them: each sends its upper eight bins (r >= 8) through the half buffer, forms C[k] AND C[M-k] for its lower eight
+// (32 fp64 instructions per pair), and sends the eight C[M-k] back -- two half exchanges, the volume of one transpose.
+// Column 0 pairs inside itself (k = r S with (16 - r) S; k = 0 with the Nyquist bin, k = M / 2 with itself): the same code with
+// one more slot of offset and a ninth evaluation in that thread's wave.
+//
+// One series per transform: nothing to isolate (no partner a NaN could poison, no sigma spread inside a transform), so no
+// redo list.  Per series 8 N bytes in and 12 out -- the row never leaves the CU between them.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <algorithm>
+
+#include "small_device.h"
+
+namespace muse {
+
+namespace real {
+
+using namespace occ4;
+using namespace fold;
+
+// one mirror pair: Z = Z[k], Zm = Z[M-k], W = W_n^k, xk = xc[k], xm = xc[M-k]  ->  Ck = 2 C[k], Cm = 2 C[M-k]
+__device__ __forceinline__ void mirror_pair(const double2 Z, const double2 Zm, const double2 W, const double2 xk, const double2 xm,
+                                            double2 &Ck, double2 &Cm)
+{
+    const double2 E2 = make_double2(Z.x + Zm.x, Z.y - Zm.y);                 // Z + conj Zm = 2 E
+    const double2 O2 = make_double2(Z.y + Zm.y, Zm.x - Z.x);                 // (Z - conj Zm) / i = 2 O
+    const double2 T = cmul(W, O2);
+    const double2 Y = make_double2(E2.x + T.x, E2.y + T.y);                  // 2 Y[k]
+    const double2 Ym = make_double2(E2.x - T.x, T.y - E2.y);                 // 2 Y[M-k] = conj(2 E - T)
+    const double2 P = cmul(Y, xk), Pm = cmul(Ym, xm);
+    const double2 A = make_double2(P.x + Pm.x, P.y - Pm.y);                  // P + conj Pm
+    const double2 B = cmul(make_double2(P.x - Pm.x, P.y + Pm.y), W);         // (P - conj Pm) W
+    Ck = make_double2(A.x - B.y, A.y + B.x);                                 // A + i B
+    Cm = make_double2(A.x + B.y, B.x - A.y);                                 // conj A + i conj B
+}
+
+} // namespace real
+
+// PADDED: N < n (leading zero pad, n / 2 < N)
+template <bool PADDED>
+__global__ __launch_bounds__(1024, 4) void xcorr_fused_real32k(const FusedParams p)
+{
+    using namespace occ4;
+    using namespace fold;
+    using namespace small;
+    using namespace real;
+    constexpr int n = 32768, M = n / 2, LM = 14, S = M / 16; // S = 1024 threads, 16 complex points each
+    constexpr int PK = padk(S);                              // one slot of the half buffer: S points, padded 17 / 16
+    __shared__ double red[112];
+    __shared__ double2 g2l[8 * 4];
+    __shared__ double2 xbuf[16 * 544]; // the half buffer of the transposes: 8 S padded points = 139 KB
+    const int t = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int j = column_of_lane<LM>(t);
+    double2 *const b = xbuf;
+    const int N = PADDED ? p.N : n, pad = PADDED ? n - N : 0;
+    const double invN = PADDED ? p.invN : 1.0 / (double)n, invNm1 = PADDED ? p.invNm1 : 1.0 / (double)(n - 1);
+    const double2 *__restrict__ twm = p.twm;
+    const double2 *__restrict__ gs = p.gsmall; // the 16384-point transform's lane-ordered pass tables
+    const double2 *__restrict__ xc = p.xc;
+    if (t < 8 * 4)
+        g2l[t] = tw_factor<4>(twm, t % 4, t / 4);
+    __syncthreads();
+    const long long total = p.M;
+
+    // point m = j + i S of z holds the samples 2m - pad and 2m + 1 - pad of the row (a pad position: 0).  N = n: one 16-byte
+    // request per point.  PADDED: two 8-byte requests (an odd pad puts the pair off 16-byte alignment); a request that lies in
+    // the pad entirely (2 (i + 1) S <= pad: wave-uniform) is pointed at the row's own first samples -- an L2 hit instead of the end
+    // of the previous row streamed from HBM only to be masked -- and one that straddles the pad's end reads at most 2 S samples in
+    // front of the row (the allocation's guard: capi_group.hip, GROUP_GUARD >= 2 S).
+    double2 x[16];
+    double K;
+    const auto request = [&](long long row) __attribute__((always_inline)) {
+        if (row >= total)
+            row = total - 1; // (nothing left: an L2-hot dummy)
+        const double *const r = p.rows + row * p.stride;
+        int jr = j;
+        asm volatile("" : "+v"(jr)); // (offsets derived per request, not hoisted)
+        jr &= S - 1;
+        K = scalar_ptr(r)[0];
+        if (!PADDED) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const d2v s = __builtin_nontemporal_load((gptr<d2v>)scalar_ptr_at(r, 2 * i * S) + (unsigned)jr);
+                x[i] = make_double2(s.x, s.y);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const bool all_pad = i < 8 && 2 * (i + 1) * S <= pad;
+                const long long off = all_pad ? 0ll : 2ll * i * S - pad;
+                x[i].x = __builtin_nontemporal_load(scalar_ptr_at(r, off) + (unsigned)(2 * jr));
+                x[i].y = __builtin_nontemporal_load(scalar_ptr_at(r, off + 1) + (unsigned)(2 * jr));
+            }
+        }
+    };
+    if (blockIdx.x < total)
+        request(blockIdx.x);
+    for (long long row = blockIdx.x; row < total; row += gridDim.x) {
+        // ---- d = x - K with K the first sample, shifted statistics (xcorr.go:84-95)
+        double2 v[16];
+        int js = j;
+        asm volatile("" : "+v"(js)); // (validity masks derived per iteration, not hoisted)
+        js &= S - 1;
+        double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int e = 2 * (js + i * S) - pad; // sample index of the point's real part
+            const bool v0 = !PADDED || i >= 8 || e >= 0, v1 = !PADDED || i >= 8 || e + 1 >= 0; // (pad < n / 2: the upper half is data)
+            const double d0 = v0 ? x[i].x - K : 0.0, d1 = v1 ? x[i].y - K : 0.0;
+            v[i] = make_double2(d0, d1);
+            q0 += d0;
+            q1 = fma(d0, d0, q1);
+            q2 += d1;
+            q3 = fma(d1, d1, q3);
+        }
+        pair_sum4<S>(q0, q1, q2, q3, red, wave);
+        bool zero, nan;
+        const double var0 = variance(Stat{q0 + q2, q1 + q3}, invN, invNm1, zero, nan);
+        const bool dead = zero || nan;
+        // the series goes into the transform at O(1): an exact power-of-two scale close to 1 / sigma, folded into the mean removal
+        const double sc = dead ? 1.0 : pow2_inv_sigma(var0);
+        const double var = uniform(var0 * sc * sc);
+        const double mean = (q0 + q2) * invN * sc;
+        asm volatile("" : "+v"(js));
+        js &= S - 1;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int e = 2 * (js + i * S) - pad;
+            const bool v0 = !PADDED || i >= 8 || e >= 0, v1 = !PADDED || i >= 8 || e + 1 >= 0;
+            v[i].x = (v0 && !dead) ? fma(v[i].x, sc, -mean) : 0.0;
+            v[i].y = (v1 && !dead) ? fma(v[i].y, sc, -mean) : 0.0;
+        }
+        // ---- Z = FFT_M(z): Z[j + r S] at v[BR16(r)]
+        forward<LM>(v, b, g2l, gs, j);
+        // ---- mirror pairs: Y, the product with the reference's spectrum, re-tangled for the second transform
+        double2 w[16];
+        {
+            int jm = j;
+            asm volatile("" : "+v"(jm)); // (addresses derived here, not hoisted out of the row loop)
+            jm &= S - 1;
+            const bool col0 = jm == 0;
+            const int cm = (S - jm) & (S - 1);                  // the partner's column (column 0: itself)
+            const int wbase = jm + (jm >> 4);                   // own column, slot 0
+            const int rbase = cm + (cm >> 4);                   // partner's column, slot 0
+            const int rbm = rbase + (col0 ? PK : 0);            // column 0 pairs bin r S with bin (16 - r) S: one slot further
+            // W_n^(j + r S) = W_n^j W_32^r: one table entry (W_65536^(2 j)) and seven constant factors
+            const double2 Wj = ldg2u(scalar_ptr(twm), (unsigned)(2 * jm));
+            // exchange 1: the upper eight bins (register r = 8 + s in slot s) to the partner
+            lds_barrier(); // (the transform's last readers of the buffer are done)
+#pragma unroll
+            for (int s = 0; s < 8; s++)
+                lds_st2(b + wbase + s * PK, v[BR16(8 + s)]);
+            // the reference's spectrum at the sixteen bins of the lower eight pairs: requested under the exchange
+            double2 xk[8], xm[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                xk[r] = ldg2u(scalar_ptr_at(xc, r * S), (unsigned)jm);                  // xc[j + r S]
+                xm[r] = ldg2u(scalar_ptr_at(xc, M - r * S - S), (unsigned)(S - jm));    // xc[M - j - r S]
+            }
+            lds_barrier();
+            double2 zm[8];
+            zm[0] = lds_ld2(b + rbase + 7 * PK);
+#pragma unroll
+            for (int r = 1; r < 8; r++)
+                zm[r] = lds_ld2(b + rbm + (7 - r) * PK);
+            if (col0)
+                zm[0] = v[BR16(0)]; // k = 0 pairs with the Nyquist bin: both come out of Z[0]
+            double2 cmv[8];
+            constexpr double C32[9] = {1.0, 0.98078528040323044913, 0.92387953251128675613, 0.83146961230254523708,
+                                       0.70710678118654752440, 0.55557023301960222474, 0.38268343236508977173, 0.19509032201612826785, 0.0};
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const double2 W = r == 0 ? Wj : cmul(Wj, make_double2(C32[r], -C32[8 - r])); // W_32^r = cos(2 pi r / 32) - i sin(2 pi r / 32)
+                mirror_pair(v[BR16(r)], zm[r], W, xk[r], xm[r], w[r], cmv[r]);
+            }
+            // exchange 2: C[M-k] of the lower eight pairs back to the partner (its registers 15 - r)
+            lds_barrier(); // (everybody has read exchange 1)
+#pragma unroll
+            for (int r = 0; r < 8; r++)
+                lds_st2(b + wbase + r * PK, cmv[r]);
+            if (wave == 0) { // column 0's ninth pair: bin M / 2 with itself (W = -i); its C lands in register 8 of that thread
+                const double2 xh = ldg2u(scalar_ptr_at(xc, M / 2), 0u);
+                double2 ck, cm2;
+                mirror_pair(v[BR16(8)], v[BR16(8)], make_double2(0.0, -1.0), xh, xh, ck, cm2);
+                w[8] = ck;
+            }
+            lds_barrier();
+            {
+                const double2 h = lds_ld2(b + rbase + 7 * PK);
+                w[8] = (wave == 0 && col0) ? w[8] : h;
+            }
+#pragma unroll
+            for (int r = 9; r < 16; r++)
+                w[r] = lds_ld2(b + rbm + (15 - r) * PK);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            v[r] = w[r];
+        // ---- c = FFT_M(C): 2 cc[2m] + 2 i cc[2m+1] with m = j + r S at v[BR16(r)]
+        forward<LM>(v, b, g2l, gs, j);
+        // ---- maxAbsIndex (xcorr.go:39-50): ascending r, real part before imaginary part = ascending lag index for this thread
+        double sv = 0.0;
+        int code = 0;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const double a0 = v[BR16(r)].x, a1 = v[BR16(r)].y;
+            const bool g0 = fabs(a0) > fabs(sv);
+            sv = g0 ? a0 : sv;
+            code = g0 ? 2 * r : code;
+            const bool g1 = fabs(a1) > fabs(sv);
+            sv = g1 ? a1 : sv;
+            code = g1 ? 2 * r + 1 : code;
+        }
+        const double ma = fabs(sv);
+        const int ia = 2 * (j + (code >> 1) * S) + (code & 1);
+        const double cc0 = v[0].x; // (column 0: cc[0], reported when nothing is above 0)
+        fence();
+        request(row + gridDim.x); // the next row: in flight during the reductions and the result write-out
+        fence();
+        double pa = ma, pb = 0.0;
+        pair_max2<S>(pa, pb, red, wave);
+        int ca = (ma == pa && pa > 0.0) ? ia : 0x7fffffff, cb = 0x7fffffff;
+        pair_min_i2<S>(ca, cb, red, wave);
+        const bool own = ca == 0x7fffffff ? j == 0 : (ia == ca && ma == pa);
+        if (own) {
+            double y = __builtin_amdgcn_rsq(var);
+            y = y * fma(-0.5 * var * y, y, 1.5);
+            y = y * fma(-0.5 * var * y, y, 1.5);
+            double mv = (ca == 0x7fffffff ? cc0 : sv) * (0.5 * y); // (the re-tangled spectrum carries 2 C)
+            const int idx = ca == 0x7fffffff ? 0 : ca;
+            int lag = idx > n / 2 ? idx - n : idx;
+            if (zero) { mv = 0.0; lag = 0; }               // xcorr.go:166-167
+            if (nan) { mv = __builtin_nan(""); lag = 0; }
+            p.mv[row] = mv;
+            p.lag[row] = lag;
+        }
+    }
+}
+
+// n = 32768, float64 rows, every row (no pair list); N in (n / 2, n]; p.gsmall = the 16384-point transform's tables, p.xc all n bins
+hipError_t launch_fused_real(const FusedParams &p_in, int num_cus, hipStream_t stream)
+{
+    const FusedParams p = with_reciprocals(p_in);
+    if (!p.rows || !p.twm || !p.xc || !p.gsmall || !p.mv || !p.lag || p.n != 32768 || p.N > p.n || 2 * p.N <= p.n || p.pair_list || p.R > 1)
+        return hipErrorInvalidValue;
+    const long long grid = std::min<long long>(p.M, (long long)num_cus * 8);
+    if (p.N < p.n)
+        hipLaunchKernelGGL(xcorr_fused_real32k<true>, dim3((unsigned)grid), dim3(1024), 0, stream, p);
+    else
+        hipLaunchKernelGGL(xcorr_fused_real32k<false>, dim3((unsigned)grid), dim3(1024), 0, stream, p);
+    return hipGetLastError();
+}
+
+} // namespace muse
