@@ -350,7 +350,7 @@ extern "C" int muse_batch_score(muse_batch *b)
             variant = KERNEL_R16_OCC3;
     } else if (b->g->f32 && !(((b->n >= 512 && b->n <= 2048) || b->n == 8192 || b->n == 16384) && (ctx->variant == 0 || ctx->variant == 12))) {
         return fail(MUSE_ERR_UNSUPPORTED, "float32-storage groups run on the default kernels only (FFT lengths 512 ... 16384)");
-    } else if (b->n == 32768 && !b->g->f32 && ctx->variant == 14 && ctx->gsmall[4]) {
+    } else if (b->n == 32768 && !b->g->f32 && (ctx->variant == 0 || ctx->variant == 14) && ctx->gsmall[4]) {
         variant = KERNEL_REAL; // one real series per 1024-thread workgroup on the 16384-point complex transform (xcorr_real.hip): no scratch slice
         p.gsmall = ctx->gsmall[4];
     } else if (b->xcp && p.twl && (b->N == b->n || b->c1) && ((b->n >= 32768 && ctx->variant == 0) || (b->n >= 16384 && ctx->variant == 13))) {
@@ -460,6 +460,8 @@ extern "C" int muse_batch_kernel_name(muse_batch *b, char *name, int32_t cap)
         snprintf(k, sizeof(k), "xcorr_fused_n4096_fold<false, %s, %s>", padded ? "true" : "false", b->g->f32 ? "true" : "false");
     else if ((b->n >= 512 && b->n <= 2048) || b->n == 8192 || b->n == 16384)
         snprintf(k, sizeof(k), "xcorr_fused_small<%d, %s, false%s>", b->logn, padded ? "true" : "false", b->g->f32 ? ", true" : ", false");
+    else if (b->n == 32768)
+        snprintf(k, sizeof(k), "xcorr_fused_real32k<%s>", padded ? "true" : "false");
     else if (b->n > 16384)
         snprintf(k, sizeof(k), "xcorr_fused_long<%d, %s, false>", b->logn, padded ? "true" : "false");
     snprintf(name, (size_t)cap, "%s", k);

@@ -34,6 +34,15 @@
 
 #include "small_device.h"
 
+// compile-time switches of tools/ablate/ab_real.sh (one box, profiles/r05_real_transform.txt): the table window (2 ... 5 pairs ahead:
+// inside the noise) and the padded rows' 16-byte requests at 8-byte alignment (- 5 ... 9 % at N = 20000 / 24001)
+#ifndef MUSE_REAL_AHEAD
+#define MUSE_REAL_AHEAD 3
+#endif
+#ifndef MUSE_REAL_WIDE
+#define MUSE_REAL_WIDE 1
+#endif
+
 namespace muse {
 
 namespace real {
@@ -41,9 +50,11 @@ namespace real {
 using namespace occ4;
 using namespace fold;
 
-// one mirror pair: Z = Z[k], Zm = Z[M-k], W = W_n^k, xk = xc[k], xm = xc[M-k]  ->  Ck = 2 C[k], Cm = 2 C[M-k]
-__device__ __forceinline__ void mirror_pair(const double2 Z, const double2 Zm, const double2 W, const double2 xk, const double2 xm,
-                                            double2 &Ck, double2 &Cm)
+// one mirror pair: Z = Z[k], Zm = Z[M-k], W = W_n^k, xk = xc[k], xm = xc[M-k]  ->  k = 2 C[k], m = 2 C[M-k]
+struct MirrorOut {
+    double2 k, m;
+};
+__device__ __forceinline__ MirrorOut mirror_pair(const double2 Z, const double2 Zm, const double2 W, const double2 xk, const double2 xm)
 {
     const double2 E2 = make_double2(Z.x + Zm.x, Z.y - Zm.y);                 // Z + conj Zm = 2 E
     const double2 O2 = make_double2(Z.y + Zm.y, Zm.x - Z.x);                 // (Z - conj Zm) / i = 2 O
@@ -53,8 +64,8 @@ __device__ __forceinline__ void mirror_pair(const double2 Z, const double2 Zm, c
     const double2 P = cmul(Y, xk), Pm = cmul(Ym, xm);
     const double2 A = make_double2(P.x + Pm.x, P.y - Pm.y);                  // P + conj Pm
     const double2 B = cmul(make_double2(P.x - Pm.x, P.y + Pm.y), W);         // (P - conj Pm) W
-    Ck = make_double2(A.x - B.y, A.y + B.x);                                 // A + i B
-    Cm = make_double2(A.x + B.y, B.x - A.y);                                 // conj A + i conj B
+    return MirrorOut{make_double2(A.x - B.y, A.y + B.x),                     // A + i B
+                     make_double2(A.x + B.y, B.x - A.y)};                    // conj A + i conj B
 }
 
 } // namespace real
@@ -86,13 +97,12 @@ __global__ __launch_bounds__(1024, 4) void xcorr_fused_real32k(const FusedParams
     __syncthreads();
     const long long total = p.M;
 
-    // point m = j + i S of z holds the samples 2m - pad and 2m + 1 - pad of the row (a pad position: 0).  N = n: one 16-byte
-    // request per point.  PADDED: two 8-byte requests (an odd pad puts the pair off 16-byte alignment); a request that lies in
+    // point m = j + i S of z holds the samples 2m - pad and 2m + 1 - pad of the row (a pad position: 0): one 16-byte request per
+    // point (PADDED: at an 8-byte aligned address when the pad is odd -- global loads only need dword alignment); a request that lies in
     // the pad entirely (2 (i + 1) S <= pad: wave-uniform) is pointed at the row's own first samples -- an L2 hit instead of the end
     // of the previous row streamed from HBM only to be masked -- and one that straddles the pad's end reads at most 2 S samples in
     // front of the row (the allocation's guard: capi_group.hip, GROUP_GUARD >= 2 S).
-    double2 x[16];
-    double K;
+    double x0[16], x1[16], K; // (plain doubles: an array of HIP's double2 struct filled under a branch stays in scratch)
     const auto request = [&](long long row) __attribute__((always_inline)) {
         if (row >= total)
             row = total - 1; // (nothing left: an L2-hot dummy)
@@ -105,15 +115,24 @@ __global__ __launch_bounds__(1024, 4) void xcorr_fused_real32k(const FusedParams
 #pragma unroll
             for (int i = 0; i < 16; i++) {
                 const d2v s = __builtin_nontemporal_load((gptr<d2v>)scalar_ptr_at(r, 2 * i * S) + (unsigned)jr);
-                x[i] = make_double2(s.x, s.y);
+                x0[i] = s.x;
+                x1[i] = s.y;
             }
         } else {
 #pragma unroll
             for (int i = 0; i < 16; i++) {
                 const bool all_pad = i < 8 && 2 * (i + 1) * S <= pad;
                 const long long off = all_pad ? 0ll : 2ll * i * S - pad;
-                x[i].x = __builtin_nontemporal_load(scalar_ptr_at(r, off) + (unsigned)(2 * jr));
-                x[i].y = __builtin_nontemporal_load(scalar_ptr_at(r, off + 1) + (unsigned)(2 * jr));
+#if MUSE_REAL_WIDE
+                // (a 16-byte request at an 8-byte aligned address when the pad is odd: global loads only need dword alignment)
+                typedef d2v __attribute__((aligned(8))) d2u;
+                const d2u s = __builtin_nontemporal_load((gptr<d2u>)scalar_ptr_at(r, off) + (unsigned)jr);
+                x0[i] = s.x;
+                x1[i] = s.y;
+#else
+                x0[i] = __builtin_nontemporal_load(scalar_ptr_at(r, off) + (unsigned)(2 * jr));
+                x1[i] = __builtin_nontemporal_load(scalar_ptr_at(r, off + 1) + (unsigned)(2 * jr));
+#endif
             }
         }
     };
@@ -130,7 +149,7 @@ __global__ __launch_bounds__(1024, 4) void xcorr_fused_real32k(const FusedParams
         for (int i = 0; i < 16; i++) {
             const int e = 2 * (js + i * S) - pad; // sample index of the point's real part
             const bool v0 = !PADDED || i >= 8 || e >= 0, v1 = !PADDED || i >= 8 || e + 1 >= 0; // (pad < n / 2: the upper half is data)
-            const double d0 = v0 ? x[i].x - K : 0.0, d1 = v1 ? x[i].y - K : 0.0;
+            const double d0 = v0 ? x0[i] - K : 0.0, d1 = v1 ? x1[i] - K : 0.0;
             v[i] = make_double2(d0, d1);
             q0 += d0;
             q1 = fma(d0, d0, q1);
@@ -157,7 +176,6 @@ __global__ __launch_bounds__(1024, 4) void xcorr_fused_real32k(const FusedParams
         // ---- Z = FFT_M(z): Z[j + r S] at v[BR16(r)]
         forward<LM>(v, b, g2l, gs, j);
         // ---- mirror pairs: Y, the product with the reference's spectrum, re-tangled for the second transform
-        double2 w[16];
         {
             int jm = j;
             asm volatile("" : "+v"(jm)); // (addresses derived here, not hoisted out of the row loop)
@@ -174,52 +192,70 @@ __global__ __launch_bounds__(1024, 4) void xcorr_fused_real32k(const FusedParams
 #pragma unroll
             for (int s = 0; s < 8; s++)
                 lds_st2(b + wbase + s * PK, v[BR16(8 + s)]);
-            // the reference's spectrum at the sixteen bins of the lower eight pairs: requested under the exchange
+            // the reference's spectrum at the two bins of a pair, xc[j + r S] and xc[M - j - r S]: requested AHEAD pairs in front of
+            // their use (a rolling window: all sixteen at once do not fit beside the bins, and requested where they are used every
+            // wave of the workgroup would wait out the L2 round trip in step)
+            constexpr int AHEAD = MUSE_REAL_AHEAD;
             double2 xk[8], xm[8];
 #pragma unroll
-            for (int r = 0; r < 8; r++) {
-                xk[r] = ldg2u(scalar_ptr_at(xc, r * S), (unsigned)jm);                  // xc[j + r S]
-                xm[r] = ldg2u(scalar_ptr_at(xc, M - r * S - S), (unsigned)(S - jm));    // xc[M - j - r S]
+            for (int r = 0; r < AHEAD; r++) {
+                xk[r] = ldg2u(scalar_ptr_at(xc, r * S), (unsigned)jm);
+                xm[r] = ldg2u(scalar_ptr_at(xc, M - r * S - S), (unsigned)(S - jm));
             }
+            const double2 v8 = v[BR16(8)]; // (column 0's ninth pair needs its bin M / 2 once more)
             lds_barrier();
-            double2 zm[8];
-            zm[0] = lds_ld2(b + rbase + 7 * PK);
-#pragma unroll
-            for (int r = 1; r < 8; r++)
-                zm[r] = lds_ld2(b + rbm + (7 - r) * PK);
-            if (col0)
-                zm[0] = v[BR16(0)]; // k = 0 pairs with the Nyquist bin: both come out of Z[0]
             double2 cmv[8];
             constexpr double C32[9] = {1.0, 0.98078528040323044913, 0.92387953251128675613, 0.83146961230254523708,
                                        0.70710678118654752440, 0.55557023301960222474, 0.38268343236508977173, 0.19509032201612826785, 0.0};
 #pragma unroll
             for (int r = 0; r < 8; r++) {
+                fence();
+                if (r + AHEAD < 8) {
+                    xk[r + AHEAD] = ldg2u(scalar_ptr_at(xc, (r + AHEAD) * S), (unsigned)jm);
+                    xm[r + AHEAD] = ldg2u(scalar_ptr_at(xc, M - (r + AHEAD) * S - S), (unsigned)(S - jm));
+                }
+                double2 zm = lds_ld2(b + (r == 0 ? rbase + 7 * PK : rbm + (7 - r) * PK));
+                if (r == 0) { // k = 0 pairs with the Nyquist bin: both come out of Z[0]
+                    // (component by component: a ?: between two double2 lvalues is a select of ADDRESSES, and an array whose element's
+                    // address escapes into one is never split into registers -- the sixteen bins went to scratch)
+                    zm.x = col0 ? v[BR16(0)].x : zm.x;
+                    zm.y = col0 ? v[BR16(0)].y : zm.y;
+                }
+                fence();
                 const double2 W = r == 0 ? Wj : cmul(Wj, make_double2(C32[r], -C32[8 - r])); // W_32^r = cos(2 pi r / 32) - i sin(2 pi r / 32)
-                mirror_pair(v[BR16(r)], zm[r], W, xk[r], xm[r], w[r], cmv[r]);
+                const MirrorOut o = mirror_pair(v[BR16(r)], zm, W, xk[r], xm[r]);
+                v[BR16(r)] = o.k; // (in place: bin k's register takes 2 C[k])
+                cmv[r] = o.m;
             }
             // exchange 2: C[M-k] of the lower eight pairs back to the partner (its registers 15 - r)
             lds_barrier(); // (everybody has read exchange 1)
 #pragma unroll
             for (int r = 0; r < 8; r++)
                 lds_st2(b + wbase + r * PK, cmv[r]);
+            double2 c8 = make_double2(0.0, 0.0);
             if (wave == 0) { // column 0's ninth pair: bin M / 2 with itself (W = -i); its C lands in register 8 of that thread
                 const double2 xh = ldg2u(scalar_ptr_at(xc, M / 2), 0u);
-                double2 ck, cm2;
-                mirror_pair(v[BR16(8)], v[BR16(8)], make_double2(0.0, -1.0), xh, xh, ck, cm2);
-                w[8] = ck;
+                c8 = mirror_pair(v8, v8, make_double2(0.0, -1.0), xh, xh).k;
             }
             lds_barrier();
             {
                 const double2 h = lds_ld2(b + rbase + 7 * PK);
-                w[8] = (wave == 0 && col0) ? w[8] : h;
+                const bool mine = wave == 0 && col0;
+                v[BR16(8)] = make_double2(mine ? c8.x : h.x, mine ? c8.y : h.y);
             }
 #pragma unroll
             for (int r = 9; r < 16; r++)
-                w[r] = lds_ld2(b + rbm + (15 - r) * PK);
+                v[BR16(r)] = lds_ld2(b + rbm + (15 - r) * PK);
         }
+        { // renamed to natural order for the second transform (2 C[j + r S] sits at v[BR16(r)])
+            double2 w[16];
 #pragma unroll
-        for (int r = 0; r < 16; r++)
-            v[r] = w[r];
+            for (int r = 0; r < 16; r++)
+                w[r] = v[BR16(r)];
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                v[r] = w[r];
+        }
         // ---- c = FFT_M(C): 2 cc[2m] + 2 i cc[2m+1] with m = j + r S at v[BR16(r)]
         forward<LM>(v, b, g2l, gs, j);
         // ---- maxAbsIndex (xcorr.go:39-50): ascending r, real part before imaginary part = ascending lag index for this thread
