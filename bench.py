@@ -198,11 +198,13 @@ def workload_name(M, N, n_gpus, max_lag, top_n):
         tag, M * n_gpus, n_gpus, M, tail)
 
 
-CONFIG5_LENGTHS = (512, 1000, 4096, 5000, 16384, 65536)
+# BASELINE configs[4]: "N in {512 ... 65536} zero-padded to next pow2" -- SURVEY 8d's six lengths plus 20000 (-> 32768, the one FFT
+# length the six leave out: every per-length kernel of the library is on the line)
+CONFIG5_LENGTHS = (512, 1000, 4096, 5000, 16384, 20000, 65536)
 
 
 def config5_leg(pkg, eng, args, rank, n_gpus, use_dist, tdev, M, N, counters):
-    """BASELINE configs[4] as ONE workload, at any number of ranks: a mixed-length Group is six (ref, Group) pairs, one per
+    """BASELINE configs[4] as ONE workload, at any number of ranks: a mixed-length Group is seven (ref, Group) pairs, one per
     length (group.go:45-51 and muse_batch.go:24-28 allow one length per Group), each sharded by rows over the ranks (~4 GB per
     GPU; the headline's length: as many rows per GPU as the headline), label groups of 50 series ("graph") INTERLEAVED over the
     rows -- graph g = global rows g, g + G, g + 2G, ... -- so that every label group has members on every rank; every Batch
@@ -235,7 +237,7 @@ def config5_leg(pkg, eng, args, rank, n_gpus, use_dist, tdev, M, N, counters):
                 rows_l = min(rows_l, args.config5_rows)
             rows_all = rows_l * n_gpus
             # (without the planted exact copies of the reference: the shared top-N is then a field of distinct scores from
-            # all six lengths, not twenty 1.0s from the first)
+            # all the lengths, not twenty 1.0s from the first)
             dgl, refl = pkg.DeviceGroup.synthetic(eng, rows_l, Nl, seed=0x6D757365, global_first=rank * rows_l, copies=False)
             dbl = pkg.DeviceBatch(eng, dgl, refl)
             Gl = max(1, rows_all // 50)
@@ -292,7 +294,7 @@ def config5_leg(pkg, eng, args, rank, n_gpus, use_dist, tdev, M, N, counters):
              "n_gpus": n_gpus, "ms_total": run_s_total * 1e3, "lengths": [e_["N"] for e_ in per_len if "error" not in e_],
              "shared_results": {"top_n": args.top_n, "fetched": len(top), "mean_abs_score": mean_abs,
                                 "lengths_in_top_n": sorted({s_.Labels.labels["len"] for s_ in top}, key=int)},
-             "note": "%s: six (ref, Group) pairs, every Group sharded by rows over %d rank(s) with its 50-series label groups interleaved "
+             "note": "%s: seven (ref, Group) pairs, every Group sharded by rows over %d rank(s) with its 50-series label groups interleaved "
                      "over ALL ranks, Run([\"graph\"]) each through dist.ShardedBatch (muse_batch_run_groups + exchange + muse_merge_group_winners "
                      "+ host feed) into ONE Results, one Fetch; per-length Run and kernel times in config5_lengths" % (tag, n_gpus)}
     return per_len, mixed

@@ -306,7 +306,7 @@ static int xcorr_groups_impl(muse_group *gx, muse_group *gy, int32_t n, int32_t 
     int *dlag = nullptr, *dnil = nullptr, *dcount = nullptr;
     long long *dlist = nullptr; // n >= 32768, no padding: the pairs the single-read launch hands to the launch that scales first
     auto cleanup = [&]() { (void)hipFree(dmv); (void)hipFree(dcc); (void)hipFree(dlag); (void)hipFree(dnil); (void)hipFree(dlist); (void)hipFree(dcount); };
-    const bool listing = n >= 32768 && Nx == n && Ny == n;
+    const bool listing = n == 65536 && Nx == n && Ny == n;
     e = hipMalloc(&dmv, (size_t)M * sizeof(double));
     if (e == hipSuccess && listing)
         e = hipMalloc(&dlist, (size_t)M * sizeof(long long));
@@ -347,7 +347,8 @@ static int xcorr_groups_impl(muse_group *gx, muse_group *gy, int32_t n, int32_t 
         p.g2 = ctx->g2;
         p.g3a = ctx->g3a;
         p.g3b = ctx->g3b;
-        p.gsmall = (p.logn >= 9 && p.logn <= 11) ? ctx->gsmall[p.logn - 9] : (p.logn == 13 || p.logn == 14) ? ctx->gsmall[p.logn - 10] : nullptr;
+        p.gsmall = (p.logn >= 9 && p.logn <= 11) ? ctx->gsmall[p.logn - 9] : (p.logn == 13 || p.logn == 14) ? ctx->gsmall[p.logn - 10]
+                   : p.logn == 15 ? ctx->gsmall[4] /* n = 32768 runs on the 16384-point transform's tables (xcorr_real.hip) */ : nullptr;
         p.gscratch = ctx->gscratch;
         p.gscratch_slices = (long long)(ctx->gscratch_elems / (size_t)n);
         p.twl = (p.logn >= 14 && p.logn <= 16) ? ctx->twl[p.logn - 14] : nullptr;

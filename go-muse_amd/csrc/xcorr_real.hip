@@ -33,6 +33,7 @@
 #include <algorithm>
 
 #include "small_device.h"
+#include "two_device.h"
 
 // compile-time switches of tools/ablate/ab_real.sh (one box, profiles/r05_real_transform.txt): the table window (2 ... 5 pairs ahead:
 // inside the noise) and the padded rows' 16-byte requests at 8-byte alignment (- 5 ... 9 % at N = 20000 / 24001)
@@ -50,22 +51,27 @@ namespace real {
 using namespace occ4;
 using namespace fold;
 
-// one mirror pair: Z = Z[k], Zm = Z[M-k], W = W_n^k, xk = xc[k], xm = xc[M-k]  ->  k = 2 C[k], m = 2 C[M-k]
-struct MirrorOut {
+// the real series' spectrum at a mirror pair of bins: Z = Z[k], Zm = Z[M-k], W = W_n^k  ->  k = 2 Y[k], m = 2 Y[M-k]
+struct TwoBins {
     double2 k, m;
 };
-__device__ __forceinline__ MirrorOut mirror_pair(const double2 Z, const double2 Zm, const double2 W, const double2 xk, const double2 xm)
+__device__ __forceinline__ TwoBins spectrum_pair(const double2 Z, const double2 Zm, const double2 W)
 {
     const double2 E2 = make_double2(Z.x + Zm.x, Z.y - Zm.y);                 // Z + conj Zm = 2 E
     const double2 O2 = make_double2(Z.y + Zm.y, Zm.x - Z.x);                 // (Z - conj Zm) / i = 2 O
     const double2 T = cmul(W, O2);
-    const double2 Y = make_double2(E2.x + T.x, E2.y + T.y);                  // 2 Y[k]
-    const double2 Ym = make_double2(E2.x - T.x, T.y - E2.y);                 // 2 Y[M-k] = conj(2 E - T)
-    const double2 P = cmul(Y, xk), Pm = cmul(Ym, xm);
+    return TwoBins{make_double2(E2.x + T.x, E2.y + T.y),                     // 2 Y[k] = 2 E + T
+                   make_double2(E2.x - T.x, T.y - E2.y)};                    // 2 Y[M-k] = conj(2 E - T)
+}
+// one mirror pair: Z = Z[k], Zm = Z[M-k], W = W_n^k, xk / xm = the factors of bins k / M - k  ->  k = 2 C[k], m = 2 C[M-k]
+__device__ __forceinline__ TwoBins mirror_pair(const double2 Z, const double2 Zm, const double2 W, const double2 xk, const double2 xm)
+{
+    const TwoBins Y = spectrum_pair(Z, Zm, W);
+    const double2 P = cmul(Y.k, xk), Pm = cmul(Y.m, xm);
     const double2 A = make_double2(P.x + Pm.x, P.y - Pm.y);                  // P + conj Pm
     const double2 B = cmul(make_double2(P.x - Pm.x, P.y + Pm.y), W);         // (P - conj Pm) W
-    return MirrorOut{make_double2(A.x - B.y, A.y + B.x),                     // A + i B
-                     make_double2(A.x + B.y, B.x - A.y)};                    // conj A + i conj B
+    return TwoBins{make_double2(A.x - B.y, A.y + B.x),                       // A + i B
+                   make_double2(A.x + B.y, B.x - A.y)};                      // conj A + i conj B
 }
 
 } // namespace real
@@ -223,7 +229,7 @@ __global__ __launch_bounds__(1024, 4) void xcorr_fused_real32k(const FusedParams
                 }
                 fence();
                 const double2 W = r == 0 ? Wj : cmul(Wj, make_double2(C32[r], -C32[8 - r])); // W_32^r = cos(2 pi r / 32) - i sin(2 pi r / 32)
-                const MirrorOut o = mirror_pair(v[BR16(r)], zm, W, xk[r], xm[r]);
+                const TwoBins o = mirror_pair(v[BR16(r)], zm, W, xk[r], xm[r]);
                 v[BR16(r)] = o.k; // (in place: bin k's register takes 2 C[k])
                 cmv[r] = o.m;
             }
@@ -295,6 +301,266 @@ __global__ __launch_bounds__(1024, 4) void xcorr_fused_real32k(const FusedParams
             p.lag[row] = lag;
         }
     }
+}
+
+// The batched two-sided xCorr (xcorr.go:102-153) at n = 32768 in the same form: pair i = (x_i, y_i), each zero-padded
+// in front on its own (any Nx, Ny <= n), ONE pair per workgroup iteration and three 16384-point transforms per pair:
+//   ZX = FFT_M(zx) is parked in the workgroup's slice of the context's scratch buffer (256 KB, natural bin order: written and read
+//   back by the same CU within one iteration), ZY = FFT_M(zy) stays in registers; at a mirror pair of bins the thread rebuilds
+//   2 X[k], 2 X[M-k] from the parked ZX[k], ZX[M-k] (its own bin and the bin at (M - k) mod M: two coalesced 16-byte reads where
+//   the xCorrWithX kernel reads the reference's table) and goes on as above with xc := conj X: cc = FFT_n(Y conj X) / n.
+// Every series is centred and scaled to O(1) by an exact power of two on its own before its own transform (two_device.h,
+// pair_scale): no pair has to be listed and redone.  Round 4's four-step kernel (xcorr_two_sided_long<15>) crossed a 512 KB slice
+// four times per pair and read the rows twice (or once, with a redo list): 5 - 6 x the algorithmic bytes; this one 2 x.
+template <bool PADDED>
+__global__ __launch_bounds__(1024, 4) void xcorr_two_sided_real32k(const FusedParams p, const two::PairInv iv)
+{
+    using namespace occ4;
+    using namespace fold;
+    using namespace small;
+    using namespace real;
+    constexpr int n = 32768, M = n / 2, LM = 14, S = M / 16;
+    constexpr int PK = padk(S);
+    __shared__ double red[112];
+    __shared__ double2 g2l[8 * 4];
+    __shared__ double2 xbuf[16 * 544];
+    const int t = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int j = column_of_lane<LM>(t);
+    double2 *const b = xbuf;
+    const int padx = PADDED ? n - p.Nx : 0, pady = PADDED ? n - p.N : 0;
+    const bool normalize = p.normalize_y != 0;
+    const double2 *__restrict__ twm = p.twm;
+    const double2 *__restrict__ gs = p.gsmall;
+    double2 *const park = p.gscratch + (size_t)blockIdx.x * (size_t)M; // the workgroup's slice: ZX in natural bin order
+    typedef d2v __attribute__((address_space(1))) *gd2;
+    if (t < 8 * 4)
+        g2l[t] = tw_factor<4>(twm, t % 4, t / 4);
+    __syncthreads();
+    const long long total = p.npairs;
+    for (long long pair = blockIdx.x; pair < total; pair += gridDim.x) {
+        double2 v[16];
+        double q[4] = {0.0, 0.0, 0.0, 0.0};
+        // one series into v: point m = j + i S holds the samples 2m - pad, 2m + 1 - pad (a pad position: 0), d = sample - K; the
+        // sums of d and d^2 over the series land in q[qo], q[qo + 1]
+        const auto load_series = [&](const double *const r, const int pad, const int qo) __attribute__((always_inline)) {
+            const double K = normalize ? scalar_ptr(r)[0] : 0.0;
+            int jr = j;
+            asm volatile("" : "+v"(jr));
+            jr &= S - 1;
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+            for (int h = 0; h < 2; h++) { // two batches of eight requests
+                d2v s8[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int i = 8 * h + k;
+                    const bool all_pad = PADDED && 2 * (i + 1) * S <= pad; // (wave-uniform: pointed at the row's own first samples, an L2 hit)
+                    const long long off = all_pad ? 0ll : 2ll * i * S - pad;
+                    typedef d2v __attribute__((aligned(8))) d2u;
+                    const d2u s = __builtin_nontemporal_load((gptr<d2u>)scalar_ptr_at(r, off) + (unsigned)jr);
+                    s8[k] = d2v{s.x, s.y};
+                }
+                fence();
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int i = 8 * h + k;
+                    const int e = 2 * (jr + i * S) - pad;
+                    const bool v0 = !PADDED || e >= 0, v1 = !PADDED || e + 1 >= 0;
+                    const double d0 = v0 ? s8[k].x - K : 0.0, d1 = v1 ? s8[k].y - K : 0.0;
+                    v[i] = make_double2(d0, d1);
+                    a0 += d0;
+                    a1 = fma(d0, d0, a1);
+                    a2 += d1;
+                    a3 = fma(d1, d1, a3);
+                }
+            }
+            pair_sum4<S>(a0, a1, a2, a3, red, wave);
+            q[qo] = uniform(a0 + a2);
+            q[qo + 1] = uniform(a1 + a3);
+        };
+        // v <- (d s - m) at valid positions, the series' own exact power-of-two scale and mean (the numbers pair_scale forms from q)
+        const auto scale_series = [&](const int pad, const double sc, const double mean, const bool dead) __attribute__((always_inline)) {
+            int jr = j;
+            asm volatile("" : "+v"(jr));
+            jr &= S - 1;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int e = 2 * (jr + i * S) - pad;
+                const bool v0 = !PADDED || e >= 0, v1 = !PADDED || e + 1 >= 0;
+                v[i].x = (v0 && !dead) ? fma(v[i].x, sc, -mean) : 0.0;
+                v[i].y = (v1 && !dead) ? fma(v[i].y, sc, -mean) : 0.0;
+            }
+        };
+        // ---- x: statistics, scale, ZX = FFT_M(zx), parked
+        load_series(p.xrows + pair * p.xstride, padx, 0);
+        {
+            double qx[4] = {q[0], q[1], 1.0, 1.0}; // (x on its own: pair_scale's numbers for series A do not depend on series B)
+            const two::PairScale px = two::pair_scale(qx, iv, normalize);
+            const bool deadx = normalize ? (px.nil || px.nan) : px.nan;
+            scale_series(padx, px.sA, px.mA, deadx);
+        }
+        forward<LM>(v, b, g2l, gs, j);
+        {
+            int jp = j;
+            asm volatile("" : "+v"(jp));
+            jp &= S - 1;
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                *((gd2)scalar_ptr_at(park, r * S) + (unsigned)jp) = d2v{v[BR16(r)].x, v[BR16(r)].y};
+        }
+        // ---- y: statistics, scale, ZY = FFT_M(zy) in registers
+        load_series(p.rows + pair * p.stride, pady, 2);
+        const two::PairScale ps = two::pair_scale(q, iv, normalize);
+        const bool dead = ps.nil || ps.nan;
+        scale_series(pady, ps.sB, ps.mB, dead);
+        forward<LM>(v, b, g2l, gs, j);
+        // ---- mirror pairs: X from the parked ZX, Y from ZY, P = Y conj X, re-tangled
+        __syncthreads(); // (every thread's part of ZX is in memory before anybody reads a mirrored bin: a workgroup barrier with the memory fence)
+        {
+            int jm = j;
+            asm volatile("" : "+v"(jm));
+            jm &= S - 1;
+            const bool col0 = jm == 0;
+            const int cm = (S - jm) & (S - 1);
+            const int wbase = jm + (jm >> 4), rbase = cm + (cm >> 4), rbm = rbase + (col0 ? PK : 0);
+            const double2 Wj = ldg2u(scalar_ptr(twm), (unsigned)(2 * jm));
+#pragma unroll
+            for (int s = 0; s < 8; s++)
+                lds_st2(b + wbase + s * PK, v[BR16(8 + s)]);
+            // ZX at the two bins of a pair, k = j + r S (own) and (M - k) mod M: a rolling window of requests, as above
+            constexpr int AHEAD = MUSE_REAL_AHEAD;
+            double2 zk[8], zq[8];
+            const auto want_k = [&](const int r) __attribute__((always_inline)) {
+                const d2v z = *((gd2)scalar_ptr_at(park, r * S) + (unsigned)jm);
+                return make_double2(z.x, z.y);
+            };
+            const auto want_m = [&](const int r) __attribute__((always_inline)) {
+                // (M - j - r S) mod M: column 0 of r = 0 is bin 0 itself
+                const unsigned idx = (unsigned)((M - r * S - jm) & (M - 1));
+                const d2v z = *((gd2)scalar_ptr(park) + idx);
+                return make_double2(z.x, z.y);
+            };
+#pragma unroll
+            for (int r = 0; r < AHEAD; r++) {
+                zk[r] = want_k(r);
+                zq[r] = want_m(r);
+            }
+            const double2 v8 = v[BR16(8)];
+            lds_barrier();
+            double2 cmv[8];
+            constexpr double C32[9] = {1.0, 0.98078528040323044913, 0.92387953251128675613, 0.83146961230254523708,
+                                       0.70710678118654752440, 0.55557023301960222474, 0.38268343236508977173, 0.19509032201612826785, 0.0};
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                fence();
+                if (r + AHEAD < 8) {
+                    zk[r + AHEAD] = want_k(r + AHEAD);
+                    zq[r + AHEAD] = want_m(r + AHEAD);
+                }
+                double2 zm = lds_ld2(b + (r == 0 ? rbase + 7 * PK : rbm + (7 - r) * PK));
+                if (r == 0) {
+                    zm.x = col0 ? v[BR16(0)].x : zm.x;
+                    zm.y = col0 ? v[BR16(0)].y : zm.y;
+                }
+                fence();
+                const double2 W = r == 0 ? Wj : cmul(Wj, make_double2(C32[r], -C32[8 - r]));
+                const TwoBins X = spectrum_pair(zk[r], zq[r], W); // 2 X[k], 2 X[M-k]
+                const TwoBins o = mirror_pair(v[BR16(r)], zm, W, make_double2(X.k.x, -X.k.y), make_double2(X.m.x, -X.m.y));
+                v[BR16(r)] = o.k;
+                cmv[r] = o.m;
+            }
+            lds_barrier();
+#pragma unroll
+            for (int r = 0; r < 8; r++)
+                lds_st2(b + wbase + r * PK, cmv[r]);
+            double2 c8 = make_double2(0.0, 0.0);
+            if (wave == 0) { // column 0's ninth pair: bin M / 2 with itself (W = -i)
+                const d2v zh = *((gd2)scalar_ptr_at(park, M / 2));
+                const double2 Wh = make_double2(0.0, -1.0);
+                const TwoBins X = spectrum_pair(make_double2(zh.x, zh.y), make_double2(zh.x, zh.y), Wh);
+                c8 = mirror_pair(v8, v8, Wh, make_double2(X.k.x, -X.k.y), make_double2(X.m.x, -X.m.y)).k;
+            }
+            lds_barrier();
+            {
+                const double2 h = lds_ld2(b + rbase + 7 * PK);
+                const bool mine = wave == 0 && col0;
+                v[BR16(8)] = make_double2(mine ? c8.x : h.x, mine ? c8.y : h.y);
+            }
+#pragma unroll
+            for (int r = 9; r < 16; r++)
+                v[BR16(r)] = lds_ld2(b + rbm + (15 - r) * PK);
+        }
+        {
+            double2 w[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                w[r] = v[BR16(r)];
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                v[r] = w[r];
+        }
+        forward<LM>(v, b, g2l, gs, j); // 4 n cc[2m] + 4 n i cc[2m+1] (before the pair's factor), m = j + r S, at v[BR16(r)]
+        const double fac = ps.fac * (1.0 / (4.0 * n)); // (2 X, 2 Y, and the 1 / n of the inverse transform: exact)
+        if (p.cc_out && !dead) {
+            double *const cc = p.cc_out + pair * (long long)n;
+            int jc = j;
+            asm volatile("" : "+v"(jc));
+            jc &= S - 1;
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                *((d2v __attribute__((address_space(1))) *)scalar_ptr_at(cc, 2 * r * S) + (unsigned)jc) = d2v{v[BR16(r)].x * fac, v[BR16(r)].y * fac};
+        }
+        double sv = 0.0;
+        int code = 0;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const double a0 = v[BR16(r)].x, a1 = v[BR16(r)].y;
+            const bool g0 = fabs(a0) > fabs(sv);
+            sv = g0 ? a0 : sv;
+            code = g0 ? 2 * r : code;
+            const bool g1 = fabs(a1) > fabs(sv);
+            sv = g1 ? a1 : sv;
+            code = g1 ? 2 * r + 1 : code;
+        }
+        const double ma = fabs(sv);
+        const int ia = 2 * (j + (code >> 1) * S) + (code & 1);
+        const double cc0 = v[0].x;
+        double pa = ma, pb = 0.0;
+        pair_max2<S>(pa, pb, red, wave);
+        int ca = (ma == pa && pa > 0.0) ? ia : 0x7fffffff, cb = 0x7fffffff;
+        pair_min_i2<S>(ca, cb, red, wave);
+        const bool own = ca == 0x7fffffff ? j == 0 : (ia == ca && ma == pa);
+        if (own) {
+            const int idx = ca == 0x7fffffff ? 0 : ca;
+            double mv = (ca == 0x7fffffff ? cc0 : sv) * fac;
+            int lag = idx > n / 2 ? idx - n : idx;
+            if (ps.nil) { mv = 0.0; lag = 0; }               // xcorr.go:110-127
+            if (ps.nan) { mv = __builtin_nan(""); lag = 0; } // every cc is NaN: maxAbsIndex keeps index 0
+            p.mv[pair] = mv;
+            p.lag[pair] = lag;
+            if (p.nil_out)
+                p.nil_out[pair] = ps.nil ? 1 : 0;
+        }
+        lds_barrier(); // (red is reused by the next pair's statistics)
+    }
+}
+
+// two-sided xCorr, n = 32768 (launch_two_sided's argument checks apply); one M-point slice of p.gscratch per workgroup
+hipError_t launch_two_sided_real(const FusedParams &p, int num_cus, hipStream_t stream)
+{
+    if (!p.xrows || !p.rows || !p.twm || !p.gsmall || !p.gscratch || !p.mv || !p.lag || p.n != 32768)
+        return hipErrorInvalidValue;
+    const long long slices = p.gscratch_slices * 2; // (gscratch_slices counts n-point slices; a workgroup parks M = n / 2 points)
+    const long long grid = std::min<long long>(std::min<long long>(p.npairs, (long long)num_cus * 4), slices);
+    if (grid < 1)
+        return hipErrorInvalidValue;
+    const two::PairInv iv = two::pair_inv(p.Nx, p.N, 32768);
+    if (p.Nx < p.n || p.N < p.n)
+        hipLaunchKernelGGL(xcorr_two_sided_real32k<true>, dim3((unsigned)grid), dim3(1024), 0, stream, p, iv);
+    else
+        hipLaunchKernelGGL(xcorr_two_sided_real32k<false>, dim3((unsigned)grid), dim3(1024), 0, stream, p, iv);
+    return hipGetLastError();
 }
 
 // n = 32768, float64 rows, every row (no pair list); N in (n / 2, n]; p.gsmall = the 16384-point transform's tables, p.xc all n bins

@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256, 4) void xcorr_two_sided_long(const FusedParams
     constexpr int R1 = n / 4096;
     constexpr int Q1 = 16 / R1;
     constexpr int NW = 4;
-    static_assert(LOGN >= 15 && LOGN <= 16, "n = 32768, 65536");
+    static_assert(LOGN >= 15 && LOGN <= 16, "n = 65536 (n = 32768 is built too, but runs on xcorr_real.hip since round 5)");
     __shared__ double2 xbuf[OCC_XBUF];
     __shared__ double2 g2s[128];
     __shared__ double red[4 * NW + NW + 2];
@@ -580,7 +580,7 @@ hipError_t launch_two_sided(const FusedParams &p, int num_cus, hipStream_t strea
             hipLaunchKernelGGL(xcorr_two_sided_fold<true>, dim3((unsigned)grid), dim3(256), 0, stream, p, iv);
         return hipGetLastError();
     }
-    case 15: return launch_two_long<15>(p, num_cus, stream);
+    case 15: return launch_two_sided_real(p, num_cus, stream); // xcorr_real.hip: each series a real transform on the 16384-point machinery
     case 16: return launch_two_long<16>(p, num_cus, stream);
     default: return hipErrorInvalidValue;
     }

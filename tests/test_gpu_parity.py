@@ -1848,9 +1848,9 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     assert d["clock_probe_in_timed_region"] is False
     cb = d["cpu_baseline"]
     assert cb["value"] > 0 and cb["kind"] == "port" and cb["cores"] >= 1 and cb["single_thread"]["value"] > 0
-    # BASELINE configs[4] at N ranks: six lengths, every Group sharded over both ranks with its label groups on both, one shared Results
+    # BASELINE configs[4] at N ranks: seven lengths, every Group sharded over both ranks with its label groups on both, one shared Results
     c5, legs = d["config5_mixed_run"], d["config5_lengths"]
-    assert c5["n_gpus"] == 2 and c5["lengths"] == [512, 1000, 4096, 5000, 16384, 65536] and c5["value"] > 0
+    assert c5["n_gpus"] == 2 and c5["lengths"] == [512, 1000, 4096, 5000, 16384, 20000, 65536] and c5["value"] > 0
     assert c5["shared_results"]["fetched"] == 20 and len(c5["shared_results"]["lengths_in_top_n"]) >= 2
     for e in legs:
         assert "error" not in e, e
