@@ -20,8 +20,9 @@
 //
 // A thread holds Z[j + r S] (S = 1024, r = 0 .. 15); bin k's partner M - k = (S - j) + (15 - r) S lives in the thread of column
 // S - j.  The pair (k, M - k) shares E, O, W O and both products, so the threads of columns j and S - j split the sixteen pairs
-// between them: each sends its upper eight bins (r >= 8) through the half buffer, forms C[k] AND C[M-k] for its lower eight
-// (32 fp64 instructions per pair), and sends the eight C[M-k] back -- two half exchanges, the volume of one transpose.
+// between them: each puts its upper eight bins (r >= 8) into the half buffer, forms C[k] AND C[M-k] for its lower eight (32 fp64
+// instructions per pair) from its own bin and the partner's, and writes C[M-k] back into the very slot the partner's bin came out
+// of -- the volume of one transpose, three workgroup barriers, no second set of registers.
 // Column 0 pairs inside itself (k = r S with (16 - r) S; k = 0 with the Nyquist bin, k = M / 2 with itself): the same code with
 // one more slot of offset and a ninth evaluation in that thread's wave.
 //
@@ -210,7 +211,6 @@ __global__ __launch_bounds__(1024, 4) void xcorr_fused_real32k(const FusedParams
             }
             const double2 v8 = v[BR16(8)]; // (column 0's ninth pair needs its bin M / 2 once more)
             lds_barrier();
-            double2 cmv[8];
             constexpr double C32[9] = {1.0, 0.98078528040323044913, 0.92387953251128675613, 0.83146961230254523708,
                                        0.70710678118654752440, 0.55557023301960222474, 0.38268343236508977173, 0.19509032201612826785, 0.0};
 #pragma unroll
@@ -220,7 +220,8 @@ __global__ __launch_bounds__(1024, 4) void xcorr_fused_real32k(const FusedParams
                     xk[r + AHEAD] = ldg2u(scalar_ptr_at(xc, (r + AHEAD) * S), (unsigned)jm);
                     xm[r + AHEAD] = ldg2u(scalar_ptr_at(xc, M - (r + AHEAD) * S - S), (unsigned)(S - jm));
                 }
-                double2 zm = lds_ld2(b + (r == 0 ? rbase + 7 * PK : rbm + (7 - r) * PK));
+                double2 *const slot = b + (r == 0 ? rbase + 7 * PK : rbm + (7 - r) * PK); // the partner's bin M - k (its register 15 - r)
+                double2 zm = lds_ld2(slot);
                 if (r == 0) { // k = 0 pairs with the Nyquist bin: both come out of Z[0]
                     // (component by component: a ?: between two double2 lvalues is a select of ADDRESSES, and an array whose element's
                     // address escapes into one is never split into registers -- the sixteen bins went to scratch)
@@ -231,27 +232,26 @@ __global__ __launch_bounds__(1024, 4) void xcorr_fused_real32k(const FusedParams
                 const double2 W = r == 0 ? Wj : cmul(Wj, make_double2(C32[r], -C32[8 - r])); // W_32^r = cos(2 pi r / 32) - i sin(2 pi r / 32)
                 const TwoBins o = mirror_pair(v[BR16(r)], zm, W, xk[r], xm[r]);
                 v[BR16(r)] = o.k; // (in place: bin k's register takes 2 C[k])
-                cmv[r] = o.m;
+                // 2 C[M-k] goes back INTO THE SLOT the partner's bin came out of: nobody else reads or writes that slot, so no barrier
+                // between the read and the write, no registers held for a second exchange -- and the partner finds the C of its
+                // register 8 + s in the slot s of its own column that it filled with Z.  (Column 0, r = 0: the pair's mirror bin is the
+                // Nyquist bin, which has no register; its slot 7 belongs to the pair r = 1.)
+                if (r > 0 || !col0)
+                    lds_st2(slot, o.m);
             }
-            // exchange 2: C[M-k] of the lower eight pairs back to the partner (its registers 15 - r)
-            lds_barrier(); // (everybody has read exchange 1)
-#pragma unroll
-            for (int r = 0; r < 8; r++)
-                lds_st2(b + wbase + r * PK, cmv[r]);
             double2 c8 = make_double2(0.0, 0.0);
             if (wave == 0) { // column 0's ninth pair: bin M / 2 with itself (W = -i); its C lands in register 8 of that thread
                 const double2 xh = ldg2u(scalar_ptr_at(xc, M / 2), 0u);
                 c8 = mirror_pair(v8, v8, make_double2(0.0, -1.0), xh, xh).k;
             }
-            lds_barrier();
-            {
-                const double2 h = lds_ld2(b + rbase + 7 * PK);
-                const bool mine = wave == 0 && col0;
-                v[BR16(8)] = make_double2(mine ? c8.x : h.x, mine ? c8.y : h.y);
-            }
+            lds_barrier(); // (every partner has written back)
 #pragma unroll
-            for (int r = 9; r < 16; r++)
-                v[BR16(r)] = lds_ld2(b + rbm + (15 - r) * PK);
+            for (int s2 = 0; s2 < 8; s2++)
+                v[BR16(8 + s2)] = lds_ld2(b + wbase + s2 * PK);
+            {
+                const bool mine = wave == 0 && col0;
+                v[BR16(8)] = make_double2(mine ? c8.x : v[BR16(8)].x, mine ? c8.y : v[BR16(8)].y);
+            }
         }
         { // renamed to natural order for the second transform (2 C[j + r S] sits at v[BR16(r)])
             double2 w[16];
@@ -448,7 +448,6 @@ __global__ __launch_bounds__(1024, 4) void xcorr_two_sided_real32k(const FusedPa
             }
             const double2 v8 = v[BR16(8)];
             lds_barrier();
-            double2 cmv[8];
             constexpr double C32[9] = {1.0, 0.98078528040323044913, 0.92387953251128675613, 0.83146961230254523708,
                                        0.70710678118654752440, 0.55557023301960222474, 0.38268343236508977173, 0.19509032201612826785, 0.0};
 #pragma unroll
@@ -458,7 +457,8 @@ __global__ __launch_bounds__(1024, 4) void xcorr_two_sided_real32k(const FusedPa
                     zk[r + AHEAD] = want_k(r + AHEAD);
                     zq[r + AHEAD] = want_m(r + AHEAD);
                 }
-                double2 zm = lds_ld2(b + (r == 0 ? rbase + 7 * PK : rbm + (7 - r) * PK));
+                double2 *const slot = b + (r == 0 ? rbase + 7 * PK : rbm + (7 - r) * PK);
+                double2 zm = lds_ld2(slot);
                 if (r == 0) {
                     zm.x = col0 ? v[BR16(0)].x : zm.x;
                     zm.y = col0 ? v[BR16(0)].y : zm.y;
@@ -468,12 +468,9 @@ __global__ __launch_bounds__(1024, 4) void xcorr_two_sided_real32k(const FusedPa
                 const TwoBins X = spectrum_pair(zk[r], zq[r], W); // 2 X[k], 2 X[M-k]
                 const TwoBins o = mirror_pair(v[BR16(r)], zm, W, make_double2(X.k.x, -X.k.y), make_double2(X.m.x, -X.m.y));
                 v[BR16(r)] = o.k;
-                cmv[r] = o.m;
+                if (r > 0 || !col0) // (back into the slot the partner's bin came out of: see xcorr_fused_real32k)
+                    lds_st2(slot, o.m);
             }
-            lds_barrier();
-#pragma unroll
-            for (int r = 0; r < 8; r++)
-                lds_st2(b + wbase + r * PK, cmv[r]);
             double2 c8 = make_double2(0.0, 0.0);
             if (wave == 0) { // column 0's ninth pair: bin M / 2 with itself (W = -i)
                 const d2v zh = *((gd2)scalar_ptr_at(park, M / 2));
@@ -482,14 +479,13 @@ __global__ __launch_bounds__(1024, 4) void xcorr_two_sided_real32k(const FusedPa
                 c8 = mirror_pair(v8, v8, Wh, make_double2(X.k.x, -X.k.y), make_double2(X.m.x, -X.m.y)).k;
             }
             lds_barrier();
-            {
-                const double2 h = lds_ld2(b + rbase + 7 * PK);
-                const bool mine = wave == 0 && col0;
-                v[BR16(8)] = make_double2(mine ? c8.x : h.x, mine ? c8.y : h.y);
-            }
 #pragma unroll
-            for (int r = 9; r < 16; r++)
-                v[BR16(r)] = lds_ld2(b + rbm + (15 - r) * PK);
+            for (int s2 = 0; s2 < 8; s2++)
+                v[BR16(8 + s2)] = lds_ld2(b + wbase + s2 * PK);
+            {
+                const bool mine = wave == 0 && col0;
+                v[BR16(8)] = make_double2(mine ? c8.x : v[BR16(8)].x, mine ? c8.y : v[BR16(8)].y);
+            }
         }
         {
             double2 w[16];

@@ -15,14 +15,14 @@ OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-ARGS="bench.py --steps $STEPS --warmup 1 --no-cpu-baseline --skip-extra in_process_shards"
+ARGS="bench.py --steps $STEPS --warmup 1 --no-cpu-baseline --skip-extra in_process_shards --skip-extra reference_bench_shapes"
 run() { # name, rocprofv3 options...
     local name=$1; shift
     echo "== $name: rocprofv3 $*" >&2
     rocprofv3 "$@" --output-format csv -d $OUT/$name -- python3 $ARGS > $OUT/$name.log 2>&1 || { tail -5 $OUT/$name.log; exit 1; }
 }
 ARGS_PMC=$ARGS
-ARGS="bench.py --steps 16 --warmup 3 --no-cpu-baseline --skip-extra in_process_shards"   # (the trace pass: enough launches for its
+ARGS="bench.py --steps 16 --warmup 3 --no-cpu-baseline --skip-extra in_process_shards --skip-extra reference_bench_shapes"   # (the trace pass: enough launches for its
 run trace --kernel-trace --stats                                                       #  average to sit behind the 30 ms clock ramp)
 ARGS=$ARGS_PMC
 run pmc_fetch --pmc FETCH_SIZE
