@@ -41,6 +41,9 @@
 #ifndef MUSE_REAL_AHEAD
 #define MUSE_REAL_AHEAD 3
 #endif
+#ifndef MUSE_REAL64_PRE
+#define MUSE_REAL64_PRE 0
+#endif
 #ifndef MUSE_REAL_WIDE
 #define MUSE_REAL_WIDE 1
 #endif
@@ -74,6 +77,104 @@ __device__ __forceinline__ TwoBins mirror_pair(const double2 Z, const double2 Zm
     return TwoBins{make_double2(A.x - B.y, A.y + B.x),                       // A + i B
                    make_double2(A.x + B.y, B.x - A.y)};                      // conj A + i conj B
 }
+
+// cos / sin of 2 pi r / 32: W_32^r = C32[r] - i C32[8 - r] for r = 0 .. 8
+constexpr double C32[9] = {1.0, 0.98078528040323044913, 0.92387953251128675613, 0.83146961230254523708,
+                           0.70710678118654752440, 0.55557023301960222474, 0.38268343236508977173, 0.19509032201612826785, 0.0};
+__device__ __forceinline__ double2 w32(const int r) // W_32^r, r = 0 .. 15 (compile-time r)
+{
+    return r <= 8 ? make_double2(C32[r], -C32[8 - r]) : make_double2(-C32[16 - r], -C32[r - 8]);
+}
+
+// The mirror stage of a 16384-point spectrum held as Z[j + r S] at v[BR16(r)] (S = 1024 threads, column j): for every mirror
+// pair of bins the two values C (mirror_pair) from the thread's own bin and the partner thread's, in place -- v[BR16(r)] <- 2 C of
+// the thread's bin j + r S for all sixteen r.  Each thread puts its upper eight bins (r >= 8, slot r - 8 of its column) into the
+// half buffer b, evaluates its lower eight pairs and writes the partner's C back into the slot the partner's bin came out of.
+//   MODE 0: bin k pairs with (H - k) mod H, H = 16 S: the partner is column S - j, register 15 - r; column 0 pairs inside itself
+//           (r with 16 - r: one slot further), its pair r = 0 is bin 0 with itself (the real transform's DC and Nyquist bins) and
+//           its bin H / 2 (register 8) pairs with itself: a ninth evaluation, ninth(v8), in that thread's wave.
+//   MODE 1: bin k pairs with H - 1 - k: column S - 1 - j, register 15 - r, no special column.
+// W(r) = the twiddle of bin j + r S = Wj W_32^r; req(r) requests the pair's two table values (AHEAD pairs in front of their use),
+// fac(raw, W) turns them into the factors of bins k and its mirror; dc0: column 0's bin 0 gets the factor 0 (a series that is not
+// centred leaves its mean in that bin alone).
+template <int MODE, int AHEAD, typename RAW, typename REQ, typename FAC, typename NINTH>
+__device__ __forceinline__ void mirror_stage(double2 (&v)[16], double2 *b, const int j_, const int wave, const double2 Wj, const bool dc0,
+                                             REQ req, FAC fac, NINTH ninth)
+{
+    using namespace small;
+    constexpr int S = 1024, PK = padk(S);
+    int jm = j_;
+    asm volatile("" : "+v"(jm)); // (addresses derived here, not hoisted out of the row loop)
+    jm &= S - 1;
+    const bool col0 = MODE == 0 && jm == 0;
+    const int cm = MODE == 0 ? ((S - jm) & (S - 1)) : (S - 1 - jm); // the partner's column (MODE 0, column 0: itself)
+    const int wbase = jm + (jm >> 4);                               // own column, slot 0
+    const int rbase = cm + (cm >> 4);                               // partner's column, slot 0
+    const int rbm = rbase + (col0 ? PK : 0);                        // column 0 pairs bin r S with bin (16 - r) S: one slot further
+    lds_barrier(); // (the transform's last readers of the buffer are done)
+#pragma unroll
+    for (int s = 0; s < 8; s++)
+        lds_st2(b + wbase + s * PK, v[BR16(8 + s)]);
+    RAW raw[8];
+#pragma unroll
+    for (int r = 0; r < AHEAD; r++)
+        raw[r] = req(r);
+    const double2 v8 = v[BR16(8)]; // (column 0's ninth pair needs its bin H / 2 once more)
+    lds_barrier();
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        fence();
+        if (r + AHEAD < 8)
+            raw[r + AHEAD] = req(r + AHEAD);
+        double2 *const slot = b + ((MODE == 0 && r == 0) ? rbase + 7 * PK : rbm + (7 - r) * PK); // the partner's mirror bin (its register 15 - r)
+        double2 zm = lds_ld2(slot);
+        if (MODE == 0 && r == 0) { // column 0: bin 0 pairs with itself
+            // (component by component: a ?: between two double2 lvalues is a select of ADDRESSES, and an array whose element's address
+            // escapes into one is never split into registers)
+            zm.x = col0 ? v[BR16(0)].x : zm.x;
+            zm.y = col0 ? v[BR16(0)].y : zm.y;
+        }
+        fence();
+        const double2 W = r == 0 ? Wj : cmul(Wj, w32(r));
+        TwoBins f = fac(raw[r], W);
+        if (MODE == 0 && r == 0) {
+            f.k.x = (dc0 && col0) ? 0.0 : f.k.x;
+            f.k.y = (dc0 && col0) ? 0.0 : f.k.y;
+        }
+        const TwoBins o = mirror_pair(v[BR16(r)], zm, W, f.k, f.m);
+        v[BR16(r)] = o.k;
+        // the mirror bin's C goes back INTO THE SLOT its Z came out of: nobody else reads or writes that slot, so no barrier between
+        // the read and the write and no registers held for a second exchange -- the partner finds the C of its register 8 + s in the
+        // slot s of its own column.  (Column 0, r = 0: the mirror bin has no register; that slot belongs to the pair r = 1.)
+        if (MODE == 1 || r > 0 || !col0)
+            lds_st2(slot, o.m);
+    }
+    double2 c8 = make_double2(0.0, 0.0);
+    if (MODE == 0 && wave == 0)
+        c8 = ninth(v8);
+    lds_barrier(); // (every partner has written back)
+#pragma unroll
+    for (int s = 0; s < 8; s++)
+        v[BR16(8 + s)] = lds_ld2(b + wbase + s * PK);
+    if (MODE == 0) {
+        const bool mine = wave == 0 && col0;
+        v[BR16(8)] = make_double2(mine ? c8.x : v[BR16(8)].x, mine ? c8.y : v[BR16(8)].y);
+    }
+}
+// v[BR16(r)] -> v[r]: the natural order the next transform takes its input in
+__device__ __forceinline__ void natural_order(double2 (&v)[16])
+{
+    double2 w[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++)
+        w[r] = v[BR16(r)];
+#pragma unroll
+    for (int r = 0; r < 16; r++)
+        v[r] = w[r];
+}
+struct RawPairXC {
+    double2 a, b;
+};
 
 } // namespace real
 
@@ -559,12 +660,262 @@ hipError_t launch_two_sided_real(const FusedParams &p, int num_cus, hipStream_t 
     return hipGetLastError();
 }
 
+// n = 65536: one real series per workgroup iteration as TWO passes of the machinery above (M = 32768 complex points do not fit a
+// CU; two transforms of H = 16384 points do, one after the other):
+//   z[m] = d[2m] + i d[2m+1];   U[m] = z[m] + z[m + H],   V[m] = (z[m] - z[m + H]) W_M^m          (radix 2, decimation in frequency)
+//   even bins  Z[2k]   = FFT_H(U)[k]: mirror pairs k <-> (H - k) mod H   (the n = 32768 kernel's stage: MODE 0)
+//   odd bins   Z[2k+1] = FFT_H(V)[k]: mirror pairs k <-> H - 1 - k       (MODE 1: no special column)
+//   each pass: Y at its bins, P = Y xc, C at its bins (a mirror pair of bins has one parity), then FFT_H of its C:
+//   ce = FFT_H(C[2k]),  co = FFT_H(C[2k+1]);   c[m] = ce[m] + W_M^m co[m],   c[m + H] = ce[m] - W_M^m co[m]   (decimation in time)
+//   cc[2m'] = Re c[m'],  cc[2m'+1] = Im c[m'].
+// V waits for the second pass and ce for the combine in the workgroup's slice of the context's scratch buffer (2 x 256 KB, every
+// thread re-reads what it wrote): per series 512 KB of rows and 1 MB of parked values cross the memory side -- 3 x the algorithmic
+// bytes where the four-step kernel (xcorr_fused_long<16>: two series per complex transform of n points, four crossings of a 1 MB
+// slice per pair) moves 5 x.  The series is transformed UNSCALED as d = x - x[0] (one series per transform: there is no partner
+// whose scale it has to match): N = n -- its mean sits in bin 0 alone, which gets the factor 0; N < n -- every lag is corrected by
+// -mean c1[lag] (FusedParams::c1, as in the four-step kernel).
+template <bool PADDED>
+__global__ __launch_bounds__(1024, 4) void xcorr_fused_real64k(const FusedParams p)
+{
+    using namespace occ4;
+    using namespace fold;
+    using namespace small;
+    using namespace real;
+    constexpr int n = 65536, M = n / 2, H = M / 2, LH = 14, S = H / 16;
+    __shared__ double red[112];
+    __shared__ double2 g2l[8 * 4];
+    __shared__ double2 xbuf[16 * 544];
+    const int t = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int j = column_of_lane<LH>(t);
+    double2 *const b = xbuf;
+    const int N = PADDED ? p.N : n, pad = PADDED ? n - N : 0;
+    const double invN = PADDED ? p.invN : 1.0 / (double)n, invNm1 = PADDED ? p.invNm1 : 1.0 / (double)(n - 1);
+    const double2 *__restrict__ twm = p.twm;
+    const double2 *__restrict__ gs = p.gsmall;
+    const double2 *__restrict__ xc = p.xc;
+    double2 *const parkV = p.gscratch + (size_t)blockIdx.x * (size_t)M; // the workgroup's slice: V [i][t], then ce [r][t]
+    double2 *const parkE = parkV + H;
+    typedef d2v __attribute__((address_space(1))) *gd2;
+    if (t < 8 * 4)
+        g2l[t] = tw_factor<4>(twm, t % 4, t / 4);
+    __syncthreads();
+    const long long total = p.M;
+    // The row's 32 requests (points m = j + i S and m + H, i = 0 .. 15) in four batches of 4 + 4, PRE batches in flight: a batch is
+    // requested as the one PRE in front of it has been consumed.  (Requested across the loop's back edge -- behind the combine of the
+    // previous row, as the other kernels do -- the batches cost 37 - 120 spilled registers: the 64 they occupy meet the peak of the
+    // statistics' and the parked values' temporaries.)
+    constexpr int PRE = MUSE_REAL64_PRE;
+    typedef d2v __attribute__((aligned(8))) d2u;
+    d2v s1[4][4], s2[4][4];
+    double K = 0.0;
+    const auto request = [&](long long row2, const int h, const double after) __attribute__((always_inline)) {
+        if (row2 >= total)
+            row2 = total - 1; // (nothing left: an L2-hot dummy)
+        const double *const rw = p.rows + row2 * p.stride;
+        int jr = j;
+        asm volatile("" : "+v"(jr) : "v"(after)); // (the requests' addresses hang on `after`: they cannot be hoisted in front of what produced it)
+        jr &= S - 1;
+        if (h == 0)
+            K = scalar_ptr(rw)[0];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = 4 * h + k;
+            const bool all_pad = PADDED && 2 * (i + 1) * S <= pad; // (wave-uniform: pointed at the row's own first samples, an L2 hit)
+            const long long off = all_pad ? 0ll : 2ll * i * S - pad;
+            const d2u a = __builtin_nontemporal_load((gptr<d2u>)scalar_ptr_at(rw, off) + (unsigned)jr);
+            const d2u c = __builtin_nontemporal_load((gptr<d2u>)scalar_ptr_at(rw, 2ll * (i * S + H) - pad) + (unsigned)jr);
+            s1[h][k] = d2v{a.x, a.y};
+            s2[h][k] = d2v{c.x, c.y};
+        }
+    };
+    for (long long row = blockIdx.x; row < total; row += gridDim.x) {
+        double2 v[16];
+        double q0 = 0.0, q1 = 0.0, q2 = 0.0, q3 = 0.0;
+#pragma unroll
+        for (int h = 0; h < PRE; h++)
+            request(row, h, 0.0);
+        // ---- the row, once: points m = j + i S (samples 2m - pad, 2m + 1 - pad; pad positions 0) and m + H (always data: pad < n / 2),
+        // d = x - K, the statistics, U kept, V = (z1 - z2) W_M^m parked
+        {
+            int jr = j;
+            asm volatile("" : "+v"(jr));
+            jr &= S - 1;
+            const double2 Wj = ldg2u(scalar_ptr(twm), (unsigned)(2 * jr)); // W_M^j = W_65536^(2 j)
+#pragma unroll
+            for (int h = 0; h < 4; h++) {
+                if (PRE == 0) {
+                    request(row, h, q3);
+                    fence();
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int i = 4 * h + k;
+                    const int e = 2 * (jr + i * S) - pad;
+                    const bool v0 = !PADDED || e >= 0, v1 = !PADDED || e + 1 >= 0;
+                    const double a0 = v0 ? s1[h][k].x - K : 0.0, a1 = v1 ? s1[h][k].y - K : 0.0;
+                    const double c0 = s2[h][k].x - K, c1 = s2[h][k].y - K;
+                    q0 += a0 + c0;
+                    q1 = fma(a0, a0, fma(c0, c0, q1));
+                    q2 += a1 + c1;
+                    q3 = fma(a1, a1, fma(c1, c1, q3));
+                    v[i] = make_double2(a0 + c0, a1 + c1);
+                    const double2 Vt = cmul(make_double2(a0 - c0, a1 - c1), i == 0 ? Wj : cmul(Wj, w32(i))); // W_M^(j + i S) = W_M^j W_32^i
+                    *((gd2)scalar_ptr_at(parkV, i * S) + (unsigned)(t & (S - 1))) = d2v{Vt.x, Vt.y};
+                }
+                fence();
+                if (PRE > 0 && h + PRE < 4) // (behind the batch just consumed: its registers are free)
+                    request(row, h + PRE, q3);
+                fence();
+            }
+        }
+        pair_sum4<S>(q0, q1, q2, q3, red, wave);
+        bool zero, nan;
+        const double var = uniform(variance(Stat{q0 + q2, q1 + q3}, invN, invNm1, zero, nan));
+        const double mean = uniform((q0 + q2) * invN);
+        // ---- pass A: even bins
+        forward<LH>(v, b, g2l, gs, j);
+        {
+            int jm = j;
+            asm volatile("" : "+v"(jm));
+            jm &= S - 1;
+            const double2 Wj = ldg2u(scalar_ptr(twm), (unsigned)(2 * jm)); // W_n^(2 j)
+            mirror_stage<0, MUSE_REAL_AHEAD, RawPairXC>(
+                v, b, j, wave, Wj, !PADDED,
+                [&](const int r) __attribute__((always_inline)) { // xc at bins 2 (j + r S) and M - 2 (j + r S)
+                    return RawPairXC{ldg2u(scalar_ptr_at(xc, 2 * r * S), (unsigned)(2 * jm)),
+                                     ldg2u(scalar_ptr_at(xc, M - 2 * r * S - 2 * S), (unsigned)(2 * (S - jm)))};
+                },
+                [&](const RawPairXC &x, const double2) __attribute__((always_inline)) { return TwoBins{x.a, x.b}; },
+                [&](const double2 v8) __attribute__((always_inline)) { // bin M / 2 of the series' spectrum: pairs with itself, W = -i
+                    const double2 xh = ldg2u(scalar_ptr_at(xc, M / 2), 0u);
+                    return mirror_pair(v8, v8, make_double2(0.0, -1.0), xh, xh).k;
+                });
+        }
+        natural_order(v);
+        forward<LH>(v, b, g2l, gs, j); // ce[j + r S] at v[BR16(r)]
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            *((gd2)scalar_ptr_at(parkE, r * S) + (unsigned)(t & (S - 1))) = d2v{v[BR16(r)].x, v[BR16(r)].y};
+        // ---- pass B: odd bins
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const d2v z = *((gd2)scalar_ptr_at(parkV, i * S) + (unsigned)(t & (S - 1)));
+            v[i] = make_double2(z.x, z.y);
+        }
+        forward<LH>(v, b, g2l, gs, j);
+        {
+            int jm = j;
+            asm volatile("" : "+v"(jm));
+            jm &= S - 1;
+            const double2 Wj = ldg2u(scalar_ptr(twm), (unsigned)(2 * jm + 1)); // W_n^(2 j + 1)
+            mirror_stage<1, MUSE_REAL_AHEAD, RawPairXC>(
+                v, b, j, wave, Wj, false,
+                [&](const int r) __attribute__((always_inline)) { // xc at bins 2 (j + r S) + 1 and M - 2 (j + r S) - 1
+                    return RawPairXC{ldg2u(scalar_ptr_at(xc, 2 * r * S + 1), (unsigned)(2 * jm)),
+                                     ldg2u(scalar_ptr_at(xc, M - 2 * r * S - 2 * S + 1), (unsigned)(2 * (S - 1 - jm)))};
+                },
+                [&](const RawPairXC &x, const double2) __attribute__((always_inline)) { return TwoBins{x.a, x.b}; },
+                [&](const double2) __attribute__((always_inline)) { return make_double2(0.0, 0.0); });
+        }
+        natural_order(v);
+        forward<LH>(v, b, g2l, gs, j); // co[j + r S] at v[BR16(r)]
+        // ---- c[m] = ce + W_M^m co, c[m + H] = ce - W_M^m co; lags 2m, 2m + 1 (lower half) and 2 (m + H), 2 (m + H) + 1 (upper half);
+        // maxAbsIndex (xcorr.go:39-50): per half ascending r = ascending lag, the lower half first
+        double sl = 0.0, su = 0.0, cc0 = 0.0;
+        int cl = 0, cu = 0;
+        {
+            int jc = j;
+            asm volatile("" : "+v"(jc));
+            jc &= S - 1;
+            const double2 Wj = ldg2u(scalar_ptr(twm), (unsigned)(2 * jc)); // W_M^j
+            const double m2 = 2.0 * mean;                                  // (the re-tangled spectrum carries 2 C)
+            constexpr int CB = PADDED ? 2 : 4; // values per batch of requests (N < n: the correction table's entries travel with them)
+#pragma unroll
+            for (int h = 0; h < 16 / CB; h++) {
+                d2v e4[CB], ka[CB], kb[CB];
+#pragma unroll
+                for (int k = 0; k < CB; k++) {
+                    const int r = CB * h + k;
+                    e4[k] = *((gd2)scalar_ptr_at(parkE, r * S) + (unsigned)(t & (S - 1)));
+                    if (PADDED) { // c1 at lags 2 (j + r S) (+1) and 2 (j + r S + H) (+1)
+                        ka[k] = ((gptr<d2v>)scalar_ptr_at(p.c1, 2 * r * S))[(unsigned)jc];
+                        kb[k] = ((gptr<d2v>)scalar_ptr_at(p.c1, 2 * (r * S + H)))[(unsigned)jc];
+                    }
+                }
+                fence();
+#pragma unroll
+                for (int k = 0; k < CB; k++) {
+                    const int r = CB * h + k;
+                    const double2 o = cmul(v[BR16(r)], r == 0 ? Wj : cmul(Wj, w32(r)));
+                    double l0 = e4[k].x + o.x, l1 = e4[k].y + o.y, u0 = e4[k].x - o.x, u1 = e4[k].y - o.y;
+                    if (PADDED) { // cc(d - mean 1_valid) = cc(d) - mean c1
+                        l0 = fma(-m2, ka[k].x, l0);
+                        l1 = fma(-m2, ka[k].y, l1);
+                        u0 = fma(-m2, kb[k].x, u0);
+                        u1 = fma(-m2, kb[k].y, u1);
+                    }
+                    if (r == 0)
+                        cc0 = l0; // (column 0: cc[0], reported when nothing is above 0)
+                    bool g = fabs(l0) > fabs(sl);
+                    sl = g ? l0 : sl;
+                    cl = g ? 2 * r : cl;
+                    g = fabs(l1) > fabs(sl);
+                    sl = g ? l1 : sl;
+                    cl = g ? 2 * r + 1 : cl;
+                    g = fabs(u0) > fabs(su);
+                    su = g ? u0 : su;
+                    cu = g ? 2 * r : cu;
+                    g = fabs(u1) > fabs(su);
+                    su = g ? u1 : su;
+                    cu = g ? 2 * r + 1 : cu;
+                }
+            }
+        }
+        const bool up = fabs(su) > fabs(sl); // (the lower half holds the lower lags: it keeps ties)
+        const double sv = up ? su : sl;
+        const int code = up ? cu : cl;
+        const double ma = fabs(sv);
+        const int ia = 2 * (j + (code >> 1) * S + (up ? H : 0)) + (code & 1);
+        double pa = ma, pb = 0.0;
+        pair_max2<S>(pa, pb, red, wave);
+        int ca = (ma == pa && pa > 0.0) ? ia : 0x7fffffff, cb = 0x7fffffff;
+        pair_min_i2<S>(ca, cb, red, wave);
+        const bool own = ca == 0x7fffffff ? j == 0 : (ia == ca && ma == pa);
+        if (own) {
+            double y = __builtin_amdgcn_rsq(var);
+            y = y * fma(-0.5 * var * y, y, 1.5);
+            y = y * fma(-0.5 * var * y, y, 1.5);
+            double mv = (ca == 0x7fffffff ? cc0 : sv) * (0.5 * y);
+            const int idx = ca == 0x7fffffff ? 0 : ca;
+            int lag = idx > n / 2 ? idx - n : idx;
+            if (zero) { mv = 0.0; lag = 0; }               // xcorr.go:166-167
+            if (nan) { mv = __builtin_nan(""); lag = 0; }
+            p.mv[row] = mv;
+            p.lag[row] = lag;
+        }
+        __syncthreads(); // (the slice and red are reused by the next row)
+    }
+}
+
 // n = 32768, float64 rows, every row (no pair list); N in (n / 2, n]; p.gsmall = the 16384-point transform's tables, p.xc all n bins
 hipError_t launch_fused_real(const FusedParams &p_in, int num_cus, hipStream_t stream)
 {
     const FusedParams p = with_reciprocals(p_in);
-    if (!p.rows || !p.twm || !p.xc || !p.gsmall || !p.mv || !p.lag || p.n != 32768 || p.N > p.n || 2 * p.N <= p.n || p.pair_list || p.R > 1)
+    if (!p.rows || !p.twm || !p.xc || !p.gsmall || !p.mv || !p.lag || (p.n != 32768 && p.n != 65536) || p.N > p.n || 2 * p.N <= p.n || p.pair_list || p.R > 1)
         return hipErrorInvalidValue;
+    if (p.n == 65536) { // two passes per series: the workgroup's slice of the scratch buffer holds M = n / 2 complex points
+        if (!p.gscratch || (p.N < p.n && !p.c1))
+            return hipErrorInvalidValue;
+        const long long grid = std::min<long long>(std::min<long long>(p.M, (long long)num_cus * 4), p.gscratch_slices * 2);
+        if (grid < 1)
+            return hipErrorInvalidValue;
+        if (p.N < p.n)
+            hipLaunchKernelGGL(xcorr_fused_real64k<true>, dim3((unsigned)grid), dim3(1024), 0, stream, p);
+        else
+            hipLaunchKernelGGL(xcorr_fused_real64k<false>, dim3((unsigned)grid), dim3(1024), 0, stream, p);
+        return hipGetLastError();
+    }
     const long long grid = std::min<long long>(p.M, (long long)num_cus * 8);
     if (p.N < p.n)
         hipLaunchKernelGGL(xcorr_fused_real32k<true>, dim3((unsigned)grid), dim3(1024), 0, stream, p);

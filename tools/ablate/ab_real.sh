@@ -9,7 +9,7 @@ for round in 1 2; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Iinclude -Igo-muse_amd/csrc $flags -c go-muse_amd/csrc/xcorr_real.hip -o $LIB/obj/xcorr_real.hip.o
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $LIB/obj/*.o -o $LIB/libmuse_hip.so
     echo "== round $round flags '$flags'"
-    [ $round = 1 ] && python3 tools/real_debug.py | grep "variant 14"
-    SIZES_AUTO_ONLY=1 SIZES_VARIANT=14 python3 tools/sizes_bench.py 4294967296 32768 20000 24001
+    [ $round = 1 ] && python3 tools/real_debug.py ${AB_CHECK:-32768 20000 24577} | grep "variant 14"
+    SIZES_AUTO_ONLY=1 SIZES_VARIANT=14 python3 tools/sizes_bench.py 4294967296 ${AB_SIZES:-32768 20000 24001}
   done
 done

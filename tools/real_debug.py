@@ -8,7 +8,7 @@ pkg = importlib.import_module("go-muse_amd")
 from oracle import oracle_py
 eng = pkg.get_engine(0)
 rng = np.random.default_rng(5)
-for N in (32768, 20000, 16385, 32767, 24577):
+for N in [int(a) for a in sys.argv[1:]] or (32768, 20000, 16385, 32767, 24577, 65536, 40000, 32769, 65535):
     M = 13
     t = np.arange(N)
     ref = 1.5 * (np.abs(t - N // 2) <= 5) + 0.1 * rng.standard_normal(N)
