@@ -44,6 +44,9 @@
 #ifndef MUSE_REAL64_PRE
 #define MUSE_REAL64_PRE 0
 #endif
+#ifndef MUSE_REAL64_BATCH
+#define MUSE_REAL64_BATCH 4
+#endif
 #ifndef MUSE_REAL_WIDE
 #define MUSE_REAL_WIDE 1
 #endif
@@ -701,13 +704,14 @@ __global__ __launch_bounds__(1024, 4) void xcorr_fused_real64k(const FusedParams
         g2l[t] = tw_factor<4>(twm, t % 4, t / 4);
     __syncthreads();
     const long long total = p.M;
-    // The row's 32 requests (points m = j + i S and m + H, i = 0 .. 15) in four batches of 4 + 4, PRE batches in flight: a batch is
+    // The row's 32 requests (points m = j + i S and m + H, i = 0 .. 15) in batches of NB + NB, PRE batches in flight: a batch is
     // requested as the one PRE in front of it has been consumed.  (Requested across the loop's back edge -- behind the combine of the
     // previous row, as the other kernels do -- the batches cost 37 - 120 spilled registers: the 64 they occupy meet the peak of the
     // statistics' and the parked values' temporaries.)
     constexpr int PRE = MUSE_REAL64_PRE;
     typedef d2v __attribute__((aligned(8))) d2u;
-    d2v s1[4][4], s2[4][4];
+    constexpr int NB = MUSE_REAL64_BATCH, NH = 16 / NB; // requests per batch and series half, batches
+    d2v s1[NH][NB], s2[NH][NB];
     double K = 0.0;
     const auto request = [&](long long row2, const int h, const double after) __attribute__((always_inline)) {
         if (row2 >= total)
@@ -719,8 +723,8 @@ __global__ __launch_bounds__(1024, 4) void xcorr_fused_real64k(const FusedParams
         if (h == 0)
             K = scalar_ptr(rw)[0];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int i = 4 * h + k;
+        for (int k = 0; k < NB; k++) {
+            const int i = NB * h + k;
             const bool all_pad = PADDED && 2 * (i + 1) * S <= pad; // (wave-uniform: pointed at the row's own first samples, an L2 hit)
             const long long off = all_pad ? 0ll : 2ll * i * S - pad;
             const d2u a = __builtin_nontemporal_load((gptr<d2u>)scalar_ptr_at(rw, off) + (unsigned)jr);
@@ -743,14 +747,14 @@ __global__ __launch_bounds__(1024, 4) void xcorr_fused_real64k(const FusedParams
             jr &= S - 1;
             const double2 Wj = ldg2u(scalar_ptr(twm), (unsigned)(2 * jr)); // W_M^j = W_65536^(2 j)
 #pragma unroll
-            for (int h = 0; h < 4; h++) {
+            for (int h = 0; h < NH; h++) {
                 if (PRE == 0) {
                     request(row, h, q3);
                     fence();
                 }
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int i = 4 * h + k;
+                for (int k = 0; k < NB; k++) {
+                    const int i = NB * h + k;
                     const int e = 2 * (jr + i * S) - pad;
                     const bool v0 = !PADDED || e >= 0, v1 = !PADDED || e + 1 >= 0;
                     const double a0 = v0 ? s1[h][k].x - K : 0.0, a1 = v1 ? s1[h][k].y - K : 0.0;
@@ -764,7 +768,7 @@ __global__ __launch_bounds__(1024, 4) void xcorr_fused_real64k(const FusedParams
                     *((gd2)scalar_ptr_at(parkV, i * S) + (unsigned)(t & (S - 1))) = d2v{Vt.x, Vt.y};
                 }
                 fence();
-                if (PRE > 0 && h + PRE < 4) // (behind the batch just consumed: its registers are free)
+                if (PRE > 0 && h + PRE < NH) // (behind the batch just consumed: its registers are free)
                     request(row, h + PRE, q3);
                 fence();
             }
