@@ -545,7 +545,7 @@ hipError_t launch_direct(const double *x, int lenx, const double *y, int leny, i
 //   2  recompute on copies scaled by exact powers of two, (gx, gy): normalized -- each series to magnitude 1 (z-normalisation
 //      cancels any scale); raw -- x 2^-k and y 2^+k, which leaves x[i] y[j] and with it every cc unchanged (bilinear) while
 //      both series meet at the geometric mean of their magnitudes.
-// The variance is the corrected two-pass of stat.StdDev as oracle/muse_oracle.c restates it: (sum d^2 - (sum d)^2 / N) / (N - 1).
+// The variance is the corrected two-pass of gonum stat.StdDev (xcorr.go:88): (sum d^2 - (sum d)^2 / N) / (N - 1) around the mean.
 struct SeriesLook {
     bool finite;   // every sample is a number
     double maxabs; // max |x|

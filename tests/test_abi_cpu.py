@@ -283,7 +283,7 @@ def test_lane_relabelling_removes_the_modelled_lds_bank_conflicts():
     assert all(sim.column_of_lane(9, l + 16) == sim.column_of_lane(9, l) + 16 for l in range(16))
     assert sim.cycles(9, identity=True)[:2] == (8, 16.0) and sim.cycles(9)[:2] == (8, 8.0)
     # the kernel source carries the same maps: the XOR terms of column bit 3 and the parity of column bit 4
-    src = open(os.path.join(root, "go-muse_amd", "csrc", "xcorr_small.hip")).read()
+    src = open(os.path.join(root, "go-muse_amd", "csrc", "small_device.h")).read()   # (column_of_lane: shared by xcorr_small.hip and xcorr_real.hip)
     assert "((l >> 4) ^ (l >> 3) ^ (l >> 2)) & 1" in src and "(LOGN == 10 || LOGN == 14) ? (l >> 1) : l" in src
     assert "(l & ~8) | ((((l >> 3) ^ (l >> 2)) & 1) << 3)" in src
 
