@@ -147,6 +147,8 @@ extern "C" int muse_batch_create(muse_ctx *ctx, muse_group *g, const double *ref
     const bool long_n = n == 16384 || n == 32768 || n == 65536; // xcorr_long.hip: spectrum rows in lane order, sweep twiddles
     if (e == hipSuccess && (n == 4096 || long_n))
         e = hipMalloc(&sp->xcp, (size_t)n * sizeof(double2));
+    if (e == hipSuccess && n == 8192) // xcorr_fused_real8k: the spectrum at its threads' bins, lane-ordered
+        e = hipMalloc(&sp->xcp, (size_t)4096 * sizeof(double2));
     if (e == hipSuccess && (n == 4096 || long_n) && N < n)
         e = hipMalloc(&sp->c1, (size_t)n * sizeof(double));
     if (e != hipSuccess) {
@@ -171,6 +173,15 @@ extern "C" int muse_batch_create(muse_ctx *ctx, muse_group *g, const double *ref
         if (e != hipSuccess) {
             muse_batch_free(b);
             return fail(MUSE_ERR_HIP, "lane-order table: %s", hipGetErrorString(e));
+        }
+    }
+    if (n == 8192) {
+        e = launch_real8k_tables(b->xc, b->xcp, ctx->stream);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            muse_batch_free(b);
+            return fail(MUSE_ERR_HIP, "n = 8192 lane-order table: %s", hipGetErrorString(e));
         }
     }
     if (long_n) {
@@ -350,6 +361,8 @@ extern "C" int muse_batch_score(muse_batch *b)
             variant = KERNEL_R16_OCC3;
     } else if (b->g->f32 && !(((b->n >= 512 && b->n <= 2048) || b->n == 8192 || b->n == 16384) && (ctx->variant == 0 || ctx->variant == 12))) {
         return fail(MUSE_ERR_UNSUPPORTED, "float32-storage groups run on the default kernels only (FFT lengths 512 ... 16384)");
+    } else if (b->n == 8192 && (ctx->variant == 0 || ctx->variant == 14) && !b->g->f32 && b->xcp) {
+        variant = KERNEL_REAL; // one real series per 256-thread workgroup on the n = 4096 kernel's transforms (xcorr_real.hip)
     } else if ((b->n == 32768 || (b->n == 65536 && (b->N == b->n || b->c1))) && (ctx->variant == 0 || ctx->variant == 14) && !b->g->f32 && ctx->gsmall[4]) {
         // one real series per 1024-thread workgroup on the 16384-point complex transform (xcorr_real.hip): n = 32768 never leaves the CU,
         // n = 65536 in two passes with 1 MB parked per series (3 x the algorithmic bytes; the four-step kernel: 5 x)
@@ -460,6 +473,8 @@ extern "C" int muse_batch_kernel_name(muse_batch *b, char *name, int32_t cap)
     const bool padded = b->N < b->n;
     if (b->n == 4096)
         snprintf(k, sizeof(k), "xcorr_fused_n4096_fold<false, %s, %s>", padded ? "true" : "false", b->g->f32 ? "true" : "false");
+    else if (b->n == 8192 && !b->g->f32)
+        snprintf(k, sizeof(k), "xcorr_fused_real8k<%s>", padded ? "true" : "false");
     else if ((b->n >= 512 && b->n <= 2048) || b->n == 8192 || b->n == 16384)
         snprintf(k, sizeof(k), "xcorr_fused_small<%d, %s, false%s>", b->logn, padded ? "true" : "false", b->g->f32 ? ", true" : ", false");
     else if (b->n == 32768 || b->n == 65536)

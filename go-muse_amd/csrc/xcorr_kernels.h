@@ -96,6 +96,7 @@ hipError_t launch_fused_multi(const FusedParams &p, int num_cus, hipStream_t str
 hipError_t launch_fused_small(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_small.hip (n = 512, 1024, 2048: default)
 hipError_t launch_fused_stockham(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_stockham.hip (n = 512 .. 2048, 8192 .. 65536)
 hipError_t launch_fused_long(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_long.hip (n = 65536: default; 16384, 32768)
+hipError_t launch_real8k_tables(const double2 *xc, double2 *out, hipStream_t stream); // xcorr_real.hip: n = 8192, xc at the threads' bins, lane-ordered ([16][256])
 hipError_t launch_two_sided_real(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_real.hip: the two-sided xCorr at n = 32768
 hipError_t launch_fused_real(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_real.hip (n = 32768: one real series per workgroup on the 16384-point transform)
 hipError_t launch_two_sided(const FusedParams &p, int num_cus, hipStream_t stream);

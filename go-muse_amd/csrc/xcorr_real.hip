@@ -33,6 +33,7 @@
 #include <stdlib.h>
 #include <algorithm>
 
+#include "foldk_device.h"
 #include "small_device.h"
 #include "two_device.h"
 
@@ -89,7 +90,7 @@ __device__ __forceinline__ double2 w32(const int r) // W_32^r, r = 0 .. 15 (comp
     return r <= 8 ? make_double2(C32[r], -C32[8 - r]) : make_double2(-C32[16 - r], -C32[r - 8]);
 }
 
-// The mirror stage of a 16384-point spectrum held as Z[j + r S] at v[BR16(r)] (S = 1024 threads, column j): for every mirror
+// The mirror stage of a 16 S-point spectrum held as Z[j + r S] at v[BR16(r)] (S threads, column j; S = 1024 or 256): for every mirror
 // pair of bins the two values C (mirror_pair) from the thread's own bin and the partner thread's, in place -- v[BR16(r)] <- 2 C of
 // the thread's bin j + r S for all sixteen r.  Each thread puts its upper eight bins (r >= 8, slot r - 8 of its column) into the
 // half buffer b, evaluates its lower eight pairs and writes the partner's C back into the slot the partner's bin came out of.
@@ -100,12 +101,12 @@ __device__ __forceinline__ double2 w32(const int r) // W_32^r, r = 0 .. 15 (comp
 // W(r) = the twiddle of bin j + r S = Wj W_32^r; req(r) requests the pair's two table values (AHEAD pairs in front of their use),
 // fac(raw, W) turns them into the factors of bins k and its mirror; dc0: column 0's bin 0 gets the factor 0 (a series that is not
 // centred leaves its mean in that bin alone).
-template <int MODE, int AHEAD, typename RAW, typename REQ, typename FAC, typename NINTH>
+template <int MODE, int AHEAD, typename RAW, int S = 1024, typename REQ, typename FAC, typename NINTH>
 __device__ __forceinline__ void mirror_stage(double2 (&v)[16], double2 *b, const int j_, const int wave, const double2 Wj, const bool dc0,
                                              REQ req, FAC fac, NINTH ninth)
 {
     using namespace small;
-    constexpr int S = 1024, PK = padk(S);
+    constexpr int PK = padk(S); // S columns per slot, padded 17 / 16 (S = 1024: the 16384-point machinery; S = 256: the 4096-point one)
     int jm = j_;
     asm volatile("" : "+v"(jm)); // (addresses derived here, not hoisted out of the row loop)
     jm &= S - 1;
@@ -902,10 +903,212 @@ __global__ __launch_bounds__(1024, 4) void xcorr_fused_real64k(const FusedParams
     }
 }
 
+// n = 8192: one real series per 256-thread workgroup as a real transform on the n = 4096 kernel's complex machinery
+// (foldk_device.h: three radix-16 passes with the twiddles folded into the butterflies, half-round transposes through 34.8 KB, 128
+// registers -> four workgroups per CU).  That machinery runs two packed series of 4096 points at 0.45 of the roofline where the
+// n = 8192 kernel of xcorr_small.hip (512 threads, four passes, 24 workgroup barriers per pair) runs at 0.28; a real series of 8192
+// points is 4096 complex points.  After the first transform thread t = 16 hi + lo holds Z[c + 256 k3] at v[BR16(k3)] with the COLUMN
+// c = hi + 16 lo: bin f's partner M - f = (256 - c) + 256 (15 - k3) is column 256 - c, register 15 - k3 -- mirror_stage with S = 256,
+// through the same 8 x 272 buffer the transposes use.  The reference's spectrum at the thread's bins comes lane-ordered
+// (FusedParams::xcp: [r][t] = xc[c(t) + 256 r], [8 + r][t] = xc[M - c(t) - 256 r]; built per batch by launch_real8k_tables): read in
+// bin order the same values are 64 different cache lines per wave instruction.  The second transform takes C where the mirror stage
+// leaves it (its plain first stage pairs the registers (r, r + 1)): no renaming.
+template <bool PADDED>
+__global__ __launch_bounds__(256, 4) void xcorr_fused_real8k(const FusedParams p)
+{
+    using namespace occ4;
+    using namespace fold;
+    using namespace foldk;
+    using namespace real;
+    constexpr int n = 8192, M = n / 2, S = 256;
+    __shared__ double2 xbuf[OCC_XBUF];
+    __shared__ double2 g2s[128];
+    __shared__ double red[24];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    double2 *const xw = xbuf + XW * wave;
+    const int N = PADDED ? p.N : n, pad = PADDED ? n - N : 0;
+    const double invN = PADDED ? p.invN : 1.0 / (double)n, invNm1 = PADDED ? p.invNm1 : 1.0 / (double)(n - 1);
+    const double2 *__restrict__ twm = p.twm;
+    const double2 *__restrict__ xcp = p.xcp;
+    if (t < 128)
+        g2s[t] = p.g2[t];
+    __syncthreads();
+    const long long total = p.M;
+    // point m = t + 256 i of z holds the samples 2m - pad, 2m + 1 - pad (a pad position: 0): one 16-byte request per point
+    double x0[16], x1[16], K;
+    const auto request = [&](long long row) __attribute__((always_inline)) {
+        if (row >= total)
+            row = total - 1; // (nothing left: an L2-hot dummy)
+        const double *const r = p.rows + row * p.stride;
+        int tr = t;
+        asm volatile("" : "+v"(tr)); // (offsets derived per request, not hoisted)
+        tr &= S - 1;
+        K = scalar_ptr(r)[0];
+        typedef d2v __attribute__((aligned(8))) d2u;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const bool all_pad = PADDED && i < 8 && 2 * (i + 1) * S <= pad; // (wave-uniform: pointed at the row's own first samples)
+            const long long off = all_pad ? 0ll : 2ll * i * S - pad;
+            const d2u s = __builtin_nontemporal_load((gptr<d2u>)scalar_ptr_at(r, off) + (unsigned)tr);
+            x0[i] = s.x;
+            x1[i] = s.y;
+        }
+    };
+    if (blockIdx.x < total)
+        request(blockIdx.x);
+    for (long long row = blockIdx.x; row < total; row += gridDim.x) {
+        double2 v[16];
+        int ts = t;
+        asm volatile("" : "+v"(ts));
+        ts &= S - 1;
+        // d = x - K with K the first sample, shifted statistics (xcorr.go:84-95); the series goes into the transform centred and at
+        // O(1) (an exact power-of-two scale close to 1 / sigma).  (Transformed unscaled, with the mean left in bin 0 / corrected by
+        // the indicator table behind the second transform as the n = 65536 kernel does, the two statistics barriers go -- and nothing
+        // is gained: four workgroups per CU hide them, the kernel is bound by its fp64 issue; the padded build loses 3 - 6 % to the
+        // table's requests.  profiles/r05_real_transform.txt)
+        double q0 = 0.0, q1 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int e = 2 * (ts + i * S) - pad;
+            const bool v0 = !PADDED || i >= 8 || e >= 0, v1 = !PADDED || i >= 8 || e + 1 >= 0; // (pad < n / 2: the upper half is data)
+            const double d0 = v0 ? x0[i] - K : 0.0, d1 = v1 ? x1[i] - K : 0.0;
+            v[i] = make_double2(d0, d1);
+            q0 += d0 + d1;
+            q1 = fma(d0, d0, fma(d1, d1, q1));
+        }
+        q0 = wave_sum_dpp(q0);
+        q1 = wave_sum_dpp(q1);
+        lds_barrier(); // (red's readers of the previous row are done)
+        if (lane == 0) {
+            red[2 * wave] = q0;
+            red[2 * wave + 1] = q1;
+        }
+        lds_barrier();
+        q0 = uniform((red[0] + red[2]) + (red[4] + red[6]));
+        q1 = uniform((red[1] + red[3]) + (red[5] + red[7]));
+        bool zero, nan;
+        const double var0 = variance(Stat{q0, q1}, invN, invNm1, zero, nan);
+        const bool dead = zero || nan;
+        const double sc = dead ? 1.0 : pow2_inv_sigma(var0);
+        const double var = uniform(var0 * sc * sc);
+        const double mean = q0 * invN * sc;
+        asm volatile("" : "+v"(ts));
+        ts &= S - 1;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int e = 2 * (ts + i * S) - pad;
+            const bool v0 = !PADDED || i >= 8 || e >= 0, v1 = !PADDED || i >= 8 || e + 1 >= 0;
+            v[i].x = (v0 && !dead) ? fma(v[i].x, sc, -mean) : 0.0;
+            v[i].y = (v1 && !dead) ? fma(v[i].y, sc, -mean) : 0.0;
+        }
+        // ---- Z = FFT_M(z): Z[hi + 16 lo + 256 k3] at v[BR16(k3)] (as xcorr_fused_n4096_fold)
+        dft16_nr(v);
+        exchange_cross<0, 1, true>(v, xbuf, wave, t);
+        gdft16_nr(v, G2Fetch{g2s, t >> 4});
+        exchange_local<1>(v, xw, t);
+        gdft16_nr_l2(v, G3Derived(p.g3a, t));
+        // ---- mirror pairs on the columns c = hi + 16 lo
+        {
+            int tm = t;
+            asm volatile("" : "+v"(tm));
+            tm &= S - 1;
+            const int c = (tm >> 4) + 16 * (tm & 15);
+            const double2 Wj = ldg2u(scalar_ptr(twm), (unsigned)(8 * c)); // W_8192^c = W_65536^(8 c); bin c + 256 r: times W_32^r
+            mirror_stage<0, MUSE_REAL_AHEAD, RawPairXC, S>(
+                v, xbuf, c, wave, Wj, false,
+                [&](const int r) __attribute__((always_inline)) {
+                    return RawPairXC{ldg2u(scalar_ptr_at(xcp, r * S), (unsigned)tm), ldg2u(scalar_ptr_at(xcp, (8 + r) * S), (unsigned)tm)};
+                },
+                [&](const RawPairXC &x, const double2) __attribute__((always_inline)) { return TwoBins{x.a, x.b}; },
+                [&](const double2 v8) __attribute__((always_inline)) { // bin M / 2: pairs with itself, W = -i
+                    const double2 xh = ldg2u(scalar_ptr_at(p.xc, M / 2), 0u);
+                    return mirror_pair(v8, v8, make_double2(0.0, -1.0), xh, xh).k;
+                });
+            lds_barrier(); // (the next use of the buffer is a wave-local transpose into a quarter other waves' columns live in)
+        }
+        // ---- c = FFT_M(C): the plain first stage pairs the registers (r, r + 1)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2)
+            bf_one(v[r], v[r + 1]);
+        dft16_rn_s234(v);
+        exchange_local<0>(v, xw, t);
+        gdft16_nr(v, G2Fetch{g2s, t & 15});
+        exchange_cross<1, 1>(v, xbuf, wave, t);
+        gdft16_nr_l2(v, G3Derived(p.g3b, t)); // 2 cc[2m] + 2 i cc[2m+1], m = t + 256 m3, at v[BR16(m3)]
+        double sv = 0.0;
+        int code = 0;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const double a0 = v[BR16(r)].x, a1 = v[BR16(r)].y;
+            const bool g0 = fabs(a0) > fabs(sv);
+            sv = g0 ? a0 : sv;
+            code = g0 ? 2 * r : code;
+            const bool g1 = fabs(a1) > fabs(sv);
+            sv = g1 ? a1 : sv;
+            code = g1 ? 2 * r + 1 : code;
+        }
+        const double ma = fabs(sv);
+        const int ia = 2 * (t + (code >> 1) * S) + (code & 1);
+        const double cc0 = v[0].x; // (thread 0: cc[0], reported when nothing is above 0)
+        fence();
+        request(row + gridDim.x); // the next row: in flight during the reductions and the result write-out
+        fence();
+        const double wa = wave_max_nonneg(ma);
+        if (lane == 0)
+            red[8 + wave] = wa;
+        lds_barrier();
+        const double pa = fmax(fmax(red[8], red[9]), fmax(red[10], red[11]));
+        const int wi = wave_min_i_dpp((ma == pa && pa > 0.0) ? ia : 0x7fffffff);
+        if (lane == 0)
+            ((int *)(red + 12))[wave] = wi;
+        lds_barrier();
+        const int *ri = (const int *)(red + 12);
+        const int ca = min(min(ri[0], ri[1]), min(ri[2], ri[3]));
+        const bool own = ca == 0x7fffffff ? t == 0 : (ia == ca && ma == pa);
+        if (own) {
+            double y = __builtin_amdgcn_rsq(var);
+            y = y * fma(-0.5 * var * y, y, 1.5);
+            y = y * fma(-0.5 * var * y, y, 1.5);
+            double mv = (ca == 0x7fffffff ? cc0 : sv) * (0.5 * y); // (the re-tangled spectrum carries 2 C)
+            const int idx = ca == 0x7fffffff ? 0 : ca;
+            int lag = idx > n / 2 ? idx - n : idx;
+            if (zero) { mv = 0.0; lag = 0; }               // xcorr.go:166-167
+            if (nan) { mv = __builtin_nan(""); lag = 0; }
+            p.mv[row] = mv;
+            p.lag[row] = lag;
+        }
+    }
+}
+// the reference's spectrum at the bins of xcorr_fused_real8k's threads, lane-ordered: out[r][t] = xc[c(t) + 256 r],
+// out[8 + r][t] = xc[4096 - c(t) - 256 r], r = 0 .. 7, c(t) = (t >> 4) + 16 (t & 15)
+__global__ void real8k_tables_kernel(const double2 *__restrict__ xc, double2 *__restrict__ out)
+{
+    const int t = threadIdx.x, r = blockIdx.x;
+    const int c = (t >> 4) + 16 * (t & 15);
+    out[r * 256 + t] = xc[c + 256 * r];
+    out[(8 + r) * 256 + t] = xc[4096 - c - 256 * r];
+}
+hipError_t launch_real8k_tables(const double2 *xc, double2 *out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(real8k_tables_kernel, dim3(8), dim3(256), 0, stream, xc, out);
+    return hipGetLastError();
+}
+
 // n = 32768, float64 rows, every row (no pair list); N in (n / 2, n]; p.gsmall = the 16384-point transform's tables, p.xc all n bins
 hipError_t launch_fused_real(const FusedParams &p_in, int num_cus, hipStream_t stream)
 {
     const FusedParams p = with_reciprocals(p_in);
+    if (p.n == 8192) { // one real series per 256-thread workgroup on the n = 4096 kernel's transforms; p.xcp: launch_real8k_tables
+        if (!p.rows || !p.twm || !p.xc || !p.xcp || !p.g2 || !p.g3a || !p.g3b || !p.mv || !p.lag || p.N > p.n || 2 * p.N <= p.n || p.pair_list || p.R > 1)
+            return hipErrorInvalidValue;
+        const long long grid = std::min<long long>(p.M, (long long)num_cus * 4 * 4);
+        if (p.N < p.n)
+            hipLaunchKernelGGL(xcorr_fused_real8k<true>, dim3((unsigned)grid), dim3(256), 0, stream, p);
+        else
+            hipLaunchKernelGGL(xcorr_fused_real8k<false>, dim3((unsigned)grid), dim3(256), 0, stream, p);
+        return hipGetLastError();
+    }
     if (!p.rows || !p.twm || !p.xc || !p.gsmall || !p.mv || !p.lag || (p.n != 32768 && p.n != 65536) || p.N > p.n || 2 * p.N <= p.n || p.pair_list || p.R > 1)
         return hipErrorInvalidValue;
     if (p.n == 65536) { // two passes per series: the workgroup's slice of the scratch buffer holds M = n / 2 complex points

@@ -747,7 +747,7 @@ def test_per_length_kernels_at_scale_match_the_stockham_kernels(muse, eng, oracl
 
 
 @pytest.mark.parametrize("N", [257, 480, 512, 700, 1000, 1024, 1025, 1500, 2048,
-                               4097, 5000, 6000, 8192, 10000, 16384, 16385, 20000, 24001, 32767, 32768, 32769, 40000, 50001, 65535, 65536])
+                               4097, 5000, 6001, 8191, 8192, 10000, 16384, 16385, 20000, 24001, 32767, 32768, 32769, 40000, 50001, 65535, 65536])
 def test_stockham_kernels_match_oracle_and_generic(muse, eng, oracle, N):
     """n = 512 ... 2048 (LDS) and 8192 ... 65536 (global scratch): the radix-16 Stockham kernels
     (auto / variant 11) against the oracle and the radix-2 generic kernel (variant 1) on the same
@@ -766,15 +766,16 @@ def test_stockham_kernels_match_oracle_and_generic(muse, eng, oracle, N):
     try:
         got = {}
         small = db.n <= 2048 or db.n in (8192, 16384)   # lengths the half-round kernel (xcorr_small.hip) is built for
-        variants = ((0, 11, 12, 1) if small else (0, 11, 1)) + ((13,) if db.n >= 16384 else ()) + ((14,) if db.n >= 32768 else ())
-        # (13: xcorr_long.hip, 14: xcorr_real.hip -- n = 32768 / 65536 as one real series per workgroup on the 16384-point transform)
+        variants = ((0, 11, 12, 1) if small else (0, 11, 1)) + ((13,) if db.n >= 16384 else ()) + ((14,) if db.n in (8192, 32768, 65536) else ())
+        # (13: xcorr_long.hip, 14: xcorr_real.hip -- one REAL series per workgroup: n = 8192 on the 4096-point transform, n = 32768 / 65536
+        # on the 16384-point one)
         for variant in variants:
             eng.set_kernel(variant)
             lag, mv = db.scores()
             assert math.isnan(mv[10]) and lag[10] == 0 and math.isnan(mv[12]) and lag[12] == 0, variant
             assert_scores_match(lag, mv, olag, omv, gap)
             got[variant] = (lag, mv)
-        auto = 14 if db.n >= 32768 else 12 if small else 11      # what automatic selection takes for this length
+        auto = 14 if db.n in (8192, 32768, 65536) else 12 if small else 11      # what automatic selection takes for this length
         assert np.array_equal(got[0][0], got[auto][0]) and np.array_equal(got[0][1], got[auto][1], equal_nan=True)
     finally:
         eng.set_kernel(0)
