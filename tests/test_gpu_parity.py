@@ -691,8 +691,11 @@ def test_many_references_one_pass_matches_single_batches(muse, eng, oracle, R, M
         assert mv[11] == 0.0 and lag[11] == 0
         assert_scores_match(lag, mv, olag, omv, gap)
         slag, smv = batches[r].scores()                 # the single-reference kernel on the same batch
-        assert np.array_equal(lag, slag)
-        np.testing.assert_allclose(mv, smv, rtol=1e-12, atol=0, equal_nan=True)
+        # (n = 8192, 32768, 65536: the single-reference kernel is a REAL transform of one series, the many-references pass a complex
+        # transform of a pair -- two float64 evaluations of the same numbers; lags may differ where the oracle flags a tie)
+        other = batches[r].n in (8192, 32768, 65536)
+        assert np.array_equal(lag, slag) or (other and np.all((lag == slag) | (gap < TIE_GAP)))
+        np.testing.assert_allclose(mv, smv, rtol=1e-9 if other else 1e-12, atol=0, equal_nan=True)
     # Run semantics for every reference in one call
     gid = (np.arange(M) // 7).astype(np.int32)
     G = int(gid.max()) + 1
@@ -1179,8 +1182,9 @@ def test_screened_run_equals_fp64_run(muse, eng, oracle, N):
                 assert got[1].tolist() == exp[1].tolist(), key
                 # (2048 < N < 4096 and n >= 32768: the all-scores kernel transforms x - x[0] and corrects for the mean
                 # afterwards, the re-evaluating kernel centres and rescales before the transform: the two fp64 results
-                # differ by ~1e-11 relative on the rows built to stress exactly that)
-                loose = 2048 < N < 4096 or N > 16384
+                # differ by ~1e-11 relative on the rows built to stress exactly that; n = 8192, 32768, 65536: the all-scores
+                # kernel is a real transform of one series (xcorr_real.hip), the re-evaluating one a complex transform of a pair)
+                loose = 2048 < N < 4096 or 4096 < N <= 8192 or N > 16384
                 np.testing.assert_allclose(got[2], exp[2], rtol=1e-9 if loose else 1e-12, atol=0, err_msg=str(key))
         # the all-scores API after a screened Run still returns fp64 results for every row
         lag2, mv2 = db.read_scores()
