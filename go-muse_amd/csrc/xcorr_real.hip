@@ -191,7 +191,6 @@ __global__ __launch_bounds__(1024, 4) void xcorr_fused_real32k(const FusedParams
     using namespace small;
     using namespace real;
     constexpr int n = 32768, M = n / 2, LM = 14, S = M / 16; // S = 1024 threads, 16 complex points each
-    constexpr int PK = padk(S);                              // one slot of the half buffer: S points, padded 17 / 16
     __shared__ double red[112];
     __shared__ double2 g2l[8 * 4];
     __shared__ double2 xbuf[16 * 544]; // the half buffer of the transposes: 8 S padded points = 139 KB
@@ -287,86 +286,26 @@ __global__ __launch_bounds__(1024, 4) void xcorr_fused_real32k(const FusedParams
         }
         // ---- Z = FFT_M(z): Z[j + r S] at v[BR16(r)]
         forward<LM>(v, b, g2l, gs, j);
-        // ---- mirror pairs: Y, the product with the reference's spectrum, re-tangled for the second transform
+        // ---- mirror pairs: Y, the product with the reference's spectrum, re-tangled for the second transform (mirror_stage above)
         {
             int jm = j;
             asm volatile("" : "+v"(jm)); // (addresses derived here, not hoisted out of the row loop)
             jm &= S - 1;
-            const bool col0 = jm == 0;
-            const int cm = (S - jm) & (S - 1);                  // the partner's column (column 0: itself)
-            const int wbase = jm + (jm >> 4);                   // own column, slot 0
-            const int rbase = cm + (cm >> 4);                   // partner's column, slot 0
-            const int rbm = rbase + (col0 ? PK : 0);            // column 0 pairs bin r S with bin (16 - r) S: one slot further
-            // W_n^(j + r S) = W_n^j W_32^r: one table entry (W_65536^(2 j)) and seven constant factors
+            // W_n^(j + r S) = W_n^j W_32^r: one table entry (W_65536^(2 j)) and seven constant factors; the reference's spectrum at the
+            // two bins of a pair, xc[j + r S] and xc[M - j - r S]
             const double2 Wj = ldg2u(scalar_ptr(twm), (unsigned)(2 * jm));
-            // exchange 1: the upper eight bins (register r = 8 + s in slot s) to the partner
-            lds_barrier(); // (the transform's last readers of the buffer are done)
-#pragma unroll
-            for (int s = 0; s < 8; s++)
-                lds_st2(b + wbase + s * PK, v[BR16(8 + s)]);
-            // the reference's spectrum at the two bins of a pair, xc[j + r S] and xc[M - j - r S]: requested AHEAD pairs in front of
-            // their use (a rolling window: all sixteen at once do not fit beside the bins, and requested where they are used every
-            // wave of the workgroup would wait out the L2 round trip in step)
-            constexpr int AHEAD = MUSE_REAL_AHEAD;
-            double2 xk[8], xm[8];
-#pragma unroll
-            for (int r = 0; r < AHEAD; r++) {
-                xk[r] = ldg2u(scalar_ptr_at(xc, r * S), (unsigned)jm);
-                xm[r] = ldg2u(scalar_ptr_at(xc, M - r * S - S), (unsigned)(S - jm));
-            }
-            const double2 v8 = v[BR16(8)]; // (column 0's ninth pair needs its bin M / 2 once more)
-            lds_barrier();
-            constexpr double C32[9] = {1.0, 0.98078528040323044913, 0.92387953251128675613, 0.83146961230254523708,
-                                       0.70710678118654752440, 0.55557023301960222474, 0.38268343236508977173, 0.19509032201612826785, 0.0};
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-                fence();
-                if (r + AHEAD < 8) {
-                    xk[r + AHEAD] = ldg2u(scalar_ptr_at(xc, (r + AHEAD) * S), (unsigned)jm);
-                    xm[r + AHEAD] = ldg2u(scalar_ptr_at(xc, M - (r + AHEAD) * S - S), (unsigned)(S - jm));
-                }
-                double2 *const slot = b + (r == 0 ? rbase + 7 * PK : rbm + (7 - r) * PK); // the partner's bin M - k (its register 15 - r)
-                double2 zm = lds_ld2(slot);
-                if (r == 0) { // k = 0 pairs with the Nyquist bin: both come out of Z[0]
-                    // (component by component: a ?: between two double2 lvalues is a select of ADDRESSES, and an array whose element's
-                    // address escapes into one is never split into registers -- the sixteen bins went to scratch)
-                    zm.x = col0 ? v[BR16(0)].x : zm.x;
-                    zm.y = col0 ? v[BR16(0)].y : zm.y;
-                }
-                fence();
-                const double2 W = r == 0 ? Wj : cmul(Wj, make_double2(C32[r], -C32[8 - r])); // W_32^r = cos(2 pi r / 32) - i sin(2 pi r / 32)
-                const TwoBins o = mirror_pair(v[BR16(r)], zm, W, xk[r], xm[r]);
-                v[BR16(r)] = o.k; // (in place: bin k's register takes 2 C[k])
-                // 2 C[M-k] goes back INTO THE SLOT the partner's bin came out of: nobody else reads or writes that slot, so no barrier
-                // between the read and the write, no registers held for a second exchange -- and the partner finds the C of its
-                // register 8 + s in the slot s of its own column that it filled with Z.  (Column 0, r = 0: the pair's mirror bin is the
-                // Nyquist bin, which has no register; its slot 7 belongs to the pair r = 1.)
-                if (r > 0 || !col0)
-                    lds_st2(slot, o.m);
-            }
-            double2 c8 = make_double2(0.0, 0.0);
-            if (wave == 0) { // column 0's ninth pair: bin M / 2 with itself (W = -i); its C lands in register 8 of that thread
-                const double2 xh = ldg2u(scalar_ptr_at(xc, M / 2), 0u);
-                c8 = mirror_pair(v8, v8, make_double2(0.0, -1.0), xh, xh).k;
-            }
-            lds_barrier(); // (every partner has written back)
-#pragma unroll
-            for (int s2 = 0; s2 < 8; s2++)
-                v[BR16(8 + s2)] = lds_ld2(b + wbase + s2 * PK);
-            {
-                const bool mine = wave == 0 && col0;
-                v[BR16(8)] = make_double2(mine ? c8.x : v[BR16(8)].x, mine ? c8.y : v[BR16(8)].y);
-            }
+            mirror_stage<0, MUSE_REAL_AHEAD, RawPairXC>(
+                v, b, j, wave, Wj, false,
+                [&](const int r) __attribute__((always_inline)) {
+                    return RawPairXC{ldg2u(scalar_ptr_at(xc, r * S), (unsigned)jm), ldg2u(scalar_ptr_at(xc, M - r * S - S), (unsigned)(S - jm))};
+                },
+                [&](const RawPairXC &x, const double2) __attribute__((always_inline)) { return TwoBins{x.a, x.b}; },
+                [&](const double2 v8) __attribute__((always_inline)) { // bin M / 2 pairs with itself, W = -i
+                    const double2 xh = ldg2u(scalar_ptr_at(xc, M / 2), 0u);
+                    return mirror_pair(v8, v8, make_double2(0.0, -1.0), xh, xh).k;
+                });
         }
-        { // renamed to natural order for the second transform (2 C[j + r S] sits at v[BR16(r)])
-            double2 w[16];
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-                w[r] = v[BR16(r)];
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-                v[r] = w[r];
-        }
+        natural_order(v); // (2 C[j + r S] sits at v[BR16(r)]; the transform takes its input in natural order)
         // ---- c = FFT_M(C): 2 cc[2m] + 2 i cc[2m+1] with m = j + r S at v[BR16(r)]
         forward<LM>(v, b, g2l, gs, j);
         // ---- maxAbsIndex (xcorr.go:39-50): ascending r, real part before imaginary part = ascending lag index for this thread
@@ -425,7 +364,6 @@ __global__ __launch_bounds__(1024, 4) void xcorr_two_sided_real32k(const FusedPa
     using namespace small;
     using namespace real;
     constexpr int n = 32768, M = n / 2, LM = 14, S = M / 16;
-    constexpr int PK = padk(S);
     __shared__ double red[112];
     __shared__ double2 g2l[8 * 4];
     __shared__ double2 xbuf[16 * 544];
@@ -526,81 +464,28 @@ __global__ __launch_bounds__(1024, 4) void xcorr_two_sided_real32k(const FusedPa
             int jm = j;
             asm volatile("" : "+v"(jm));
             jm &= S - 1;
-            const bool col0 = jm == 0;
-            const int cm = (S - jm) & (S - 1);
-            const int wbase = jm + (jm >> 4), rbase = cm + (cm >> 4), rbm = rbase + (col0 ? PK : 0);
             const double2 Wj = ldg2u(scalar_ptr(twm), (unsigned)(2 * jm));
-#pragma unroll
-            for (int s = 0; s < 8; s++)
-                lds_st2(b + wbase + s * PK, v[BR16(8 + s)]);
-            // ZX at the two bins of a pair, k = j + r S (own) and (M - k) mod M: a rolling window of requests, as above
-            constexpr int AHEAD = MUSE_REAL_AHEAD;
-            double2 zk[8], zq[8];
-            const auto want_k = [&](const int r) __attribute__((always_inline)) {
-                const d2v z = *((gd2)scalar_ptr_at(park, r * S) + (unsigned)jm);
-                return make_double2(z.x, z.y);
+            // the pair's factors: conj of 2 X at the two bins, rebuilt from the parked ZX[k] (own bin) and ZX[(M - k) mod M]
+            const auto conj_x = [](const RawPairXC &z, const double2 W) __attribute__((always_inline)) {
+                const TwoBins X = spectrum_pair(z.a, z.b, W);
+                return TwoBins{make_double2(X.k.x, -X.k.y), make_double2(X.m.x, -X.m.y)};
             };
-            const auto want_m = [&](const int r) __attribute__((always_inline)) {
-                // (M - j - r S) mod M: column 0 of r = 0 is bin 0 itself
-                const unsigned idx = (unsigned)((M - r * S - jm) & (M - 1));
-                const d2v z = *((gd2)scalar_ptr(park) + idx);
-                return make_double2(z.x, z.y);
-            };
-#pragma unroll
-            for (int r = 0; r < AHEAD; r++) {
-                zk[r] = want_k(r);
-                zq[r] = want_m(r);
-            }
-            const double2 v8 = v[BR16(8)];
-            lds_barrier();
-            constexpr double C32[9] = {1.0, 0.98078528040323044913, 0.92387953251128675613, 0.83146961230254523708,
-                                       0.70710678118654752440, 0.55557023301960222474, 0.38268343236508977173, 0.19509032201612826785, 0.0};
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-                fence();
-                if (r + AHEAD < 8) {
-                    zk[r + AHEAD] = want_k(r + AHEAD);
-                    zq[r + AHEAD] = want_m(r + AHEAD);
-                }
-                double2 *const slot = b + (r == 0 ? rbase + 7 * PK : rbm + (7 - r) * PK);
-                double2 zm = lds_ld2(slot);
-                if (r == 0) {
-                    zm.x = col0 ? v[BR16(0)].x : zm.x;
-                    zm.y = col0 ? v[BR16(0)].y : zm.y;
-                }
-                fence();
-                const double2 W = r == 0 ? Wj : cmul(Wj, make_double2(C32[r], -C32[8 - r]));
-                const TwoBins X = spectrum_pair(zk[r], zq[r], W); // 2 X[k], 2 X[M-k]
-                const TwoBins o = mirror_pair(v[BR16(r)], zm, W, make_double2(X.k.x, -X.k.y), make_double2(X.m.x, -X.m.y));
-                v[BR16(r)] = o.k;
-                if (r > 0 || !col0) // (back into the slot the partner's bin came out of: see xcorr_fused_real32k)
-                    lds_st2(slot, o.m);
-            }
-            double2 c8 = make_double2(0.0, 0.0);
-            if (wave == 0) { // column 0's ninth pair: bin M / 2 with itself (W = -i)
-                const d2v zh = *((gd2)scalar_ptr_at(park, M / 2));
-                const double2 Wh = make_double2(0.0, -1.0);
-                const TwoBins X = spectrum_pair(make_double2(zh.x, zh.y), make_double2(zh.x, zh.y), Wh);
-                c8 = mirror_pair(v8, v8, Wh, make_double2(X.k.x, -X.k.y), make_double2(X.m.x, -X.m.y)).k;
-            }
-            lds_barrier();
-#pragma unroll
-            for (int s2 = 0; s2 < 8; s2++)
-                v[BR16(8 + s2)] = lds_ld2(b + wbase + s2 * PK);
-            {
-                const bool mine = wave == 0 && col0;
-                v[BR16(8)] = make_double2(mine ? c8.x : v[BR16(8)].x, mine ? c8.y : v[BR16(8)].y);
-            }
+            mirror_stage<0, MUSE_REAL_AHEAD, RawPairXC>(
+                v, b, j, wave, Wj, false,
+                [&](const int r) __attribute__((always_inline)) {
+                    const d2v zk = *((gd2)scalar_ptr_at(park, r * S) + (unsigned)jm);
+                    const d2v zq = *((gd2)scalar_ptr(park) + (unsigned)((M - r * S - jm) & (M - 1))); // (column 0 of r = 0: bin 0 itself)
+                    return RawPairXC{make_double2(zk.x, zk.y), make_double2(zq.x, zq.y)};
+                },
+                conj_x,
+                [&](const double2 v8) __attribute__((always_inline)) { // bin M / 2 pairs with itself, W = -i
+                    const d2v zh = *((gd2)scalar_ptr_at(park, M / 2));
+                    const double2 Wh = make_double2(0.0, -1.0);
+                    const TwoBins f = conj_x(RawPairXC{make_double2(zh.x, zh.y), make_double2(zh.x, zh.y)}, Wh);
+                    return mirror_pair(v8, v8, Wh, f.k, f.m).k;
+                });
         }
-        {
-            double2 w[16];
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-                w[r] = v[BR16(r)];
-#pragma unroll
-            for (int r = 0; r < 16; r++)
-                v[r] = w[r];
-        }
+        natural_order(v);
         forward<LM>(v, b, g2l, gs, j); // 4 n cc[2m] + 4 n i cc[2m+1] (before the pair's factor), m = j + r S, at v[BR16(r)]
         const double fac = ps.fac * (1.0 / (4.0 * n)); // (2 X, 2 Y, and the 1 / n of the inverse transform: exact)
         if (p.cc_out && !dead) {

@@ -1864,6 +1864,24 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
         assert e["exchange"].startswith("all_gather")
 
 
+def test_reference_bench_shapes_harness(muse):
+    """go-muse_amd/host/muse_ref_bench.cpp (the reference's six `go test -bench` bodies over the C++ mirror; bench.py's
+    reference_bench_shapes runs it as a child process): builds, runs, prints one JSON object with every benchmark and a positive
+    time per op beside the README's figure."""
+    import json
+    import subprocess
+    exe = muse.build.build_ref_bench()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1000:]
+    d = json.loads(r.stdout)
+    assert sorted(d) == ["BenchmarkMuseBatchRun", "BenchmarkMuseBatchRunLarge", "BenchmarkMuseRun", "BenchmarkMuseRunLarge",
+                         "BenchmarkXCorr", "BenchmarkXCorrWithX"]
+    for name, o in d.items():
+        assert o["ns_per_op"] > 0 and o["reps"] >= 3 and "source" in o, name
+    assert d["BenchmarkMuseRun"]["readme_ns_per_op"] == 5019 and d["BenchmarkXCorrWithX"]["readme_ns_per_op"] == 4910405
+    assert d["BenchmarkMuseRunLarge"]["ns_per_op"] < 128044546 / 10      # (two orders below the README's laptop on any MI355X box)
+
+
 def test_many_references_on_a_float32_storage_group(muse, eng, oracle):
     """muse_batch_score_many over an opt-in float32-storage group at n = 4096 (N = 4096 and a padded length): one pass over the
     float32 rows for all references; per reference the scores of the oracle on the ROUNDED rows, and what single passes give"""
