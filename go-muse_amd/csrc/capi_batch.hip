@@ -363,6 +363,9 @@ extern "C" int muse_batch_score(muse_batch *b)
         return fail(MUSE_ERR_UNSUPPORTED, "float32-storage groups run on the default kernels only (FFT lengths 512 ... 16384)");
     } else if (b->n == 8192 && (ctx->variant == 0 || ctx->variant == 14) && !b->g->f32 && b->xcp) {
         variant = KERNEL_REAL; // one real series per 256-thread workgroup on the n = 4096 kernel's transforms (xcorr_real.hip)
+    } else if (b->n == 16384 && (ctx->variant == 0 || ctx->variant == 14) && !b->g->f32 && ctx->gsmall[3]) {
+        variant = KERNEL_REAL; // one real series per 512-thread workgroup on the 8192-point complex transform, two workgroups per CU
+        p.gsmall = ctx->gsmall[3];
     } else if ((b->n == 32768 || (b->n == 65536 && (b->N == b->n || b->c1))) && (ctx->variant == 0 || ctx->variant == 14) && !b->g->f32 && ctx->gsmall[4]) {
         // one real series per 1024-thread workgroup on the 16384-point complex transform (xcorr_real.hip): n = 32768 never leaves the CU,
         // n = 65536 in two passes with 1 MB parked per series (3 x the algorithmic bytes; the four-step kernel: 5 x)
@@ -475,6 +478,8 @@ extern "C" int muse_batch_kernel_name(muse_batch *b, char *name, int32_t cap)
         snprintf(k, sizeof(k), "xcorr_fused_n4096_fold<false, %s, %s>", padded ? "true" : "false", b->g->f32 ? "true" : "false");
     else if (b->n == 8192 && !b->g->f32)
         snprintf(k, sizeof(k), "xcorr_fused_real8k<%s>", padded ? "true" : "false");
+    else if (b->n == 16384 && !b->g->f32)
+        snprintf(k, sizeof(k), "xcorr_fused_real16k<%s>", padded ? "true" : "false");
     else if ((b->n >= 512 && b->n <= 2048) || b->n == 8192 || b->n == 16384)
         snprintf(k, sizeof(k), "xcorr_fused_small<%d, %s, false%s>", b->logn, padded ? "true" : "false", b->g->f32 ? ", true" : ", false");
     else if (b->n == 32768 || b->n == 65536)

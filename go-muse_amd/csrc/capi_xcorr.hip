@@ -358,10 +358,15 @@ static int xcorr_groups_impl(muse_group *gx, muse_group *gy, int32_t n, int32_t 
         p.cc_out = dcc;
         p.ovf_list = dlist;
         p.ovf_count = dcount;
+        // n = 16384: each series a real transform on the 8192-point machinery, two workgroups per CU (xcorr_real.hip); test hook 12
+        // keeps the pair-packed 16384-point kernel (xcorr_two_sided_small<14>)
+        const bool real16k = p.logn == 14 && ctx->variant != 12 && ctx->gsmall[3];
+        if (real16k)
+            p.gsmall = ctx->gsmall[3];
         LaunchTimer timer(ctx);
         e = timer.begin();
         if (e == hipSuccess)
-            e = launch_two_sided(p, ctx->num_cus, ctx->stream);
+            e = real16k ? launch_two_sided_real(p, ctx->num_cus, ctx->stream) : launch_two_sided(p, ctx->num_cus, ctx->stream);
         if (e == hipSuccess)
             e = timer.end();
     }

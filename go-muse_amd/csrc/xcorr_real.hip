@@ -182,18 +182,22 @@ struct RawPairXC {
 
 } // namespace real
 
+// One real series of n = 2 M samples per workgroup iteration on the M = 2^LM-point complex transform: LM = 14 (n = 32768, 1024 threads,
+// one workgroup per CU) and LM = 13 (n = 16384, 512 threads, 70 KB of LDS: TWO workgroups per CU, one's barriers under the other's
+// arithmetic -- where the pair-packed 16384-point kernel, xcorr_fused_small<14>, has one workgroup of 16 waves per CU in lockstep).
 // PADDED: N < n (leading zero pad, n / 2 < N)
-template <bool PADDED>
-__global__ __launch_bounds__(1024, 4) void xcorr_fused_real32k(const FusedParams p)
+template <int LM, bool PADDED>
+__device__ __forceinline__ void real_one_series(const FusedParams &p)
 {
     using namespace occ4;
     using namespace fold;
     using namespace small;
     using namespace real;
-    constexpr int n = 32768, M = n / 2, LM = 14, S = M / 16; // S = 1024 threads, 16 complex points each
+    constexpr int M = 1 << LM, n = 2 * M, S = M / 16, R1 = LM == 14 ? 4 : 2; // S threads, 16 complex points each
+    static_assert(LM == 13 || LM == 14, "the 8192- and 16384-point transforms of small_device.h");
     __shared__ double red[112];
-    __shared__ double2 g2l[8 * 4];
-    __shared__ double2 xbuf[16 * 544]; // the half buffer of the transposes: 8 S padded points = 139 KB
+    __shared__ double2 g2l[8 * R1];
+    __shared__ double2 xbuf[(S / 64) * 544]; // the half buffer of the transposes: 8 S padded points = 139 KB (LM = 14), 70 KB (LM = 13)
     const int t = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int j = column_of_lane<LM>(t);
@@ -201,10 +205,10 @@ __global__ __launch_bounds__(1024, 4) void xcorr_fused_real32k(const FusedParams
     const int N = PADDED ? p.N : n, pad = PADDED ? n - N : 0;
     const double invN = PADDED ? p.invN : 1.0 / (double)n, invNm1 = PADDED ? p.invNm1 : 1.0 / (double)(n - 1);
     const double2 *__restrict__ twm = p.twm;
-    const double2 *__restrict__ gs = p.gsmall; // the 16384-point transform's lane-ordered pass tables
+    const double2 *__restrict__ gs = p.gsmall; // the M-point transform's lane-ordered pass tables
     const double2 *__restrict__ xc = p.xc;
-    if (t < 8 * 4)
-        g2l[t] = tw_factor<4>(twm, t % 4, t / 4);
+    if (t < 8 * R1)
+        g2l[t] = tw_factor<R1>(twm, t % R1, t / R1);
     __syncthreads();
     const long long total = p.M;
 
@@ -291,10 +295,10 @@ __global__ __launch_bounds__(1024, 4) void xcorr_fused_real32k(const FusedParams
             int jm = j;
             asm volatile("" : "+v"(jm)); // (addresses derived here, not hoisted out of the row loop)
             jm &= S - 1;
-            // W_n^(j + r S) = W_n^j W_32^r: one table entry (W_65536^(2 j)) and seven constant factors; the reference's spectrum at the
-            // two bins of a pair, xc[j + r S] and xc[M - j - r S]
-            const double2 Wj = ldg2u(scalar_ptr(twm), (unsigned)(2 * jm));
-            mirror_stage<0, MUSE_REAL_AHEAD, RawPairXC>(
+            // W_n^(j + r S) = W_n^j W_32^r: one table entry (W_65536^(j 65536 / n)) and seven constant factors; the reference's spectrum
+            // at the two bins of a pair, xc[j + r S] and xc[M - j - r S]
+            const double2 Wj = ldg2u(scalar_ptr(twm), (unsigned)((65536 / n) * jm));
+            mirror_stage<0, MUSE_REAL_AHEAD, RawPairXC, S>(
                 v, b, j, wave, Wj, false,
                 [&](const int r) __attribute__((always_inline)) {
                     return RawPairXC{ldg2u(scalar_ptr_at(xc, r * S), (unsigned)jm), ldg2u(scalar_ptr_at(xc, M - r * S - S), (unsigned)(S - jm))};
@@ -346,6 +350,16 @@ __global__ __launch_bounds__(1024, 4) void xcorr_fused_real32k(const FusedParams
         }
     }
 }
+template <bool PADDED>
+__global__ __launch_bounds__(1024, 4) void xcorr_fused_real32k(const FusedParams p)
+{
+    real_one_series<14, PADDED>(p);
+}
+template <bool PADDED>
+__global__ __launch_bounds__(512, 4) void xcorr_fused_real16k(const FusedParams p)
+{
+    real_one_series<13, PADDED>(p);
+}
 
 // The batched two-sided xCorr (xcorr.go:102-153) at n = 32768 in the same form: pair i = (x_i, y_i), each zero-padded
 // in front on its own (any Nx, Ny <= n), ONE pair per workgroup iteration and three 16384-point transforms per pair:
@@ -356,17 +370,18 @@ __global__ __launch_bounds__(1024, 4) void xcorr_fused_real32k(const FusedParams
 // Every series is centred and scaled to O(1) by an exact power of two on its own before its own transform (two_device.h,
 // pair_scale): no pair has to be listed and redone.  Round 4's four-step kernel (xcorr_two_sided_long<15>) crossed a 512 KB slice
 // four times per pair and read the rows twice (or once, with a redo list): 5 - 6 x the algorithmic bytes; this one 2 x.
-template <bool PADDED>
-__global__ __launch_bounds__(1024, 4) void xcorr_two_sided_real32k(const FusedParams p, const two::PairInv iv)
+template <int LM, bool PADDED>
+__device__ __forceinline__ void real_two_sided(const FusedParams &p, const two::PairInv &iv)
 {
     using namespace occ4;
     using namespace fold;
     using namespace small;
     using namespace real;
-    constexpr int n = 32768, M = n / 2, LM = 14, S = M / 16;
+    constexpr int M = 1 << LM, n = 2 * M, S = M / 16, R1 = LM == 14 ? 4 : 2;
+    static_assert(LM == 13 || LM == 14, "the 8192- and 16384-point transforms of small_device.h");
     __shared__ double red[112];
-    __shared__ double2 g2l[8 * 4];
-    __shared__ double2 xbuf[16 * 544];
+    __shared__ double2 g2l[8 * R1];
+    __shared__ double2 xbuf[(S / 64) * 544];
     const int t = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int j = column_of_lane<LM>(t);
@@ -377,8 +392,8 @@ __global__ __launch_bounds__(1024, 4) void xcorr_two_sided_real32k(const FusedPa
     const double2 *__restrict__ gs = p.gsmall;
     double2 *const park = p.gscratch + (size_t)blockIdx.x * (size_t)M; // the workgroup's slice: ZX in natural bin order
     typedef d2v __attribute__((address_space(1))) *gd2;
-    if (t < 8 * 4)
-        g2l[t] = tw_factor<4>(twm, t % 4, t / 4);
+    if (t < 8 * R1)
+        g2l[t] = tw_factor<R1>(twm, t % R1, t / R1);
     __syncthreads();
     const long long total = p.npairs;
     for (long long pair = blockIdx.x; pair < total; pair += gridDim.x) {
@@ -398,8 +413,11 @@ __global__ __launch_bounds__(1024, 4) void xcorr_two_sided_real32k(const FusedPa
 #pragma unroll
                 for (int k = 0; k < 8; k++) {
                     const int i = 8 * h + k;
-                    const bool all_pad = PADDED && 2 * (i + 1) * S <= pad; // (wave-uniform: pointed at the row's own first samples, an L2 hit)
-                    const long long off = all_pad ? 0ll : 2ll * i * S - pad;
+                    // (wave-uniform: a request inside the pad is pointed at the row's own first samples, an L2 hit -- or, when the series
+                    // is shorter than the 2 S samples such a request spans, at the 2 S samples in FRONT of the row: the allocation's guard
+                    // or earlier rows, never past the end of the group's last row)
+                    const bool all_pad = PADDED && 2 * (i + 1) * S <= pad;
+                    const long long off = all_pad ? (n - pad >= 2 * S ? 0ll : -2ll * S) : 2ll * i * S - pad;
                     typedef d2v __attribute__((aligned(8))) d2u;
                     const d2u s = __builtin_nontemporal_load((gptr<d2u>)scalar_ptr_at(r, off) + (unsigned)jr);
                     s8[k] = d2v{s.x, s.y};
@@ -464,13 +482,13 @@ __global__ __launch_bounds__(1024, 4) void xcorr_two_sided_real32k(const FusedPa
             int jm = j;
             asm volatile("" : "+v"(jm));
             jm &= S - 1;
-            const double2 Wj = ldg2u(scalar_ptr(twm), (unsigned)(2 * jm));
+            const double2 Wj = ldg2u(scalar_ptr(twm), (unsigned)((65536 / n) * jm));
             // the pair's factors: conj of 2 X at the two bins, rebuilt from the parked ZX[k] (own bin) and ZX[(M - k) mod M]
             const auto conj_x = [](const RawPairXC &z, const double2 W) __attribute__((always_inline)) {
                 const TwoBins X = spectrum_pair(z.a, z.b, W);
                 return TwoBins{make_double2(X.k.x, -X.k.y), make_double2(X.m.x, -X.m.y)};
             };
-            mirror_stage<0, MUSE_REAL_AHEAD, RawPairXC>(
+            mirror_stage<0, MUSE_REAL_AHEAD, RawPairXC, S>(
                 v, b, j, wave, Wj, false,
                 [&](const int r) __attribute__((always_inline)) {
                     const d2v zk = *((gd2)scalar_ptr_at(park, r * S) + (unsigned)jm);
@@ -531,18 +549,37 @@ __global__ __launch_bounds__(1024, 4) void xcorr_two_sided_real32k(const FusedPa
         lds_barrier(); // (red is reused by the next pair's statistics)
     }
 }
+template <bool PADDED>
+__global__ __launch_bounds__(1024, 4) void xcorr_two_sided_real32k(const FusedParams p, const two::PairInv iv)
+{
+    real_two_sided<14, PADDED>(p, iv);
+}
+template <bool PADDED>
+__global__ __launch_bounds__(512, 4) void xcorr_two_sided_real16k(const FusedParams p, const two::PairInv iv)
+{
+    real_two_sided<13, PADDED>(p, iv);
+}
 
-// two-sided xCorr, n = 32768 (launch_two_sided's argument checks apply); one M-point slice of p.gscratch per workgroup
+// two-sided xCorr, n = 16384 (p.gsmall: the 8192-point transform's tables) or 32768 (the 16384-point one's); launch_two_sided's argument
+// checks apply; one M-point slice of p.gscratch per workgroup
 hipError_t launch_two_sided_real(const FusedParams &p, int num_cus, hipStream_t stream)
 {
-    if (!p.xrows || !p.rows || !p.twm || !p.gsmall || !p.gscratch || !p.mv || !p.lag || p.n != 32768)
+    if (!p.xrows || !p.rows || !p.twm || !p.gsmall || !p.gscratch || !p.mv || !p.lag || (p.n != 16384 && p.n != 32768) || p.npairs < 1 || p.Nx < 1 ||
+        p.N < 1 || p.Nx > p.n || p.N > p.n || (p.normalize_y && (p.Nx < 2 || p.N < 2)))
         return hipErrorInvalidValue;
     const long long slices = p.gscratch_slices * 2; // (gscratch_slices counts n-point slices; a workgroup parks M = n / 2 points)
-    const long long grid = std::min<long long>(std::min<long long>(p.npairs, (long long)num_cus * 4), slices);
+    const long long resident = p.n == 16384 ? 2 : 1;
+    const long long grid = std::min<long long>(std::min<long long>(p.npairs, (long long)num_cus * resident * 4), slices);
     if (grid < 1)
         return hipErrorInvalidValue;
-    const two::PairInv iv = two::pair_inv(p.Nx, p.N, 32768);
-    if (p.Nx < p.n || p.N < p.n)
+    const two::PairInv iv = two::pair_inv(p.Nx, p.N, p.n);
+    const bool padded = p.Nx < p.n || p.N < p.n;
+    if (p.n == 16384) {
+        if (padded)
+            hipLaunchKernelGGL(xcorr_two_sided_real16k<true>, dim3((unsigned)grid), dim3(512), 0, stream, p, iv);
+        else
+            hipLaunchKernelGGL(xcorr_two_sided_real16k<false>, dim3((unsigned)grid), dim3(512), 0, stream, p, iv);
+    } else if (padded)
         hipLaunchKernelGGL(xcorr_two_sided_real32k<true>, dim3((unsigned)grid), dim3(1024), 0, stream, p, iv);
     else
         hipLaunchKernelGGL(xcorr_two_sided_real32k<false>, dim3((unsigned)grid), dim3(1024), 0, stream, p, iv);
@@ -980,7 +1017,8 @@ hipError_t launch_real8k_tables(const double2 *xc, double2 *out, hipStream_t str
     return hipGetLastError();
 }
 
-// n = 32768, float64 rows, every row (no pair list); N in (n / 2, n]; p.gsmall = the 16384-point transform's tables, p.xc all n bins
+// n = 8192 ... 65536, float64 rows, every row (no pair list); N in (n / 2, n]; p.gsmall = the tables of the complex transform the length runs on
+// (n = 16384: 8192 points; n = 32768, 65536: 16384 points), p.xc all n bins
 hipError_t launch_fused_real(const FusedParams &p_in, int num_cus, hipStream_t stream)
 {
     const FusedParams p = with_reciprocals(p_in);
@@ -994,8 +1032,16 @@ hipError_t launch_fused_real(const FusedParams &p_in, int num_cus, hipStream_t s
             hipLaunchKernelGGL(xcorr_fused_real8k<false>, dim3((unsigned)grid), dim3(256), 0, stream, p);
         return hipGetLastError();
     }
-    if (!p.rows || !p.twm || !p.xc || !p.gsmall || !p.mv || !p.lag || (p.n != 32768 && p.n != 65536) || p.N > p.n || 2 * p.N <= p.n || p.pair_list || p.R > 1)
+    if (!p.rows || !p.twm || !p.xc || !p.gsmall || !p.mv || !p.lag || (p.n != 16384 && p.n != 32768 && p.n != 65536) || p.N > p.n || 2 * p.N <= p.n || p.pair_list || p.R > 1)
         return hipErrorInvalidValue;
+    if (p.n == 16384) { // p.gsmall: the 8192-point transform's tables; two 512-thread workgroups per CU
+        const long long grid = std::min<long long>(p.M, (long long)num_cus * 2 * 8);
+        if (p.N < p.n)
+            hipLaunchKernelGGL(xcorr_fused_real16k<true>, dim3((unsigned)grid), dim3(512), 0, stream, p);
+        else
+            hipLaunchKernelGGL(xcorr_fused_real16k<false>, dim3((unsigned)grid), dim3(512), 0, stream, p);
+        return hipGetLastError();
+    }
     if (p.n == 65536) { // two passes per series: the workgroup's slice of the scratch buffer holds M = n / 2 complex points
         if (!p.gscratch || (p.N < p.n && !p.c1))
             return hipErrorInvalidValue;

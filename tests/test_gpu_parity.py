@@ -769,7 +769,7 @@ def test_stockham_kernels_match_oracle_and_generic(muse, eng, oracle, N):
     try:
         got = {}
         small = db.n <= 2048 or db.n in (8192, 16384)   # lengths the half-round kernel (xcorr_small.hip) is built for
-        variants = ((0, 11, 12, 1) if small else (0, 11, 1)) + ((13,) if db.n >= 16384 else ()) + ((14,) if db.n in (8192, 32768, 65536) else ())
+        variants = ((0, 11, 12, 1) if small else (0, 11, 1)) + ((13,) if db.n >= 16384 else ()) + ((14,) if db.n >= 8192 else ())
         # (13: xcorr_long.hip, 14: xcorr_real.hip -- one REAL series per workgroup: n = 8192 on the 4096-point transform, n = 32768 / 65536
         # on the 16384-point one)
         for variant in variants:
@@ -778,7 +778,7 @@ def test_stockham_kernels_match_oracle_and_generic(muse, eng, oracle, N):
             assert math.isnan(mv[10]) and lag[10] == 0 and math.isnan(mv[12]) and lag[12] == 0, variant
             assert_scores_match(lag, mv, olag, omv, gap)
             got[variant] = (lag, mv)
-        auto = 14 if db.n in (8192, 32768, 65536) else 12 if small else 11      # what automatic selection takes for this length
+        auto = 14 if db.n >= 8192 else 12 if small else 11      # what automatic selection takes for this length
         assert np.array_equal(got[0][0], got[auto][0]) and np.array_equal(got[0][1], got[auto][1], equal_nan=True)
     finally:
         eng.set_kernel(0)
@@ -1967,6 +1967,28 @@ def test_xcorr_batch_matches_oracle(eng, oracle, n, normalize):
         X[5] *= 1e200
         Y[6] *= 1e160
         _check_xcorr_batch(eng, oracle, X, Y, n, normalize)
+
+
+def test_xcorr_batch_16384_both_kernels(eng, oracle):
+    """n = 16384: automatic selection transforms each series as a REAL series on the 8192-point machinery (xcorr_two_sided_real16k,
+    two workgroups per CU); test hook 12 keeps the pair-packed kernel (xcorr_two_sided_small<14>).  Both against the oracle, padded
+    and not, more pairs than one resident set of workgroups."""
+    rng = np.random.default_rng(16384)
+    n, M = 16384, 19
+    for lens in ((n, n), (n - 4099, n), (9000, 12001)):
+        X = rng.normal(size=(M, lens[0])) * rng.uniform(0.1, 30.0, size=(M, 1)) + 2.0
+        Y = rng.normal(size=(M, lens[1])) * 4.0 - 1.0
+        k = min(lens)
+        Y[1, :k] = X[1, :k] * -2.0
+        X[2] = 1.25
+        Y[3, 17] = np.nan
+        for variant in (0, 12):
+            eng.set_kernel(variant)
+            try:
+                for normalize in (True, False):
+                    _check_xcorr_batch(eng, oracle, X, Y, n, normalize)
+            finally:
+                eng.set_kernel(0)
 
 
 @pytest.mark.parametrize("n", [32768, 65536])

@@ -12,6 +12,7 @@ pkg = importlib.import_module("go-muse_amd")
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000
 Ns = [int(a) for a in sys.argv[2:]] or [4096]
 eng = pkg.get_engine(0)
+eng.set_kernel(int(os.environ.get("MUSE_TEST_KERNEL", "0")))  # a test hook (muse_hip_test.h) instead of automatic selection
 for N in Ns:
     rows = max(1024, min(P, (6 << 30) // (8 * N)))
     gx, _ = pkg.DeviceGroup.synthetic(eng, rows, N, seed=0x78636F72)
