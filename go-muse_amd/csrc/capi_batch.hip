@@ -94,6 +94,7 @@ void adopt_spectrum(muse_batch *b)
     b->X = b->sp->X;
     b->xc = b->sp->xc;
     b->xcp = b->sp->xcp;
+    b->xcw = b->sp->xcw;
     b->xcf = b->sp->xcf;
     b->xs = b->sp->xs;
     b->c1 = b->sp->c1;
@@ -149,6 +150,8 @@ extern "C" int muse_batch_create(muse_ctx *ctx, muse_group *g, const double *ref
         e = hipMalloc(&sp->xcp, (size_t)n * sizeof(double2));
     if (e == hipSuccess && n == 8192) // xcorr_fused_real8k: the spectrum at its threads' bins, lane-ordered
         e = hipMalloc(&sp->xcp, (size_t)4096 * sizeof(double2));
+    if (e == hipSuccess && n == 32768) // xcorr_real.hip, the 16 x 1024 split: xc at the threads' lower eight bins and their mirror bins
+        e = hipMalloc(&sp->xcw, (size_t)16384 * sizeof(double2));
     if (e == hipSuccess && (n == 4096 || long_n) && N < n)
         e = hipMalloc(&sp->c1, (size_t)n * sizeof(double));
     if (e != hipSuccess) {
@@ -189,6 +192,8 @@ extern "C" int muse_batch_create(muse_ctx *ctx, muse_group *g, const double *ref
         e = ensure_twl(ctx, n);
         if (e == hipSuccess)
             e = launch_lane_order_rows(b->xc, b->xcp, R1, ctx->stream);
+        if (e == hipSuccess && b->xcw)
+            e = launch_real_split_tables(b->xc, b->xcw, ctx->stream);
         if (e == hipSuccess && b->c1)
             e = launch_indicator_corr(b->xs, (int)n, (int)(n - N), b->c1, ctx->stream);
         if (e == hipSuccess)
@@ -307,6 +312,9 @@ FusedParams base_params(muse_batch *b)
     p.g3b = ctx->g3b;
     p.gsmall = (b->logn >= 9 && b->logn <= 11) ? ctx->gsmall[b->logn - 9] : (b->logn == 13 || b->logn == 14) ? ctx->gsmall[b->logn - 10] : nullptr;
     p.xcp = b->xcp;
+    p.xcw = b->xcw;
+    p.gsmall_b = ctx->gsmall[1];
+    p.wsplit = ctx->wsplit;
     p.c1 = b->c1;
     p.twl = (b->logn >= 14 && b->logn <= 16) ? ctx->twl[b->logn - 14] : nullptr;
     p.tw1f = ctx->tw1f;
@@ -366,6 +374,9 @@ extern "C" int muse_batch_score(muse_batch *b)
     } else if (b->n == 16384 && (ctx->variant == 0 || ctx->variant == 14) && !b->g->f32 && ctx->gsmall[3]) {
         variant = KERNEL_REAL; // one real series per 512-thread workgroup on the 8192-point complex transform, two workgroups per CU
         p.gsmall = ctx->gsmall[3];
+    } else if (b->n == 32768 && ctx->variant == 15 && !b->g->f32 && ctx->gsmall[4] && b->xcw) {
+        variant = KERNEL_REAL_SPLIT; // the same on the 16 x 1024 split of the 16384-point transform (wave-local 1024-point transforms)
+        p.gsmall = ctx->gsmall[4];
     } else if ((b->n == 32768 || (b->n == 65536 && (b->N == b->n || b->c1))) && (ctx->variant == 0 || ctx->variant == 14) && !b->g->f32 && ctx->gsmall[4]) {
         // one real series per 1024-thread workgroup on the 16384-point complex transform (xcorr_real.hip): n = 32768 never leaves the CU,
         // n = 65536 in two passes with 1 MB parked per series (3 x the algorithmic bytes; the four-step kernel: 5 x)
@@ -498,6 +509,7 @@ extern "C" int muse_batch_free(muse_batch *b)
         (void)hipFree(b->sp->X);
         (void)hipFree(b->sp->xc);
         (void)hipFree(b->sp->xcp);
+        (void)hipFree(b->sp->xcw);
         (void)hipFree(b->sp->xcf);
         (void)hipFree(b->sp->xs);
         (void)hipFree(b->sp->c1);

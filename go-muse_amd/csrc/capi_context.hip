@@ -158,6 +158,14 @@ extern "C" int muse_ctx_create(int32_t device, muse_ctx **out)
             HIP_TRY(hipMemcpy(ctx->gsmall[k], gs.data(), gs.size() * sizeof(double2), hipMemcpyHostToDevice));
         }
     }
+    {   // xcorr_real.hip's 16 x 1024 split of the 16384-point transform: the twiddles W_16384^(j k1) behind the register pass
+        std::vector<double2> ws((size_t)15 * 1024);
+        for (int k1 = 1; k1 < 16; k1++)
+            for (int j = 0; j < 1024; j++)
+                fill_twiddle(ws, (size_t)(k1 - 1) * 1024 + j, (long long)j * k1, 16384);
+        HIP_TRY(hipMalloc(&ctx->wsplit, ws.size() * sizeof(double2)));
+        HIP_TRY(hipMemcpy(ctx->wsplit, ws.data(), ws.size() * sizeof(double2), hipMemcpyHostToDevice));
+    }
     std::vector<float2> t1f(t1.size()), t2f(t2.size());
     for (size_t i = 0; i < t1.size(); i++)
         t1f[i] = make_float2((float)t1[i].x, (float)t1[i].y);
@@ -221,6 +229,7 @@ void ctx_release(muse_ctx *ctx)
     (void)hipFree(ctx->g3b);
     for (int k = 0; k < 5; k++)
         (void)hipFree(ctx->gsmall[k]);
+    (void)hipFree(ctx->wsplit);
     for (int k = 0; k < 3; k++)
         (void)hipFree(ctx->twl[k]);
     (void)hipFree(ctx->zscratch);
@@ -272,8 +281,8 @@ extern "C" int muse_ctx_device_info(muse_ctx *ctx, char *name, int32_t name_cap,
 
 extern "C" int muse_ctx_set_kernel(muse_ctx *ctx, int32_t variant)
 {
-    if (!ctx || !(variant == 0 || variant == 1 || variant == 7 || variant == 10 || variant == 11 || variant == 12 || variant == 13 || variant == 14))
-        return fail(MUSE_ERR_INVALID, "bad kernel variant (0 auto, 1 generic, 7 rescaling n=4096, 10 default n=4096, 11 Stockham, 12 half-round, 13 long series, 14 real transform n=32768)");
+    if (!ctx || !(variant == 0 || variant == 1 || variant == 7 || variant == 10 || variant == 11 || variant == 12 || variant == 13 || variant == 14 || variant == 15))
+        return fail(MUSE_ERR_INVALID, "bad kernel variant (0 auto, 1 generic, 7 rescaling n=4096, 10 default n=4096, 11 Stockham, 12 half-round, 13 long series, 14 real transform, 15 real transform on the 16 x 1024 split)");
     ctx->variant = variant;
     return MUSE_OK;
 }

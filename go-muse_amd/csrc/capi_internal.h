@@ -48,6 +48,7 @@ struct muse_ctx {
     double2 *g2 = nullptr, *g3a = nullptr, *g3b = nullptr; // folded-twiddle tables (xcorr_r16_fold.hip)
     double2 *twl[3] = {nullptr, nullptr, nullptr};          // xcorr_long.hip (n = 16384, 32768, 65536): [4096] W_n^(m2), built on first use
     double2 *gsmall[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // the same for xcorr_small.hip: n = 512, 1024, 2048: [8][n/16]; n = 8192: [8][32] + [8][512]; n = 16384: [8][64] + [8][1024]
+    double2 *wsplit = nullptr; // xcorr_real.hip: [15][1024] W_16384^(j k1) (FusedParams::wsplit)
     float2 *tw1f = nullptr, *tw2f = nullptr, *twmf = nullptr; // fp32 copies for the screening kernels
     // many-reference pass (muse_batch_score_many): parked spectra + device pointer tables
     // pinned staging buffers (32 MB each) lent to groups that receive many small appends; allocated once
@@ -121,6 +122,7 @@ struct muse_group {
 struct muse_spectrum {
     std::atomic<int> refs{1};
     double2 *X = nullptr, *xc = nullptr, *xcp = nullptr;
+    double2 *xcw = nullptr; // n == 32768: FusedParams::xcw
     float2 *xcf = nullptr;
     double *xs = nullptr;
     double *c1 = nullptr; // n == 4096, N < 4096: indicator correlation (xcorr_r16_fast.hip, PADDED)
@@ -135,6 +137,7 @@ struct muse_batch {
     double *c1 = nullptr;
     double2 *X = nullptr, *xc = nullptr;
     double2 *xcp = nullptr; // n == 4096: xc in the lane order of xcorr_r16_fast.hip
+    double2 *xcw = nullptr; // n == 32768: FusedParams::xcw (xcorr_real.hip)
     float2 *xcf = nullptr; // fp32 conj(X)/n (screening kernel)
     double *xs = nullptr;  // padded time-domain reference (exact re-evaluation)
     int *ovf_count = nullptr;

@@ -435,6 +435,132 @@ __device__ __forceinline__ void forward(double2 (&v)[16], double2 *b, const doub
         level<S, 16 * R1>(v, b, gs + 8 * 16 * R1, j, rbase, sync); // pass 4 (n = 8192): Ns = 256 R1 = S
 }
 
+// ---- The 16384-point transform as 16 x 1024 (xcorr_real.hip): sixteen waves, each with a 1024-point transform of its OWN
+// (forward<10>: its two transposes stay inside the wave -- no workgroup barrier, the waves drift apart and one wave's LDS phase
+// runs under another's arithmetic) and ONE transpose across the workgroup per transform, where forward<14> has three with four
+// barriers each and every wave of the CU in lockstep (measured on the lockstep kernels: the vector unit busy 0.54 - 0.59 of the
+// time, on the kernels whose transposes are wave-local 0.79 - 0.86: profiles/r05_counters.json).  M = 16384, thread j = 64 w + c
+// (w = wave, c = the lane's column of the 1024-point transform), b = the workgroup's buffer (16 x 544 points: the global transpose
+// uses 16 x 512 of them unpadded -- a wave's 64 lanes store / load 64 consecutive points --, the wave-local transforms 544 each).
+//
+// Decimation in frequency (the FIRST transform of a series: the rows arrive coalesced as z[j + 1024 i]):
+//   Y[k1] = W_M^(j k1) sum_i W_16^(i k1) z[j + 1024 i]        (dft16_nr + fifteen products, wfetch(k1) = W_M^(j k1))
+//   transpose: wave k1 collects Y[k1] of all 1024 threads;  Z[k1 + 16 k2] = FFT_1024 over j of Y[k1][j]
+// out: Z[w + 16 (c + 64 r)] at v[BR16(r)].
+template <typename TW>
+__device__ __forceinline__ void forward_split_dif(double2 (&v)[16], double2 *b, const double2 *g2l, const double2 *__restrict__ gs10,
+                                                  const int j_, const int wave, TW wfetch)
+{
+    int j = j_;
+    asm volatile("" : "+v"(j)); // (addresses derived here, per call)
+    j &= 1023;
+    {
+        double2 ta[5], tb[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+            ta[k] = wfetch(1 + k);
+        fence();
+        dft16_nr(v); // Y[k1] at v[BR16(k1)], before its twiddle
+        fence();
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+            tb[k] = wfetch(6 + k);
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+            v[BR16(1 + k)] = cmul(v[BR16(1 + k)], ta[k]);
+        fence();
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+            ta[k] = wfetch(11 + k);
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+            v[BR16(6 + k)] = cmul(v[BR16(6 + k)], tb[k]);
+        fence();
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+            v[BR16(11 + k)] = cmul(v[BR16(11 + k)], ta[k]);
+    }
+    // the transpose across the workgroup, two half rounds: threads j < 512 (waves 0 - 7) store all sixteen values, everybody
+    // loads eight; then the other half.  Position k1 512 + (j mod 512).
+    const int c = j & 63, wpos = j & 511, rpos = wave * 512 + c;
+    double2 w[16];
+    lds_barrier(); // (the buffer's previous users are done)
+    if (wave < 8) {
+#pragma unroll
+        for (int k1 = 0; k1 < 16; k1++)
+            lds_st2(b + k1 * 512 + wpos, v[BR16(k1)]);
+    }
+    lds_barrier();
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        w[i] = lds_ld2(b + rpos + 64 * i);
+    lds_barrier();
+    if (wave >= 8) {
+#pragma unroll
+        for (int k1 = 0; k1 < 16; k1++)
+            lds_st2(b + k1 * 512 + wpos, v[BR16(k1)]);
+    }
+    lds_barrier();
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        w[8 + i] = lds_ld2(b + rpos + 64 * i);
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+        v[i] = w[i];
+    lds_barrier(); // (every wave has its values: the wave-local buffers lie over the transpose's image)
+    forward<10>(v, b + wave * 544, g2l, gs10, c);
+}
+// Decimation in time (the SECOND transform: its input sits where the first one's output does, v[i] = C[w + 16 (c + 64 i)]):
+//   y[m1][k2] = FFT_1024 over b of C[m1 + 16 b]            (wave m1, forward<10>)
+//   transpose: thread j = k2 collects y[m1][k2], m1 = 0 .. 15
+//   X[1024 k1 + j] = sum_m1 W_16^(m1 k1) W_M^(m1 j) y[m1][j]   (the generalised pass that ends forward<14>: tab = its table, [8][1024])
+// out: X[j + 1024 r] at v[BR16(r)] -- forward<14>'s order.
+__device__ __forceinline__ void forward_split_dit(double2 (&v)[16], double2 *b, const double2 *g2l, const double2 *__restrict__ gs10,
+                                                  const double2 *__restrict__ tab, const int j_, const int wave)
+{
+    int j = j_;
+    asm volatile("" : "+v"(j));
+    j &= 1023;
+    const int c = j & 63, wpos = wave * 512 + c, rpos = j & 511;
+    lds_barrier(); // (the buffer's previous users are done)
+    forward<10>(v, b + wave * 544, g2l, gs10, c); // y[w][c + 64 r] at v[BR16(r)]
+    double2 ga[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) // the last pass's first factors travel during the transpose
+        ga[s] = ldg2u(scalar_ptr_at(tab, s * 1024), (unsigned)j);
+    fence();
+    // two half rounds: every wave stores its registers r < 8 (k2 < 512), the threads j < 512 load their sixteen; then r >= 8
+    lds_barrier(); // (every wave is through with its own buffer)
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+        lds_st2(b + wpos + 64 * r, v[BR16(r)]);
+    lds_barrier();
+    if (wave < 8) {
+        double2 w[16];
+#pragma unroll
+        for (int m = 0; m < 16; m++)
+            w[m] = lds_ld2(b + m * 512 + rpos);
+        lds_barrier();
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+            lds_st2(b + wpos + 64 * r, v[BR16(8 + r)]);
+        lds_barrier();
+#pragma unroll
+        for (int m = 0; m < 16; m++)
+            v[m] = w[m];
+    } else {
+        lds_barrier();
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+            lds_st2(b + wpos + 64 * r, v[BR16(8 + r)]);
+        lds_barrier();
+#pragma unroll
+        for (int m = 0; m < 16; m++)
+            v[m] = lds_ld2(b + m * 512 + rpos);
+    }
+    gpass_pre(v, ga, [&](int s) __attribute__((always_inline)) { return ldg2u(scalar_ptr_at(tab, s * 1024), (unsigned)j); });
+}
+
 // Which column j (elements j + i S) a lane works on.  Any bijection inside a wave is correct -- j is only ever an index --
 // and the choice decides the LDS bank conflicts of the transposes: a ds_read_b128 is served in four groups of sixteen lanes,
 // {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 (MI355X_MICROARCH.md, LDS), i.e. by the parity of lane bits

@@ -8,7 +8,7 @@
 
 namespace muse {
 
-enum { KERNEL_GENERIC = 0, KERNEL_R16_OCC3 = 6, KERNEL_STOCKHAM = 10, KERNEL_R16_FOLD = 11, KERNEL_SMALL = 12, KERNEL_LONG = 13, KERNEL_REAL = 14 };
+enum { KERNEL_GENERIC = 0, KERNEL_R16_OCC3 = 6, KERNEL_STOCKHAM = 10, KERNEL_R16_FOLD = 11, KERNEL_SMALL = 12, KERNEL_LONG = 13, KERNEL_REAL = 14, KERNEL_REAL_SPLIT = 15 };
 
 struct FusedParams {
     const double *rows; // M x N row-major, row stride `stride` elements (float64 groups)
@@ -29,6 +29,10 @@ struct FusedParams {
     const double2 *g3a;  // [8][256] first transform, pass 3: u = (t >> 4) + 16 (t & 15)
     const double2 *g3b;  // [8][256] second transform, pass 3: u = t
     const double2 *gsmall; // [8][n/16] xcorr_small.hip (n = 512, 1024, 2048): last-pass factors, delta = j / (n/16), lane-ordered
+    // xcorr_real.hip, the 16384-point transform as 16 x 1024 (wave-local 1024-point transforms around ONE workgroup transpose):
+    const double2 *gsmall_b; // [8][64]: the 1024-point transform's last-pass factors (the context's table for n = 1024)
+    const double2 *wsplit;   // [15][1024] W_16384^(j k1), k1 = 1 .. 15: the twiddles between the register pass and the wave-local transforms
+    const double2 *xcw;      // [2][8][1024] xc at the bins of a thread's lower eight registers, k = w + 16 c + 1024 r (j = 64 w + c), and at M - k
     const double2 *twl;  // [4096] W_n^(m2): the base of the sweeps' twiddles W_n^(m2 k1) of the long-series kernel (xcorr_long.hip forms the powers)
     const double *c1;    // [n] (n = 4096 and the long-series kernel) N < n: correlation of the valid-sample indicator with the reference (xcorr_r16_fold.hip)
     // many references in one pass (xcorr_fused_n4096_multi): device arrays of R pointers
@@ -96,8 +100,10 @@ hipError_t launch_fused_multi(const FusedParams &p, int num_cus, hipStream_t str
 hipError_t launch_fused_small(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_small.hip (n = 512, 1024, 2048: default)
 hipError_t launch_fused_stockham(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_stockham.hip (n = 512 .. 2048, 8192 .. 65536)
 hipError_t launch_fused_long(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_long.hip (n = 65536: default; 16384, 32768)
+hipError_t launch_real_split_tables(const double2 *xc, double2 *out, hipStream_t stream); // xcorr_real.hip: FusedParams::xcw for n = 32768
 hipError_t launch_real8k_tables(const double2 *xc, double2 *out, hipStream_t stream); // xcorr_real.hip: n = 8192, xc at the threads' bins, lane-ordered ([16][256])
 hipError_t launch_two_sided_real(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_real.hip: the two-sided xCorr at n = 32768
+hipError_t launch_fused_real_split(const FusedParams &p, int num_cus, hipStream_t stream); // the same, the 16384-point transform as 16 x 1024 (test hook 15)
 hipError_t launch_fused_real(const FusedParams &p, int num_cus, hipStream_t stream); // xcorr_real.hip (n = 32768: one real series per workgroup on the 16384-point transform)
 hipError_t launch_two_sided(const FusedParams &p, int num_cus, hipStream_t stream);
 // the same for n = 512 ... 2048, 8192, 16384 on xcorr_small.hip's transforms (called by launch_two_sided)

@@ -470,6 +470,8 @@ hipError_t launch_fused(const FusedParams &p, int variant, int num_cus, hipStrea
         return launch_fused_long(p, num_cus, stream);
     if (variant == KERNEL_REAL)
         return launch_fused_real(p, num_cus, stream);
+    if (variant == KERNEL_REAL_SPLIT)
+        return launch_fused_real_split(p, num_cus, stream);
     if (variant == KERNEL_STOCKHAM)
         return launch_fused_stockham(p, num_cus, stream);
     if (variant == KERNEL_R16_OCC3)

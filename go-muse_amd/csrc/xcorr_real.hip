@@ -51,6 +51,11 @@
 #ifndef MUSE_REAL_WIDE
 #define MUSE_REAL_WIDE 1
 #endif
+// timing ablations (results are WRONG with any bit set; tools/ablate/ab_real_phases.sh): 1 no row requests inside the loop, 2 no mirror
+// stage, 4 no second transform, 8 no first transform, 16 no statistics reduction
+#ifndef MUSE_REAL_ABL
+#define MUSE_REAL_ABL 0
+#endif
 
 namespace muse {
 
@@ -165,6 +170,68 @@ __device__ __forceinline__ void mirror_stage(double2 (&v)[16], double2 *b, const
         v[BR16(8)] = make_double2(mine ? c8.x : v[BR16(8)].x, mine ? c8.y : v[BR16(8)].y);
     }
 }
+// The same stage on the output of small::forward_split_dif (M = 16384 as 16 x 1024): thread j = 64 w + c holds bin w + 16 (c + 64 r) at
+// v[BR16(r)].  Bin k's mirror M - k sits in wave (16 - w) mod 16: for w >= 1 at column 63 - c, register 15 - r (MODE 1 above, across two
+// waves; wave 8 pairs inside itself); wave 0 pairs inside itself like MODE 0 with S = 64 (column 64 - c, register 15 - r; column 0: r with
+// 16 - r, bin 0 with the Nyquist bin, bin M / 2 with itself).  Which of the two a wave does is a scalar; the buffer is addressed as sixteen
+// wave images of eight slots x 68 (the wave-local transforms' padding).  W(r) = W_n^(w + 16 c) W_32^r.
+template <int AHEAD, typename RAW, typename REQ, typename FAC, typename NINTH>
+__device__ __forceinline__ void mirror_stage_split(double2 (&v)[16], double2 *b, const int j_, const int wave, const double2 Wj, const bool dc0,
+                                                   REQ req, FAC fac, NINTH ninth)
+{
+    constexpr int PK = 68, WR = 8 * PK;
+    int jm = j_;
+    asm volatile("" : "+v"(jm)); // (addresses derived here, not hoisted out of the row loop)
+    jm &= 63;
+    const bool wave0 = wave == 0;
+    const bool col0 = wave0 && jm == 0;
+    const int cm = wave0 ? ((64 - jm) & 63) : (63 - jm); // the partner's column (wave 0, column 0: itself)
+    const int pw = (16 - wave) & 15;                     // the partner's wave
+    const int wbase = wave * WR + jm + (jm >> 4);
+    const int rbase = pw * WR + cm + (cm >> 4);
+    const int rbm = rbase + (col0 ? PK : 0);
+    lds_barrier(); // (the transform's last readers of the buffer are done)
+#pragma unroll
+    for (int s = 0; s < 8; s++)
+        lds_st2(b + wbase + s * PK, v[BR16(8 + s)]);
+    RAW raw[8];
+#pragma unroll
+    for (int r = 0; r < AHEAD; r++)
+        raw[r] = req(r);
+    const double2 v8 = v[BR16(8)];
+    lds_barrier();
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        fence();
+        if (r + AHEAD < 8)
+            raw[r + AHEAD] = req(r + AHEAD);
+        double2 *const slot = b + (r == 0 ? rbase + 7 * PK : rbm + (7 - r) * PK);
+        double2 zm = lds_ld2(slot);
+        if (r == 0) { // (component by component: see mirror_stage)
+            zm.x = col0 ? v[BR16(0)].x : zm.x;
+            zm.y = col0 ? v[BR16(0)].y : zm.y;
+        }
+        fence();
+        const double2 W = r == 0 ? Wj : cmul(Wj, w32(r));
+        TwoBins f = fac(raw[r], W);
+        if (r == 0) {
+            f.k.x = (dc0 && col0) ? 0.0 : f.k.x;
+            f.k.y = (dc0 && col0) ? 0.0 : f.k.y;
+        }
+        const TwoBins o = mirror_pair(v[BR16(r)], zm, W, f.k, f.m);
+        v[BR16(r)] = o.k;
+        if (r > 0 || !col0)
+            lds_st2(slot, o.m);
+    }
+    double2 c8 = make_double2(0.0, 0.0);
+    if (wave == 0)
+        c8 = ninth(v8);
+    lds_barrier(); // (every partner has written back)
+#pragma unroll
+    for (int s = 0; s < 8; s++)
+        v[BR16(8 + s)] = lds_ld2(b + wbase + s * PK);
+    v[BR16(8)] = make_double2(col0 ? c8.x : v[BR16(8)].x, col0 ? c8.y : v[BR16(8)].y);
+}
 // v[BR16(r)] -> v[r]: the natural order the next transform takes its input in
 __device__ __forceinline__ void natural_order(double2 (&v)[16])
 {
@@ -186,7 +253,8 @@ struct RawPairXC {
 // one workgroup per CU) and LM = 13 (n = 16384, 512 threads, 70 KB of LDS: TWO workgroups per CU, one's barriers under the other's
 // arithmetic -- where the pair-packed 16384-point kernel, xcorr_fused_small<14>, has one workgroup of 16 waves per CU in lockstep).
 // PADDED: N < n (leading zero pad, n / 2 < N)
-template <int LM, bool PADDED>
+// SPLIT (LM = 14): the transforms as 16 x 1024 (small::forward_split_dif / _dit: two of a transform's three transposes inside a wave)
+template <int LM, bool PADDED, bool SPLIT = false>
 __device__ __forceinline__ void real_one_series(const FusedParams &p)
 {
     using namespace occ4;
@@ -195,12 +263,13 @@ __device__ __forceinline__ void real_one_series(const FusedParams &p)
     using namespace real;
     constexpr int M = 1 << LM, n = 2 * M, S = M / 16, R1 = LM == 14 ? 4 : 2; // S threads, 16 complex points each
     static_assert(LM == 13 || LM == 14, "the 8192- and 16384-point transforms of small_device.h");
+    static_assert(!SPLIT || LM == 14, "the split is built for 16384 = 16 x 1024");
     __shared__ double red[112];
     __shared__ double2 g2l[8 * R1];
     __shared__ double2 xbuf[(S / 64) * 544]; // the half buffer of the transposes: 8 S padded points = 139 KB (LM = 14), 70 KB (LM = 13)
     const int t = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int j = column_of_lane<LM>(t);
+    const int j = SPLIT ? column_of_lane<10>(t) : column_of_lane<LM>(t); // (SPLIT: j = 64 wave + the lane's column of the 1024-point transform)
     double2 *const b = xbuf;
     const int N = PADDED ? p.N : n, pad = PADDED ? n - N : 0;
     const double invN = PADDED ? p.invN : 1.0 / (double)n, invNm1 = PADDED ? p.invNm1 : 1.0 / (double)(n - 1);
@@ -271,7 +340,8 @@ __device__ __forceinline__ void real_one_series(const FusedParams &p)
             q2 += d1;
             q3 = fma(d1, d1, q3);
         }
-        pair_sum4<S>(q0, q1, q2, q3, red, wave);
+        if (!(MUSE_REAL_ABL & 16))
+            pair_sum4<S>(q0, q1, q2, q3, red, wave);
         bool zero, nan;
         const double var0 = variance(Stat{q0 + q2, q1 + q3}, invN, invNm1, zero, nan);
         const bool dead = zero || nan;
@@ -288,7 +358,38 @@ __device__ __forceinline__ void real_one_series(const FusedParams &p)
             v[i].x = (v0 && !dead) ? fma(v[i].x, sc, -mean) : 0.0;
             v[i].y = (v1 && !dead) ? fma(v[i].y, sc, -mean) : 0.0;
         }
+        if constexpr (SPLIT) {
+            // ---- Z = FFT_M(z): Z[w + 16 (c + 64 r)] at v[BR16(r)], j = 64 w + c
+            int jm = j;
+            asm volatile("" : "+v"(jm));
+            jm &= S - 1;
+            const double2 *__restrict__ ws = p.wsplit;
+            if (!(MUSE_REAL_ABL & 8))
+            forward_split_dif(v, b, g2l, p.gsmall_b, j, wave,
+                              [&](const int k1) __attribute__((always_inline)) { return ldg2u(scalar_ptr_at(ws, (k1 - 1) * 1024), (unsigned)jm); });
+            // ---- mirror pairs in that order; the reference's spectrum at the thread's bins and their mirrors from FusedParams::xcw
+            asm volatile("" : "+v"(jm));
+            jm &= S - 1;
+            const double2 *__restrict__ xw = p.xcw;
+            const double2 Wj = ldg2u(scalar_ptr(twm), (unsigned)(2 * ((jm >> 6) + 16 * (jm & 63)))); // W_n^(w + 16 c)
+            if (!(MUSE_REAL_ABL & 2))
+            mirror_stage_split<MUSE_REAL_AHEAD, RawPairXC>(
+                v, b, j, wave, Wj, false,
+                [&](const int r) __attribute__((always_inline)) {
+                    return RawPairXC{ldg2u(scalar_ptr_at(xw, r * 1024), (unsigned)jm), ldg2u(scalar_ptr_at(xw, 8192 + r * 1024), (unsigned)jm)};
+                },
+                [&](const RawPairXC &x, const double2) __attribute__((always_inline)) { return TwoBins{x.a, x.b}; },
+                [&](const double2 v8) __attribute__((always_inline)) { // bin M / 2 pairs with itself, W = -i
+                    const double2 xh = ldg2u(scalar_ptr_at(xc, M / 2), 0u);
+                    return mirror_pair(v8, v8, make_double2(0.0, -1.0), xh, xh).k;
+                });
+            natural_order(v);
+            // ---- c = FFT_M(C): 2 cc[2m] + 2 i cc[2m+1] with m = j + r S at v[BR16(r)]
+            if (!(MUSE_REAL_ABL & 4))
+            forward_split_dit(v, b, g2l, p.gsmall_b, gs + 8 * 16 * R1, j, wave);
+        } else {
         // ---- Z = FFT_M(z): Z[j + r S] at v[BR16(r)]
+        if (!(MUSE_REAL_ABL & 8))
         forward<LM>(v, b, g2l, gs, j);
         // ---- mirror pairs: Y, the product with the reference's spectrum, re-tangled for the second transform (mirror_stage above)
         {
@@ -298,6 +399,7 @@ __device__ __forceinline__ void real_one_series(const FusedParams &p)
             // W_n^(j + r S) = W_n^j W_32^r: one table entry (W_65536^(j 65536 / n)) and seven constant factors; the reference's spectrum
             // at the two bins of a pair, xc[j + r S] and xc[M - j - r S]
             const double2 Wj = ldg2u(scalar_ptr(twm), (unsigned)((65536 / n) * jm));
+            if (!(MUSE_REAL_ABL & 2))
             mirror_stage<0, MUSE_REAL_AHEAD, RawPairXC, S>(
                 v, b, j, wave, Wj, false,
                 [&](const int r) __attribute__((always_inline)) {
@@ -311,7 +413,9 @@ __device__ __forceinline__ void real_one_series(const FusedParams &p)
         }
         natural_order(v); // (2 C[j + r S] sits at v[BR16(r)]; the transform takes its input in natural order)
         // ---- c = FFT_M(C): 2 cc[2m] + 2 i cc[2m+1] with m = j + r S at v[BR16(r)]
+        if (!(MUSE_REAL_ABL & 4))
         forward<LM>(v, b, g2l, gs, j);
+        }
         // ---- maxAbsIndex (xcorr.go:39-50): ascending r, real part before imaginary part = ascending lag index for this thread
         double sv = 0.0;
         int code = 0;
@@ -329,7 +433,8 @@ __device__ __forceinline__ void real_one_series(const FusedParams &p)
         const int ia = 2 * (j + (code >> 1) * S) + (code & 1);
         const double cc0 = v[0].x; // (column 0: cc[0], reported when nothing is above 0)
         fence();
-        request(row + gridDim.x); // the next row: in flight during the reductions and the result write-out
+        if (!(MUSE_REAL_ABL & 1))
+            request(row + gridDim.x); // the next row: in flight during the reductions and the result write-out
         fence();
         double pa = ma, pb = 0.0;
         pair_max2<S>(pa, pb, red, wave);
@@ -359,6 +464,11 @@ template <bool PADDED>
 __global__ __launch_bounds__(512, 4) void xcorr_fused_real16k(const FusedParams p)
 {
     real_one_series<13, PADDED>(p);
+}
+template <bool PADDED>
+__global__ __launch_bounds__(1024, 4) void xcorr_fused_real32k_split(const FusedParams p)
+{
+    real_one_series<14, PADDED, true>(p);
 }
 
 // The batched two-sided xCorr (xcorr.go:102-153) at n = 32768 in the same form: pair i = (x_i, y_i), each zero-padded
@@ -1011,6 +1121,20 @@ __global__ void real8k_tables_kernel(const double2 *__restrict__ xc, double2 *__
     out[r * 256 + t] = xc[c + 256 * r];
     out[(8 + r) * 256 + t] = xc[4096 - c - 256 * r];
 }
+// FusedParams::xcw (n = 32768 on the 16 x 1024 split): out[r 1024 + j] = xc[k], out[8192 + r 1024 + j] = xc[16384 - k],
+// k = (j >> 6) + 16 (j & 63) + 1024 r, r < 8 -- the bins of thread j's lower eight registers and their mirror bins, one coalesced row per r
+__global__ void real_split_tables_kernel(const double2 *__restrict__ xc, double2 *__restrict__ out)
+{
+    const int r = blockIdx.x, j = threadIdx.x;
+    const int k = (j >> 6) + 16 * (j & 63) + 1024 * r;
+    out[r * 1024 + j] = xc[k];
+    out[8192 + r * 1024 + j] = xc[16384 - k];
+}
+hipError_t launch_real_split_tables(const double2 *xc, double2 *out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(real_split_tables_kernel, dim3(8), dim3(1024), 0, stream, xc, out);
+    return hipGetLastError();
+}
 hipError_t launch_real8k_tables(const double2 *xc, double2 *out, hipStream_t stream)
 {
     hipLaunchKernelGGL(real8k_tables_kernel, dim3(8), dim3(256), 0, stream, xc, out);
@@ -1059,6 +1183,21 @@ hipError_t launch_fused_real(const FusedParams &p_in, int num_cus, hipStream_t s
         hipLaunchKernelGGL(xcorr_fused_real32k<true>, dim3((unsigned)grid), dim3(1024), 0, stream, p);
     else
         hipLaunchKernelGGL(xcorr_fused_real32k<false>, dim3((unsigned)grid), dim3(1024), 0, stream, p);
+    return hipGetLastError();
+}
+
+// n = 32768 with the 16384-point transforms as 16 x 1024 (launch_fused_real's conditions; p.gsmall_b, p.wsplit, p.xcw as FusedParams says)
+hipError_t launch_fused_real_split(const FusedParams &p_in, int num_cus, hipStream_t stream)
+{
+    const FusedParams p = with_reciprocals(p_in);
+    if (!p.rows || !p.twm || !p.xc || !p.gsmall || !p.gsmall_b || !p.wsplit || !p.xcw || !p.mv || !p.lag || p.n != 32768 || p.N > p.n || 2 * p.N <= p.n ||
+        p.pair_list || p.R > 1)
+        return hipErrorInvalidValue;
+    const long long grid = std::min<long long>(p.M, (long long)num_cus * 8);
+    if (p.N < p.n)
+        hipLaunchKernelGGL(xcorr_fused_real32k_split<true>, dim3((unsigned)grid), dim3(1024), 0, stream, p);
+    else
+        hipLaunchKernelGGL(xcorr_fused_real32k_split<false>, dim3((unsigned)grid), dim3(1024), 0, stream, p);
     return hipGetLastError();
 }
 

@@ -769,7 +769,7 @@ def test_stockham_kernels_match_oracle_and_generic(muse, eng, oracle, N):
     try:
         got = {}
         small = db.n <= 2048 or db.n in (8192, 16384)   # lengths the half-round kernel (xcorr_small.hip) is built for
-        variants = ((0, 11, 12, 1) if small else (0, 11, 1)) + ((13,) if db.n >= 16384 else ()) + ((14,) if db.n >= 8192 else ())
+        variants = ((0, 11, 12, 1) if small else (0, 11, 1)) + ((13,) if db.n >= 16384 else ()) + ((14,) if db.n >= 8192 else ()) + ((15,) if db.n == 32768 else ())
         # (13: xcorr_long.hip, 14: xcorr_real.hip -- one REAL series per workgroup: n = 8192 on the 4096-point transform, n = 32768 / 65536
         # on the 16384-point one)
         for variant in variants:
