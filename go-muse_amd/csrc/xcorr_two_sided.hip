@@ -83,63 +83,55 @@ __global__ __launch_bounds__(256, 4) void xcorr_two_sided_fold(const FusedParams
         }
     };
 
-    // position e = t + 256 i of the padded arrays holds y[e - pady] and x[(-e mod n) - padx] (leading zero pads, xcorr.go:129-130).
-    // A pair's 32 samples per lane are REQUESTED behind the previous pair's second transform (its values are in the wave records by
-    // then, the registers free) and travel during the write-out and the loop's back edge: requested at the top of the iteration, in
-    // four batches, every pair paid four exposed round trips to memory (3.8 us of its 22 -- profiles/r05_sizes.txt).
-    double xa[16], yb[16], KA = 0.0, KB = 0.0; // (plain doubles: xcorr_real.hip's note on arrays filled under a branch)
-    const auto request = [&](long long q) __attribute__((always_inline)) {
-        if (q >= p.npairs)
-            q = p.npairs - 1; // (nothing left: an L2-hot dummy)
-        const double *const rx = p.xrows + q * p.xstride, *const ry = p.rows + q * p.stride;
-        typedef const double __attribute__((address_space(4))) *cptr; // the shift constants through the scalar cache
-        if (normalize) {
-            KA = *(cptr)(unsigned long long)rx;
-            KB = *(cptr)(unsigned long long)ry;
-        }
-        int tb = t;
-        asm volatile("" : "+v"(tb)); // (offsets formed per request, not hoisted out of the pair loop)
-        tb &= 255;
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            if (PADDED) {
-                const int e = tb + 256 * i;
-                const int ex = ((n - e) & (n - 1)) - padx, ey = e - pady;
-                xa[i] = __builtin_nontemporal_load(scalar_ptr(rx) + (unsigned)(ex < 0 ? 0 : ex));
-                yb[i] = __builtin_nontemporal_load(scalar_ptr(ry) + (unsigned)(ey < 0 ? 0 : ey));
-            } else {
-                // y[t + 256 i]; x[4096 - 256 i - t] = x[256 (15 - i) + (256 - t)] for i >= 1; position 0 reads x[0]
-                if (i == 0)
-                    xa[i] = __builtin_nontemporal_load(scalar_ptr(rx) + (tb == 0 ? 0u : (unsigned)(4096 - tb)));
-                else
-                    xa[i] = __builtin_nontemporal_load(scalar_ptr_at(rx, 256 * (15 - i)) + (unsigned)(256 - tb));
-                yb[i] = __builtin_nontemporal_load(scalar_ptr_at(ry, 256 * i) + (unsigned)tb);
-            }
-        }
-    };
     long long pair = blockIdx.x;
-    if (pair < p.npairs)
-        request(pair);
     for (; pair < p.npairs; pair += gridDim.x) {
         double2 v[16];
         {
+            const double *const rx = p.xrows + pair * p.xstride, *const ry = p.rows + pair * p.stride;
+            typedef const double __attribute__((address_space(4))) *cptr; // the shift constants through the scalar cache
+            const double KA = normalize ? *(cptr)(unsigned long long)rx : 0.0, KB = normalize ? *(cptr)(unsigned long long)ry : 0.0;
             double q[4] = {0.0, 0.0, 0.0, 0.0};
-            int tb = t;
-            if (PADDED)
-                asm volatile("" : "+v"(tb)); // (the masks are formed here, not kept across the loop)
+            // position e = t + 256 i of the padded arrays holds y[e - pady] and x[(-e mod n) - padx] (leading zero pads,
+            // xcorr.go:129-130); four batches of four positions bound the registers in flight
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                double da = xa[i] - KA, db = yb[i] - KB;
-                if (PADDED) {
-                    const int e = tb + 256 * i;
-                    da = ((n - e) & (n - 1)) - padx >= 0 ? da : 0.0;
-                    db = e - pady >= 0 ? db : 0.0;
+            for (int h = 0; h < 4; h++) {
+                double xa[4], yb[4];
+                int tb = t;
+                if (PADDED)
+                    asm volatile("" : "+v"(tb)); // (a batch's offsets and masks are formed in the batch, not hoisted in front of all four)
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int i = 4 * h + k;
+                    if (PADDED) {
+                        const int e = tb + 256 * i;
+                        const int ex = ((n - e) & (n - 1)) - padx, ey = e - pady;
+                        xa[k] = __builtin_nontemporal_load(scalar_ptr(rx) + (unsigned)(ex < 0 ? 0 : ex));
+                        yb[k] = __builtin_nontemporal_load(scalar_ptr(ry) + (unsigned)(ey < 0 ? 0 : ey));
+                    } else {
+                        // y[t + 256 i]; x[4096 - 256 i - t] = x[256 (15 - i) + (256 - t)] for i >= 1; position 0 reads x[0]
+                        if (i == 0)
+                            xa[k] = __builtin_nontemporal_load(scalar_ptr(rx) + (t == 0 ? 0u : (unsigned)(4096 - t)));
+                        else
+                            xa[k] = __builtin_nontemporal_load(scalar_ptr_at(rx, 256 * (15 - i)) + (unsigned)(256 - t));
+                        yb[k] = __builtin_nontemporal_load(scalar_ptr_at(ry, 256 * i) + (unsigned)t);
+                    }
                 }
-                v[i] = make_double2(da, db);
-                q[0] += da;
-                q[1] = fma(da, da, q[1]);
-                q[2] += db;
-                q[3] = fma(db, db, q[3]);
+                fence();
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int i = 4 * h + k;
+                    double da = xa[k] - KA, db = yb[k] - KB;
+                    if (PADDED) {
+                        const int e = tb + 256 * i;
+                        da = ((n - e) & (n - 1)) - padx >= 0 ? da : 0.0;
+                        db = e - pady >= 0 ? db : 0.0;
+                    }
+                    v[i] = make_double2(da, db);
+                    q[0] += da;
+                    q[1] = fma(da, da, q[1]);
+                    q[2] += db;
+                    q[3] = fma(db, db, q[3]);
+                }
             }
 #pragma unroll
             for (int k = 0; k < 4; k++)
@@ -205,9 +197,6 @@ __global__ __launch_bounds__(256, 4) void xcorr_two_sided_fold(const FusedParams
         if (t == 0)
             arg[parity][12] = v[0].y;
         parity ^= 1;
-        fence();
-        request(pair + gridDim.x); // the next pair's rows: in flight across the back edge
-        fence();
     }
     lds_barrier();
     finish_prev(pair - gridDim.x);

@@ -9,6 +9,9 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 pkg = importlib.import_module("go-muse_amd")
+if os.environ.get("MUSE_AB_LIB"):  # another build of the library (an A/B on one box: boxes differ by several per cent)
+    pkg.build.LIB = os.path.abspath(os.environ["MUSE_AB_LIB"])
+    pkg.build.stale = lambda: False
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000
 Ns = [int(a) for a in sys.argv[2:]] or [4096]
 eng = pkg.get_engine(0)
@@ -18,11 +21,12 @@ for N in Ns:
     gx, _ = pkg.DeviceGroup.synthetic(eng, rows, N, seed=0x78636F72)
     gy, _ = pkg.DeviceGroup.synthetic(eng, rows, N, seed=0x6D757365)
     for normalize in (True, False):
-        pkg.xcorr_groups(gx, gy, N, normalize)
+        for _ in range(8):  # (past the clock ramp: the first launches of a process run at a boost clock the part does not hold)
+            pkg.xcorr_groups(gx, gy, N, normalize)
         eng.synchronize()
         eng.kernel_time()
         eng.kernel_timing(True)
-        for _ in range(3):
+        for _ in range(8):
             pkg.xcorr_groups(gx, gy, N, normalize)
         eng.synchronize()
         eng.kernel_timing(False)
