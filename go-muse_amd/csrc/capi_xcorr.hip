@@ -358,10 +358,10 @@ static int xcorr_groups_impl(muse_group *gx, muse_group *gy, int32_t n, int32_t 
         p.cc_out = dcc;
         p.ovf_list = dlist;
         p.ovf_count = dcount;
-        // n = 16384: each series a real transform on the 8192-point machinery, two workgroups per CU (xcorr_real.hip); test hook 12
-        // keeps the pair-packed 16384-point kernel (xcorr_two_sided_small<14>)
-        const bool real16k = p.logn == 14 && ctx->variant != 12 && ctx->gsmall[3];
-        if (real16k)
+        // n = 8192, 16384: each series a real transform on the 4096- / 8192-point machinery (xcorr_real.hip); test hook 12 keeps the
+        // pair-packed kernels (xcorr_two_sided_small<13 / 14>)
+        const bool real16k = (p.logn == 14 && ctx->variant != 12 && ctx->gsmall[3]) || (p.logn == 13 && ctx->variant != 12); // (and n = 8192: on the n = 4096 kernel's)
+        if (real16k && p.logn == 14)
             p.gsmall = ctx->gsmall[3];
         LaunchTimer timer(ctx);
         e = timer.begin();

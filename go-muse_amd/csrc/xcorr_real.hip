@@ -670,14 +670,33 @@ __global__ __launch_bounds__(512, 4) void xcorr_two_sided_real16k(const FusedPar
     real_two_sided<13, PADDED>(p, iv);
 }
 
-// two-sided xCorr, n = 16384 (p.gsmall: the 8192-point transform's tables) or 32768 (the 16384-point one's); launch_two_sided's argument
+template <bool PADDED>
+__global__ void xcorr_two_sided_real8k(const FusedParams p, const two::PairInv iv); // (below, beside xcorr_fused_real8k)
+
+// two-sided xCorr, n = 8192 (the n = 4096 kernel's tables: p.g2, p.g3a, p.g3b), 16384 (p.gsmall: the 8192-point transform's tables) or 32768
+// (the 16384-point one's); launch_two_sided's argument
 // checks apply; one M-point slice of p.gscratch per workgroup
 hipError_t launch_two_sided_real(const FusedParams &p, int num_cus, hipStream_t stream)
 {
-    if (!p.xrows || !p.rows || !p.twm || !p.gsmall || !p.gscratch || !p.mv || !p.lag || (p.n != 16384 && p.n != 32768) || p.npairs < 1 || p.Nx < 1 ||
+    if (!p.xrows || !p.rows || !p.twm || !p.gscratch || !p.mv || !p.lag || (p.n != 8192 && p.n != 16384 && p.n != 32768) || p.npairs < 1 || p.Nx < 1 ||
         p.N < 1 || p.Nx > p.n || p.N > p.n || (p.normalize_y && (p.Nx < 2 || p.N < 2)))
         return hipErrorInvalidValue;
     const long long slices = p.gscratch_slices * 2; // (gscratch_slices counts n-point slices; a workgroup parks M = n / 2 points)
+    if (p.n == 8192) { // on the n = 4096 kernel's transforms, four 256-thread workgroups per CU
+        if (!p.g2 || !p.g3a || !p.g3b)
+            return hipErrorInvalidValue;
+        const long long grid = std::min<long long>(std::min<long long>(p.npairs, (long long)num_cus * 8), slices);
+        if (grid < 1)
+            return hipErrorInvalidValue;
+        const two::PairInv iv = two::pair_inv(p.Nx, p.N, p.n);
+        if (p.Nx < p.n || p.N < p.n)
+            hipLaunchKernelGGL(xcorr_two_sided_real8k<true>, dim3((unsigned)grid), dim3(256), 0, stream, p, iv);
+        else
+            hipLaunchKernelGGL(xcorr_two_sided_real8k<false>, dim3((unsigned)grid), dim3(256), 0, stream, p, iv);
+        return hipGetLastError();
+    }
+    if (!p.gsmall)
+        return hipErrorInvalidValue;
     const long long resident = p.n == 16384 ? 2 : 1;
     const long long grid = std::min<long long>(std::min<long long>(p.npairs, (long long)num_cus * resident * 4), slices);
     if (grid < 1)
@@ -1112,6 +1131,216 @@ __global__ __launch_bounds__(256, 4) void xcorr_fused_real8k(const FusedParams p
         }
     }
 }
+// The batched two-sided xCorr at n = 8192 in the form of real_two_sided above, on the n = 4096 kernel's transforms: pair i = (x_i, y_i),
+// each zero-padded in front on its own, ONE pair per 256-thread workgroup iteration (four workgroups per CU) and three 4096-point
+// transforms per pair where the pair-packed kernel (xcorr_two_sided_small<13>: 512 threads, four passes) runs two of 8192 points:
+// per lane 2 200 vector instructions and 7 x 32 LDS operations in 4 waves against 1 400 and 6 x 32 in 8.  ZX is parked in the
+// workgroup's slice of the scratch buffer in THREAD order -- park[256 k3 + t] = ZX[c(t) + 256 k3], c(t) = (t >> 4) + 16 (t & 15) the
+// thread's column: coalesced stores, coalesced loads of a thread's own bins; the mirror bin (M - k) mod M = c' + 256 k3' sits at
+// 256 k3' + tcol(c'), tcol(c) = 16 (c & 15) + (c >> 4): sixteen lanes of one hi read sixteen consecutive entries backwards.
+template <bool PADDED>
+__global__ __launch_bounds__(256, 4) void xcorr_two_sided_real8k(const FusedParams p, const two::PairInv iv)
+{
+    using namespace occ4;
+    using namespace fold;
+    using namespace foldk;
+    using namespace real;
+    constexpr int n = 8192, M = n / 2, S = 256;
+    __shared__ double2 xbuf[OCC_XBUF];
+    __shared__ double2 g2s[128];
+    __shared__ double red[24];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    double2 *const xw = xbuf + XW * wave;
+    const int padx = PADDED ? n - p.Nx : 0, pady = PADDED ? n - p.N : 0;
+    const bool normalize = p.normalize_y != 0;
+    const double2 *__restrict__ twm = p.twm;
+    double2 *const park = p.gscratch + (size_t)blockIdx.x * (size_t)M;
+    typedef d2v __attribute__((address_space(1))) *gd2;
+    if (t < 128)
+        g2s[t] = p.g2[t];
+    __syncthreads();
+    const long long total = p.npairs;
+    for (long long pair = blockIdx.x; pair < total; pair += gridDim.x) {
+        double2 v[16];
+        double q[4] = {0.0, 0.0, 0.0, 0.0};
+        // one series into v: point m = t + 256 i holds the samples 2m - pad, 2m + 1 - pad (a pad position: 0), d = sample - K; the sums
+        // of d and d^2 over the series land in q[qo], q[qo + 1]
+        const auto load_series = [&](const double *const r, const int pad, const int qo) __attribute__((always_inline)) {
+            const double K = normalize ? scalar_ptr(r)[0] : 0.0;
+            int tr = t;
+            asm volatile("" : "+v"(tr));
+            tr &= S - 1;
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int h = 0; h < 2; h++) { // two batches of eight requests
+                d2v s8[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int i = 8 * h + k;
+                    // (a request inside the pad: the row's own first samples, an L2 hit -- or the 2 S samples in front of a row shorter
+                    // than that: guard or earlier rows, never past the group's last row)
+                    const bool all_pad = PADDED && 2 * (i + 1) * S <= pad;
+                    const long long off = all_pad ? (n - pad >= 2 * S ? 0ll : -2ll * S) : 2ll * i * S - pad;
+                    typedef d2v __attribute__((aligned(8))) d2u;
+                    const d2u s = __builtin_nontemporal_load((gptr<d2u>)scalar_ptr_at(r, off) + (unsigned)tr);
+                    s8[k] = d2v{s.x, s.y};
+                }
+                fence();
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int i = 8 * h + k;
+                    const int e = 2 * (tr + i * S) - pad;
+                    const bool v0 = !PADDED || e >= 0, v1 = !PADDED || e + 1 >= 0;
+                    const double d0 = v0 ? s8[k].x - K : 0.0, d1 = v1 ? s8[k].y - K : 0.0;
+                    v[i] = make_double2(d0, d1);
+                    a0 += d0 + d1;
+                    a1 = fma(d0, d0, fma(d1, d1, a1));
+                }
+            }
+            a0 = wave_sum_dpp(a0);
+            a1 = wave_sum_dpp(a1);
+            lds_barrier(); // (red's previous readers are done)
+            if (lane == 0) {
+                red[2 * wave] = a0;
+                red[2 * wave + 1] = a1;
+            }
+            lds_barrier();
+            q[qo] = uniform((red[0] + red[2]) + (red[4] + red[6]));
+            q[qo + 1] = uniform((red[1] + red[3]) + (red[5] + red[7]));
+        };
+        const auto scale_series = [&](const int pad, const double sc, const double mean, const bool dead) __attribute__((always_inline)) {
+            int tr = t;
+            asm volatile("" : "+v"(tr));
+            tr &= S - 1;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int e = 2 * (tr + i * S) - pad;
+                const bool v0 = !PADDED || e >= 0, v1 = !PADDED || e + 1 >= 0;
+                v[i].x = (v0 && !dead) ? fma(v[i].x, sc, -mean) : 0.0;
+                v[i].y = (v1 && !dead) ? fma(v[i].y, sc, -mean) : 0.0;
+            }
+        };
+        // Z = FFT_M(z): Z[c + 256 k3] at v[BR16(k3)], c = hi + 16 lo (as xcorr_fused_n4096_fold)
+        const auto first_transform = [&]() __attribute__((always_inline)) {
+            dft16_nr(v);
+            exchange_cross<0, 1, true>(v, xbuf, wave, t);
+            gdft16_nr(v, G2Fetch{g2s, t >> 4});
+            exchange_local<1>(v, xw, t);
+            gdft16_nr_l2(v, G3Derived(p.g3a, t));
+        };
+        // ---- x: statistics, scale, ZX = FFT_M(zx), parked
+        load_series(p.xrows + pair * p.xstride, padx, 0);
+        {
+            double qx[4] = {q[0], q[1], 1.0, 1.0}; // (x on its own: pair_scale's numbers for series A do not depend on series B)
+            const two::PairScale px = two::pair_scale(qx, iv, normalize);
+            const bool deadx = normalize ? (px.nil || px.nan) : px.nan;
+            scale_series(padx, px.sA, px.mA, deadx);
+        }
+        first_transform();
+        {
+            int tp = t;
+            asm volatile("" : "+v"(tp));
+            tp &= S - 1;
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                *((gd2)scalar_ptr_at(park, r * S) + (unsigned)tp) = d2v{v[BR16(r)].x, v[BR16(r)].y};
+        }
+        // ---- y: statistics, scale, ZY = FFT_M(zy) in registers
+        load_series(p.rows + pair * p.stride, pady, 2);
+        const two::PairScale ps = two::pair_scale(q, iv, normalize);
+        const bool dead = ps.nil || ps.nan;
+        scale_series(pady, ps.sB, ps.mB, dead);
+        first_transform();
+        // ---- mirror pairs: X from the parked ZX, Y from ZY, P = Y conj X, re-tangled
+        __syncthreads(); // (every thread's part of ZX is in memory before anybody reads a mirrored bin)
+        {
+            int tm = t;
+            asm volatile("" : "+v"(tm));
+            tm &= S - 1;
+            const int c = (tm >> 4) + 16 * (tm & 15);
+            const double2 Wj = ldg2u(scalar_ptr(twm), (unsigned)(8 * c)); // W_8192^c = W_65536^(8 c); bin c + 256 r: times W_32^r
+            const auto conj_x = [](const RawPairXC &z, const double2 W) __attribute__((always_inline)) {
+                const TwoBins X = spectrum_pair(z.a, z.b, W);
+                return TwoBins{make_double2(X.k.x, -X.k.y), make_double2(X.m.x, -X.m.y)};
+            };
+            mirror_stage<0, MUSE_REAL_AHEAD, RawPairXC, S>(
+                v, xbuf, c, wave, Wj, false,
+                [&](const int r) __attribute__((always_inline)) {
+                    const d2v zk = *((gd2)scalar_ptr_at(park, r * S) + (unsigned)tm);
+                    const int bm = (M - r * S - c) & (M - 1), cm = bm & (S - 1);   // the mirror bin (column 0 of r = 0: bin 0 itself)
+                    const d2v zq = *((gd2)scalar_ptr(park) + (unsigned)((bm & ~(S - 1)) + 16 * (cm & 15) + (cm >> 4)));
+                    return RawPairXC{make_double2(zk.x, zk.y), make_double2(zq.x, zq.y)};
+                },
+                conj_x,
+                [&](const double2 v8) __attribute__((always_inline)) { // bin M / 2 (column 0, register 8) pairs with itself, W = -i
+                    const d2v zh = *((gd2)scalar_ptr_at(park, 8 * S));
+                    const double2 Wh = make_double2(0.0, -1.0);
+                    const TwoBins f = conj_x(RawPairXC{make_double2(zh.x, zh.y), make_double2(zh.x, zh.y)}, Wh);
+                    return mirror_pair(v8, v8, Wh, f.k, f.m).k;
+                });
+            lds_barrier(); // (the next use of the buffer is a wave-local transpose into a quarter other waves' columns live in)
+        }
+        // ---- c = FFT_M(C): 4 n cc[2m] + 4 n i cc[2m+1] (before the pair's factor), m = t + 256 m3, at v[BR16(m3)]
+#pragma unroll
+        for (int r = 0; r < 16; r += 2)
+            bf_one(v[r], v[r + 1]);
+        dft16_rn_s234(v);
+        exchange_local<0>(v, xw, t);
+        gdft16_nr(v, G2Fetch{g2s, t & 15});
+        exchange_cross<1, 1>(v, xbuf, wave, t);
+        gdft16_nr_l2(v, G3Derived(p.g3b, t));
+        const double fac = ps.fac * (1.0 / (4.0 * n)); // (2 X, 2 Y, and the 1 / n of the inverse transform: exact)
+        if (p.cc_out && !dead) {
+            double *const cc = p.cc_out + pair * (long long)n;
+            int tc = t;
+            asm volatile("" : "+v"(tc));
+            tc &= S - 1;
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                *((d2v __attribute__((address_space(1))) *)scalar_ptr_at(cc, 2 * r * S) + (unsigned)tc) = d2v{v[BR16(r)].x * fac, v[BR16(r)].y * fac};
+        }
+        double sv = 0.0;
+        int code = 0;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const double a0 = v[BR16(r)].x, a1 = v[BR16(r)].y;
+            const bool g0 = fabs(a0) > fabs(sv);
+            sv = g0 ? a0 : sv;
+            code = g0 ? 2 * r : code;
+            const bool g1 = fabs(a1) > fabs(sv);
+            sv = g1 ? a1 : sv;
+            code = g1 ? 2 * r + 1 : code;
+        }
+        const double ma = fabs(sv);
+        const int ia = 2 * (t + (code >> 1) * S) + (code & 1);
+        const double cc0 = v[0].x;
+        const double wa = wave_max_nonneg(ma);
+        if (lane == 0)
+            red[8 + wave] = wa;
+        lds_barrier();
+        const double pa = fmax(fmax(red[8], red[9]), fmax(red[10], red[11]));
+        const int wi = wave_min_i_dpp((ma == pa && pa > 0.0) ? ia : 0x7fffffff);
+        if (lane == 0)
+            ((int *)(red + 12))[wave] = wi;
+        lds_barrier();
+        const int *ri = (const int *)(red + 12);
+        const int ca = min(min(ri[0], ri[1]), min(ri[2], ri[3]));
+        const bool own = ca == 0x7fffffff ? t == 0 : (ia == ca && ma == pa);
+        if (own) {
+            const int idx = ca == 0x7fffffff ? 0 : ca;
+            double mv = (ca == 0x7fffffff ? cc0 : sv) * fac;
+            int lag = idx > n / 2 ? idx - n : idx;
+            if (ps.nil) { mv = 0.0; lag = 0; }               // xcorr.go:110-127
+            if (ps.nan) { mv = __builtin_nan(""); lag = 0; } // every cc is NaN: maxAbsIndex keeps index 0
+            p.mv[pair] = mv;
+            p.lag[pair] = lag;
+            if (p.nil_out)
+                p.nil_out[pair] = ps.nil ? 1 : 0;
+        }
+    }
+}
+
 // the reference's spectrum at the bins of xcorr_fused_real8k's threads, lane-ordered: out[r][t] = xc[c(t) + 256 r],
 // out[8 + r][t] = xc[4096 - c(t) - 256 r], r = 0 .. 7, c(t) = (t >> 4) + 16 (t & 15)
 __global__ void real8k_tables_kernel(const double2 *__restrict__ xc, double2 *__restrict__ out)

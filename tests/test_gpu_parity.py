@@ -1969,13 +1969,16 @@ def test_xcorr_batch_matches_oracle(eng, oracle, n, normalize):
         _check_xcorr_batch(eng, oracle, X, Y, n, normalize)
 
 
-def test_xcorr_batch_16384_both_kernels(eng, oracle):
-    """n = 16384: automatic selection transforms each series as a REAL series on the 8192-point machinery (xcorr_two_sided_real16k,
-    two workgroups per CU); test hook 12 keeps the pair-packed kernel (xcorr_two_sided_small<14>).  Both against the oracle, padded
-    and not, more pairs than one resident set of workgroups."""
-    rng = np.random.default_rng(16384)
-    n, M = 16384, 19
-    for lens in ((n, n), (n - 4099, n), (9000, 12001)):
+@pytest.mark.parametrize("n", [8192, 16384])
+def test_xcorr_batch_real_and_pair_packed_kernels(eng, oracle, n):
+    """n = 8192, 16384: automatic selection transforms each series as a REAL series on the 4096- / 8192-point machinery
+    (xcorr_two_sided_real8k / real16k); test hook 12 keeps the pair-packed kernels (xcorr_two_sided_small<13 / 14>).  Both against
+    the oracle, padded and not, series shorter than one request row, more pairs than one resident set of workgroups."""
+    rng = np.random.default_rng(n)
+    M = 19 if n == 16384 else 2100
+    for lens in ((n, n), (n - n // 4 - 3, n), (n // 2 + 808, 3 * n // 4 - 287), (n, 37)):
+        if M > 100 and lens != (n, n):
+            M = 23
         X = rng.normal(size=(M, lens[0])) * rng.uniform(0.1, 30.0, size=(M, 1)) + 2.0
         Y = rng.normal(size=(M, lens[1])) * 4.0 - 1.0
         k = min(lens)
