@@ -4,7 +4,7 @@
     constant / exactly tied members, through the copy and (small groups) straight out of pinned memory;
   * the batched two-sided xCorr at random FFT lengths 512 ... 65536 with magnitudes between 1e-200 and 1e200 mixed into the pairs
     (the statistics that leave the float64 range: NaN stands / every cc zero / recomputed on rescaled copies);
-  * the all-scores pass at random lengths around the real-transform kernels' ranges (4097 ... 8192, 16385 ... 65536), odd and even pads.
+  * the all-scores pass at random lengths around the real-transform kernels' ranges (4097 ... 65536: n = 8192, 16384, 32768, 65536), odd and even pads.
 usage: soak_round5.py [seconds] [seed]"""
 import importlib
 import os
@@ -140,7 +140,7 @@ def soak_xcorr():
 
 def soak_scores():
     global bad
-    lo, hi = [(4097, 8192), (16385, 32768), (32769, 65536)][int(rng.integers(0, 3))]
+    lo, hi = [(4097, 8192), (8193, 16384), (16385, 32768), (32769, 65536)][int(rng.integers(0, 4))]
     N = hi if rng.random() < 0.3 else int(rng.integers(lo, hi + 1))
     M = int(rng.integers(1, 12))
     t = np.arange(N)
