@@ -360,13 +360,13 @@ static int xcorr_groups_impl(muse_group *gx, muse_group *gy, int32_t n, int32_t 
         p.ovf_count = dcount;
         // n = 8192, 16384: each series a real transform on the 4096- / 8192-point machinery (xcorr_real.hip); test hook 12 keeps the
         // pair-packed kernels (xcorr_two_sided_small<13 / 14>)
-        const bool real16k = (p.logn == 14 && ctx->variant != 12 && ctx->gsmall[3]) || (p.logn == 13 && ctx->variant != 12); // (and n = 8192: on the n = 4096 kernel's)
-        if (real16k && p.logn == 14)
-            p.gsmall = ctx->gsmall[3];
+        const bool real_form = ctx->variant != 12 && (p.logn == 13 || (p.logn == 14 && ctx->gsmall[3]));
+        if (real_form && p.logn == 14)
+            p.gsmall = ctx->gsmall[3]; // (n = 8192 runs on the n = 4096 kernel's tables: p.g2, p.g3a, p.g3b)
         LaunchTimer timer(ctx);
         e = timer.begin();
         if (e == hipSuccess)
-            e = real16k ? launch_two_sided_real(p, ctx->num_cus, ctx->stream) : launch_two_sided(p, ctx->num_cus, ctx->stream);
+            e = real_form ? launch_two_sided_real(p, ctx->num_cus, ctx->stream) : launch_two_sided(p, ctx->num_cus, ctx->stream);
         if (e == hipSuccess)
             e = timer.end();
     }
