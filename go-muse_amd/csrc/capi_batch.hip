@@ -374,8 +374,10 @@ extern "C" int muse_batch_score(muse_batch *b)
     } else if (b->n == 16384 && (ctx->variant == 0 || ctx->variant == 14) && !b->g->f32 && ctx->gsmall[3]) {
         variant = KERNEL_REAL; // one real series per 512-thread workgroup on the 8192-point complex transform, two workgroups per CU
         p.gsmall = ctx->gsmall[3];
-    } else if (b->n == 32768 && ctx->variant == 15 && !b->g->f32 && ctx->gsmall[4] && b->xcw) {
-        variant = KERNEL_REAL_SPLIT; // the same on the 16 x 1024 split of the 16384-point transform (wave-local 1024-point transforms)
+    } else if (b->n == 32768 && (ctx->variant == 0 || ctx->variant == 15) && !b->g->f32 && ctx->gsmall[4] && b->xcw && ctx->wsplit) {
+        // one real series per 1024-thread workgroup with each 16384-point transform as 16 x 1024 (wave-local 1024-point transforms around one
+        // workgroup transpose): + 1 ... 4 % over test hook 14's three-transpose form on every box measured (profiles/r05_real_transform.txt)
+        variant = KERNEL_REAL_SPLIT;
         p.gsmall = ctx->gsmall[4];
     } else if ((b->n == 32768 || (b->n == 65536 && (b->N == b->n || b->c1))) && (ctx->variant == 0 || ctx->variant == 14) && !b->g->f32 && ctx->gsmall[4]) {
         // one real series per 1024-thread workgroup on the 16384-point complex transform (xcorr_real.hip): n = 32768 never leaves the CU,
@@ -493,6 +495,8 @@ extern "C" int muse_batch_kernel_name(muse_batch *b, char *name, int32_t cap)
         snprintf(k, sizeof(k), "xcorr_fused_real16k<%s>", padded ? "true" : "false");
     else if ((b->n >= 512 && b->n <= 2048) || b->n == 8192 || b->n == 16384)
         snprintf(k, sizeof(k), "xcorr_fused_small<%d, %s, false%s>", b->logn, padded ? "true" : "false", b->g->f32 ? ", true" : ", false");
+    else if (b->n == 32768 && b->xcw)
+        snprintf(k, sizeof(k), "xcorr_fused_real32k_split<%s>", padded ? "true" : "false");
     else if (b->n == 32768 || b->n == 65536)
         snprintf(k, sizeof(k), "xcorr_fused_real%dk<%s>", b->n / 1024, padded ? "true" : "false");
     snprintf(name, (size_t)cap, "%s", k);

@@ -16,8 +16,8 @@ extern "C" {
  * target of the default kernel), 10 = the default n = 4096 kernel, 11 = round-1 radix-16 Stockham / four-step kernels
  * (n = 512 .. 2048, 8192 .. 65536), 12 = the pair-packed half-round kernels (n = 512 .. 2048: what auto takes; 8192, 16384; also the
  * two-sided xCorr at n = 16384), 13 = the four-step long-series kernel (n = 16384 .. 65536), 14 = one REAL series per workgroup
- * (n = 8192 .. 65536: what auto takes there), 15 = 14 at n = 32768 with each 16384-point transform as 16 x 1024 (wave-local
- * 1024-point transforms around one workgroup transpose).  The parity tests run every kernel on the same inputs. */
+ * (n = 8192 .. 65536: what auto takes at 8192, 16384 and 65536), 15 = the same at n = 32768 with each 16384-point transform as
+ * 16 x 1024 (wave-local 1024-point transforms around one workgroup transpose: what auto takes at 32768).  The parity tests run every kernel on the same inputs. */
 int muse_ctx_set_kernel(muse_ctx *ctx, int32_t variant);
 /* Scales the error bound the filter-and-refine Run assumes for its fp32 estimates (1.0 = the derived bound): the
  * guard test shrinks it a million-fold to force the fp64 re-run. */

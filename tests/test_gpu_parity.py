@@ -778,7 +778,7 @@ def test_stockham_kernels_match_oracle_and_generic(muse, eng, oracle, N):
             assert math.isnan(mv[10]) and lag[10] == 0 and math.isnan(mv[12]) and lag[12] == 0, variant
             assert_scores_match(lag, mv, olag, omv, gap)
             got[variant] = (lag, mv)
-        auto = 14 if db.n >= 8192 else 12 if small else 11      # what automatic selection takes for this length
+        auto = 15 if db.n == 32768 else 14 if db.n >= 8192 else 12 if small else 11      # what automatic selection takes for this length
         assert np.array_equal(got[0][0], got[auto][0]) and np.array_equal(got[0][1], got[auto][1], equal_nan=True)
     finally:
         eng.set_kernel(0)
