@@ -38,7 +38,11 @@ def check(lag, mv, olag, omv, gap, what):
         print("MISMATCH", what, flush=True)
 
 
+t_said = time.time()
 while time.time() < t_end:
+    if time.time() - t_said > 60.0:  # (a GPU box takes a run that prints nothing for minutes to be hung)
+        t_said = time.time()
+        print("... %d cases, %d mismatches so far" % (cases, bad), flush=True)
     # ---- xCorrWithX
     n = int(rng.choice([8192, 16384, 32768, 65536]))
     N = n if rng.random() < 0.4 else int(rng.integers(n // 2 + 1, n))

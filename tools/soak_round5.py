@@ -167,7 +167,11 @@ def soak_scores():
     cases["scores"] += 1
 
 
+t_said = time.time()
 while time.time() < t_end:
+    if time.time() - t_said > 60.0:  # (a GPU box takes a run that prints nothing for minutes to be hung)
+        t_said = time.time()
+        print("... %s cases, %d mismatches so far" % (cases, bad), flush=True)
     r = rng.random()
     if r < 0.4:
         soak_run_rows()
