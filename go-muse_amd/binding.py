@@ -64,6 +64,10 @@ SIGNATURES = {
     "muse_batch_create": (ctypes.c_int, [_vp, _vp, _dp, _i32, ctypes.POINTER(_vp)]),
     "muse_batch_create_like": (ctypes.c_int, [_vp, _vp, ctypes.POINTER(_vp)]),
     "muse_batch_run_rows": (ctypes.c_int, [_vp, _dp, _i64, _i64, _i32, _recp, ctypes.POINTER(ctypes.c_uint8)]),
+    "muse_batch_run_row_ptrs": (ctypes.c_int, [_vp, ctypes.POINTER(_dp), _i64, _i32, _recp, ctypes.POINTER(ctypes.c_uint8)]),
+    "muse_group_stage": (ctypes.c_int, [_vp, _i64, ctypes.POINTER(_dp), _i64p]),
+    "muse_group_commit": (ctypes.c_int, [_vp, _i64, _i64]),
+    "muse_ctx_trim": (ctypes.c_int, [_vp]),
     "muse_batch_fft_len": (ctypes.c_int, [_vp, _i32p]),
     "muse_batch_spectrum": (ctypes.c_int, [_vp, _dp]),
     "muse_batch_score": (ctypes.c_int, [_vp]),
@@ -86,6 +90,8 @@ SIGNATURES = {
     "muse_test_screen_bound": (ctypes.c_int, [_i32, _f64, _dp]),
     "muse_test_wave_argmax": (ctypes.c_int, [_vp, _dp, _dp, _dp]),
     "muse_test_rows_always_copy": (ctypes.c_int, [_vp, _i32]),
+    "muse_test_pool_stats": (ctypes.c_int, [_vp, _i64p, _i64p, _i64p, _i64p]),
+    "muse_test_xcorr_repeat": (ctypes.c_int, [_vp, _i32]),
     "muse_test_clock_probe_start": (ctypes.c_int, [_vp, _f64, _f64]),
     "muse_test_clock_probe_stop": (ctypes.c_int, [_vp]),
     "muse_test_clock_probe_read": (ctypes.c_int, [_vp, _dp, _i32, _i32p]),

@@ -97,3 +97,20 @@ def build_ref_bench(force=False):
                            "-I" + os.path.join(PKG, "host"), src, "-o", REF_BENCH,
                            "-L" + LIBDIR, "-lmuse_hip", "-pthread", "-Wl,-rpath," + LIBDIR])
     return REF_BENCH
+
+
+COLD_PHASES = os.path.join(LIBDIR, "muse_cold_phases")
+
+
+def build_cold_phases(force=False):
+    """g++ build of the cold-path phase breakdown (host/muse_cold_phases.cpp; profiles/r06_cold_path.txt)."""
+    src = os.path.join(PKG, "host", "muse_cold_phases.cpp")
+    hdr = os.path.join(PKG, "host", "muse.hpp")
+    build()
+    if (not force and os.path.exists(COLD_PHASES)
+            and os.path.getmtime(COLD_PHASES) >= max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(LIB))):
+        return COLD_PHASES
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"),
+                           "-I" + os.path.join(PKG, "host"), src, "-o", COLD_PHASES,
+                           "-L" + LIBDIR, "-lmuse_hip", "-pthread", "-Wl,-rpath," + LIBDIR])
+    return COLD_PHASES

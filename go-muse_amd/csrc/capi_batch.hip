@@ -23,10 +23,10 @@ int build_spectrum(muse_ctx *ctx, const double *ref_host, int N, int n, int norm
     double *dref = nullptr;
     int *dstat = nullptr;
     double2 *dscr = nullptr; // n > 8192: global work buffer for the radix-2 passes
-    HIP_TRY(hipMalloc(&dref, (size_t)N * sizeof(double)));
-    hipError_t e = hipMalloc(&dstat, sizeof(int));
+    HIP_TRY(dmalloc(ctx, &dref, (size_t)N * sizeof(double)));
+    hipError_t e = dmalloc(ctx, &dstat, sizeof(int));
     if (e == hipSuccess && n > GENERIC_LDS_MAX_N)
-        e = hipMalloc(&dscr, (size_t)n * sizeof(double2));
+        e = dmalloc(ctx, &dscr, (size_t)n * sizeof(double2));
     if (e == hipSuccess)
         e = hipMemcpyAsync(dref, ref_host, (size_t)N * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess)
@@ -37,9 +37,9 @@ int build_spectrum(muse_ctx *ctx, const double *ref_host, int N, int n, int norm
         e = hipMemcpyAsync(&st, dstat, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess)
         e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(dref);
-    (void)hipFree(dstat);
-    (void)hipFree(dscr);
+    dfree(ctx, dref);
+    dfree(ctx, dstat);
+    dfree(ctx, dscr);
     HIP_TRY(e);
     *zero_std = st;
     return MUSE_OK;
@@ -130,7 +130,7 @@ extern "C" int muse_batch_create(muse_ctx *ctx, muse_group *g, const double *ref
     b->N = N;
     b->n = (int32_t)n;
     b->logn = ilog2(n);
-    hipError_t e = hipMalloc(&b->ovf_count, 2 * sizeof(int)); // [0] overflow-pair count, [1] dynamic work counter
+    hipError_t e = dmalloc(ctx, &b->ovf_count, 2 * sizeof(int)); // [0] overflow-pair count, [1] dynamic work counter
     if (e == hipSuccess)
         e = ensure_gscratch(ctx, n);
     muse_spectrum *sp = new (std::nothrow) muse_spectrum();
@@ -138,22 +138,22 @@ extern "C" int muse_batch_create(muse_ctx *ctx, muse_group *g, const double *ref
         e = hipErrorOutOfMemory;
     b->sp = sp;
     if (e == hipSuccess)
-        e = hipMalloc(&sp->X, (size_t)(n / 2 + 1) * sizeof(double2));
+        e = dmalloc(ctx, &sp->X, (size_t)(n / 2 + 1) * sizeof(double2));
     if (e == hipSuccess)
-        e = hipMalloc(&sp->xc, (size_t)n * sizeof(double2));
+        e = dmalloc(ctx, &sp->xc, (size_t)n * sizeof(double2));
     if (e == hipSuccess)
-        e = hipMalloc(&sp->xcf, (size_t)n * sizeof(float2));
+        e = dmalloc(ctx, &sp->xcf, (size_t)n * sizeof(float2));
     if (e == hipSuccess)
-        e = hipMalloc(&sp->xs, (size_t)n * sizeof(double));
+        e = dmalloc(ctx, &sp->xs, (size_t)n * sizeof(double));
     const bool long_n = n == 16384 || n == 32768 || n == 65536; // xcorr_long.hip: spectrum rows in lane order, sweep twiddles
     if (e == hipSuccess && (n == 4096 || long_n))
-        e = hipMalloc(&sp->xcp, (size_t)n * sizeof(double2));
+        e = dmalloc(ctx, &sp->xcp, (size_t)n * sizeof(double2));
     if (e == hipSuccess && n == 8192) // xcorr_fused_real8k: the spectrum at its threads' bins, lane-ordered
-        e = hipMalloc(&sp->xcp, (size_t)4096 * sizeof(double2));
+        e = dmalloc(ctx, &sp->xcp, (size_t)4096 * sizeof(double2));
     if (e == hipSuccess && n == 32768) // xcorr_real.hip, the 16 x 1024 split: xc at the threads' lower eight bins and their mirror bins
-        e = hipMalloc(&sp->xcw, (size_t)16384 * sizeof(double2));
+        e = dmalloc(ctx, &sp->xcw, (size_t)16384 * sizeof(double2));
     if (e == hipSuccess && (n == 4096 || long_n) && N < n)
-        e = hipMalloc(&sp->c1, (size_t)n * sizeof(double));
+        e = dmalloc(ctx, &sp->c1, (size_t)n * sizeof(double));
     if (e != hipSuccess) {
         muse_batch_free(b);
         return fail(MUSE_ERR_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e));
@@ -238,7 +238,7 @@ extern "C" int muse_batch_create_like(muse_batch *src, muse_group *g, muse_batch
     b->sp = src->sp;
     b->sp->refs.fetch_add(1);
     adopt_spectrum(b);
-    hipError_t e = hipMalloc(&b->ovf_count, 2 * sizeof(int));
+    hipError_t e = dmalloc(ctx, &b->ovf_count, 2 * sizeof(int));
     if (e != hipSuccess) {
         muse_batch_free(b);
         return fail(MUSE_ERR_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e));
@@ -271,13 +271,13 @@ int ensure_scores(muse_batch *b)
     const int64_t M = b->g->M;
     if (M <= b->score_cap)
         return MUSE_OK;
-    (void)hipFree(b->mv);
-    (void)hipFree(b->lag);
+    dfree(b->ctx, b->mv);
+    dfree(b->ctx, b->lag);
     b->mv = nullptr;
     b->lag = nullptr;
     b->score_cap = 0;
-    HIP_TRY(hipMalloc(&b->mv, (size_t)M * sizeof(double)));
-    HIP_TRY(hipMalloc(&b->lag, (size_t)M * sizeof(int)));
+    HIP_TRY(dmalloc(b->ctx, &b->mv, (size_t)M * sizeof(double)));
+    HIP_TRY(dmalloc(b->ctx, &b->lag, (size_t)M * sizeof(int)));
     b->score_cap = M;
     return MUSE_OK;
 }
@@ -334,12 +334,13 @@ extern "C" int muse_batch_score(muse_batch *b)
     int rc = use_device(ctx);
     if (rc)
         return rc;
-    rc = group_ready(b->g); // rows still in the staging buffer are uploaded (copy stream) ahead of the kernel
+    rc = group_ready(b->g, b->stream()); // rows still in the staging buffer are uploaded (copy stream) ahead of the kernel
     if (rc)
         return rc;
     const int64_t M = b->g->M;
     if (M == 0)
         return MUSE_OK;
+    const hipStream_t st = b->stream();
     rc = ensure_scores(b);
     if (rc)
         return rc;
@@ -393,25 +394,25 @@ extern "C" int muse_batch_score(muse_batch *b)
     }
     if (variant == KERNEL_GENERIC && b->n <= GENERIC_LDS_MAX_N)
         p.gscratch = nullptr; // the generic kernel takes a non-NULL scratch pointer as "work in global memory"
-    LaunchTimer timer(ctx); // (brackets the fused launch alone: not the counter reset in front of it, not the redo launch behind it)
-    LaunchTimer redo_timer(ctx, true); // the launch that redoes the listed pairs: its own sum (muse_ctx_redo_time)
+    LaunchTimer timer(ctx, false, st); // (brackets the fused launch alone: not the counter reset in front of it, not the redo launch behind it)
+    LaunchTimer redo_timer(ctx, true, st); // the launch that redoes the listed pairs: its own sum (muse_ctx_redo_time)
     if (variant == KERNEL_R16_FOLD) {
         // pairs with a NaN/Inf series or with sigmas too far apart for one shared transform are listed by the kernel
         // (once per such series: 2 entries per pair) and redone by the rescaling kernel right behind it (no host round
         // trip: the count stays on the device and bounds the second launch's loop)
         if (2 * p.npairs > b->ovf_cap) {
-            (void)hipFree(b->ovf_list);
+            dfree(ctx, b->ovf_list);
             b->ovf_list = nullptr;
             b->ovf_cap = 0;
-            HIP_TRY(hipMalloc(&b->ovf_list, (size_t)(2 * p.npairs) * sizeof(long long)));
+            HIP_TRY(dmalloc(ctx, &b->ovf_list, (size_t)(2 * p.npairs) * sizeof(long long)));
             b->ovf_cap = 2 * p.npairs;
         }
         p.ovf_count = b->ovf_count;
         p.work_counter = b->ovf_count + 1;
         p.ovf_list = b->ovf_list;
-        HIP_TRY(hipMemsetAsync(b->ovf_count, 0, 2 * sizeof(int), ctx->stream));
+        HIP_TRY(hipMemsetAsync(b->ovf_count, 0, 2 * sizeof(int), st));
         HIP_TRY(timer.begin());
-        HIP_TRY(launch_fused(p, variant, ctx->num_cus, ctx->stream));
+        HIP_TRY(launch_fused(p, variant, ctx->num_cus, st));
         HIP_TRY(timer.end());
         FusedParams q = p;
         q.pair_list = b->ovf_list;
@@ -423,41 +424,41 @@ extern "C" int muse_batch_score(muse_batch *b)
         // (mixed-unit metrics: sigmas far apart) is redone at full width; an empty list costs a few microseconds
         q.npairs = std::min<long long>(p.npairs, (long long)ctx->num_cus * 3);
         HIP_TRY(redo_timer.begin());
-        HIP_TRY(launch_fused(q, KERNEL_R16_OCC3, ctx->num_cus, ctx->stream));
+        HIP_TRY(launch_fused(q, KERNEL_R16_OCC3, ctx->num_cus, st));
         HIP_TRY(redo_timer.end());
         if (p.npairs >= 1024) { // (small groups: a pinned allocation costs more than it can save)
             if (!b->handoff_host)
-                HIP_TRY(hipHostMalloc((void **)&b->handoff_host, sizeof(int), hipHostMallocDefault));
+                HIP_TRY(hmalloc(ctx, &b->handoff_host, sizeof(int)));
             *b->handoff_host = 0;
             b->handoff_M = M;
-            HIP_TRY(hipMemcpyAsync(b->handoff_host, b->ovf_count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipMemcpyAsync(b->handoff_host, b->ovf_count, sizeof(int), hipMemcpyDeviceToHost, st));
         }
     } else if (variant == KERNEL_LONG) {
         // as above: NaN / Inf and sigma-spread pairs are listed (one entry per pair) and redone by the four-step kernel that
         // isolates and rescales the series first
         if (2 * p.npairs > b->ovf_cap) {
-            (void)hipFree(b->ovf_list);
+            dfree(ctx, b->ovf_list);
             b->ovf_list = nullptr;
             b->ovf_cap = 0;
-            HIP_TRY(hipMalloc(&b->ovf_list, (size_t)(2 * p.npairs) * sizeof(long long)));
+            HIP_TRY(dmalloc(ctx, &b->ovf_list, (size_t)(2 * p.npairs) * sizeof(long long)));
             b->ovf_cap = 2 * p.npairs;
         }
         p.ovf_count = b->ovf_count;
         p.ovf_list = b->ovf_list;
-        HIP_TRY(hipMemsetAsync(b->ovf_count, 0, 2 * sizeof(int), ctx->stream));
+        HIP_TRY(hipMemsetAsync(b->ovf_count, 0, 2 * sizeof(int), st));
         HIP_TRY(timer.begin());
-        HIP_TRY(launch_fused(p, variant, ctx->num_cus, ctx->stream));
+        HIP_TRY(launch_fused(p, variant, ctx->num_cus, st));
         HIP_TRY(timer.end());
         FusedParams q = p;
         q.pair_list = b->ovf_list;
         q.pair_count = b->ovf_count;
         q.npairs = std::min<long long>(p.npairs, (long long)ctx->num_cus * STOCKHAM_GLOBAL_WGS_PER_CU);
         HIP_TRY(redo_timer.begin());
-        HIP_TRY(launch_fused(q, KERNEL_STOCKHAM, ctx->num_cus, ctx->stream));
+        HIP_TRY(launch_fused(q, KERNEL_STOCKHAM, ctx->num_cus, st));
         HIP_TRY(redo_timer.end());
     } else {
         HIP_TRY(timer.begin());
-        HIP_TRY(launch_fused(p, variant, ctx->num_cus, ctx->stream));
+        HIP_TRY(launch_fused(p, variant, ctx->num_cus, st));
         HIP_TRY(timer.end());
     }
     return MUSE_OK;
@@ -473,9 +474,9 @@ extern "C" int muse_batch_scores(muse_batch *b, int32_t *lag, double *mv)
         return MUSE_OK;
     if (!lag || !mv)
         return fail(MUSE_ERR_INVALID, "NULL output");
-    HIP_TRY(hipMemcpyAsync(lag, b->lag, (size_t)M * sizeof(int), hipMemcpyDeviceToHost, b->ctx->stream));
-    HIP_TRY(hipMemcpyAsync(mv, b->mv, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, b->ctx->stream));
-    HIP_TRY(hipStreamSynchronize(b->ctx->stream));
+    HIP_TRY(hipMemcpyAsync(lag, b->lag, (size_t)M * sizeof(int), hipMemcpyDeviceToHost, b->stream()));
+    HIP_TRY(hipMemcpyAsync(mv, b->mv, (size_t)M * sizeof(double), hipMemcpyDeviceToHost, b->stream()));
+    HIP_TRY(hipStreamSynchronize(b->stream()));
     return MUSE_OK;
 }
 
@@ -507,53 +508,54 @@ extern "C" int muse_batch_free(muse_batch *b)
 {
     if (!b)
         return MUSE_OK;
-    (void)hipSetDevice(b->ctx->device);
-    (void)hipStreamSynchronize(b->ctx->stream);
+    muse_ctx *const c = b->ctx;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(b->stream());
     if (b->sp && b->sp->refs.fetch_sub(1) == 1) {
-        (void)hipFree(b->sp->X);
-        (void)hipFree(b->sp->xc);
-        (void)hipFree(b->sp->xcp);
-        (void)hipFree(b->sp->xcw);
-        (void)hipFree(b->sp->xcf);
-        (void)hipFree(b->sp->xs);
-        (void)hipFree(b->sp->c1);
+        dfree(c, b->sp->X);
+        dfree(c, b->sp->xc);
+        dfree(c, b->sp->xcp);
+        dfree(c, b->sp->xcw);
+        dfree(c, b->sp->xcf);
+        dfree(c, b->sp->xs);
+        dfree(c, b->sp->c1);
         delete b->sp;
     }
-    (void)hipFree(b->ovf_count);
+    dfree(c, b->ovf_count);
     if (b->handoff_host)
-        (void)hipHostFree(b->handoff_host);
-    (void)hipFree(b->ovf_list);
-    (void)hipFree(b->mv);
-    (void)hipFree(b->lag);
-    (void)hipFree(b->gid_dev);
-    (void)hipFree(b->gw.key);
-    (void)hipFree(b->gw.first);
-    (void)hipFree(b->gw.win);
-    (void)hipFree(b->rec);
-    (void)hipFree(b->selkey);
-    (void)hipFree(b->cand);
+        hfree(c, b->handoff_host);
+    dfree(c, b->ovf_list);
+    dfree(c, b->mv);
+    dfree(c, b->lag);
+    dfree(c, b->gid_dev);
+    dfree(c, b->gw.key);
+    dfree(c, b->gw.first);
+    dfree(c, b->gw.win);
+    dfree(c, b->rec);
+    dfree(c, b->selkey);
+    dfree(c, b->cand);
     if (b->cand_host)
-        (void)hipHostFree(b->cand_host);
+        hfree(c, b->cand_host);
     if (b->cnt_host)
-        (void)hipHostFree(b->cnt_host);
+        hfree(c, b->cnt_host);
     if (b->rec_host)
-        (void)hipHostFree(b->rec_host);
+        hfree(c, b->rec_host);
     if (b->key_host)
-        (void)hipHostFree(b->key_host);
-    (void)hipFree(b->cnt);
-    (void)hipFree(b->scr_flags);
-    (void)hipFree(b->scr_var);
-    (void)hipFree(b->include);
-    (void)hipFree(b->scr_keys);
-    (void)hipFree(b->scr_gmay);
-    (void)hipFree(b->scr_gkplus);
-    (void)hipFree(b->scr_gcert);
+        hfree(c, b->key_host);
+    dfree(c, b->cnt);
+    dfree(c, b->scr_flags);
+    dfree(c, b->scr_var);
+    dfree(c, b->include);
+    dfree(c, b->scr_keys);
+    dfree(c, b->scr_gmay);
+    dfree(c, b->scr_gkplus);
+    dfree(c, b->scr_gcert);
     if (b->refine_host)
-        (void)hipHostFree(b->refine_host);
+        hfree(c, b->refine_host);
     if (b->err_host)
-        (void)hipHostFree(b->err_host);
-    (void)hipFree(b->err_dev);
-    (void)hipFree(b->est_save);
+        hfree(c, b->err_host);
+    dfree(c, b->err_dev);
+    dfree(c, b->est_save);
     muse_group *g = b->g;
     muse_ctx *ctx = b->ctx;
     delete b;

@@ -55,6 +55,101 @@ int use_device(muse_ctx *ctx)
     return MUSE_OK;
 }
 
+// ------------------------------------------------------------ allocation cache
+// Size classes: powers of two up to 1 MB, multiples of 1 MB beyond (a group of M x N rows always asks for the same class).
+static size_t pool_class(size_t bytes)
+{
+    if (bytes <= 256)
+        return 256;
+    if (bytes <= ((size_t)1 << 20)) {
+        size_t c = 256;
+        while (c < bytes)
+            c <<= 1;
+        return c;
+    }
+    return (bytes + (((size_t)1 << 20) - 1)) & ~(((size_t)1 << 20) - 1);
+}
+
+hipError_t pool_alloc(muse_ctx *ctx, bool host, void **out, size_t bytes)
+{
+    MemPool &mp = host ? ctx->host_pool : ctx->dev_pool;
+    const size_t cls = pool_class(bytes);
+    *out = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(mp.mu);
+        auto it = mp.idle.find(cls);
+        if (it != mp.idle.end()) {
+            *out = it->second;
+            mp.idle.erase(it);
+            mp.idle_bytes -= cls;
+            return hipSuccess;
+        }
+    }
+    void *p = nullptr;
+    hipError_t e = host ? hipHostMalloc(&p, cls, hipHostMallocDefault) : hipMalloc(&p, cls);
+    if (e != hipSuccess) { // out of memory with blocks cached: give them back and try once more
+        (void)hipGetLastError();
+        pool_drain(ctx);
+        e = host ? hipHostMalloc(&p, cls, hipHostMallocDefault) : hipMalloc(&p, cls);
+    }
+    if (e != hipSuccess)
+        return e;
+    {
+        std::lock_guard<std::mutex> lock(mp.mu);
+        mp.size_of[p] = cls;
+    }
+    *out = p;
+    return hipSuccess;
+}
+
+void pool_free(muse_ctx *ctx, bool host, void *p)
+{
+    if (!p)
+        return;
+    MemPool &mp = host ? ctx->host_pool : ctx->dev_pool;
+    {
+        std::lock_guard<std::mutex> lock(mp.mu);
+        auto it = mp.size_of.find(p);
+        if (it != mp.size_of.end()) {
+            const size_t cls = it->second;
+            if (cls <= mp.block_cap && mp.idle_bytes + cls <= mp.idle_cap) {
+                mp.idle.emplace(cls, p);
+                mp.idle_bytes += cls;
+                return;
+            }
+            mp.size_of.erase(it);
+        }
+    }
+    // (not one of the pool's blocks, or the cache is full)
+    if (host)
+        (void)hipHostFree(p);
+    else
+        (void)hipFree(p);
+}
+
+void pool_drain(muse_ctx *ctx)
+{
+    for (int h = 0; h < 2; h++) {
+        MemPool &mp = h ? ctx->host_pool : ctx->dev_pool;
+        std::vector<void *> blocks;
+        {
+            std::lock_guard<std::mutex> lock(mp.mu);
+            for (auto &kv : mp.idle) {
+                blocks.push_back(kv.second);
+                mp.size_of.erase(kv.second);
+            }
+            mp.idle.clear();
+            mp.idle_bytes = 0;
+        }
+        for (void *b : blocks) {
+            if (h)
+                (void)hipHostFree(b);
+            else
+                (void)hipFree(b);
+        }
+    }
+}
+
 // ----------------------------------------------------------------- context
 void fill_twiddle(std::vector<double2> &v, size_t i, long long num, long long den)
 {
@@ -85,6 +180,11 @@ extern "C" int muse_ctx_create(int32_t device, muse_ctx **out)
     if (!ctx)
         return fail(MUSE_ERR_NOMEM, "host allocation failed");
     ctx->device = device;
+    // what an idle context may keep cached: 1 GB of HBM in blocks of up to 256 MB, 192 MB of pinned host memory in blocks of up to 64 MB
+    ctx->dev_pool.idle_cap = (size_t)1 << 30;
+    ctx->dev_pool.block_cap = (size_t)256 << 20;
+    ctx->host_pool.idle_cap = (size_t)192 << 20;
+    ctx->host_pool.block_cap = (size_t)64 << 20;
     ctx->num_cus = prop.multiProcessorCount;
     ctx->hbm = (int64_t)prop.totalGlobalMem;
     snprintf(ctx->name, sizeof(ctx->name), "%s (%s)", prop.name, prop.gcnArchName);
@@ -214,6 +314,7 @@ void ctx_release(muse_ctx *ctx)
         (void)hipStreamDestroy(ctx->copy_stream);
     }
     rows_slots_free(ctx);
+    pool_drain(ctx);
     for (auto *ev : {&ctx->events, &ctx->redo_events})
         for (auto &e : *ev) {
             (void)hipEventDestroy(e.first);
@@ -263,6 +364,45 @@ extern "C" int muse_ctx_synchronize(muse_ctx *ctx)
     if (rc)
         return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return MUSE_OK;
+}
+
+extern "C" int muse_ctx_trim(muse_ctx *ctx)
+{
+    int rc = use_device(ctx);
+    if (rc)
+        return rc;
+    pool_drain(ctx);
+    return MUSE_OK;
+}
+
+extern "C" int muse_test_pool_stats(muse_ctx *ctx, int64_t *dev_idle_bytes, int64_t *dev_idle_blocks, int64_t *host_idle_bytes,
+                                    int64_t *host_idle_blocks)
+{
+    if (!ctx)
+        return fail(MUSE_ERR_INVALID, "NULL context");
+    {
+        std::lock_guard<std::mutex> lock(ctx->dev_pool.mu);
+        if (dev_idle_bytes)
+            *dev_idle_bytes = (int64_t)ctx->dev_pool.idle_bytes;
+        if (dev_idle_blocks)
+            *dev_idle_blocks = (int64_t)ctx->dev_pool.idle.size();
+    }
+    {
+        std::lock_guard<std::mutex> lock(ctx->host_pool.mu);
+        if (host_idle_bytes)
+            *host_idle_bytes = (int64_t)ctx->host_pool.idle_bytes;
+        if (host_idle_blocks)
+            *host_idle_blocks = (int64_t)ctx->host_pool.idle.size();
+    }
+    return MUSE_OK;
+}
+
+extern "C" int muse_test_xcorr_repeat(muse_ctx *ctx, int32_t repeat)
+{
+    if (!ctx || repeat < 1 || repeat > 1000)
+        return fail(MUSE_ERR_INVALID, "repeat must be 1 .. 1000");
+    ctx->xcorr_repeat = repeat;
     return MUSE_OK;
 }
 

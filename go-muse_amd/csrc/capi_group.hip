@@ -24,6 +24,17 @@ extern "C" int muse_group_create_f32(muse_ctx *ctx, int64_t capacity_rows, int32
         return fail(MUSE_ERR_UNSUPPORTED, "float32-storage groups are built for series of length 257 .. 16384 (got %d)", N);
     return group_create(ctx, capacity_rows, N, true, out);
 }
+// a fresh allocation's guard is zeroed on the copy stream (no device-wide synchronisation): `uploaded` orders every reader behind it
+static hipError_t zero_guard(muse_group *g, void *base)
+{
+    hipError_t e = hipMemsetAsync(base, 0, GROUP_GUARD * g->elem(), g->ctx->copy_stream);
+    if (e == hipSuccess)
+        e = hipEventRecord(g->uploaded, g->ctx->copy_stream);
+    if (e == hipSuccess)
+        g->upload_pending = true;
+    return e;
+}
+
 static int group_create(muse_ctx *ctx, int64_t capacity_rows, int32_t N, bool f32, muse_group **out)
 {
     if (!out)
@@ -47,12 +58,15 @@ static int group_create(muse_ctx *ctx, int64_t capacity_rows, int32_t N, bool f3
         return fail(MUSE_ERR_HIP, "hipEventCreate failed");
     }
     if (capacity_rows > 0) {
+        // (from the context's allocation cache: a block a freed group handed back carries that group's rows and guard --
+        // the guard is zeroed again here, the rows are only ever read below M)
         void *mem = nullptr;
-        hipError_t e = hipMalloc(&mem, ((size_t)capacity_rows * (size_t)N + GROUP_GUARD) * g->elem());
+        hipError_t e = dmalloc(ctx, &mem, ((size_t)capacity_rows * (size_t)N + GROUP_GUARD) * g->elem());
         if (e == hipSuccess)
-            e = hipMemset(mem, 0, GROUP_GUARD * g->elem());
+            e = zero_guard(g, mem);
         if (e != hipSuccess) {
-            (void)hipFree(mem);
+            dfree(ctx, mem);
+            (void)hipEventDestroy(g->uploaded);
             delete g;
             return fail(MUSE_ERR_NOMEM, "hipMalloc of %lld x %d samples failed: %s", (long long)capacity_rows, N,
                         hipGetErrorString(e));
@@ -71,54 +85,84 @@ static int group_reserve(muse_group *g, int64_t rows)
         return MUSE_OK;
     int64_t ncap = std::max<int64_t>(rows, g->cap * 2);
     void *nr = nullptr;
-    hipError_t e = hipMalloc(&nr, ((size_t)ncap * (size_t)g->N + GROUP_GUARD) * g->elem());
-    if (e == hipSuccess)
-        e = hipMemset(nr, 0, GROUP_GUARD * g->elem());
-    if (e != hipSuccess) {
-        (void)hipFree(nr);
+    hipError_t e = dmalloc(g->ctx, &nr, ((size_t)ncap * (size_t)g->N + GROUP_GUARD) * g->elem());
+    if (e != hipSuccess)
         return fail(MUSE_ERR_NOMEM, "hipMalloc of %lld rows failed: %s", (long long)ncap, hipGetErrorString(e));
-    }
-    nr = (char *)nr + GROUP_GUARD * g->elem();
     HIP_TRY(hipStreamSynchronize(g->ctx->copy_stream)); // uploads into the old allocation have landed
     HIP_TRY(hipStreamSynchronize(g->ctx->stream));      // no kernel is still reading it
+    HIP_TRY(zero_guard(g, nr));
+    nr = (char *)nr + GROUP_GUARD * g->elem();
     if (g->M > 0) {
         HIP_TRY(hipMemcpyAsync(nr, g->base(), (size_t)g->M * (size_t)g->N * g->elem(), hipMemcpyDeviceToDevice,
-                               g->ctx->stream));
-        HIP_TRY(hipStreamSynchronize(g->ctx->stream));
+                               g->ctx->copy_stream));
+        HIP_TRY(hipStreamSynchronize(g->ctx->copy_stream));
     }
     if (g->base())
-        (void)hipFree((char *)g->base() - GROUP_GUARD * g->elem());
+        dfree(g->ctx, (char *)g->base() - GROUP_GUARD * g->elem());
     (g->f32 ? (void *&)g->rows32 : (void *&)g->rows) = nr;
     g->cap = ncap;
     return MUSE_OK;
 }
 
-// enqueue the staged rows' upload (asynchronous); the buffer is reusable after stage_done
-static int group_flush(muse_group *g)
+constexpr size_t STAGE_BYTES = 32u << 20;      // one staging buffer
+constexpr size_t STAGE_FLUSH_BYTES = 1u << 20; // packed rows go out in pieces of at least this size
+
+// the staging pair, borrowed from the context's pool on first use
+static int group_stage_buffers(muse_group *g)
 {
-    if (!g->staged)
+    if (g->stage[0])
         return MUSE_OK;
-    const int64_t first = g->M - g->staged;
-    HIP_TRY(hipMemcpyAsync((char *)g->base() + (size_t)(first * g->stride) * g->elem(), g->stage[g->cur],
-                           (size_t)g->staged * (size_t)g->N * g->elem(), hipMemcpyHostToDevice, g->ctx->copy_stream));
-    HIP_TRY(hipEventRecord(g->stage_done[g->cur], g->ctx->copy_stream));
-    HIP_TRY(hipEventRecord(g->uploaded, g->ctx->copy_stream));
-    g->upload_pending = true;
-    g->staged = 0;
-    g->cur ^= 1;
-    HIP_TRY(hipEventSynchronize(g->stage_done[g->cur])); // the other buffer's last upload has landed
+    g->stage_rows = std::max<int64_t>(1, (int64_t)(STAGE_BYTES / ((size_t)g->N * g->elem())));
+    for (int i = 0; i < 2; i++) {
+        double *buf = nullptr;
+        {
+            std::lock_guard<std::mutex> lock(g->ctx->stage_mu);
+            if (!g->ctx->stage_pool.empty()) {
+                buf = g->ctx->stage_pool.back();
+                g->ctx->stage_pool.pop_back();
+            }
+        }
+        if (!buf)
+            HIP_TRY(hipHostMalloc((void **)&buf, std::max(STAGE_BYTES, (size_t)g->N * g->elem()), hipHostMallocDefault));
+        g->stage[i] = buf;
+        HIP_TRY(hipEventCreateWithFlags(&g->stage_done[i], hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(g->stage_done[i], g->ctx->copy_stream));
+    }
     return MUSE_OK;
 }
 
-// staged rows enqueued for upload, and the compute stream ordered behind every upload enqueued so far: call before
-// anything on the compute stream reads the rows
-int group_ready(muse_group *g)
+// enqueue the upload of the packed rows not sent yet (asynchronous); a full buffer is left for the other one
+static int group_flush(muse_group *g)
 {
+    if (g->staged > g->flushed) {
+        const int64_t k = g->staged - g->flushed, first = g->M - k;
+        HIP_TRY(hipMemcpyAsync((char *)g->base() + (size_t)(first * g->stride) * g->elem(),
+                               (char *)g->stage[g->cur] + (size_t)g->flushed * (size_t)g->N * g->elem(),
+                               (size_t)k * (size_t)g->N * g->elem(), hipMemcpyHostToDevice, g->ctx->copy_stream));
+        HIP_TRY(hipEventRecord(g->stage_done[g->cur], g->ctx->copy_stream));
+        HIP_TRY(hipEventRecord(g->uploaded, g->ctx->copy_stream));
+        g->upload_pending = true;
+        g->flushed = g->staged;
+    }
+    if (g->staged == g->stage_rows && g->stage_rows > 0) {
+        g->staged = g->flushed = 0;
+        g->cur ^= 1;
+        HIP_TRY(hipEventSynchronize(g->stage_done[g->cur])); // the other buffer's last upload has landed
+    }
+    return MUSE_OK;
+}
+
+// packed rows enqueued for upload, and `stream` (the context's compute stream by default) ordered behind every upload
+// enqueued so far: call before anything on that stream reads the rows
+int group_ready(muse_group *g, hipStream_t stream)
+{
+    if (g->win_rows)
+        return fail(MUSE_ERR_INVALID, "the group has an open staging window (muse_group_stage without its commits)");
     int rc = group_flush(g);
     if (rc)
         return rc;
     if (g->upload_pending) {
-        HIP_TRY(hipStreamWaitEvent(g->ctx->stream, g->uploaded, 0));
+        HIP_TRY(hipStreamWaitEvent(stream ? stream : g->ctx->stream, g->uploaded, 0));
         g->upload_pending = false;
     }
     return MUSE_OK;
@@ -133,11 +177,12 @@ extern "C" int muse_group_append(muse_group *g, const double *rows, int64_t coun
     if (row_stride < g->N) // group.go:45-51: one length per group
         return fail(MUSE_ERR_LENGTH, "Timeseries has length %lld, but current group has length %d",
                     (long long)row_stride, g->N);
+    if (g->win_rows)
+        return fail(MUSE_ERR_INVALID, "the group has an open staging window");
     int rc = use_device(g->ctx);
     if (rc)
         return rc;
     const size_t row_bytes = (size_t)g->N * sizeof(double);
-    constexpr size_t STAGE_BYTES = 32u << 20;
     // small appends are staged from the SECOND one on: a group that is uploaded in one call (Muse.Run builds one
     // per call) never needs the staging pair
     bool small = (size_t)count * row_bytes < STAGE_BYTES / 4 && row_bytes <= STAGE_BYTES;
@@ -145,23 +190,10 @@ extern "C" int muse_group_append(muse_group *g, const double *rows, int64_t coun
         small = false;
     if (g->f32) // float32 storage: every append is narrowed on the host into the pinned staging pair (half the PCIe bytes too)
         small = true;
-    if (small && !g->stage[0]) { // borrow the staging pair from the context's pool
-        g->stage_rows = std::max<int64_t>(1, (int64_t)(STAGE_BYTES / ((size_t)g->N * g->elem())));
-        for (int i = 0; i < 2; i++) {
-            double *buf = nullptr;
-            {
-                std::lock_guard<std::mutex> lock(g->ctx->stage_mu);
-                if (!g->ctx->stage_pool.empty()) {
-                    buf = g->ctx->stage_pool.back();
-                    g->ctx->stage_pool.pop_back();
-                }
-            }
-            if (!buf)
-                HIP_TRY(hipHostMalloc((void **)&buf, STAGE_BYTES, hipHostMallocDefault));
-            g->stage[i] = buf;
-            HIP_TRY(hipEventCreateWithFlags(&g->stage_done[i], hipEventDisableTiming));
-            HIP_TRY(hipEventRecord(g->stage_done[i], g->ctx->copy_stream));
-        }
+    if (small) {
+        rc = group_stage_buffers(g);
+        if (rc)
+            return rc;
     }
     if (!small) { // a slab: upload it directly (synchronously: the caller's memory is not retained)
         rc = group_flush(g);
@@ -179,12 +211,8 @@ extern "C" int muse_group_append(muse_group *g, const double *rows, int64_t coun
         g->M += count;
         return MUSE_OK;
     }
+    const int64_t flush_rows = std::max<int64_t>(1, (int64_t)(STAGE_FLUSH_BYTES / ((size_t)g->N * g->elem())));
     for (int64_t r = 0; r < count; r++) {
-        if (g->staged == g->stage_rows) {
-            rc = group_flush(g);
-            if (rc)
-                return rc;
-        }
         if (g->M + 1 > g->cap) {
             // growing re-allocates and copies on the stream; staged rows are uploaded first
             rc = group_flush(g);
@@ -203,6 +231,82 @@ extern "C" int muse_group_append(muse_group *g, const double *rows, int64_t coun
         }
         g->staged++;
         g->M++;
+        if (g->staged == g->stage_rows || g->staged - g->flushed >= flush_rows) {
+            rc = group_flush(g);
+            if (rc)
+                return rc;
+        }
+    }
+    return MUSE_OK;
+}
+
+// ---- the caller packs rows straight into pinned memory (no staging copy inside the library, any number of filling threads)
+extern "C" int muse_group_stage(muse_group *g, int64_t count, double **window, int64_t *granted)
+{
+    if (!g || !window || !granted || count < 0)
+        return fail(MUSE_ERR_INVALID, "bad staging arguments");
+    *window = nullptr;
+    *granted = 0;
+    if (count == 0)
+        return MUSE_OK;
+    if (g->f32)
+        return fail(MUSE_ERR_UNSUPPORTED, "staging windows hold float64 rows (float32-storage groups narrow inside muse_group_append)");
+    if (g->win_rows)
+        return fail(MUSE_ERR_INVALID, "the group already has an open staging window");
+    int rc = use_device(g->ctx);
+    if (rc)
+        return rc;
+    rc = group_stage_buffers(g);
+    if (rc)
+        return rc;
+    rc = group_flush(g);
+    if (rc)
+        return rc;
+    if (g->staged > 0) { // a window starts a buffer of its own
+        g->staged = g->flushed = 0;
+        g->cur ^= 1;
+        HIP_TRY(hipEventSynchronize(g->stage_done[g->cur]));
+    } else {
+        HIP_TRY(hipEventSynchronize(g->stage_done[g->cur])); // (a window the previous call filled: its copies have landed)
+    }
+    const int64_t k = std::min<int64_t>(count, g->stage_rows);
+    rc = group_reserve(g, g->M + k);
+    if (rc)
+        return rc;
+    g->win_rows = k;
+    g->win_committed = 0;
+    *window = g->stage[g->cur];
+    *granted = k;
+    return MUSE_OK;
+}
+
+extern "C" int muse_group_commit(muse_group *g, int64_t first, int64_t count)
+{
+    if (!g || first < 0 || count < 0)
+        return fail(MUSE_ERR_INVALID, "bad commit arguments");
+    if (count == 0)
+        return MUSE_OK;
+    std::lock_guard<std::mutex> lock(g->win_mu); // (the filling threads commit their own pieces)
+    if (!g->win_rows || first + count > g->win_rows || g->win_committed + count > g->win_rows)
+        return fail(MUSE_ERR_INVALID, "commit of rows [%lld, %lld) outside the open window of %lld rows", (long long)first,
+                    (long long)(first + count), (long long)g->win_rows);
+    int rc = use_device(g->ctx);
+    if (rc)
+        return rc;
+    HIP_TRY(hipMemcpyAsync(g->rows + (g->M + first) * g->stride, g->stage[g->cur] + first * g->N,
+                           (size_t)count * (size_t)g->N * sizeof(double), hipMemcpyHostToDevice, g->ctx->copy_stream));
+    g->win_committed += count;
+    if (g->win_committed == g->win_rows) { // the window is complete: its rows join the group
+        HIP_TRY(hipEventRecord(g->stage_done[g->cur], g->ctx->copy_stream));
+        HIP_TRY(hipEventRecord(g->uploaded, g->ctx->copy_stream));
+        g->upload_pending = true;
+        g->M += g->win_rows;
+        g->staged = g->flushed = g->win_rows;
+        g->win_rows = g->win_committed = 0;
+        if (g->staged == g->stage_rows) { // (as group_flush leaves a full buffer; the next user waits for its event)
+            g->staged = g->flushed = 0;
+            g->cur ^= 1;
+        }
     }
     return MUSE_OK;
 }
@@ -305,7 +409,7 @@ void group_release(muse_group *g)
     if (g->uploaded)
         (void)hipEventDestroy(g->uploaded);
     if (g->base())
-        (void)hipFree((char *)g->base() - GROUP_GUARD * g->elem());
+        dfree(g->ctx, (char *)g->base() - GROUP_GUARD * g->elem());
     for (int i = 0; i < 2; i++) {
         if (g->stage[i]) { // back to the context's pool (the stream is idle: no upload reads it any more)
             std::lock_guard<std::mutex> lock(g->ctx->stage_mu);

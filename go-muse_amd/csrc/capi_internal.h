@@ -14,8 +14,10 @@
 #include <cstring>
 #include <ctime>
 #include <limits>
+#include <map>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 
@@ -36,6 +38,19 @@ int fail(int status, const char *fmt, ...);
     } while (0)
 
 // ----------------------------------------------------------------- handles
+// Per-context cache of device and pinned-host allocations (capi_context.hip: dmalloc / dfree / hmalloc / hfree).  hipMalloc,
+// hipFree (a device-wide synchronisation each) and hipHostMalloc (hundreds of microseconds) were most of a cold
+// NewGroup -> Add -> NewBatch -> Run -> free cycle (profiles/r06_cold_path.txt); a freed block is kept by size class and handed to
+// the next request of that class.  A block handed back must no longer be in use by the device (the handles synchronise
+// their streams before they free, as they did in front of hipFree).
+struct MemPool {
+    std::mutex mu;
+    std::unordered_map<void *, size_t> size_of;            // every block this pool allocated (in use or cached): its class size
+    std::multimap<size_t, void *> idle;                     // cached blocks by class size
+    size_t idle_bytes = 0;
+    size_t idle_cap = 0;                                    // cached bytes kept at most
+    size_t block_cap = 0;                                   // larger blocks are never cached
+};
 constexpr int PROBE_WINDOWS = 4096; // clock probe (muse_test_clock_probe_*): windows its pinned buffer holds; the window count and the stop flag sit behind them
 struct muse_ctx {
     int device = 0;
@@ -74,6 +89,7 @@ struct muse_ctx {
     int64_t screen_min_rows = 0;
     double screen_e_scale = 1.0;     // test hook (muse_test_set_screen_bound_scale): scales the error bound, to exercise the guard
     int variant = 0;
+    int xcorr_repeat = 1; // measurement hook (muse_test_xcorr_repeat)
     // measurement hook (muse_test_clock_probe_*): a one-wave kernel on its own stream sampling the shader clock
     hipStream_t probe_stream = nullptr;
     unsigned long long *probe_buf = nullptr; // pinned host memory: [2 * PROBE_WINDOWS] ticks + the window count behind them
@@ -84,7 +100,9 @@ struct muse_ctx {
     char pci[32] = {0}; // PCI bus id of the device ("0000:05:00.0"): tells two contexts on one GPU from two GPUs
     // muse_batch_run_rows (capi_rows.hip): idle slots (RowsSlot *) -- pinned staging, device rows, score buffers, a pinned
     // result record and an event each -- so that a Muse.Run allocates nothing in steady state
-    bool rows_always_copy = false; // test hook (muse_test_rows_always_copy): never let a kernel read the pinned staging buffer
+    MemPool dev_pool, host_pool;   // dmalloc / hmalloc
+    std::mutex timing_mu;          // events / redo_events (LaunchTimer::end from concurrent muse_batch_run_rows callers)
+    std::atomic<bool> rows_always_copy{false}; // test hook (muse_test_rows_always_copy): never let a kernel read the pinned staging buffer
     std::vector<void *> rows_slots;
     std::mutex rows_mu;
     // Handles may be released in any order (Go finalizers, Python GC): the
@@ -102,15 +120,21 @@ struct muse_group {
     void *base() const { return f32 ? (void *)rows32 : (void *)rows; }
     int64_t cap = 0, M = 0, stride = 0; // M counts staged rows too
     int32_t N = 0;
-    // Small appends (Group.Add calls muse_group_append once per Series) are packed into
-    // two pinned staging buffers and uploaded asynchronously on the context's stream, one
-    // buffer in flight while the other fills; kernels on that stream are ordered behind.
+    // Appends that are small (Group.Add calls muse_group_append once per Series) are packed into two pinned staging buffers
+    // borrowed from the context's pool and uploaded asynchronously on the context's copy stream: a piece goes out whenever
+    // STAGE_FLUSH_BYTES have gathered (so the copies run beside the caller's next Adds), the buffers alternate when one is
+    // full; kernels are ordered behind the copies through `uploaded`.
     double *stage[2] = {nullptr, nullptr};
     hipEvent_t stage_done[2] = {nullptr, nullptr};
     int cur = 0;
-    int64_t staged = 0;     // rows waiting in stage[cur]
+    int64_t staged = 0;     // rows packed into stage[cur] (already counted in M)
+    int64_t flushed = 0;    // of those, the rows whose upload is enqueued
     int64_t stage_rows = 0; // capacity of one staging buffer, in rows
     int small_appends = 0;  // the first small append goes straight to the device (Muse.Run: one upload per group)
+    // an open window (muse_group_stage): the caller is filling rows [0, win_rows) of stage[cur] itself -- from any number of
+    // threads -- and commits them piece by piece (muse_group_commit); they become rows [M, M + win_rows) of the group
+    int64_t win_rows = 0, win_committed = 0;
+    std::mutex win_mu;
     // uploads run on the context's copy stream; `uploaded` is recorded behind the last one enqueued and the compute stream
     // waits for it (hipStreamWaitEvent) before a kernel reads the rows: an append of NEW rows overlaps a running score pass
     hipEvent_t uploaded = nullptr;
@@ -132,6 +156,10 @@ struct muse_spectrum {
 struct muse_batch {
     muse_ctx *ctx = nullptr;
     muse_group *g = nullptr;
+    // the stream this batch's kernels and copies are enqueued on: the context's, except for the slot batches of
+    // muse_batch_run_rows (capi_rows.hip), which own one each so that concurrent callers' kernels overlap
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream() const { return own_stream ? own_stream : ctx->stream; }
     int32_t N = 0, n = 0, logn = 0;
     muse_spectrum *sp = nullptr; // owner of the five tables below (the pointers are copies)
     double *c1 = nullptr;
@@ -214,7 +242,8 @@ struct LaunchTimer {
     muse_ctx *ctx;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     bool redo; // the bracket of the launches that redo listed pairs behind a fused launch (muse_ctx_redo_time)
-    explicit LaunchTimer(muse_ctx *c, bool redo_ = false) : ctx(c), redo(redo_) {}
+    hipStream_t stream; // the stream the bracketed launch goes to
+    explicit LaunchTimer(muse_ctx *c, bool redo_ = false, hipStream_t s = nullptr) : ctx(c), redo(redo_), stream(s ? s : c->stream) {}
     LaunchTimer(const LaunchTimer &) = delete;
     LaunchTimer &operator=(const LaunchTimer &) = delete;
     hipError_t begin()
@@ -225,15 +254,16 @@ struct LaunchTimer {
         if (e == hipSuccess)
             e = hipEventCreate(&e1);
         if (e == hipSuccess)
-            e = hipEventRecord(e0, ctx->stream);
+            e = hipEventRecord(e0, stream);
         return e;
     }
     hipError_t end()
     {
         if (!e0 || !e1)
             return hipSuccess;
-        const hipError_t e = hipEventRecord(e1, ctx->stream);
+        const hipError_t e = hipEventRecord(e1, stream);
         if (e == hipSuccess) {
+            std::lock_guard<std::mutex> lock(ctx->timing_mu); // (muse_batch_run_rows: any number of callers on one context)
             (redo ? ctx->redo_events : ctx->events).emplace_back(e0, e1);
             e0 = e1 = nullptr;
         }
@@ -249,9 +279,16 @@ struct LaunchTimer {
 };
 
 // ---- helpers shared by the parts
+hipError_t pool_alloc(muse_ctx *ctx, bool host, void **out, size_t bytes); // capi_context.hip
+void pool_free(muse_ctx *ctx, bool host, void *p);
+void pool_drain(muse_ctx *ctx);                                            // frees every cached block (context teardown, tests)
+template <class T> inline hipError_t dmalloc(muse_ctx *ctx, T **out, size_t bytes) { return pool_alloc(ctx, false, (void **)out, bytes); }
+template <class T> inline hipError_t hmalloc(muse_ctx *ctx, T **out, size_t bytes) { return pool_alloc(ctx, true, (void **)out, bytes); }
+inline void dfree(muse_ctx *ctx, void *p) { pool_free(ctx, false, p); }
+inline void hfree(muse_ctx *ctx, void *p) { pool_free(ctx, true, p); }
 void fill_twiddle(std::vector<double2> &v, size_t i, long long num, long long den);
 void ctx_release(muse_ctx *ctx);                       // capi_context.hip: drops one reference, frees the context with the last
-int group_ready(muse_group *g);                        // capi_group.hip: staged rows uploaded, the compute stream behind the copies
+int group_ready(muse_group *g, hipStream_t stream = nullptr); // capi_group.hip: staged rows uploaded, the compute stream behind the copies
 void group_release(muse_group *g);
 void rows_slots_free(muse_ctx *ctx);                   // capi_rows.hip: the idle slots of muse_batch_run_rows (streams idle)
 int ilog2(int64_t n);                                  // capi_batch.hip

@@ -114,10 +114,10 @@ extern "C" int muse_batch_score_many(muse_batch *const *bs, int32_t R)
     p.zscratch = ctx->zscratch;
     p.zslots = ctx->zslots;
     if (2 * p.npairs > b0->ovf_cap) {
-        (void)hipFree(b0->ovf_list);
+        dfree(b0->ctx, b0->ovf_list);
         b0->ovf_list = nullptr;
         b0->ovf_cap = 0;
-        HIP_TRY(hipMalloc(&b0->ovf_list, (size_t)(2 * p.npairs) * sizeof(long long)));
+        HIP_TRY(dmalloc(b0->ctx, &b0->ovf_list, (size_t)(2 * p.npairs) * sizeof(long long)));
         b0->ovf_cap = 2 * p.npairs;
     }
     p.ovf_count = b0->ovf_count;

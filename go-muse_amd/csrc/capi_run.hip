@@ -88,72 +88,72 @@ std::vector<muse_record> heap_select(std::vector<muse_record> cands, int64_t top
 int ensure_select_ws(muse_batch *b, int64_t M, int64_t G, bool with_gid, int K, bool on_device)
 {
     if (with_gid && M > b->gid_cap) {
-        (void)hipFree(b->gid_dev);
+        dfree(b->ctx, b->gid_dev);
         b->gid_dev = nullptr;
         b->gid_cap = 0;
         b->gid_valid = false;
-        HIP_TRY(hipMalloc(&b->gid_dev, (size_t)M * sizeof(int)));
+        HIP_TRY(dmalloc(b->ctx, &b->gid_dev, (size_t)M * sizeof(int)));
         b->gid_cap = M;
     }
     if (G > b->grp_cap) {
-        (void)hipFree(b->gw.key);
-        (void)hipFree(b->gw.first);
-        (void)hipFree(b->gw.win);
-        (void)hipFree(b->rec);
-        (void)hipFree(b->selkey);
+        dfree(b->ctx, b->gw.key);
+        dfree(b->ctx, b->gw.first);
+        dfree(b->ctx, b->gw.win);
+        dfree(b->ctx, b->rec);
+        dfree(b->ctx, b->selkey);
         b->gw = GroupWork{nullptr, nullptr, nullptr};
         b->rec = nullptr;
         b->selkey = nullptr;
         b->grp_cap = 0;
-        HIP_TRY(hipMalloc(&b->gw.key, (size_t)G * sizeof(unsigned long long)));
-        HIP_TRY(hipMalloc(&b->gw.first, (size_t)G * sizeof(long long)));
-        HIP_TRY(hipMalloc(&b->gw.win, (size_t)G * sizeof(long long)));
-        HIP_TRY(hipMalloc(&b->rec, (size_t)G * sizeof(muse_record)));
-        HIP_TRY(hipMalloc(&b->selkey, (size_t)G * sizeof(unsigned long long)));
+        HIP_TRY(dmalloc(b->ctx, &b->gw.key, (size_t)G * sizeof(unsigned long long)));
+        HIP_TRY(dmalloc(b->ctx, &b->gw.first, (size_t)G * sizeof(long long)));
+        HIP_TRY(dmalloc(b->ctx, &b->gw.win, (size_t)G * sizeof(long long)));
+        HIP_TRY(dmalloc(b->ctx, &b->rec, (size_t)G * sizeof(muse_record)));
+        HIP_TRY(dmalloc(b->ctx, &b->selkey, (size_t)G * sizeof(unsigned long long)));
         b->grp_cap = G;
     }
     const int64_t nb = (G + TOPN_CHUNK - 1) / TOPN_CHUNK;
     if (nb > b->cnt_cap) {
-        (void)hipFree(b->cnt);
+        dfree(b->ctx, b->cnt);
         b->cnt = nullptr;
         b->cnt_cap = 0;
-        HIP_TRY(hipMalloc(&b->cnt, (size_t)nb * sizeof(int)));
+        HIP_TRY(dmalloc(b->ctx, &b->cnt, (size_t)nb * sizeof(int)));
         b->cnt_cap = nb;
     }
     if (nb * K > b->cand_cap) {
-        (void)hipFree(b->cand);
+        dfree(b->ctx, b->cand);
         b->cand = nullptr;
         b->cand_cap = 0;
-        HIP_TRY(hipMalloc(&b->cand, (size_t)(nb * K) * sizeof(muse_record)));
+        HIP_TRY(dmalloc(b->ctx, &b->cand, (size_t)(nb * K) * sizeof(muse_record)));
         b->cand_cap = nb * K;
     }
     if (!on_device && G > b->rec_host_cap) { // the exact feed: every group's record and selection key through pinned memory
         if (b->rec_host)
-            (void)hipHostFree(b->rec_host);
+            hfree(b->ctx, b->rec_host);
         if (b->key_host)
-            (void)hipHostFree(b->key_host);
+            hfree(b->ctx, b->key_host);
         b->rec_host = nullptr;
         b->key_host = nullptr;
         b->rec_host_cap = 0;
         const int64_t cap = std::max<int64_t>(G, 64);
-        HIP_TRY(hipHostMalloc((void **)&b->rec_host, (size_t)cap * sizeof(muse_record), hipHostMallocDefault));
-        HIP_TRY(hipHostMalloc((void **)&b->key_host, (size_t)cap * sizeof(unsigned long long), hipHostMallocDefault));
+        HIP_TRY(hmalloc(b->ctx, &b->rec_host, (size_t)cap * sizeof(muse_record)));
+        HIP_TRY(hmalloc(b->ctx, &b->key_host, (size_t)cap * sizeof(unsigned long long)));
         b->rec_host_cap = cap;
     }
     if (on_device && nb > b->cnt_host_cap) {
         if (b->cnt_host)
-            (void)hipHostFree(b->cnt_host); // (hipHostFree(NULL) leaves a sticky error behind)
+            hfree(b->ctx, b->cnt_host); // (hipHostFree(NULL) leaves a sticky error behind)
         b->cnt_host = nullptr;
         b->cnt_host_cap = 0;
-        HIP_TRY(hipHostMalloc((void **)&b->cnt_host, (size_t)nb * sizeof(int), hipHostMallocDefault));
+        HIP_TRY(hmalloc(b->ctx, &b->cnt_host, (size_t)nb * sizeof(int)));
         b->cnt_host_cap = nb;
     }
     if (on_device && nb * K > b->cand_host_cap) {
         if (b->cand_host)
-            (void)hipHostFree(b->cand_host);
+            hfree(b->ctx, b->cand_host);
         b->cand_host = nullptr;
         b->cand_host_cap = 0;
-        HIP_TRY(hipHostMalloc((void **)&b->cand_host, (size_t)(nb * K) * sizeof(muse_record), hipHostMallocDefault));
+        HIP_TRY(hmalloc(b->ctx, &b->cand_host, (size_t)(nb * K) * sizeof(muse_record)));
         b->cand_host_cap = nb * K;
     }
     return MUSE_OK;
@@ -169,7 +169,7 @@ int upload_group_ids(muse_batch *b, const int32_t *group_id, int64_t M)
     if (!same) {
         b->gid_host.assign(group_id, group_id + M);
         HIP_TRY(hipMemcpyAsync(b->gid_dev, b->gid_host.data(), (size_t)M * sizeof(int), hipMemcpyHostToDevice,
-                               b->ctx->stream));
+                               b->stream()));
         b->gid_valid = true;
     }
     return MUSE_OK;
@@ -231,17 +231,17 @@ int run_select(muse_batch *b, const int32_t *group_id, int32_t G_in, int64_t ser
     sp.sign_filter = sign_filter;
     sp.series_offset = series_offset;
     sp.include = screened ? b->include : nullptr;
-    HIP_TRY(launch_group_reduce(sp, b->gw, b->rec, b->selkey, ctx->stream));
+    HIP_TRY(launch_group_reduce(sp, b->gw, b->rec, b->selkey, b->stream()));
     std::vector<muse_record> cands;
     if (on_device) {
         const int64_t nb = (G + TOPN_CHUNK - 1) / TOPN_CHUNK;
-        HIP_TRY(launch_topn(b->rec, b->selkey, (int)G, K, b->cand, b->cnt, ctx->stream));
+        HIP_TRY(launch_topn(b->rec, b->selkey, (int)G, K, b->cand, b->cnt, b->stream()));
         const int *cnt = b->cnt_host;
         const muse_record *cand = b->cand_host;
-        HIP_TRY(hipMemcpyAsync(b->cnt_host, b->cnt, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(b->cnt_host, b->cnt, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, b->stream()));
         HIP_TRY(hipMemcpyAsync(b->cand_host, b->cand, (size_t)(nb * K) * sizeof(muse_record), hipMemcpyDeviceToHost,
-                               ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
+                               b->stream()));
+        HIP_TRY(hipStreamSynchronize(b->stream()));
         for (int64_t blk = 0; blk < nb; blk++)
             for (int r = 0; r < cnt[(size_t)blk]; r++)
                 cands.push_back(cand[(size_t)(blk * K + r)]);
@@ -254,10 +254,10 @@ int run_select(muse_batch *b, const int32_t *group_id, int32_t G_in, int64_t ser
     } else {
         const muse_record *rec = b->rec_host;
         const unsigned long long *key = b->key_host;
-        HIP_TRY(hipMemcpyAsync(b->rec_host, b->rec, (size_t)G * sizeof(muse_record), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(b->rec_host, b->rec, (size_t)G * sizeof(muse_record), hipMemcpyDeviceToHost, b->stream()));
         HIP_TRY(hipMemcpyAsync(b->key_host, b->selkey, (size_t)G * sizeof(unsigned long long), hipMemcpyDeviceToHost,
-                               ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
+                               b->stream()));
+        HIP_TRY(hipStreamSynchronize(b->stream()));
         for (int64_t g = 0; g < G; g++)
             if (key[(size_t)g] != 0ull)
                 cands.push_back(rec[(size_t)g]);
@@ -357,11 +357,11 @@ extern "C" int muse_batch_run_groups(muse_batch *b, const int32_t *group_id, int
     sp.abs_scores = abs_scores ? 1 : 0;
     sp.series_offset = series_offset;
     sp.partial = 1;
-    HIP_TRY(launch_group_reduce(sp, b->gw, b->rec, b->selkey, ctx->stream));
+    HIP_TRY(launch_group_reduce(sp, b->gw, b->rec, b->selkey, b->stream()));
     std::vector<unsigned long long> st((size_t)G);
-    HIP_TRY(hipMemcpyAsync(out_records, b->rec, (size_t)G * sizeof(muse_record), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(st.data(), b->selkey, (size_t)G * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpyAsync(out_records, b->rec, (size_t)G * sizeof(muse_record), hipMemcpyDeviceToHost, b->stream()));
+    HIP_TRY(hipMemcpyAsync(st.data(), b->selkey, (size_t)G * sizeof(unsigned long long), hipMemcpyDeviceToHost, b->stream()));
+    HIP_TRY(hipStreamSynchronize(b->stream()));
     for (int32_t g = 0; g < G; g++)
         out_state[g] = (uint8_t)st[(size_t)g];
     return MUSE_OK;

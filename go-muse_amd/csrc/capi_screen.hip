@@ -96,58 +96,58 @@ static int screen_prepare(muse_batch *b, int32_t top_n, const int *gid_dev, int6
         return rc;
     const int64_t npairs = (M + 1) / 2;
     if (M > b->scr_cap) {
-        (void)hipFree(b->scr_flags);
-        (void)hipFree(b->scr_var);
-        (void)hipFree(b->include);
+        dfree(b->ctx, b->scr_flags);
+        dfree(b->ctx, b->scr_var);
+        dfree(b->ctx, b->include);
         b->scr_flags = nullptr;
         b->scr_var = nullptr;
         b->include = nullptr;
         b->scr_cap = 0;
-        HIP_TRY(hipMalloc(&b->scr_flags, (size_t)M * sizeof(unsigned)));
-        HIP_TRY(hipMalloc(&b->scr_var, (size_t)M * sizeof(double)));
-        HIP_TRY(hipMalloc(&b->include, (size_t)M));
+        HIP_TRY(dmalloc(b->ctx, &b->scr_flags, (size_t)M * sizeof(unsigned)));
+        HIP_TRY(dmalloc(b->ctx, &b->scr_var, (size_t)M * sizeof(double)));
+        HIP_TRY(dmalloc(b->ctx, &b->include, (size_t)M));
         b->scr_cap = M;
     }
     const int64_t nkeys = screen_select_scratch(gid_dev ? G : M, top_n);
     if (gid_dev && G > b->scr_gcap) {
-        (void)hipFree(b->scr_gmay);
-        (void)hipFree(b->scr_gkplus);
-        (void)hipFree(b->scr_gcert);
+        dfree(b->ctx, b->scr_gmay);
+        dfree(b->ctx, b->scr_gkplus);
+        dfree(b->ctx, b->scr_gcert);
         b->scr_gmay = b->scr_gkplus = nullptr;
         b->scr_gcert = nullptr;
         b->scr_gcap = 0;
-        HIP_TRY(hipMalloc(&b->scr_gmay, (size_t)G * sizeof(unsigned long long)));
-        HIP_TRY(hipMalloc(&b->scr_gkplus, (size_t)G * sizeof(unsigned long long)));
-        HIP_TRY(hipMalloc(&b->scr_gcert, (size_t)G * sizeof(int)));
+        HIP_TRY(dmalloc(b->ctx, &b->scr_gmay, (size_t)G * sizeof(unsigned long long)));
+        HIP_TRY(dmalloc(b->ctx, &b->scr_gkplus, (size_t)G * sizeof(unsigned long long)));
+        HIP_TRY(dmalloc(b->ctx, &b->scr_gcert, (size_t)G * sizeof(int)));
         b->scr_gcap = G;
     }
     if (nkeys > b->scr_keys_cap) {
-        (void)hipFree(b->scr_keys);
+        dfree(b->ctx, b->scr_keys);
         b->scr_keys = nullptr;
         b->scr_keys_cap = 0;
-        HIP_TRY(hipMalloc(&b->scr_keys, (size_t)nkeys * sizeof(unsigned long long)));
+        HIP_TRY(dmalloc(b->ctx, &b->scr_keys, (size_t)nkeys * sizeof(unsigned long long)));
         b->scr_keys_cap = nkeys;
     }
     if (!b->refine_host)
-        HIP_TRY(hipHostMalloc((void **)&b->refine_host, sizeof(int), hipHostMallocDefault));
+        HIP_TRY(hmalloc(b->ctx, &b->refine_host, sizeof(int)));
     if (!b->err_host)
-        HIP_TRY(hipHostMalloc((void **)&b->err_host, sizeof(unsigned long long), hipHostMallocDefault));
+        HIP_TRY(hmalloc(b->ctx, &b->err_host, sizeof(unsigned long long)));
     if (!b->err_dev)
-        HIP_TRY(hipMalloc(&b->err_dev, sizeof(unsigned long long)));
+        HIP_TRY(dmalloc(b->ctx, &b->err_dev, sizeof(unsigned long long)));
     if (4 * npairs > b->est_cap) { // two estimates per listed pair; the list holds the selection's pairs plus the guard sample
-        (void)hipFree(b->est_save);
+        dfree(b->ctx, b->est_save);
         b->est_save = nullptr;
         b->est_cap = 0;
-        HIP_TRY(hipMalloc(&b->est_save, (size_t)(4 * npairs) * sizeof(double)));
+        HIP_TRY(dmalloc(b->ctx, &b->est_save, (size_t)(4 * npairs) * sizeof(double)));
         b->est_cap = 4 * npairs;
     }
     // the list takes the selection's pairs (at most npairs) plus the guard sample (about npairs / 1024, not de-duplicated
     // against the selection): 2 npairs entries, the same capacity the fp64 pass's hand-off list has
     if (2 * npairs > b->ovf_cap) {
-        (void)hipFree(b->ovf_list);
+        dfree(b->ctx, b->ovf_list);
         b->ovf_list = nullptr;
         b->ovf_cap = 0;
-        HIP_TRY(hipMalloc(&b->ovf_list, (size_t)(2 * npairs) * sizeof(long long)));
+        HIP_TRY(dmalloc(b->ctx, &b->ovf_list, (size_t)(2 * npairs) * sizeof(long long)));
         b->ovf_cap = 2 * npairs;
     }
     if (b->sp->xmax < 0.0) { // once per reference: max |X[f]| (X holds the non-redundant half of a real signal's spectrum)

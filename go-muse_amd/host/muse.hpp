@@ -17,15 +17,21 @@
 #pragma once
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstdint>
+#include <cstring>
+#include <functional>
 #include <limits>
 #include <map>
 #include <memory>
+#include <memory_resource>
 #include <mutex>
 #include <random>
 #include <stdexcept>
 #include <string>
+#include <string_view>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -103,21 +109,121 @@ public:
             snprintf(buf, sizeof(buf), "%016llx%016llx", (unsigned long long)rng(), (unsigned long long)rng());
             labels_ = NewLabels({{DefaultLabel, buf}});
         }
+        uid_ = labels_->ID(); // (labels are immutable: formed once, not on every Group.Add / indexLabelValues)
     }
     int Length() const { return (int)y_.size(); }
     const std::vector<double> &Values() const { return y_; }
-    LabelsPtr Labels() const { return labels_; }
-    std::string UID() const { return labels_->ID(); } // series.go:40-42
+    const LabelsPtr &Labels() const { return labels_; }
+    const std::string &UID() const { return uid_; } // series.go:40-42
 
 private:
     std::vector<double> y_;
     LabelsPtr labels_;
+    std::string uid_;
 };
 using SeriesPtr = std::shared_ptr<Series>;
 inline SeriesPtr NewSeries(std::vector<double> y, LabelsPtr labels = nullptr)
 {
     return std::make_shared<Series>(std::move(y), std::move(labels));
 }
+
+// ------------------------------------------------ a few parked host threads
+// Packing a Group's rows into the pinned upload window (muse_group_stage) is a memory copy of the whole Group: one
+// thread moves ~10 GB/s where PCIe takes 57.  The reference fans its work out over goroutines (muse_batch.go:99-130);
+// here a handful of parked threads take the pieces of a window.  run(n, fn) calls fn(0) .. fn(n - 1), the caller
+// taking part, and returns when all have finished; one job at a time.
+namespace detail {
+class Workers {
+public:
+    static Workers &get()
+    {
+        static Workers w;
+        return w;
+    }
+    int width() const { return (int)threads_.size() + 1; }
+    void run(int n, const std::function<void(int)> &fn)
+    {
+        if (n <= 1 || threads_.empty()) {
+            for (int i = 0; i < n; i++)
+                fn(i);
+            return;
+        }
+        std::lock_guard<std::mutex> one(job_mu_);
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            fn_ = &fn;
+            total_ = n;
+            next_.store(1);
+            pending_ = n - 1;
+            generation_++;
+        }
+        cv_.notify_all();
+        fn(0);
+        for (;;) { // the caller keeps taking tasks, then waits for the ones still running
+            const int i = next_.fetch_add(1);
+            if (i >= n)
+                break;
+            fn(i);
+            std::lock_guard<std::mutex> lock(mu_);
+            pending_--;
+        }
+        std::unique_lock<std::mutex> lock(mu_);
+        done_cv_.wait(lock, [&] { return pending_ == 0; });
+        fn_ = nullptr;
+    }
+    ~Workers()
+    {
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : threads_)
+            t.join();
+    }
+
+private:
+    Workers()
+    {
+        const unsigned hw = std::thread::hardware_concurrency();
+        const int extra = (int)std::min(7u, hw > 1 ? hw / 2 : 0u);
+        for (int i = 0; i < extra; i++)
+            threads_.emplace_back([this] { loop(); });
+    }
+    void loop()
+    {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lock(mu_);
+        for (;;) {
+            cv_.wait(lock, [&] { return stop_ || generation_ != seen; });
+            if (stop_)
+                return;
+            seen = generation_;
+            for (;;) {
+                const std::function<void(int)> *fn = fn_;
+                if (!fn)
+                    break;
+                const int i = next_.fetch_add(1);
+                if (i >= total_)
+                    break;
+                lock.unlock();
+                (*fn)(i);
+                lock.lock();
+                if (--pending_ == 0)
+                    done_cv_.notify_all();
+            }
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::mutex mu_, job_mu_;
+    std::condition_variable cv_, done_cv_;
+    const std::function<void(int)> *fn_ = nullptr;
+    std::atomic<int> next_{0};
+    int total_ = 0, pending_ = 0;
+    uint64_t generation_ = 0;
+    bool stop_ = false;
+};
+} // namespace detail
 
 // ------------------------------------------------------ engine (muse_ctx)
 class Engine {
@@ -189,25 +295,25 @@ public:
         for (auto &s : series) {
             if (s->Labels()->Keys().empty())
                 throw Error(MUSE_ERR_INVALID, "Invalid Series with no labels");
-            const std::string uid = s->UID();
-            if (registry_.count(uid))
-                throw Error(MUSE_ERR_INVALID,
-                            "Series with label:values, " + uid + ", already exists within group, " + Name);
+            const std::string &uid = s->UID();
             if (order_.empty())
                 n_ = s->Length();
-            else if (s->Length() != n_)
+            else if (s->Length() != n_ && !registry_.count(uid))
                 throw Error(MUSE_ERR_LENGTH, "Timeseries has length " + std::to_string(s->Length()) +
                                                  ", but current group has length " + std::to_string(n_));
-            registry_[uid] = order_.size();
+            // (the key views the Series' own uid string: the Series lives in order_ as long as the registry does)
+            if (!registry_.try_emplace(std::string_view(uid), order_.size()).second)
+                throw Error(MUSE_ERR_INVALID,
+                            "Series with label:values, " + uid + ", already exists within group, " + Name);
             order_.push_back(s);
         }
     }
     std::vector<SeriesPtr> FilterByLabelValues(const Labels &labels) const // group.go:60-71
     {
         std::vector<SeriesPtr> out;
-        auto it = index_.find(labels.ID());
-        if (it != index_.end())
-            for (size_t i : it->second)
+        auto it = index_ids_.find(labels.ID());
+        if (it != index_ids_.end())
+            for (size_t i : index_members_[(size_t)it->second])
                 out.push_back(order_[i]);
         return out;
     }
@@ -218,8 +324,9 @@ public:
                                             std::vector<int32_t> *group_id_out = nullptr)
     {
         // The partition depends on the label names and on the series alone, and series are only ever added (group.go has no
-        // removal): a repeated Run with the same grouping over the same series (the reference's benchmark loops,
-        // muse_batch_test.go:127-131, 157-161) reuses it instead of rebuilding 5 000 label strings per Run.
+        // removal, and the registry is private here): a repeated Run with the same grouping over the same series (the
+        // reference's benchmark loops, muse_batch_test.go:127-131, 157-161) reuses it instead of rebuilding 5 000 label
+        // strings per Run.
         std::string key = std::to_string(order_.size());
         for (auto &l : groupByLabels)
             key += '\x1f' + l;
@@ -229,22 +336,34 @@ public:
             return index_distinct_;
         }
         std::vector<LabelsPtr> distinct;
-        index_.clear();
-        std::unordered_map<std::string, int32_t> gid;
+        index_ids_.clear();
+        index_members_.clear();
         std::vector<int32_t> gid_of(order_.size(), 0);
-        if (group_id_out)
-            group_id_out->assign(order_.size(), 0);
+        const bool by_uid = groupByLabels.empty();
+        if (by_uid && !order_.empty())
+            groupByLabels = order_[0]->Labels()->Keys(); // group.go:88 (first series' keys)
+        std::sort(groupByLabels.begin(), groupByLabels.end()); // labels.go:60: ID sorts the names it is given
+        std::string guid;
         for (size_t i = 0; i < order_.size(); i++) {
             auto &s = order_[i];
-            std::string guid;
-            if (!groupByLabels.empty()) {
-                guid = s->Labels()->ID(groupByLabels);
-            } else {
-                guid = s->UID();
-                groupByLabels = s->Labels()->Keys(); // group.go:88 (first series' keys)
+            const std::string *id = &s->UID();
+            if (!by_uid) { // Labels.ID(groupByLabels), labels.go:54-73, into a reused buffer
+                guid.clear();
+                const LabelMap &m = s->Labels()->Map();
+                for (auto &name : groupByLabels) {
+                    auto it = m.find(name);
+                    if (it != m.end()) {
+                        if (!guid.empty())
+                            guid += ',';
+                        guid += name;
+                        guid += ':';
+                        guid += it->second;
+                    }
+                }
+                id = &guid;
             }
-            auto it = gid.find(guid);
-            if (it == gid.end()) {
+            auto it = index_ids_.find(*id);
+            if (it == index_ids_.end()) {
                 LabelMap lv;
                 for (auto &name : groupByLabels) {
                     std::string v;
@@ -252,9 +371,10 @@ public:
                         lv[name] = v;
                 }
                 distinct.push_back(NewLabels(lv));
-                it = gid.emplace(guid, (int32_t)gid.size()).first;
+                it = index_ids_.emplace(*id, (int32_t)index_ids_.size()).first;
+                index_members_.emplace_back();
             }
-            index_[guid].push_back(i);
+            index_members_[(size_t)it->second].push_back(i);
             gid_of[i] = it->second;
         }
         if (group_id_out)
@@ -303,7 +423,7 @@ public:
     }
 
     // device residency: rows are uploaded once and appended to (muse_group_append)
-    muse_group *device(const std::shared_ptr<Engine> &eng)
+    muse_group *device(const std::shared_ptr<Engine> &eng, const std::function<void()> *side = nullptr)
     {
         if (!dev_ || eng_ != eng) {
             if (dev_)
@@ -313,25 +433,69 @@ public:
             uploaded_ = 0;
             check(muse_group_create(eng->handle(), (int64_t)order_.size(), n_ > 0 ? n_ : 1, &dev_));
         }
-        append_rows(dev_, uploaded_, order_.size());
+        append_rows(dev_, uploaded_, order_.size(), side);
         uploaded_ = order_.size();
         return dev_;
     }
 
 private:
-    // series [first, last) to a device group in slabs of up to 32 MB: one C-ABI call per slab, not per Series
-    void append_rows(muse_group *dev, size_t first, size_t last)
+    // series [first, last) to a device group through the library's pinned windows (muse_group_stage / _commit): every Series is
+    // copied ONCE, straight into pinned memory, by a few threads in pieces of ~256 KB; a piece that completes the packed
+    // prefix of the window hands that prefix -- its own rows and every finished piece behind them, as ONE copy -- to the
+    // copy stream, so the rows cross PCIe while the next pieces are packed and the copies stay few and large.
+    // `side` (optional) runs on the calling thread while the other threads pack: host work that does not need the rows
+    // (Batch.Run partitions the labels there).
+    void append_rows(muse_group *dev, size_t first, size_t last, const std::function<void()> *side = nullptr)
     {
-        if (first >= last)
-            return;
-        const size_t per = std::max<size_t>(1, std::min<size_t>(last - first, ((size_t)32 << 20) / (8 * (size_t)n_)));
-        std::vector<double> slab(per * (size_t)n_);
-        for (size_t i = first; i < last; i += per) {
-            const size_t k = std::min(per, last - i);
-            for (size_t r = 0; r < k; r++)
-                std::copy(order_[i + r]->Values().begin(), order_[i + r]->Values().end(), slab.begin() + r * (size_t)n_);
-            check(muse_group_append(dev, slab.data(), (int64_t)k, n_));
+        const size_t row_bytes = sizeof(double) * (size_t)n_;
+        bool side_done = side == nullptr;
+        while (first < last) {
+            double *win = nullptr;
+            int64_t granted = 0;
+            check(muse_group_stage(dev, (int64_t)(last - first), &win, &granted));
+            // (measured on the MI355X box, tools/probe/upload_probe.cpp: one H2D copy command costs ~13 us whatever its size --
+            // 19.2 MB cross in 365 us as one copy, 409 us in 4 MB copies, 1 116 us in 256 KB copies -- while packing wants
+            // pieces small enough to spread over the threads: pack in 256 KB pieces, commit in runs of >= 4 MB)
+            const size_t piece = std::max<size_t>(1, ((size_t)256 << 10) / row_bytes);
+            const int npieces = (int)(((size_t)granted + piece - 1) / piece);
+            const int commit_pieces = (int)std::max<size_t>(1, ((size_t)4 << 20) / (piece * row_bytes));
+            std::vector<char> done((size_t)npieces, 0);
+            int watermark = 0; // pieces [0, watermark) are committed
+            int status = MUSE_OK;
+            std::string message;
+            std::mutex commit_mu;
+            const int extra = side_done ? 0 : 1;
+            detail::Workers::get().run(npieces + extra, [&](int task) {
+                if (task < extra) { // (task 0 runs on the calling thread)
+                    (*side)();
+                    return;
+                }
+                const int p = task - extra;
+                const size_t lo = (size_t)p * piece, hi = std::min((size_t)granted, lo + piece);
+                for (size_t r = lo; r < hi; r++)
+                    memcpy(win + r * (size_t)n_, order_[first + r]->Values().data(), row_bytes);
+                std::lock_guard<std::mutex> lock(commit_mu);
+                done[(size_t)p] = 1;
+                int w = watermark;
+                while (w < npieces && done[(size_t)w])
+                    w++;
+                if (w > watermark && (w == npieces || w - watermark >= commit_pieces)) { // (every row is committed even after a failure: the window has to close)
+                    const size_t clo = (size_t)watermark * piece, chi = std::min((size_t)granted, (size_t)w * piece);
+                    const int rc = muse_group_commit(dev, (int64_t)clo, (int64_t)(chi - clo));
+                    if (rc && status == MUSE_OK) {
+                        status = rc;
+                        message = muse_last_error(); // (thread-local: read it on the thread that failed)
+                    }
+                    watermark = w;
+                }
+            });
+            side_done = true;
+            if (status)
+                throw Error(status, message);
+            first += (size_t)granted;
         }
+        if (!side_done)
+            (*side)();
     }
     void free_shards()
     {
@@ -342,8 +506,11 @@ private:
     }
     int n_ = 0;
     std::vector<SeriesPtr> order_;
-    std::unordered_map<std::string, size_t> registry_;
-    std::unordered_map<std::string, std::vector<size_t>> index_;
+    // (nodes from a monotonic arena: no allocation per Add, one release in the destructor)
+    std::pmr::monotonic_buffer_resource registry_arena_{(size_t)64 << 10};
+    std::pmr::unordered_map<std::string_view, size_t> registry_{&registry_arena_};
+    std::unordered_map<std::string, int32_t> index_ids_;     // label-values id -> partition index (indexLabelValues)
+    std::vector<std::vector<size_t>> index_members_;          // partition index -> its series, in insertion order
     std::string index_key_;                  // the grouping index_ / index_gid_ / index_distinct_ were built for (series count + label names)
     std::vector<int32_t> index_gid_;
     std::vector<LabelsPtr> index_distinct_;
@@ -483,22 +650,27 @@ public:
                 throw Error(MUSE_ERR_LENGTH, s->UID() + " from comparison group series does not have the same "
                                                         "length as the reference");
         n = (int)muse_next_pow2((double)ref->Length());
-        muse_group *probe = nullptr; // validates the reference even when the group is empty
-        check(muse_group_create(eng_->handle(), 0, ref->Length() > 0 ? ref->Length() : 1, &probe));
-        muse_batch *b = nullptr;
-        int rc = muse_batch_create(eng_->handle(), probe, ref_.data(), (int32_t)ref_.size(), &b);
-        std::string msg = rc ? muse_last_error() : "";
-        muse_batch_free(b);
-        muse_group_free(probe);
-        if (rc)
+        // the reference is validated and transformed ONCE, here (muse_batch.go:35-47), against an empty group; the batch over
+        // the Comparison group's resident rows shares that spectrum (muse_batch_create_like)
+        check(muse_group_create(eng_->handle(), 0, ref->Length() > 0 ? ref->Length() : 1, &probe_));
+        int rc = muse_batch_create(eng_->handle(), probe_, ref_.data(), (int32_t)ref_.size(), &template_);
+        if (rc) {
+            std::string msg = muse_last_error();
+            muse_group_free(probe_);
+            probe_ = nullptr;
             throw Error(rc, msg);
+        }
     }
     ~Batch()
     {
         muse_batch_free(batch_);
         for (auto &sb : shard_batches_)
             muse_batch_free(sb.batch);
+        muse_batch_free(template_);
+        muse_group_free(probe_);
     }
+    Batch(const Batch &) = delete;
+    Batch &operator=(const Batch &) = delete;
     int n = 0;
     GroupPtr Comparison;
     ResultsPtr Results_;
@@ -508,7 +680,15 @@ public:
     void Run(const std::vector<std::string> &groupByLabels)
     {
         std::vector<int32_t> gid;
-        auto lvs = Comparison->indexLabelValues(groupByLabels, &gid);
+        std::vector<LabelsPtr> lvs;
+        if (engines_.empty()) {
+            // rows added since the last Run go up now; the calling thread partitions the labels (group.go:76-104) while the
+            // other host threads pack them into the pinned window
+            const std::function<void()> side = [&] { lvs = Comparison->indexLabelValues(groupByLabels, &gid); };
+            Comparison->device(eng_, &side);
+        } else {
+            lvs = Comparison->indexLabelValues(groupByLabels, &gid);
+        }
         if (lvs.empty())
             return;
         if ((int64_t)lvs.size() <= EXACT_FEED_MAX_GROUPS) {
@@ -744,7 +924,7 @@ private:
         if (!batch_ || batch_group_ != dg) {
             muse_batch_free(batch_);
             batch_ = nullptr;
-            check(muse_batch_create(eng_->handle(), dg, ref_.data(), (int32_t)ref_.size(), &batch_));
+            check(muse_batch_create_like(template_, dg, &batch_));
             batch_group_ = dg;
         }
     }
@@ -752,6 +932,8 @@ private:
     std::vector<double> ref_;
     muse_batch *batch_ = nullptr;
     muse_group *batch_group_ = nullptr;
+    muse_group *probe_ = nullptr;    // empty group the template batch is bound to
+    muse_batch *template_ = nullptr; // owns the reference spectrum
 };
 inline std::shared_ptr<Batch> NewBatch(SeriesPtr ref, GroupPtr comp, ResultsPtr results, int cc)
 {
@@ -795,17 +977,24 @@ public:
     {
         if (compGraphs.empty())
             return;
-        std::vector<double> rows;
-        for (auto &s : compGraphs) {
-            if (s->Length() != refN_) // muse.go:68-70
-                throw Error(MUSE_ERR_LENGTH, "Encountered a comparison graph with differing length than the reference");
-            rows.insert(rows.end(), s->Values().begin(), s->Values().end());
-        }
-        // one ABI call: upload, fused kernel, group maximum, record back (muse_batch_run_rows; signed scores: muse.go:72-76).
+        // one ABI call: the series are gathered straight into the call's pinned buffer (no packed copy here), then upload,
+        // fused kernel, group maximum, record back (muse_batch_run_row_ptrs; signed scores: muse.go:72-76).
         // Results.Update applies passed() to the group's Score exactly as the reference does (results.go:55-72).
+        const double *small[64];
+        std::vector<const double *> many;
+        const double **rows = small;
+        if (compGraphs.size() > 64) {
+            many.resize(compGraphs.size());
+            rows = many.data();
+        }
+        for (size_t i = 0; i < compGraphs.size(); i++) {
+            if (compGraphs[i]->Length() != refN_) // muse.go:68-70
+                throw Error(MUSE_ERR_LENGTH, "Encountered a comparison graph with differing length than the reference");
+            rows[i] = compGraphs[i]->Values().data();
+        }
         muse_record win{};
         uint8_t state = 0;
-        check(muse_batch_run_rows(template_, rows.data(), (int64_t)compGraphs.size(), refN_, 0, &win, &state));
+        check(muse_batch_run_row_ptrs(template_, rows, (int64_t)compGraphs.size(), 0, &win, &state));
         if (state == 1 && win.series >= 0)
             Results_->Update(Score{compGraphs[(size_t)win.series]->Labels(), win.lag, win.score});
     }

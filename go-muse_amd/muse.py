@@ -72,6 +72,20 @@ class Engine:
         """test hook (include/muse_hip_test.h): scales the error bound the filter-and-refine Run assumes"""
         B.check(B.load().muse_test_set_screen_bound_scale(self._h, float(scale)))
 
+    def trim(self):
+        """muse_ctx_trim: hands the context's cached device / pinned blocks back to the system"""
+        B.check(B.load().muse_ctx_trim(self._h))
+
+    def pool_stats(self):
+        """test hook: (device idle bytes, device idle blocks, pinned idle bytes, pinned idle blocks) of the allocation cache"""
+        v = [ctypes.c_int64(0) for _ in range(4)]
+        B.check(B.load().muse_test_pool_stats(self._h, *[ctypes.byref(x) for x in v]))
+        return tuple(int(x.value) for x in v)
+
+    def xcorr_repeat(self, repeat):
+        """measurement hook: muse_xcorr_groups launches its kernel `repeat` times back to back"""
+        B.check(B.load().muse_test_xcorr_repeat(self._h, int(repeat)))
+
     def rows_always_copy(self, on):
         """test hook: muse_batch_run_rows copies even the smallest groups to HBM instead of letting the kernel read the pinned buffer"""
         B.check(B.load().muse_test_rows_always_copy(self._h, 1 if on else 0))
@@ -240,6 +254,34 @@ class DeviceGroup:
         stride = rows.strides[0] // 8 if rows.shape[0] > 1 else self.N
         B.check(B.load().muse_group_append(self._h, rows.ctypes.data_as(B._dp), rows.shape[0], stride))
 
+    def stage(self, count):
+        """muse_group_stage: a window of pinned host memory for up to `count` more rows -> a (granted, N) float64 array VIEW of
+        it; fill it, then commit(first, k) every piece (any order, each row once).  The rows join the group with the last commit."""
+        win, granted = B._dp(), ctypes.c_int64(0)
+        B.check(B.load().muse_group_stage(self._h, int(count), ctypes.byref(win), ctypes.byref(granted)))
+        k = int(granted.value)
+        if k == 0:
+            return np.zeros((0, self.N))
+        return np.ctypeslib.as_array(win, shape=(k, self.N))
+
+    def commit(self, first, count):
+        B.check(B.load().muse_group_commit(self._h, int(first), int(count)))
+
+    def append_staged(self, series, piece_rows=None):
+        """Group.Add for a list of separate per-series arrays: each is copied ONCE, straight into the pinned window, and the
+        window goes out piece by piece beside the copying (the host mirrors' upload path)"""
+        i, total = 0, len(series)
+        while i < total:
+            win = self.stage(total - i)
+            k = win.shape[0]
+            step = piece_rows or max(1, (512 << 10) // (8 * self.N))
+            for lo in range(0, k, step):
+                hi = min(k, lo + step)
+                for r in range(lo, hi):
+                    win[r, :] = series[i + r]
+                self.commit(lo, hi - lo)
+            i += k
+
     @property
     def M(self):
         m, n = ctypes.c_int64(0), ctypes.c_int32(0)
@@ -375,6 +417,19 @@ class DeviceBatch:
         state = ctypes.c_uint8(0)
         B.check(B.load().muse_batch_run_rows(self._h, rows.ctypes.data_as(B._dp), rows.shape[0], stride,
                                              1 if abs_scores else 0, B.recptr(rec), ctypes.byref(state)))
+        return rec[0], int(state.value)
+
+    def run_row_ptrs(self, series, abs_scores=False):
+        """muse_batch_run_row_ptrs: the same with one pointer per series (a list of separate contiguous float64 arrays of the
+        reference's length): gathered straight into the call's pinned buffer"""
+        arrs = [np.ascontiguousarray(a, dtype=np.float64) for a in series]
+        for a in arrs:
+            if a.ndim != 1 or a.shape[0] != self.dgroup.N:
+                raise MuseError(B.MUSE_ERR_LENGTH, "Encountered a comparison graph with differing length than the reference")
+        ptrs = (B._dp * max(len(arrs), 1))(*[a.ctypes.data_as(B._dp) for a in arrs])
+        rec = np.zeros(1, dtype=B.RECORD_DTYPE)
+        state = ctypes.c_uint8(0)
+        B.check(B.load().muse_batch_run_row_ptrs(self._h, ptrs, len(arrs), 1 if abs_scores else 0, B.recptr(rec), ctypes.byref(state)))
         return rec[0], int(state.value)
 
     def run_groups(self, group_id, G, series_offset=0, abs_scores=True):

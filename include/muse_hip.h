@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define MUSE_HIP_ABI_VERSION 4
+#define MUSE_HIP_ABI_VERSION 5
 
 typedef enum muse_status {
     MUSE_OK = 0,
@@ -81,6 +81,11 @@ int muse_ctx_create(int32_t device, muse_ctx **out);
 int muse_device_count(int32_t *count);
 int muse_ctx_destroy(muse_ctx *ctx);
 int muse_ctx_synchronize(muse_ctx *ctx);
+/* A context keeps the device and pinned-host blocks its groups and batches hand back (by size class, at most 1 GB of HBM
+ * and 192 MB of pinned memory) and gives them to the next group / batch of the same shape: a steady
+ * NewGroup -> Add -> NewBatch -> Run -> free cycle then makes no hipMalloc / hipFree / hipHostMalloc (each a device-wide
+ * synchronisation or hundreds of microseconds).  muse_ctx_trim returns every cached block to the system. */
+int muse_ctx_trim(muse_ctx *ctx);
 /* name: >= 64 bytes.  Any out pointer may be NULL. */
 int muse_ctx_device_info(muse_ctx *ctx, char *name, int32_t name_cap,
                          int32_t *compute_units, int64_t *hbm_bytes);
@@ -146,6 +151,17 @@ int muse_group_create_f32(muse_ctx *ctx, int64_t capacity_rows, int32_t N,
  * This is what Group.Add calls once per Series (count = 1) or per slab. */
 int muse_group_append(muse_group *g, const double *rows, int64_t count,
                       int64_t row_stride);
+/* The same without a staging copy inside the library (Group.Add "stages series into a C-allocated pinned
+ * buffer"): muse_group_stage opens a WINDOW of pinned host memory for up to `count` more rows -- *granted <= count of them,
+ * row-major, N doubles per row, at *window -- which the caller fills itself, from as many threads (goroutines) as it likes:
+ * the copy out of the Series' own slices (series.go:20) is the only one the host makes.  muse_group_commit(first, k) hands
+ * rows [first, first + k) of the window to the copy stream as soon as they are filled (any thread, any order, every row of
+ * the window exactly once); the upload of the first pieces runs beside the filling of the later ones, and with the last
+ * commit the rows join the group as rows [M, M + granted).  Two windows alternate: the next muse_group_stage returns while
+ * the previous window is still crossing PCIe.  One window at a time per group; no other call on the group between
+ * _stage and its last _commit.  float64 groups only (MUSE_ERR_UNSUPPORTED for float32-storage groups). */
+int muse_group_stage(muse_group *g, int64_t count, double **window, int64_t *granted);
+int muse_group_commit(muse_group *g, int64_t first, int64_t count);
 /* create + append in one call */
 int muse_group_upload(muse_ctx *ctx, const double *rows, int64_t M, int32_t N,
                       int64_t row_stride, muse_group **out);
@@ -200,6 +216,12 @@ int muse_batch_create_like(muse_batch *src, muse_group *g, muse_batch **out);
  * context); any number of host threads may call it on one tmpl at the same time (muse_test.go:203-214). */
 int muse_batch_run_rows(muse_batch *tmpl, const double *rows, int64_t M, int64_t row_stride,
                         int32_t abs_scores, muse_record *out_winner, uint8_t *out_state);
+/* The same with one pointer per row (rows[r] -> the N samples of row r): the comparison series of a Muse.Run are separate
+ * slices (muse.go:46, compGraphs []*Series), gathered here straight into the call's pinned buffer instead of being packed
+ * by the caller first.  (cgo: an array of Go pointers may only cross when the slices are pinned, runtime.Pinner;
+ * INTEGRATION.md keeps the packed form for Go.) */
+int muse_batch_run_row_ptrs(muse_batch *tmpl, const double *const *rows, int64_t M,
+                            int32_t abs_scores, muse_record *out_winner, uint8_t *out_state);
 int muse_batch_fft_len(muse_batch *b, int32_t *n);
 /* The batch's x (muse_batch.go:47): n/2+1 complex128, interleaved re,im. */
 int muse_batch_spectrum(muse_batch *b, double *out);

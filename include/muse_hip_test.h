@@ -52,6 +52,14 @@ int muse_test_wave_argmax(muse_ctx *ctx, const double *ccA, const double *ccB, d
  * runs both). */
 int muse_test_rows_always_copy(muse_ctx *ctx, int32_t always_copy);
 
+/* The context's allocation cache (muse_ctx_trim): bytes and blocks it holds idle, device and pinned host.  Any out
+ * pointer may be NULL. */
+int muse_test_pool_stats(muse_ctx *ctx, int64_t *dev_idle_bytes, int64_t *dev_idle_blocks, int64_t *host_idle_bytes,
+                         int64_t *host_idle_blocks);
+/* Measurement hook: muse_xcorr_groups launches its kernel `repeat` times back to back (same results) -- a sustained burst
+ * for the clock probe and for HIP-event timing without the host's work between calls (tools/clock_trace_two_sided.py). */
+int muse_test_xcorr_repeat(muse_ctx *ctx, int32_t repeat);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,7 +32,7 @@ def test_header_symbols_all_exported(muse):
     for name in sorted(declared):
         assert hasattr(lib, name), "libmuse_hip.so does not export %s" % name
     assert declared == set(muse.binding.SIGNATURES), "binding.py and the headers disagree"
-    assert muse.binding.load().muse_abi_version() == 4
+    assert muse.binding.load().muse_abi_version() == 5
     # nothing is exported that no header declares
     import subprocess
     out = subprocess.check_output(["nm", "-D", "--defined-only", muse.build.LIB], text=True)
