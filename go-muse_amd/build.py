@@ -13,8 +13,8 @@ ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libmuse_hip.so")
-SOURCES = ["xcorr_kernels.hip", "xcorr_r16_fold.hip", "xcorr_r16_occ4.hip", "xcorr_stockham.hip", "xcorr_two_sided.hip", "xcorr_small.hip", "xcorr_long.hip", "xcorr_real.hip", "xcorr_r16_screen.hip", "xcorr_screen_stk.hip", "reduce_kernels.hip", "diag_kernels.hip", "capi_context.hip", "capi_group.hip", "capi_batch.hip", "capi_run.hip", "capi_rows.hip", "capi_screen.hip", "capi_many.hip", "capi_xcorr.hip"]
-HEADERS = [os.path.join(CSRC, "xcorr_kernels.h"), os.path.join(CSRC, "fft_device.h"), os.path.join(CSRC, "r16_device.h"), os.path.join(CSRC, "fold_device.h"), os.path.join(CSRC, "foldk_device.h"), os.path.join(CSRC, "long_device.h"), os.path.join(CSRC, "stk_device.h"), os.path.join(CSRC, "small_device.h"), os.path.join(CSRC, "two_device.h"), os.path.join(CSRC, "capi_internal.h"), os.path.join(ROOT, "include", "muse_hip.h"), os.path.join(ROOT, "include", "muse_hip_test.h")]
+SOURCES = ["xcorr_kernels.hip", "xcorr_r16_fold.hip", "xcorr_r16_occ4.hip", "xcorr_stockham.hip", "xcorr_two_sided.hip", "xcorr_small.hip", "xcorr_long.hip", "xcorr_real.hip", "xcorr_huge.hip", "xcorr_r16_screen.hip", "xcorr_screen_stk.hip", "reduce_kernels.hip", "diag_kernels.hip", "capi_context.hip", "capi_group.hip", "capi_batch.hip", "capi_run.hip", "capi_rows.hip", "capi_screen.hip", "capi_many.hip", "capi_huge.hip", "capi_xcorr.hip"]
+HEADERS = [os.path.join(CSRC, "xcorr_kernels.h"), os.path.join(CSRC, "xcorr_huge.h"), os.path.join(CSRC, "fft_device.h"), os.path.join(CSRC, "r16_device.h"), os.path.join(CSRC, "fold_device.h"), os.path.join(CSRC, "foldk_device.h"), os.path.join(CSRC, "long_device.h"), os.path.join(CSRC, "stk_device.h"), os.path.join(CSRC, "small_device.h"), os.path.join(CSRC, "two_device.h"), os.path.join(CSRC, "capi_internal.h"), os.path.join(ROOT, "include", "muse_hip.h"), os.path.join(ROOT, "include", "muse_hip_test.h")]
 
 
 def _hipcc():

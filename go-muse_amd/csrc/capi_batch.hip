@@ -3,6 +3,7 @@
 // parts share).  Host-side orchestration only; there is no CPU compute fallback anywhere: without a gfx950 device every
 // compute entry point returns MUSE_ERR_NO_DEVICE.
 #include "capi_internal.h"
+#include "xcorr_huge.h"
 
 using namespace muse;
 
@@ -118,8 +119,9 @@ extern "C" int muse_batch_create(muse_ctx *ctx, muse_group *g, const double *ref
     if (N < 2)
         return fail(MUSE_ERR_INVALID, "series length 1 has no sample standard deviation");
     const int64_t n = muse_next_pow2((double)N); // muse_batch.go:35
-    if (n > GENERIC_MAX_N)
-        return fail(MUSE_ERR_UNSUPPORTED, "FFT length %lld > %d is not built", (long long)n, GENERIC_MAX_N);
+    if (n > HUGE_MAX_N)
+        return fail(MUSE_ERR_UNSUPPORTED, "FFT length %lld > %d is not built", (long long)n, HUGE_MAX_N);
+    const bool huge = n > GENERIC_MAX_N; // series longer than 65 536 samples: xcorr_huge.hip
     muse_batch *b = new (std::nothrow) muse_batch();
     if (!b)
         return fail(MUSE_ERR_NOMEM, "host allocation failed");
@@ -131,7 +133,7 @@ extern "C" int muse_batch_create(muse_ctx *ctx, muse_group *g, const double *ref
     b->n = (int32_t)n;
     b->logn = ilog2(n);
     hipError_t e = dmalloc(ctx, &b->ovf_count, 2 * sizeof(int)); // [0] overflow-pair count, [1] dynamic work counter
-    if (e == hipSuccess)
+    if (e == hipSuccess && !huge)
         e = ensure_gscratch(ctx, n);
     muse_spectrum *sp = new (std::nothrow) muse_spectrum();
     if (!sp)
@@ -139,6 +141,29 @@ extern "C" int muse_batch_create(muse_ctx *ctx, muse_group *g, const double *ref
     b->sp = sp;
     if (e == hipSuccess)
         e = dmalloc(ctx, &sp->X, (size_t)(n / 2 + 1) * sizeof(double2));
+    if (huge) {
+        // the spectrum in natural order (muse_batch_spectrum) and as the lane-ordered multiplier rows of huge_rows: the only
+        // two tables these lengths use (no fp32 screening copy, no time-domain copy, no indicator correlation)
+        if (e == hipSuccess)
+            e = dmalloc(ctx, &sp->xcp, (size_t)n * sizeof(double2));
+        if (e != hipSuccess) {
+            muse_batch_free(b);
+            return fail(MUSE_ERR_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e));
+        }
+        adopt_spectrum(b);
+        int zero = 0;
+        rc = huge_reference(ctx, ref, N, (int)n, sp->X, sp->xcp, &zero);
+        if (rc) {
+            muse_batch_free(b);
+            return rc;
+        }
+        if (zero) { // muse_batch.go:39-41
+            muse_batch_free(b);
+            return fail(MUSE_ERR_ZERO_STD, "Invalid input query, Standard deviation of zero");
+        }
+        *out = b;
+        return MUSE_OK;
+    }
     if (e == hipSuccess)
         e = dmalloc(ctx, &sp->xc, (size_t)n * sizeof(double2));
     if (e == hipSuccess)
@@ -344,6 +369,12 @@ extern "C" int muse_batch_score(muse_batch *b)
     rc = ensure_scores(b);
     if (rc)
         return rc;
+    if (b->n > GENERIC_MAX_N) { // series longer than 65 536 samples: a sequence of chip-wide kernels per batch of pairs (xcorr_huge.hip)
+        if (b->g->f32)
+            return fail(MUSE_ERR_UNSUPPORTED, "float32-storage groups run on the default kernels only (FFT lengths 512 ... 16384)");
+        b->scores_exact = true;
+        return huge_score(b);
+    }
     // long series work in the context's scratch buffer: its pointer must not be swapped (a concurrent
     // muse_batch_create growing it) between reading it and enqueueing the launch
     std::unique_lock<std::mutex> scratch_lock(ctx->stage_mu, std::defer_lock);
@@ -488,7 +519,9 @@ extern "C" int muse_batch_kernel_name(muse_batch *b, char *name, int32_t cap)
     // (the names rocprofv3 prints for the instantiations automatic selection launches: profiles/r*_counters.json is keyed by them)
     char k[96] = "xcorr_fused_generic";
     const bool padded = b->N < b->n;
-    if (b->n == 4096)
+    if (b->n > GENERIC_MAX_N) // (the pass is a sequence of kernels: the one that moves the most bytes)
+        snprintf(k, sizeof(k), "huge_rows<false>");
+    else if (b->n == 4096)
         snprintf(k, sizeof(k), "xcorr_fused_n4096_fold<false, %s, %s>", padded ? "true" : "false", b->g->f32 ? "true" : "false");
     else if (b->n == 8192 && !b->g->f32)
         snprintf(k, sizeof(k), "xcorr_fused_real8k<%s>", padded ? "true" : "false");

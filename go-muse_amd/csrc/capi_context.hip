@@ -314,6 +314,7 @@ void ctx_release(muse_ctx *ctx)
         (void)hipStreamDestroy(ctx->copy_stream);
     }
     rows_slots_free(ctx);
+    huge_free(ctx);
     pool_drain(ctx);
     for (auto *ev : {&ctx->events, &ctx->redo_events})
         for (auto &e : *ev) {

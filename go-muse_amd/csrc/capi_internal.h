@@ -51,6 +51,14 @@ struct MemPool {
     size_t idle_cap = 0;                                    // cached bytes kept at most
     size_t block_cap = 0;                                   // larger blocks are never cached
 };
+// FFT lengths 2^17 ... 2^20 (xcorr_huge.hip, capi_huge.hip): twiddle tables per length, the work buffer of one batch of pairs,
+// per-pair multiplier tables (two-sided xCorr), chunk sums / flags / tile maxima; grown on demand under muse_ctx::huge_mu
+struct HugeWork {
+    double2 *thi[4] = {nullptr, nullptr, nullptr, nullptr}, *tlo[4] = {nullptr, nullptr, nullptr, nullptr};
+    double2 *Y = nullptr, *T = nullptr;
+    double *part = nullptr, *sfin = nullptr, *sfin_x = nullptr, *amax = nullptr;
+    size_t Y_bytes = 0, T_bytes = 0, part_bytes = 0, sfin_bytes = 0, sfin_x_bytes = 0, amax_bytes = 0;
+};
 constexpr int PROBE_WINDOWS = 4096; // clock probe (muse_test_clock_probe_*): windows its pinned buffer holds; the window count and the stop flag sit behind them
 struct muse_ctx {
     int device = 0;
@@ -101,6 +109,8 @@ struct muse_ctx {
     // muse_batch_run_rows (capi_rows.hip): idle slots (RowsSlot *) -- pinned staging, device rows, score buffers, a pinned
     // result record and an event each -- so that a Muse.Run allocates nothing in steady state
     MemPool dev_pool, host_pool;   // dmalloc / hmalloc
+    HugeWork huge;                 // series longer than 65 536 samples
+    std::mutex huge_mu;
     std::mutex timing_mu;          // events / redo_events (LaunchTimer::end from concurrent muse_batch_run_rows callers)
     std::atomic<bool> rows_always_copy{false}; // test hook (muse_test_rows_always_copy): never let a kernel read the pinned staging buffer
     std::vector<void *> rows_slots;
@@ -292,6 +302,12 @@ int group_ready(muse_group *g, hipStream_t stream = nullptr); // capi_group.hip:
 void group_release(muse_group *g);
 void rows_slots_free(muse_ctx *ctx);                   // capi_rows.hip: the idle slots of muse_batch_run_rows (streams idle)
 int ilog2(int64_t n);                                  // capi_batch.hip
+// capi_huge.hip: FFT lengths above GENERIC_MAX_N up to HUGE_MAX_N (xcorr_huge.h)
+void huge_free(muse_ctx *ctx);
+int huge_reference(muse_ctx *ctx, const double *ref_host, int N, int n, double2 *X, double2 *table, int *zero_std);
+int huge_score(muse_batch *b);
+int huge_pairs(muse_ctx *ctx, const double *xrows, int64_t xstride, int Nx, int normalize_x, double x_scale, const double *yrows,
+               int64_t ystride, int Ny, int normalize_y, int64_t M, int n, double cc_scale, double *mv, int *lag, int *nil, double *cc);
 void adopt_spectrum(muse_batch *b);                    // the batch's table pointers from its muse_spectrum
 int build_spectrum(muse_ctx *ctx, const double *ref_host, int N, int n, int normalize, double x_scale,
                           double xc_scale, double2 *X, double2 *xc, float2 *xcf, double *xs, int *zero_std);

@@ -3,6 +3,7 @@
 // parts share).  Host-side orchestration only; there is no CPU compute fallback anywhere: without a gfx950 device every
 // compute entry point returns MUSE_ERR_NO_DEVICE.
 #include "capi_internal.h"
+#include "xcorr_huge.h"
 
 using namespace muse;
 
@@ -22,9 +23,9 @@ static int single_pair(muse_ctx *ctx, const double *x, int lenx, const double *y
         return fail(MUSE_ERR_INVALID, "bad single-pair arguments");
     if ((normalize_x && lenx < 2) || (normalize_y && leny < 2))
         return fail(MUSE_ERR_INVALID, "series length 1 has no sample standard deviation");
-    if (n > GENERIC_MAX_N || (!is_pow2(n) && n > 8192))
+    if (n > HUGE_MAX_N || (!is_pow2(n) && n > 8192))
         return fail(MUSE_ERR_UNSUPPORTED, "FFT length %d is not built (powers of two up to %d, any n up to 8192)", n,
-                    GENERIC_MAX_N);
+                    HUGE_MAX_N);
     double *dx = nullptr, *dy = nullptr, *dcc = nullptr, *dmv = nullptr;
     int *dlag = nullptr, *dstat = nullptr;
     double2 *dX = nullptr, *dxc = nullptr, *dscr = nullptr;
@@ -49,7 +50,20 @@ static int single_pair(muse_ctx *ctx, const double *x, int lenx, const double *y
     SP_TRY(hipMalloc(&dlag, sizeof(int)));
     SP_TRY(hipMalloc(&dstat, sizeof(int)));
     SP_TRY(hipMemcpyAsync(dy, y, (size_t)leny * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    if (is_pow2(n) && n >= 2) {
+    if (n > GENERIC_MAX_N) { // series longer than 65 536 samples: the pairwise form of xcorr_huge.hip, one pair
+        SP_TRY(hipMalloc(&dx, (size_t)lenx * sizeof(double)));
+        SP_TRY(hipMemcpyAsync(dx, x, (size_t)lenx * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        rc = huge_pairs(ctx, dx, lenx, lenx, normalize_x, x_scale, dy, leny, leny, normalize_y, 1, n, cc_scale, dmv, dlag, dstat, dcc);
+        if (rc) {
+            (void)hipStreamSynchronize(ctx->stream);
+            cleanup();
+            return rc;
+        }
+        SP_TRY(hipMemcpyAsync(&lg, dlag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        SP_TRY(hipMemcpyAsync(&val, dmv, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        SP_TRY(hipMemcpyAsync(&nil, dstat, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        SP_TRY(hipStreamSynchronize(ctx->stream));
+    } else if (is_pow2(n) && n >= 2) {
         // FFT path: the same device code the batch uses (generic kernel)
         SP_TRY(hipMalloc(&dX, (size_t)(n / 2 + 1) * sizeof(double2)));
         SP_TRY(hipMalloc(&dxc, (size_t)n * sizeof(double2)));
@@ -99,6 +113,8 @@ static int single_pair(muse_ctx *ctx, const double *x, int lenx, const double *y
     }
     if (cc && !nil)
         SP_TRY(hipMemcpy(cc, dcc, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    if (cc && !nil && n > GENERIC_MAX_N && val != val) // (a NaN / Inf series enters the long-series transform as zeros: every cc is NaN in the reference)
+        std::fill(cc, cc + n, std::numeric_limits<double>::quiet_NaN());
 #undef SP_TRY
     cleanup();
     *lag = nil ? 0 : lg;
@@ -277,7 +293,10 @@ static int xcorr_groups_impl(muse_group *gx, muse_group *gy, int32_t n, int32_t 
         rc = group_ready(gy);
     if (rc)
         return rc;
-    if (!is_pow2(n) || n < 512 || n > GENERIC_MAX_N) {
+    if (n > HUGE_MAX_N)
+        return fail(MUSE_ERR_UNSUPPORTED, "FFT length %d > %d is not built", n, HUGE_MAX_N);
+    const bool huge = is_pow2(n) && n > GENERIC_MAX_N; // series longer than 65 536 samples (xcorr_huge.hip)
+    if (!is_pow2(n) || n < 512) {
         // FFT lengths without a batched kernel (the reference's n = 5 tables, short series): pair by pair through the
         // single-pair path (generic radix-2 kernel, or the direct kernel for n that is not a power of two)
         std::vector<double> x((size_t)Nx), y((size_t)Ny);
@@ -297,8 +316,8 @@ static int xcorr_groups_impl(muse_group *gx, muse_group *gy, int32_t n, int32_t 
         }
         return MUSE_OK;
     }
-    hipError_t e = ensure_gscratch(ctx, n);
-    if (e == hipSuccess && n >= 32768)
+    hipError_t e = huge ? hipSuccess : ensure_gscratch(ctx, n);
+    if (e == hipSuccess && n >= 32768 && !huge)
         e = ensure_twl(ctx, n);
     if (e != hipSuccess)
         return fail(MUSE_ERR_NOMEM, "scratch: %s", hipGetErrorString(e));
@@ -326,7 +345,15 @@ static int xcorr_groups_impl(muse_group *gx, muse_group *gy, int32_t n, int32_t 
         cleanup();
         return fail(MUSE_ERR_NOMEM, "hipMalloc failed: %s", hipGetErrorString(e));
     }
-    {
+    if (huge) {
+        rc = huge_pairs(ctx, gx->rows, gx->stride, Nx, normalize ? 1 : 0, 1.0, gy->rows, gy->stride, Ny, normalize ? 1 : 0, M, n,
+                        normalize ? 1.0 / ((double)n * (double)(n - 1)) : 1.0 / (double)n, dmv, dlag, dnil, dcc);
+        if (rc) {
+            (void)hipStreamSynchronize(ctx->stream);
+            cleanup();
+            return rc;
+        }
+    } else {
         // long series work in the context's scratch buffer: its pointer must not be swapped between reading it and the launch
         std::unique_lock<std::mutex> scratch_lock(ctx->stage_mu, std::defer_lock);
         if (n >= GENERIC_LDS_MAX_N)
