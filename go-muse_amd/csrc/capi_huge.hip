@@ -61,6 +61,8 @@ int huge_ensure(muse_ctx *ctx, int logn, int64_t pairs, bool tables)
     if (e == hipSuccess)
         e = grow((void **)&w.part, w.part_bytes, (size_t)(2 * pairs) * (size_t)R1 * 2 * sizeof(double));
     if (e == hipSuccess)
+        e = grow((void **)&w.snorm, w.snorm_bytes, (size_t)(2 * pairs) * 4 * sizeof(double));
+    if (e == hipSuccess)
         e = grow((void **)&w.sfin, w.sfin_bytes, (size_t)(2 * pairs) * sizeof(double));
     if (e == hipSuccess)
         e = grow((void **)&w.sfin_x, w.sfin_x_bytes, (size_t)(2 * pairs) * sizeof(double));
@@ -84,13 +86,23 @@ HugeParams huge_base(muse_ctx *ctx, int logn)
     p.g3b = ctx->g3b;
     p.Y = ctx->huge.Y;
     p.part = ctx->huge.part;
+    p.snorm = ctx->huge.snorm;
     p.sfin = ctx->huge.sfin;
     p.amax = ctx->huge.amax;
     p.pre_scale = 1.0;
+#ifdef MUSE_HUGE_ABL
+    p.abl = getenv("MUSE_HUGE_ABL") ? atoi(getenv("MUSE_HUGE_ABL")) : 0;
+#endif
     return p;
 }
 
-int64_t pairs_per_batch(int64_t n) { return std::max<int64_t>(1, (int64_t)(HUGE_BATCH_BYTES / ((size_t)n * sizeof(double2)))); }
+int64_t pairs_per_batch(int64_t n)
+{
+    size_t bytes = HUGE_BATCH_BYTES;
+    if (const char *e = getenv("MUSE_HUGE_BATCH_MB")) // measurement knob (tools/huge_bench.py): the work buffer of one batch
+        bytes = (size_t)std::max(1, atoi(e)) << 20;
+    return std::max<int64_t>(1, (int64_t)(bytes / ((size_t)n * sizeof(double2))));
+}
 
 } // namespace
 
@@ -104,6 +116,7 @@ void huge_free(muse_ctx *ctx)
     (void)hipFree(w.Y);
     (void)hipFree(w.T);
     (void)hipFree(w.part);
+    (void)hipFree(w.snorm);
     (void)hipFree(w.sfin);
     (void)hipFree(w.sfin_x);
     (void)hipFree(w.amax);

@@ -56,8 +56,8 @@ struct MemPool {
 struct HugeWork {
     double2 *thi[4] = {nullptr, nullptr, nullptr, nullptr}, *tlo[4] = {nullptr, nullptr, nullptr, nullptr};
     double2 *Y = nullptr, *T = nullptr;
-    double *part = nullptr, *sfin = nullptr, *sfin_x = nullptr, *amax = nullptr;
-    size_t Y_bytes = 0, T_bytes = 0, part_bytes = 0, sfin_bytes = 0, sfin_x_bytes = 0, amax_bytes = 0;
+    double *part = nullptr, *snorm = nullptr, *sfin = nullptr, *sfin_x = nullptr, *amax = nullptr;
+    size_t Y_bytes = 0, T_bytes = 0, part_bytes = 0, snorm_bytes = 0, sfin_bytes = 0, sfin_x_bytes = 0, amax_bytes = 0;
 };
 constexpr int PROBE_WINDOWS = 4096; // clock probe (muse_test_clock_probe_*): windows its pinned buffer holds; the window count and the stop flag sit behind them
 struct muse_ctx {

@@ -36,6 +36,7 @@ struct HugeParams {
     long long table_stride;
     double2 *Y;               // work buffer: n complex per pair of the batch
     double *part;             // [series of the batch][R1][2] chunk sums
+    double *snorm;            // [series of the batch][4]: first sample, mean of the shifted samples, pre_scale / sigma, flag
     double *sfin;             // [series of the batch] flag: 0 ok, 1 sigma == 0, 2 NaN / Inf statistics
     const double *sfin_x;     // two-sided: the flags of the batch's x series (same slots), or nullptr
     double *amax;             // [pair][R1][8] tile maxima
@@ -45,6 +46,9 @@ struct HugeParams {
     double *cc_out;           // optional: (first + slot) * n + lag index
     double2 *table_out;       // HUGE_STAGE_ROWS_FORWARD: pair i at table_out + i * n
     double table_scale;
+#ifdef MUSE_HUGE_ABL
+    int abl;                  // diagnostic builds only (tools/ablate/ab_huge.sh): parts of sweep 1 left out / made contiguous
+#endif
     double2 *X_out;           // optional: bins 0 .. n / 2 in natural order, pair i at X_out + i * (n / 2 + 1)
 };
 

@@ -94,10 +94,32 @@ __global__ __launch_bounds__(256) void huge_stats(const HugeParams p)
     }
 }
 
-// the series' shift (first sample + mean of the shifted samples), 1 / sigma and flag from its chunk sums; every workgroup of a
-// pair adds them in the same shape, so all of them use the same bits
-__device__ __forceinline__ void series_norm(const HugeParams &p, const long long slot, const double *__restrict__ row, double *red4,
-                                            const int t, double &K, double &mean, double &inv, int &flag)
+// the series' shift (first sample, mean of the shifted samples), 1 / sigma (times pre_scale) and flag from its chunk sums, once per
+// series: sweep 1 reads the four values instead of every one of its R1 workgroups per pair reducing the chunk sums again
+// (a prologue of eight barriers in front of the row requests of a workgroup that has only one neighbour on its CU)
+__global__ __launch_bounds__(256) void huge_norm(const HugeParams p)
+{
+    __shared__ double red4[4];
+    const int t = threadIdx.x;
+    const long long slot = blockIdx.x;
+    const double a = t < p.R1 ? p.part[(slot * p.R1 + t) * 2 + 0] : 0.0;
+    const double b = t < p.R1 ? p.part[(slot * p.R1 + t) * 2 + 1] : 0.0;
+    const double s1 = block_sum_fixed(a, red4, t), s2 = block_sum_fixed(b, red4, t);
+    if (t == 0) {
+        const double invN = 1.0 / (double)p.N, invNm1 = 1.0 / (double)(p.N - 1);
+        bool zero, nan;
+        const double var = variance(Stat{s1, s2}, invN, invNm1, zero, nan);
+        const int flag = nan ? FLAG_NAN : zero ? FLAG_ZERO : FLAG_OK;
+        double *__restrict__ o = p.snorm + slot * 4;
+        o[0] = series_row(p, slot)[0];
+        o[1] = s1 * invN;
+        o[2] = flag == FLAG_OK ? p.pre_scale / sqrt(var) : 0.0;
+        o[3] = (double)flag;
+        p.sfin[slot] = (double)flag;
+    }
+}
+
+__device__ __forceinline__ void series_norm(const HugeParams &p, const long long slot, double &K, double &mean, double &inv, int &flag)
 {
     K = 0.0;
     mean = 0.0;
@@ -105,73 +127,101 @@ __device__ __forceinline__ void series_norm(const HugeParams &p, const long long
     flag = FLAG_OK;
     if (!p.normalize)
         return;
-    const double a = t < p.R1 ? p.part[(slot * p.R1 + t) * 2 + 0] : 0.0;
-    const double b = t < p.R1 ? p.part[(slot * p.R1 + t) * 2 + 1] : 0.0;
-    const double s1 = block_sum_fixed(a, red4, t), s2 = block_sum_fixed(b, red4, t);
-    const double invN = 1.0 / (double)p.N, invNm1 = 1.0 / (double)(p.N - 1);
-    bool zero, nan;
-    const double var = variance(Stat{s1, s2}, invN, invNm1, zero, nan);
-    K = row[0];
-    mean = s1 * invN;
-    flag = nan ? FLAG_NAN : zero ? FLAG_ZERO : FLAG_OK;
-    inv = flag == FLAG_OK ? p.pre_scale / sqrt(var) : 0.0;
+    const double *__restrict__ o = p.snorm + slot * 4;
+    K = uniform(o[0]);
+    mean = uniform(o[1]);
+    inv = uniform(o[2]);
+    flag = __builtin_amdgcn_readfirstlane((int)o[3]);
+}
+
+// Workgroup -> (pair, tile) of the sweeps.  A tile touches 128 B (sweep 1's reads) or 256 B of EVERY row of its pair: on
+// its own a scatter over R1 DRAM pages.  Workgroups are handed to the eight XCDs round-robin by their linear index, so the
+// map gives each XCD a run of R1 / 8 neighbouring tiles of one pair: the workgroups resident on an XCD at one time then cover
+// 4 ... 8 KB of every row between them (measured: profiles/r06_long_series.txt).
+__device__ __forceinline__ void sweep_tile(const int R1, long long &pair, int &tl)
+{
+    const unsigned lin = blockIdx.x, xcd = lin & 7u, slot = lin >> 3;
+    const unsigned run = (unsigned)R1 >> 3;
+    pair = slot / run;
+    tl = (int)(xcd * run + slot % run);
 }
 
 // ------------------------------------------------------------------------------------------------ sweep 1
 // R = R1 / 16 (2, 4, 8, 16): the R1-point DFT over m1 = q + R i is a radix-16 over i in registers, the factor W_R1^(q ka), one LDS
 // transpose and a radix-R over q; thread (c, q) <-> (column, residue) before the transpose, (c, j) <-> (column, the outputs
 // ka = j Q .. j Q + Q - 1 of the first step, Q = 16 / R) behind it.
+// The transpose moves the real parts, then the imaginary parts, through ONE 32 KB buffer: with all 64 KB of a tile resident a CU
+// holds two workgroups, and a copy-only build of sweep 1 moves its 268 MB in 79 us at two workgroups per CU but in 56 us at three
+// (tools/ablate/ab_huge.sh; profiles/r06_long_series.txt).
 template <int R>
-__device__ __forceinline__ void column_dft(double2 (&v)[16], double2 *tile, const double2 *__restrict__ thi, const int t)
+__device__ __forceinline__ void column_dft(double2 (&v)[16], double *tile, const double2 *__restrict__ thi, const int t, const int ABL = 0)
 {
     constexpr int TW = 256 / R, Q = 16 / R;
     const int c = t % TW, q = t / TW;
-    dft16_nr(v); // u_q[ka] at v[BR16(ka)]
+    if (!(ABL & 16))
+        dft16_nr(v); // u_q[ka] at v[BR16(ka)]
+    if (!(ABL & 32)) {
 #pragma unroll
-    for (int ka = 1; ka < 16; ka++) // W_R1^(q ka) = W_n^(4096 q ka) = thi[4 q ka]
-        v[BR16(ka)] = cmul(v[BR16(ka)], thi[4 * q * ka]);
+        for (int ka = 1; ka < 16; ka++) // W_R1^(q ka) = W_n^(4096 q ka) = thi[4 q ka]
+            v[BR16(ka)] = cmul(v[BR16(ka)], thi[4 * q * ka]);
+    }
+    const int j = q; // (the same split of t: column c, group j)
+    double re[16];
 #pragma unroll
     for (int ka = 0; ka < 16; ka++)
-        lds_st2(tile + (ka * R + q) * TW + c, v[BR16(ka)]);
+        tile[(ka * R + q) * TW + c] = v[BR16(ka)].x;
     __syncthreads();
-    const int j = q; // (the same split of t: column c, group j)
 #pragma unroll
     for (int m = 0; m < Q; m++)
 #pragma unroll
         for (int s = 0; s < R; s++)
-            v[m + s * Q] = lds_ld2(tile + ((j * Q + m) * R + s) * TW + c);
-    sweep_dft<R>(v); // output kb of (ka = j Q + m) at v[m + brev<R>(kb) Q]: element k1 = ka + 16 kb
+            re[m + s * Q] = tile[((j * Q + m) * R + s) * TW + c];
+    __syncthreads();
+#pragma unroll
+    for (int ka = 0; ka < 16; ka++)
+        tile[(ka * R + q) * TW + c] = v[BR16(ka)].y;
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < Q; m++)
+#pragma unroll
+        for (int s = 0; s < R; s++)
+            v[m + s * Q] = make_double2(re[m + s * Q], tile[((j * Q + m) * R + s) * TW + c]);
+    if (!(ABL & 16))
+        sweep_dft<R>(v); // output kb of (ka = j Q + m) at v[m + brev<R>(kb) Q]: element k1 = ka + 16 kb
     __syncthreads();
 }
 
 template <int R>
-__global__ __launch_bounds__(256, 2) void huge_sweep1(const HugeParams p)
+__global__ __launch_bounds__(256, 3) void huge_sweep1(const HugeParams p)
 {
     constexpr int TW = 256 / R, Q = 16 / R, R1 = 16 * R;
-    __shared__ double2 tile[4096];
-    __shared__ double red4[4];
-    const int t = threadIdx.x, tl = blockIdx.x;
-    const long long pair = blockIdx.y;
+    __shared__ double tile[4096];
+    const int t = threadIdx.x;
+    long long pair;
+    int tl;
+    sweep_tile(R1, pair, tl);
     const long long sA = p.solo ? pair : 2 * pair, sB = sA + 1;
     const bool hasB = !p.solo && sB < p.count;
     const double *__restrict__ ra = series_row(p, sA);
     const double *__restrict__ rb = series_row(p, hasB ? sB : sA);
     double KA, mA, iA, KB = 0.0, mB = 0.0, iB = 0.0;
     int fA, fB = FLAG_OK;
-    series_norm(p, sA, ra, red4, t, KA, mA, iA, fA);
+    series_norm(p, sA, KA, mA, iA, fA);
     if (hasB)
-        series_norm(p, sB, rb, red4, t, KB, mB, iB, fB);
-    if (tl == 0 && t == 0) {
-        p.sfin[sA] = (double)fA;
-        if (hasB)
-            p.sfin[sB] = (double)fB;
-    }
+        series_norm(p, sB, KB, mB, iB, fB);
     const int c = t % TW, q = t / TW;
     const int m2 = tl * TW + c, pad = p.n - p.N;
     double2 v[16];
+#ifdef MUSE_HUGE_ABL
+    const int ABL = p.abl;
+#else
+    constexpr int ABL = 0;
+#endif
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-        const int e = (q + R * i) * 4096 + m2 - pad; // (leading zeros: xcorr.go:176-181)
+        int e = (q + R * i) * 4096 + m2 - pad; // (leading zeros: xcorr.go:176-181)
+        if (ABL & 4)
+            e = tl * 4096 + 256 * i + t; // (diagnostic: the same bytes, contiguous per workgroup)
         double xa = 0.0, xb = 0.0;
         if (e >= 0) {
             xa = ((ra[e] - KA) - mA) * iA;
@@ -181,7 +231,8 @@ __global__ __launch_bounds__(256, 2) void huge_sweep1(const HugeParams p)
         // (a flagged series enters as zeros: 1 / sigma is 0 for it, but NaN * 0 and Inf * 0 are NaN)
         v[i] = make_double2(fA == FLAG_OK ? xa : 0.0, fB == FLAG_OK ? xb : 0.0);
     }
-    column_dft<R>(v, tile, p.thi, t);
+    if (!(ABL & 8))
+        column_dft<R>(v, tile, p.thi, t, ABL);
     double2 *__restrict__ Y = p.Y + (size_t)pair * (size_t)p.n;
     const int j = q;
 #pragma unroll
@@ -190,9 +241,12 @@ __global__ __launch_bounds__(256, 2) void huge_sweep1(const HugeParams p)
         for (int kb = 0; kb < R; kb++) {
             const int k1 = j * Q + m + 16 * kb;
             const double2 z = v[m + brev<R>(kb) * Q];
-            Y[(size_t)k1 * 4096 + m2] = k1 == 0 ? z : cmul(z, twiddle(p.thi, p.tlo, (unsigned)(m2 * k1)));
+            const double2 zz = (k1 == 0 || (ABL & 1)) ? z : cmul(z, twiddle(p.thi, p.tlo, (unsigned)(m2 * k1)));
+            if (ABL & 2)
+                Y[(size_t)tl * 4096 + 256 * (m * R + kb) + t] = zz; // (diagnostic: the same bytes, contiguous per workgroup)
+            else
+                Y[(size_t)k1 * 4096 + m2] = zz;
         }
-    (void)R1;
 }
 
 // ------------------------------------------------------------------------------------------------ rows
@@ -254,14 +308,16 @@ __global__ __launch_bounds__(256, 3) void huge_rows(const HugeParams p) // (at f
 
 // ------------------------------------------------------------------------------------------------ sweep 2
 template <int R>
-__global__ __launch_bounds__(256, 2) void huge_sweep2(const HugeParams p)
+__global__ __launch_bounds__(256, 3) void huge_sweep2(const HugeParams p)
 {
     constexpr int TW = 256 / R, Q = 16 / R;
-    __shared__ double2 tile[4096];
+    __shared__ double tile[4096];
     __shared__ double redm[8];
     __shared__ int redi[8];
-    const int t = threadIdx.x, tl = blockIdx.x, lane = t & 63, wave = t >> 6;
-    const long long pair = blockIdx.y;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    long long pair;
+    int tl;
+    sweep_tile(16 * R, pair, tl);
     const long long sA = p.solo ? pair : 2 * pair, sB = sA + 1;
     const bool hasB = !p.solo && sB < p.count;
     const int c = t % TW, q = t / TW;
@@ -391,8 +447,9 @@ __global__ __launch_bounds__(256) void huge_final(const HugeParams p)
 }
 
 template <int R>
-hipError_t launch_sweeps(const HugeParams &p, const int which, const dim3 grid, hipStream_t stream)
+hipError_t launch_sweeps(const HugeParams &p, const int which, const dim3 grid2, hipStream_t stream)
 {
+    const dim3 grid(grid2.x * grid2.y); // (one dimension: sweep_tile maps the linear index)
     if (which == 1)
         hipLaunchKernelGGL((huge_sweep1<R>), grid, dim3(256), 0, stream, p);
     else
@@ -412,8 +469,13 @@ hipError_t launch_huge(const HugeParams &p, const unsigned stages, hipStream_t s
     const dim3 gp((unsigned)p.R1, (unsigned)pairs);
     hipError_t e = hipSuccess;
     if ((stages & HUGE_STAGE_STATS) && p.normalize) {
+        if (!p.snorm)
+            return hipErrorInvalidValue;
         hipLaunchKernelGGL(huge_stats, dim3((unsigned)p.R1, (unsigned)p.count), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(huge_norm, dim3((unsigned)p.count), dim3(256), 0, stream, p);
         e = hipGetLastError();
+    } else if ((stages & HUGE_STAGE_STATS) && p.sfin) { // raw samples: every flag "ok" (huge_final reads none of them, a later batch's x flags might)
+        e = hipMemsetAsync(p.sfin, 0, (size_t)p.count * sizeof(double), stream);
     }
     for (int which = 1; which <= 2 && e == hipSuccess; which++) {
         if (which == 1 ? !(stages & HUGE_STAGE_SWEEP1) : !(stages & HUGE_STAGE_SWEEP2))
