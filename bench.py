@@ -345,6 +345,110 @@ def reference_bench_shapes(pkg):
     return obj
 
 
+def in_process_shards(pkg, args, eng, ref, N, devs=None):
+    """SURVEY 8e inside ONE process (what NewBatch over a device list does -- the path a Go / C++ caller of the C ABI takes:
+    INTEGRATION.md): the same logical group cut into one contiguous row range per context, every shard scored at the same time
+    from its own host thread, per-shard top-N records merged on the host.  With one GPU visible the contexts share it (device 0
+    listed twice): that exercises the path and prices its host side; it is NOT a scaling number."""
+    import threading
+    import numpy as np
+    ndev = pkg.device_count()
+    sel = args.in_process_devices
+    if devs is None:
+        if sel == "all":
+            devs = list(range(ndev))
+        elif sel == "auto":
+            devs = list(range(ndev)) if ndev > 1 else [0, 0]
+        else:
+            devs = list(range(min(int(sel), ndev)))
+            if len(devs) < 2:
+                devs = [0, 0]
+    per = args.in_process_rows
+    engs = [pkg.Engine(d) for d in devs]
+    # (without the planted exact copies of the reference: among exactly tied scores the ORDER Fetch returns depends on
+    # the heap's history, results.go:55-87, and a pre-selected merge has another history than one long feed)
+    parts = [pkg.DeviceGroup.synthetic(e, per, N, seed=0x6D757365, global_first=k * per, copies=False) for k, e in enumerate(engs)]
+    if ref is None:
+        ref = parts[0][1]
+    sb = [pkg.DeviceBatch(e, g, ref) for e, (g, _) in zip(engs, parts)]
+    whole, _ = pkg.DeviceGroup.synthetic(eng, per * len(devs), N, seed=0x6D757365, copies=False)
+    wb = pkg.DeviceBatch(eng, whole, ref)
+
+    def sharded():
+        recs = [None] * len(sb)
+
+        def work(k):
+            recs[k] = sb[k].run_shard(None, 0, k * per, args.max_lag, args.top_n, 0.0, 0, True)
+        th = [threading.Thread(target=work, args=(k,)) for k in range(len(sb))]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        return pkg.merge_records(np.concatenate(recs), args.top_n)
+
+    a = sharded()
+    b = wb.run(None, 0, args.max_lag, args.top_n, 0.0, 0, True)
+    same = a[0].tolist() == b[0].tolist() and a[1].tolist() == b[1].tolist() and np.array_equal(a[2], b[2])
+    reps = 5
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        sharded()
+    dsh = (time.perf_counter() - t1) / reps
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        wb.run(None, 0, args.max_lag, args.top_n, 0.0, 0, True)
+    dwh = (time.perf_counter() - t1) / reps
+    out = {
+        "devices": devs, "distinct_devices": len({e.pci_bus_id() for e in engs}), "pci_bus_ids": [e.pci_bus_id() for e in engs],
+        "rows_per_shard": per, "length": N,
+        "ms_per_run_sharded": dsh * 1e3, "ms_per_run_one_context_same_rows": dwh * 1e3,
+        "value": per * len(devs) / dsh, "unit": "series-pairs/s", "records_identical_to_one_context": bool(same),
+        "note": "one process, one muse_ctx + host thread per listed device, muse_batch_run_shard + muse_merge_records"
+                + ("" if len(set(devs)) > 1 else "; ONE GPU: the contexts share it -- a check of the path and of its host-side cost, not a scaling number")}
+    for x in sb:
+        x.close()
+    wb.close()
+    whole.close()
+    for g, _ in parts:
+        g.close()
+    return out
+
+
+def in_process_child_main(args):
+    """`bench.py --in-process-child --gpus N`: the in_process_shards object over devices 0 .. N-1 in a process of its own (what
+    rank 0 of an N-rank run starts once the ranks have finished), printed as one JSON object."""
+    pkg = importlib.import_module("go-muse_amd")
+    eng = pkg.Engine(0)
+    eng.set_screening(False)
+    try:
+        ndev = pkg.device_count()   # (a rehearsal on a box with fewer GPUs than ranks lists its devices again: the note says so)
+        out = in_process_shards(pkg, args, eng, None, args.length, devs=[d % ndev for d in range(args.gpus)])
+    except Exception as e:
+        out = {"error": str(e)}
+    print(json.dumps(out), flush=True)
+
+
+def run_in_process_child(args):
+    """rank 0 of an N-rank run, after the process group is gone and its own rows are freed: the one-process design over the
+    same N devices, so that the node the driver measures `dist.py` on also measures what a Go / C++ caller gets"""
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT",
+                        "MUSE_BENCH_CHILD") and not k.startswith("TORCHELASTIC") and not k.startswith("NCCL_ASYNC")}
+    cmd = [sys.executable, os.path.abspath(__file__), "--in-process-child", "--gpus", str(args.gpus), "--length", str(args.length),
+           "--in-process-rows", str(args.in_process_rows), "--top-n", str(args.top_n), "--max-lag", str(args.max_lag)]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        for ln in reversed(r.stdout.splitlines()):
+            if ln.startswith("{"):
+                out = json.loads(ln)
+                out["note"] = out.get("note", "") + "; a child process started by rank 0 after the ranks' timed region (the ranks' rows freed first)"
+                return out
+        return {"error": "child exited with code %d: %s" % (r.returncode, (r.stderr or "")[-300:])}
+    except Exception as e:
+        return {"error": str(e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -363,6 +467,11 @@ def main():
                          "SURVEY 8e / INTEGRATION.md): 'all' = every visible GPU, a number k = the first k, 'auto' = all when "
                          "more than one is visible, else device 0 twice (a check of the path, not a scaling number)")
     ap.add_argument("--in-process-rows", type=int, default=200_000, help="rows per shard of in_process_shards")
+    ap.add_argument("--with-in-process-child", action="store_true",
+                    help="run the in_process_shards child of an N-rank run even with --no-extras / in a rehearsal (tests)")
+    ap.add_argument("--in-process-child", action="store_true",
+                    help="(internal) print the in_process_shards object over devices 0 .. --gpus - 1 and exit: what rank 0 of an "
+                         "N-rank run starts as a child once the ranks are done")
     ap.add_argument("--many-refs", type=int, default=8,
                     help="also time muse_batch_run_many with this many references (N=1 only; 0 = skip); "
                          "reported as an extra object, never as `value`")
@@ -381,6 +490,9 @@ def main():
     args = ap.parse_args()
     if args.gpus < 1:
         ap.error("--gpus must be >= 1")
+    if args.in_process_child:
+        in_process_child_main(args)
+        return
 
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
@@ -716,68 +828,8 @@ def main():
             except Exception as e:
                 line["two_sided_xcorr"] = {"error": str(e)}
         if extras and "in_process_shards" not in args.skip_extra:
-            # SURVEY 8e inside ONE process (what NewBatch over a device list does: INTEGRATION.md): the same logical group cut into
-            # one contiguous row range per context, every shard scored at the same time from its own host thread, per-shard top-N
-            # records merged on the host.  With one GPU visible the contexts share it (device 0 listed twice): this exercises the
-            # path and prices its host side; it is NOT a scaling number.
             try:
-                import threading
-                ndev = pkg.device_count()
-                sel = args.in_process_devices
-                if sel == "all":
-                    devs = list(range(ndev))
-                elif sel == "auto":
-                    devs = list(range(ndev)) if ndev > 1 else [0, 0]
-                else:
-                    devs = list(range(min(int(sel), ndev)))
-                    if len(devs) < 2:
-                        devs = [0, 0]
-                per = args.in_process_rows
-                engs = [pkg.Engine(d) for d in devs]
-                # (without the planted exact copies of the reference: among exactly tied scores the ORDER Fetch returns depends on
-                # the heap's history, results.go:55-87, and a pre-selected merge has another history than one long feed)
-                parts = [pkg.DeviceGroup.synthetic(e, per, N, seed=0x6D757365, global_first=k * per, copies=False) for k, e in enumerate(engs)]
-                sb = [pkg.DeviceBatch(e, g, ref) for e, (g, _) in zip(engs, parts)]
-                whole, _ = pkg.DeviceGroup.synthetic(eng, per * len(devs), N, seed=0x6D757365, copies=False)
-                wb = pkg.DeviceBatch(eng, whole, ref)
-
-                def sharded():
-                    recs = [None] * len(sb)
-
-                    def work(k):
-                        recs[k] = sb[k].run_shard(None, 0, k * per, args.max_lag, args.top_n, 0.0, 0, True)
-                    th = [threading.Thread(target=work, args=(k,)) for k in range(len(sb))]
-                    for x in th:
-                        x.start()
-                    for x in th:
-                        x.join()
-                    return pkg.merge_records(np.concatenate(recs), args.top_n)
-
-                a = sharded()
-                b = wb.run(None, 0, args.max_lag, args.top_n, 0.0, 0, True)
-                same = a[0].tolist() == b[0].tolist() and a[1].tolist() == b[1].tolist() and np.array_equal(a[2], b[2])
-                reps = 5
-                t1 = time.perf_counter()
-                for _ in range(reps):
-                    sharded()
-                dsh = (time.perf_counter() - t1) / reps
-                t1 = time.perf_counter()
-                for _ in range(reps):
-                    wb.run(None, 0, args.max_lag, args.top_n, 0.0, 0, True)
-                dwh = (time.perf_counter() - t1) / reps
-                line["in_process_shards"] = {
-                    "devices": devs, "distinct_devices": len({e.pci_bus_id() for e in engs}), "pci_bus_ids": [e.pci_bus_id() for e in engs],
-                    "rows_per_shard": per, "length": N,
-                    "ms_per_run_sharded": dsh * 1e3, "ms_per_run_one_context_same_rows": dwh * 1e3,
-                    "value": per * len(devs) / dsh, "unit": "series-pairs/s", "records_identical_to_one_context": bool(same),
-                    "note": "one process, one muse_ctx + host thread per listed device, muse_batch_run_shard + muse_merge_records"
-                            + ("" if len(set(devs)) > 1 else "; ONE GPU: the contexts share it -- a check of the path and of its host-side cost, not a scaling number")}
-                for x in sb:
-                    x.close()
-                wb.close()
-                whole.close()
-                for g, _ in parts:
-                    g.close()
+                line["in_process_shards"] = in_process_shards(pkg, args, eng, ref, N)
             except Exception as e:
                 line["in_process_shards"] = {"error": str(e)}
         if c5 is not None:
@@ -791,10 +843,20 @@ def main():
         if not args.no_cpu_baseline:
             # (at every N, on rank 0's host cores over a sample of rank 0's shard: the other ranks wait at the closing barrier)
             line["cpu_baseline"] = cpu_baseline(dg, ref, N)
-        print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        if n_gpus > 1 and (args.with_in_process_child or (not args.no_extras and not args.rehearse_on_one_gpu
+                                                          and "in_process_shards" not in args.skip_extra and pkg.device_count() >= n_gpus)):
+            # the design a Go / C++ caller of the C ABI uses (one process, one context + host thread per device, host merge) on
+            # the SAME node, after the ranks are done: the ranks have passed the closing barrier and left the process group (they
+            # exit; nothing of theirs is running), this rank's rows go back first, and the measurement runs in a child process
+            db.close()
+            dg.close()
+            eng.trim()
+            line["in_process_shards"] = run_in_process_child(args)
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

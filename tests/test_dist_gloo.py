@@ -126,6 +126,18 @@ def test_sharded_run_world_size_3_with_an_empty_shard_gloo():
     assert empties >= 1       # the case under test did occur
 
 
+def test_sharded_run_world_size_8_gloo():
+    """eight ranks -- the size the driver's node runs -- with six EMPTY shards in the two-group case (every rank still takes part
+    in the gather and ends with the same records)"""
+    res = _run_world(8)
+    empties = 0
+    for rank, out in res:
+        for name, (ok, bounds) in out.items():
+            assert ok, (rank, name, bounds)
+        empties += int(out["two groups"][1][0] == out["two groups"][1][1])
+    assert empties == 6
+
+
 def test_shard_bounds_cover_and_align():
     muse = pkg()
     for total in (0, 1, 7, 1000, 1_000_001):
@@ -266,6 +278,21 @@ def _grouped_worker(rank, world, port, q):
         have = [(s.Labels.labels["batch"], s.Labels.labels["row"], s.Lag, s.PercentScore) for s in got]
         ok["shared Results"] = have == expect and mean == omean
         ok["ties at the top"] = len({h[3] for h in have[:5]}) == 1           # (the planted copies really tie)
+        # (c) fewer rows than ranks can hold in pairs: at world size 8 the last rank's shard is EMPTY and still takes part in both
+        #     exchange paths (the all_gather of G records and the all_to_all slices)
+        rng = np.random.default_rng(5)
+        tref, trows = rng.standard_normal(16), rng.standard_normal((13, 16))
+        trows[4] = trows[9]
+        tgid = (np.arange(13) % 5).astype(np.int32)
+        tlag, tmv = oracle_py.batch_scores(tref, trows)[:2]
+        lo, hi = D.shard_bounds(13, world, rank)
+        want = oracle_py.results(tlag, tmv, tgid, 5, True, 16, 4, 0.0, 0)
+        for limit in (None, 0):
+            stub = StubGroupsBatch(muse, tlag[lo:hi], tmv[lo:hi])
+            got = D.run_grouped_sharded(stub, lo, tgid[lo:hi], 5, 16, 4, 0.0, 0, True, exact_feed_max_groups=limit, with_groups=True)
+            ok["tiny rows limit %s" % limit] = bool(got[1].tolist() == want[1].tolist() and got[2].tolist() == want[2].tolist()
+                                                    and (limit is not None or got[0].tolist() == want[0].tolist()))
+        ok["_empty"] = lo == hi
         q.put((rank, ok, [h[:2] for h in have]))
     finally:
         dist.destroy_process_group()
@@ -287,15 +314,16 @@ def _run_grouped_world(world):
     return res
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_grouped_run_with_straddling_label_groups_gloo(world):
     """Batch.Run(["graph"]) over a Group sharded by rows with one process per GPU, graphs interleaved over all ranks, exact
     ties planted: every rank ends with the reference's Results over ALL rows (oracle.results = muse_batch.go:56-93,
     results.go:46-87 restated), through both exchange paths and through a Results shared by two Batches (configs[4])."""
     res = _run_grouped_world(world)
     firsts = None
+    assert any(ok["_empty"] for _, ok, _ in res) == (world == 8)     # (at eight ranks the tiny case leaves one rank without rows)
     for rank, ok, have in res:
         for name, good in ok.items():
-            assert good, (rank, name)
+            assert good or name == "_empty", (rank, name)
         firsts = firsts or have
         assert have == firsts                                       # every rank holds the same Results

@@ -1828,7 +1828,8 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
     env["MASTER_PORT"] = "29641"
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rows", "20001", "--steps", "2", "--warmup", "1",
-                        "--no-extras", "--with-config5", "--config5-rows", "3001", "--rehearse-on-one-gpu"],
+                        "--no-extras", "--with-config5", "--config5-rows", "3001", "--rehearse-on-one-gpu",
+                        "--with-in-process-child", "--in-process-rows", "6000"],
                        capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     assert r.stdout.count("\n") == 1 and r.stdout.startswith("{"), r.stdout[-2000:]   # stdout = rank 0's ONE line, nothing else
@@ -1853,6 +1854,12 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     assert d["clock_probe_in_timed_region"] is False
     cb = d["cpu_baseline"]
     assert cb["value"] > 0 and cb["kind"] == "port" and cb["cores"] >= 1 and cb["single_thread"]["value"] > 0
+    # the one-process design a Go / C++ caller of the C ABI uses, measured by a CHILD of rank 0 once the ranks are done (at N ranks on
+    # an N-GPU node: over those N devices; here both shards on GPU 0)
+    ips = d["in_process_shards"]
+    assert "error" not in ips, ips
+    assert ips["devices"] == [0, 0] and ips["rows_per_shard"] == 6000 and ips["records_identical_to_one_context"] is True
+    assert ips["value"] > 0 and "child process" in ips["note"]
     # BASELINE configs[4] at N ranks: seven lengths, every Group sharded over both ranks with its label groups on both, one shared Results
     c5, legs = d["config5_mixed_run"], d["config5_lengths"]
     assert c5["n_gpus"] == 2 and c5["lengths"] == [512, 1000, 4096, 5000, 16384, 20000, 65536] and c5["value"] > 0
