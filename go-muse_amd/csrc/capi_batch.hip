@@ -348,6 +348,12 @@ FusedParams base_params(muse_batch *b)
     p.xcf = b->xcf;
     p.xs = b->xs;
     p.screen_delta = ctx->screen_delta;
+#ifdef MUSE_REAL64_STAMPS
+    // diagnostic build (tools/ablate/ab_real64_stamps.sh): phase stamps of xcorr_fused_real64k, dumped when the context goes
+    if (!ctx->dbg_stamps && hipMalloc(&ctx->dbg_stamps, (size_t)ctx->num_cus * 4 * 16 * 16 * sizeof(unsigned long long)) == hipSuccess)
+        (void)hipMemset(ctx->dbg_stamps, 0, (size_t)ctx->num_cus * 4 * 16 * 16 * sizeof(unsigned long long));
+    p.dbg = ctx->dbg_stamps;
+#endif
     return p;
 }
 

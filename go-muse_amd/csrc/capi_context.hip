@@ -313,6 +313,24 @@ void ctx_release(muse_ctx *ctx)
         (void)hipStreamSynchronize(ctx->copy_stream);
         (void)hipStreamDestroy(ctx->copy_stream);
     }
+#ifdef MUSE_REAL64_STAMPS
+    if (ctx->dbg_stamps && getenv("MUSE_STAMPS_OUT")) {
+        std::vector<unsigned long long> h((size_t)ctx->num_cus * 4 * 16 * 16);
+        if (hipMemcpy(h.data(), ctx->dbg_stamps, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess) {
+            if (FILE *f = fopen(getenv("MUSE_STAMPS_OUT"), "w")) {
+                for (int wg = 0; wg < ctx->num_cus * 4; wg++)
+                    for (int w = 0; w < 16; w++) {
+                        fprintf(f, "%d %d", wg, w);
+                        for (int i = 0; i < 16; i++)
+                            fprintf(f, " %llu", h[((size_t)wg * 16 + w) * 16 + i]);
+                        fprintf(f, "\n");
+                    }
+                fclose(f);
+            }
+        }
+    }
+#endif
+    (void)hipFree(ctx->dbg_stamps);
     rows_slots_free(ctx);
     huge_free(ctx);
     pool_drain(ctx);

@@ -98,6 +98,7 @@ struct muse_ctx {
     double screen_e_scale = 1.0;     // test hook (muse_test_set_screen_bound_scale): scales the error bound, to exercise the guard
     int variant = 0;
     int xcorr_repeat = 1; // measurement hook (muse_test_xcorr_repeat)
+    unsigned long long *dbg_stamps = nullptr; // diagnostic builds only (-DMUSE_REAL64_STAMPS): [CUs][16 waves][16 phases] cycle sums
     // measurement hook (muse_test_clock_probe_*): a one-wave kernel on its own stream sampling the shader clock
     hipStream_t probe_stream = nullptr;
     unsigned long long *probe_buf = nullptr; // pinned host memory: [2 * PROBE_WINDOWS] ticks + the window count behind them

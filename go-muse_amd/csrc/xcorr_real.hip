@@ -756,6 +756,12 @@ __global__ __launch_bounds__(1024, 4) void xcorr_fused_real64k(const FusedParams
         g2l[t] = tw_factor<4>(twm, t % 4, t / 4);
     __syncthreads();
     const long long total = p.M;
+#ifdef MUSE_REAL64_STAMPS
+    PhaseClock<true> clk; // diagnostic build (tools/ablate/ab_real64_stamps.sh): shader-clock cycles per phase and wave, summed over the series
+#else
+    PhaseClock<false> clk;
+#endif
+    clk.start();
     // The row's 32 requests (points m = j + i S and m + H, i = 0 .. 15) in batches of NB + NB, PRE batches in flight: a batch is
     // requested as the one PRE in front of it has been consumed.  (Requested across the loop's back edge -- behind the combine of the
     // previous row, as the other kernels do -- the batches cost 37 - 120 spilled registers: the 64 they occupy meet the peak of the
@@ -825,12 +831,15 @@ __global__ __launch_bounds__(1024, 4) void xcorr_fused_real64k(const FusedParams
                 fence();
             }
         }
+        clk.template stamp<0>(); // rows requested and consumed, V parked (stores issued)
         pair_sum4<S>(q0, q1, q2, q3, red, wave);
         bool zero, nan;
         const double var = uniform(variance(Stat{q0 + q2, q1 + q3}, invN, invNm1, zero, nan));
         const double mean = uniform((q0 + q2) * invN);
+        clk.template stamp<1>(); // statistics reduced
         // ---- pass A: even bins
         forward<LH>(v, b, g2l, gs, j);
+        clk.template stamp<2>();
         {
             int jm = j;
             asm volatile("" : "+v"(jm));
@@ -848,8 +857,10 @@ __global__ __launch_bounds__(1024, 4) void xcorr_fused_real64k(const FusedParams
                     return mirror_pair(v8, v8, make_double2(0.0, -1.0), xh, xh).k;
                 });
         }
+        clk.template stamp<3>(); // mirror stage A
         natural_order(v);
         forward<LH>(v, b, g2l, gs, j); // ce[j + r S] at v[BR16(r)]
+        clk.template stamp<4>();
 #pragma unroll
         for (int r = 0; r < 16; r++)
             *((gd2)scalar_ptr_at(parkE, r * S) + (unsigned)(t & (S - 1))) = d2v{v[BR16(r)].x, v[BR16(r)].y};
@@ -859,7 +870,12 @@ __global__ __launch_bounds__(1024, 4) void xcorr_fused_real64k(const FusedParams
             const d2v z = *((gd2)scalar_ptr_at(parkV, i * S) + (unsigned)(t & (S - 1)));
             v[i] = make_double2(z.x, z.y);
         }
+#ifdef MUSE_REAL64_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (diagnostic: the read-back of V is charged to its own phase)
+#endif
+        clk.template stamp<5>(); // ce parked (stores issued), V read back
         forward<LH>(v, b, g2l, gs, j);
+        clk.template stamp<6>();
         {
             int jm = j;
             asm volatile("" : "+v"(jm));
@@ -874,8 +890,10 @@ __global__ __launch_bounds__(1024, 4) void xcorr_fused_real64k(const FusedParams
                 [&](const RawPairXC &x, const double2) __attribute__((always_inline)) { return TwoBins{x.a, x.b}; },
                 [&](const double2) __attribute__((always_inline)) { return make_double2(0.0, 0.0); });
         }
+        clk.template stamp<7>(); // mirror stage B
         natural_order(v);
         forward<LH>(v, b, g2l, gs, j); // co[j + r S] at v[BR16(r)]
+        clk.template stamp<8>();
         // ---- c[m] = ce + W_M^m co, c[m + H] = ce - W_M^m co; lags 2m, 2m + 1 (lower half) and 2 (m + H), 2 (m + H) + 1 (upper half);
         // maxAbsIndex (xcorr.go:39-50): per half ascending r = ascending lag, the lower half first
         double sl = 0.0, su = 0.0, cc0 = 0.0;
@@ -928,6 +946,7 @@ __global__ __launch_bounds__(1024, 4) void xcorr_fused_real64k(const FusedParams
                 }
             }
         }
+        clk.template stamp<9>(); // ce read back, combine, per-thread maximum
         const bool up = fabs(su) > fabs(sl); // (the lower half holds the lower lags: it keeps ties)
         const double sv = up ? su : sl;
         const int code = up ? cu : cl;
@@ -951,7 +970,15 @@ __global__ __launch_bounds__(1024, 4) void xcorr_fused_real64k(const FusedParams
             p.lag[row] = lag;
         }
         __syncthreads(); // (the slice and red are reused by the next row)
+        clk.template stamp<10>(); // workgroup maximum, result, closing barrier
     }
+#ifdef MUSE_REAL64_STAMPS
+    if (p.dbg && (t & 63) == 0) {
+#pragma unroll
+        for (int i = 0; i < NPHASE; i++)
+            p.dbg[((long long)blockIdx.x * 16 + wave) * NPHASE + i] = clk.acc[i];
+    }
+#endif
 }
 
 // n = 8192: one real series per 256-thread workgroup as a real transform on the n = 4096 kernel's complex machinery

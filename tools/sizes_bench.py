@@ -35,3 +35,4 @@ for N in Ns:
     eng.set_kernel(0)
     print("N=%5d n=%5d rows=%6d: %s" % (N, db.n, rows, " | ".join(out)), flush=True)
     db.close(); dg.close()
+eng.close()  # (diagnostic builds dump their phase stamps when the context goes)
