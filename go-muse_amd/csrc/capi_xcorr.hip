@@ -251,10 +251,29 @@ static int rescue_overflowed_pairs(muse_group *gx, muse_group *gy, int32_t n, in
     if (!rc)
         for (int k = 0; k < K2; k++) {
             const int64_t i = list2[(size_t)k];
+            // raw samples: the pair was recomputed at magnitude ~1; the result goes back by the exact power of two the two scales
+            // took out (normalised: the scales cancel in x / sigma).  A value that leaves the float64 range on the way back is
+            // where the reference's own products overflow: NaN stands for the whole pair.
+            const int back = normalize ? 0 : -(std::ilogb(scale2[(size_t)k].x) + std::ilogb(scale2[(size_t)k].y));
+            double v = std::ldexp(mv2[(size_t)k], back);
+            bool over = std::isinf(v) && !std::isinf(mv2[(size_t)k]);
+            double *dst = cc ? cc + (size_t)i * (size_t)n : nullptr;
+            if (cc) {
+                const double *src = cc2.data() + (size_t)k * (size_t)n;
+                for (int32_t q = 0; q < n; q++) {
+                    dst[q] = std::ldexp(src[q], back);
+                    over = over || (std::isinf(dst[q]) && !std::isinf(src[q]));
+                }
+            }
+            if (over) {
+                lag[i] = 0;
+                mv[i] = std::numeric_limits<double>::quiet_NaN();
+                if (cc)
+                    std::fill(dst, dst + n, std::numeric_limits<double>::quiet_NaN());
+                continue;
+            }
             lag[i] = lag2[(size_t)k];
-            mv[i] = mv2[(size_t)k];
-            if (cc)
-                std::copy(cc2.begin() + (size_t)k * (size_t)n, cc2.begin() + (size_t)(k + 1) * (size_t)n, cc + (size_t)i * (size_t)n);
+            mv[i] = v;
         }
     cleanup();
     return rc;

@@ -627,16 +627,17 @@ __global__ __launch_bounds__(256) void two_sided_rescue_kernel(const double *__r
             c = 1;
         } else {
             const int ex = exp_of(a.maxabs), ey = exp_of(b.maxabs);
-            // after balancing both magnitudes sit at 2^((ex + ey) / 2): the squares of the shared transform (and the reference's
-            // own products X conj(Y), up to n max|x| max|y|) must stay inside the float64 range -- above it the reference
-            // overflows too (NaN stands), below it every product underflows there as well (every cc is zero)
+            // both series are brought to magnitude ~1 (exact powers of two), the pair is recomputed there, and the HOST scales lag
+            // value and cc back by 2^(ex + ey) (capi_xcorr.hip): the result overflows exactly where the reference's own products
+            // X conj(Y) (up to n max|x| max|y|) leave the float64 range -- NaN stands there, as in the reference -- and not 24 ... 50
+            // binades earlier, as the round-5 bound on the recomputation's intermediates had it.  Below 2^-1000 every product
+            // underflows in the reference as well: every cc is zero.
             if (ex + ey < -1000) {
                 c = 1;
-            } else if (ex + ey + 2 * (32 - __clz(n)) < 1000) {
-                const int k = max(-1022, min(1022, (ex - ey) / 2));
+            } else {
                 c = 2;
-                gx = pow2(-k);
-                gy = pow2(k);
+                gx = pow2(-max(-1022, min(1022, ex)));
+                gy = pow2(-max(-1022, min(1022, ey)));
             }
         }
     }

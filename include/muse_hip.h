@@ -338,7 +338,8 @@ int muse_xcorr(muse_ctx *ctx, const double *x, int32_t lenx, const double *y,
                int32_t *lag, double *mv, int32_t *is_nil);
 /* xCorr (xcorr.go:102-153) for M independent pairs in ONE launch: pair i = (row i of gx, row i of gy).
  * The two groups may hold series of different lengths (each is zero-padded on its own, xcorr.go:129-130); n is raised
- * to max(n, Nx, Ny) (xcorr.go:104-106).  FFT lengths 512 ... 65536 that are powers of two run the batched kernels, in two
+ * to max(n, Nx, Ny) (xcorr.go:104-106).  Powers of two 2^17 ... 2^20 run the long-series kernels (xcorr_huge.hip: one series
+ * per transform, every x its own multiplier table).  FFT lengths 512 ... 65536 that are powers of two run the batched kernels, in two
  * forms: n <= 4096 and n = 65536 -- z = (x read backwards) + i y, one forward transform, cc = Im FFT(Z^2) / 2n on the xCorrWithX
  * kernels' transforms (xcorr_small.hip; xcorr_two_sided.hip: n = 4096 and, on the four-step transform with one scratch slice per
  * workgroup, n = 65536); n = 8192, 16384, 32768 -- each series a REAL transform of n / 2 complex points, X parked in the
@@ -346,8 +347,9 @@ int muse_xcorr(muse_ctx *ctx, const double *x, int32_t lenx, const double *y,
  * scale 1 / (n (n - 1)) when normalized else 1 / n, exactly as xcorr.go:139-143.  At n = 65536 with Nx = Ny = n the rows are
  * read once and the spectrum squared unscaled; pairs whose series differ by more than 2^16 in scale (or whose magnitudes are
  * extreme) are listed on the device and redone by a second launch that takes the statistics first.  Finite samples whose SQUARES leave the float64 range (|x| >~ 1e154) are looked at again by a device
- * kernel and give what the reference's arithmetic gives: finite correlations (raw), all zeros (normalized, sigma = +Inf) or
- * NaN (the reference's own sums overflow).  Any other n (the reference's n = 5 tables, short series) goes pair by pair
+ * kernel and give what the reference's arithmetic gives: finite correlations (raw: the pair is recomputed at magnitude 1 and
+ * scaled back by an exact power of two, so the results are numbers exactly as long as n max|x| max|y| stays inside the float64
+ * range, as in xcorr.go:108-143), all zeros (normalized, sigma = +Inf) or NaN (the reference's own sums overflow).  Any other n (the reference's n = 5 tables, short series) goes pair by pair
  * through muse_xcorr's path.  The groups are not mutated (the reference's zNormalize mutates x and y in place).
  * Outputs (host): lag[M], mv[M]; is_nil[M] (may be NULL) = 1 where the reference returns (nil, 0, 0), i.e. normalize
  * and sigma(x) == 0 or sigma(y) == 0; cc (may be NULL): M x n correlations (rows of nil pairs are zero). */

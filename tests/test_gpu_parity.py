@@ -2027,6 +2027,25 @@ def test_xcorr_batch_long_series_single_read_and_its_redo_list(eng, oracle, n):
         _check_xcorr_batch(eng, oracle, X, Y, n, normalize)
 
 
+@pytest.mark.parametrize("n", [4096, 32768])
+def test_xcorr_batch_raw_products_up_to_the_float64_range(eng, oracle, n):
+    """Raw xCorr of finite samples whose product is huge: the reference (xcorr.go:108-143) returns numbers as long as
+    n max|x| max|y| stays inside the float64 range and NaN beyond.  Round 5 returned NaN from 2^974 / n^2 on (a bound on the
+    recomputation's intermediates: ADVICE r05); now the pair is recomputed at magnitude 1 and scaled back exactly, so the
+    boundary is the reference's: 2^520 x 2^460 (cc ~ 2^990) is finite and equal to the oracle's, 2^520 x 2^500 is NaN in both."""
+    rng = np.random.default_rng(n + 9)
+    M = 6
+    X = rng.normal(size=(M, n))
+    Y = rng.normal(size=(M, n))
+    Y[0] = np.roll(X[0], 5) * 1.5
+    X[0] *= 2.0 ** 520; Y[0] *= 2.0 ** 460           # finite in the reference: cc up to ~ n 2^980
+    X[1] *= 2.0 ** 500; Y[1] *= 2.0 ** 495           # ~ n 2^995 (+ a few binades of the sum): still finite
+    X[2] *= 2.0 ** 520; Y[2] *= 2.0 ** 500           # n 2^1020 > 2^1024: the reference's products overflow
+    X[3] *= 2.0 ** 1000; Y[3] *= 2.0 ** -1000        # magnitudes cancel: an ordinary result
+    X[4] *= 2.0 ** -400; Y[4] *= 2.0 ** -400         # tiny products (2^-800): recomputed at magnitude 1, scaled back
+    _check_xcorr_batch(eng, oracle, X, Y, n, False)
+
+
 def test_xcorr_batch_different_lengths_and_raised_n(eng, oracle):
     rng = np.random.default_rng(77)
     M = 9
