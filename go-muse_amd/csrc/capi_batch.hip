@@ -357,6 +357,63 @@ FusedParams base_params(muse_batch *b)
     return p;
 }
 
+// The kernel the all-scores pass of batch b takes (ctx->variant 0 = automatic selection; the others are test hooks,
+// muse_hip_test.h): decided HERE, for muse_batch_score's launch and for the name muse_batch_kernel_name reports.
+struct KernelChoice {
+    int variant = KERNEL_GENERIC;
+    const double2 *gsmall = nullptr; // the pass table the kernel wants instead of base_params' (nullptr: keep)
+    const char *error = nullptr;
+};
+static KernelChoice choose_kernel(muse_batch *b, long long npairs)
+{
+    muse_ctx *ctx = b->ctx;
+    const int64_t M = b->g->M;
+    const bool has_twl = b->logn >= 14 && b->logn <= 16 && ctx->twl[b->logn - 14];
+    KernelChoice kc;
+    if (b->n == 4096) {
+        switch (ctx->variant) {
+        case 0: case 10: kc.variant = KERNEL_R16_FOLD; break; // fastest measured (profiles/)
+        case 7: kc.variant = KERNEL_R16_OCC3; break;          // rescales both series before the shared transform
+        default: kc.variant = KERNEL_GENERIC; break;
+        }
+        if (b->g->f32 && kc.variant == KERNEL_GENERIC) {
+            kc.error = "the generic kernel does not read float32-storage groups";
+            return kc;
+        }
+        if (kc.variant == KERNEL_R16_FOLD && b->N != 4096 && !b->c1) // (N < n needs the batch's correction table)
+            kc.variant = KERNEL_R16_OCC3;
+        // a group of mixed-unit series (sigmas far apart inside most pairs) makes the default kernel hand most
+        // pairs to kernel 7 anyway: once a pass over these rows has shown that, go there directly
+        if (kc.variant == KERNEL_R16_FOLD && ctx->variant == 0 && b->handoff_host && b->handoff_M == M &&
+            (long long)*(volatile int *)b->handoff_host * 8 > npairs)
+            kc.variant = KERNEL_R16_OCC3;
+    } else if (b->g->f32 && !(((b->n >= 512 && b->n <= 2048) || b->n == 8192 || b->n == 16384) && (ctx->variant == 0 || ctx->variant == 12))) {
+        kc.error = "float32-storage groups run on the default kernels only (FFT lengths 512 ... 16384)";
+    } else if (b->n == 8192 && (ctx->variant == 0 || ctx->variant == 14) && !b->g->f32 && b->xcp) {
+        kc.variant = KERNEL_REAL; // one real series per 256-thread workgroup on the n = 4096 kernel's transforms (xcorr_real.hip)
+    } else if (b->n == 16384 && (ctx->variant == 0 || ctx->variant == 14) && !b->g->f32 && ctx->gsmall[3]) {
+        kc.variant = KERNEL_REAL; // one real series per 512-thread workgroup on the 8192-point complex transform, two workgroups per CU
+        kc.gsmall = ctx->gsmall[3];
+    } else if (b->n == 32768 && (ctx->variant == 0 || ctx->variant == 15) && !b->g->f32 && ctx->gsmall[4] && b->xcw && ctx->wsplit) {
+        // one real series per 1024-thread workgroup with each 16384-point transform as 16 x 1024 (wave-local 1024-point transforms around one
+        // workgroup transpose): + 1 ... 4 % over test hook 14's three-transpose form on every box measured (profiles/r05_real_transform.txt)
+        kc.variant = KERNEL_REAL_SPLIT;
+        kc.gsmall = ctx->gsmall[4];
+    } else if ((b->n == 32768 || (b->n == 65536 && (b->N == b->n || b->c1))) && (ctx->variant == 0 || ctx->variant == 14) && !b->g->f32 && ctx->gsmall[4]) {
+        // one real series per 1024-thread workgroup on the 16384-point complex transform (xcorr_real.hip): n = 32768 never leaves the CU,
+        // n = 65536 in two passes with 1 MB parked per series (3 x the algorithmic bytes; the four-step kernel: 5 x)
+        kc.variant = KERNEL_REAL;
+        kc.gsmall = ctx->gsmall[4];
+    } else if (b->xcp && has_twl && (b->N == b->n || b->c1) && ((b->n >= 32768 && ctx->variant == 0) || (b->n >= 16384 && ctx->variant == 13))) {
+        kc.variant = KERNEL_LONG; // four-step, 4096-point rows on the n = 4096 kernel's transforms (xcorr_long.hip)
+    } else if (((b->n >= 512 && b->n <= 2048) || b->n == 8192 || b->n == 16384) && (ctx->variant == 0 || ctx->variant == 12)) {
+        kc.variant = KERNEL_SMALL; // half-round transposes at 16 waves per CU (xcorr_small.hip)
+    } else if (((b->n >= 512 && b->n <= 2048) || b->n >= 8192) && (ctx->variant == 0 || ctx->variant == 11)) {
+        kc.variant = KERNEL_STOCKHAM; // radix-16 Stockham through LDS / global scratch (xcorr_stockham.hip)
+    }
+    return kc;
+}
+
 extern "C" int muse_batch_score(muse_batch *b)
 {
     if (!b)
@@ -388,47 +445,14 @@ extern "C" int muse_batch_score(muse_batch *b)
         scratch_lock.lock();
     FusedParams p = base_params(b);
     b->scores_exact = true;
-    // kernel selection: ctx->variant 0 = auto; the others are test hooks (muse_hip_test.h)
-    int variant = KERNEL_GENERIC;
-    if (b->n == 4096) {
-        switch (ctx->variant) {
-        case 0: case 10: variant = KERNEL_R16_FOLD; break; // fastest measured (profiles/)
-        case 7: variant = KERNEL_R16_OCC3; break;          // rescales both series before the shared transform
-        default: variant = KERNEL_GENERIC; break;
-        }
-        if (b->g->f32 && variant == KERNEL_GENERIC)
-            return fail(MUSE_ERR_UNSUPPORTED, "the generic kernel does not read float32-storage groups");
-        if (variant == KERNEL_R16_FOLD && b->N != 4096 && !b->c1) // (N < n needs the batch's correction table)
-            variant = KERNEL_R16_OCC3;
-        // a group of mixed-unit series (sigmas far apart inside most pairs) makes the default kernel hand most
-        // pairs to kernel 7 anyway: once a pass over these rows has shown that, go there directly
-        if (variant == KERNEL_R16_FOLD && ctx->variant == 0 && b->handoff_host && b->handoff_M == M &&
-            (long long)*(volatile int *)b->handoff_host * 8 > p.npairs)
-            variant = KERNEL_R16_OCC3;
-    } else if (b->g->f32 && !(((b->n >= 512 && b->n <= 2048) || b->n == 8192 || b->n == 16384) && (ctx->variant == 0 || ctx->variant == 12))) {
-        return fail(MUSE_ERR_UNSUPPORTED, "float32-storage groups run on the default kernels only (FFT lengths 512 ... 16384)");
-    } else if (b->n == 8192 && (ctx->variant == 0 || ctx->variant == 14) && !b->g->f32 && b->xcp) {
-        variant = KERNEL_REAL; // one real series per 256-thread workgroup on the n = 4096 kernel's transforms (xcorr_real.hip)
-    } else if (b->n == 16384 && (ctx->variant == 0 || ctx->variant == 14) && !b->g->f32 && ctx->gsmall[3]) {
-        variant = KERNEL_REAL; // one real series per 512-thread workgroup on the 8192-point complex transform, two workgroups per CU
-        p.gsmall = ctx->gsmall[3];
-    } else if (b->n == 32768 && (ctx->variant == 0 || ctx->variant == 15) && !b->g->f32 && ctx->gsmall[4] && b->xcw && ctx->wsplit) {
-        // one real series per 1024-thread workgroup with each 16384-point transform as 16 x 1024 (wave-local 1024-point transforms around one
-        // workgroup transpose): + 1 ... 4 % over test hook 14's three-transpose form on every box measured (profiles/r05_real_transform.txt)
-        variant = KERNEL_REAL_SPLIT;
-        p.gsmall = ctx->gsmall[4];
-    } else if ((b->n == 32768 || (b->n == 65536 && (b->N == b->n || b->c1))) && (ctx->variant == 0 || ctx->variant == 14) && !b->g->f32 && ctx->gsmall[4]) {
-        // one real series per 1024-thread workgroup on the 16384-point complex transform (xcorr_real.hip): n = 32768 never leaves the CU,
-        // n = 65536 in two passes with 1 MB parked per series (3 x the algorithmic bytes; the four-step kernel: 5 x)
-        variant = KERNEL_REAL;
-        p.gsmall = ctx->gsmall[4];
-    } else if (b->xcp && p.twl && (b->N == b->n || b->c1) && ((b->n >= 32768 && ctx->variant == 0) || (b->n >= 16384 && ctx->variant == 13))) {
-        variant = KERNEL_LONG; // four-step, 4096-point rows on the n = 4096 kernel's transforms (xcorr_long.hip)
-    } else if (((b->n >= 512 && b->n <= 2048) || b->n == 8192 || b->n == 16384) && (ctx->variant == 0 || ctx->variant == 12)) {
-        variant = KERNEL_SMALL; // half-round transposes at 16 waves per CU (xcorr_small.hip)
-    } else if (((b->n >= 512 && b->n <= 2048) || b->n >= 8192) && (ctx->variant == 0 || ctx->variant == 11)) {
-        variant = KERNEL_STOCKHAM; // radix-16 Stockham through LDS / global scratch (xcorr_stockham.hip)
-    }
+    // kernel selection: ctx->variant 0 = auto; the others are test hooks (muse_hip_test.h).  One helper decides, for the launch
+    // here and for the name muse_batch_kernel_name reports (bench.py keys its counters by it)
+    const KernelChoice kc = choose_kernel(b, p.npairs);
+    if (kc.error)
+        return fail(MUSE_ERR_UNSUPPORTED, "%s", kc.error);
+    const int variant = kc.variant;
+    if (kc.gsmall)
+        p.gsmall = kc.gsmall;
     if (variant == KERNEL_GENERIC && b->n <= GENERIC_LDS_MAX_N)
         p.gscratch = nullptr; // the generic kernel takes a non-NULL scratch pointer as "work in global memory"
     LaunchTimer timer(ctx, false, st); // (brackets the fused launch alone: not the counter reset in front of it, not the redo launch behind it)
@@ -518,27 +542,30 @@ extern "C" int muse_batch_scores(muse_batch *b, int32_t *lag, double *mv)
 }
 
 // the kernel automatic selection takes for this batch's all-scores pass (bench.py names it in its roofline object)
+// the kernel the all-scores pass takes for this batch (bench.py names it in its roofline object), from the same choice the launch
+// makes -- test hooks, missing tables and the learned hand-off included
 extern "C" int muse_batch_kernel_name(muse_batch *b, char *name, int32_t cap)
 {
     if (!b || !name || cap < 1)
         return fail(MUSE_ERR_INVALID, "NULL argument");
-    // (the names rocprofv3 prints for the instantiations automatic selection launches: profiles/r*_counters.json is keyed by them)
+    // (the names rocprofv3 prints for the instantiations: profiles/r*_counters.json is keyed by them)
     char k[96] = "xcorr_fused_generic";
-    const bool padded = b->N < b->n;
-    if (b->n > GENERIC_MAX_N) // (the pass is a sequence of kernels: the one that moves the most bytes)
+    const char *padded = b->N < b->n ? "true" : "false", *f32 = b->g->f32 ? "true" : "false";
+    if (b->n > GENERIC_MAX_N) { // (the pass is a sequence of kernels: the one that moves the most bytes)
         snprintf(k, sizeof(k), "huge_rows<false>");
-    else if (b->n == 4096)
-        snprintf(k, sizeof(k), "xcorr_fused_n4096_fold<false, %s, %s>", padded ? "true" : "false", b->g->f32 ? "true" : "false");
-    else if (b->n == 8192 && !b->g->f32)
-        snprintf(k, sizeof(k), "xcorr_fused_real8k<%s>", padded ? "true" : "false");
-    else if (b->n == 16384 && !b->g->f32)
-        snprintf(k, sizeof(k), "xcorr_fused_real16k<%s>", padded ? "true" : "false");
-    else if ((b->n >= 512 && b->n <= 2048) || b->n == 8192 || b->n == 16384)
-        snprintf(k, sizeof(k), "xcorr_fused_small<%d, %s, false%s>", b->logn, padded ? "true" : "false", b->g->f32 ? ", true" : ", false");
-    else if (b->n == 32768 && b->xcw)
-        snprintf(k, sizeof(k), "xcorr_fused_real32k_split<%s>", padded ? "true" : "false");
-    else if (b->n == 32768 || b->n == 65536)
-        snprintf(k, sizeof(k), "xcorr_fused_real%dk<%s>", b->n / 1024, padded ? "true" : "false");
+    } else {
+        const KernelChoice kc = choose_kernel(b, (b->g->M + 1) / 2);
+        switch (kc.error ? -1 : kc.variant) {
+        case KERNEL_R16_FOLD: snprintf(k, sizeof(k), "xcorr_fused_n4096_fold<false, %s, %s>", padded, f32); break;
+        case KERNEL_R16_OCC3: snprintf(k, sizeof(k), "xcorr_fused_n4096_occ4"); break;
+        case KERNEL_SMALL: snprintf(k, sizeof(k), "xcorr_fused_small<%d, %s, false, %s>", b->logn, padded, f32); break;
+        case KERNEL_LONG: snprintf(k, sizeof(k), "xcorr_fused_long<%d, %s, false>", b->logn, padded); break;
+        case KERNEL_STOCKHAM: snprintf(k, sizeof(k), b->n >= 8192 ? "xcorr_fused_stk_4step" : "xcorr_fused_stockham"); break;
+        case KERNEL_REAL_SPLIT: snprintf(k, sizeof(k), "xcorr_fused_real32k_split<%s>", padded); break;
+        case KERNEL_REAL: snprintf(k, sizeof(k), "xcorr_fused_real%dk<%s>", b->n / 1024, padded); break;
+        default: break;
+        }
+    }
     snprintf(name, (size_t)cap, "%s", k);
     return MUSE_OK;
 }

@@ -619,12 +619,32 @@ def NewSeries(y, labels=None):
 
 
 # ---------------------------------------------------------------- group.go
+class _Registry(dict):
+    """Group.registry: uid -> Series, insertion ordered, and PUBLIC (the reference's field).  Every mutation bumps `version`,
+    which is what the cached partition of indexLabelValues (and the device copy of the rows) is keyed by: a series replaced or
+    removed and re-added at the same count is seen.  (A Series' labels and values are taken as immutable once it is added.)"""
+
+    def __init__(self):
+        super().__init__()
+        self.version = 0
+
+    def _bump(name):                              # noqa: N805 (a decorator factory evaluated in the class body)
+        def method(self, *a, **kw):
+            self.version += 1
+            return getattr(dict, name)(self, *a, **kw)
+        method.__name__ = name
+        return method
+    for _m in ("__setitem__", "__delitem__", "pop", "popitem", "clear", "update", "setdefault", "__ior__"):
+        locals()[_m] = _bump(_m)
+    del _m, _bump
+
+
 class Group:
     def __init__(self, name):
         self.Name = name
         self.n = 0
         self.index = {}
-        self.registry = {}                        # uid -> Series, insertion ordered
+        self.registry = _Registry()               # uid -> Series, insertion ordered
         self._dev = None                          # (engine, DeviceGroup, rows uploaded)
 
     def Length(self):
@@ -653,8 +673,8 @@ class Group:
         groupByLabels = list(groupByLabels) if groupByLabels else []
         # the partition depends on the label names and the series alone, and series are only ever added: a repeated Run with the
         # same grouping over the same series reuses it (and the group ids derived from it: _group_ids)
-        key = (len(self.registry), tuple(groupByLabels))
-        if getattr(self, "_index_key", None) == key and self.registry:
+        key = (getattr(self.registry, "version", None), len(self.registry), tuple(groupByLabels))
+        if key[0] is not None and getattr(self, "_index_key", None) == key and self.registry:   # (a plain dict put in its place: no cache)
             return self._index_distinct
         distinct = []
         self.index = {}
@@ -692,14 +712,23 @@ class Group:
     def _series_list(self):
         return list(self.registry.values())
 
+    def _appended_only(self, seen_version, seen_count):
+        """True when everything that happened to the (public) registry since (seen_version, seen_count) was the adding of new series"""
+        v = getattr(self.registry, "version", None)
+        return v is not None and len(self.registry) >= seen_count and v - seen_version == len(self.registry) - seen_count
+
     def _device_group(self, engine):
         ser = self._series_list()
-        if self._dev is None or self._dev[0] is not engine:
-            self._dev = [engine, DeviceGroup(engine, self.n, len(ser)), 0]
-        _, dg, done = self._dev
+        stale = self._dev is not None and not self._appended_only(self._dev[3], self._dev[2])
+        if self._dev is None or self._dev[0] is not engine or stale:
+            if self._dev is not None and stale:
+                self._dev[1].close()              # a series was replaced or removed: the resident rows are rebuilt
+            self._dev = [engine, DeviceGroup(engine, self.n, len(ser)), 0, getattr(self.registry, "version", 0) - len(ser)]
+        _, dg, done, _ = self._dev
         if done < len(ser):
             dg.append(np.stack([s.y for s in ser[done:]]))
-            self._dev[2] = len(ser)
+        self._dev[2] = len(ser)
+        self._dev[3] = getattr(self.registry, "version", 0)
         return dg
 
 

@@ -203,6 +203,20 @@ def test_labels_series_group(muse):
     assert [x.ID(None) for x in lvs] == ["graph:a", "graph:b"]
     assert [x.UID() for x in g.FilterByLabelValues(lvs[0])] == [a.UID(), b.UID()]
     assert len(g.indexLabelValues(None)) == 3
+    # the cached partition is keyed by the registry's VERSION, not its size: the registry is a public dict -- a series
+    # removed and another added at the same count, or one replaced under its uid, must be seen (group.go:80-81 rebuilds every Run)
+    assert [x.ID(None) for x in g.indexLabelValues(["graph"])] == ["graph:a", "graph:b"]
+    del g.registry[c.UID()]
+    d = muse.NewSeries([9, 9, 1], muse.NewLabels({"graph": "c", "host": "1"}))
+    g.Add(d)
+    assert len(g.registry) == 3
+    assert [x.ID(None) for x in g.indexLabelValues(["graph"])] == ["graph:a", "graph:c"]
+    assert g._group_ids().tolist() == [0, 0, 1]
+    v0 = g.registry.version
+    g.registry[b.UID()] = muse.NewSeries([7, 7, 8], muse.NewLabels({"graph": "a", "host": "2"}))   # replaced in place
+    assert g.registry.version == v0 + 1 and not g._appended_only(v0, 3)
+    g.Add(muse.NewSeries([0, 1, 0], muse.NewLabels({"graph": "c", "host": "2"})))
+    assert g._appended_only(g.registry.version - 1, 3)
 
 
 def test_results_heap_matches_oracle(muse, oracle):
