@@ -204,7 +204,7 @@ int run_select(muse_batch *b, const int32_t *group_id, int32_t G_in, int64_t ser
     // fed ONE Score per group in group order: the reference's own feed (muse_batch.go:124-128, results.go:55-72), so exactly tied
     // scores -- every series that clamps to 1.0 ties -- survive at the TopN boundary and come back from Fetch as they do there,
     // for every binding of this entry point.  Beyond that the device pre-selects each chunk's best top_n (ties at the boundary
-    // then go to the lower group id: DESIGN 8.3).
+    // then go to the lower group id: docs/HISTORY.md 8.3).
     const bool on_device = select_on_device(top_n, G);
     const int K = on_device ? top_n : 1;
     rc = ensure_select_ws(b, M, G, group_id != nullptr, K, on_device);

@@ -7,7 +7,7 @@
 using namespace muse;
 
 
-// ---- filter-and-refine Run: ungrouped N = n = 4096 Runs under automatic kernel selection
+// ---- filter-and-refine Run (docs/HISTORY.md 4.6): ungrouped N = n = 4096 Runs under automatic kernel selection
 muse_batch::RunKey run_key(const muse_batch *b, const int32_t *group_id, int64_t G, int32_t max_lag, int32_t top_n,
                                   double threshold, int32_t sign_filter, int32_t abs_scores)
 {

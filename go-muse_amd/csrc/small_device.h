@@ -569,14 +569,14 @@ __device__ __forceinline__ void forward_split_dit(double2 (&v)[16], double2 *b, 
 // transpose A hit every second slot twice.  A GF(2)-linear relabelling makes each read group read ONE aligned block of
 // sixteen columns (column bit 4 = that parity) and spreads the eight lanes of a write group over the eight slots
 // (column bit 3 ^= lane bit 1 for R1 = 4, lane bit 0 for R1 = 2 / 8): reads 8 -> 4 LDS cycles, transpose-A writes
-// 16 -> 8; n = 8192: 26.0 % -> 27.9 % of the HBM roofline, n = 1024 / 2048: + 1 point.  Global addresses are
+// 16 -> 8 (docs/HISTORY.md section 4.2); n = 8192: 26.0 % -> 27.9 % of the HBM roofline, n = 1024 / 2048: + 1 point.  Global addresses are
 // permuted inside aligned 32-lane groups only: every wave instruction touches the same cache lines as before.
 template <int LOGN>
 __device__ __forceinline__ int column_of_lane(const int l)
 {
     const int rg = ((l >> 4) ^ (l >> 3) ^ (l >> 2)) & 1;
     if (LOGN == 9) // n = 512: the register trade of transpose B (level()) pairs lane l with lane l + 16 as columns c and c + 16, so
-                   // column bit 4 must stay lane bit 4 and the read groups keep their pad-slot conflict;
+                   // column bit 4 must stay lane bit 4 and the read groups keep their pad-slot conflict (docs/HISTORY.md section 4.2);
                    // column bit 3 ^= lane bit 2 still spreads the stride-2 writes of transpose A over all eight slots
                    // (tools/lds_bank_sim.py: 16 -> 8 LDS cycles per store) and leaves transpose B's stores conflict-free
         return (l & ~8) | ((((l >> 3) ^ (l >> 2)) & 1) << 3);

@@ -12,7 +12,7 @@
 //          transforms (three radix-16 passes each, half-round LDS transposes, 34.8 KB of LDS per workgroup);
 // sweep 2: twiddle W_n^(k1 l2), radix R1 over k1 -> cc; (N < n: minus mean * c1[lag]) ; running argmax.
 // The pair crosses the scratch slice four times (2 writes + 2 reads of 16 n bytes) next to its 16 N bytes of HBM input:
-// that traffic, not arithmetic, bounds the kernel.
+// that traffic, not arithmetic, bounds the kernel (docs/HISTORY.md section 4.3).
 //
 // As in xcorr_r16_fold.hip both series of a pair share one complex transform UNSCALED (their statistics are only known
 // behind sweep 1): pairs with a NaN / Inf series or with sigmas too far apart are listed and redone by the kernel that

@@ -1,5 +1,5 @@
 // xcorr_r16_screen.hip -- the fp32 screening pass of the OPT-IN filter-and-refine Run, n = 4096
-// (muse_ctx_set_screening).  Not on the default path: by default every series is scored by
+// (muse_ctx_set_screening; docs/HISTORY.md 4.6).  Not on the default path: by default every series is scored by
 // the float64 kernel (xcorr_r16_fold.hip), the arithmetic of the reference (xcorr.go:160-197).
 //
 // What the pass does: z-normalisation statistics in fp64 while the rows arrive, both transforms in fp32 on a
@@ -153,7 +153,7 @@ __device__ __forceinline__ void reduce_series(const double (&r)[16], const doubl
 // re-evaluation.  Per series it writes
 //   mv[row]   sigma times the fp32 estimate of the signed score at the fp32 argmax (the fp32 value with its exact
 //             power-of-two scale, as a double) and scr_var[row] = sigma^2: score estimate = mv / sqrt(var), with
-//             |estimate - exact| <= E at every lag (E: the caller's bound), and
+//             |estimate - exact| <= E at every lag (E: the caller's bound, docs/HISTORY.md 4.6), and
 //   flags[row]: what the lags whose fp32 |cc| lies within `screen_delta` = 2 E (scaled units) of the fp32 maximum -- the
 //             only lags that can be the exact argmax -- look like:
 //             SCR_IN / SCR_OUT: one of them has |lag| <= / > max_lag;  SCR_POS / SCR_NEG: its value is > 0 / < 0

@@ -1,4 +1,4 @@
-// xcorr_screen_stk.hip -- the fp32 screening pass of the filter-and-refine Run for the FFT lengths
+// xcorr_screen_stk.hip -- the fp32 screening pass of the filter-and-refine Run (docs/HISTORY.md 4.6) for the FFT lengths
 // n = 512, 1024, 2048 and 8192 (series of n/2 < N <= n samples, leading zero pad): the radix-16 Stockham structure of
 // xcorr_stockham.hip (xcorr_fused_stk_lds) with 8-byte complex values -- half the LDS bytes and twice the resident
 // workgroups of the fp64 kernel (three per CU at 168 VGPRs instead of two).  Same contract as xcorr_screen_pass_n4096 (xcorr_r16_screen.hip): per series an

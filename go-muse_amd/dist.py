@@ -233,7 +233,7 @@ class ShardedBatch:
         idx, lag, score, _, grp = run_grouped_sharded(self.dbatch, self.series_offset, group_id, G, r.MaxLag, r.TopN, r.Threshold,
                                                       r.SignFilter, True, self.group, self.device, with_groups=True)
         # the pre-selected candidates, fed in group order (muse_batch.go:124-128); among EXACTLY tied scores the survivor at the
-        # TopN boundary may differ from a full feed
+        # TopN boundary may differ from a full feed (docs/HISTORY.md 8.3)
         for k in np.lexsort((idx, grp)):
             r.Update(Score(self.labels_of(int(idx[k]), int(grp[k])), int(lag[k]), float(score[k])))
         return None

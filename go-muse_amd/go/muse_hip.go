@@ -25,6 +25,7 @@ import (
 	"runtime"
 	"sort"
 	"sync"
+	"sync/atomic"
 	"unsafe"
 )
 
@@ -156,36 +157,88 @@ func SetScreening(enable bool, minRows int) error {
 	return hipError(C.muse_ctx_set_screening(e.ctx, v))
 }
 
-// appendSeries uploads series (all of length n) to a device group in slabs of up to 32 MB packed in C memory: one cgo
-// call per slab instead of one per Series (a million calls for a million-series Group), and no Go pointer crosses.
+// appendSeries uploads series (all of length n) to a device group through the library's pinned staging windows
+// (muse_group_stage / muse_group_commit): every Series is copied ONCE, straight out of its Go slice into pinned C memory, by a
+// few goroutines in pieces of ~256 KB; a piece that completes the packed prefix of the window commits that prefix -- runs of
+// >= 4 MB, one host-to-device copy command each (a command costs ~13 us whatever its size) -- so the rows cross PCIe while the
+// next pieces are packed.  No Go pointer crosses: the window is C memory, the goroutines write into it through unsafe.Slice.
 func appendSeries(g *C.muse_group, series []*Series, n int) error {
-	if len(series) == 0 {
-		return nil
-	}
-	rowsPerSlab := (32 << 20) / (8 * n)
-	if rowsPerSlab < 1 {
-		rowsPerSlab = 1
-	}
-	if rowsPerSlab > len(series) {
-		rowsPerSlab = len(series)
-	}
-	buf := (*C.double)(C.malloc(C.size_t(rowsPerSlab) * C.size_t(n) * 8))
-	if buf == nil {
-		return errors.New("out of memory staging series for upload")
-	}
-	defer C.free(unsafe.Pointer(buf))
-	slab := unsafe.Slice((*float64)(unsafe.Pointer(buf)), rowsPerSlab*n)
-	for i := 0; i < len(series); i += rowsPerSlab {
-		k := rowsPerSlab
-		if k > len(series)-i {
-			k = len(series) - i
-		}
-		for r := 0; r < k; r++ {
-			copy(slab[r*n:(r+1)*n], series[i+r].y)
-		}
-		if err := hipError(C.muse_group_append(g, buf, C.int64_t(k), C.int64_t(n))); err != nil {
+	for first := 0; first < len(series); {
+		var win *C.double
+		var granted C.int64_t
+		if err := hipError(C.muse_group_stage(g, C.int64_t(len(series)-first), &win, &granted)); err != nil {
 			return err
 		}
+		k := int(granted)
+		rows := unsafe.Slice((*float64)(unsafe.Pointer(win)), k*n)
+		piece := (256 << 10) / (8 * n)
+		if piece < 1 {
+			piece = 1
+		}
+		npieces := (k + piece - 1) / piece
+		commitPieces := (4 << 20) / (piece * 8 * n)
+		if commitPieces < 1 {
+			commitPieces = 1
+		}
+		workers := runtime.GOMAXPROCS(0)
+		if workers > 8 {
+			workers = 8
+		}
+		if workers > npieces {
+			workers = npieces
+		}
+		var (
+			mu        sync.Mutex
+			done      = make([]bool, npieces)
+			watermark = 0
+			next      int64 = -1
+			firstErr  error
+			wg        sync.WaitGroup
+		)
+		for w := 0; w < workers; w++ {
+			wg.Add(1)
+			go func() {
+				defer wg.Done()
+				runtime.LockOSThread() // (muse_last_error is per host thread)
+				defer runtime.UnlockOSThread()
+				for {
+					p := int(atomic.AddInt64(&next, 1))
+					if p >= npieces {
+						return
+					}
+					lo, hi := p*piece, (p+1)*piece
+					if hi > k {
+						hi = k
+					}
+					for r := lo; r < hi; r++ {
+						copy(rows[r*n:(r+1)*n], series[first+r].y)
+					}
+					mu.Lock()
+					done[p] = true
+					wm := watermark
+					for wm < npieces && done[wm] {
+						wm++
+					}
+					if wm > watermark && (wm == npieces || wm-watermark >= commitPieces) {
+						clo, chi := watermark*piece, wm*piece
+						if chi > k {
+							chi = k
+						}
+						// (every row is committed even after a failure: the window has to close)
+						if err := hipError(C.muse_group_commit(g, C.int64_t(clo), C.int64_t(chi-clo))); err != nil && firstErr == nil {
+							firstErr = err
+						}
+						watermark = wm
+					}
+					mu.Unlock()
+				}
+			}()
+		}
+		wg.Wait()
+		if firstErr != nil {
+			return firstErr
+		}
+		first += k
 	}
 	return nil
 }
@@ -285,7 +338,9 @@ type Batch struct {
 	Comparison  *Group
 	Results     *Results
 	Concurrency int
-	batch       *C.muse_batch
+	probe       *C.muse_group // empty group the template batch is bound to
+	template    *C.muse_batch // owns the reference spectrum: validated and transformed ONCE, in NewBatch
+	batch       *C.muse_batch // the batch over the Comparison group's resident rows: shares the template's spectrum
 	batchGroup  *C.muse_group
 	shardBatch  []*C.muse_batch // sharded Runs (SetDevices): one device batch per shard
 	shardGroup  []*C.muse_group
@@ -310,23 +365,22 @@ func NewBatch(ref *Series, comp *Group, results *Results, cc int) (*Batch, error
 	// validate the reference now (sigma == 0 -> error), as the reference does
 	runtime.LockOSThread()
 	defer runtime.UnlockOSThread()
-	var probe *C.muse_group
-	if err := hipError(C.muse_group_create(e.ctx, 0, C.int32_t(len(b.ref)), &probe)); err != nil {
+	if err := hipError(C.muse_group_create(e.ctx, 0, C.int32_t(len(b.ref)), &b.probe)); err != nil {
 		return nil, err
 	}
-	defer C.muse_group_free(probe)
-	var mb *C.muse_batch
-	st := C.muse_batch_create(e.ctx, probe, (*C.double)(unsafe.Pointer(&b.ref[0])), C.int32_t(len(b.ref)), &mb)
+	st := C.muse_batch_create(e.ctx, b.probe, (*C.double)(unsafe.Pointer(&b.ref[0])), C.int32_t(len(b.ref)), &b.template)
 	if err := hipError(st); err != nil {
+		C.muse_group_free(b.probe)
 		return nil, fmt.Errorf("Invalid input query, %v", err)
 	}
-	C.muse_batch_free(mb)
-	// the device batch Run creates lazily is released with the Batch (muse_batch_free takes no error path)
+	// the device handles are released with the Batch (muse_batch_free takes no error path)
 	runtime.SetFinalizer(b, func(b *Batch) {
 		if b.batch != nil {
 			C.muse_batch_free(b.batch)
 			b.batch = nil
 		}
+		C.muse_batch_free(b.template)
+		C.muse_group_free(b.probe)
 		for _, sb := range b.shardBatch {
 			if sb != nil {
 				C.muse_batch_free(sb)
@@ -382,7 +436,8 @@ func (b *Batch) Run(groupByLabels []string) error {
 		if b.batch != nil {
 			C.muse_batch_free(b.batch)
 		}
-		st := C.muse_batch_create(e.ctx, dg, (*C.double)(unsafe.Pointer(&b.ref[0])), C.int32_t(len(b.ref)), &b.batch)
+		// (no second transform of the reference: the batch over the resident rows shares the template's spectrum)
+		st := C.muse_batch_create_like(b.template, dg, &b.batch)
 		if err := hipError(st); err != nil {
 			return err
 		}

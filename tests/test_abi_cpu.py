@@ -96,7 +96,8 @@ def test_go_shim_calls_match_the_header():
         assert nargs == declared[name], "C.%s called with %d arguments, the header declares %d" % (name, nargs, declared[name])
         used.add(name)
     # the calls a drop-in Batch / Muse / sharded Run cannot do without
-    for need in ("muse_ctx_create", "muse_group_create", "muse_group_append", "muse_batch_create", "muse_batch_run",
+    for need in ("muse_ctx_create", "muse_group_create", "muse_group_stage", "muse_group_commit", "muse_batch_create",
+                 "muse_batch_create_like", "muse_batch_run",
                  "muse_batch_run_shard", "muse_batch_run_groups", "muse_merge_records", "muse_merge_group_records",
                  "muse_batch_run_rows", "muse_last_error", "muse_device_count"):
         assert need in used, need

@@ -1,7 +1,7 @@
 // EXPERIMENT (diagnostic only, not part of libmuse_hip.so): how fast is a PURE fp32 screening pass over
 // 1 M x 4096 at four workgroups per CU (128 VGPRs, 37 KB LDS)?  Approximate scores only (fp32 transform error,
 // ~1e-6 absolute): a product path would re-evaluate the rows that can reach the top-N / sit near a filter bound
-// with the fp64 kernel (filter-and-refine).  See DESIGN.md "what comes next".
+// with the fp64 kernel (filter-and-refine).  See docs/HISTORY.md 4.6.
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -I include -I go-muse_amd/csrc tools/ablate/screen_only.hip -o tools/ablate/screen_only
 #include <hip/hip_runtime.h>
 #include <cstdio>

@@ -3,7 +3,7 @@
 
 Compiles each source for gfx950 with -Rpass-analysis=kernel-resource-usage and prints one line per kernel:
 VGPRs, AGPRs, scratch bytes per lane (spills), SGPRs, LDS bytes, occupancy (waves per SIMD).  Used to check that a
-kernel change did not start spilling (a scratch reload queues on the same in-order vmcnt as the HBM stream).
+kernel change did not start spilling (docs/HISTORY.md 4.1: a scratch reload queues on the same in-order vmcnt as the HBM stream).
 """
 import os
 import re
