@@ -79,6 +79,9 @@ static int group_create(muse_ctx *ctx, int64_t capacity_rows, int32_t N, bool f3
     return MUSE_OK;
 }
 
+// Growth never waits for the device: the new block's guard is zeroed and the rows are copied over ON THE COPY STREAM (behind
+// every upload into the old block that is still in flight), `uploaded` orders the readers behind that, and the old block stays
+// alive until the group goes -- a score pass enqueued earlier may still be reading it.
 static int group_reserve(muse_group *g, int64_t rows)
 {
     if (rows <= g->cap)
@@ -88,17 +91,18 @@ static int group_reserve(muse_group *g, int64_t rows)
     hipError_t e = dmalloc(g->ctx, &nr, ((size_t)ncap * (size_t)g->N + GROUP_GUARD) * g->elem());
     if (e != hipSuccess)
         return fail(MUSE_ERR_NOMEM, "hipMalloc of %lld rows failed: %s", (long long)ncap, hipGetErrorString(e));
-    HIP_TRY(hipStreamSynchronize(g->ctx->copy_stream)); // uploads into the old allocation have landed
-    HIP_TRY(hipStreamSynchronize(g->ctx->stream));      // no kernel is still reading it
     HIP_TRY(zero_guard(g, nr));
     nr = (char *)nr + GROUP_GUARD * g->elem();
     if (g->M > 0) {
-        HIP_TRY(hipMemcpyAsync(nr, g->base(), (size_t)g->M * (size_t)g->N * g->elem(), hipMemcpyDeviceToDevice,
-                               g->ctx->copy_stream));
-        HIP_TRY(hipStreamSynchronize(g->ctx->copy_stream));
+        // (rows still packed in the staging buffer and not sent yet are not in the old block: only the sent ones are copied)
+        const int64_t sent = g->M - (g->staged - g->flushed);
+        if (sent > 0)
+            HIP_TRY(hipMemcpyAsync(nr, g->base(), (size_t)sent * (size_t)g->N * g->elem(), hipMemcpyDeviceToDevice, g->ctx->copy_stream));
+        HIP_TRY(hipEventRecord(g->uploaded, g->ctx->copy_stream));
+        g->upload_pending = true;
     }
     if (g->base())
-        dfree(g->ctx, (char *)g->base() - GROUP_GUARD * g->elem());
+        g->retired.push_back((char *)g->base() - GROUP_GUARD * g->elem());
     (g->f32 ? (void *&)g->rows32 : (void *&)g->rows) = nr;
     g->cap = ncap;
     return MUSE_OK;
@@ -337,6 +341,8 @@ extern "C" int muse_group_fill_synthetic(muse_group *g, int64_t first, int64_t c
     if (rc)
         return rc;
     rc = group_reserve(g, first + count);
+    if (!rc)
+        rc = group_ready(g); // (a growth copies the old rows over on the copy stream: the fill waits for it)
     if (rc)
         return rc;
     if (g->f32)
@@ -410,6 +416,8 @@ void group_release(muse_group *g)
         (void)hipEventDestroy(g->uploaded);
     if (g->base())
         dfree(g->ctx, (char *)g->base() - GROUP_GUARD * g->elem());
+    for (void *old : g->retired)
+        dfree(g->ctx, old);
     for (int i = 0; i < 2; i++) {
         if (g->stage[i]) { // back to the context's pool (the stream is idle: no upload reads it any more)
             std::lock_guard<std::mutex> lock(g->ctx->stage_mu);

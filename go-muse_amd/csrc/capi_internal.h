@@ -130,6 +130,9 @@ struct muse_group {
     size_t elem() const { return f32 ? sizeof(float) : sizeof(double); }
     void *base() const { return f32 ? (void *)rows32 : (void *)rows; }
     int64_t cap = 0, M = 0, stride = 0; // M counts staged rows too
+    // allocations the group has outgrown: kept until the group goes (kernels enqueued before the growth may still read them),
+    // so that growing never waits for the device (group_reserve)
+    std::vector<void *> retired;
     int32_t N = 0;
     // Appends that are small (Group.Add calls muse_group_append once per Series) are packed into two pinned staging buffers
     // borrowed from the context's pool and uploaded asynchronously on the context's copy stream: a piece goes out whenever

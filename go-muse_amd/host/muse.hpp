@@ -22,7 +22,9 @@
 #include <condition_variable>
 #include <cstdint>
 #include <cstring>
+#include <deque>
 #include <functional>
+#include <future>
 #include <limits>
 #include <map>
 #include <memory>
@@ -223,6 +225,58 @@ private:
     uint64_t generation_ = 0;
     bool stop_ = false;
 };
+// One parked thread that runs upload jobs in order (Group.Add streams the rows it has been given towards the device while
+// the caller goes on adding: the job packs with the Workers above and commits; the caller meets it again in Group::device).
+class Uploader {
+public:
+    static Uploader &get()
+    {
+        static Uploader u;
+        return u;
+    }
+    std::future<void> submit(std::function<void()> fn)
+    {
+        std::packaged_task<void()> task(std::move(fn));
+        std::future<void> f = task.get_future();
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            q_.push_back(std::move(task));
+        }
+        cv_.notify_one();
+        return f;
+    }
+    ~Uploader()
+    {
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        th_.join();
+    }
+
+private:
+    Uploader() : th_([this] { loop(); }) {}
+    void loop()
+    {
+        std::unique_lock<std::mutex> lock(mu_);
+        for (;;) {
+            cv_.wait(lock, [&] { return stop_ || !q_.empty(); });
+            if (q_.empty())
+                return;
+            std::packaged_task<void()> task = std::move(q_.front());
+            q_.pop_front();
+            lock.unlock();
+            task();
+            lock.lock();
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<std::packaged_task<void()>> q_;
+    bool stop_ = false;
+    std::thread th_; // (declared last: the thread starts with every other member built)
+};
 } // namespace detail
 
 // ------------------------------------------------------ engine (muse_ctx)
@@ -236,8 +290,11 @@ public:
     static std::shared_ptr<Engine> Default()
     {
         static std::shared_ptr<Engine> e = std::make_shared<Engine>(0);
+        default_created().store(true);
         return e;
     }
+    // the default engine if some caller has already made it (never creates a context: Group.Add uses it to stream rows ahead)
+    static std::shared_ptr<Engine> DefaultIfCreated() { return default_created().load() ? Default() : nullptr; }
     // One engine (context, stream, tables) per listed device: the device set a Batch shards its Comparison group over
     // (the goroutine fan-out of muse_batch.go:99-130 becomes one host thread per device).  A device may be
     // listed more than once (several contexts on one GPU: what the tests on a one-GPU box do).
@@ -274,6 +331,11 @@ public:
     }
 
 private:
+    static std::atomic<bool> &default_created()
+    {
+        static std::atomic<bool> flag{false};
+        return flag;
+    }
     muse_ctx *ctx_ = nullptr;
 };
 
@@ -283,10 +345,18 @@ public:
     explicit Group(std::string name) : Name(std::move(name)) {}
     ~Group()
     {
+        drain_stream(false);
         if (dev_)
             muse_group_free(dev_);
         free_shards();
     }
+    // Rows are streamed towards the default engine's HBM as they are added ("Group.Add stages series into a
+    // C-allocated pinned buffer"): whenever STREAM_BYTES of new series have gathered, a background job packs them into a pinned
+    // window and commits them, while the caller goes on adding -- by the time a Batch runs, most of the Group is resident.
+    // Only if the process already HAS a default engine (Add never creates a GPU context), and only towards it: a Batch on
+    // another engine or over a device list uploads on its own, as before.  Off: Group::StreamOnAdd = false.
+    static inline bool StreamOnAdd = true;
+    static constexpr size_t STREAM_BYTES = (size_t)4 << 20;
     std::string Name;
     int Length() const { return n_; }
     // group.go:31-56; errors come back as muse::Error(MUSE_ERR_INVALID / MUSE_ERR_LENGTH)
@@ -306,6 +376,8 @@ public:
                 throw Error(MUSE_ERR_INVALID,
                             "Series with label:values, " + uid + ", already exists within group, " + Name);
             order_.push_back(s);
+            if (StreamOnAdd && (order_.size() - uploaded_) * (size_t)n_ * sizeof(double) >= STREAM_BYTES)
+                maybe_stream();
         }
     }
     std::vector<SeriesPtr> FilterByLabelValues(const Labels &labels) const // group.go:60-71
@@ -425,6 +497,17 @@ public:
     // device residency: rows are uploaded once and appended to (muse_group_append)
     muse_group *device(const std::shared_ptr<Engine> &eng, const std::function<void()> *side = nullptr)
     {
+        if (dev_ && eng_ == eng && stream_job_.valid()) {
+            // rows are already streaming towards this engine: the rest goes to the background uploader as well (behind the job
+            // in flight), the caller's side work runs beside it, then the two meet
+            if (uploaded_ < order_.size())
+                submit_rest();
+            if (side) {
+                (*side)();
+                side = nullptr;
+            }
+        }
+        drain_stream(true); // (rows handed to the background uploader are committed; its errors surface here)
         if (!dev_ || eng_ != eng) {
             if (dev_)
                 muse_group_free(dev_);
@@ -446,6 +529,26 @@ private:
     // `side` (optional) runs on the calling thread while the other threads pack: host work that does not need the rows
     // (Batch.Run partitions the labels there).
     void append_rows(muse_group *dev, size_t first, size_t last, const std::function<void()> *side = nullptr)
+    {
+        if (first >= last) {
+            if (side)
+                (*side)();
+            return;
+        }
+        const std::vector<const double *> rows = row_pointers(first, last);
+        append_window_loop(dev, rows.data(), 0, rows.size(), n_, side);
+    }
+    // the sample pointers of series [first, last): what a packing job reads (the Series stay alive in order_ as long as the Group
+    // does, and the Group's destructor waits for its jobs; order_ itself may be growing under Add meanwhile)
+    std::vector<const double *> row_pointers(size_t first, size_t last) const
+    {
+        std::vector<const double *> rows(last - first);
+        for (size_t i = first; i < last; i++)
+            rows[i - first] = order_[i]->Values().data();
+        return rows;
+    }
+    static void append_window_loop(muse_group *dev, const double *const *rows, size_t first, const size_t last, const int n_,
+                                   const std::function<void()> *side)
     {
         const size_t row_bytes = sizeof(double) * (size_t)n_;
         bool side_done = side == nullptr;
@@ -473,7 +576,7 @@ private:
                 const int p = task - extra;
                 const size_t lo = (size_t)p * piece, hi = std::min((size_t)granted, lo + piece);
                 for (size_t r = lo; r < hi; r++)
-                    memcpy(win + r * (size_t)n_, order_[first + r]->Values().data(), row_bytes);
+                    memcpy(win + r * (size_t)n_, rows[first + r], row_bytes);
                 std::lock_guard<std::mutex> lock(commit_mu);
                 done[(size_t)p] = 1;
                 int w = watermark;
@@ -497,6 +600,63 @@ private:
         if (!side_done)
             (*side)();
     }
+    // hand the series added since the last hand-over to the background uploader (one job in flight at a time: while one runs,
+    // the next Adds just accumulate)
+    void maybe_stream()
+    {
+        if (!stream_checked_) {
+            stream_checked_ = true;
+            stream_eng_ = Engine::DefaultIfCreated();
+        }
+        if (!stream_eng_ || (dev_ && eng_ != stream_eng_) || !shards_.empty())
+            return;
+        if (stream_job_.valid()) {
+            if (stream_job_.wait_for(std::chrono::seconds(0)) != std::future_status::ready)
+                return;
+            stream_job_.get(); // (rethrows what the job met)
+        }
+        if (!dev_) {
+            eng_ = stream_eng_;
+            uploaded_ = 0;
+            // (capacity for four hand-overs; growth beyond is asynchronous in the library: muse_group_append's reserve)
+            check(muse_group_create(eng_->handle(), (int64_t)(4 * (order_.size() - uploaded_)), n_, &dev_));
+        }
+        submit_rest();
+    }
+    // series [uploaded_, size) to the background uploader (jobs run in order: one that is still queued behind another is fine)
+    void submit_rest()
+    {
+        auto part = std::make_shared<std::vector<const double *>>(row_pointers(uploaded_, order_.size()));
+        uploaded_ = order_.size();
+        muse_group *const dev = dev_;
+        const int n = n_;
+        if (stream_job_.valid())
+            stream_older_.push_back(std::move(stream_job_));
+        stream_job_ = detail::Uploader::get().submit([part, dev, n] { append_window_loop(dev, part->data(), 0, part->size(), n, nullptr); });
+    }
+    void drain_stream(bool rethrow)
+    {
+        std::exception_ptr first;
+        for (auto &f : stream_older_) {
+            try {
+                f.get();
+            } catch (...) {
+                if (!first)
+                    first = std::current_exception();
+            }
+        }
+        stream_older_.clear();
+        if (stream_job_.valid()) {
+            try {
+                stream_job_.get();
+            } catch (...) {
+                if (!first)
+                    first = std::current_exception();
+            }
+        }
+        if (first && rethrow)
+            std::rethrow_exception(first);
+    }
     void free_shards()
     {
         for (auto &sh : shards_)
@@ -516,8 +676,12 @@ private:
     std::vector<LabelsPtr> index_distinct_;
     std::shared_ptr<Engine> eng_;
     muse_group *dev_ = nullptr;
-    size_t uploaded_ = 0;
+    size_t uploaded_ = 0;                 // series resident in dev_ or handed to the background uploader
     std::vector<Shard> shards_;
+    std::shared_ptr<Engine> stream_eng_;  // the engine Add streams towards (the default engine, if the process had one at the first hand-over)
+    bool stream_checked_ = false;
+    std::future<void> stream_job_;              // the newest job
+    std::vector<std::future<void>> stream_older_; // jobs queued in front of it whose outcome has not been collected yet
 };
 using GroupPtr = std::shared_ptr<Group>;
 inline GroupPtr NewGroup(std::string name) { return std::make_shared<Group>(std::move(name)); }
