@@ -5,6 +5,7 @@
 // Exit code 0 = all passed.  Needs a gfx950 GPU (there is no CPU fallback).
 #include <cstdio>
 #include <cmath>
+#include <random>
 #include <string>
 #include <thread>
 #include <vector>
@@ -473,6 +474,48 @@ static void TestXCorrBatchEqualsSinglePairs() // xcorr_test.go:86-202 exercises 
     }
 }
 
+// Rows streamed towards the device while the Group is still being built (Group::StreamOnAdd: background hand-overs of >= 4 MB, the
+// group growing past its first capacity while copies are in flight, series added after a Run, a second Run) must give the Results
+// of the same Group uploaded in one piece at Run.
+static void TestStreamedGroupEqualsUploadedAtRun()
+{
+    std::mt19937_64 rng(77);
+    std::normal_distribution<double> nd(0.0, 1.0);
+    const int N = 700, M = 9000; // 50 MB: a dozen hand-overs, three growths
+    std::vector<double> refv((size_t)N);
+    for (auto &x : refv)
+        x = nd(rng);
+    auto ref = NewSeries(refv, NewLabels({{"graph", "ref"}}));
+    std::vector<SeriesPtr> all;
+    for (int i = 0; i < M; i++) {
+        std::vector<double> y((size_t)N);
+        for (auto &x : y)
+            x = nd(rng);
+        if (i % 7 == 0)
+            for (int t = 0; t < N; t++)
+                y[(size_t)t] += 1.5 * refv[(size_t)((t + 3 + i % 5) % N)];
+        all.push_back(NewSeries(std::move(y), NewLabels({{"graph", "g" + std::to_string(i % 300)}, {"host", "h" + std::to_string(i)}})));
+    }
+    std::pair<Scores, double> out[2], out2[2];
+    for (int streamed = 0; streamed < 2; streamed++) {
+        Group::StreamOnAdd = streamed != 0;
+        auto g = NewGroup("targets");
+        for (int i = 0; i < M - 500; i++)
+            g->Add({all[(size_t)i]});
+        auto b = NewBatch(ref, g, NewResults(40, 25, 0, SignFilter_ANY), 4);
+        b->Run({"graph"});
+        out[streamed] = b->Results_->Fetch();
+        for (int i = M - 500; i < M; i++) // series added after a Run extend the resident rows
+            g->Add({all[(size_t)i]});
+        b->Run({"graph"});
+        out2[streamed] = b->Results_->Fetch();
+    }
+    Group::StreamOnAdd = true;
+    EXPECT(out[0].first.size() == 25 && out2[0].first.size() == 25, "streamed group: 25 scores");
+    sameScores(out[0], out[1], "streamed group vs uploaded at Run");
+    sameScores(out2[0], out2[1], "streamed group vs uploaded at Run, after more Adds");
+}
+
 int main()
 {
     try {
@@ -498,6 +541,7 @@ int main()
         TestBatchRunAllVisibleDevices();
         Batch::EXACT_FEED_MAX_GROUPS = 65536;
         TestXCorrBatchEqualsSinglePairs();
+        TestStreamedGroupEqualsUploadedAtRun();
     } catch (const Error &e) {
         printf("muse::Error %d: %s\n", e.status, e.what());
         return 2;
