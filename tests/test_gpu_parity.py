@@ -39,6 +39,19 @@ def eng(muse):
     return muse.get_engine(0)
 
 
+def _record_worst(tag, a, b):
+    """MUSE_TEST_WORST=<file>: appends the worst relative difference of a kernel-vs-kernel comparison (how the measured values
+    quoted beside the loosened tolerances below were obtained)"""
+    path = os.environ.get("MUSE_TEST_WORST")
+    if not path:
+        return
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    ok = np.isfinite(a) & np.isfinite(b) & (b != 0)
+    worst = float(np.max(np.abs(a[ok] - b[ok]) / np.abs(b[ok]))) if ok.any() else 0.0
+    with open(path, "a") as f:
+        f.write("%s %.3e\n" % (tag, worst))
+
+
 def assert_scores_match(lag, mv, olag, omv, gap, max_ties=0):
     lag, mv, olag, omv = map(np.asarray, (lag, mv, olag, omv))
     nan_o = np.isnan(omv)
@@ -695,7 +708,10 @@ def test_many_references_one_pass_matches_single_batches(muse, eng, oracle, R, M
         # transform of a pair -- two float64 evaluations of the same numbers; lags may differ where the oracle flags a tie)
         other = batches[r].n in (8192, 32768, 65536)
         assert np.array_equal(lag, slag) or (other and np.all((lag == slag) | (gap < TIE_GAP)))
-        np.testing.assert_allclose(mv, smv, rtol=1e-9 if other else 1e-12, atol=0, equal_nan=True)
+        # measured worst relative difference (MUSE_TEST_WORST, round 6, one box): 0 at n = 512 ... 2048 (the same kernel), 1.4e-15 at
+        # 4096, 2.7e-15 at 8192, 3.2e-15 at 16384, 1.7e-15 at 32768 / 65536 -- round 5's 1e-9 for the "other" lengths was never needed
+        _record_worst("many_vs_single n=%d" % batches[r].n, mv, smv)
+        np.testing.assert_allclose(mv, smv, rtol=1e-12, atol=0, equal_nan=True)
     # Run semantics for every reference in one call
     gid = (np.arange(M) // 7).astype(np.int32)
     G = int(gid.max()) + 1
@@ -1184,8 +1200,11 @@ def test_screened_run_equals_fp64_run(muse, eng, oracle, N):
                 # afterwards, the re-evaluating kernel centres and rescales before the transform: the two fp64 results
                 # differ by ~1e-11 relative on the rows built to stress exactly that; n = 8192, 32768, 65536: the all-scores
                 # kernel is a real transform of one series (xcorr_real.hip), the re-evaluating one a complex transform of a pair)
-                loose = 2048 < N < 4096 or 4096 < N <= 8192 or N > 16384
-                np.testing.assert_allclose(got[2], exp[2], rtol=1e-9 if loose else 1e-12, atol=0, err_msg=str(key))
+                # measured worst relative difference (MUSE_TEST_WORST, round 6, one box): 0 up to N = 2048, 2.6e-12 at N = 3000,
+                # 3.5e-13 at 4096, 4.8e-13 at 5000, 1.4e-12 at 8192, 9.5e-13 at 16384, 3.8e-12 at 40000, 3.7e-12 at 65536
+                loose = 2048 < N < 4096 or N > 4096
+                _record_worst("screened_vs_all_scores N=%d" % N, got[2], exp[2])
+                np.testing.assert_allclose(got[2], exp[2], rtol=5e-11 if loose else 1e-12, atol=0, err_msg=str(key))
         # the all-scores API after a screened Run still returns fp64 results for every row
         lag2, mv2 = db.read_scores()
         assert np.array_equal(lag2, lag)
