@@ -92,6 +92,7 @@ SIGNATURES = {
     "muse_test_rows_always_copy": (ctypes.c_int, [_vp, _i32]),
     "muse_test_pool_stats": (ctypes.c_int, [_vp, _i64p, _i64p, _i64p, _i64p]),
     "muse_test_xcorr_repeat": (ctypes.c_int, [_vp, _i32]),
+    "muse_test_huge_batch_mb": (ctypes.c_int, [_vp, _i32]),
     "muse_test_clock_probe_start": (ctypes.c_int, [_vp, _f64, _f64]),
     "muse_test_clock_probe_stop": (ctypes.c_int, [_vp]),
     "muse_test_clock_probe_read": (ctypes.c_int, [_vp, _dp, _i32, _i32p]),

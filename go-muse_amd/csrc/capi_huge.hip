@@ -96,11 +96,10 @@ HugeParams huge_base(muse_ctx *ctx, int logn)
     return p;
 }
 
-int64_t pairs_per_batch(int64_t n)
+int64_t pairs_per_batch(const muse_ctx *ctx, int64_t n)
 {
-    size_t bytes = HUGE_BATCH_BYTES;
-    if (const char *e = getenv("MUSE_HUGE_BATCH_MB")) // measurement knob (tools/huge_bench.py): the work buffer of one batch
-        bytes = (size_t)std::max(1, atoi(e)) << 20;
+    // (measurement hook muse_test_huge_batch_mb, tools/huge_bench.py: the work buffer of one batch; 0 = the built-in 128 MB)
+    const size_t bytes = ctx->huge_batch_mb > 0 ? (size_t)ctx->huge_batch_mb << 20 : HUGE_BATCH_BYTES;
     return std::max<int64_t>(1, (int64_t)(bytes / ((size_t)n * sizeof(double2))));
 }
 
@@ -165,7 +164,7 @@ int huge_score(muse_batch *b)
 {
     muse_ctx *ctx = b->ctx;
     const int64_t M = b->g->M, n = b->n;
-    const int64_t ppb = pairs_per_batch(n);
+    const int64_t ppb = pairs_per_batch(ctx, n);
     std::lock_guard<std::mutex> lock(ctx->huge_mu);
     int rc = huge_ensure(ctx, b->logn, ppb, false);
     if (rc)
@@ -198,7 +197,7 @@ int huge_pairs(muse_ctx *ctx, const double *xrows, int64_t xstride, int Nx, int 
                int64_t ystride, int Ny, int normalize_y, int64_t M, int n, double cc_scale, double *mv, int *lag, int *nil, double *cc)
 {
     const int logn = ilog2(n);
-    const int64_t ppb = pairs_per_batch(n);
+    const int64_t ppb = pairs_per_batch(ctx, n);
     std::lock_guard<std::mutex> lock(ctx->huge_mu);
     int rc = huge_ensure(ctx, logn, std::min<int64_t>(ppb, M), true);
     if (rc)
@@ -235,5 +234,13 @@ int huge_pairs(muse_ctx *ctx, const double *xrows, int64_t xstride, int Nx, int 
         py.cc_out = cc;
         HIP_TRY(launch_huge(py, HUGE_STAGE_STATS | HUGE_STAGE_SWEEP1 | HUGE_STAGE_ROWS | HUGE_STAGE_SWEEP2 | HUGE_STAGE_FINAL, ctx->stream));
     }
+    return MUSE_OK;
+}
+
+extern "C" int muse_test_huge_batch_mb(muse_ctx *ctx, int32_t megabytes)
+{
+    if (!ctx || megabytes < 0 || megabytes > 4096)
+        return fail(MUSE_ERR_INVALID, "batch size 0 (built-in) ... 4096 MB");
+    ctx->huge_batch_mb = megabytes;
     return MUSE_OK;
 }

@@ -111,6 +111,7 @@ struct muse_ctx {
     // result record and an event each -- so that a Muse.Run allocates nothing in steady state
     MemPool dev_pool, host_pool;   // dmalloc / hmalloc
     HugeWork huge;                 // series longer than 65 536 samples
+    int huge_batch_mb = 0;         // measurement hook (muse_test_huge_batch_mb): 0 = HUGE_BATCH_BYTES
     std::mutex huge_mu;
     std::mutex timing_mu;          // events / redo_events (LaunchTimer::end from concurrent muse_batch_run_rows callers)
     std::atomic<bool> rows_always_copy{false}; // test hook (muse_test_rows_always_copy): never let a kernel read the pinned staging buffer

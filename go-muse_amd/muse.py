@@ -86,6 +86,10 @@ class Engine:
         """measurement hook: muse_xcorr_groups launches its kernel `repeat` times back to back"""
         B.check(B.load().muse_test_xcorr_repeat(self._h, int(repeat)))
 
+    def huge_batch_mb(self, megabytes):
+        """measurement hook: work buffer of one batch of the long-series pass (0 = built-in 128 MB)"""
+        B.check(B.load().muse_test_huge_batch_mb(self._h, int(megabytes)))
+
     def rows_always_copy(self, on):
         """test hook: muse_batch_run_rows copies even the smallest groups to HBM instead of letting the kernel read the pinned buffer"""
         B.check(B.load().muse_test_rows_always_copy(self._h, 1 if on else 0))

@@ -60,6 +60,10 @@ int muse_test_pool_stats(muse_ctx *ctx, int64_t *dev_idle_bytes, int64_t *dev_id
  * for the clock probe and for HIP-event timing without the host's work between calls (tools/clock_trace_two_sided.py). */
 int muse_test_xcorr_repeat(muse_ctx *ctx, int32_t repeat);
 
+/* Measurement hook: the work buffer of one batch of the long-series pass (FFT lengths above 65 536; xcorr_huge.hip) in MB;
+ * 0 = the built-in 128 MB (half the Infinity Cache).  tools/huge_bench.py, profiles/r06_long_series.txt. */
+int muse_test_huge_batch_mb(muse_ctx *ctx, int32_t megabytes);
+
 #ifdef __cplusplus
 }
 #endif

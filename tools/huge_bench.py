@@ -13,6 +13,8 @@ pkg = importlib.import_module("go-muse_amd")
 GB = float(sys.argv[1]) if len(sys.argv) > 1 else 4.0
 Ns = [int(a) for a in sys.argv[2:]] or [65536, 131072, 262144, 524288, 1048576, 100000, 600000]
 eng = pkg.get_engine(0)
+if os.environ.get("MUSE_HUGE_BATCH_MB"):  # the batch's work buffer (measurement hook; default 128 MB)
+    eng.huge_batch_mb(int(os.environ["MUSE_HUGE_BATCH_MB"]))
 for N in Ns:
     M = max(8, int(GB * (1 << 30) / (8 * N)) // 2 * 2)
     dg, ref = pkg.DeviceGroup.synthetic(eng, M, N)
