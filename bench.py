@@ -841,6 +841,34 @@ def main():
                 line["in_process_shards"] = in_process_shards(pkg, args, eng, ref, N)
             except Exception as e:
                 line["in_process_shards"] = {"error": str(e)}
+        if extras and "long_series" not in args.skip_extra:
+            # series longer than 65 536 samples (the reference has no length limit: xcorr.go:19-24, muse_batch.go:33-37): FFT lengths
+            # 2^17 and 2^20 through the chip-wide four-step kernels of xcorr_huge.hip, 1 GB groups, HIP events around the whole pass
+            out = []
+            for NL in (131072, 1048576):
+                try:
+                    ML = max(8, (1 << 30) // (8 * NL))
+                    gl, refl = pkg.DeviceGroup.synthetic(eng, ML, NL)
+                    bl = pkg.DeviceBatch(eng, gl, refl)
+                    for _ in range(2):
+                        bl.score()
+                    eng.synchronize()
+                    eng.kernel_time()
+                    eng.kernel_timing(True)
+                    for _ in range(4):
+                        bl.score()
+                    eng.synchronize()
+                    eng.kernel_timing(False)
+                    kms, kcnt = eng.kernel_time()
+                    ts = kms / max(kcnt, 1) * 1e-3
+                    out.append({"length": NL, "fft_len": bl.n, "rows": ML, "pass_ms": ts * 1e3, "value": ML / ts, "unit": "series-pairs/s",
+                                "ps_per_sample": ts / (ML * float(NL)) * 1e12, "roofline_frac": ML * (8.0 * NL + 16) / ts / 1e9 / HBM_PEAK_GBPS,
+                                "kernels": "huge_stats, huge_norm, huge_sweep1, huge_rows, huge_sweep2, huge_final per batch of pairs"})
+                    bl.close()
+                    gl.close()
+                except Exception as e:
+                    out.append({"length": NL, "error": str(e)})
+            line["long_series"] = out
         if c5 is not None:
             line["config5_lengths"], line["config5_mixed_run"] = c5
         if extras and "reference_bench_shapes" not in args.skip_extra:

@@ -21,7 +21,7 @@ def find(sub, pat):
 
 def short(name):
     """'void muse::xcorr_fused_small<9, false, false>(muse::FusedParams)' -> 'xcorr_fused_small<9, false, false>'"""
-    name = name.strip()
+    name = name.strip().replace("(anonymous namespace)::", "")
     depth, cut = 0, len(name)
     for i, ch in enumerate(name):          # cut the argument list: the first '(' outside template brackets
         if ch == "<":
@@ -32,7 +32,7 @@ def short(name):
             cut = i
             break
     name = name[:cut]
-    return re.sub(r"^void\s+", "", name).replace("muse::", "").strip()
+    return re.sub(r"^void\s+", "", name).replace("(anonymous namespace)::", "").replace("muse::", "").strip()
 
 
 def csrc_sha():
@@ -46,7 +46,7 @@ def csrc_sha():
 
 
 def ours(k):
-    return k.startswith("xcorr_")
+    return k.startswith("xcorr_") or k.startswith("huge_")
 
 
 print("# rocprofv3 summary for", out)
