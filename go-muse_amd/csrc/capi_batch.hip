@@ -176,7 +176,7 @@ extern "C" int muse_batch_create(muse_ctx *ctx, muse_group *g, const double *ref
     if (e == hipSuccess && n == 8192) // xcorr_fused_real8k: the spectrum at its threads' bins, lane-ordered
         e = dmalloc(ctx, &sp->xcp, (size_t)4096 * sizeof(double2));
     if (e == hipSuccess && n == 32768) // xcorr_real.hip, the 16 x 1024 split: xc at the threads' lower eight bins and their mirror bins
-        e = dmalloc(ctx, &sp->xcw, (size_t)16384 * sizeof(double2));
+        e = dmalloc(ctx, &sp->xcw, (size_t)16385 * sizeof(double2)); // ([16384]: the reference's bin n / 4)
     if (e == hipSuccess && (n == 4096 || long_n) && N < n)
         e = dmalloc(ctx, &sp->c1, (size_t)n * sizeof(double));
     if (e != hipSuccess) {

@@ -53,12 +53,18 @@ extern "C" int muse_batch_score_many(muse_batch *const *bs, int32_t R)
     const bool small_n = (b0->n >= 512 && b0->n <= 2048) || b0->n == 8192 || b0->n == 16384; // xcorr_small.hip's lengths
     // (float32-storage groups: the n = 4096 one-pass kernel reads them; the other lengths' one-pass builds do not)
     // long series (xcorr_long.hip, MULTI): 3 + 3 R slice crossings per pair against 4 R -- from three references on
-    const bool long_n = (b0->n == 32768 || b0->n == 65536) && R >= 3 && !b0->g->f32 && ctx->variant == 0 && b0->logn >= 14 && ctx->twl[b0->logn - 14];
+    // n = 32768 (round 6): ONE real series per workgroup, first-transformed once, every reference from the parked spectrum
+    // (xcorr_fused_real32k_multi: 1 x the row bytes where the four-step kernel below moves 5 x); from three references on (two: as
+    // fast as two passes -- profiles/r06_many_refs.txt)
+    bool real_n = b0->n == 32768 && R >= 3 && !b0->g->f32 && ctx->variant == 0 && ctx->gsmall[4] && ctx->wsplit;
+    for (int r = 0; r < R && real_n; r++)
+        real_n = bs[r]->N == b0->N && bs[r]->xcw != nullptr;
+    const bool long_n = !real_n && (b0->n == 32768 || b0->n == 65536) && R >= 3 && !b0->g->f32 && ctx->variant == 0 && b0->logn >= 14 && ctx->twl[b0->logn - 14];
     bool one_pass = R > 1 &&
                     ((b0->n == 4096 && (ctx->variant == 0 || ctx->variant == 10)) ||
-                     (small_n && !b0->g->f32 && (ctx->variant == 0 || ctx->variant == 12)) || long_n);
+                     (small_n && !b0->g->f32 && (ctx->variant == 0 || ctx->variant == 12)) || long_n || real_n);
     for (int r = 0; r < R && one_pass; r++)
-        one_pass = bs[r]->N == b0->N && (small_n || b0->N == b0->n || bs[r]->c1 != nullptr) && (!long_n || bs[r]->xcp != nullptr);
+        one_pass = bs[r]->N == b0->N && (small_n || real_n || b0->N == b0->n || bs[r]->c1 != nullptr) && (!long_n || bs[r]->xcp != nullptr);
     if (!one_pass) {
         for (int r = 0; r < R; r++) {
             int rc = muse_batch_score(bs[r]);
@@ -83,6 +89,8 @@ extern "C" int muse_batch_score_many(muse_batch *const *bs, int32_t R)
     }
     if (long_n) // two n-element slices per resident workgroup
         HIP_TRY(ensure_gscratch(ctx, b0->n, 2 * LONG_WGS_PER_CU));
+    if (real_n) // (half an n-element slice per workgroup: the batches' own creation sized the buffer for far more)
+        HIP_TRY(ensure_gscratch(ctx, b0->n));
     if (b0->n == 16384 && !ctx->zscratch) { // (every other length keeps the spectra in registers: no scratch)
         const int slots = ctx->num_cus * 4; // one 64 KB slice per resident workgroup
         HIP_TRY(hipMalloc(&ctx->zscratch, (size_t)slots * 4096 * sizeof(double2)));
@@ -99,7 +107,7 @@ extern "C" int muse_batch_score_many(muse_batch *const *bs, int32_t R)
     std::vector<void *> &tab = ctx->many_host;
     tab.assign((size_t)R * 4, nullptr);
     for (int r = 0; r < R; r++) {
-        tab[(size_t)r] = small_n ? bs[r]->xc : bs[r]->xcp;
+        tab[(size_t)r] = small_n ? bs[r]->xc : real_n ? bs[r]->xcw : bs[r]->xcp;
         tab[(size_t)R + r] = bs[r]->mv;
         tab[(size_t)2 * R + r] = bs[r]->lag;
         tab[(size_t)3 * R + r] = bs[r]->c1;
@@ -125,7 +133,7 @@ extern "C" int muse_batch_score_many(muse_batch *const *bs, int32_t R)
     p.ovf_list = b0->ovf_list;
     // (the long-series kernel works in the context's scratch buffer: its pointer must not be swapped between reading it and the launch)
     std::unique_lock<std::mutex> scratch_lock(ctx->stage_mu, std::defer_lock);
-    if (long_n) {
+    if (long_n || real_n) {
         scratch_lock.lock();
         p.gscratch = ctx->gscratch;
         p.gscratch_slices = (long long)(ctx->gscratch_elems / (size_t)b0->n);
@@ -137,6 +145,11 @@ extern "C" int muse_batch_score_many(muse_batch *const *bs, int32_t R)
         HIP_TRY(launch_fused_small(p, ctx->num_cus, ctx->stream));
         for (int r = 0; r < R; r++)
             bs[r]->scores_exact = true;
+    } else if (real_n) { // (one series per transform: nothing to isolate, no redo list)
+        p.gsmall = ctx->gsmall[4];
+        HIP_TRY(launch_fused_real_split(p, ctx->num_cus, ctx->stream));
+        for (int r = 0; r < R; r++)
+            bs[r]->scores_exact = true;
     } else if (long_n)
         HIP_TRY(launch_fused_long(p, ctx->num_cus, ctx->stream));
     else
@@ -145,9 +158,9 @@ extern "C" int muse_batch_score_many(muse_batch *const *bs, int32_t R)
     // pairs holding a NaN/Inf series (listed once, by reference 0): redone per reference by the
     // kernel that isolates the dead series before the shared transform
     LaunchTimer redo_timer(ctx, true); // (one bracket around the R redo launches)
-    if (!small_n)
+    if (!small_n && !real_n)
         HIP_TRY(redo_timer.begin());
-    for (int r = 0; r < R && !small_n; r++) {
+    for (int r = 0; r < R && !small_n && !real_n; r++) {
         FusedParams q = base_params(bs[r]);
         q.pair_list = b0->ovf_list;
         q.pair_count = b0->ovf_count;

@@ -254,9 +254,13 @@ struct RawPairXC {
 // arithmetic -- where the pair-packed 16384-point kernel, xcorr_fused_small<14>, has one workgroup of 16 waves per CU in lockstep).
 // PADDED: N < n (leading zero pad, n / 2 < N)
 // SPLIT (LM = 14): the transforms as 16 x 1024 (small::forward_split_dif / _dit: two of a transform's three transposes inside a wave)
-template <int LM, bool PADDED, bool SPLIT = false>
+// MULTI (SPLIT only; SURVEY 8f-2, README.md:10-13 of the reference): R references against the group in ONE pass -- the row is read,
+// normalised and first-transformed once, Z is parked in the workgroup's 256 KB scratch slice (every thread re-reads what it wrote),
+// and every reference takes mirror stage, second transform and argmax from there: per reference ~half a pass, 1 x the row bytes.
+template <int LM, bool PADDED, bool SPLIT = false, bool MULTI = false>
 __device__ __forceinline__ void real_one_series(const FusedParams &p)
 {
+    static_assert(!MULTI || SPLIT, "many references run on the split form");
     using namespace occ4;
     using namespace fold;
     using namespace small;
@@ -367,10 +371,39 @@ __device__ __forceinline__ void real_one_series(const FusedParams &p)
             if (!(MUSE_REAL_ABL & 8))
             forward_split_dif(v, b, g2l, p.gsmall_b, j, wave,
                               [&](const int k1) __attribute__((always_inline)) { return ldg2u(scalar_ptr_at(ws, (k1 - 1) * 1024), (unsigned)jm); });
+        } else {
+            // ---- Z = FFT_M(z): Z[j + r S] at v[BR16(r)]
+            if (!(MUSE_REAL_ABL & 8))
+            forward<LM>(v, b, g2l, gs, j);
+        }
+        typedef d2v __attribute__((address_space(1))) *gd2p;
+        double2 *const zpark = MULTI ? p.gscratch + (size_t)blockIdx.x * (size_t)M : nullptr; // the workgroup's slice: Z [i][t]
+        if constexpr (MULTI) {
+#pragma unroll
+            for (int i = 0; i < 16; i++)
+                *((gd2p)scalar_ptr_at(zpark, i * S) + (unsigned)(t & (S - 1))) = d2v{v[i].x, v[i].y};
+        }
+        const int R = MULTI ? p.R : 1;
+#pragma clang loop unroll(disable)
+        for (int ref = 0; ref < R; ref++) {
+        if constexpr (MULTI) {
+            if (ref > 0) {
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const d2v z = *((gd2p)scalar_ptr_at(zpark, i * S) + (unsigned)(t & (S - 1)));
+                    v[i] = make_double2(z.x, z.y);
+                }
+            }
+        }
+        double *const mv_out = MULTI ? uniform_ptr(p.mv_many[ref]) : p.mv;
+        int *const lag_out = MULTI ? uniform_ptr(p.lag_many[ref]) : p.lag;
+        if constexpr (SPLIT) {
             // ---- mirror pairs in that order; the reference's spectrum at the thread's bins and their mirrors from FusedParams::xcw
+            // ([16384]: the reference's bin M / 2, which pairs with itself)
+            int jm = j;
             asm volatile("" : "+v"(jm));
             jm &= S - 1;
-            const double2 *__restrict__ xw = p.xcw;
+            const double2 *__restrict__ xw = MULTI ? uniform_ptr(p.xcp_many[ref]) : p.xcw;
             const double2 Wj = ldg2u(scalar_ptr(twm), (unsigned)(2 * ((jm >> 6) + 16 * (jm & 63)))); // W_n^(w + 16 c)
             if (!(MUSE_REAL_ABL & 2))
             mirror_stage_split<MUSE_REAL_AHEAD, RawPairXC>(
@@ -380,7 +413,7 @@ __device__ __forceinline__ void real_one_series(const FusedParams &p)
                 },
                 [&](const RawPairXC &x, const double2) __attribute__((always_inline)) { return TwoBins{x.a, x.b}; },
                 [&](const double2 v8) __attribute__((always_inline)) { // bin M / 2 pairs with itself, W = -i
-                    const double2 xh = ldg2u(scalar_ptr_at(xc, M / 2), 0u);
+                    const double2 xh = ldg2u(scalar_ptr_at(xw, 16384), 0u);
                     return mirror_pair(v8, v8, make_double2(0.0, -1.0), xh, xh).k;
                 });
             natural_order(v);
@@ -388,9 +421,6 @@ __device__ __forceinline__ void real_one_series(const FusedParams &p)
             if (!(MUSE_REAL_ABL & 4))
             forward_split_dit(v, b, g2l, p.gsmall_b, gs + 8 * 16 * R1, j, wave);
         } else {
-        // ---- Z = FFT_M(z): Z[j + r S] at v[BR16(r)]
-        if (!(MUSE_REAL_ABL & 8))
-        forward<LM>(v, b, g2l, gs, j);
         // ---- mirror pairs: Y, the product with the reference's spectrum, re-tangled for the second transform (mirror_stage above)
         {
             int jm = j;
@@ -433,7 +463,7 @@ __device__ __forceinline__ void real_one_series(const FusedParams &p)
         const int ia = 2 * (j + (code >> 1) * S) + (code & 1);
         const double cc0 = v[0].x; // (column 0: cc[0], reported when nothing is above 0)
         fence();
-        if (!(MUSE_REAL_ABL & 1))
+        if (!MULTI && !(MUSE_REAL_ABL & 1))
             request(row + gridDim.x); // the next row: in flight during the reductions and the result write-out
         fence();
         double pa = ma, pb = 0.0;
@@ -450,9 +480,14 @@ __device__ __forceinline__ void real_one_series(const FusedParams &p)
             int lag = idx > n / 2 ? idx - n : idx;
             if (zero) { mv = 0.0; lag = 0; }               // xcorr.go:166-167
             if (nan) { mv = __builtin_nan(""); lag = 0; }
-            p.mv[row] = mv;
-            p.lag[row] = lag;
+            mv_out[row] = mv;
+            lag_out[row] = lag;
         }
+        } // (references)
+        // (many references: the next row is requested behind the loop -- requested inside it, the 64 registers of the requests
+        // are live across every reference's transforms and 140 registers go to scratch)
+        if (MULTI && !(MUSE_REAL_ABL & 1))
+            request(row + gridDim.x);
     }
 }
 template <bool PADDED>
@@ -469,6 +504,11 @@ template <bool PADDED>
 __global__ __launch_bounds__(1024, 4) void xcorr_fused_real32k_split(const FusedParams p)
 {
     real_one_series<14, PADDED, true>(p);
+}
+template <bool PADDED>
+__global__ __launch_bounds__(1024, 4) void xcorr_fused_real32k_multi(const FusedParams p)
+{
+    real_one_series<14, PADDED, true, true>(p);
 }
 
 // The batched two-sided xCorr (xcorr.go:102-153) at n = 32768 in the same form: pair i = (x_i, y_i), each zero-padded
@@ -1385,6 +1425,8 @@ __global__ void real_split_tables_kernel(const double2 *__restrict__ xc, double2
     const int k = (j >> 6) + 16 * (j & 63) + 1024 * r;
     out[r * 1024 + j] = xc[k];
     out[8192 + r * 1024 + j] = xc[16384 - k];
+    if (r == 0 && j == 0)
+        out[16384] = xc[8192]; // the reference's bin M / 2 (it pairs with itself)
 }
 hipError_t launch_real_split_tables(const double2 *xc, double2 *out, hipStream_t stream)
 {
@@ -1446,8 +1488,21 @@ hipError_t launch_fused_real(const FusedParams &p_in, int num_cus, hipStream_t s
 hipError_t launch_fused_real_split(const FusedParams &p_in, int num_cus, hipStream_t stream)
 {
     const FusedParams p = with_reciprocals(p_in);
-    if (!p.rows || !p.twm || !p.xc || !p.gsmall || !p.gsmall_b || !p.wsplit || !p.xcw || !p.mv || !p.lag || p.n != 32768 || p.N > p.n || 2 * p.N <= p.n ||
-        p.pair_list || p.R > 1)
+    if (!p.rows || !p.twm || !p.gsmall || !p.gsmall_b || !p.wsplit || p.n != 32768 || p.N > p.n || 2 * p.N <= p.n || p.pair_list)
+        return hipErrorInvalidValue;
+    if (p.R > 1) { // many references in one pass: p.xcp_many = the references' xcw tables; one 16384-point slice per workgroup
+        if (!p.xcp_many || !p.mv_many || !p.lag_many || !p.gscratch)
+            return hipErrorInvalidValue;
+        const long long mgrid = std::min<long long>(std::min<long long>(p.M, (long long)num_cus * 4), p.gscratch_slices * 2);
+        if (mgrid < 1)
+            return hipErrorInvalidValue;
+        if (p.N < p.n)
+            hipLaunchKernelGGL(xcorr_fused_real32k_multi<true>, dim3((unsigned)mgrid), dim3(1024), 0, stream, p);
+        else
+            hipLaunchKernelGGL(xcorr_fused_real32k_multi<false>, dim3((unsigned)mgrid), dim3(1024), 0, stream, p);
+        return hipGetLastError();
+    }
+    if (!p.xcw || !p.mv || !p.lag)
         return hipErrorInvalidValue;
     const long long grid = std::min<long long>(p.M, (long long)num_cus * 8);
     if (p.N < p.n)

@@ -9,6 +9,12 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 pkg = importlib.import_module("go-muse_amd")
+if os.environ.get("MUSE_AB_LIB"):  # another build of the library (an A/B on one box: boxes differ by several per cent)
+    import ctypes
+    pkg.build.LIB = os.path.abspath(os.environ["MUSE_AB_LIB"])
+    pkg.build.stale = lambda: False
+    _L = ctypes.CDLL(pkg.build.LIB)
+    pkg.binding.SIGNATURES = {k: v for k, v in pkg.binding.SIGNATURES.items() if hasattr(_L, k)}
 budget = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 30
 R = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 Ns = [int(a) for a in sys.argv[3:]] or [512, 1024, 2048, 4096, 8192, 16384]
