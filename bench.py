@@ -808,10 +808,10 @@ def main():
                     pkg.xcorr_groups(gx, gy, N, True)
                 eng.synchronize()
                 dtx = (time.perf_counter() - t1) / 3
-                # the kernel time is taken over a SUSTAINED burst (the measurement hook makes one call launch the kernel 40 times back
+                # the kernel time is taken over a SUSTAINED burst (the measurement hook makes one call launch the kernel 150 times back
                 # to back, same results): one call costs the host tens of milliseconds around its 4.5 ms kernel, so calls in a loop
                 # leave the GPU idle and every launch runs at the 2.4 GHz boost clock (profiles/r06_two_sided_clock.txt)
-                eng.xcorr_repeat(40)
+                eng.xcorr_repeat(150)   # (0.7 s: the clock settles within the first ~60 ms of a burst)
                 pkg.xcorr_groups(gx, gy, N, True)
                 eng.synchronize()
                 eng.kernel_time()
