@@ -825,7 +825,9 @@ def main():
                 bx = float(P) * (16 * N + 16)
                 xk = "xcorr_two_sided_fold<false>"
                 line["two_sided_xcorr"] = {"value": P / kx_s if kx_s > 0 else None, "unit": "xCorr pairs/s (kernel)", "pairs": P, "rows": P, "length": N,
-                                           "normalize": True, "dtype": "f64", "kernel": xk, "kernel_ms_avg": kx_s * 1e3, "launches_timed": kx_cnt, "sustained": True,
+                                           "normalize": True, "dtype": "f64", "kernel": xk, "kernel_ms_avg": kx_s * 1e3, "launches_timed": kx_cnt,
+                                           "burst": "150 launches back to back (0.6 s) behind one such burst; after several seconds of bursts the part settles at "
+                                                    "1.94 GHz and 4.89 ms per launch = 0.335 (profiles/r06_two_sided_clock.txt)",
                                            "ms_per_call_with_copy_back": dtx * 1e3, "algorithmic_bytes_per_launch": bx,
                                            "roofline_frac": bx / kx_s / 1e9 / HBM_PEAK_GBPS if kx_s > 0 else None,
                                            "note": "muse_xcorr_groups: z = (x read backwards) + i y, one forward transform, cc = Im FFT(Z^2) / 2n on the "
