@@ -350,6 +350,7 @@ extern "C" int muse_group_fill_synthetic(muse_group *g, int64_t first, int64_t c
     else
         HIP_TRY(launch_synth(g->rows, g->stride, first, count, global_first, g->N, seed, flags, g->ctx->stream));
     g->M = std::max(g->M, first + count);
+    g->hstats_rows = std::min(g->hstats_rows, first); // (rows rewritten: their kept statistics go)
     if (ref_out) {
         double *d = nullptr;
         HIP_TRY(hipMalloc(&d, (size_t)g->N * sizeof(double)));
@@ -418,6 +419,7 @@ void group_release(muse_group *g)
         dfree(g->ctx, (char *)g->base() - GROUP_GUARD * g->elem());
     for (void *old : g->retired)
         dfree(g->ctx, old);
+    dfree(g->ctx, g->hstats);
     for (int i = 0; i < 2; i++) {
         if (g->stage[i]) { // back to the context's pool (the stream is idle: no upload reads it any more)
             std::lock_guard<std::mutex> lock(g->ctx->stage_mu);

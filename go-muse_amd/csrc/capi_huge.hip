@@ -159,32 +159,56 @@ int huge_reference(muse_ctx *ctx, const double *ref_host, int N, int n, double2 
     return MUSE_OK;
 }
 
-// the all-scores pass of a batch whose FFT length is above 65 536: (lag, signed max value) of every series of the group
+// the all-scores pass of a batch whose FFT length is above 65 536: (lag, signed max value) of every series of the group.
+// The series' statistics are the GROUP's (muse_group::hstats): the rows are immutable, so the first pass over them computes first
+// sample, mean, 1 / sigma and flag per row and every later Run -- and every other reference -- skips that read of the rows.
 int huge_score(muse_batch *b)
 {
     muse_ctx *ctx = b->ctx;
-    const int64_t M = b->g->M, n = b->n;
+    muse_group *g = b->g;
+    const int64_t M = g->M, n = b->n;
     const int64_t ppb = pairs_per_batch(ctx, n);
     std::lock_guard<std::mutex> lock(ctx->huge_mu);
     int rc = huge_ensure(ctx, b->logn, ppb, false);
     if (rc)
         return rc;
+    if (g->hstats_cap < M) { // (grown with the group; what was computed is recomputed: rare)
+        dfree(ctx, g->hstats);
+        g->hstats = nullptr;
+        g->hstats_cap = g->hstats_rows = 0;
+        const int64_t cap = std::max<int64_t>(M, g->cap);
+        HIP_TRY(dmalloc(ctx, &g->hstats, (size_t)cap * 4 * sizeof(double)));
+        g->hstats_cap = cap;
+    }
     LaunchTimer timer(ctx, false, b->stream()); // (one bracket around the pass: its kernels are one unit of work per batch of pairs)
     HIP_TRY(timer.begin());
+    for (int64_t first = g->hstats_rows; first < M; first += 2 * ppb) { // rows without statistics yet
+        HugeParams p = huge_base(ctx, b->logn);
+        p.rows = g->rows;
+        p.stride = g->stride;
+        p.first = first;
+        p.count = (int)std::min<int64_t>(2 * ppb, M - first);
+        p.N = b->N;
+        p.normalize = 1;
+        p.snorm = g->hstats + first * 4;
+        HIP_TRY(launch_huge(p, HUGE_STAGE_STATS_ONLY, b->stream()));
+    }
+    g->hstats_rows = M;
     for (int64_t first = 0; first < M; first += 2 * ppb) {
         HugeParams p = huge_base(ctx, b->logn);
-        p.rows = b->g->rows;
-        p.stride = b->g->stride;
+        p.rows = g->rows;
+        p.stride = g->stride;
         p.first = first;
         p.count = (int)std::min<int64_t>(2 * ppb, M - first);
         p.N = b->N;
         p.solo = 0;
         p.normalize = 1;
+        p.snorm = g->hstats + first * 4;
         p.table = b->xcp;
         p.table_stride = 0;
         p.mv = b->mv;
         p.lag = b->lag;
-        HIP_TRY(launch_huge(p, HUGE_STAGE_STATS | HUGE_STAGE_SWEEP1 | HUGE_STAGE_ROWS | HUGE_STAGE_SWEEP2 | HUGE_STAGE_FINAL, b->stream()));
+        HIP_TRY(launch_huge(p, HUGE_STAGE_SWEEP1 | HUGE_STAGE_ROWS | HUGE_STAGE_SWEEP2 | HUGE_STAGE_FINAL, b->stream()));
     }
     HIP_TRY(timer.end());
     return MUSE_OK;

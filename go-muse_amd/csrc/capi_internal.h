@@ -131,6 +131,11 @@ struct muse_group {
     size_t elem() const { return f32 ? sizeof(float) : sizeof(double); }
     void *base() const { return f32 ? (void *)rows32 : (void *)rows; }
     int64_t cap = 0, M = 0, stride = 0; // M counts staged rows too
+    // FFT lengths above 65 536 (capi_huge.hip): the rows never change, so neither do a series' zNormalize statistics -- first sample,
+    // mean of the shifted samples, 1 / sigma, flag per row, computed by the first pass that needs them and kept for every later Run
+    // and every other reference (rows appended later are added; a re-allocation starts over)
+    double *hstats = nullptr;
+    int64_t hstats_cap = 0, hstats_rows = 0;
     // allocations the group has outgrown: kept until the group goes (kernels enqueued before the growth may still read them),
     // so that growing never waits for the device (group_reserve)
     std::vector<void *> retired;

@@ -55,6 +55,7 @@ static void slot_destroy(RowsSlot *s)
         (void)hipHostFree(s->out);
     if (s->done)
         (void)hipEventDestroy(s->done);
+    dfree(ctx, s->g.hstats);
     dfree(ctx, s->b.mv);
     dfree(ctx, s->b.lag);
     dfree(ctx, s->b.ovf_count);
@@ -227,6 +228,7 @@ static int run_rows(muse_batch *tmpl, const double *rows, const double *const *r
     s->g.stride = N;
     s->g.M = M;
     s->g.cap = M;
+    s->g.hstats_rows = 0; // (other rows than the slot's last call: no kept statistics)
     s->b.N = tmpl->N;
     s->b.n = tmpl->n;
     s->b.logn = tmpl->logn;

@@ -16,6 +16,7 @@ enum : unsigned {
     HUGE_STAGE_ROWS_FORWARD = 8u, // Y -> forward -> table_out (and X_out)
     HUGE_STAGE_SWEEP2 = 16u,      // Y -> cc -> amax (and cc_out)
     HUGE_STAGE_FINAL = 32u,       // amax -> mv, lag, nil
+    HUGE_STAGE_STATS_ONLY = 64u,  // huge_stats + huge_norm alone (snorm and sfin of the batch), nothing else
 };
 
 struct HugeParams {
@@ -37,6 +38,7 @@ struct HugeParams {
     double2 *Y;               // work buffer: n complex per pair of the batch
     double *part;             // [series of the batch][R1][2] chunk sums
     double *snorm;            // [series of the batch][4]: first sample, mean of the shifted samples, pre_scale / sigma, flag
+                              // (the all-scores pass of a group points it into the group's kept statistics: capi_huge.hip)
     double *sfin;             // [series of the batch] flag: 0 ok, 1 sigma == 0, 2 NaN / Inf statistics
     const double *sfin_x;     // two-sided: the flags of the batch's x series (same slots), or nullptr
     double *amax;             // [pair][R1][8] tile maxima

@@ -191,8 +191,11 @@ __device__ __forceinline__ void column_dft(double2 (&v)[16], double *tile, const
     __syncthreads();
 }
 
+#ifndef MUSE_HUGE_S1_OCC
+#define MUSE_HUGE_S1_OCC 3
+#endif
 template <int R>
-__global__ __launch_bounds__(256, 3) void huge_sweep1(const HugeParams p)
+__global__ __launch_bounds__(256, MUSE_HUGE_S1_OCC) void huge_sweep1(const HugeParams p)
 {
     constexpr int TW = 256 / R, Q = 16 / R, R1 = 16 * R;
     __shared__ double tile[4096];
@@ -307,8 +310,11 @@ __global__ __launch_bounds__(256, 3) void huge_rows(const HugeParams p) // (at f
 }
 
 // ------------------------------------------------------------------------------------------------ sweep 2
+#ifndef MUSE_HUGE_S2_OCC
+#define MUSE_HUGE_S2_OCC 3
+#endif
 template <int R>
-__global__ __launch_bounds__(256, 3) void huge_sweep2(const HugeParams p)
+__global__ __launch_bounds__(256, MUSE_HUGE_S2_OCC) void huge_sweep2(const HugeParams p)
 {
     constexpr int TW = 256 / R, Q = 16 / R;
     __shared__ double tile[4096];
@@ -426,7 +432,7 @@ __global__ __launch_bounds__(256) void huge_final(const HugeParams p)
             const int idx = none ? 0 : (int)I;
             double mv = none ? p.amax[(size_t)pair * (size_t)p.R1 * 8 + 6 + s] : sv; // nothing above 0: index 0, mv = cc[0]
             int lag = idx > p.n / 2 ? idx - p.n : idx;                                 // xcorr.go:192-194
-            int flag = p.normalize ? (int)p.sfin[sA + s] : FLAG_OK;
+            int flag = p.normalize ? (int)p.snorm[(sA + s) * 4 + 3] : FLAG_OK;
             const int fx = p.sfin_x ? (int)p.sfin_x[sA + s] : FLAG_OK;                 // two-sided: the pair's x
             if (fx == FLAG_ZERO || (fx == FLAG_OK && flag == FLAG_ZERO)) {             // xcorr.go:107-127, 164-172: (nil, 0, 0)
                 mv = 0.0;
@@ -462,6 +468,13 @@ hipError_t launch_sweeps(const HugeParams &p, const int which, const dim3 grid2,
 // one batch: p.count series (solo: one per transform; else two), stages selected by `stages` (HUGE_STAGE_* bits)
 hipError_t launch_huge(const HugeParams &p, const unsigned stages, hipStream_t stream)
 {
+    if (stages == HUGE_STAGE_STATS_ONLY) {
+        if (!p.rows || !p.part || !p.snorm || !p.sfin || p.count < 1 || p.N < 2 || p.R1 != p.n / 4096)
+            return hipErrorInvalidValue;
+        hipLaunchKernelGGL(huge_stats, dim3((unsigned)p.R1, (unsigned)p.count), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL(huge_norm, dim3((unsigned)p.count), dim3(256), 0, stream, p);
+        return hipGetLastError();
+    }
     if (p.logn < 17 || p.logn > HUGE_MAX_LOGN || p.n != (1 << p.logn) || p.R1 != p.n / 4096 || p.count < 1 || p.N < 2 || p.N > p.n ||
         !p.rows || !p.Y || !p.thi || !p.tlo || !p.part || !p.sfin)
         return hipErrorInvalidValue;

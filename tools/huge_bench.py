@@ -10,6 +10,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 pkg = importlib.import_module("go-muse_amd")
+if os.environ.get("MUSE_AB_LIB"):  # another build of the library (an A/B on one box)
+    import ctypes
+    pkg.build.LIB = os.path.abspath(os.environ["MUSE_AB_LIB"])
+    pkg.build.stale = lambda: False
 GB = float(sys.argv[1]) if len(sys.argv) > 1 else 4.0
 Ns = [int(a) for a in sys.argv[2:]] or [65536, 131072, 262144, 524288, 1048576, 100000, 600000]
 eng = pkg.get_engine(0)
