@@ -362,7 +362,13 @@ public:
     // group.go:31-56; errors come back as muse::Error(MUSE_ERR_INVALID / MUSE_ERR_LENGTH)
     void Add(const std::vector<SeriesPtr> &series)
     {
-        for (auto &s : series) {
+        for (auto &s : series)
+            Add(s);
+    }
+    // (one Series: Go's variadic Add(series ...*Series) called with one argument -- `g->Add({s})` binds here without building a vector)
+    void Add(const SeriesPtr &s)
+    {
+        {
             if (s->Labels()->Keys().empty())
                 throw Error(MUSE_ERR_INVALID, "Invalid Series with no labels");
             const std::string &uid = s->UID();

@@ -516,6 +516,48 @@ static void TestStreamedGroupEqualsUploadedAtRun()
     sameScores(out2[0], out2[1], "streamed group vs uploaded at Run, after more Adds");
 }
 
+// Series longer than 65 536 samples through the mirror (the reference has no length limit: xcorr.go:19-24, muse_batch.go:33-37):
+// planted shifted copies of the reference come back with score ~1 and the planted lag, a constant series with score 0, through
+// Batch.Run with label groups and through Muse.Run.
+static void TestLongSeries()
+{
+    std::mt19937_64 rng(5);
+    std::normal_distribution<double> nd(0.0, 1.0);
+    const int N = 100000;
+    std::vector<double> refv((size_t)N);
+    for (auto &x : refv)
+        x = nd(rng);
+    auto ref = NewSeries(refv, NewLabels({{"graph", "ref"}}));
+    auto shifted = [&](int by, double gain, double noise) {
+        std::vector<double> y((size_t)N);
+        for (int t = 0; t < N; t++)
+            y[(size_t)t] = gain * refv[(size_t)(((t - by) % N + N) % N)] + noise * nd(rng);
+        return y;
+    };
+    auto g = NewGroup("targets");
+    g->Add({NewSeries(shifted(0, 3.0, 0.0), NewLabels({{"graph", "copy"}, {"host", "a"}})),
+            NewSeries(shifted(7, -2.0, 0.1), NewLabels({{"graph", "late"}, {"host", "a"}})),
+            NewSeries(shifted(-5, 1.0, 0.1), NewLabels({{"graph", "early"}, {"host", "a"}})),
+            NewSeries(std::vector<double>((size_t)N, 4.0), NewLabels({{"graph", "flat"}, {"host", "a"}})),
+            NewSeries(shifted(3, 1.0, 3.0), NewLabels({{"graph", "late"}, {"host", "b"}}))});
+    auto b = NewBatch(ref, g, NewResults(10, 20, 0, SignFilter_ANY), 4);
+    EXPECT(b->n == 131072, "long series: n = %d", b->n);
+    b->Run({"graph"});
+    auto got = b->Results_->Fetch().first;
+    EXPECT(got.size() == 4, "long series: %zu label groups", got.size());
+    if (got.size() == 4) {
+        EXPECT(std::fabs(got[0].PercentScore - 1.0) < 1e-9 && got[0].Lag == 0, "long series: copy %.6f lag %d", got[0].PercentScore, got[0].Lag);
+        // (a series that lags the reference by k samples has lag -k: xcorr.go:103)
+        EXPECT(got[1].PercentScore > 0.98 && std::abs(got[1].Lag) <= 7 && got[1].Lag != 0, "long series: second %.4f lag %d", got[1].PercentScore, got[1].Lag);
+        EXPECT(got[3].PercentScore == 0.0 && got[3].Lag == 0, "long series: flat %.4f", got[3].PercentScore);
+    }
+    auto m = New(ref, NewResults(10, 5, 0, SignFilter_ANY));
+    m->Run({g->series()[1], g->series()[4]});
+    auto one = m->Results_->Fetch().first;
+    EXPECT(one.size() == 1 && one[0].PercentScore < -0.98 && one[0].Lag == -7, "long series Muse.Run: %zu scores, %.4f lag %d", one.size(),
+           one.empty() ? 0.0 : one[0].PercentScore, one.empty() ? 0 : one[0].Lag);
+}
+
 int main()
 {
     try {
@@ -542,6 +584,7 @@ int main()
         Batch::EXACT_FEED_MAX_GROUPS = 65536;
         TestXCorrBatchEqualsSinglePairs();
         TestStreamedGroupEqualsUploadedAtRun();
+        TestLongSeries();
     } catch (const Error &e) {
         printf("muse::Error %d: %s\n", e.status, e.what());
         return 2;
