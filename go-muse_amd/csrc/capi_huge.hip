@@ -99,7 +99,7 @@ HugeParams huge_base(muse_ctx *ctx, int logn)
 int64_t pairs_per_batch(const muse_ctx *ctx, int64_t n)
 {
     // (measurement hook muse_test_huge_batch_mb, tools/huge_bench.py: the work buffer of one batch; 0 = the built-in 128 MB)
-    const size_t bytes = ctx->huge_batch_mb > 0 ? (size_t)ctx->huge_batch_mb << 20 : HUGE_BATCH_BYTES;
+    const size_t bytes = ctx->huge_batch_mb != 0 ? (size_t)std::abs(ctx->huge_batch_mb) << 20 : HUGE_BATCH_BYTES;
     return std::max<int64_t>(1, (int64_t)(bytes / ((size_t)n * sizeof(double2))));
 }
 
@@ -119,6 +119,16 @@ void huge_free(muse_ctx *ctx)
     (void)hipFree(w.sfin);
     (void)hipFree(w.sfin_x);
     (void)hipFree(w.amax);
+    (void)hipFree(w.Y2);
+    (void)hipFree(w.amax2);
+    if (w.stream2) {
+        (void)hipStreamSynchronize(w.stream2);
+        (void)hipStreamDestroy(w.stream2);
+    }
+    if (w.fork)
+        (void)hipEventDestroy(w.fork);
+    if (w.join)
+        (void)hipEventDestroy(w.join);
     w = HugeWork{};
 }
 
@@ -180,6 +190,36 @@ int huge_score(muse_batch *b)
         HIP_TRY(dmalloc(ctx, &g->hstats, (size_t)cap * 4 * sizeof(double)));
         g->hstats_cap = cap;
     }
+    // two streams: the batches alternate between the batch's stream and a second one, each with its own work buffer (half the
+    // batch size each: the same footprint in the Infinity Cache), so the ragged end of one batch's kernels runs under the next
+    // batch's; the second stream forks behind the pass's start and joins before its end (the timer's bracket covers both)
+    const bool dual = ctx->huge_batch_mb >= 0 && M > 2 * ppb;
+    const int64_t spb = dual ? std::max<int64_t>(2, ppb) : 2 * ppb; // series per batch (dual: ppb / 2 pairs per stream)
+    HugeWork &w = ctx->huge;
+    if (dual) {
+        const int64_t R1 = n / 4096, pairs2 = (spb + 1) / 2;
+        const auto grow2 = [&](void **ptr, size_t &have, size_t need) -> hipError_t {
+            if (need <= have)
+                return hipSuccess;
+            if (w.stream2)
+                (void)hipStreamSynchronize(w.stream2);
+            (void)hipFree(*ptr);
+            *ptr = nullptr;
+            have = 0;
+            const hipError_t e = hipMalloc(ptr, need);
+            if (e == hipSuccess)
+                have = need;
+            return e;
+        };
+        HIP_TRY(grow2((void **)&w.Y2, w.Y2_bytes, (size_t)pairs2 * (size_t)n * sizeof(double2)));
+        HIP_TRY(grow2((void **)&w.amax2, w.amax2_bytes, (size_t)pairs2 * (size_t)R1 * 8 * sizeof(double)));
+        if (!w.stream2)
+            HIP_TRY(hipStreamCreateWithFlags(&w.stream2, hipStreamNonBlocking));
+        if (!w.fork)
+            HIP_TRY(hipEventCreateWithFlags(&w.fork, hipEventDisableTiming));
+        if (!w.join)
+            HIP_TRY(hipEventCreateWithFlags(&w.join, hipEventDisableTiming));
+    }
     LaunchTimer timer(ctx, false, b->stream()); // (one bracket around the pass: its kernels are one unit of work per batch of pairs)
     HIP_TRY(timer.begin());
     for (int64_t first = g->hstats_rows; first < M; first += 2 * ppb) { // rows without statistics yet
@@ -194,12 +234,17 @@ int huge_score(muse_batch *b)
         HIP_TRY(launch_huge(p, HUGE_STAGE_STATS_ONLY, b->stream()));
     }
     g->hstats_rows = M;
-    for (int64_t first = 0; first < M; first += 2 * ppb) {
+    if (dual) {
+        HIP_TRY(hipEventRecord(w.fork, b->stream()));
+        HIP_TRY(hipStreamWaitEvent(w.stream2, w.fork, 0));
+    }
+    int which = 0;
+    for (int64_t first = 0; first < M; first += spb, which ^= 1) {
         HugeParams p = huge_base(ctx, b->logn);
         p.rows = g->rows;
         p.stride = g->stride;
         p.first = first;
-        p.count = (int)std::min<int64_t>(2 * ppb, M - first);
+        p.count = (int)std::min<int64_t>(spb, M - first);
         p.N = b->N;
         p.solo = 0;
         p.normalize = 1;
@@ -208,7 +253,16 @@ int huge_score(muse_batch *b)
         p.table_stride = 0;
         p.mv = b->mv;
         p.lag = b->lag;
-        HIP_TRY(launch_huge(p, HUGE_STAGE_SWEEP1 | HUGE_STAGE_ROWS | HUGE_STAGE_SWEEP2 | HUGE_STAGE_FINAL, b->stream()));
+        const bool second = dual && which;
+        if (second) {
+            p.Y = w.Y2;
+            p.amax = w.amax2;
+        }
+        HIP_TRY(launch_huge(p, HUGE_STAGE_SWEEP1 | HUGE_STAGE_ROWS | HUGE_STAGE_SWEEP2 | HUGE_STAGE_FINAL, second ? w.stream2 : b->stream()));
+    }
+    if (dual) {
+        HIP_TRY(hipEventRecord(w.join, w.stream2));
+        HIP_TRY(hipStreamWaitEvent(b->stream(), w.join, 0));
     }
     HIP_TRY(timer.end());
     return MUSE_OK;
@@ -263,8 +317,8 @@ int huge_pairs(muse_ctx *ctx, const double *xrows, int64_t xstride, int Nx, int 
 
 extern "C" int muse_test_huge_batch_mb(muse_ctx *ctx, int32_t megabytes)
 {
-    if (!ctx || megabytes < 0 || megabytes > 4096)
-        return fail(MUSE_ERR_INVALID, "batch size 0 (built-in) ... 4096 MB");
+    if (!ctx || megabytes < -4096 || megabytes > 4096)
+        return fail(MUSE_ERR_INVALID, "batch size 0 (built-in) ... 4096 MB; negative: that size with every batch on one stream");
     ctx->huge_batch_mb = megabytes;
     return MUSE_OK;
 }

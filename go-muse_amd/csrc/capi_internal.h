@@ -58,6 +58,13 @@ struct HugeWork {
     double2 *Y = nullptr, *T = nullptr;
     double *part = nullptr, *snorm = nullptr, *sfin = nullptr, *sfin_x = nullptr, *amax = nullptr;
     size_t Y_bytes = 0, T_bytes = 0, part_bytes = 0, snorm_bytes = 0, sfin_bytes = 0, sfin_x_bytes = 0, amax_bytes = 0;
+    // the all-scores pass runs its batches on TWO streams alternately (the tail of one batch's kernels under the head of the
+    // next one's): a second work buffer and tile-maximum buffer, the second stream, and the events that fork / join it
+    double2 *Y2 = nullptr;
+    double *amax2 = nullptr;
+    size_t Y2_bytes = 0, amax2_bytes = 0;
+    hipStream_t stream2 = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
 };
 constexpr int PROBE_WINDOWS = 4096; // clock probe (muse_test_clock_probe_*): windows its pinned buffer holds; the window count and the stop flag sit behind them
 struct muse_ctx {
@@ -111,7 +118,7 @@ struct muse_ctx {
     // result record and an event each -- so that a Muse.Run allocates nothing in steady state
     MemPool dev_pool, host_pool;   // dmalloc / hmalloc
     HugeWork huge;                 // series longer than 65 536 samples
-    int huge_batch_mb = 0;         // measurement hook (muse_test_huge_batch_mb): 0 = HUGE_BATCH_BYTES
+    int huge_batch_mb = 0;         // measurement hook (muse_test_huge_batch_mb): 0 = HUGE_BATCH_BYTES; negative: |mb| on ONE stream
     std::mutex huge_mu;
     std::mutex timing_mu;          // events / redo_events (LaunchTimer::end from concurrent muse_batch_run_rows callers)
     std::atomic<bool> rows_always_copy{false}; // test hook (muse_test_rows_always_copy): never let a kernel read the pinned staging buffer
