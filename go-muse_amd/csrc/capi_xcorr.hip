@@ -23,9 +23,50 @@ static int single_pair(muse_ctx *ctx, const double *x, int lenx, const double *y
         return fail(MUSE_ERR_INVALID, "bad single-pair arguments");
     if ((normalize_x && lenx < 2) || (normalize_y && leny < 2))
         return fail(MUSE_ERR_INVALID, "series length 1 has no sample standard deviation");
-    if (n > HUGE_MAX_N || (!is_pow2(n) && n > 8192))
-        return fail(MUSE_ERR_UNSUPPORTED, "FFT length %d is not built (powers of two up to %d, any n up to 8192)", n,
-                    HUGE_MAX_N);
+    if (n > HUGE_MAX_N || (!is_pow2(n) && n > HUGE_MAX_N / 2))
+        return fail(MUSE_ERR_UNSUPPORTED, "FFT length %d is not built (powers of two up to %d, any other n up to %d)", n,
+                    HUGE_MAX_N, HUGE_MAX_N / 2);
+    if (!is_pow2(n) && n > 8192) {
+        // Any n (xCorr takes the n it is given, xcorr.go:104-106; gonum transforms any length): the circular correlation of the two
+        // sequences padded to n is folded out of the one at a power of two L >= 2 n, where nothing wraps around --
+        //   cc_L[k] = r[k] (0 <= k < n),  cc_L[L - m] = r[-m] (0 < m < n)   (r = the linear correlation),   cc_n[k] = r[k] + r[k - n]
+        // -- on the batched kernels of that length; zeroPad(x, L) = zeroPad(zeroPad(x, n), L), the statistics are the series' own,
+        // and the scale keeps its n: cc_scale is the reference's factor BEHIND an unnormalised inverse of length n, so at length L
+        // it becomes cc_scale n / L.  The fold and maxAbsIndex (xcorr.go:39-50) run on the host: a single-pair entry point.
+        int64_t L = 1;
+        while (L < 2 * (int64_t)n)
+            L <<= 1;
+        std::vector<double> ccL((size_t)L);
+        int32_t lagL = 0, nilL = 0;
+        double mvL = 0.0;
+        rc = single_pair(ctx, x, lenx, y, leny, (int)L, normalize_x, normalize_y, x_scale, cc_scale * (double)n / (double)L, ccL.data(),
+                         &lagL, &mvL, &nilL);
+        if (rc)
+            return rc;
+        if (is_nil)
+            *is_nil = nilL;
+        if (nilL) { // (nil, 0, 0)
+            *lag = 0;
+            *mv = 0.0;
+            return MUSE_OK;
+        }
+        int64_t mi = 0;
+        double best = 0.0, first = 0.0;
+        for (int64_t k = 0; k < n; k++) {
+            const double v = k == 0 ? ccL[0] : ccL[(size_t)k] + ccL[(size_t)(L - n + k)];
+            if (cc)
+                cc[k] = v;
+            if (k == 0)
+                first = v;
+            if (std::fabs(v) > std::fabs(best)) { // strictly greater: the first index keeps ties; NaN never wins
+                best = v;
+                mi = k;
+            }
+        }
+        *mv = mi == 0 ? first : best; // (nothing above 0, or every cc NaN: index 0, mv = cc[0])
+        *lag = (int32_t)(mi > n / 2 ? mi - n : mi);
+        return MUSE_OK;
+    }
     double *dx = nullptr, *dy = nullptr, *dcc = nullptr, *dmv = nullptr;
     int *dlag = nullptr, *dstat = nullptr;
     double2 *dX = nullptr, *dxc = nullptr, *dscr = nullptr;

@@ -332,7 +332,9 @@ int muse_xcorr_with_x(muse_ctx *ctx, const double *ref, const double *y,
                       int32_t N, int32_t n, double *cc, int32_t *lag,
                       double *mv, int32_t *is_nil);
 /* xCorr (xcorr.go:102-153): n is raised to max(n, lenx, leny); cc holds that
- * many doubles. */
+ * many doubles.  n is used as given (not rounded up: the reference transforms any length): powers of two up to 2^20 run
+ * the batched kernels; any other n up to 8192 the direct kernel; any other n up to 2^19 is folded out of the correlation at
+ * a power of two L >= 2 n, where nothing wraps around (cc_n[k] = r[k] + r[k - n]; the fold and the argmax run on the host). */
 int muse_xcorr(muse_ctx *ctx, const double *x, int32_t lenx, const double *y,
                int32_t leny, int32_t n, int32_t normalize, double *cc,
                int32_t *lag, double *mv, int32_t *is_nil);

@@ -175,6 +175,54 @@ def test_huge_single_pair_entry_points(muse, eng, oracle):
     assert cc3 is None and lag3 == 0 and mv3 == 0.0
 
 
+def _numpy_xcorr(x, y, n, normalize):
+    """xcorr.go:102-153 restated with numpy's FFT (any n): the checker for lengths the C oracle's naive DFT cannot reach in time"""
+    n = max(n, len(x), len(y))
+
+    def zn(v):
+        v = v - v.sum() / len(v)
+        sd = np.sqrt(np.sum((v - v.mean()) ** 2) / (len(v) - 1))
+        return None if sd == 0 else v / sd
+    if normalize:
+        x, y = zn(x), zn(y)
+        if x is None or y is None:
+            return None, 0, 0.0
+    xp, yp = np.zeros(n), np.zeros(n)
+    xp[n - len(x):] = x
+    yp[n - len(y):] = y
+    cc = np.fft.irfft(np.fft.rfft(xp) * np.conj(np.fft.rfft(yp)), n) * n      # gonum's Sequence is unnormalised
+    cc *= 1.0 / (float(n) * (n - 1)) if normalize else 1.0 / n
+    mi = 0
+    best = 0.0
+    a = np.abs(cc)
+    mi = int(np.argmax(a)) if a.max() > 0 else 0                                # (argmax returns the first maximum)
+    mv = cc[mi]
+    return cc, (mi - n if mi > n // 2 else mi), mv
+
+
+@pytest.mark.parametrize("lenx,leny,n", [(10000, 10000, 0), (9000, 12001, 0), (20000, 5000, 30000), (70001, 70001, 0), (300000, 250000, 0)])
+def test_xcorr_at_any_n(muse, eng, lenx, leny, n):
+    """xCorr takes the n it is given (xcorr.go:104-106) and gonum transforms any length: for n that is not a power of two the
+    circular correlation is folded out of a power-of-two one at L >= 2 n (muse_xcorr: single pair, fold and argmax on the host) --
+    n = 10 000 ... 300 000 against a numpy restatement, normalised and raw, full cc; a constant series is nil."""
+    rng = np.random.default_rng(lenx + leny)
+    x = rng.standard_normal(lenx) * 3.0 + 1.0
+    y = rng.standard_normal(leny)
+    L = min(lenx, leny)
+    y[leny - L:] += 1.5 * np.roll(x[lenx - L:], 11)
+    for normalize in (True, False):
+        cc, lag, mv = eng.xcorr(x, y, n, normalize)
+        occ, olag, omv = _numpy_xcorr(x, y, n, normalize)
+        assert len(cc) == len(occ) == max(n, lenx, leny)
+        assert np.max(np.abs(cc - occ)) <= 1e-9 * np.max(np.abs(occ))
+        assert lag == olag and abs(mv - omv) <= SCORE_RTOL * abs(omv)
+    cc, lag, mv = eng.xcorr(np.full(lenx, 2.0), y, n, True)
+    assert cc is None and lag == 0 and mv == 0.0
+    with pytest.raises(muse.MuseError) as ei:
+        eng.xcorr(np.zeros(600000), np.zeros(600000), 0, False)                 # beyond 2^19 only powers of two are built
+    assert ei.value.status == muse.binding.MUSE_ERR_UNSUPPORTED
+
+
 def test_lengths_above_the_limit_are_refused(muse, eng):
     N = (1 << 20) + 1
     dg = muse.DeviceGroup(eng, N, 0)
