@@ -587,6 +587,10 @@ extern "C" int muse_batch_free(muse_batch *b)
         dfree(c, b->sp->c1);
         delete b->sp;
     }
+    if (b->small_out) { // kept by the context for its next batch (coherent pinned memory is slow to allocate)
+        std::lock_guard<std::mutex> lock(c->small_mu);
+        c->small_free.push_back(b->small_out);
+    }
     dfree(c, b->ovf_count);
     if (b->handoff_host)
         hfree(c, b->handoff_host);

@@ -175,6 +175,48 @@ int upload_group_ids(muse_batch *b, const int32_t *group_id, int64_t M)
     return MUSE_OK;
 }
 
+// Small Runs: launch_group_reduce's outcome from one launch, read from coherent pinned memory once the kernel's flag arrives
+// (reduce_kernels.hip, small_groups_kernel).  *rec / *key stay valid until the batch's next Run.
+static bool small_run(int64_t M, int64_t G) { return M <= SMALL_GROUPS_MAX_M && G <= SMALL_GROUPS_MAX_G; }
+static int small_reduce(muse_batch *b, const SelectParams &sp, const muse_record **rec, const unsigned long long **key)
+{
+    constexpr size_t REC_OFF = 64, KEY_OFF = REC_OFF + (size_t)SMALL_GROUPS_MAX_G * sizeof(muse_record);
+    if (!b->small_out) {
+        std::lock_guard<std::mutex> lock(b->ctx->small_mu);
+        if (!b->ctx->small_free.empty()) {
+            b->small_out = b->ctx->small_free.back();
+            b->ctx->small_free.pop_back();
+        }
+    }
+    if (!b->small_out)
+        HIP_TRY(hipHostMalloc((void **)&b->small_out, KEY_OFF + (size_t)SMALL_GROUPS_MAX_G * sizeof(unsigned long long),
+                              hipHostMallocCoherent | hipHostMallocMapped));
+    volatile unsigned long long *flag = (volatile unsigned long long *)b->small_out;
+    const unsigned long long token = ++b->small_token;
+    *flag = 0ull;
+    HIP_TRY(launch_small_groups(sp, (muse_record *)(b->small_out + REC_OFF), (unsigned long long *)(b->small_out + KEY_OFF),
+                                (unsigned long long *)b->small_out, token, b->stream()));
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (unsigned spin = 1; *flag != token; spin++) {
+        __builtin_ia32_pause();
+        if ((spin & 1023u) == 0) {
+            clock_gettime(CLOCK_MONOTONIC, &t1);
+            if ((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec) > 200000000ll) // 0.2 s: hand over to the runtime
+                break;
+        }
+    }
+    if (*flag != token) {
+        HIP_TRY(hipStreamSynchronize(b->stream()));
+        if (*flag != token)
+            return fail(MUSE_ERR_HIP, "small Run: the records did not arrive");
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    *rec = (const muse_record *)(b->small_out + REC_OFF);
+    *key = (const unsigned long long *)(b->small_out + KEY_OFF);
+    return MUSE_OK;
+}
+
 int run_select(muse_batch *b, const int32_t *group_id, int32_t G_in, int64_t series_offset, int32_t max_lag,
                       int32_t top_n, double threshold, int32_t sign_filter, int32_t abs_scores,
                       std::vector<muse_record> &out, bool already_scored, bool prescreened)
@@ -207,7 +249,8 @@ int run_select(muse_batch *b, const int32_t *group_id, int32_t G_in, int64_t ser
     // then go to the lower group id: docs/HISTORY.md 8.3).
     const bool on_device = select_on_device(top_n, G);
     const int K = on_device ? top_n : 1;
-    rc = ensure_select_ws(b, M, G, group_id != nullptr, K, on_device);
+    const bool small = !on_device && !screened && small_run(M, G); // (a screened Run's host-side checks wait on the stream)
+    rc = ensure_select_ws(b, M, small ? 0 : G, group_id != nullptr, K, on_device);
     if (rc)
         return rc;
     rc = upload_group_ids(b, group_id, M);
@@ -231,9 +274,18 @@ int run_select(muse_batch *b, const int32_t *group_id, int32_t G_in, int64_t ser
     sp.sign_filter = sign_filter;
     sp.series_offset = series_offset;
     sp.include = screened ? b->include : nullptr;
-    HIP_TRY(launch_group_reduce(sp, b->gw, b->rec, b->selkey, b->stream()));
     std::vector<muse_record> cands;
-    if (on_device) {
+    if (small) {
+        const muse_record *rec;
+        const unsigned long long *key;
+        rc = small_reduce(b, sp, &rec, &key);
+        if (rc)
+            return rc;
+        for (int64_t g = 0; g < G; g++)
+            if (key[(size_t)g] != 0ull)
+                cands.push_back(rec[(size_t)g]);
+    } else if (on_device) {
+        HIP_TRY(launch_group_reduce(sp, b->gw, b->rec, b->selkey, b->stream()));
         const int64_t nb = (G + TOPN_CHUNK - 1) / TOPN_CHUNK;
         HIP_TRY(launch_topn(b->rec, b->selkey, (int)G, K, b->cand, b->cnt, b->stream()));
         const int *cnt = b->cnt_host;
@@ -252,6 +304,7 @@ int run_select(muse_batch *b, const int32_t *group_id, int32_t G_in, int64_t ser
         if (screened && screen_guard_tripped(b)) // an estimate left its bound: this Run is redone entirely in fp64
             return run_select(b, group_id, G_in, series_offset, max_lag, top_n, threshold, sign_filter, abs_scores, out, false);
     } else {
+        HIP_TRY(launch_group_reduce(sp, b->gw, b->rec, b->selkey, b->stream()));
         const muse_record *rec = b->rec_host;
         const unsigned long long *key = b->key_host;
         HIP_TRY(hipMemcpyAsync(b->rec_host, b->rec, (size_t)G * sizeof(muse_record), hipMemcpyDeviceToHost, b->stream()));
@@ -342,7 +395,8 @@ extern "C" int muse_batch_run_groups(muse_batch *b, const int32_t *group_id, int
     }
     if (M == 0 || G == 0)
         return MUSE_OK;
-    rc = ensure_select_ws(b, M, G, true, 1, false);
+    const bool small = small_run(M, G);
+    rc = small ? ensure_select_ws(b, M, 0, true, 1, false) : ensure_select_ws(b, M, G, true, 1, false);
     if (rc)
         return rc;
     rc = upload_group_ids(b, group_id, M);
@@ -357,6 +411,17 @@ extern "C" int muse_batch_run_groups(muse_batch *b, const int32_t *group_id, int
     sp.abs_scores = abs_scores ? 1 : 0;
     sp.series_offset = series_offset;
     sp.partial = 1;
+    if (small) {
+        const muse_record *rec;
+        const unsigned long long *key;
+        rc = small_reduce(b, sp, &rec, &key);
+        if (rc)
+            return rc;
+        memcpy(out_records, rec, (size_t)G * sizeof(muse_record));
+        for (int32_t g = 0; g < G; g++)
+            out_state[g] = (uint8_t)key[g];
+        return MUSE_OK;
+    }
     HIP_TRY(launch_group_reduce(sp, b->gw, b->rec, b->selkey, b->stream()));
     std::vector<unsigned long long> st((size_t)G);
     HIP_TRY(hipMemcpyAsync(out_records, b->rec, (size_t)G * sizeof(muse_record), hipMemcpyDeviceToHost, b->stream()));

@@ -82,52 +82,116 @@ __device__ __forceinline__ bool passed(double s, int lag, const SelectParams &sp
            (sp.sign_filter == 0 || (s > 0 && sp.sign_filter == 1) || (s < 0 && sp.sign_filter == -1));
 }
 
+// one group's record + selection key from its first member f and its winner w (IDX_NONE: none)
+__device__ __forceinline__ void final_record(const SelectParams &sp, int g, long long f, long long w, muse_record &r,
+                                             unsigned long long &key)
+{
+    r.series = -1;
+    r.score = 0.0;
+    r.lag = 0;
+    r.group = g;
+    key = 0ull;
+    if (sp.group_id) {
+        if (f == IDX_NONE) // empty group: Score.Labels == nil, results.go:56-59
+            return;
+        const double vf = clamp_score(sp.mv[f], sp.abs_scores);
+        if (sp.partial) { // one shard of the group: the merge over shards decides (muse_merge_group_records)
+            key = vf != vf ? 2ull : 1ull;
+            if (w != IDX_NONE) {
+                r.series = w + sp.series_offset;
+                r.score = clamp_score(sp.mv[w], sp.abs_scores);
+                r.lag = sp.lag[w];
+            }
+            return;
+        }
+        if (w == IDX_NONE || vf != vf) // first member NaN is never replaced (x > NaN is false)
+            w = f;
+    } else {
+        w = g;
+    }
+    const double s = clamp_score(sp.mv[w], sp.abs_scores);
+    const int lg = sp.lag[w];
+    r.series = w + sp.series_offset;
+    r.score = s;
+    r.lag = lg;
+    // (filter-and-refine Run: only rows the fp64 kernel has re-evaluated may be selected)
+    key = (!sp.include || sp.include[w] == 1) && passed(s, lg, sp) ? abs_bits(s) + 1ull : 0ull;
+}
+
 // pass C: one record + selection key per group
 __global__ void group_final_kernel(SelectParams sp, GroupWork gw, muse_record *rec, unsigned long long *selkey)
 {
     for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < sp.G; g += gridDim.x * blockDim.x) {
-        long long w;
-        if (sp.group_id) {
-            const long long f = gw.first[g];
-            if (f == IDX_NONE) { // empty group: Score.Labels == nil, results.go:56-59
-                rec[g].series = -1;
-                rec[g].score = 0.0;
-                rec[g].lag = 0;
-                rec[g].group = g;
-                selkey[g] = 0ull;
-                continue;
-            }
-            w = gw.win[g];
-            const double vf = clamp_score(sp.mv[f], sp.abs_scores);
-            if (sp.partial) { // one shard of the group: the merge over shards decides (muse_merge_group_records)
-                selkey[g] = vf != vf ? 2ull : 1ull;
-                if (w == IDX_NONE) {
-                    rec[g].series = -1;
-                    rec[g].score = 0.0;
-                    rec[g].lag = 0;
-                    rec[g].group = g;
-                } else {
-                    rec[g].series = w + sp.series_offset;
-                    rec[g].score = clamp_score(sp.mv[w], sp.abs_scores);
-                    rec[g].lag = sp.lag[w];
-                    rec[g].group = g;
-                }
-                continue;
-            }
-            if (w == IDX_NONE || vf != vf) // first member NaN is never replaced (x > NaN is false)
-                w = f;
-        } else {
-            w = g;
-        }
-        const double s = clamp_score(sp.mv[w], sp.abs_scores);
-        const int lg = sp.lag[w];
-        rec[g].series = w + sp.series_offset;
-        rec[g].score = s;
-        rec[g].lag = lg;
-        rec[g].group = g;
-        // (filter-and-refine Run: only rows the fp64 kernel has re-evaluated may be selected)
-        selkey[g] = (!sp.include || sp.include[w] == 1) && passed(s, lg, sp) ? abs_bits(s) + 1ull : 0ull;
+        muse_record r;
+        unsigned long long key;
+        final_record(sp, g, sp.group_id ? gw.first[g] : IDX_NONE, sp.group_id ? gw.win[g] : IDX_NONE, r, key);
+        rec[g] = r;
+        selkey[g] = key;
     }
+}
+
+// Small Runs (the reference's own benchmark shapes: 5 000 series in 100 label groups, muse_batch_test.go:134-162): the four passes
+// above in ONE workgroup with the per-group work arrays in LDS, the records and keys written straight into pinned host memory
+// and a flag behind them -- one launch and a poll where the general path has four launches, two copies and a synchronisation.
+__global__ __launch_bounds__(1024) void small_groups_kernel(SelectParams sp, muse_record *out_rec, unsigned long long *out_key,
+                                                            unsigned long long *flag, unsigned long long token)
+{
+    extern __shared__ unsigned long long sm[];
+    unsigned long long *key = sm;
+    long long *first = (long long *)(sm + sp.G), *win = (long long *)(sm + 2 * (size_t)sp.G);
+    const int t = threadIdx.x;
+    if (sp.group_id) {
+        for (int g = t; g < sp.G; g += 1024) {
+            key[g] = 0ull;
+            first[g] = IDX_NONE;
+            win[g] = IDX_NONE;
+        }
+        __syncthreads();
+        for (long long i = t; i < sp.M; i += 1024) { // group_key_kernel
+            const int g = sp.group_id[i];
+            if (g < 0 || g >= sp.G)
+                continue;
+            atomicMin(&first[g], i);
+            if (sp.include && sp.include[i] != 1)
+                continue;
+            const double v = clamp_score(sp.mv[i], sp.abs_scores);
+            if (v == v)
+                atomicMax(&key[g], abs_bits(v));
+        }
+        __syncthreads();
+        for (long long i = t; i < sp.M; i += 1024) { // group_win_kernel
+            const int g = sp.group_id[i];
+            if (g < 0 || g >= sp.G)
+                continue;
+            if (sp.include && sp.include[i] != 1)
+                continue;
+            const double v = clamp_score(sp.mv[i], sp.abs_scores);
+            if (v == v && abs_bits(v) == key[g])
+                atomicMin(&win[g], i);
+        }
+        __syncthreads();
+    }
+    for (int g = t; g < sp.G; g += 1024) {
+        muse_record r;
+        unsigned long long k;
+        final_record(sp, g, sp.group_id ? first[g] : IDX_NONE, sp.group_id ? win[g] : IDX_NONE, r, k);
+        out_rec[g] = r;
+        out_key[g] = k;
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0)
+        *flag = token;
+}
+
+hipError_t launch_small_groups(const SelectParams &sp, muse_record *out_rec, unsigned long long *out_key, unsigned long long *flag,
+                               unsigned long long token, hipStream_t stream)
+{
+    if (sp.G <= 0 || sp.G > SMALL_GROUPS_MAX_G)
+        return hipErrorInvalidValue;
+    hipLaunchKernelGGL(small_groups_kernel, dim3(1), dim3(1024), sp.group_id ? (size_t)sp.G * 3 * sizeof(unsigned long long) : 0, stream,
+                       sp, out_rec, out_key, flag, token);
+    return hipGetLastError();
 }
 
 hipError_t launch_group_reduce(const SelectParams &sp, const GroupWork &gw, muse_record *rec,
