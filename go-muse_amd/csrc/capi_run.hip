@@ -175,45 +175,47 @@ int upload_group_ids(muse_batch *b, const int32_t *group_id, int64_t M)
     return MUSE_OK;
 }
 
-// Small Runs: launch_group_reduce's outcome from one launch, read from coherent pinned memory once the kernel's flag arrives
-// (reduce_kernels.hip, small_groups_kernel).  *rec / *key stay valid until the batch's next Run.
+// Small Runs: launch_group_reduce's outcome from one launch, read from coherent pinned memory as the kernel's per-slot stamps arrive
+// (reduce_kernels.hip, small_groups_kernel).  *out stays valid until the batch's next Run.
 static bool small_run(int64_t M, int64_t G) { return M <= SMALL_GROUPS_MAX_M && G <= SMALL_GROUPS_MAX_G; }
-static int small_reduce(muse_batch *b, const SelectParams &sp, const muse_record **rec, const unsigned long long **key)
+static int small_reduce(muse_batch *b, const SelectParams &sp, const SmallSlot **out)
 {
-    constexpr size_t REC_OFF = 64, KEY_OFF = REC_OFF + (size_t)SMALL_GROUPS_MAX_G * sizeof(muse_record);
-    if (!b->small_out) {
-        std::lock_guard<std::mutex> lock(b->ctx->small_mu);
-        if (!b->ctx->small_free.empty()) {
-            b->small_out = b->ctx->small_free.back();
-            b->ctx->small_free.pop_back();
+    muse_ctx *ctx = b->ctx;
+    unsigned long long token;
+    {
+        std::lock_guard<std::mutex> lock(ctx->small_mu);
+        token = ++ctx->small_token; // per context, as the buffers are: no slot has ever held this stamp
+        if (!b->small_out && !ctx->small_free.empty()) {
+            b->small_out = ctx->small_free.back();
+            ctx->small_free.pop_back();
         }
     }
-    if (!b->small_out)
-        HIP_TRY(hipHostMalloc((void **)&b->small_out, KEY_OFF + (size_t)SMALL_GROUPS_MAX_G * sizeof(unsigned long long),
-                              hipHostMallocCoherent | hipHostMallocMapped));
-    volatile unsigned long long *flag = (volatile unsigned long long *)b->small_out;
-    const unsigned long long token = ++b->small_token;
-    *flag = 0ull;
-    HIP_TRY(launch_small_groups(sp, (muse_record *)(b->small_out + REC_OFF), (unsigned long long *)(b->small_out + KEY_OFF),
-                                (unsigned long long *)b->small_out, token, b->stream()));
+    if (!b->small_out) {
+        HIP_TRY(hipHostMalloc((void **)&b->small_out, (size_t)SMALL_GROUPS_MAX_G * sizeof(SmallSlot), hipHostMallocCoherent | hipHostMallocMapped));
+        memset(b->small_out, 0, (size_t)SMALL_GROUPS_MAX_G * sizeof(SmallSlot));
+    }
+    const volatile SmallSlot *slots = (const volatile SmallSlot *)b->small_out;
+    HIP_TRY(launch_small_groups(sp, (SmallSlot *)b->small_out, token, b->stream()));
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
-    for (unsigned spin = 1; *flag != token; spin++) {
-        __builtin_ia32_pause();
-        if ((spin & 1023u) == 0) {
+    bool synced = false;
+    for (int g = sp.G - 1; g >= 0; g--) { // (the last slot first: the others have mostly arrived by then)
+        for (unsigned spin = 1; slots[g].stamp != token; spin++) {
+            __builtin_ia32_pause();
+            if ((spin & 1023u) != 0)
+                continue;
             clock_gettime(CLOCK_MONOTONIC, &t1);
-            if ((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec) > 200000000ll) // 0.2 s: hand over to the runtime
-                break;
+            if ((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec) <= 200000000ll) // 0.2 s, then the runtime waits
+                continue;
+            if (synced)
+                return fail(MUSE_ERR_HIP, "small Run: the records did not arrive");
+            HIP_TRY(hipStreamSynchronize(b->stream()));
+            synced = true;
+            clock_gettime(CLOCK_MONOTONIC, &t0);
         }
     }
-    if (*flag != token) {
-        HIP_TRY(hipStreamSynchronize(b->stream()));
-        if (*flag != token)
-            return fail(MUSE_ERR_HIP, "small Run: the records did not arrive");
-    }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
-    *rec = (const muse_record *)(b->small_out + REC_OFF);
-    *key = (const unsigned long long *)(b->small_out + KEY_OFF);
+    *out = (const SmallSlot *)b->small_out;
     return MUSE_OK;
 }
 
@@ -276,14 +278,13 @@ int run_select(muse_batch *b, const int32_t *group_id, int32_t G_in, int64_t ser
     sp.include = screened ? b->include : nullptr;
     std::vector<muse_record> cands;
     if (small) {
-        const muse_record *rec;
-        const unsigned long long *key;
-        rc = small_reduce(b, sp, &rec, &key);
+        const SmallSlot *slot;
+        rc = small_reduce(b, sp, &slot);
         if (rc)
             return rc;
         for (int64_t g = 0; g < G; g++)
-            if (key[(size_t)g] != 0ull)
-                cands.push_back(rec[(size_t)g]);
+            if (slot[g].key != 0u)
+                cands.push_back(muse_record{slot[g].series, slot[g].score, slot[g].lag, (int32_t)g});
     } else if (on_device) {
         HIP_TRY(launch_group_reduce(sp, b->gw, b->rec, b->selkey, b->stream()));
         const int64_t nb = (G + TOPN_CHUNK - 1) / TOPN_CHUNK;
@@ -412,14 +413,14 @@ extern "C" int muse_batch_run_groups(muse_batch *b, const int32_t *group_id, int
     sp.series_offset = series_offset;
     sp.partial = 1;
     if (small) {
-        const muse_record *rec;
-        const unsigned long long *key;
-        rc = small_reduce(b, sp, &rec, &key);
+        const SmallSlot *slot;
+        rc = small_reduce(b, sp, &slot);
         if (rc)
             return rc;
-        memcpy(out_records, rec, (size_t)G * sizeof(muse_record));
-        for (int32_t g = 0; g < G; g++)
-            out_state[g] = (uint8_t)key[g];
+        for (int32_t g = 0; g < G; g++) {
+            out_records[g] = muse_record{slot[g].series, slot[g].score, slot[g].lag, g};
+            out_state[g] = (uint8_t)slot[g].key;
+        }
         return MUSE_OK;
     }
     HIP_TRY(launch_group_reduce(sp, b->gw, b->rec, b->selkey, b->stream()));

@@ -131,10 +131,12 @@ __global__ void group_final_kernel(SelectParams sp, GroupWork gw, muse_record *r
 }
 
 // Small Runs (the reference's own benchmark shapes: 5 000 series in 100 label groups, muse_batch_test.go:134-162): the four passes
-// above in ONE workgroup with the per-group work arrays in LDS, the records and keys written straight into pinned host memory
-// and a flag behind them -- one launch and a poll where the general path has four launches, two copies and a synchronisation.
-__global__ __launch_bounds__(1024) void small_groups_kernel(SelectParams sp, muse_record *out_rec, unsigned long long *out_key,
-                                                            unsigned long long *flag, unsigned long long token)
+// above in ONE workgroup with the per-group work arrays in LDS, each group's record written straight into a 32-byte slot of pinned
+// host memory -- one launch and a poll where the general path has four launches, two copies and a synchronisation.  Every slot
+// carries its own stamp, stored by the thread that wrote the slot, behind a system-scope fence and into the same 32-byte block:
+// writes to DIFFERENT blocks of host memory arrive in no particular order (one flag behind all records was seen to overtake them:
+// tools/soak_round6.py), so the host waits for every slot's stamp.
+__global__ __launch_bounds__(1024) void small_groups_kernel(SelectParams sp, SmallSlot *out, unsigned long long token)
 {
     extern __shared__ unsigned long long sm[];
     unsigned long long *key = sm;
@@ -171,26 +173,29 @@ __global__ __launch_bounds__(1024) void small_groups_kernel(SelectParams sp, mus
         }
         __syncthreads();
     }
-    for (int g = t; g < sp.G; g += 1024) {
-        muse_record r;
-        unsigned long long k;
-        final_record(sp, g, sp.group_id ? first[g] : IDX_NONE, sp.group_id ? win[g] : IDX_NONE, r, k);
-        out_rec[g] = r;
-        out_key[g] = k;
+    for (int g0 = 0; g0 < sp.G; g0 += 1024) { // (uniform trip count: the fence below is reached by whole waves)
+        const int g = g0 + t;
+        if (g < sp.G) {
+            muse_record r;
+            unsigned long long k;
+            final_record(sp, g, sp.group_id ? first[g] : IDX_NONE, sp.group_id ? win[g] : IDX_NONE, r, k);
+            out[g].series = r.series;
+            out[g].score = r.score;
+            out[g].lag = r.lag;
+            out[g].key = k > 2ull ? 3u : (unsigned)k;
+        }
+        __threadfence_system();
+        if (g < sp.G)
+            __hip_atomic_store(&out[g].stamp, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    __threadfence_system();
-    __syncthreads();
-    if (t == 0)
-        *flag = token;
 }
 
-hipError_t launch_small_groups(const SelectParams &sp, muse_record *out_rec, unsigned long long *out_key, unsigned long long *flag,
-                               unsigned long long token, hipStream_t stream)
+hipError_t launch_small_groups(const SelectParams &sp, SmallSlot *out, unsigned long long token, hipStream_t stream)
 {
     if (sp.G <= 0 || sp.G > SMALL_GROUPS_MAX_G)
         return hipErrorInvalidValue;
     hipLaunchKernelGGL(small_groups_kernel, dim3(1), dim3(1024), sp.group_id ? (size_t)sp.G * 3 * sizeof(unsigned long long) : 0, stream,
-                       sp, out_rec, out_key, flag, token);
+                       sp, out, token);
     return hipGetLastError();
 }
 

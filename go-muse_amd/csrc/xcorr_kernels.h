@@ -221,12 +221,19 @@ hipError_t launch_screen_select(const ScreenSelect &q, int top_n, unsigned long 
 // per-group winners -> rec[G] (+ selection keys selkey[G]: 0 = filtered out)
 hipError_t launch_group_reduce(const SelectParams &sp, const GroupWork &gw, muse_record *rec,
                                unsigned long long *selkey, hipStream_t stream);
-// small Runs in one launch (reduce_kernels.hip, small_groups_kernel): what launch_group_reduce computes, the records and keys
-// written into pinned host memory with `token` stored to *flag behind them
-constexpr int SMALL_GROUPS_MAX_G = 2048;       // label groups (three 8-byte work arrays in LDS)
+// small Runs in one launch (reduce_kernels.hip, small_groups_kernel): what launch_group_reduce computes, one 32-byte slot of pinned
+// host memory per label group, each with its own stamp (= token) stored last
+constexpr int SMALL_GROUPS_MAX_G = 2048;        // label groups (three 8-byte work arrays in LDS)
 constexpr long long SMALL_GROUPS_MAX_M = 32768; // series
-hipError_t launch_small_groups(const SelectParams &sp, muse_record *out_rec, unsigned long long *out_key, unsigned long long *flag,
-                               unsigned long long token, hipStream_t stream);
+struct SmallSlot {
+    long long series; // muse_record::series, ::score, ::lag of group g (::group = g)
+    double score;
+    int lag;
+    unsigned key;     // the selection key: 0 not selectable / empty; partial mode: the group's state 0 / 1 / 2
+    unsigned long long stamp;
+};
+static_assert(sizeof(SmallSlot) == 32, "one slot = one 32-byte block");
+hipError_t launch_small_groups(const SelectParams &sp, SmallSlot *out, unsigned long long token, hipStream_t stream);
 // one label group in one launch (Muse.Run): the winner record and the group's state (reduce_kernels.hip)
 struct SingleGroupOut {
     muse_record rec;

@@ -5,7 +5,10 @@
   * the two-sided xCorr at those lengths (different lengths per side, normalised and raw, full cc);
   * groups built through staging windows with random piece sizes and commit orders, interleaved with ordinary appends, on a context
     whose allocation cache is warm with blocks of other shapes: rows read back bit for bit, scores equal to a group uploaded at once;
-  * muse_batch_run_row_ptrs against muse_batch_run_rows at random lengths and group sizes.
+  * muse_batch_run_row_ptrs against muse_batch_run_rows at random lengths and group sizes;
+  * small Runs (one-launch reduction, reduce_kernels.hip small_groups_kernel) on both sides of its limits (32 768 series, 2 048 label
+    groups): muse_batch_run_groups against a numpy restatement of the per-group winner, muse_batch_run against the general path
+    (the same label map padded with empty groups).
 usage: soak_round6.py [seconds] [seed]"""
 import importlib
 import os
@@ -24,7 +27,7 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
 rng = np.random.default_rng(seed)
 eng = pkg.get_engine(0)
 t_end = time.time() + budget
-cases = {"huge_scores": 0, "huge_xcorr": 0, "windows": 0, "row_ptrs": 0}
+cases = {"huge_scores": 0, "huge_xcorr": 0, "windows": 0, "row_ptrs": 0, "small_run": 0}
 bad = 0
 last_note = time.time()
 print("seed", seed, flush=True)
@@ -178,7 +181,71 @@ def soak_row_ptrs():
     cases["row_ptrs"] += 1
 
 
-kinds = [soak_huge_scores, soak_huge_xcorr, soak_windows, soak_row_ptrs]
+def soak_small_run():
+    global bad
+    N = int(rng.choice([2, 8, 30, 480, int(rng.integers(2, 2000))]))
+    M = int(rng.choice([int(rng.integers(1, 60)), int(rng.integers(1, 6000)), int(rng.integers(30000, 36000))]))
+    M = max(1, min(M, 40_000_000 // (8 * N)))
+    G = int(rng.choice([1, int(rng.integers(1, 120)), int(rng.integers(1900, 2200)), M]))
+    ref = rng.standard_normal(N)
+    rows = rng.standard_normal((M, N)) + rng.uniform(-3, 3, (M, 1)) * np.roll(ref, int(rng.integers(-3, 4)))[None, :]
+    for _ in range(int(rng.integers(0, 6))):
+        i = int(rng.integers(0, M))
+        r = rng.random()
+        if r < 0.4:
+            rows[i] = rng.uniform(-5, 5)
+        elif r < 0.7:
+            rows[i, int(rng.integers(0, N))] = np.nan
+        elif i > 0:
+            rows[i] = rows[i - 1]
+    gid = rng.integers(0, G, M).astype(np.int32)
+    if G == M and rng.random() < 0.5:
+        gid = np.arange(M, dtype=np.int32)
+    dg = pkg.DeviceGroup.from_rows(eng, rows)
+    db = pkg.DeviceBatch(eng, dg, ref)
+    lag, mv = db.scores()
+    off = int(rng.integers(0, 1000))
+    for abs_scores in (True, False):
+        rec, st = db.run_groups(gid, G, off, abs_scores=abs_scores)
+        v = np.clip(np.abs(mv) if abs_scores else mv, -1.0, 1.0)
+        order = np.lexsort((np.arange(M), gid))            # by group, then by index
+        gs = gid[order]
+        starts = np.flatnonzero(np.r_[True, gs[1:] != gs[:-1]])
+        ends = np.r_[starts[1:], M]
+        want_st = np.zeros(G, dtype=np.uint8)
+        want_series = np.full(G, -1, dtype=np.int64)
+        for a, b in zip(starts, ends):
+            idx = order[a:b]
+            g = int(gs[a])
+            want_st[g] = 2 if np.isnan(v[idx[0]]) else 1
+            num = idx[~np.isnan(v[idx])]
+            if num.size:
+                want_series[g] = num[np.argmax(np.abs(v[num]))] + off
+        good = np.array_equal(st, want_st) and np.array_equal(rec["series"], want_series)
+        has = want_series >= 0
+        w = want_series[has] - off
+        good = good and np.array_equal(rec["score"][has], v[w]) and np.array_equal(rec["lag"][has], lag[w])
+        good = good and not rec["score"][~has].any() and np.array_equal(rec["group"], np.arange(G))
+        if not good:
+            bad += 1
+            print("MISMATCH small_run groups N=%d M=%d G=%d abs=%d" % (N, M, G, abs_scores), flush=True)
+    kw = dict(max_lag=int(rng.integers(0, N + 1)), top_n=int(rng.choice([1, 5, 20, 500])), threshold=float(rng.choice([0.0, 0.3, 0.8])),
+              sign_filter=int(rng.integers(-1, 2)), abs_scores=bool(rng.integers(0, 2)))
+    a = db.run(gid, G, **kw)
+    b = db.run(gid, G + 2049, **kw)
+    same = all(x.tolist() == y.tolist() for x, y in zip(a[:3], b[:3])) and (a[3] == b[3] or (np.isnan(a[3]) and np.isnan(b[3])))
+    if not same:
+        bad += 1
+        print("MISMATCH small_run run N=%d M=%d G=%d" % (N, M, G), kw, flush=True)
+    db.close()
+    dg.close()
+    cases["small_run"] += 1
+
+
+kinds = [soak_huge_scores, soak_huge_xcorr, soak_windows, soak_row_ptrs, soak_small_run]
+only = os.environ.get("SOAK_ONLY")
+if only:
+    kinds = [k for k in kinds if k.__name__ == "soak_" + only]
 while time.time() < t_end:
     kinds[int(rng.integers(0, len(kinds)))]()
     if time.time() - last_note > 50:
