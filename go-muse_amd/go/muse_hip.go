@@ -8,7 +8,8 @@
 // xcorr.go's hot loop.  Every cgo call copies its inputs (no Go pointer is
 // retained by C after the call returns), as the cgo pointer rules require.
 //
-// Needs Go >= 1.17 (unsafe.Slice / unsafe.Add over C memory; the reference's go.mod says 1.13).
+// Builds at the reference's own language level (go.mod:3, go 1.13): C memory is viewed through the array-pointer
+// idiom (f64View ... below), not unsafe.Slice / unsafe.Add (Go 1.17).
 // Build: CGO_CFLAGS="-I${REPO}/include" CGO_LDFLAGS="-L${REPO}/go-muse_amd/lib -lmuse_hip"
 package muse
 
@@ -28,6 +29,20 @@ import (
 	"sync/atomic"
 	"unsafe"
 )
+
+// Views of C memory as Go slices (n <= maxView elements; the array types only bound the index arithmetic, nothing of
+// that size is ever allocated).
+const maxView = 1 << 30
+
+func f64View(p unsafe.Pointer, n int) []float64 { return (*[maxView]float64)(p)[:n:n] }
+func i32View(p unsafe.Pointer, n int) []int32   { return (*[maxView]int32)(p)[:n:n] }
+func u8View(p *C.uint8_t, n int) []C.uint8_t    { return (*[maxView]C.uint8_t)(unsafe.Pointer(p))[:n:n] }
+func recView(p *C.muse_record, n int) []C.muse_record {
+	return (*[maxView]C.muse_record)(unsafe.Pointer(p))[:n:n]
+}
+func batchView(p **C.muse_batch, n int) []*C.muse_batch {
+	return (*[maxView]*C.muse_batch)(unsafe.Pointer(p))[:n:n]
+}
 
 // hipError turns a muse_status into a Go error carrying muse_last_error().
 func hipError(status C.int) error {
@@ -161,7 +176,7 @@ func SetScreening(enable bool, minRows int) error {
 // (muse_group_stage / muse_group_commit): every Series is copied ONCE, straight out of its Go slice into pinned C memory, by a
 // few goroutines in pieces of ~256 KB; a piece that completes the packed prefix of the window commits that prefix -- runs of
 // >= 4 MB, one host-to-device copy command each (a command costs ~13 us whatever its size) -- so the rows cross PCIe while the
-// next pieces are packed.  No Go pointer crosses: the window is C memory, the goroutines write into it through unsafe.Slice.
+// next pieces are packed.  No Go pointer crosses: the window is C memory, the goroutines write into it through f64View.
 func appendSeries(g *C.muse_group, series []*Series, n int) error {
 	for first := 0; first < len(series); {
 		var win *C.double
@@ -170,7 +185,7 @@ func appendSeries(g *C.muse_group, series []*Series, n int) error {
 			return err
 		}
 		k := int(granted)
-		rows := unsafe.Slice((*float64)(unsafe.Pointer(win)), k*n)
+		rows := f64View(unsafe.Pointer(win), k*n)
 		piece := (256 << 10) / (8 * n)
 		if piece < 1 {
 			piece = 1
@@ -493,8 +508,8 @@ func (b *Batch) feedGroupWinners(recs *C.muse_record, state *C.uint8_t, nShards,
 	if err := hipError(C.muse_merge_group_winners(recs, state, C.int32_t(nShards), C.int32_t(G), win, wst)); err != nil {
 		return err
 	}
-	winv := unsafe.Slice(win, G)
-	wstv := unsafe.Slice(wst, G)
+	winv := recView(win, G)
+	wstv := u8View(wst, G)
 	for g := 0; g < G; g++ {
 		if wstv[g] != 1 { // 0: no member; 2: the group's score is NaN, which never passes Results.passed
 			continue
@@ -575,11 +590,13 @@ func (b *Batch) runSharded(es []*engine, gid []C.int32_t, G int, exact bool) err
 	// C memory for what the devices write concurrently (muse_record is a plain 24-byte struct)
 	recs := (*C.muse_record)(C.calloc(C.size_t(W*per), C.size_t(unsafe.Sizeof(C.muse_record{}))))
 	defer C.free(unsafe.Pointer(recs))
-	recv := unsafe.Slice(recs, W*per)
+	recv := recView(recs, W*per)
 	var state *C.uint8_t
+	var statev []C.uint8_t
 	if straddle {
 		state = (*C.uint8_t)(C.calloc(C.size_t(W*G), 1))
 		defer C.free(unsafe.Pointer(state))
+		statev = u8View(state, W*G)
 	}
 	cnt := make([]C.int32_t, W)
 	errs := make([]error, W)
@@ -597,7 +614,7 @@ func (b *Batch) runSharded(es []*engine, gid []C.int32_t, G int, exact bool) err
 			var st C.int
 			if straddle {
 				st = C.muse_batch_run_groups(b.shardBatch[r], g, C.int32_t(G), C.int64_t(sh.lo), 1, &recv[r*per],
-					(*C.uint8_t)(unsafe.Add(unsafe.Pointer(state), r*G)))
+					&statev[r*G])
 			} else {
 				st = C.muse_batch_run_shard(b.shardBatch[r], g, C.int32_t(G), C.int64_t(sh.lo), C.int32_t(res.MaxLag),
 					C.int32_t(top), C.double(res.Threshold), C.int32_t(res.SignFilter), 1, &recv[r*per], &cnt[r])
@@ -706,7 +723,7 @@ func RunMany(batches []*Batch, groupByLabels []string) error {
 	R := len(batches)
 	hs := (**C.muse_batch)(C.malloc(C.size_t(R) * C.size_t(unsafe.Sizeof((*C.muse_batch)(nil)))))
 	defer C.free(unsafe.Pointer(hs))
-	hv := unsafe.Slice(hs, R)
+	hv := batchView(hs, R)
 	for i, b := range batches {
 		if b.batch == nil || b.batchGroup != dg {
 			if b.batch != nil {
@@ -783,8 +800,8 @@ func xCorrBatch(xs, ys [][]float64, n int, normalize bool) (lags []int, mvs []fl
 	if bx == nil || by == nil || clag == nil || cnil == nil || cmv == nil {
 		return nil, nil, nil, errors.New("out of memory staging series for xCorrBatch")
 	}
-	sx := unsafe.Slice((*float64)(unsafe.Pointer(bx)), m*lenx)
-	sy := unsafe.Slice((*float64)(unsafe.Pointer(by)), m*leny)
+	sx := f64View(unsafe.Pointer(bx), m*lenx)
+	sy := f64View(unsafe.Pointer(by), m*leny)
 	for i := 0; i < m; i++ {
 		copy(sx[i*lenx:(i+1)*lenx], xs[i])
 		copy(sy[i*leny:(i+1)*leny], ys[i])
@@ -798,9 +815,9 @@ func xCorrBatch(xs, ys [][]float64, n int, normalize bool) (lags []int, mvs []fl
 		return nil, nil, nil, err
 	}
 	lags, mvs, isNil = make([]int, m), make([]float64, m), make([]bool, m)
-	gl := unsafe.Slice((*int32)(unsafe.Pointer(clag)), m)
-	gn := unsafe.Slice((*int32)(unsafe.Pointer(cnil)), m)
-	gv := unsafe.Slice((*float64)(unsafe.Pointer(cmv)), m)
+	gl := i32View(unsafe.Pointer(clag), m)
+	gn := i32View(unsafe.Pointer(cnil), m)
+	gv := f64View(unsafe.Pointer(cmv), m)
 	for i := 0; i < m; i++ {
 		lags[i], mvs[i], isNil[i] = int(gl[i]), gv[i], gn[i] != 0
 	}
