@@ -111,6 +111,10 @@ def test_go_shim_calls_match_the_header():
     fields = set(re.findall(r"\b(\w+);", rec.group(1)))
     for f in set(re.findall(r"\brecs?\[[^\]]*\]\.(\w+)\b", go_nc)):
         assert f in fields, "muse_hip.go reads muse_record.%s; the header has %s" % (f, sorted(fields))
+    # the reference's language level (go.mod:3, go 1.13): nothing of Go 1.17+ (unsafe.Slice / unsafe.Add), no generics, no 1.21 builtins
+    for later in (r"\bunsafe\.(Slice|Add|String|SliceData)\(", r"\batomic\.(Int32|Int64|Uint32|Uint64|Bool|Pointer)\b", r"\bfunc \w+\[",
+                  r"\bany\b", r"(?<![.\w])(min|max|clear)\("):
+        assert not re.search(later, go_nc), "muse_hip.go needs a newer Go than the reference's go.mod: %s" % later
 
 
 def test_record_layout(muse):
