@@ -589,7 +589,7 @@ extern "C" int muse_batch_free(muse_batch *b)
     }
     if (b->small_out) { // kept by the context for its next batch (coherent pinned memory is slow to allocate)
         std::lock_guard<std::mutex> lock(c->small_mu);
-        c->small_free.push_back(b->small_out);
+        c->small_free.emplace_back(b->small_out, b->small_cap);
     }
     dfree(c, b->ovf_count);
     if (b->handoff_host)

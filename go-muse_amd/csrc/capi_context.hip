@@ -333,8 +333,8 @@ void ctx_release(muse_ctx *ctx)
     (void)hipFree(ctx->dbg_stamps);
     rows_slots_free(ctx);
     huge_free(ctx);
-    for (unsigned char *p : ctx->small_free)
-        (void)hipHostFree(p);
+    for (auto &p : ctx->small_free)
+        (void)hipHostFree(p.first);
     ctx->small_free.clear();
     pool_drain(ctx);
     for (auto *ev : {&ctx->events, &ctx->redo_events})

@@ -121,7 +121,7 @@ struct muse_ctx {
     int huge_batch_mb = 0;         // measurement hook (muse_test_huge_batch_mb): 0 = HUGE_BATCH_BYTES; negative: |mb| on ONE stream
     std::mutex huge_mu;
     std::mutex small_mu;           // small_free: the pinned record buffers of small Runs between batches (capi_run.hip)
-    std::vector<unsigned char *> small_free;
+    std::vector<std::pair<unsigned char *, int>> small_free; // (buffer, its capacity in slots)
     unsigned long long small_token = 0; // the stamp of the context's last small Run
     std::mutex timing_mu;          // events / redo_events (LaunchTimer::end from concurrent muse_batch_run_rows callers)
     std::atomic<bool> rows_always_copy{false}; // test hook (muse_test_rows_always_copy): never let a kernel read the pinned staging buffer
@@ -208,8 +208,9 @@ struct muse_batch {
     double *mv = nullptr;
     int *lag = nullptr;
     int64_t score_cap = 0;
-    // small Runs (launch_small_groups): SMALL_GROUPS_MAX_G slots of coherent pinned memory, handed back to the context on free
+    // small Runs (launch_small_groups): small_cap slots of coherent pinned memory, handed back to the context on free
     unsigned char *small_out = nullptr;
+    int small_cap = 0;
     // selection workspace
     int *gid_dev = nullptr;
     int64_t gid_cap = 0;

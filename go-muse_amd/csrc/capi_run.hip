@@ -177,7 +177,10 @@ int upload_group_ids(muse_batch *b, const int32_t *group_id, int64_t M)
 
 // Small Runs: launch_group_reduce's outcome from one launch, read from coherent pinned memory as the kernel's per-slot stamps arrive
 // (reduce_kernels.hip, small_groups_kernel).  *out stays valid until the batch's next Run.
-static bool small_run(int64_t M, int64_t G) { return M <= SMALL_GROUPS_MAX_M && G <= SMALL_GROUPS_MAX_G; }
+static bool small_run(int64_t M, int64_t G, bool grouped)
+{
+    return grouped ? M <= SMALL_GROUPS_MAX_M && G <= SMALL_GROUPS_MAX_G : G <= SMALL_UNGROUPED_MAX;
+}
 static int small_reduce(muse_batch *b, const SelectParams &sp, const SmallSlot **out)
 {
     muse_ctx *ctx = b->ctx;
@@ -185,14 +188,22 @@ static int small_reduce(muse_batch *b, const SelectParams &sp, const SmallSlot *
     {
         std::lock_guard<std::mutex> lock(ctx->small_mu);
         token = ++ctx->small_token; // per context, as the buffers are: no slot has ever held this stamp
-        if (!b->small_out && !ctx->small_free.empty()) {
-            b->small_out = ctx->small_free.back();
-            ctx->small_free.pop_back();
+        if (b->small_out && b->small_cap < sp.G) { // (a Run(nil) behind grouped Runs: the larger buffer)
+            ctx->small_free.emplace_back(b->small_out, b->small_cap);
+            b->small_out = nullptr;
         }
+        for (size_t i = 0; !b->small_out && i < ctx->small_free.size(); i++)
+            if (ctx->small_free[i].second >= sp.G) {
+                b->small_out = ctx->small_free[i].first;
+                b->small_cap = ctx->small_free[i].second;
+                ctx->small_free.erase(ctx->small_free.begin() + (long)i);
+            }
     }
     if (!b->small_out) {
-        HIP_TRY(hipHostMalloc((void **)&b->small_out, (size_t)SMALL_GROUPS_MAX_G * sizeof(SmallSlot), hipHostMallocCoherent | hipHostMallocMapped));
-        memset(b->small_out, 0, (size_t)SMALL_GROUPS_MAX_G * sizeof(SmallSlot));
+        const int cap = sp.G <= SMALL_GROUPS_MAX_G ? SMALL_GROUPS_MAX_G : SMALL_UNGROUPED_MAX;
+        HIP_TRY(hipHostMalloc((void **)&b->small_out, (size_t)cap * sizeof(SmallSlot), hipHostMallocCoherent | hipHostMallocMapped));
+        memset(b->small_out, 0, (size_t)cap * sizeof(SmallSlot));
+        b->small_cap = cap;
     }
     const volatile SmallSlot *slots = (const volatile SmallSlot *)b->small_out;
     HIP_TRY(launch_small_groups(sp, (SmallSlot *)b->small_out, token, b->stream()));
@@ -251,7 +262,7 @@ int run_select(muse_batch *b, const int32_t *group_id, int32_t G_in, int64_t ser
     // then go to the lower group id: docs/HISTORY.md 8.3).
     const bool on_device = select_on_device(top_n, G);
     const int K = on_device ? top_n : 1;
-    const bool small = !on_device && !screened && small_run(M, G); // (a screened Run's host-side checks wait on the stream)
+    const bool small = !on_device && !screened && small_run(M, G, group_id != nullptr); // (a screened Run's host-side checks wait on the stream)
     rc = ensure_select_ws(b, M, small ? 0 : G, group_id != nullptr, K, on_device);
     if (rc)
         return rc;
@@ -396,7 +407,7 @@ extern "C" int muse_batch_run_groups(muse_batch *b, const int32_t *group_id, int
     }
     if (M == 0 || G == 0)
         return MUSE_OK;
-    const bool small = small_run(M, G);
+    const bool small = small_run(M, G, true);
     rc = small ? ensure_select_ws(b, M, 0, true, 1, false) : ensure_select_ws(b, M, G, true, 1, false);
     if (rc)
         return rc;

@@ -130,10 +130,27 @@ __global__ void group_final_kernel(SelectParams sp, GroupWork gw, muse_record *r
     }
 }
 
+// one 32-byte slot of pinned host memory: the record in ordinary stores (neighbouring lanes' slots leave the chip combined into a few
+// large writes), a wait until the memory system has taken them, then the stamp into the same 32-byte block -- slots are 32-byte
+// aligned, so a slot never straddles a 64-byte line, and writes to one line stay in order.  Measured alternatives
+// (tools/time_small_runs.py, 10 000-series Run(nil) / 5 000 x 480 in 100 groups): __threadfence_system() between record and stamp
+// 438 / 40 us (its L2 write-back costs ~2 us per wave and serialises); system-scope (sc0 sc1) stores 1 733 / 68 us (every 8-byte
+// store its own PCIe write, ~43 ns each).
+__device__ __forceinline__ void write_slot(SmallSlot *slot, const muse_record &r, unsigned long long k, unsigned long long token)
+{
+    slot->series = r.series;
+    slot->score = r.score;
+    slot->lag = r.lag;
+    slot->key = k > 2ull ? 3u : (unsigned)k;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    slot->stamp = token; // (an ordinary store too: a volatile one is sc0 sc1)
+    asm volatile("" ::: "memory");
+}
+
 // Small Runs (the reference's own benchmark shapes: 5 000 series in 100 label groups, muse_batch_test.go:134-162): the four passes
 // above in ONE workgroup with the per-group work arrays in LDS, each group's record written straight into a 32-byte slot of pinned
 // host memory -- one launch and a poll where the general path has four launches, two copies and a synchronisation.  Every slot
-// carries its own stamp, stored by the thread that wrote the slot, behind a system-scope fence and into the same 32-byte block:
+// carries its own stamp, stored by the thread that wrote the slot, behind the slot's own stores and into the same 32-byte block:
 // writes to DIFFERENT blocks of host memory arrive in no particular order (one flag behind all records was seen to overtake them:
 // tools/soak_round6.py), so the host waits for every slot's stamp.
 __global__ __launch_bounds__(1024) void small_groups_kernel(SelectParams sp, SmallSlot *out, unsigned long long token)
@@ -173,29 +190,35 @@ __global__ __launch_bounds__(1024) void small_groups_kernel(SelectParams sp, Sma
         }
         __syncthreads();
     }
-    for (int g0 = 0; g0 < sp.G; g0 += 1024) { // (uniform trip count: the fence below is reached by whole waves)
-        const int g = g0 + t;
-        if (g < sp.G) {
-            muse_record r;
-            unsigned long long k;
-            final_record(sp, g, sp.group_id ? first[g] : IDX_NONE, sp.group_id ? win[g] : IDX_NONE, r, k);
-            out[g].series = r.series;
-            out[g].score = r.score;
-            out[g].lag = r.lag;
-            out[g].key = k > 2ull ? 3u : (unsigned)k;
-        }
-        __threadfence_system();
-        if (g < sp.G)
-            __hip_atomic_store(&out[g].stamp, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (int g = t; g < sp.G; g += 1024) {
+        muse_record r;
+        unsigned long long k;
+        final_record(sp, g, sp.group_id ? first[g] : IDX_NONE, sp.group_id ? win[g] : IDX_NONE, r, k);
+        write_slot(out + g, r, k, token);
     }
+}
+
+// the same without a label map (Run(nil): every series its own group): no reduction at all, one thread per series on as many
+// workgroups as it takes, each writing its slot and then the slot's stamp
+__global__ __launch_bounds__(256) void ungrouped_slots_kernel(SelectParams sp, SmallSlot *out, unsigned long long token)
+{
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= sp.G)
+        return;
+    muse_record r;
+    unsigned long long k;
+    final_record(sp, g, IDX_NONE, IDX_NONE, r, k);
+    write_slot(out + g, r, k, token);
 }
 
 hipError_t launch_small_groups(const SelectParams &sp, SmallSlot *out, unsigned long long token, hipStream_t stream)
 {
-    if (sp.G <= 0 || sp.G > SMALL_GROUPS_MAX_G)
+    if (sp.G <= 0 || sp.G > (sp.group_id ? SMALL_GROUPS_MAX_G : SMALL_UNGROUPED_MAX))
         return hipErrorInvalidValue;
-    hipLaunchKernelGGL(small_groups_kernel, dim3(1), dim3(1024), sp.group_id ? (size_t)sp.G * 3 * sizeof(unsigned long long) : 0, stream,
-                       sp, out, token);
+    if (sp.group_id)
+        hipLaunchKernelGGL(small_groups_kernel, dim3(1), dim3(1024), (size_t)sp.G * 3 * sizeof(unsigned long long), stream, sp, out, token);
+    else
+        hipLaunchKernelGGL(ungrouped_slots_kernel, dim3((sp.G + 255) / 256), dim3(256), 0, stream, sp, out, token);
     return hipGetLastError();
 }
 

@@ -225,6 +225,7 @@ hipError_t launch_group_reduce(const SelectParams &sp, const GroupWork &gw, muse
 // host memory per label group, each with its own stamp (= token) stored last
 constexpr int SMALL_GROUPS_MAX_G = 2048;        // label groups (three 8-byte work arrays in LDS)
 constexpr long long SMALL_GROUPS_MAX_M = 32768; // series
+constexpr int SMALL_UNGROUPED_MAX = 32768;      // series of a Run without a label map (one slot each, no work arrays)
 struct SmallSlot {
     long long series; // muse_record::series, ::score, ::lag of group g (::group = g)
     double score;

@@ -125,11 +125,13 @@ def test_small_run_equals_the_restatement_and_the_general_path(muse, eng, M, N, 
     dg.close()
 
 
-def test_small_run_ungrouped_and_repeated(muse, eng):
-    """no label map: every series its own group (muse_batch.go:60-66 with an empty label set); the same batch run again and again
-    (the flag's token advances per Run), interleaved with a Run on a second batch of the same context"""
-    rng = np.random.default_rng(77)
-    N, M = 60, 1500
+@pytest.mark.parametrize("M", [1500, 10000, 32768])
+def test_small_run_ungrouped_and_repeated(muse, eng, M):
+    """no label map: every series its own group (muse_batch.go:60-66 with an empty label set; up to 32 768 series go through one
+    launch of one thread per series); the same batch run again and again (the stamp advances per Run), interleaved with a Run on a
+    second batch of the same context and with grouped Runs on the same batch (the smaller record buffer, then the larger again)"""
+    rng = np.random.default_rng(77 + M)
+    N = 60
     ref = rng.standard_normal(N)
     rows = _rows(rng, M, N, ref)
     rows[9] = -1.0
@@ -140,10 +142,15 @@ def test_small_run_ungrouped_and_repeated(muse, eng):
     kw = dict(max_lag=20, top_n=25, threshold=0.2, sign_filter=0, abs_scores=True)
     want_set, want = _restate_run(mv, lag, None, M, **kw)
     first = None
-    for it in range(50):
+    gid = (np.arange(M) % 50).astype(np.int32)
+    grouped = db.run(gid, 50, **kw)
+    for it in range(50 if M < 5000 else 12):
         s, l, v, mean = db.run(None, 0, **kw)
         if it % 7 == 0:
             other.run(None, 0, **kw)
+        if it % 5 == 0:
+            again = db.run(gid, 50, **kw)
+            assert all(a.tolist() == b.tolist() for a, b in zip(again[:3], grouped[:3]))
         assert set(s.tolist()) == want_set
         if first is None:
             first = (s.tolist(), l.tolist(), v.tolist())

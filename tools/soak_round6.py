@@ -237,6 +237,13 @@ def soak_small_run():
     if not same:
         bad += 1
         print("MISMATCH small_run run N=%d M=%d G=%d" % (N, M, G), kw, flush=True)
+    # Run(nil) (one thread per series, one launch up to 32 768 series) against the same Run with the identity label map
+    a = db.run(None, 0, **kw)
+    b = db.run(np.arange(M, dtype=np.int32), M, **kw)
+    same = all(x.tolist() == y.tolist() for x, y in zip(a[:3], b[:3])) and (a[3] == b[3] or (np.isnan(a[3]) and np.isnan(b[3])))
+    if not same:
+        bad += 1
+        print("MISMATCH small_run ungrouped N=%d M=%d" % (N, M), kw, flush=True)
     db.close()
     dg.close()
     cases["small_run"] += 1
