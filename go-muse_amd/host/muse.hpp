@@ -142,6 +142,8 @@ public:
         static Workers w;
         return w;
     }
+    // parked threads beside the caller (read once, when the first job starts the pool): set it before anything uploads
+    static inline int MaxExtra = 7;
     int width() const { return (int)threads_.size() + 1; }
     void run(int n, const std::function<void(int)> &fn)
     {
@@ -188,7 +190,7 @@ private:
     Workers()
     {
         const unsigned hw = std::thread::hardware_concurrency();
-        const int extra = (int)std::min(7u, hw > 1 ? hw / 2 : 0u);
+        const int extra = (int)std::min((unsigned)std::max(MaxExtra, 0), hw > 1 ? hw / 2 : 0u);
         for (int i = 0; i < extra; i++)
             threads_.emplace_back([this] { loop(); });
     }

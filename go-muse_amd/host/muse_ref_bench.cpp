@@ -65,9 +65,11 @@ static std::vector<std::vector<SeriesPtr>> small_comp() // muse_test.go:151-170
             {S({0.0, 0.0, 0.0, -0.2, -0.4, -0.6, 1.0, 0.0}, "graph5", "host1")}};
 }
 
-int main()
+int main(int argc, char **argv)
 {
     try {
+        if (argc > 1) // (experiments: parked packing threads beside the caller; default 7)
+            detail::Workers::MaxExtra = atoi(argv[1]);
         auto eng = Engine::Default();
         std::string out = "{";
         char buf[512];
