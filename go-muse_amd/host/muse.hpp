@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstdint>
@@ -144,6 +145,8 @@ public:
     }
     // parked threads beside the caller (read once, when the first job starts the pool): set it before anything uploads
     static inline int MaxExtra = 7;
+    // how long a thread that has just finished a job keeps looking for the next one before it parks (0: parks at once)
+    static inline int SpinMicros = 1000;
     int width() const { return (int)threads_.size() + 1; }
     void run(int n, const std::function<void(int)> &fn)
     {
@@ -159,7 +162,7 @@ public:
             total_ = n;
             next_.store(1);
             pending_ = n - 1;
-            generation_++;
+            generation_.fetch_add(1, std::memory_order_release);
         }
         cv_.notify_all();
         fn(0);
@@ -199,10 +202,18 @@ private:
         uint64_t seen = 0;
         std::unique_lock<std::mutex> lock(mu_);
         for (;;) {
-            cv_.wait(lock, [&] { return stop_ || generation_ != seen; });
+            if (SpinMicros > 0 && seen != 0) { // the windows of a streamed Group follow each other within ~0.1 ms: stay awake that long
+                lock.unlock();
+                const auto t0 = std::chrono::steady_clock::now();
+                while (generation_.load(std::memory_order_acquire) == seen &&
+                       std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(SpinMicros))
+                    __builtin_ia32_pause();
+                lock.lock();
+            }
+            cv_.wait(lock, [&] { return stop_ || generation_.load() != seen; });
             if (stop_)
                 return;
-            seen = generation_;
+            seen = generation_.load();
             for (;;) {
                 const std::function<void(int)> *fn = fn_;
                 if (!fn)
@@ -224,7 +235,7 @@ private:
     const std::function<void(int)> *fn_ = nullptr;
     std::atomic<int> next_{0};
     int total_ = 0, pending_ = 0;
-    uint64_t generation_ = 0;
+    std::atomic<uint64_t> generation_{0};
     bool stop_ = false;
 };
 // One parked thread that runs upload jobs in order (Group.Add streams the rows it has been given towards the device while
