@@ -39,6 +39,10 @@
 #include <unordered_map>
 #include <vector>
 
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
+
 #include "muse_hip.h"
 
 namespace muse {
@@ -129,6 +133,47 @@ inline SeriesPtr NewSeries(std::vector<double> y, LabelsPtr labels = nullptr)
 {
     return std::make_shared<Series>(std::move(y), std::move(labels));
 }
+
+// ------------------------------------------------ rows into the pinned upload window
+// The window is written once and read by the DMA engine, never by this CPU: streaming stores skip the read-for-ownership an
+// ordinary copy pays per destination line and leave the caches to the Series.  Rows whose window address or length is not a
+// multiple of 32 bytes, CPUs without AVX2, and `detail::StreamingStores = false` take memcpy.
+namespace detail {
+inline bool StreamingStores = true;
+#if defined(__x86_64__)
+__attribute__((target("avx2"))) inline void copy_row_streaming(double *dst, const double *src, size_t n)
+{
+    size_t i = 0;
+    for (; i + 16 <= n; i += 16) {
+        const __m256d a = _mm256_loadu_pd(src + i), b = _mm256_loadu_pd(src + i + 4), c = _mm256_loadu_pd(src + i + 8),
+                      d = _mm256_loadu_pd(src + i + 12);
+        _mm256_stream_pd(dst + i, a);
+        _mm256_stream_pd(dst + i + 4, b);
+        _mm256_stream_pd(dst + i + 8, c);
+        _mm256_stream_pd(dst + i + 12, d);
+    }
+    for (; i + 4 <= n; i += 4)
+        _mm256_stream_pd(dst + i, _mm256_loadu_pd(src + i));
+}
+#endif
+inline void copy_row(double *dst, const double *src, size_t n)
+{
+#if defined(__x86_64__)
+    static const bool avx2 = __builtin_cpu_supports("avx2");
+    if (StreamingStores && avx2 && n % 4 == 0 && ((uintptr_t)dst & 31u) == 0) {
+        copy_row_streaming(dst, src, n);
+        return;
+    }
+#endif
+    memcpy(dst, src, n * sizeof(double));
+}
+inline void copy_rows_done()
+{
+#if defined(__x86_64__)
+    _mm_sfence(); // streaming stores are weakly ordered: before the commit tells the device to read them
+#endif
+}
+} // namespace detail
 
 // ------------------------------------------------ a few parked host threads
 // Packing a Group's rows into the pinned upload window (muse_group_stage) is a memory copy of the whole Group: one
@@ -595,7 +640,8 @@ private:
                 const int p = task - extra;
                 const size_t lo = (size_t)p * piece, hi = std::min((size_t)granted, lo + piece);
                 for (size_t r = lo; r < hi; r++)
-                    memcpy(win + r * (size_t)n_, rows[first + r], row_bytes);
+                    detail::copy_row(win + r * (size_t)n_, rows[first + r], (size_t)n_);
+                detail::copy_rows_done();
                 std::lock_guard<std::mutex> lock(commit_mu);
                 done[(size_t)p] = 1;
                 int w = watermark;
