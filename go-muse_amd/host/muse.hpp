@@ -415,6 +415,8 @@ public:
     // another engine or over a device list uploads on its own, as before.  Off: Group::StreamOnAdd = false.
     static inline bool StreamOnAdd = true;
     static constexpr size_t STREAM_BYTES = (size_t)4 << 20;
+    // the first hand-over of a Group could leave earlier; measured, 1 MB is worse than 4 (cold BenchmarkMuseBatchRunLarge 740 -> 791 us)
+    static inline size_t StreamFirstBytes = (size_t)4 << 20;
     std::string Name;
     int Length() const { return n_; }
     // group.go:31-56; errors come back as muse::Error(MUSE_ERR_INVALID / MUSE_ERR_LENGTH)
@@ -440,7 +442,7 @@ public:
                 throw Error(MUSE_ERR_INVALID,
                             "Series with label:values, " + uid + ", already exists within group, " + Name);
             order_.push_back(s);
-            if (StreamOnAdd && (order_.size() - uploaded_) * (size_t)n_ * sizeof(double) >= STREAM_BYTES)
+            if (StreamOnAdd && (order_.size() - uploaded_) * (size_t)n_ * sizeof(double) >= (uploaded_ ? STREAM_BYTES : StreamFirstBytes))
                 maybe_stream();
         }
     }

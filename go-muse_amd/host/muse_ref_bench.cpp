@@ -70,6 +70,8 @@ int main(int argc, char **argv)
     try {
         if (argc > 1) // (experiments: parked packing threads beside the caller; default 7)
             detail::Workers::MaxExtra = atoi(argv[1]);
+        if (argc > 4) // (bytes gathered before a Group's first hand-over to the uploader)
+            Group::StreamFirstBytes = (size_t)atol(argv[4]);
         if (argc > 3) // (0: rows go into the pinned window with memcpy instead of streaming stores)
             detail::StreamingStores = atoi(argv[3]) != 0;
         if (argc > 2) // (how long a packing thread spins for the next job before parking, us)
