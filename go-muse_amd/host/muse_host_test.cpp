@@ -516,6 +516,34 @@ static void TestStreamedGroupEqualsUploadedAtRun()
     sameScores(out2[0], out2[1], "streamed group vs uploaded at Run, after more Adds");
 }
 
+// detail::copy_row (streaming stores into the pinned window where alignment and length allow, memcpy otherwise) moves every
+// length and alignment bit for bit, and leaves the bytes around the destination alone.
+static void TestCopyRow()
+{
+    std::mt19937_64 rng(11);
+    std::vector<double> src(2048 + 8), dst(2048 + 16);
+    for (auto &x : src)
+        x = (double)rng() / 3.0;
+    bool ok = true;
+    for (int streaming = 0; streaming < 2; streaming++) {
+        detail::StreamingStores = streaming != 0;
+        for (size_t n : {(size_t)1, (size_t)3, (size_t)4, (size_t)5, (size_t)8, (size_t)12, (size_t)15, (size_t)16, (size_t)17, (size_t)20, (size_t)36, (size_t)480, (size_t)700, (size_t)2048})
+            for (size_t doff = 0; doff < 5; doff++)
+                for (size_t soff = 0; soff < 3; soff++) {
+                    std::fill(dst.begin(), dst.end(), -7.0);
+                    detail::copy_row(dst.data() + 4 + doff, src.data() + soff, n);
+                    detail::copy_rows_done();
+                    ok = ok && memcmp(dst.data() + 4 + doff, src.data() + soff, n * sizeof(double)) == 0;
+                    for (size_t i = 0; i < 4 + doff; i++)
+                        ok = ok && dst[i] == -7.0;
+                    for (size_t i = 4 + doff + n; i < dst.size(); i++)
+                        ok = ok && dst[i] == -7.0;
+                }
+    }
+    detail::StreamingStores = true;
+    EXPECT(ok, "copy_row: every length and alignment, nothing outside the row");
+}
+
 // Series longer than 65 536 samples through the mirror (the reference has no length limit: xcorr.go:19-24, muse_batch.go:33-37):
 // planted shifted copies of the reference come back with score ~1 and the planted lag, a constant series with score 0, through
 // Batch.Run with label groups and through Muse.Run.
@@ -584,6 +612,7 @@ int main()
         Batch::EXACT_FEED_MAX_GROUPS = 65536;
         TestXCorrBatchEqualsSinglePairs();
         TestStreamedGroupEqualsUploadedAtRun();
+        TestCopyRow();
         TestLongSeries();
     } catch (const Error &e) {
         printf("muse::Error %d: %s\n", e.status, e.what());
