@@ -176,57 +176,112 @@ int upload_group_ids(muse_batch *b, const int32_t *group_id, int64_t M)
 }
 
 // Small Runs: launch_group_reduce's outcome from one launch, read from coherent pinned memory as the kernel's per-slot stamps arrive
-// (reduce_kernels.hip, small_groups_kernel).  *out stays valid until the batch's next Run.
+// (reduce_kernels.hip, small_groups_kernel / ungrouped_slots_kernel).  *out stays valid until the batch's next Run.
 static bool small_run(int64_t M, int64_t G, bool grouped)
 {
     return grouped ? M <= SMALL_GROUPS_MAX_M && G <= SMALL_GROUPS_MAX_G : G <= SMALL_UNGROUPED_MAX;
 }
-static int small_reduce(muse_batch *b, const SelectParams &sp, const SmallSlot **out)
+// the batch's pinned slot buffer with room for `need` slots (from the context's free list, or new) and a stamp no slot of this
+// context has ever held
+static int small_acquire(muse_batch *b, int64_t need, unsigned long long *token)
 {
     muse_ctx *ctx = b->ctx;
-    unsigned long long token;
     {
         std::lock_guard<std::mutex> lock(ctx->small_mu);
-        token = ++ctx->small_token; // per context, as the buffers are: no slot has ever held this stamp
-        if (b->small_out && b->small_cap < sp.G) { // (a Run(nil) behind grouped Runs: the larger buffer)
+        *token = ++ctx->small_token;
+        if (b->small_out && b->small_cap < need) { // (a Run(nil) behind grouped Runs: the larger buffer)
             ctx->small_free.emplace_back(b->small_out, b->small_cap);
             b->small_out = nullptr;
         }
         for (size_t i = 0; !b->small_out && i < ctx->small_free.size(); i++)
-            if (ctx->small_free[i].second >= sp.G) {
+            if (ctx->small_free[i].second >= need) {
                 b->small_out = ctx->small_free[i].first;
                 b->small_cap = ctx->small_free[i].second;
                 ctx->small_free.erase(ctx->small_free.begin() + (long)i);
             }
     }
     if (!b->small_out) {
-        const int cap = sp.G <= SMALL_GROUPS_MAX_G ? SMALL_GROUPS_MAX_G : SMALL_UNGROUPED_MAX;
+        const int cap = need <= SMALL_GROUPS_MAX_G ? SMALL_GROUPS_MAX_G : need <= SMALL_UNGROUPED_MAX ? SMALL_UNGROUPED_MAX : SMALL_DIRECT_MAX_SLOTS;
         HIP_TRY(hipHostMalloc((void **)&b->small_out, (size_t)cap * sizeof(SmallSlot), hipHostMallocCoherent | hipHostMallocMapped));
         memset(b->small_out, 0, (size_t)cap * sizeof(SmallSlot));
         b->small_cap = cap;
     }
-    const volatile SmallSlot *slots = (const volatile SmallSlot *)b->small_out;
-    HIP_TRY(launch_small_groups(sp, (SmallSlot *)b->small_out, token, b->stream()));
-    struct timespec t0, t1;
-    clock_gettime(CLOCK_MONOTONIC, &t0);
+    return MUSE_OK;
+}
+// waits until *stamp == token: polls for 0.2 s, then lets the runtime wait for the stream once (a kernel that never delivers)
+struct StampWait {
+    muse_batch *b;
+    struct timespec t0;
     bool synced = false;
-    for (int g = sp.G - 1; g >= 0; g--) { // (the last slot first: the others have mostly arrived by then)
-        for (unsigned spin = 1; slots[g].stamp != token; spin++) {
+    explicit StampWait(muse_batch *batch) : b(batch) { clock_gettime(CLOCK_MONOTONIC, &t0); }
+    int operator()(const volatile unsigned long long *stamp, unsigned long long token)
+    {
+        for (unsigned spin = 1; *stamp != token; spin++) {
             __builtin_ia32_pause();
             if ((spin & 1023u) != 0)
                 continue;
+            struct timespec t1;
             clock_gettime(CLOCK_MONOTONIC, &t1);
-            if ((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec) <= 200000000ll) // 0.2 s, then the runtime waits
+            if ((t1.tv_sec - t0.tv_sec) * 1000000000ll + (t1.tv_nsec - t0.tv_nsec) <= 200000000ll)
                 continue;
             if (synced)
-                return fail(MUSE_ERR_HIP, "small Run: the records did not arrive");
+                return fail(MUSE_ERR_HIP, "Run: the records did not arrive");
             HIP_TRY(hipStreamSynchronize(b->stream()));
             synced = true;
             clock_gettime(CLOCK_MONOTONIC, &t0);
         }
+        return MUSE_OK;
     }
+};
+static int small_reduce(muse_batch *b, const SelectParams &sp, const SmallSlot **out)
+{
+    unsigned long long token;
+    int rc = small_acquire(b, sp.G, &token);
+    if (rc)
+        return rc;
+    const volatile SmallSlot *slots = (const volatile SmallSlot *)b->small_out;
+    HIP_TRY(launch_small_groups(sp, (SmallSlot *)b->small_out, token, b->stream()));
+    StampWait wait(b);
+    for (int g = sp.G - 1; g >= 0; g--) // (the last slot first: the others have mostly arrived by then)
+        if ((rc = wait(&slots[g].stamp, token)))
+            return rc;
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
     *out = (const SmallSlot *)b->small_out;
+    return MUSE_OK;
+}
+// Run(nil) over more series than the exact feed takes (> 65 536): each chunk of TOPN_CHUNK series selects its best K from keys it
+// computes itself and writes those candidates' records straight into pinned slots (reduce_kernels.hip, topn_ungrouped_kernel) --
+// one launch and a poll where group_final + topn + two copies + a synchronisation were (the same candidates in the same order).
+static bool direct_topn(int64_t G, int K)
+{
+    const int64_t nb = (G + TOPN_CHUNK - 1) / TOPN_CHUNK;
+    return K >= 1 && K <= TOPN_DEVICE_MAX && nb * K + (nb + 1) / 2 <= SMALL_DIRECT_MAX_SLOTS;
+}
+static int direct_topn_reduce(muse_batch *b, const SelectParams &sp, int K, std::vector<muse_record> &cands)
+{
+    const int64_t nb = ((int64_t)sp.G + TOPN_CHUNK - 1) / TOPN_CHUNK;
+    unsigned long long token;
+    int rc = small_acquire(b, nb * K + (nb + 1) / 2, &token);
+    if (rc)
+        return rc;
+    SmallSlot *cand = (SmallSlot *)b->small_out;
+    CountSlot *cnt = (CountSlot *)(cand + nb * K);
+    HIP_TRY(launch_topn_ungrouped(sp, K, cand, cnt, token, b->stream()));
+    StampWait wait(b);
+    for (int64_t blk = 0; blk < nb; blk++) {
+        const volatile CountSlot *c = cnt + blk;
+        if ((rc = wait(&c->stamp, token)))
+            return rc;
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        const int n = (int)c->count;
+        for (int r = 0; r < n; r++) {
+            const volatile SmallSlot *sl = cand + blk * K + r;
+            if ((rc = wait(&sl->stamp, token)))
+                return rc;
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            cands.push_back(muse_record{sl->series, sl->score, sl->lag, (int32_t)std::min<int64_t>(sl->series, 0x7fffffffLL)});
+        }
+    }
     return MUSE_OK;
 }
 
@@ -263,7 +318,8 @@ int run_select(muse_batch *b, const int32_t *group_id, int32_t G_in, int64_t ser
     const bool on_device = select_on_device(top_n, G);
     const int K = on_device ? top_n : 1;
     const bool small = !on_device && !screened && small_run(M, G, group_id != nullptr); // (a screened Run's host-side checks wait on the stream)
-    rc = ensure_select_ws(b, M, small ? 0 : G, group_id != nullptr, K, on_device);
+    const bool direct = on_device && !screened && !group_id && direct_topn(G, K);
+    rc = ensure_select_ws(b, M, small || direct ? 0 : G, group_id != nullptr, K, on_device && !direct);
     if (rc)
         return rc;
     rc = upload_group_ids(b, group_id, M);
@@ -296,6 +352,10 @@ int run_select(muse_batch *b, const int32_t *group_id, int32_t G_in, int64_t ser
         for (int64_t g = 0; g < G; g++)
             if (slot[g].key != 0u)
                 cands.push_back(muse_record{slot[g].series, slot[g].score, slot[g].lag, (int32_t)g});
+    } else if (direct) {
+        rc = direct_topn_reduce(b, sp, K, cands);
+        if (rc)
+            return rc;
     } else if (on_device) {
         HIP_TRY(launch_group_reduce(sp, b->gw, b->rec, b->selkey, b->stream()));
         const int64_t nb = (G + TOPN_CHUNK - 1) / TOPN_CHUNK;

@@ -318,6 +318,92 @@ __global__ __launch_bounds__(256) void topn_kernel(const muse_record *__restrict
 }
 
 
+// Run(nil) over more series than the exact feed takes: topn_kernel's selection with the keys computed here (what
+// group_final_kernel writes for an ungrouped Run: the series' own clamped score through passed()) and the picked series' records
+// written straight into pinned slots -- the M records and keys of the general path are never materialised.
+__global__ __launch_bounds__(256) void topn_ungrouped_kernel(SelectParams sp, int K, SmallSlot *cand, CountSlot *cnt,
+                                                             unsigned long long token)
+{
+    __shared__ unsigned long long sk[4];
+    __shared__ int si[4];
+    __shared__ int picked[TOPN_DEVICE_MAX];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const long long base = (long long)blockIdx.x * TOPN_CHUNK;
+    unsigned long long k[16];
+#pragma unroll
+    for (int m = 0; m < 16; m++) {
+        const long long g = base + t + 256 * m;
+        k[m] = 0ull;
+        if (g < sp.G) {
+            const double s = clamp_score(sp.mv[g], sp.abs_scores);
+            if (passed(s, sp.lag[g], sp))
+                k[m] = abs_bits(s) + 1ull;
+        }
+    }
+    int r = 0;
+    for (; r < K; r++) {
+        unsigned long long bk = 0ull;
+        int bm = 0;
+#pragma unroll
+        for (int m = 0; m < 16; m++)
+            if (k[m] > bk) {
+                bk = k[m];
+                bm = m;
+            }
+        const unsigned long long wk = wave_max_u64(bk);
+        if (lane == 0)
+            sk[wave] = wk;
+        __syncthreads();
+        unsigned long long BK = sk[0];
+        BK = sk[1] > BK ? sk[1] : BK;
+        BK = sk[2] > BK ? sk[2] : BK;
+        BK = sk[3] > BK ? sk[3] : BK;
+        if (BK == 0ull)
+            break; // uniform
+        int ci = (bk == BK) ? (t + 256 * bm) : 0x7fffffff;
+        ci = wave_min_i32(ci);
+        if (lane == 0)
+            si[wave] = ci;
+        __syncthreads();
+        const int CI = min(min(si[0], si[1]), min(si[2], si[3]));
+        if (t == (CI & 255)) {
+            const int mm = CI >> 8;
+#pragma unroll
+            for (int m = 0; m < 16; m++)
+                if (m == mm)
+                    k[m] = 0ull;
+            picked[r] = CI;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    for (int i = t; i < r; i += 256) {
+        const long long g = base + picked[i];
+        muse_record rec;
+        rec.series = g + sp.series_offset;
+        rec.score = clamp_score(sp.mv[g], sp.abs_scores);
+        rec.lag = sp.lag[g];
+        rec.group = 0;
+        write_slot(cand + (long long)blockIdx.x * K + i, rec, 1ull, token);
+    }
+    if (t == 0) {
+        cnt[blockIdx.x].count = (unsigned long long)r;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        cnt[blockIdx.x].stamp = token;
+        asm volatile("" ::: "memory");
+    }
+}
+
+hipError_t launch_topn_ungrouped(const SelectParams &sp, int K, SmallSlot *cand, CountSlot *cnt, unsigned long long token,
+                                 hipStream_t stream)
+{
+    if (sp.G <= 0 || sp.group_id || sp.include || K < 1 || K > TOPN_DEVICE_MAX)
+        return hipErrorInvalidValue;
+    const int nb = (sp.G + TOPN_CHUNK - 1) / TOPN_CHUNK;
+    hipLaunchKernelGGL(topn_ungrouped_kernel, dim3(nb), dim3(256), 0, stream, sp, K, cand, cnt, token);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------- filter-and-refine Run (ungrouped, n = 4096)
 // Selection keys of one row from the screening pass's estimate `s` (|s - exact| <= E at every possible argmax) and
 // its SCR_* flags: kmin <= exact key <= kplus, where the exact key is what group_final_kernel computes from the

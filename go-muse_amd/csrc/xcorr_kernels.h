@@ -235,6 +235,15 @@ struct SmallSlot {
 };
 static_assert(sizeof(SmallSlot) == 32, "one slot = one 32-byte block");
 hipError_t launch_small_groups(const SelectParams &sp, SmallSlot *out, unsigned long long token, hipStream_t stream);
+// Run(nil) over many series: per chunk of TOPN_CHUNK series the best K candidates (what group_final_kernel + topn_kernel select,
+// in the same order) written into pinned slots cand[chunk * K + r], their number into cnt[chunk] (each with its stamp)
+constexpr int SMALL_DIRECT_MAX_SLOTS = 131072;  // 4 MB of pinned slots
+struct CountSlot {
+    unsigned long long count;
+    unsigned long long stamp;
+};
+hipError_t launch_topn_ungrouped(const SelectParams &sp, int K, SmallSlot *cand, CountSlot *cnt, unsigned long long token,
+                                 hipStream_t stream);
 // one label group in one launch (Muse.Run): the winner record and the group's state (reduce_kernels.hip)
 struct SingleGroupOut {
     muse_record rec;

@@ -167,3 +167,40 @@ def test_small_run_ungrouped_and_repeated(muse, eng, M):
     assert (s.tolist(), l.tolist(), v.tolist()) == first
     db.close()
     dg.close()
+
+
+@pytest.mark.parametrize("M,N", [(150000, 32), (70001, 100)])
+def test_direct_topn_equals_the_general_path(muse, eng, M, N):
+    """Run(nil) over more than 65 536 series: the chunks' candidates are selected and written into pinned slots by ONE launch
+    (reduce_kernels.hip, topn_ungrouped_kernel).  Against the general path (group_final + topn + copies), reached for the same rows
+    through the identity label map: the same series, lags and scores in the same order, with exact ties planted across and inside
+    chunks, for top_n up to the device limit, with filters that leave chunks empty, and with a series offset (a shard's Run)."""
+    rng = np.random.default_rng(M)
+    ref = rng.standard_normal(N)
+    rows = rng.standard_normal((M, N))
+    rows[::5] += rng.uniform(-3, 3, (len(rows[::5]), 1)) * np.roll(ref, 2)[None, :]
+    for i in rng.integers(1, M, 400):            # exact copies of another row: tied scores, far apart and adjacent
+        rows[i] = rows[int(rng.integers(0, i))]
+    rows[4097] = rows[4096] = rows[4095]
+    rows[10] = 1.25                              # NaN score
+    rows[8000:8192] = ref * 2.0                  # 192 series that all clamp to 1.0 inside one chunk and across a chunk boundary
+    dg = muse.DeviceGroup.from_rows(eng, rows)
+    db = muse.DeviceBatch(eng, dg, ref)
+    ident = np.arange(M, dtype=np.int32)
+    for kw in (dict(max_lag=N, top_n=20, threshold=0.0, sign_filter=0, abs_scores=True),
+               dict(max_lag=N, top_n=256, threshold=0.0, sign_filter=0, abs_scores=True),
+               dict(max_lag=2, top_n=1, threshold=0.5, sign_filter=0, abs_scores=True),
+               dict(max_lag=N, top_n=50, threshold=0.9999, sign_filter=1, abs_scores=False),
+               dict(max_lag=0, top_n=7, threshold=2.0, sign_filter=0, abs_scores=True)):      # nothing passes
+        a = db.run(None, 0, **kw)
+        b = db.run(ident, M, **kw)
+        assert a[0].tolist() == b[0].tolist() and a[1].tolist() == b[1].tolist() and a[2].tolist() == b[2].tolist(), kw
+        assert a[3] == b[3] or (np.isnan(a[3]) and np.isnan(b[3]))
+        ra = db.run_shard(None, 0, series_offset=12345, **kw)
+        rb = db.run_shard(ident, M, series_offset=12345, **kw)
+        assert ra["series"].tolist() == rb["series"].tolist() and ra["score"].tolist() == rb["score"].tolist()
+        assert ra["lag"].tolist() == rb["lag"].tolist()
+        assert ra["series"].tolist() == (a[0] + 12345).tolist()
+    assert len(db.run(None, 0, max_lag=N, top_n=256, threshold=0.0, sign_filter=0, abs_scores=True)[0]) == 256
+    db.close()
+    dg.close()

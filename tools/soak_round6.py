@@ -8,7 +8,8 @@
   * muse_batch_run_row_ptrs against muse_batch_run_rows at random lengths and group sizes;
   * small Runs (one-launch reduction, reduce_kernels.hip small_groups_kernel) on both sides of its limits (32 768 series, 2 048 label
     groups): muse_batch_run_groups against a numpy restatement of the per-group winner, muse_batch_run against the general path
-    (the same label map padded with empty groups).
+    (the same label map padded with empty groups); Run(nil) against the identity label map, also beyond 65 536 series (the
+    one-launch per-chunk selection, topn_ungrouped_kernel, against group_final + topn).
 usage: soak_round6.py [seconds] [seed]"""
 import importlib
 import os
@@ -184,7 +185,9 @@ def soak_row_ptrs():
 def soak_small_run():
     global bad
     N = int(rng.choice([2, 8, 30, 480, int(rng.integers(2, 2000))]))
-    M = int(rng.choice([int(rng.integers(1, 60)), int(rng.integers(1, 6000)), int(rng.integers(30000, 36000))]))
+    M = int(rng.choice([int(rng.integers(1, 60)), int(rng.integers(1, 6000)), int(rng.integers(30000, 36000)), int(rng.integers(65000, 140000))]))
+    if M > 40000:  # (beyond the exact feed: Run(nil) selects per chunk on the device, topn_ungrouped_kernel against the general path)
+        N = int(rng.choice([2, 8, 30]))
     M = max(1, min(M, 40_000_000 // (8 * N)))
     G = int(rng.choice([1, int(rng.integers(1, 120)), int(rng.integers(1900, 2200)), M]))
     ref = rng.standard_normal(N)
@@ -229,7 +232,7 @@ def soak_small_run():
         if not good:
             bad += 1
             print("MISMATCH small_run groups N=%d M=%d G=%d abs=%d" % (N, M, G, abs_scores), flush=True)
-    kw = dict(max_lag=int(rng.integers(0, N + 1)), top_n=int(rng.choice([1, 5, 20, 500])), threshold=float(rng.choice([0.0, 0.3, 0.8])),
+    kw = dict(max_lag=int(rng.integers(0, N + 1)), top_n=int(rng.choice([1, 5, 20, 256, 500])), threshold=float(rng.choice([0.0, 0.3, 0.8])),
               sign_filter=int(rng.integers(-1, 2)), abs_scores=bool(rng.integers(0, 2)))
     a = db.run(gid, G, **kw)
     b = db.run(gid, G + 2049, **kw)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Latency of small Runs through the C ABI (muse_batch_run): Run(nil), Run over 100 label groups and Run with the identity label
-map (every series its own group, through the general reduction when M > 2048) on 10 000 x 4096, 5 000 x 480 and 6 x 8."""
+map (every series its own group, through the general reduction when M > 2048) on 100 000 / 10 000 x 4096, 5 000 x 480 and 6 x 8."""
 import importlib
 import os
 import sys
@@ -11,7 +11,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("go-muse_amd")
 eng = pkg.get_engine(0)
-for M, N in ((10000, 4096), (5000, 480), (6, 8)):
+for M, N in ((100000, 4096), (10000, 4096), (5000, 480), (6, 8)):
     dg, ref = pkg.DeviceGroup.synthetic(eng, M, N, copies=False, constants=False) if M > 100 else (None, None)
     if dg is None:
         rng = np.random.default_rng(1); rows = rng.standard_normal((M, N)); ref = rng.standard_normal(N)
