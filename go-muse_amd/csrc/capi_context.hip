@@ -395,6 +395,13 @@ extern "C" int muse_ctx_trim(muse_ctx *ctx)
     if (rc)
         return rc;
     pool_drain(ctx);
+    std::vector<std::pair<unsigned char *, int>> slots;
+    {
+        std::lock_guard<std::mutex> lock(ctx->small_mu); // (the record buffers of small Runs no batch holds at the moment)
+        slots.swap(ctx->small_free);
+    }
+    for (auto &p : slots)
+        (void)hipHostFree(p.first);
     return MUSE_OK;
 }
 
