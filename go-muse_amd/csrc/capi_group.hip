@@ -351,6 +351,7 @@ extern "C" int muse_group_fill_synthetic(muse_group *g, int64_t first, int64_t c
         HIP_TRY(launch_synth(g->rows, g->stride, first, count, global_first, g->N, seed, flags, g->ctx->stream));
     g->M = std::max(g->M, first + count);
     g->hstats_rows = std::min(g->hstats_rows, first); // (rows rewritten: their kept statistics go)
+    g->rewrites++;
     if (ref_out) {
         double *d = nullptr;
         HIP_TRY(hipMalloc(&d, (size_t)g->N * sizeof(double)));

@@ -146,6 +146,7 @@ struct muse_group {
     // and every other reference (rows appended later are added; a re-allocation starts over)
     double *hstats = nullptr;
     int64_t hstats_cap = 0, hstats_rows = 0;
+    uint64_t rewrites = 0;          // how often rows already in the group were rewritten (muse_group_fill_synthetic: rows are otherwise immutable)
     // allocations the group has outgrown: kept until the group goes (kernels enqueued before the growth may still read them),
     // so that growing never waits for the device (group_reserve)
     std::vector<void *> retired;
@@ -202,7 +203,8 @@ struct muse_batch {
     // automatic kernel selection learns from the previous pass over the same (immutable) rows: the number of
     // pairs the default N = 4096 kernel handed to the rescaling kernel lands here (pinned, asynchronous copy)
     int *handoff_host = nullptr;
-    int64_t handoff_M = -1;
+    int64_t handoff_M = -1;         // the rows the count was taken over: M of them, after handoff_rewrites rewrites of the group
+    uint64_t handoff_rewrites = 0;
     long long *ovf_list = nullptr;
     int64_t ovf_cap = 0;
     double *mv = nullptr;
