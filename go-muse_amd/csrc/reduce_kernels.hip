@@ -166,27 +166,60 @@ __global__ __launch_bounds__(1024) void small_groups_kernel(SelectParams sp, Sma
             win[g] = IDX_NONE;
         }
         __syncthreads();
-        for (long long i = t; i < sp.M; i += 1024) { // group_key_kernel
-            const int g = sp.group_id[i];
-            if (g < 0 || g >= sp.G)
-                continue;
-            atomicMin(&first[g], i);
-            if (sp.include && sp.include[i] != 1)
-                continue;
-            const double v = clamp_score(sp.mv[i], sp.abs_scores);
-            if (v == v)
-                atomicMax(&key[g], abs_bits(v));
+        // (one workgroup: what it waits for is the latency of its own loads -- eight series per thread are requested before the
+        // first of them is used: 13.7 -> 9.3 us for 10 000 series in 100 groups, rocprofv3 kernel trace)
+        constexpr int U = 8;
+        for (long long i0 = t; i0 < sp.M; i0 += U * 1024) { // group_key_kernel
+            int g[U];
+            double v[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const long long i = i0 + u * 1024;
+                g[u] = -1;
+                v[u] = 0.0;
+                if (i < sp.M) {
+                    g[u] = sp.group_id[i];
+                    v[u] = sp.mv[i];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const long long i = i0 + u * 1024;
+                if (g[u] < 0 || g[u] >= sp.G)
+                    continue;
+                atomicMin(&first[g[u]], i);
+                if (sp.include && sp.include[i] != 1)
+                    continue;
+                const double c = clamp_score(v[u], sp.abs_scores);
+                if (c == c)
+                    atomicMax(&key[g[u]], abs_bits(c));
+            }
         }
         __syncthreads();
-        for (long long i = t; i < sp.M; i += 1024) { // group_win_kernel
-            const int g = sp.group_id[i];
-            if (g < 0 || g >= sp.G)
-                continue;
-            if (sp.include && sp.include[i] != 1)
-                continue;
-            const double v = clamp_score(sp.mv[i], sp.abs_scores);
-            if (v == v && abs_bits(v) == key[g])
-                atomicMin(&win[g], i);
+        for (long long i0 = t; i0 < sp.M; i0 += U * 1024) { // group_win_kernel
+            int g[U];
+            double v[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const long long i = i0 + u * 1024;
+                g[u] = -1;
+                v[u] = 0.0;
+                if (i < sp.M) {
+                    g[u] = sp.group_id[i];
+                    v[u] = sp.mv[i];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const long long i = i0 + u * 1024;
+                if (g[u] < 0 || g[u] >= sp.G)
+                    continue;
+                if (sp.include && sp.include[i] != 1)
+                    continue;
+                const double c = clamp_score(v[u], sp.abs_scores);
+                if (c == c && abs_bits(c) == key[g[u]])
+                    atomicMin(&win[g[u]], i);
+            }
         }
         __syncthreads();
     }
